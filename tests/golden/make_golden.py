@@ -1,0 +1,99 @@
+"""Regenerates tests/golden/*.npz by running the REFERENCE's own Python functions
+(/root/reference, imported through ref_shim) on seeded synthetic inputs.
+
+Run in the build container only:   python tests/golden/make_golden.py [name ...]
+
+Inputs are never stored: tests regenerate them from the recorded seeds with
+eprecon_amd.synthetic (numpy default_rng, identical on every machine).  Stored outputs are
+reduced to keep each fixture small: full integer results (visible-view counts, which determine
+the valid set and the output order), plus sampled feature rows and per-row checksums.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import ref_shim  # noqa: E402
+
+torch = ref_shim.install()
+
+from eprecon_amd import synthetic as S  # noqa: E402
+
+
+def _save(name, **arrays):
+    arrays["torch_version"] = np.array(torch.__version__)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def _sample_rows(n, k, seed):
+    rng = np.random.default_rng(seed)
+    if n <= k:
+        return np.arange(n, dtype=np.int64)
+    return np.sort(rng.choice(n, size=k, replace=False)).astype(np.int64)
+
+
+def bp_case(window, lvl, interval, n_vox, feat_seed, min_view, batch=1):
+    c, h, w = S.pyramid_shapes(*window["image_hw"])[lvl]
+    feats = S.make_features(feat_seed, 9, (c, h, w), batch=batch)
+    coords = S.dense_coords(n_vox, interval, batch=batch)
+    kr = np.repeat(window["proj_matrices"][:, lvl][:, None], batch, axis=1).copy()
+    origin = np.repeat(window["vol_origin_partial"][None], batch, axis=0).copy()
+    if batch > 1:  # make the second batch element see a shifted volume
+        origin[1:, 0] += 0.36
+    return coords, origin, feats, np.ascontiguousarray(kr)
+
+
+def gen_back_project():
+    from models.occupancy_initialization import Back_Project
+    from ops.back_project import back_project as ops_back_project
+
+    out = {}
+    # cfg1: 320x240 window, dense 32^3 single-scale volume on the 1/4-res map [24,60,80]
+    # cfg2: 640x480 window, dense 24^3 / 48^3 / 96^3 on the three pyramid levels
+    cases = [("cfg1_l0", dict(seed=1, width=320, height=240, n_vox=(32, 32, 32)), 0, 1, 1),
+             ("cfg1b2_l1", dict(seed=2, width=320, height=240, n_vox=(32, 32, 32)), 1, 2, 2),
+             ("cfg2_l2", dict(seed=0), 2, 4, 1),
+             ("cfg2_l1", dict(seed=0), 1, 2, 1),
+             ("cfg2_l0", dict(seed=0), 0, 1, 1)]
+    for name, wargs, lvl, interval, batch in cases:
+        window = S.make_window(**wargs)
+        for mv in (0, 2):
+            coords, origin, feats, kr = bp_case(window, lvl, interval, window["n_vox"],
+                                                 1000 + lvl, mv, batch)
+            tc, to, tf, tk = (torch.from_numpy(x) for x in (coords, origin, feats, kr))
+            res = Back_Project(feats.shape[2])(tc, to, window["voxel_size"], tf, tk, mv)
+            vol, vcoords, grid, mask, count = [r.numpy() for r in res]
+            n_valid = vol.shape[0]
+            rows = _sample_rows(n_valid, 384, 7)
+            key = f"{name}_mv{mv}"
+            out[key + "_count"] = count.astype(np.uint8)
+            out[key + "_nvalid"] = np.int64(n_valid)
+            out[key + "_rows"] = rows
+            out[key + "_feat_rows"] = vol[rows]
+            out[key + "_grid_rows"] = grid[:, rows]
+            out[key + "_mask_rows"] = mask[:, rows]
+            out[key + "_coord_rows"] = vcoords[rows].astype(np.int32)
+            out[key + "_rowsum"] = vol.sum(axis=1, dtype=np.float64).astype(np.float32)[::32]
+            if mv == 2 and name.startswith("cfg1"):
+                # canonical op with the normalised-depth channel (ops/back_project.py:69-75)
+                r2 = ops_back_project(tc, to, window["voxel_size"], tf, tk, mv)
+                out[key + "_depth_rows"] = r2[0].numpy()[rows, -1]
+                assert np.array_equal(r2[0].numpy()[:, :-1], vol)
+        out[name + "_meta"] = np.array([lvl, interval, batch, wargs.get("seed", 0),
+                                        wargs.get("width", 640), wargs.get("height", 480),
+                                        window["n_vox"][0], 1000 + lvl], dtype=np.int64)
+    _save("back_project", **out)
+
+
+GENERATORS = {"back_project": gen_back_project}
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(GENERATORS)
+    for n in names:
+        GENERATORS[n]()
