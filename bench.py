@@ -1,0 +1,143 @@
+#!/usr/bin/env python
+"""bench.py — fragments/sec of the MI355X per-fragment 3D path on BASELINE.json's config 2.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over ONE synthetic 9-view 640x480 fragment window whose
+inputs (feature pyramids, projection matrices, voxel lists) are already resident in HBM:
+the stages listed in `Cfg2Step` (eprecon_amd.fragment_step).  With N ranks every rank processes its
+own fragment per step (independent fragment windows shard one-per-GPU), so
+value = N * K / max-over-ranks(time) and scaling is "weak".
+
+Prints ONE JSON line on rank 0 with the driver's keys plus
+  roofline     dominant kernel (bp_gather on the dense 96^3 / C=24 / 120x160 level), HIP-event timed
+  cpu_baseline the CPU oracle (C + OpenMP port of the reference algorithm) on the same windows.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured streaming ceiling)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+                    help="approximate CPU time to spend on the cpu_baseline leg (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(step, seconds):
+    """The same step on the host cores with the CPU oracle (oracle/c/back_project_oracle.c, a
+    C + OpenMP port of the reference algorithm; `kind` = "port").  Bounded sample: whole steps are
+    repeated until about `seconds` of wall time are spent (at least 2 after one warm-up)."""
+    from oracle import back_project as O
+    from eprecon_amd import synthetic as S
+    from eprecon_amd.fragment_step import LEVELS
+
+    w = step.window
+    origin = w["vol_origin_partial"][None]
+    feats = [f.cpu().numpy() for f in step.feats]
+    feats_init = step.feats_init.cpu().numpy()
+    kr = [np.ascontiguousarray(w["proj_matrices"][:, l][:, None]) for l in range(3)]
+    coords = {iv: S.dense_coords(w["n_vox"], iv) for iv in (4, 2, 1)}
+
+    def one_step():
+        O.back_project(coords[2], origin, w["voxel_size"], feats_init, kr[1], 2, O.MODE_VARIANCE)
+        for _, lvl, interval, mv in LEVELS:
+            O.back_project(coords[interval], origin, w["voxel_size"], feats[lvl], kr[lvl], mv)
+
+    one_step()
+    n, t0 = 0, time.perf_counter()
+    while n < 2 or time.perf_counter() - t0 < seconds:
+        one_step()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "fragments/s", "cores": O.num_threads(), "kind": "port",
+            "sample": f"{n} whole steps of the same workload (same window, seed {step.seed}) in {dt:.1f} s",
+            "ms_per_step": dt / n * 1e3}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from eprecon_amd import _lib
+    from eprecon_amd.fragment_step import Cfg2Step
+
+    lib = _lib.load()
+    # every rank owns a different fragment window (seed = rank)
+    step = Cfg2Step(seed=rank, device=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step.run()
+    lib.eprecon_profile_enable(1)
+    gather_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step.run()
+        # the last back-projection of a step is the dense 96^3 level: its gather kernel is the
+        # dominant kernel; reading the event pair costs one sync the reference has as well
+        gather_ms.append(step.dominant_kernel_ms(lib))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    lib.eprecon_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed
+        gm = float(np.mean([g for g in gather_ms if g > 0])) if any(g > 0 for g in gather_ms) else None
+        alg = step.dominant_kernel_bytes()
+        roof = {"bound": "hbm", "kernel": "bp_gather_kernel<256,MEAN,4,6> (dense 96^3, C=24, 120x160)",
+                "achieved": (alg / (gm * 1e-3) / 1e9) if gm else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (alg / (gm * 1e-3) / 1e9 / HBM_PEAK_GBS) if gm else None,
+                "traffic": None, "algorithmic_bytes": alg, "avg_launch_ms": gm}
+        out = {"metric": "fragments_per_sec", "value": value, "unit": "fragments/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic", "config": step.describe(), "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(step, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,95 @@
+"""ctypes binding of libeprecon_hip.so (the C ABI in include/eprecon_hip.h).
+
+There is NO fallback: if the library is missing or was not built for gfx950 the import of any
+operator raises.  torch is imported first so that the library binds to the same libamdhip64.so.7
+(the one bundled with PyTorch-ROCm) instead of bringing a second HIP runtime into the process.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be loaded before the HIP library, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeprecon_hip.so")
+
+_c = ctypes
+_vp, _i, _i64, _f, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/eprecon_hip.h declares
+# (tests/test_cabi_symbols.py checks the two against each other)
+SIGNATURES = {
+    "eprecon_abi_version": (_i, []),
+    "eprecon_build_arch": (_c.c_char_p, []),
+    "eprecon_back_project_workspace_bytes": (_sz, [_i64, _i, _i, _i, _i, _i, _i]),
+    "eprecon_back_project_async": (_i, [_vp, _i64, _vp, _i, _f, _vp, _i, _vp, _i, _i, _i, _i, _i, _i,
+                                        _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "eprecon_back_project": (_i, [_vp, _i64, _vp, _i, _f, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i,
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "eprecon_profile_enable": (_i, [_i]),
+    "eprecon_profile_gather_ms": (_f, []),
+    "eprecon_nchw_to_nhwc_async": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+}
+
+EPRECON_OK, EPRECON_EMPTY = 0, 1
+ABI_VERSION = 1
+
+
+class EpreconError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises EpreconError when it is absent (no CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EpreconError(
+            f"{LIB_PATH} not found: build it with `python -m eprecon_amd.build` "
+            "(hipcc --offload-arch=gfx950). eprecon_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.eprecon_abi_version() != ABI_VERSION:
+        raise EpreconError("libeprecon_hip.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    """0 -> True, EPRECON_EMPTY -> False (caller returns None like the reference), <0 raises."""
+    if rc == EPRECON_OK:
+        return True
+    if rc == EPRECON_EMPTY:
+        return False
+    if rc <= -1000:
+        raise EpreconError(f"{what}: HIP error {-(rc + 1000)}")
+    raise EpreconError(f"{what}: error {rc} "
+                       "(-1 bad argument, -2 workspace too small, -3 unsupported size)")
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)"""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_WORKSPACES = {}
+
+
+def workspace(nbytes, device):
+    """grow-only per-device scratch buffer (PyTorch-owned device memory)"""
+    key = (device.type, device.index)
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = buf
+    return buf

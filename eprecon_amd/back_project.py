@@ -1,0 +1,134 @@
+"""Multi-view back-projection — host-side mirror of the reference operators, running on
+libeprecon_hip.so (csrc/back_project.hip).
+
+  back_project(...)        same signature / return as ops/back_project.py:5-80
+  Back_Project.forward     same signature / return as models/occupancy_initialization.py:189-261
+  view_variance(...)       the sampling + mean/variance block of
+                           Occupancy_Initialization.forward (models/occupancy_initialization.py:79-128)
+
+"Nothing to do" is signalled by returning None exactly where the reference does.  Device memory,
+streams and the host sync on n_valid are PyTorch's; everything else is the HIP library.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+MODE_MEAN, MODE_MEAN_DEPTH, MODE_VARIANCE = 0, 1, 2
+LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
+
+
+def _prep_feats(feats):
+    """feats: [V, B, C, H, W] (logical shape).  Channels-last storage (stride of C == 1) is passed
+    through without a copy; anything else is made NCHW-contiguous."""
+    v, b, c, h, w = feats.shape
+    if feats.dtype != torch.float32:
+        feats = feats.float()
+    if feats.stride() == (b * h * w * c, h * w * c, 1, w * c, c):
+        return feats, LAYOUT_NHWC
+    return feats.contiguous(), LAYOUT_NCHW
+
+
+def run(coords, origin, voxel_size, feats, krcam, min_view, mode=MODE_MEAN, min_valid_per_batch=1,
+        want_grid=False, want_mean=False):
+    """Low-level entry: returns None (reference: `return None`) or a dict of device tensors
+    {feats [n_valid, C(+1)], coords int32 [n_valid, 4], count f32 [N], n_valid, (grid, mask, mean)}."""
+    lib = _lib.load()
+    dev = feats.device
+    if dev.type != "cuda":
+        raise _lib.EpreconError("eprecon_amd operators need device tensors (no CPU fallback)")
+    v, b, c, h, w = feats.shape
+    n = coords.shape[0]
+    coords_i = coords if coords.dtype == torch.int32 else coords.to(torch.int32)
+    coords_i = coords_i.contiguous()
+    origin_f = origin.to(device=dev, dtype=torch.float32).reshape(-1, 3).contiguous()
+    krcam_f = krcam.to(device=dev, dtype=torch.float32).contiguous()
+    assert krcam_f.shape == (v, b, 4, 4) and origin_f.shape[0] == b
+    feats_c, layout = _prep_feats(feats)
+    cout = c + 1 if mode == MODE_MEAN_DEPTH else c
+
+    out_feats = torch.empty((n, cout), dtype=torch.float32, device=dev)
+    out_coords = torch.empty((n, 4), dtype=torch.int32, device=dev)
+    count = torch.empty((n,), dtype=torch.float32, device=dev)
+    out_mean = torch.empty((n, c), dtype=torch.float32, device=dev) if want_mean else None
+    out_grid = torch.empty((v * n * 2,), dtype=torch.float32, device=dev) if want_grid else None
+    out_mask = torch.empty((v * n,), dtype=torch.uint8, device=dev) if want_grid else None
+    n_valid_dev = torch.empty((1 + b,), dtype=torch.int32, device=dev)
+    n_valid_host = (ctypes.c_int32 * (1 + b))()
+    ws_bytes = lib.eprecon_back_project_workspace_bytes(n, b, v, c, h, w, layout)
+    ws = _lib.workspace(ws_bytes, dev)
+
+    rc = lib.eprecon_back_project(
+        _lib.ptr(coords_i), n, _lib.ptr(origin_f), b, float(voxel_size), _lib.ptr(feats_c), layout,
+        _lib.ptr(krcam_f), v, c, h, w, int(min_view), mode, int(min_valid_per_batch),
+        _lib.ptr(out_feats), _lib.ptr(out_mean), _lib.ptr(out_coords), _lib.ptr(count),
+        _lib.ptr(out_grid), _lib.ptr(out_mask), _lib.ptr(n_valid_dev),
+        ctypes.cast(n_valid_host, ctypes.c_void_p), _lib.ptr(ws), ws.numel(), _lib.current_stream())
+    if not _lib.check(rc, "eprecon_back_project"):
+        return None
+    nv = int(n_valid_host[0])
+    res = {"feats": out_feats[:nv], "coords": out_coords[:nv], "count": count, "n_valid": nv,
+           "n_valid_per_batch": [int(x) for x in n_valid_host[1:]]}
+    if want_grid:
+        res["grid"] = out_grid[: v * nv * 2].view(v, nv, 2)
+        res["mask"] = out_mask[: v * nv].view(v, nv).bool()
+    if want_mean:
+        res["mean"] = out_mean[:nv]
+    return res
+
+
+def back_project(coords, origin, voxel_size, feats, KRcam, min_view_number):
+    """ops/back_project.py:5-80.  Returns [features f32[N_valid, C+1] (last channel = normalised
+    mean depth), coords float32[N_valid, 4], count f32[N]] or None when a batch has no valid voxel."""
+    res = run(coords, origin, voxel_size, feats, KRcam, min_view_number, MODE_MEAN_DEPTH)
+    if res is None:
+        return None
+    # the reference concatenates onto torch.empty(0, 4) (float32), so its coords come back as float
+    return [res["feats"], res["coords"].to(torch.float32), res["count"]]
+
+
+class Back_Project(nn.Module):
+    """models/occupancy_initialization.py:185-261.  `forward` returns
+    [features f32[N_valid, C], coords (input dtype)[N_valid, 4], im_grid, mask, count f32[N]].
+
+    The reference's only caller consumes entries 0, 1 and 4 (models/neucon_network.py:374-378);
+    materialising im_grid f32[V, N_valid, 2] and mask bool[V, N_valid] costs 9 extra bytes per
+    (view, voxel), so they are produced only when `return_projection` is True, else None."""
+
+    def __init__(self, dim, return_projection=False):
+        super().__init__()
+        self.return_projection = return_projection
+
+    def forward(self, coords, origin, voxel_size, feats, KRcam, min_view_number):
+        res = run(coords, origin, voxel_size, feats, KRcam, min_view_number, MODE_MEAN,
+                  want_grid=self.return_projection)
+        if res is None:
+            return None
+        out_coords = res["coords"] if coords.dtype == torch.int32 else res["coords"].to(coords.dtype)
+        return [res["feats"], out_coords, res.get("grid"), res.get("mask"), res["count"]]
+
+
+def view_variance(coords, origin, voxel_size, feats_fused, KRcam, min_view_number, min_valid=1000):
+    """Per-voxel population variance over the visible views of the fused 32-channel maps
+    (models/occupancy_initialization.py:79-128).  Returns None when fewer than `min_valid` voxels
+    are valid (:107-108), else dict(var, mean, coords, count, n_valid)."""
+    res = run(coords, origin, voxel_size, feats_fused, KRcam, min_view_number, MODE_VARIANCE,
+              min_valid_per_batch=min_valid, want_mean=True)
+    if res is None:
+        return None
+    res["var"] = res.pop("feats")
+    return res
+
+
+def to_channels_last(feats):
+    """[V, B, C, H, W] -> same logical tensor stored [V, B, H, W, C] with the HIP re-layout kernel,
+    for callers that back-project the same maps more than once."""
+    lib = _lib.load()
+    v, b, c, h, w = feats.shape
+    src = feats.float().contiguous()
+    dst = torch.empty((v, b, h, w, c), dtype=torch.float32, device=feats.device)
+    _lib.check(lib.eprecon_nchw_to_nhwc_async(_lib.ptr(src), _lib.ptr(dst), v * b, c, h * w,
+                                               _lib.current_stream()), "eprecon_nchw_to_nhwc_async")
+    return dst.permute(0, 1, 4, 2, 3)

@@ -1,0 +1,617 @@
+// Multi-view back-projection for gfx950 (MI355X): image-feature pyramid -> voxel list.
+//
+// Replaces Back_Project.forward (models/occupancy_initialization.py:189-261 of the reference),
+// ops/back_project.py:5-80 and the sample + mean/variance block of
+// Occupancy_Initialization.forward (models/occupancy_initialization.py:79-128).
+//
+// Pipeline per call (all on the caller's stream):
+//   [nchw_to_nhwc]   re-layout of the V*B feature maps to channels-last, so that the C channels of
+//                    one bilinear tap are one contiguous 4*C-byte run (skipped when the caller
+//                    already holds channels-last maps);
+//   bp_count         one thread per voxel: 9 projections, visible-view count (float, all N),
+//                    per-block valid totals by wave ballot + popcount, per-batch valid counts;
+//   bp_scan          exclusive scan of the block totals (one workgroup) -> output offsets, n_valid;
+//   bp_gather        phase 1, one thread per voxel: re-project, stable in-block compaction by
+//                    ballot/prefix-sum, pixel coordinates of every (voxel, view) staged in LDS;
+//                    phase 2, one thread per (valid voxel, 4-channel group): bilinear gather of
+//                    the visible views with 16-byte loads, mean (or two-sweep variance) in
+//                    registers, fully coalesced 16-byte stores in compacted order.
+//   [bp_depth_norm]  ops.back_project's extra normalised-depth channel.
+//
+// Roofline: HBM/L2 bandwidth (about 2 flop per gathered byte).  Algorithmic bytes per call
+//   16 N (coords in) + 4 N (count out) + 4 V C H W (maps, once) + n_valid (4 C + 16) (rows out).
+// Arithmetic contract (bit-exact indices): see oracle/c/back_project_oracle.c and DESIGN.md.
+#include "common.hpp"
+
+namespace {
+using namespace ep;
+
+struct BpParams {
+    const int32_t *coords;
+    int n;
+    const float *origin;
+    int batch;
+    float voxel_size;
+    const float *feats_nhwc;  // [V*B][H*W][C]
+    const float *krcam;       // [V*B][16]
+    int V, C, H, W;
+    int min_view;
+    float *out_feats;
+    float *out_mean;
+    int32_t *out_coords;
+    float *count;
+    float *out_grid;
+    uint8_t *out_mask;
+    int32_t *n_valid_dev;  // [1 + B]
+    int32_t *block_offsets;
+};
+
+struct Proj {
+    float gx, gy, pz;
+    bool vis;
+};
+
+// P: rows 0..2 of a 4x4 row-major projection (12 floats).  k-ordered fma chain == torch CPU bmm
+// == fp32 MFMA accumulation order (see the oracle header for the evidence).
+__device__ __forceinline__ Proj project(const float *P, float X, float Y, float Z, float wm1,
+                                        float hm1)
+{
+    const float px = __fmaf_rn(P[3], 1.0f, __fmaf_rn(P[2], Z, __fmaf_rn(P[1], Y, __fmul_rn(P[0], X))));
+    const float py = __fmaf_rn(P[7], 1.0f, __fmaf_rn(P[6], Z, __fmaf_rn(P[5], Y, __fmul_rn(P[4], X))));
+    const float pz = __fmaf_rn(P[11], 1.0f, __fmaf_rn(P[10], Z, __fmaf_rn(P[9], Y, __fmul_rn(P[8], X))));
+    const float u = __fdiv_rn(px, pz);
+    const float v = __fdiv_rn(py, pz);
+    Proj r;
+    r.gx = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, u), wm1), 1.0f);
+    r.gy = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, v), hm1), 1.0f);
+    r.pz = pz;
+    r.vis = (fabsf(r.gx) <= 1.0f) && (fabsf(r.gy) <= 1.0f) && (pz > 0.0f);
+    return r;
+}
+
+__device__ __forceinline__ void voxel_centre(const int4 c, const float *origin, float vs, float &X,
+                                             float &Y, float &Z)
+{
+    // float(c) * voxel_size + origin: separate multiply and add (models/occupancy_initialization.py:213)
+    X = __fadd_rn(__fmul_rn((float)c.y, vs), origin[3 * c.x + 0]);
+    Y = __fadd_rn(__fmul_rn((float)c.z, vs), origin[3 * c.x + 1]);
+    Z = __fadd_rn(__fmul_rn((float)c.w, vs), origin[3 * c.x + 2]);
+}
+
+__device__ __forceinline__ void stage_matrices(float *sP, const float *krcam, int nmat, int tid,
+                                               int nthreads)
+{
+    for (int i = tid; i < nmat * 12; i += nthreads) {
+        const int m = i / 12, e = i - m * 12;
+        sP[i] = krcam[m * 16 + e];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: visible-view count for every voxel, valid totals per block and per batch element
+// ---------------------------------------------------------------------------------------------
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void bp_count_kernel(BpParams p, int32_t *block_sums)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *sP = reinterpret_cast<float *>(smem);
+    int *sBatch = reinterpret_cast<int *>(sP + p.V * p.batch * 12);
+    int *sWave = sBatch + p.batch;
+    const int tid = threadIdx.x;
+    stage_matrices(sP, p.krcam, p.V * p.batch, tid, BLOCK);
+    for (int b = tid; b < p.batch; b += BLOCK) sBatch[b] = 0;
+    __syncthreads();
+
+    const int i = blockIdx.x * BLOCK + tid;
+    bool valid = false;
+    if (i < p.n) {
+        const int4 c = reinterpret_cast<const int4 *>(p.coords)[i];
+        int cnt = 0;
+        const bool in_range = c.x >= 0 && c.x < p.batch;
+        if (in_range) {
+            float X, Y, Z;
+            voxel_centre(c, p.origin, p.voxel_size, X, Y, Z);
+            const float wm1 = (float)(p.W - 1), hm1 = (float)(p.H - 1);
+            for (int v = 0; v < p.V; ++v)
+                cnt += project(sP + (v * p.batch + c.x) * 12, X, Y, Z, wm1, hm1).vis ? 1 : 0;
+        }
+        p.count[i] = (float)cnt;
+        valid = in_range && cnt >= p.min_view;
+        if (valid) atomicAdd(&sBatch[c.x], 1);
+    }
+    int total;
+    block_exclusive_rank<BLOCK>(valid, sWave, total);
+    if (tid == 0) block_sums[blockIdx.x] = total;
+    for (int b = tid; b < p.batch; b += BLOCK)
+        if (sBatch[b]) atomicAdd(&p.n_valid_dev[1 + b], sBatch[b]);
+}
+
+// exclusive scan of the block totals, one workgroup; also publishes n_valid
+__global__ __launch_bounds__(1024) void bp_scan_kernel(int32_t *block_sums, int nblk,
+                                                       int32_t *n_valid_dev)
+{
+    __shared__ int sWave[1024 / kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+    int carry = 0;
+    for (int base = 0; base < nblk; base += 1024) {
+        const int i = base + tid;
+        const int v = i < nblk ? block_sums[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == kWave - 1) sWave[wid] = x;
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 1024 / kWave; ++w) {
+            const int c = sWave[w];
+            woff += (w < wid) ? c : 0;
+            tot += c;
+        }
+        if (i < nblk) block_sums[i] = carry + woff + x - v;
+        carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) n_valid_dev[0] = carry;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2 + K3 (+K4): compaction and bilinear gather
+// ---------------------------------------------------------------------------------------------
+struct Taps {
+    int o00, o10, o01, o11;  // element offsets of the four taps inside one NHWC map (channel 0)
+    float w00, w10, w01, w11;
+};
+
+__device__ __forceinline__ Taps make_taps(float ix, float iy, int W, int H, int C)
+{
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    int x0 = (int)x0f, y0 = (int)y0f;
+    float wx1 = ix - x0f, wx0 = (x0f + 1.0f) - ix;
+    float wy1 = iy - y0f, wy0 = (y0f + 1.0f) - iy;
+    int x1 = x0 + 1, y1 = y0 + 1;
+    // zero padding: a visible voxel has ix in [0, W-1], so only the +1 taps can leave the image,
+    // and then only with weight exactly 0
+    if (x1 >= W) { x1 = W - 1; wx1 = 0.0f; }
+    if (y1 >= H) { y1 = H - 1; wy1 = 0.0f; }
+    Taps t;
+    t.o00 = (y0 * W + x0) * C;
+    t.o10 = (y0 * W + x1) * C;
+    t.o01 = (y1 * W + x0) * C;
+    t.o11 = (y1 * W + x1) * C;
+    t.w00 = wx0 * wy0;
+    t.w10 = wx1 * wy0;
+    t.w01 = wx0 * wy1;
+    t.w11 = wx1 * wy1;
+    return t;
+}
+
+template <int VEC>
+struct Chan;
+template <>
+struct Chan<4> {
+    float4 v;
+    __device__ __forceinline__ static Chan zero() { return Chan{make_float4(0.f, 0.f, 0.f, 0.f)}; }
+    __device__ __forceinline__ static Chan sample(const float *m, const Taps &t)
+    {
+        const float4 a = *reinterpret_cast<const float4 *>(m + t.o00);
+        const float4 b = *reinterpret_cast<const float4 *>(m + t.o10);
+        const float4 c = *reinterpret_cast<const float4 *>(m + t.o01);
+        const float4 d = *reinterpret_cast<const float4 *>(m + t.o11);
+        Chan r;
+        r.v.x = fmaf(d.x, t.w11, fmaf(c.x, t.w01, fmaf(b.x, t.w10, a.x * t.w00)));
+        r.v.y = fmaf(d.y, t.w11, fmaf(c.y, t.w01, fmaf(b.y, t.w10, a.y * t.w00)));
+        r.v.z = fmaf(d.z, t.w11, fmaf(c.z, t.w01, fmaf(b.z, t.w10, a.z * t.w00)));
+        r.v.w = fmaf(d.w, t.w11, fmaf(c.w, t.w01, fmaf(b.w, t.w10, a.w * t.w00)));
+        return r;
+    }
+    __device__ __forceinline__ void add(const Chan &o) { v.x += o.v.x; v.y += o.v.y; v.z += o.v.z; v.w += o.v.w; }
+    __device__ __forceinline__ void add_sqdiff(const Chan &f, const Chan &mean)
+    {
+        const float dx = f.v.x - mean.v.x, dy = f.v.y - mean.v.y, dz = f.v.z - mean.v.z, dw = f.v.w - mean.v.w;
+        v.x = fmaf(dx, dx, v.x); v.y = fmaf(dy, dy, v.y); v.z = fmaf(dz, dz, v.z); v.w = fmaf(dw, dw, v.w);
+    }
+    __device__ __forceinline__ Chan div(float d) const
+    {
+        return Chan{make_float4(__fdiv_rn(v.x, d), __fdiv_rn(v.y, d), __fdiv_rn(v.z, d), __fdiv_rn(v.w, d))};
+    }
+    __device__ __forceinline__ void store(float *dst, bool aligned16) const
+    {
+        if (aligned16) {
+            *reinterpret_cast<float4 *>(dst) = v;
+        } else {
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+    }
+};
+template <>
+struct Chan<1> {
+    float v;
+    __device__ __forceinline__ static Chan zero() { return Chan{0.f}; }
+    __device__ __forceinline__ static Chan sample(const float *m, const Taps &t)
+    {
+        return Chan{fmaf(m[t.o11], t.w11, fmaf(m[t.o01], t.w01, fmaf(m[t.o10], t.w10, m[t.o00] * t.w00)))};
+    }
+    __device__ __forceinline__ void add(const Chan &o) { v += o.v; }
+    __device__ __forceinline__ void add_sqdiff(const Chan &f, const Chan &mean)
+    {
+        const float d = f.v - mean.v;
+        v = fmaf(d, d, v);
+    }
+    __device__ __forceinline__ Chan div(float d) const { return Chan{__fdiv_rn(v, d)}; }
+    __device__ __forceinline__ void store(float *dst, bool) const { dst[0] = v; }
+};
+
+// QT > 0: channel groups per voxel known at compile time (fast div/mod); QT == 0: runtime
+template <int BLOCK, int MODE, int VEC, int QT>
+__global__ __launch_bounds__(BLOCK) void bp_gather_kernel(BpParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS carve (every offset a multiple of 16 bytes)
+    float2 *sPix = reinterpret_cast<float2 *>(smem);                     // [BLOCK][V] pixel coords
+    float *sP = reinterpret_cast<float *>(sPix + BLOCK * p.V);           // [V*B][12]
+    const int nP = (p.V * p.batch * 12 + 3) & ~3;
+    uint32_t *sVis = reinterpret_cast<uint32_t *>(sP + nP);              // [BLOCK] view bitmask
+    float *sDen = reinterpret_cast<float *>(sVis + BLOCK);               // [BLOCK] divisor
+    int *sBatch = reinterpret_cast<int *>(sDen + BLOCK);                 // [BLOCK] batch index
+    int *sSlot = sBatch + BLOCK;                                         // [BLOCK] rank -> thread
+    int *sWave = sSlot + BLOCK;                                          // [BLOCK/64]
+
+    const int tid = threadIdx.x;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    stage_matrices(sP, p.krcam, p.V * p.batch, tid, BLOCK);
+    __syncthreads();
+
+    const int i = lb * BLOCK + tid;
+    const float wm1 = (float)(p.W - 1), hm1 = (float)(p.H - 1);
+    bool valid = false;
+    int4 c = make_int4(0, 0, 0, 0);
+    float X = 0.f, Y = 0.f, Z = 0.f, zsum = 0.f;
+    int cnt = 0;
+    uint32_t vis = 0;
+    if (i < p.n) {
+        c = reinterpret_cast<const int4 *>(p.coords)[i];
+        if (c.x >= 0 && c.x < p.batch) {
+            voxel_centre(c, p.origin, p.voxel_size, X, Y, Z);
+            for (int v = 0; v < p.V; ++v) {
+                const Proj pr = project(sP + (v * p.batch + c.x) * 12, X, Y, Z, wm1, hm1);
+                // grid -> pixel exactly as grid_sample(align_corners=True) un-normalises
+                const float ix = __fmul_rn(__fdiv_rn(__fadd_rn(pr.gx, 1.0f), 2.0f), wm1);
+                const float iy = __fmul_rn(__fdiv_rn(__fadd_rn(pr.gy, 1.0f), 2.0f), hm1);
+                sPix[tid * p.V + v] = make_float2(ix, iy);
+                if (pr.vis) {
+                    vis |= 1u << v;
+                    cnt += 1;
+                    zsum += pr.pz;
+                }
+            }
+            valid = cnt >= p.min_view;
+        }
+    }
+    int nloc;
+    const int rank = block_exclusive_rank<BLOCK>(valid, sWave, nloc);
+    if (nloc == 0) return;
+    const int base = p.block_offsets[lb];
+    const int n_valid = p.n_valid_dev[0];
+    const int cout = (MODE == EPRECON_BP_MEAN_DEPTH) ? p.C + 1 : p.C;
+    if (valid) {
+        const int o = base + rank;
+        sSlot[rank] = tid;
+        sVis[tid] = vis;
+        const float den = (float)(cnt > 0 ? cnt : 1);
+        sDen[tid] = den;
+        sBatch[tid] = c.x;
+        reinterpret_cast<int4 *>(p.out_coords)[o] = c;
+        if (MODE == EPRECON_BP_MEAN_DEPTH) p.out_feats[(size_t)o * cout + p.C] = __fdiv_rn(zsum, den);
+        if (p.out_grid || p.out_mask) {
+            for (int v = 0; v < p.V; ++v) {
+                const Proj pr = project(sP + (v * p.batch + c.x) * 12, X, Y, Z, wm1, hm1);
+                if (p.out_grid)
+                    reinterpret_cast<float2 *>(p.out_grid)[(size_t)v * n_valid + o] = make_float2(pr.gx, pr.gy);
+                if (p.out_mask) p.out_mask[(size_t)v * n_valid + o] = pr.vis ? 1 : 0;
+            }
+        }
+    }
+    __syncthreads();
+
+    const int Q = QT > 0 ? QT : p.C / VEC;
+    const size_t map_elems = (size_t)p.H * p.W * p.C;
+    const bool aligned16 = (MODE != EPRECON_BP_MEAN_DEPTH);
+    for (int w = tid; w < nloc * Q; w += BLOCK) {
+        const int r = w / Q;
+        const int q = w - r * Q;
+        const int t = sSlot[r];
+        const uint32_t vm = sVis[t];
+        const float den = sDen[t];
+        const int b = sBatch[t];
+        const float *fb = p.feats_nhwc + (size_t)b * map_elems + q * VEC;
+        const size_t vstride = (size_t)p.batch * map_elems;
+        Chan<VEC> acc = Chan<VEC>::zero();
+        for (int v = 0; v < p.V; ++v) {
+            if (vm & (1u << v)) {
+                const float2 px = sPix[t * p.V + v];
+                const Taps tp = make_taps(px.x, px.y, p.W, p.H, p.C);
+                acc.add(Chan<VEC>::sample(fb + (size_t)v * vstride, tp));
+            }
+        }
+        float *dst = p.out_feats + (size_t)(base + r) * cout + q * VEC;
+        if (MODE == EPRECON_BP_VARIANCE) {
+            // models/occupancy_initialization.py:127-128: population variance over visible views
+            const Chan<VEC> mean = acc.div(den);
+            Chan<VEC> sq = Chan<VEC>::zero();
+            for (int v = 0; v < p.V; ++v) {
+                if (vm & (1u << v)) {
+                    const float2 px = sPix[t * p.V + v];
+                    const Taps tp = make_taps(px.x, px.y, p.W, p.H, p.C);
+                    sq.add_sqdiff(Chan<VEC>::sample(fb + (size_t)v * vstride, tp), mean);
+                }
+            }
+            sq.div(den).store(dst, true);
+            if (p.out_mean) mean.store(p.out_mean + (size_t)(base + r) * p.C + q * VEC, true);
+        } else {
+            acc.div(den).store(dst, aligned16);
+        }
+    }
+}
+
+// ops/back_project.py:69-75 — per batch element: mu = mean(d[d>0]); sigma = ||d[d>0]-mu||_2 + 1e-5;
+// d_hat = (d-mu)/sigma, 0 where d <= 0.  One workgroup per batch element, three sweeps.
+__global__ __launch_bounds__(1024) void bp_depth_norm_kernel(float *out_feats, int cout,
+                                                             const int32_t *n_valid_dev)
+{
+    __shared__ float sRed[1024 / kWave];
+    __shared__ float sBcast[2];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+    int start = 0;
+    for (int k = 0; k < b; ++k) start += n_valid_dev[1 + k];
+    const int len = n_valid_dev[1 + b];
+    float *d = out_feats + (size_t)start * cout + (cout - 1);
+
+    auto block_sum = [&](float x) -> float {
+#pragma unroll
+        for (int s = kWave / 2; s > 0; s >>= 1) x += __shfl_xor(x, s);
+        __syncthreads();
+        if (lane == 0) sRed[wid] = x;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 1024 / kWave; ++w) t += sRed[w];
+        return t;
+    };
+    float s = 0.f, m = 0.f;
+    for (int j = tid; j < len; j += 1024) {
+        const float x = d[(size_t)j * cout];
+        if (x > 0.f) { s += x; m += 1.f; }
+    }
+    const float tot = block_sum(s), cntp = block_sum(m);
+    const float mu = tot / cntp;
+    float ss = 0.f;
+    for (int j = tid; j < len; j += 1024) {
+        const float x = d[(size_t)j * cout];
+        if (x > 0.f) ss = fmaf(x - mu, x - mu, ss);
+    }
+    const float sigma = sqrtf(block_sum(ss)) + 1e-5f;
+    for (int j = tid; j < len; j += 1024) {
+        const float x = d[(size_t)j * cout];
+        d[(size_t)j * cout] = x > 0.f ? (x - mu) / sigma : 0.f;
+    }
+    (void)sBcast;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NCHW -> NHWC through an LDS tile: reads coalesced along H*W, writes coalesced along (pixel, C)
+// ---------------------------------------------------------------------------------------------
+constexpr int kTrPix = 64;
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restrict__ in,
+                                                           float *__restrict__ out, int C, int hw)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *tile = reinterpret_cast<float *>(smem);  // [C][kTrPix + 1]
+    const int map = blockIdx.y;
+    const int p0 = blockIdx.x * kTrPix;
+    const int npix = min(kTrPix, hw - p0);
+    const float *src = in + (size_t)map * C * hw;
+    float *dst = out + (size_t)map * hw * C + (size_t)p0 * C;
+    for (int e = threadIdx.x; e < C * kTrPix; e += 256) {
+        const int c = e / kTrPix, px = e - c * kTrPix;
+        if (px < npix) tile[c * (kTrPix + 1) + px] = src[(size_t)c * hw + p0 + px];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < npix * C; e += 256) {
+        const int px = e / C, c = e - px * C;
+        dst[e] = tile[c * (kTrPix + 1) + px];
+    }
+}
+
+struct ProfileState {
+    bool on = false, recorded = false;
+    hipEvent_t start = nullptr, stop = nullptr;
+} g_prof;
+
+size_t gather_lds_bytes(int block, int V, int B)
+{
+    const size_t nP = ((size_t)V * B * 12 + 3) & ~(size_t)3;
+    return (size_t)block * V * sizeof(float2) + nP * sizeof(float) + (size_t)block * 4 * 4 +
+           (size_t)(block / kWave) * 4 + 16;
+}
+
+template <int BLOCK, int MODE>
+int launch_gather(const BpParams &p, int nblk, hipStream_t st)
+{
+    const size_t lds = gather_lds_bytes(BLOCK, p.V, p.batch);
+    const dim3 grid(nblk), block(BLOCK);
+#define EP_GATHER(VEC, QT) hipLaunchKernelGGL((bp_gather_kernel<BLOCK, MODE, VEC, QT>), grid, block, lds, st, p)
+    if (p.C % 4 == 0) {
+        switch (p.C / 4) {
+            case 6: EP_GATHER(4, 6); break;    // C = 24  (1/4-res level)
+            case 8: EP_GATHER(4, 8); break;    // C = 32  (fused initialisation maps)
+            case 10: EP_GATHER(4, 10); break;  // C = 40  (1/8-res level)
+            case 20: EP_GATHER(4, 20); break;  // C = 80  (1/16-res level)
+            default: EP_GATHER(4, 0); break;
+        }
+    } else {
+        EP_GATHER(1, 0);
+    }
+#undef EP_GATHER
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int eprecon_abi_version(void) { return EPRECON_ABI_VERSION; }
+const char *eprecon_build_arch(void) { return "gfx950"; }
+
+size_t eprecon_back_project_workspace_bytes(int64_t n, int batch, int n_views, int channels,
+                                            int height, int width, int feats_layout)
+{
+    size_t bytes = ep::align_up((size_t)ep::ceil_div(n > 0 ? n : 1, 64) * sizeof(int32_t), 256);
+    if (feats_layout == EPRECON_LAYOUT_NCHW)
+        bytes += ep::align_up((size_t)n_views * batch * channels * height * width * sizeof(float), 256);
+    return bytes + 256;
+}
+
+int eprecon_profile_enable(int on)
+{
+    if (on && !g_prof.start) {
+        EP_HIP_CHECK(hipEventCreate(&g_prof.start));
+        EP_HIP_CHECK(hipEventCreate(&g_prof.stop));
+    }
+    g_prof.on = on != 0;
+    g_prof.recorded = false;
+    return EPRECON_OK;
+}
+
+float eprecon_profile_gather_ms(void)
+{
+    if (!g_prof.recorded) return -1.0f;
+    if (hipEventSynchronize(g_prof.stop) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, g_prof.start, g_prof.stop) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+int eprecon_nchw_to_nhwc_async(const float *in, float *out, int maps, int channels, int hw,
+                               void *stream)
+{
+    if (!in || !out || maps <= 0 || channels <= 0 || hw <= 0) return EPRECON_ERR_ARG;
+    const size_t lds = (size_t)channels * (kTrPix + 1) * sizeof(float);
+    if (lds > 64 * 1024) return EPRECON_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)ep::ceil_div(hw, kTrPix), (unsigned)maps);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), lds, (hipStream_t)stream, in, out,
+                       channels, hw);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *origin, int batch,
+                               float voxel_size, const float *feats, int feats_layout,
+                               const float *krcam, int n_views, int channels, int height,
+                               int width, int min_view, int mode, float *out_feats,
+                               float *out_mean, int32_t *out_coords, float *count,
+                               float *out_grid, uint8_t *out_mask, int32_t *n_valid_dev,
+                               void *workspace, size_t workspace_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 0 || n > 0x7fffffff / 64 || batch <= 0 || n_views <= 0 || n_views > 32 || channels <= 0 ||
+        height <= 1 || width <= 1 || mode < 0 || mode > 2)
+        return EPRECON_ERR_ARG;
+    if (!origin || !feats || !krcam || !n_valid_dev || !workspace) return EPRECON_ERR_ARG;
+    if (n > 0 && (!coords || !out_feats || !out_coords || !count)) return EPRECON_ERR_ARG;
+    if ((size_t)n_views * batch * 12 * sizeof(float) > 32 * 1024) return EPRECON_ERR_UNSUPPORTED;
+    if (workspace_bytes < eprecon_back_project_workspace_bytes(n, batch, n_views, channels, height,
+                                                               width, feats_layout))
+        return EPRECON_ERR_WORKSPACE;
+    if ((size_t)n_views * batch * channels * height * width > 0x7fffffffull) return EPRECON_ERR_UNSUPPORTED;
+
+    EP_HIP_CHECK(hipMemsetAsync(n_valid_dev, 0, sizeof(int32_t) * (size_t)(1 + batch), st));
+    if (n == 0) return EPRECON_OK;
+
+    char *ws = reinterpret_cast<char *>(workspace);
+    int32_t *block_sums = reinterpret_cast<int32_t *>(ws);
+    ws += ep::align_up((size_t)ep::ceil_div(n, 64) * sizeof(int32_t), 256);
+    const float *nhwc = feats;
+    if (feats_layout == EPRECON_LAYOUT_NCHW) {
+        float *tmp = reinterpret_cast<float *>(ws);
+        const int rc = eprecon_nchw_to_nhwc_async(feats, tmp, n_views * batch, channels, height * width, stream);
+        if (rc != EPRECON_OK) return rc;
+        nhwc = tmp;
+    } else if (feats_layout != EPRECON_LAYOUT_NHWC) {
+        return EPRECON_ERR_ARG;
+    }
+
+    BpParams p;
+    p.coords = coords; p.n = (int)n; p.origin = origin; p.batch = batch; p.voxel_size = voxel_size;
+    p.feats_nhwc = nhwc; p.krcam = krcam; p.V = n_views; p.C = channels; p.H = height; p.W = width;
+    p.min_view = min_view; p.out_feats = out_feats; p.out_mean = out_mean; p.out_coords = out_coords;
+    p.count = count; p.out_grid = out_grid; p.out_mask = out_mask; p.n_valid_dev = n_valid_dev;
+    p.block_offsets = block_sums;
+
+    // small voxel lists (the 24^3 stage: <= 13,824 voxels) use one-wave workgroups so that the
+    // launch still covers the 256 CUs
+    const bool small = n < 64 * 1024;
+    const int blk = small ? 64 : 256;
+    const int nblk = (int)ep::ceil_div(n, blk);
+    const size_t lds_count = ((size_t)n_views * batch * 12 + batch + blk / ep::kWave) * 4 + 16;
+    if (small)
+        hipLaunchKernelGGL((bp_count_kernel<64>), dim3(nblk), dim3(64), lds_count, st, p, block_sums);
+    else
+        hipLaunchKernelGGL((bp_count_kernel<256>), dim3(nblk), dim3(256), lds_count, st, p, block_sums);
+    EP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bp_scan_kernel, dim3(1), dim3(1024), 0, st, block_sums, nblk, n_valid_dev);
+    EP_LAUNCH_CHECK();
+
+    const bool prof = g_prof.on && g_prof.start;
+    if (prof) EP_HIP_CHECK(hipEventRecord(g_prof.start, st));
+    int rc;
+    if (small) {
+        rc = mode == EPRECON_BP_MEAN ? launch_gather<64, EPRECON_BP_MEAN>(p, nblk, st)
+           : mode == EPRECON_BP_MEAN_DEPTH ? launch_gather<64, EPRECON_BP_MEAN_DEPTH>(p, nblk, st)
+                                           : launch_gather<64, EPRECON_BP_VARIANCE>(p, nblk, st);
+    } else {
+        rc = mode == EPRECON_BP_MEAN ? launch_gather<256, EPRECON_BP_MEAN>(p, nblk, st)
+           : mode == EPRECON_BP_MEAN_DEPTH ? launch_gather<256, EPRECON_BP_MEAN_DEPTH>(p, nblk, st)
+                                           : launch_gather<256, EPRECON_BP_VARIANCE>(p, nblk, st);
+    }
+    if (rc != EPRECON_OK) return rc;
+    if (prof) {
+        EP_HIP_CHECK(hipEventRecord(g_prof.stop, st));
+        g_prof.recorded = true;
+    }
+    if (mode == EPRECON_BP_MEAN_DEPTH) {
+        hipLaunchKernelGGL(bp_depth_norm_kernel, dim3(batch), dim3(1024), 0, st, out_feats,
+                           channels + 1, n_valid_dev);
+        EP_LAUNCH_CHECK();
+    }
+    return EPRECON_OK;
+}
+
+int eprecon_back_project(const int32_t *coords, int64_t n, const float *origin, int batch,
+                         float voxel_size, const float *feats, int feats_layout,
+                         const float *krcam, int n_views, int channels, int height, int width,
+                         int min_view, int mode, int min_valid_per_batch, float *out_feats,
+                         float *out_mean, int32_t *out_coords, float *count, float *out_grid,
+                         uint8_t *out_mask, int32_t *n_valid_dev, int32_t *n_valid_host,
+                         void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!n_valid_host) return EPRECON_ERR_ARG;
+    const int rc = eprecon_back_project_async(coords, n, origin, batch, voxel_size, feats, feats_layout,
+                                              krcam, n_views, channels, height, width, min_view, mode,
+                                              out_feats, out_mean, out_coords, count, out_grid, out_mask,
+                                              n_valid_dev, workspace, workspace_bytes, stream);
+    if (rc != EPRECON_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    EP_HIP_CHECK(hipMemcpyAsync(n_valid_host, n_valid_dev, sizeof(int32_t) * (size_t)(1 + batch),
+                                hipMemcpyDeviceToHost, st));
+    EP_HIP_CHECK(hipStreamSynchronize(st));
+    for (int b = 0; b < batch; ++b)
+        if (n_valid_host[1 + b] < min_valid_per_batch) return EPRECON_EMPTY;
+    return EPRECON_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+// Shared device/host helpers for libeprecon_hip.so (gfx950 only; wave = 64, 8 XCDs).
+//
+// The whole library is compiled with -ffp-contract=off: wherever a fused multiply-add is part of
+// the arithmetic contract (or wanted for speed) it is written as fmaf()/__fmaf_rn explicitly, and
+// nowhere else may the compiler fuse — bit-exact voxel indices depend on it.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/eprecon_hip.h"
+
+#define EP_HIP_CHECK(expr)                                            \
+    do {                                                              \
+        hipError_t e_ = (expr);                                       \
+        if (e_ != hipSuccess) return EPRECON_ERR_HIP_BASE - (int)e_;  \
+    } while (0)
+#define EP_LAUNCH_CHECK() EP_HIP_CHECK(hipGetLastError())
+
+namespace ep {
+
+constexpr int kWave = 64;
+constexpr int kXcd = 8;
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Hardware block id -> logical block id.  The dispatcher places hardware block h on XCD h % 8
+// (observed, speed only); this bijection gives every XCD one contiguous range of logical blocks
+// so that neighbouring tiles, which touch neighbouring image regions, share one L2.
+__device__ __forceinline__ int xcd_remap(int hw_bid, int nblk)
+{
+    const int q = nblk / kXcd, r = nblk % kXcd;
+    const int xcd = hw_bid % kXcd, k = hw_bid / kXcd;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + k;
+}
+
+// Exclusive rank of this thread among the threads of its block for which `pred` holds, by wave
+// ballot + popcount and a per-wave count table in LDS (`wave_counts` holds BLOCK/64 ints).
+// Contains one __syncthreads(); every thread of the block must call it.
+template <int BLOCK>
+__device__ __forceinline__ int block_exclusive_rank(bool pred, int *wave_counts, int &block_total)
+{
+    const unsigned long long m = __ballot(pred);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wid = threadIdx.x / kWave;
+    const int within = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_counts[wid] = __popcll(m);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / kWave; ++w) {
+        const int c = wave_counts[w];
+        off += (w < wid) ? c : 0;
+        tot += c;
+    }
+    block_total = tot;
+    return off + within;
+}
+
+}  // namespace ep
