@@ -25,6 +25,20 @@ SIGNATURES = {
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "eprecon_back_project": (_i, [_vp, _i64, _vp, _i, _f, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "eprecon_hash_capacity": (_c.c_uint32, [_i64]),
+    "eprecon_hash_table_bytes": (_sz, [_c.c_uint32]),
+    "eprecon_hash_build_async": (_i, [_vp, _i64, _i, _vp, _c.c_uint32, _vp]),
+    "eprecon_hash_query_async": (_i, [_vp, _c.c_uint32, _vp, _i64, _i, _vp, _vp]),
+    "eprecon_hash_status": (_i, [_vp, _vp]),
+    "eprecon_unique_workspace_bytes": (_sz, [_i64]),
+    "eprecon_unique_coords_async": (_i, [_vp, _i64, _i, _vp, _c.c_uint32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "eprecon_kernel_map_async": (_i, [_vp, _c.c_uint32, _vp, _i64, _i, _i, _vp, _vp]),
+    "eprecon_transpose_map_async": (_i, [_vp, _i64, _vp, _i, _vp, _vp]),
+    "eprecon_sparse_conv_async": (_i, [_vp, _i64, _i, _vp, _i, _i64, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "eprecon_batchnorm_workspace_bytes": (_sz, [_i64, _i]),
+    "eprecon_batchnorm_train_async": (_i, [_vp, _i64, _i, _i, _vp, _vp, _f, _vp, _i, _i, _vp, _i, _vp, _vp,
+                                           _vp, _sz, _vp]),
+    "eprecon_rowwise_layernorm_async": (_i, [_vp, _i64, _i, _i, _vp, _i, _vp, _vp, _f, _i, _i, _vp, _i, _vp]),
     "eprecon_profile_enable": (_i, [_i]),
     "eprecon_profile_gather_ms": (_f, []),
     "eprecon_nchw_to_nhwc_async": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -59,4 +59,8 @@ __device__ __forceinline__ int block_exclusive_rank(bool pred, int *wave_counts,
     return off + within;
 }
 
+// device-wide exclusive scan of int32 (kernel_map.hip); scratch holds ceil(n / 2048) int32
+int exclusive_scan_i32(const int32_t *in, int n, int32_t *out, int32_t *scratch, int32_t *total_dev,
+                       hipStream_t st);
+
 }  // namespace ep

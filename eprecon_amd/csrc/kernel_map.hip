@@ -1,0 +1,391 @@
+// Coordinate bookkeeping for the sparse layers on gfx950: hash-grid build / query, unique
+// voxel ids (stable, first-occurrence order), stride-1 and strided kernel maps.
+//
+// Replaces (reference call sites; implementations are in the un-vendored torchsparse / spconv):
+//   F.sphash + F.sphashquery            ops/torchsparse_utils.py:19-21,44-50,73-79
+//   torch.unique(hash) voxel ids        ops/torchsparse_utils.py:20-22   (initial_voxelize)
+//   spnn.Conv3d kernel maps (k3 s1, k2 s2 and its transpose), spconv SubMConv3d indice pairs
+//                                       models/modules.py:19-64,90-122,181,252,444
+// Ordering contract of this build (the reference's voxel order is "ascending hash", i.e. arbitrary
+// and never relied on — SURVEY.md appendix A.2): unique voxels are numbered in order of FIRST
+// OCCURRENCE in the input list.  All kernels are atomic-free in their outputs except the hash
+// insert (atomicCAS on the key, atomicMin on the row index), whose result is order-independent.
+#include "hashgrid.hpp"
+
+namespace {
+using namespace ep;
+
+// -------------------------------------------------------------------------------------------
+// device-wide exclusive scan of int32 (n up to 2^31), three launches, deterministic
+// -------------------------------------------------------------------------------------------
+constexpr int kScanBlock = 256;
+constexpr int kScanItems = 8;                       // per thread
+constexpr int kScanTile = kScanBlock * kScanItems;  // 2048 per block
+
+__global__ __launch_bounds__(kScanBlock) void scan_tile_sums(const int32_t *in, int n, int32_t *sums)
+{
+    __shared__ int sWave[kScanBlock / kWave];
+    const int base = blockIdx.x * kScanTile;
+    int s = 0;
+    for (int k = 0; k < kScanItems; ++k) {
+        const int i = base + k * kScanBlock + threadIdx.x;
+        if (i < n) s += in[i];
+    }
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) s += __shfl_xor(s, d);
+    if ((threadIdx.x & (kWave - 1)) == 0) sWave[threadIdx.x / kWave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < kScanBlock / kWave; ++w) t += sWave[w];
+        sums[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void scan_sums_inplace(int32_t *sums, int nblk, int32_t *total)
+{
+    __shared__ int sWave[1024 / kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+    int carry = 0;
+    for (int base = 0; base < nblk; base += 1024) {
+        const int i = base + tid;
+        const int v = i < nblk ? sums[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == kWave - 1) sWave[wid] = x;
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 1024 / kWave; ++w) {
+            const int c = sWave[w];
+            woff += (w < wid) ? c : 0;
+            tot += c;
+        }
+        if (i < nblk) sums[i] = carry + woff + x - v;
+        carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0 && total) *total = carry;
+}
+
+// out[i] = exclusive prefix of in[0..i); each block rescans its 2048-element tile in LDS
+__global__ __launch_bounds__(kScanBlock) void scan_apply(const int32_t *in, int n, const int32_t *sums,
+                                                         int32_t *out)
+{
+    __shared__ int sWave[kScanBlock / kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+    const int base = blockIdx.x * kScanTile + tid * kScanItems;  // blocked arrangement
+    int v[kScanItems];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        s += v[k];
+    }
+    int x = s;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    if (lane == kWave - 1) sWave[wid] = x;
+    __syncthreads();
+    int off = sums[blockIdx.x] + x - s;
+    for (int w = 0; w < wid; ++w) off += sWave[w];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        if (base + k < n) out[base + k] = off;
+        off += v[k];
+    }
+}
+
+}  // namespace
+
+namespace ep {
+// scratch: ceil(n / 2048) int32.  `total_dev` (optional) receives the grand total.
+int exclusive_scan_i32(const int32_t *in, int n, int32_t *out, int32_t *scratch, int32_t *total_dev,
+                       hipStream_t st)
+{
+    if (n <= 0) {
+        if (total_dev) EP_HIP_CHECK(hipMemsetAsync(total_dev, 0, sizeof(int32_t), st));
+        return EPRECON_OK;
+    }
+    const int nblk = (int)ceil_div(n, kScanTile);
+    hipLaunchKernelGGL(scan_tile_sums, dim3(nblk), dim3(kScanBlock), 0, st, in, n, scratch);
+    EP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(1024), 0, st, scratch, nblk, total_dev);
+    EP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_apply, dim3(nblk), dim3(kScanBlock), 0, st, in, n, scratch, out);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+}  // namespace ep
+
+namespace {
+
+__device__ __forceinline__ int floor_div(int a, int q) { return (a >= 0) ? a / q : -((-a + q - 1) / q); }
+
+__global__ void hash_clear_kernel(unsigned long long *keys, int32_t *vals, uint32_t cap, int32_t *status)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) {
+        keys[i] = kEmptyKey;
+        vals[i] = 0x7fffffff;
+    }
+    if (i == 0) status[0] = 0;
+}
+
+// coords int32[n,4] (b,x,y,z); key = floor(c / q) * q per spatial coordinate (q >= 1)
+__global__ void hash_insert_kernel(HashTable t, const int4 *coords, int n, int q, int32_t *status)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int4 c = coords[i];
+    if (q > 1) {
+        c.y = floor_div(c.y, q) * q;
+        c.z = floor_div(c.z, q) * q;
+        c.w = floor_div(c.w, q) * q;
+    }
+    if (!key_in_range(c.x, c.y, c.z, c.w)) {
+        atomicOr(status, 1);
+        return;
+    }
+    if (!hash_insert(t, pack_key(c.x, c.y, c.z, c.w), i)) atomicOr(status, 2);
+}
+
+__global__ void hash_query_kernel(HashTable t, const int4 *queries, int m, int q, int32_t *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    int4 c = queries[i];
+    if (q > 1) {
+        c.y = floor_div(c.y, q) * q;
+        c.z = floor_div(c.z, q) * q;
+        c.w = floor_div(c.w, q) * q;
+    }
+    out[i] = key_in_range(c.x, c.y, c.z, c.w) ? hash_lookup(t, pack_key(c.x, c.y, c.z, c.w)) : -1;
+}
+
+// first[i] = 1 when row i is the first occurrence of its (quantised) key
+__global__ void first_flag_kernel(HashTable t, const int4 *coords, int n, int q, int32_t *first,
+                                  int32_t *owner)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int4 c = coords[i];
+    if (q > 1) {
+        c.y = floor_div(c.y, q) * q;
+        c.z = floor_div(c.z, q) * q;
+        c.w = floor_div(c.w, q) * q;
+    }
+    const int o = key_in_range(c.x, c.y, c.z, c.w) ? hash_lookup(t, pack_key(c.x, c.y, c.z, c.w)) : -1;
+    owner[i] = o;
+    first[i] = (o == i) ? 1 : 0;
+}
+
+// inverse[i] = unique id of row i; unique_coords[uid] = quantised coords of the first occurrence;
+// the table values are rewritten from "first row" to "unique id" so later lookups return ids.
+__global__ void unique_finalize_kernel(HashTable t, const int4 *coords, int n, int q,
+                                       const int32_t *owner, const int32_t *rank, int32_t *inverse,
+                                       int4 *unique_coords)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int o = owner[i];
+    if (o < 0) {
+        inverse[i] = -1;
+        return;
+    }
+    const int uid = rank[o];
+    inverse[i] = uid;
+    if (o == i) {
+        int4 c = coords[i];
+        if (q > 1) {
+            c.y = floor_div(c.y, q) * q;
+            c.z = floor_div(c.z, q) * q;
+            c.w = floor_div(c.w, q) * q;
+        }
+        unique_coords[uid] = c;
+    }
+}
+
+__global__ void table_vals_to_ids_kernel(HashTable t, uint32_t cap, const int32_t *rank)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < cap && t.keys[s] != kEmptyKey) t.vals[s] = rank[t.vals[s]];
+}
+
+// nbr[k][i] = row of the voxel at coords[i] + offset_k * stride (or -1).
+// ksize 3: 27 offsets, x fastest (k = ((dz+1)*3 + (dy+1))*3 + (dx+1));
+// ksize 2: 8 offsets in {0,1}^3, z fastest (k = 4*bx + 2*by + bz)   
+__global__ void kernel_map_kernel(HashTable t, const int4 *coords, int n, int ksize, int stride,
+                                  int32_t *nbr)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    if (i >= n) return;
+    const int4 c = coords[i];
+    int dx, dy, dz;
+    if (ksize == 3) {
+        dx = k % 3 - 1;
+        dy = (k / 3) % 3 - 1;
+        dz = k / 9 - 1;
+    } else {
+        dx = (k >> 2) & 1;
+        dy = (k >> 1) & 1;
+        dz = k & 1;
+    }
+    const int x = c.y + dx * stride, y = c.z + dy * stride, z = c.w + dz * stride;
+    nbr[(size_t)k * n + i] = key_in_range(c.x, x, y, z) ? hash_lookup(t, pack_key(c.x, x, y, z)) : -1;
+}
+
+// transposed k2s2 map: up[k][i] = parent row of fine voxel i when i is child k of its parent, else -1
+__global__ void transpose_map_kernel(const int4 *fine, int n, const int32_t *parent, int fine_stride,
+                                     int32_t *up)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = fine[i];
+    const int q = 2 * fine_stride;
+    const int bx = (c.y - floor_div(c.y, q) * q) / fine_stride;
+    const int by = (c.z - floor_div(c.z, q) * q) / fine_stride;
+    const int bz = (c.w - floor_div(c.w, q) * q) / fine_stride;
+    const int kk = 4 * bx + 2 * by + bz;
+    const int par = parent[i];
+    for (int k = 0; k < 8; ++k) up[(size_t)k * n + i] = (k == kk) ? par : -1;
+}
+
+HashTable make_table(void *mem, uint32_t cap)
+{
+    HashTable t;
+    t.keys = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(mem) + 256);
+    t.vals = reinterpret_cast<int32_t *>(t.keys + cap);
+    t.mask = cap - 1;
+    return t;
+}
+int32_t *table_status(void *mem) { return reinterpret_cast<int32_t *>(mem); }
+bool is_pow2(uint32_t c) { return c >= 1024 && (c & (c - 1)) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+uint32_t eprecon_hash_capacity(int64_t n) { return ep::hash_capacity_for(n); }
+size_t eprecon_hash_table_bytes(uint32_t capacity) { return 256 + (size_t)capacity * 12; }
+
+int eprecon_hash_build_async(const int32_t *coords, int64_t n, int quantum, void *table,
+                             uint32_t capacity, void *stream)
+{
+    if (!table || !is_pow2(capacity) || n < 0 || quantum < 1 || (uint64_t)capacity < (uint64_t)n + 1 ||
+        (n > 0 && !coords))
+        return EPRECON_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HashTable t = make_table(table, capacity);
+    hipLaunchKernelGGL(hash_clear_kernel, dim3((capacity + 255) / 256), dim3(256), 0, st, t.keys, t.vals,
+                       capacity, table_status(table));
+    EP_LAUNCH_CHECK();
+    if (n > 0) {
+        hipLaunchKernelGGL(hash_insert_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, t,
+                           reinterpret_cast<const int4 *>(coords), (int)n, quantum, table_status(table));
+        EP_LAUNCH_CHECK();
+    }
+    return EPRECON_OK;
+}
+
+int eprecon_hash_query_async(const void *table, uint32_t capacity, const int32_t *queries, int64_t m,
+                             int quantum, int32_t *out_index, void *stream)
+{
+    if (!table || !is_pow2(capacity) || m < 0 || quantum < 1 || (m > 0 && (!queries || !out_index)))
+        return EPRECON_ERR_ARG;
+    if (m == 0) return EPRECON_OK;
+    HashTable t = make_table(const_cast<void *>(table), capacity);
+    hipLaunchKernelGGL(hash_query_kernel, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0,
+                       (hipStream_t)stream, t, reinterpret_cast<const int4 *>(queries), (int)m, quantum,
+                       out_index);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_hash_status(const void *table, void *stream)
+{
+    int32_t s = 0;
+    EP_HIP_CHECK(hipMemcpyAsync(&s, table, sizeof(s), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    EP_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return s == 0 ? EPRECON_OK : (s & 1 ? EPRECON_ERR_UNSUPPORTED : EPRECON_ERR_WORKSPACE);
+}
+
+size_t eprecon_unique_workspace_bytes(int64_t n)
+{
+    return align_up((size_t)(n > 0 ? n : 1) * 4, 256) * 3 + align_up((size_t)ceil_div(n > 0 ? n : 1, 2048) * 4, 256) + 256;
+}
+
+int eprecon_unique_coords_async(const int32_t *coords, int64_t n, int quantum, void *table,
+                                uint32_t capacity, int32_t *inverse, int32_t *unique_coords,
+                                int32_t *n_unique_dev, void *workspace, size_t workspace_bytes,
+                                void *stream)
+{
+    if (!n_unique_dev || !workspace || workspace_bytes < eprecon_unique_workspace_bytes(n))
+        return n_unique_dev && workspace ? EPRECON_ERR_WORKSPACE : EPRECON_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = eprecon_hash_build_async(coords, n, quantum, table, capacity, stream);
+    if (rc != EPRECON_OK) return rc;
+    if (n == 0) {
+        EP_HIP_CHECK(hipMemsetAsync(n_unique_dev, 0, sizeof(int32_t), st));
+        return EPRECON_OK;
+    }
+    if (!inverse || !unique_coords) return EPRECON_ERR_ARG;
+    char *ws = reinterpret_cast<char *>(workspace);
+    const size_t seg = align_up((size_t)n * 4, 256);
+    int32_t *first = reinterpret_cast<int32_t *>(ws);
+    int32_t *owner = reinterpret_cast<int32_t *>(ws + seg);
+    int32_t *rank = reinterpret_cast<int32_t *>(ws + 2 * seg);
+    int32_t *scratch = reinterpret_cast<int32_t *>(ws + 3 * seg);
+    HashTable t = make_table(table, capacity);
+    const dim3 grid((unsigned)ceil_div(n, 256)), block(256);
+    const int4 *c4 = reinterpret_cast<const int4 *>(coords);
+    hipLaunchKernelGGL(first_flag_kernel, grid, block, 0, st, t, c4, (int)n, quantum, first, owner);
+    EP_LAUNCH_CHECK();
+    rc = ep::exclusive_scan_i32(first, (int)n, rank, scratch, n_unique_dev, st);
+    if (rc != EPRECON_OK) return rc;
+    hipLaunchKernelGGL(unique_finalize_kernel, grid, block, 0, st, t, c4, (int)n, quantum, owner, rank,
+                       inverse, reinterpret_cast<int4 *>(unique_coords));
+    EP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(table_vals_to_ids_kernel, dim3((capacity + 255) / 256), block, 0, st, t, capacity,
+                       rank);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_kernel_map_async(const void *table, uint32_t capacity, const int32_t *coords, int64_t n,
+                             int ksize, int stride, int32_t *nbr, void *stream)
+{
+    if (!table || !is_pow2(capacity) || n < 0 || (ksize != 2 && ksize != 3) || stride < 1 ||
+        (n > 0 && (!coords || !nbr)))
+        return EPRECON_ERR_ARG;
+    if (n == 0) return EPRECON_OK;
+    HashTable t = make_table(const_cast<void *>(table), capacity);
+    const int kvol = ksize * ksize * ksize;
+    hipLaunchKernelGGL(kernel_map_kernel, dim3((unsigned)ceil_div(n, 256), kvol), dim3(256), 0,
+                       (hipStream_t)stream, t, reinterpret_cast<const int4 *>(coords), (int)n, ksize,
+                       stride, nbr);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_transpose_map_async(const int32_t *fine_coords, int64_t n, const int32_t *parent,
+                                int fine_stride, int32_t *up_map, void *stream)
+{
+    if (n < 0 || fine_stride < 1 || (n > 0 && (!fine_coords || !parent || !up_map))) return EPRECON_ERR_ARG;
+    if (n == 0) return EPRECON_OK;
+    hipLaunchKernelGGL(transpose_map_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, reinterpret_cast<const int4 *>(fine_coords), (int)n, parent,
+                       fine_stride, up_map);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,173 @@
+"""Host-side handles for the sparse primitives of libeprecon_hip.so: coordinate sets with their
+hash grid and cached kernel maps (the role torchsparse's SparseTensor.cmaps/.kmaps and spconv's
+indice pairs play in the reference), sparse convolution, and the normalisation epilogues.
+
+Coordinates are int32[N,4] rows (batch, x, y, z) everywhere in this package; wrappers that mirror
+torchsparse's xyzb order convert at their boundary.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "row-major 2-D tensor expected"
+    return t.stride(0)
+
+
+class HashGrid:
+    """device hash table over a coordinate set (eprecon_hash_*)"""
+
+    def __init__(self, n, device):
+        lib = _lib.load()
+        self.capacity = int(lib.eprecon_hash_capacity(int(n)))
+        self.mem = torch.empty(int(lib.eprecon_hash_table_bytes(self.capacity)), dtype=torch.uint8,
+                               device=device)
+
+    def build(self, coords, quantum=1):
+        lib = _lib.load()
+        _lib.check(lib.eprecon_hash_build_async(_lib.ptr(coords), coords.shape[0], quantum,
+                                                _lib.ptr(self.mem), self.capacity,
+                                                _lib.current_stream()), "eprecon_hash_build_async")
+        return self
+
+    def query(self, queries, quantum=1):
+        lib = _lib.load()
+        out = torch.empty(queries.shape[0], dtype=torch.int32, device=queries.device)
+        _lib.check(lib.eprecon_hash_query_async(_lib.ptr(self.mem), self.capacity, _lib.ptr(queries),
+                                                queries.shape[0], quantum, _lib.ptr(out),
+                                                _lib.current_stream()), "eprecon_hash_query_async")
+        return out
+
+    def status_ok(self):
+        """blocking; raises when a key was out of range or the table overflowed"""
+        lib = _lib.load()
+        return _lib.check(lib.eprecon_hash_status(_lib.ptr(self.mem), _lib.current_stream()),
+                          "eprecon_hash_status")
+
+
+def unique_coords(coords, quantum=1):
+    """-> (unique int32[M,4] in first-occurrence order, inverse int32[N], HashGrid mapping key -> id).
+    One host sync to learn M (the reference's torch.unique syncs as well)."""
+    lib = _lib.load()
+    coords = coords.contiguous()
+    n, dev = coords.shape[0], coords.device
+    grid = HashGrid(n, dev)
+    inverse = torch.empty(n, dtype=torch.int32, device=dev)
+    uniq = torch.empty((n, 4), dtype=torch.int32, device=dev)
+    n_unique = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = _lib.workspace(lib.eprecon_unique_workspace_bytes(n), dev)
+    _lib.check(lib.eprecon_unique_coords_async(_lib.ptr(coords), n, quantum, _lib.ptr(grid.mem),
+                                               grid.capacity, _lib.ptr(inverse), _lib.ptr(uniq),
+                                               _lib.ptr(n_unique), _lib.ptr(ws), ws.numel(),
+                                               _lib.current_stream()), "eprecon_unique_coords_async")
+    m = int(n_unique.item())
+    return uniq[:m], inverse, grid
+
+
+class VoxelSet:
+    """A set of active voxels at one tensor stride: coords int32[N,4] (b,x,y,z), its hash grid and
+    the kernel maps built on it.  Maps are built once and reused by every layer on the set."""
+
+    def __init__(self, coords, stride=1, grid=None):
+        assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
+        self.coords = coords.contiguous()
+        self.stride = int(stride)
+        self._grid = grid
+        self._k3 = None
+        self._down = None
+
+    @property
+    def n(self):
+        return self.coords.shape[0]
+
+    @property
+    def grid(self):
+        if self._grid is None:
+            self._grid = HashGrid(self.n, self.coords.device).build(self.coords)
+        return self._grid
+
+    def kernel_map(self, ksize=3):
+        """int32[27, N] neighbour table of the stride-1 k=3 convolution on this set"""
+        assert ksize == 3
+        if self._k3 is None:
+            lib = _lib.load()
+            nbr = torch.empty((27, self.n), dtype=torch.int32, device=self.coords.device)
+            _lib.check(lib.eprecon_kernel_map_async(_lib.ptr(self.grid.mem), self.grid.capacity,
+                                                    _lib.ptr(self.coords), self.n, 3, self.stride,
+                                                    _lib.ptr(nbr), _lib.current_stream()),
+                       "eprecon_kernel_map_async")
+            self._k3 = nbr
+        return self._k3
+
+    def downsample(self):
+        """k2s2 strided set: -> (coarse VoxelSet, down_map int32[8, M], up_map int32[8, N])"""
+        if self._down is None:
+            lib = _lib.load()
+            q = 2 * self.stride
+            uniq, parent, cgrid = unique_coords(self.coords, quantum=q)
+            coarse = VoxelSet(uniq, q, grid=cgrid)
+            m = coarse.n
+            down = torch.empty((8, m), dtype=torch.int32, device=self.coords.device)
+            _lib.check(lib.eprecon_kernel_map_async(_lib.ptr(self.grid.mem), self.grid.capacity,
+                                                    _lib.ptr(coarse.coords), m, 2, self.stride,
+                                                    _lib.ptr(down), _lib.current_stream()),
+                       "eprecon_kernel_map_async")
+            up = torch.empty((8, self.n), dtype=torch.int32, device=self.coords.device)
+            _lib.check(lib.eprecon_transpose_map_async(_lib.ptr(self.coords), self.n, _lib.ptr(parent),
+                                                       self.stride, _lib.ptr(up), _lib.current_stream()),
+                       "eprecon_transpose_map_async")
+            self._down = (coarse, down, up)
+        return self._down
+
+
+def sparse_conv(x, weight, nbr=None, bias=None, out=None, relu=False, accumulate=False):
+    """out[i] (op)= bias + sum_k x[nbr[k][i]] @ weight[k].  weight f32[K, Cin, Cout] (or [Cin, Cout]
+    with nbr None: a per-voxel linear layer).  x / out may be column slices of wider buffers."""
+    lib = _lib.load()
+    if weight.dim() == 2:
+        weight = weight.unsqueeze(0)
+    kvol, cin, cout = weight.shape
+    weight = weight.contiguous()
+    n_out = x.shape[0] if nbr is None else nbr.shape[1]
+    assert x.shape[1] == cin and x.dtype == torch.float32
+    if nbr is not None:
+        assert nbr.dtype == torch.int32 and nbr.shape[0] == kvol and nbr.is_contiguous()
+    if out is None:
+        out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+    assert out.shape == (n_out, cout)
+    _lib.check(lib.eprecon_sparse_conv_async(_lib.ptr(x), x.shape[0], _ld(x), _lib.ptr(nbr), kvol, n_out,
+                                             _lib.ptr(weight), cin, cout, _lib.ptr(bias), _lib.ptr(out),
+                                             _ld(out), int(relu), int(accumulate), _lib.current_stream()),
+               "eprecon_sparse_conv_async")
+    return out
+
+
+def batchnorm_train(x, gamma=None, beta=None, eps=1e-5, residual=None, relu=False, out=None):
+    """train-mode BatchNorm over all rows (+ optional residual add and ReLU); out may be x"""
+    lib = _lib.load()
+    n, c = x.shape
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    ws = _lib.workspace(lib.eprecon_batchnorm_workspace_bytes(n, c), x.device)
+    _lib.check(lib.eprecon_batchnorm_train_async(
+        _lib.ptr(x), n, c, _ld(x), _lib.ptr(gamma), _lib.ptr(beta), float(eps), _lib.ptr(residual),
+        _ld(residual) if residual is not None else 0, int(relu), _lib.ptr(out), _ld(out), None, None,
+        _lib.ptr(ws), ws.numel(), _lib.current_stream()), "eprecon_batchnorm_train_async")
+    return out
+
+
+def rowwise_layernorm(x, gamma=None, beta=None, eps=1e-5, residual=None, pre_relu=False, post_relu=False,
+                      out=None):
+    """y = [relu]( LN( [relu](x) [+ residual] ) * gamma + beta ) per row; out may be x"""
+    lib = _lib.load()
+    n, c = x.shape
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    _lib.check(lib.eprecon_rowwise_layernorm_async(
+        _lib.ptr(x), n, c, _ld(x), _lib.ptr(residual), _ld(residual) if residual is not None else 0,
+        _lib.ptr(gamma), _lib.ptr(beta), float(eps), int(pre_relu), int(post_relu), _lib.ptr(out),
+        _ld(out), _lib.current_stream()), "eprecon_rowwise_layernorm_async")
+    return out

@@ -110,6 +110,90 @@ float eprecon_profile_gather_ms(void);
 int eprecon_nchw_to_nhwc_async(const float *in, float *out, int maps, int channels, int hw,
                                void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Hash grid over voxel coordinates  (K6 / K7)
+ *
+ * Replaces  torchsparse F.sphash + F.sphashquery   ops/torchsparse_utils.py:19-21,44-50,73-79
+ *           torch.unique(hash) voxel numbering     ops/torchsparse_utils.py:20-22
+ * (torchsparse is an un-vendored dependency of the reference, README.md:19; semantics restated
+ * in DESIGN.md.)  A table is caller-owned device memory of eprecon_hash_table_bytes(capacity)
+ * bytes, capacity = eprecon_hash_capacity(n) (a power of two >= 2n).  Keys are exact 64-bit
+ * packings of (b, x, y, z): |coordinate| < 2^19 - 1, 0 <= b <= 14.  `quantum` q >= 1 maps every
+ * spatial coordinate to floor(c / q) * q before hashing (q = 2 * tensor_stride builds the strided
+ * coordinate set of a k2s2 convolution).
+ * ------------------------------------------------------------------------------------------ */
+uint32_t eprecon_hash_capacity(int64_t n);
+size_t eprecon_hash_table_bytes(uint32_t capacity);
+/* value of a key = smallest input row that carries it */
+int eprecon_hash_build_async(const int32_t *coords, int64_t n, int quantum, void *table,
+                             uint32_t capacity, void *stream);
+/* out_index[i] = value stored for queries[i] (int32[m,4] bxyz), or -1 */
+int eprecon_hash_query_async(const void *table, uint32_t capacity, const int32_t *queries, int64_t m,
+                             int quantum, int32_t *out_index, void *stream);
+/* blocking: EPRECON_OK, EPRECON_ERR_UNSUPPORTED (a key was out of range) or
+ * EPRECON_ERR_WORKSPACE (table full) */
+int eprecon_hash_status(const void *table, void *stream);
+
+/* Unique (quantised) coordinates in FIRST-OCCURRENCE order:
+ *   inverse[i]           id of row i's voxel                        int32[n]
+ *   unique_coords[id]    its quantised (b,x,y,z)                     int32[n,4] (first n_unique rows)
+ *   n_unique_dev         int32[1]
+ * afterwards the table maps key -> voxel id (so eprecon_hash_query_async returns ids). */
+size_t eprecon_unique_workspace_bytes(int64_t n);
+int eprecon_unique_coords_async(const int32_t *coords, int64_t n, int quantum, void *table,
+                                uint32_t capacity, int32_t *inverse, int32_t *unique_coords,
+                                int32_t *n_unique_dev, void *workspace, size_t workspace_bytes,
+                                void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Kernel maps and sparse convolution  (K5, K10, K11, K13)
+ *
+ * Replaces  spnn.Conv3d (k3 s1 / k2 s2 / transposed / k1)   models/modules.py:19-64,90-122,181
+ *           spconv SubMConv3d (k1 / k3, bias)               models/modules.py:252,444
+ * nbr is int32[K][n]: nbr[k][i] = row of the voxel at coords[i] + offset_k * stride in the set the
+ * table was built on, or -1.  ksize 3: K = 27, offsets in {-1,0,1}^3 with x fastest;
+ * ksize 2: K = 8, offsets in {0,1}^3 with z fastest (k = 4 bx + 2 by + bz).
+ *   stride-1 k3 conv on a set S:   table(S), coords = S, stride = tensor stride of S
+ *   k2s2 down-conv S -> T:         table(S), coords = T (= unique of S at quantum 2 ts), stride = ts
+ *   its transpose T -> S:          eprecon_transpose_map_async(S, parent = inverse from the unique call)
+ * ------------------------------------------------------------------------------------------ */
+int eprecon_kernel_map_async(const void *table, uint32_t capacity, const int32_t *coords, int64_t n,
+                             int ksize, int stride, int32_t *nbr, void *stream);
+int eprecon_transpose_map_async(const int32_t *fine_coords, int64_t n, const int32_t *parent,
+                                int fine_stride, int32_t *up_map, void *stream);
+/*
+ * out[i, 0:cout] (op)= bias + sum_k x[nbr[k][i], 0:cin] @ weight[k]      weight f32[kvol][cin][cout]
+ * x / out are row-major with leading dimensions ld_x / ld_out (so a layer can read from / write
+ * into a channel slice of a wider buffer = torchsparse.cat for free).  nbr == NULL means the
+ * identity map (kvol must be 1: a per-voxel linear layer).  relu != 0 fuses ReLU; accumulate != 0
+ * adds to the existing contents of out.  cout <= 128.  fp32 MFMA, deterministic.
+ */
+int eprecon_sparse_conv_async(const float *x, int64_t n_in, int ld_x, const int32_t *nbr, int kvol,
+                              int64_t n_out, const float *weight, int cin, int cout, const float *bias,
+                              float *out, int ld_out, int relu, int accumulate, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Normalisation epilogues  (K12)
+ *
+ * Replaces  spnn.BatchNorm / nn.BatchNorm1d in TRAIN mode (batch statistics over all active
+ *           voxels; the reference tests in train mode, main.py:357)   models/modules.py:22,41,54,60,65
+ *           nn.LayerNorm with the ReLU / residual wiring of           models/modules.py:447-452,473-482
+ *                                                                     models/occupancy_initialization.py:141-169
+ * ------------------------------------------------------------------------------------------ */
+size_t eprecon_batchnorm_workspace_bytes(int64_t n, int channels);
+/* out = [relu]( (x - mean) / sqrt(var + eps) * gamma + beta [+ residual] ), biased variance;
+ * out may alias x; mean_out / var_out optional f32[channels] */
+int eprecon_batchnorm_train_async(const float *x, int64_t n, int channels, int ld_x, const float *gamma,
+                                  const float *beta, float eps, const float *residual, int ld_res,
+                                  int relu, float *out, int ld_out, float *mean_out, float *var_out,
+                                  void *workspace, size_t workspace_bytes, void *stream);
+/* per row: t = x; if pre_relu t = relu(t); if residual t += residual; y = LN(t) * gamma + beta;
+ * if post_relu y = relu(y).  out may alias x. */
+int eprecon_rowwise_layernorm_async(const float *x, int64_t n, int channels, int ld_x,
+                                    const float *residual, int ld_res, const float *gamma,
+                                    const float *beta, float eps, int pre_relu, int post_relu,
+                                    float *out, int ld_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
