@@ -39,6 +39,8 @@ SIGNATURES = {
     "eprecon_batchnorm_train_async": (_i, [_vp, _i64, _i, _i, _vp, _vp, _f, _vp, _i, _i, _vp, _i, _vp, _vp,
                                            _vp, _sz, _vp]),
     "eprecon_rowwise_layernorm_async": (_i, [_vp, _i64, _i, _i, _vp, _i, _vp, _vp, _f, _i, _i, _vp, _i, _vp]),
+    "eprecon_init_select_async": (_i, [_vp, _vp, _i64, _f, _i, _i, _i, _vp, _vp, _vp]),
+    "eprecon_upsample_async": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "eprecon_profile_enable": (_i, [_i]),
     "eprecon_profile_gather_ms": (_f, []),
     "eprecon_nchw_to_nhwc_async": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -1,0 +1,167 @@
+// Small dense-grid helpers of the coarse-to-fine loop for gfx950.
+//
+//   init_select   sigmoid(logit) > thr on the valid 48^3 voxels -> OR-pool 2^3 -> erode -> dilate x2
+//                 -> raster-order coordinates * 4           models/neucon_network.py:264,298-318
+//                 (the whole 24^3 occupancy volume lives in LDS; one workgroup)
+//   upsample      every voxel -> its 8 children, parent-major, features replicated
+//                                                            models/neucon_network.py:193-214
+#include "common.hpp"
+
+namespace {
+using namespace ep;
+
+constexpr int kSelThreads = 1024;
+
+__device__ __forceinline__ bool box27(const unsigned char *vol, int D, int x, int y, int z, bool want_all)
+{
+    // zero padding: cells outside the volume count as 0 (F.conv3d padding=1 with an all-ones kernel)
+    int s = 0;
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dz = -1; dz <= 1; ++dz) {
+                const int a = x + dx, b = y + dy, c = z + dz;
+                if (a >= 0 && a < D && b >= 0 && b < D && c >= 0 && c < D) s += vol[(a * D + b) * D + c];
+            }
+    return want_all ? (s == 27) : (s >= 1);
+}
+
+__global__ __launch_bounds__(kSelThreads) void init_select_kernel(const float *logit, const int4 *coords,
+                                                                  int n, float thr, int batch, int D,
+                                                                  int cell, int out_scale, int4 *out_coords,
+                                                                  int32_t *n_out_dev)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int cells = D * D * D;
+    unsigned char *va = reinterpret_cast<unsigned char *>(smem);
+    unsigned char *vb = va + ((cells + 15) & ~15);
+    int *sWave = reinterpret_cast<int *>(vb + ((cells + 15) & ~15));
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+    int written = 0;
+    for (int b = 0; b < batch; ++b) {
+        for (int i = tid; i < cells; i += kSelThreads) va[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += kSelThreads) {
+            const int4 c = coords[i];
+            if (c.x != b) continue;
+            const float sig = 1.0f / (1.0f + expf(-logit[i]));
+            if (sig > thr) {
+                const int x = c.y / cell, y = c.z / cell, z = c.w / cell;
+                if (x >= 0 && x < D && y >= 0 && y < D && z >= 0 && z < D) va[(x * D + y) * D + z] = 1;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < cells; i += kSelThreads) {  // erode
+            const int z = i % D, y = (i / D) % D, x = i / (D * D);
+            vb[i] = box27(va, D, x, y, z, true) ? 1 : 0;
+        }
+        __syncthreads();
+        for (int i = tid; i < cells; i += kSelThreads) {  // dilate 1
+            const int z = i % D, y = (i / D) % D, x = i / (D * D);
+            va[i] = box27(vb, D, x, y, z, false) ? 1 : 0;
+        }
+        __syncthreads();
+        for (int i = tid; i < cells; i += kSelThreads) {  // dilate 2
+            const int z = i % D, y = (i / D) % D, x = i / (D * D);
+            vb[i] = box27(va, D, x, y, z, false) ? 1 : 0;
+        }
+        __syncthreads();
+        // raster-order compaction: thread t owns the contiguous cell range [t*per, (t+1)*per)
+        const int per = (cells + kSelThreads - 1) / kSelThreads;
+        const int c0 = tid * per, c1 = min(cells, c0 + per);
+        int mine = 0;
+        for (int i = c0; i < c1; ++i) mine += vb[i];
+        int x = mine;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == kWave - 1) sWave[wid] = x;
+        __syncthreads();
+        int off = written + x - mine, tot = 0;
+        for (int w = 0; w < kSelThreads / kWave; ++w) {
+            const int c = sWave[w];
+            if (w < wid) off += c;
+            tot += c;
+        }
+        for (int i = c0; i < c1; ++i)
+            if (vb[i]) {
+                const int z = i % D, y = (i / D) % D, xx = i / (D * D);
+                out_coords[off++] = make_int4(b, xx * out_scale, y * out_scale, z * out_scale);
+            }
+        if (tid == 0) n_out_dev[1 + b] = tot;
+        written += tot;
+        __syncthreads();
+    }
+    if (tid == 0) n_out_dev[0] = written;
+}
+
+__global__ __launch_bounds__(256) void upsample_coords_kernel(const int4 *coords, int n, int interval,
+                                                              int4 *up)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * 8) return;
+    const int i = e >> 3, k = e & 7;
+    // child order (models/neucon_network.py:204-209): 0, x, y, z, xy, xz, yz, xyz
+    const int dx = (0xB2 >> k) & 1;  // k in {1,4,5,7}
+    const int dy = (0xD4 >> k) & 1;  // k in {2,4,6,7}
+    const int dz = (0xE8 >> k) & 1;  // k in {3,5,6,7}
+    int4 c = coords[i];
+    c.y += dx * interval;
+    c.z += dy * interval;
+    c.w += dz * interval;
+    up[e] = c;
+}
+
+__global__ __launch_bounds__(256) void upsample_feat_kernel(const float *feat, int n, int C, int ld,
+                                                            float *up)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)n * 8 * C;
+    if (e >= total) return;
+    const int c = (int)(e % C);
+    const size_t row = e / C;
+    up[e] = feat[(row >> 3) * ld + c];
+}
+
+}  // namespace
+
+extern "C" {
+
+int eprecon_init_select_async(const float *logit, const int32_t *coords, int64_t n, float threshold,
+                              int batch, int dim, int cell, int32_t *out_coords, int32_t *n_out_dev,
+                              void *stream)
+{
+    if (n < 0 || batch <= 0 || dim <= 0 || dim > 40 || cell <= 0 || !out_coords || !n_out_dev ||
+        (n > 0 && (!logit || !coords)))
+        return EPRECON_ERR_ARG;
+    const int cells = dim * dim * dim;
+    const size_t lds = 2 * (size_t)((cells + 15) & ~15) + (kSelThreads / kWave) * sizeof(int) + 16;
+    hipLaunchKernelGGL(init_select_kernel, dim3(1), dim3(kSelThreads), lds, (hipStream_t)stream, logit,
+                       reinterpret_cast<const int4 *>(coords), (int)n, threshold, batch, dim, cell, cell,
+                       reinterpret_cast<int4 *>(out_coords), n_out_dev);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_upsample_async(const float *feat, int ld_feat, const int32_t *coords, int64_t n, int channels,
+                           int interval, float *up_feat, int32_t *up_coords, void *stream)
+{
+    if (n < 0 || channels < 0 || interval <= 0 || (n > 0 && (!coords || !up_coords))) return EPRECON_ERR_ARG;
+    if (n == 0) return EPRECON_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(upsample_coords_kernel, dim3((unsigned)ceil_div(n * 8, 256)), dim3(256), 0, st,
+                       reinterpret_cast<const int4 *>(coords), (int)n, interval,
+                       reinterpret_cast<int4 *>(up_coords));
+    EP_LAUNCH_CHECK();
+    if (channels > 0) {
+        if (!feat || !up_feat || ld_feat < channels) return EPRECON_ERR_ARG;
+        const size_t total = (size_t)n * 8 * channels;
+        hipLaunchKernelGGL(upsample_feat_kernel, dim3((unsigned)ceil_div((int64_t)total, 256)), dim3(256), 0,
+                           st, feat, (int)n, channels, ld_feat, up_feat);
+        EP_LAUNCH_CHECK();
+    }
+    return EPRECON_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,39 @@
+"""Host wrappers for the dense-grid helpers (csrc/grid_ops.hip)."""
+import torch
+
+from . import _lib
+
+
+def init_select(logit, coords, batch_size, dim=24, cell=4, threshold=0.3):
+    """models/neucon_network.py:264,298-318.  logit f32[N(,1)] and coords int32[N,4] of the valid
+    48^3 voxels -> int32[M,4] stage-0 coordinates (raster order per batch element) and the
+    per-batch counts (one host sync, like the reference's torch.nonzero)."""
+    lib = _lib.load()
+    logit = logit.reshape(-1).contiguous()
+    coords = coords.contiguous()
+    assert coords.dtype == torch.int32 and logit.dtype == torch.float32
+    dev = coords.device
+    out = torch.empty((batch_size * dim ** 3, 4), dtype=torch.int32, device=dev)
+    counts = torch.zeros(1 + batch_size, dtype=torch.int32, device=dev)
+    _lib.check(lib.eprecon_init_select_async(_lib.ptr(logit), _lib.ptr(coords), coords.shape[0],
+                                             float(threshold), batch_size, dim, cell, _lib.ptr(out),
+                                             _lib.ptr(counts), _lib.current_stream()),
+               "eprecon_init_select_async")
+    host = counts.cpu().tolist()
+    return out[: host[0]], host[1:]
+
+
+def upsample(pre_feat, pre_coords, interval):
+    """models/neucon_network.py:193-214 -> (up_feat f32[8N, C], up_coords int32[8N, 4])"""
+    lib = _lib.load()
+    n = pre_coords.shape[0]
+    coords = pre_coords if pre_coords.dtype == torch.int32 else pre_coords.to(torch.int32)
+    coords = coords.contiguous()
+    feat = pre_feat.contiguous()
+    c = feat.shape[1]
+    up_feat = torch.empty((8 * n, c), dtype=torch.float32, device=feat.device)
+    up_coords = torch.empty((8 * n, 4), dtype=torch.int32, device=feat.device)
+    _lib.check(lib.eprecon_upsample_async(_lib.ptr(feat), feat.stride(0), _lib.ptr(coords), n, c,
+                                          int(interval), _lib.ptr(up_feat), _lib.ptr(up_coords),
+                                          _lib.current_stream()), "eprecon_upsample_async")
+    return up_feat, up_coords

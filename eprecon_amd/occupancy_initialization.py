@@ -1,0 +1,90 @@
+"""Occupancy initialisation ("depth prior") — mirror of models/occupancy_initialization.py:11-182.
+
+Per batch element: fuse the three pyramid levels of the 9 views into 32-channel 1/8-resolution maps
+(dense 2D convolutions, PyTorch-ROCm), back-project them onto the dense 48^3 grid and take the
+per-voxel variance over the visible views (HIP, csrc/back_project.hip), then run the submanifold
+stack BN -> sparse ELAN -> 3 x (SubM3 + ReLU + residual + LN) -> SubM3(32->1) -> BN on the voxels
+seen by >= min_view views (HIP: hash-grid kernel map built once, MFMA gather-GEMM convolutions,
+fused normalisation epilogues).  Returns [occupancy logit f32[N_valid,1], coords[N_valid,4],
+count f32[N]] or None when a batch element has fewer than 1000 valid voxels (:107-108).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import back_project as BP
+from . import sparse as SP
+from .config import INIT_MIN_VALID
+from .modules import (Conv2d_Block, Conv2d_Residual_Block, Fusion_Block, SparseSubMConv3d, Spares3dELAN,
+                      TrainBatchNorm1d, _RowLayerNorm)
+
+
+class Occupancy_Initialization(nn.Module):
+    def __init__(self, ch_initialization_all, ch_initialization_down, n_views):
+        super().__init__()
+        ch_all = sum(ch_initialization_all[:3])
+        d = ch_initialization_down
+        self.self_fusion_1x = Fusion_Block(ch_initialization_all[0])
+        self.self_fusion_2x = Fusion_Block(ch_initialization_all[1])
+        self.self_fusion_4x = Fusion_Block(ch_initialization_all[2])
+        self.pool4x = nn.AvgPool2d(2)
+        self.fusion_down = Conv2d_Block(ch_all, d, 1)
+        self.post_fusion_1 = Conv2d_Residual_Block(d, 3)
+        self.post_fusion_2 = Conv2d_Residual_Block(d, 3)
+        self.post_fusion_3 = Conv2d_Residual_Block(d, 3)
+        self.post_fusion_4 = Conv2d_Residual_Block(d, 3)
+
+        self.similary_1 = Spares3dELAN(d)
+        self.norm0 = TrainBatchNorm1d(d)
+        self.subm1 = SparseSubMConv3d(d, d, 3)
+        self.norm1 = _RowLayerNorm(d)
+        self.subm2 = SparseSubMConv3d(d, d, 3)
+        self.norm2 = _RowLayerNorm(d)
+        self.subm3 = SparseSubMConv3d(d, d, 3)
+        self.norm3 = _RowLayerNorm(d)
+        self.subm4 = SparseSubMConv3d(d, 1, 3)
+        self.norm4 = TrainBatchNorm1d(1)
+
+    def feat_fusion_pre(self, feats_1x, feats_2x, feats_4x):
+        """[V,80,H/16,W/16], [V,40,H/8,W/8], [V,24,H/4,W/4] -> [V,32,H/8,W/8]  (:41-58)"""
+        f1 = F.interpolate(self.self_fusion_1x(feats_1x), scale_factor=2, mode="bilinear")
+        f2 = self.self_fusion_2x(feats_2x)
+        f4 = self.pool4x(self.self_fusion_4x(feats_4x))
+        x = self.fusion_down(torch.cat([f1, f2, f4], dim=1))
+        for blk in (self.post_fusion_1, self.post_fusion_2, self.post_fusion_3, self.post_fusion_4):
+            x = blk(x)
+        return x
+
+    def sparse_stack(self, var, vset):
+        """variance volume f32[N,32] on the voxel set -> occupancy logit f32[N,1]  (:131-174)"""
+        x = self.norm0.run(var)
+        x = self.similary_1.run(x, vset)
+        for conv, norm in ((self.subm1, self.norm1), (self.subm2, self.norm2), (self.subm3, self.norm3)):
+            y = conv.run(x, vset)
+            x = norm.run(y, residual=x, pre_relu=True, out=y)  # LN(x + ReLU(conv(x)))
+        y = self.subm4.run(x, vset)
+        return self.norm4.run(y, out=y)
+
+    def forward(self, coords, origin, voxel_size, features_all, KRcam, shape, stage, min_view_number):
+        feats_1x = torch.stack([f[2] for f in features_all])  # [V,B,80,h,w]   1/16
+        feats_2x = torch.stack([f[1] for f in features_all])  # [V,B,40,2h,2w] 1/8
+        feats_4x = torch.stack([f[0] for f in features_all])  # [V,B,24,4h,4w] 1/4
+        bs = feats_1x.shape[1]
+        fused = torch.stack([self.feat_fusion_pre(feats_1x[:, b], feats_2x[:, b], feats_4x[:, b])
+                             for b in range(bs)], dim=1)       # [V,B,32,H,W] at the `stage` resolution
+        res = BP.view_variance(coords, origin, voxel_size, fused, KRcam, min_view_number,
+                               min_valid=INIT_MIN_VALID)
+        if res is None:
+            return None
+        interval = 2 ** (2 - stage)
+        coord_valid = res["coords"]
+        occ = torch.empty((res["n_valid"], 1), dtype=torch.float32, device=fused.device)
+        start = 0
+        for b in range(bs):  # statistics of norm0 / norm4 are per batch element, as in the reference
+            nb = res["n_valid_per_batch"][b]
+            seg = slice(start, start + nb)
+            vset = SP.VoxelSet(coord_valid[seg], interval)
+            occ[seg] = self.sparse_stack(res["var"][seg], vset)
+            start += nb
+        out_coords = coord_valid if coords.dtype == torch.int32 else coord_valid.to(coords.dtype)
+        return [occ, out_coords, res["count"]]

@@ -194,6 +194,28 @@ int eprecon_rowwise_layernorm_async(const float *x, int64_t n, int channels, int
                                     const float *beta, float eps, int pre_relu, int post_relu,
                                     float *out, int ld_out, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Dense-grid helpers of the coarse-to-fine loop  (K14, K16)
+ * ------------------------------------------------------------------------------------------ */
+/*
+ * Initialisation -> coarse selection (models/neucon_network.py:264,298-318): per batch element,
+ * mark the (dim^3) coarse cells that contain a voxel with sigmoid(logit) > threshold (the 2^3
+ * max-pool of the 48^3 volume when cell = 4 and the voxels sit on the interval-2 grid), erode with
+ * a zero-padded 3^3 box, dilate twice, and emit the surviving cells in raster order as
+ * (b, cell*x, cell*y, cell*z).  coords int32[n,4] are the valid voxels the logits belong to.
+ * out_coords int32[batch*dim^3, 4]; n_out_dev int32[1 + batch] ([0] total, [1+b] per batch).
+ */
+int eprecon_init_select_async(const float *logit, const int32_t *coords, int64_t n, float threshold,
+                              int batch, int dim, int cell, int32_t *out_coords, int32_t *n_out_dev,
+                              void *stream);
+/*
+ * NeuConNet.upsample (models/neucon_network.py:193-214): up_coords int32[8n,4], up_feat f32[8n,C];
+ * children of a voxel are consecutive, in the order 0, +x, +y, +z, +xy, +xz, +yz, +xyz (x `interval`).
+ * channels == 0 expands the coordinates only.
+ */
+int eprecon_upsample_async(const float *feat, int ld_feat, const int32_t *coords, int64_t n, int channels,
+                           int interval, float *up_feat, int32_t *up_coords, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

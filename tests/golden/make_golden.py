@@ -91,7 +91,52 @@ def gen_back_project():
     _save("back_project", **out)
 
 
-GENERATORS = {"back_project": gen_back_project}
+def gen_grid_ops():
+    """generate_grid, NeuConNet.upsample and the init -> coarse selection
+    (models/neucon_network.py:193-228,298-318) on seeded inputs"""
+    import torch.nn.functional as F
+    from ops.generate_grids import generate_grid
+    from models.neucon_network import NeuConNet
+
+    out = {}
+    for interval in (1, 2, 4):
+        g, dims = generate_grid([96, 96, 96], interval)
+        out[f"grid_i{interval}_checksum"] = np.array([float(g.numpy().astype(np.float64).sum()),
+                                                      float((g.numpy().astype(np.float64) *
+                                                             np.arange(1, g.shape[1] + 1)).sum())])
+        out[f"grid_i{interval}_head"] = g.numpy()[:, :200]
+        out[f"grid_i{interval}_dims"] = np.array(dims)
+    rng = np.random.default_rng(31)
+    coords = rng.integers(0, 24, size=(500, 3)) * 4
+    coords = np.concatenate([rng.integers(0, 2, size=(500, 1)), coords], 1).astype(np.int32)
+    feat = rng.standard_normal((500, 7)).astype(np.float32)
+    uf, uc = NeuConNet.upsample(None, torch.from_numpy(feat), torch.from_numpy(coords), 2)
+    out["up_feat"], out["up_coords"] = uf.numpy(), uc.numpy()
+    # selection: seeded logits on the voxels of a 48^3 grid seen by >= 2 views (here: a random
+    # 85 % subset), smooth blob structure so that erosion leaves something
+    gx, gy, gz = np.meshgrid(*[np.arange(48)] * 3, indexing="ij")
+    blob = (np.sin(gx / 5.0) + np.cos(gy / 7.0) + np.sin(gz / 6.0 + 1.0)).astype(np.float32)
+    noise = rng.standard_normal((48, 48, 48)).astype(np.float32) * 0.6
+    logit_vol = blob + noise - 0.4
+    valid = rng.random((48, 48, 48)) < 0.85
+    sel_out = []
+    shape_init = (48, 48, 48)
+    logit = torch.from_numpy(logit_vol[valid])          # raster order of the valid voxels
+    occ_sel = logit.sigmoid() > 0.3
+    vol = torch.zeros(shape_init, dtype=torch.bool)
+    vol[torch.from_numpy(valid)] = occ_sel
+    vol = F.max_pool3d(vol.unsqueeze(0).float(), 2).squeeze(0)
+    vol = NeuConNet.erode(None, vol, kernel_size=3)
+    vol = NeuConNet.dilate(None, vol, kernel_size=3)
+    vol = NeuConNet.dilate(None, vol, kernel_size=3)
+    nz = torch.nonzero(vol).squeeze(1) * 4
+    out["sel_logit_vol"] = logit_vol
+    out["sel_valid"] = valid
+    out["sel_coords"] = nz.numpy().astype(np.int32)
+    _save("grid_ops", **out)
+
+
+GENERATORS = {"back_project": gen_back_project, "grid_ops": gen_grid_ops}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GENERATORS)
