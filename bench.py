@@ -41,22 +41,36 @@ def parse():
 
 
 def cpu_baseline(step, seconds):
-    """The same step on the host cores with the CPU oracle (oracle/c/back_project_oracle.c, a
-    C + OpenMP port of the reference algorithm; `kind` = "port").  Bounded sample: whole steps are
-    repeated until about `seconds` of wall time are spent (at least 2 after one warm-up)."""
+    """The same step on the host cores with the CPU oracle (`kind` = "port": oracle/c/*.c is a
+    C + OpenMP port of the reference's back-projection, oracle/*.py numpy ports of the sparse
+    layers; the 2D fusion convolutions run as the same PyTorch modules on CPU threads).
+    Bounded sample: whole steps are repeated until about `seconds` of wall time are spent."""
+    import torch
     from oracle import back_project as O
+    from oracle import grid_ops as OG
+    from oracle import occupancy_init as OI
     from eprecon_amd import synthetic as S
     from eprecon_amd.fragment_step import LEVELS
 
     w = step.window
     origin = w["vol_origin_partial"][None]
     feats = [f.cpu().numpy() for f in step.feats]
-    feats_init = step.feats_init.cpu().numpy()
     kr = [np.ascontiguousarray(w["proj_matrices"][:, l][:, None]) for l in range(3)]
     coords = {iv: S.dense_coords(w["n_vox"], iv) for iv in (4, 2, 1)}
+    import copy
+    net = copy.deepcopy(step.init_net).cpu()
+    sd = {k: v.numpy() for k, v in net.state_dict().items()}
+    f_init = [[t.cpu() for t in view] for view in step.features_init]
+    torch.set_num_threads(os.cpu_count() or 1)
 
     def one_step():
-        O.back_project(coords[2], origin, w["voxel_size"], feats_init, kr[1], 2, O.MODE_VARIANCE)
+        with torch.no_grad():
+            fused = net.feat_fusion_pre(torch.stack([f[2][0] for f in f_init]),
+                                        torch.stack([f[1][0] for f in f_init]),
+                                        torch.stack([f[0][0] for f in f_init])).unsqueeze(1).numpy()
+        r = O.back_project(coords[2], origin, w["voxel_size"], fused, kr[1], 2, O.MODE_VARIANCE)
+        logit = OI.sparse_stack(sd, r["feats"], r["coords"], 2)
+        OG.init_select(logit, r["coords"], 1)
         for _, lvl, interval, mv in LEVELS:
             O.back_project(coords[interval], origin, w["voxel_size"], feats[lvl], kr[lvl], mv)
 

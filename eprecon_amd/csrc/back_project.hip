@@ -90,9 +90,12 @@ __device__ __forceinline__ void stage_matrices(float *sP, const float *krcam, in
 // ---------------------------------------------------------------------------------------------
 // K1: visible-view count for every voxel, valid totals per block and per batch element
 // ---------------------------------------------------------------------------------------------
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void bp_count_kernel(BpParams p, int32_t *block_sums)
+// One thread per voxel, 256 per workgroup.  The valid totals are produced per TILE of VOX consecutive
+// voxels (VOX = 256, 64 or 16: the tile the gather kernel hands to one workgroup).
+template <int VOX>
+__global__ __launch_bounds__(256) void bp_count_kernel(BpParams p, int32_t *tile_sums)
 {
+    constexpr int BLOCK = 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *sP = reinterpret_cast<float *>(smem);
     int *sBatch = reinterpret_cast<int *>(sP + p.V * p.batch * 12);
@@ -119,9 +122,19 @@ __global__ __launch_bounds__(BLOCK) void bp_count_kernel(BpParams p, int32_t *bl
         valid = in_range && cnt >= p.min_view;
         if (valid) atomicAdd(&sBatch[c.x], 1);
     }
-    int total;
-    block_exclusive_rank<BLOCK>(valid, sWave, total);
-    if (tid == 0) block_sums[blockIdx.x] = total;
+    if (VOX == 256) {
+        int total;
+        block_exclusive_rank<BLOCK>(valid, sWave, total);
+        if (tid == 0) tile_sums[blockIdx.x] = total;
+    } else {
+        const unsigned long long m = __ballot(valid);
+        const int lane = tid & (kWave - 1);
+        if ((lane % VOX) == 0 && i < p.n) {
+            const unsigned long long seg = (VOX == 64) ? m : ((m >> lane) & ((1ull << VOX) - 1ull));
+            tile_sums[i / VOX] = __popcll(seg);
+        }
+        __syncthreads();
+    }
     for (int b = tid; b < p.batch; b += BLOCK)
         if (sBatch[b]) atomicAdd(&p.n_valid_dev[1 + b], sBatch[b]);
 }
@@ -246,33 +259,34 @@ struct Chan<1> {
 };
 
 // QT > 0: channel groups per voxel known at compile time (fast div/mod); QT == 0: runtime
-template <int BLOCK, int MODE, int VEC, int QT>
-__global__ __launch_bounds__(BLOCK) void bp_gather_kernel(BpParams p)
+template <int VOX, int MODE, int VEC, int QT>
+__global__ __launch_bounds__(256) void bp_gather_kernel(BpParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BLOCK = 256;
     // LDS carve (every offset a multiple of 16 bytes)
-    float2 *sPix = reinterpret_cast<float2 *>(smem);                     // [BLOCK][V] pixel coords
-    float *sP = reinterpret_cast<float *>(sPix + BLOCK * p.V);           // [V*B][12]
+    float2 *sPix = reinterpret_cast<float2 *>(smem);                     // [VOX][V] pixel coords
+    float *sP = reinterpret_cast<float *>(sPix + VOX * p.V);             // [V*B][12]
     const int nP = (p.V * p.batch * 12 + 3) & ~3;
-    uint32_t *sVis = reinterpret_cast<uint32_t *>(sP + nP);              // [BLOCK] view bitmask
-    float *sDen = reinterpret_cast<float *>(sVis + BLOCK);               // [BLOCK] divisor
-    int *sBatch = reinterpret_cast<int *>(sDen + BLOCK);                 // [BLOCK] batch index
-    int *sSlot = sBatch + BLOCK;                                         // [BLOCK] rank -> thread
-    int *sWave = sSlot + BLOCK;                                          // [BLOCK/64]
+    uint32_t *sVis = reinterpret_cast<uint32_t *>(sP + nP);              // [VOX] view bitmask
+    float *sDen = reinterpret_cast<float *>(sVis + VOX);                 // [VOX] divisor
+    int *sBatch = reinterpret_cast<int *>(sDen + VOX);                   // [VOX] batch index
+    int *sSlot = sBatch + VOX;                                           // [VOX] rank -> thread
+    int *sWave = sSlot + VOX;                                            // [BLOCK/64]
 
     const int tid = threadIdx.x;
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
     stage_matrices(sP, p.krcam, p.V * p.batch, tid, BLOCK);
     __syncthreads();
 
-    const int i = lb * BLOCK + tid;
+    const int i = lb * VOX + tid;
     const float wm1 = (float)(p.W - 1), hm1 = (float)(p.H - 1);
     bool valid = false;
     int4 c = make_int4(0, 0, 0, 0);
     float X = 0.f, Y = 0.f, Z = 0.f, zsum = 0.f;
     int cnt = 0;
     uint32_t vis = 0;
-    if (i < p.n) {
+    if (tid < VOX && i < p.n) {
         c = reinterpret_cast<const int4 *>(p.coords)[i];
         if (c.x >= 0 && c.x < p.batch) {
             voxel_centre(c, p.origin, p.voxel_size, X, Y, Z);
@@ -431,19 +445,19 @@ struct ProfileState {
     hipEvent_t start = nullptr, stop = nullptr;
 } g_prof;
 
-size_t gather_lds_bytes(int block, int V, int B)
+size_t gather_lds_bytes(int vox, int V, int B)
 {
     const size_t nP = ((size_t)V * B * 12 + 3) & ~(size_t)3;
-    return (size_t)block * V * sizeof(float2) + nP * sizeof(float) + (size_t)block * 4 * 4 +
-           (size_t)(block / kWave) * 4 + 16;
+    return (size_t)vox * V * sizeof(float2) + nP * sizeof(float) + (size_t)vox * 4 * 4 +
+           (size_t)(256 / kWave) * 4 + 16;
 }
 
-template <int BLOCK, int MODE>
+template <int VOX, int MODE>
 int launch_gather(const BpParams &p, int nblk, hipStream_t st)
 {
-    const size_t lds = gather_lds_bytes(BLOCK, p.V, p.batch);
-    const dim3 grid(nblk), block(BLOCK);
-#define EP_GATHER(VEC, QT) hipLaunchKernelGGL((bp_gather_kernel<BLOCK, MODE, VEC, QT>), grid, block, lds, st, p)
+    const size_t lds = gather_lds_bytes(VOX, p.V, p.batch);
+    const dim3 grid(nblk), block(256);
+#define EP_GATHER(VEC, QT) hipLaunchKernelGGL((bp_gather_kernel<VOX, MODE, VEC, QT>), grid, block, lds, st, p)
     if (p.C % 4 == 0) {
         switch (p.C / 4) {
             case 6: EP_GATHER(4, 6); break;    // C = 24  (1/4-res level)
@@ -470,7 +484,7 @@ const char *eprecon_build_arch(void) { return "gfx950"; }
 size_t eprecon_back_project_workspace_bytes(int64_t n, int batch, int n_views, int channels,
                                             int height, int width, int feats_layout)
 {
-    size_t bytes = ep::align_up((size_t)ep::ceil_div(n > 0 ? n : 1, 64) * sizeof(int32_t), 256);
+    size_t bytes = ep::align_up((size_t)ep::ceil_div(n > 0 ? n : 1, 16) * sizeof(int32_t), 256);
     if (feats_layout == EPRECON_LAYOUT_NCHW)
         bytes += ep::align_up((size_t)n_views * batch * channels * height * width * sizeof(float), 256);
     return bytes + 256;
@@ -534,7 +548,7 @@ int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *or
 
     char *ws = reinterpret_cast<char *>(workspace);
     int32_t *block_sums = reinterpret_cast<int32_t *>(ws);
-    ws += ep::align_up((size_t)ep::ceil_div(n, 64) * sizeof(int32_t), 256);
+    ws += ep::align_up((size_t)ep::ceil_div(n, 16) * sizeof(int32_t), 256);
     const float *nhwc = feats;
     if (feats_layout == EPRECON_LAYOUT_NCHW) {
         float *tmp = reinterpret_cast<float *>(ws);
@@ -552,32 +566,34 @@ int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *or
     p.count = count; p.out_grid = out_grid; p.out_mask = out_mask; p.n_valid_dev = n_valid_dev;
     p.block_offsets = block_sums;
 
-    // small voxel lists (the 24^3 stage: <= 13,824 voxels) use one-wave workgroups so that the
-    // launch still covers the 256 CUs
-    const bool small = n < 64 * 1024;
-    const int blk = small ? 64 : 256;
-    const int nblk = (int)ep::ceil_div(n, blk);
-    const size_t lds_count = ((size_t)n_views * batch * 12 + batch + blk / ep::kWave) * 4 + 16;
-    if (small)
-        hipLaunchKernelGGL((bp_count_kernel<64>), dim3(nblk), dim3(64), lds_count, st, p, block_sums);
+    // Tile = voxels handed to one 256-thread workgroup of the gather kernel.  Short lists get
+    // small tiles so that the launch still covers the 256 CUs with several waves each
+    // (13,824 voxels -> 864 workgroups of 16; 110,592 -> 1,728 of 64; 884,736 -> 3,456 of 256).
+    const int vox = n >= 512 * 1024 ? 256 : (n >= 48 * 1024 ? 64 : 16);
+    const int ntile = (int)ep::ceil_div(n, vox);
+    const int nblk_count = (int)ep::ceil_div(n, 256);
+    const size_t lds_count = ((size_t)n_views * batch * 12 + batch + 256 / ep::kWave) * 4 + 16;
+    if (vox == 256)
+        hipLaunchKernelGGL((bp_count_kernel<256>), dim3(nblk_count), dim3(256), lds_count, st, p, block_sums);
+    else if (vox == 64)
+        hipLaunchKernelGGL((bp_count_kernel<64>), dim3(nblk_count), dim3(256), lds_count, st, p, block_sums);
     else
-        hipLaunchKernelGGL((bp_count_kernel<256>), dim3(nblk), dim3(256), lds_count, st, p, block_sums);
+        hipLaunchKernelGGL((bp_count_kernel<16>), dim3(nblk_count), dim3(256), lds_count, st, p, block_sums);
     EP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bp_scan_kernel, dim3(1), dim3(1024), 0, st, block_sums, nblk, n_valid_dev);
+    hipLaunchKernelGGL(bp_scan_kernel, dim3(1), dim3(1024), 0, st, block_sums, ntile, n_valid_dev);
     EP_LAUNCH_CHECK();
 
     const bool prof = g_prof.on && g_prof.start;
     if (prof) EP_HIP_CHECK(hipEventRecord(g_prof.start, st));
     int rc;
-    if (small) {
-        rc = mode == EPRECON_BP_MEAN ? launch_gather<64, EPRECON_BP_MEAN>(p, nblk, st)
-           : mode == EPRECON_BP_MEAN_DEPTH ? launch_gather<64, EPRECON_BP_MEAN_DEPTH>(p, nblk, st)
-                                           : launch_gather<64, EPRECON_BP_VARIANCE>(p, nblk, st);
-    } else {
-        rc = mode == EPRECON_BP_MEAN ? launch_gather<256, EPRECON_BP_MEAN>(p, nblk, st)
-           : mode == EPRECON_BP_MEAN_DEPTH ? launch_gather<256, EPRECON_BP_MEAN_DEPTH>(p, nblk, st)
-                                           : launch_gather<256, EPRECON_BP_VARIANCE>(p, nblk, st);
-    }
+#define EP_MODE_DISPATCH(VOX)                                                                        \
+    rc = mode == EPRECON_BP_MEAN ? launch_gather<VOX, EPRECON_BP_MEAN>(p, ntile, st)                   \
+       : mode == EPRECON_BP_MEAN_DEPTH ? launch_gather<VOX, EPRECON_BP_MEAN_DEPTH>(p, ntile, st)       \
+                                       : launch_gather<VOX, EPRECON_BP_VARIANCE>(p, ntile, st)
+    if (vox == 256) { EP_MODE_DISPATCH(256); }
+    else if (vox == 64) { EP_MODE_DISPATCH(64); }
+    else { EP_MODE_DISPATCH(16); }
+#undef EP_MODE_DISPATCH
     if (rc != EPRECON_OK) return rc;
     if (prof) {
         EP_HIP_CHECK(hipEventRecord(g_prof.stop, st));

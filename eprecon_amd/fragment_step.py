@@ -1,22 +1,29 @@
 """One pass of the per-fragment hot path over one synthetic window, at BASELINE.json's configs.
 
 Cfg2Step = config 2 ("9-frame 640x480 window, 96^3 coarse back_project + occupancy only"):
-the stages NeuConNet.forward runs before the sparse-conv U-Nets (models/neucon_network.py:239-369
-of the reference), on dense voxel grids — the upper-bound bandwidth case of SURVEY.md section 8d:
+what NeuConNet.forward does before the sparse-conv U-Nets (models/neucon_network.py:239-369 of the
+reference), with the back-projections on DENSE voxel grids — the upper-bound bandwidth case of
+SURVEY.md section 8d:
 
-  init   view-variance volume of the fused 32-channel 60x80 maps on the dense 48^3 grid, min_view 2
-         (models/occupancy_initialization.py:79-128)
-  bp24   Back_Project, dense 24^3 (interval 4), C=80 @ 30x40,   min_view 2   (stage 0)
-  bp48   Back_Project, dense 48^3 (interval 2), C=40 @ 60x80,   min_view 0   (stage 1)
-  bp96   Back_Project, dense 96^3 (interval 1), C=24 @ 120x160, min_view 0   (stage 2)
+  init    Occupancy_Initialization.forward on the dense 48^3 grid, min_view 2: 2D fusion convolutions
+          (PyTorch-ROCm) -> view-variance volume -> BN / sparse ELAN / 3 residual SubM blocks /
+          SubM(32->1) / BN                          (models/occupancy_initialization.py:61-182)
+  select  sigmoid > 0.3 -> 2^3 OR-pool -> erode -> dilate x2 -> stage-0 coordinates
+                                                    (models/neucon_network.py:264,298-318)
+  bp24    Back_Project, dense 24^3 (interval 4), C=80 @ 30x40,   min_view 2   (stage 0)
+  bp48    Back_Project, dense 48^3 (interval 2), C=40 @ 60x80,   min_view 0   (stage 1)
+  bp96    Back_Project, dense 96^3 (interval 1), C=24 @ 120x160, min_view 0   (stage 2)
 
-Inputs are device-resident before run() is called; every stage goes through the C ABI.
+Inputs (both backbones' feature pyramids, projection matrices, voxel lists) are device-resident
+before run() is called; weights are seeded random (no checkpoint exists in this environment).
 """
 import torch
 
 from . import back_project as BP
+from . import grid_ops as GO
 from . import synthetic as S
-from .config import CH_INIT_DOWN, N_VIEWS
+from .config import CH_IMG, CH_INIT_DOWN, N_VIEWS
+from .occupancy_initialization import Occupancy_Initialization
 
 LEVELS = [("bp24", 2, 4, 2), ("bp48", 1, 2, 0), ("bp96", 0, 1, 0)]  # name, proj level, interval, min_view
 
@@ -32,16 +39,26 @@ class Cfg2Step:
         self.origin = t(self.window["vol_origin_partial"][None].copy())
         self.voxel_size = self.window["voxel_size"]
         self.krcam = [t(self.window["proj_matrices"][:, l][:, None].copy()) for l in range(3)]
+        # backbone #2 pyramid (surface reconstruction) as [V,B,C,H,W] stacks per level
         self.feats = [t(S.make_features(1000 * seed + 10 + l, N_VIEWS, self.shapes[l])) for l in range(3)]
-        c1, h1, w1 = self.shapes[1]
-        self.feats_init = t(S.make_features(1000 * seed + 20, N_VIEWS, (CH_INIT_DOWN, h1, w1)))
+        # backbone #1 pyramid (initialisation) in the reference's list-of-views form
+        f1 = [t(S.make_features(1000 * seed + 20 + l, N_VIEWS, self.shapes[l])) for l in range(3)]
+        self.features_init = [[f1[l][v] for l in range(3)] for v in range(N_VIEWS)]
         self.coords = {iv: t(S.dense_coords(n_vox, iv)) for iv in (4, 2, 1)}
+        self.shape_init = tuple(n // 2 for n in n_vox)
+        torch.manual_seed(1234)
+        self.init_net = Occupancy_Initialization(CH_IMG, CH_INIT_DOWN, N_VIEWS).to(dev)
+        self.init_net.train()  # the reference tests in train mode (main.py:357)
         self.last = {}
 
+    @torch.no_grad()
     def run(self):
         out = {}
-        out["init"] = BP.view_variance(self.coords[2], self.origin, self.voxel_size, self.feats_init,
-                                       self.krcam[1], 2)
+        init = self.init_net(self.coords[2], self.origin, self.voxel_size, self.features_init,
+                             self.krcam[1], self.shape_init, 1, 2)
+        out["init"] = init
+        if init is not None:
+            out["stage0_coords"], _ = GO.init_select(init[0], init[1], 1, dim=self.shape_init[0] // 2, cell=4)
         for name, lvl, interval, mv in LEVELS:
             out[name] = BP.run(self.coords[interval], self.origin, self.voxel_size, self.feats[lvl],
                                self.krcam[lvl], mv)
@@ -62,7 +79,9 @@ class Cfg2Step:
         return 16 * n + 4 * N_VIEWS * c * h * w + nv * (4 * c + 16)
 
     def describe(self):
-        return {"workload": "cfg2: one 9-view 640x480 window, 96^3 FBV: view-variance volume on dense 48^3 "
-                            "(C=32 @60x80) + Back_Project on dense 24^3/48^3/96^3 (C=80/40/24)",
+        return {"workload": "cfg2: one 9-view 640x480 window, 96^3 FBV: Occupancy_Initialization on the dense "
+                            "48^3 grid (2D fusion convs + variance volume + submanifold stack) + stage-0 "
+                            "selection + Back_Project on dense 24^3/48^3/96^3 (C=80/40/24)",
                 "views": N_VIEWS, "image": "640x480", "n_vox": list(self.window["n_vox"]),
-                "stages": ["init_variance48"] + [l[0] for l in LEVELS], "fragments_per_step_per_gpu": 1}
+                "stages": ["occupancy_init48", "init_select"] + [l[0] for l in LEVELS],
+                "weights": "seeded random", "fragments_per_step_per_gpu": 1}

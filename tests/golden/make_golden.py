@@ -136,7 +136,36 @@ def gen_grid_ops():
     _save("grid_ops", **out)
 
 
-GENERATORS = {"back_project": gen_back_project, "grid_ops": gen_grid_ops}
+def gen_dense_blocks():
+    """the reference's dense PyTorch blocks (models/modules.py:273-399) with seeded weights:
+    state_dict + input seed + output, so that eprecon_amd.modules can be checked key-for-key"""
+    from models.modules import Conv2d_Residual_Block, Fusion_Block, Linear4xTrans, Linear_Residual
+
+    out = {}
+    torch.manual_seed(123)
+    cases = {"fusion8": (Fusion_Block(8), (9, 8, 12, 16)),
+             "res6": (Conv2d_Residual_Block(6, 3), (9, 6, 10, 10)),
+             "l4x_12_1": (Linear4xTrans(12, 1), (50, 12)),
+             "l4x_12_12": (Linear4xTrans(12, 12), (50, 12)),
+             "linres10": (Linear_Residual(10), (40, 10))}
+    for name, (mod, shape) in cases.items():
+        mod.train()
+        with torch.no_grad():
+            for p in mod.parameters():
+                if p.dim() == 1:
+                    p.add_(torch.randn_like(p) * 0.2)
+        x = torch.from_numpy(np.random.default_rng(5).standard_normal(shape).astype(np.float32))
+        sd = {k: v.clone() for k, v in mod.state_dict().items()}  # before BN running-stat updates
+        with torch.no_grad():
+            y = mod(x)
+        for k, v in sd.items():
+            out[f"{name}__sd__{k}"] = v.numpy()
+        out[f"{name}__shape"] = np.array(shape)
+        out[f"{name}__out"] = y.numpy()
+    _save("dense_blocks", **out)
+
+
+GENERATORS = {"back_project": gen_back_project, "grid_ops": gen_grid_ops, "dense_blocks": gen_dense_blocks}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GENERATORS)
