@@ -61,7 +61,13 @@ def cpu_baseline(step, seconds):
     net = copy.deepcopy(step.init_net).cpu()
     sd = {k: v.numpy() for k, v in net.state_dict().items()}
     f_init = [[t.cpu() for t in view] for view in step.features_init]
-    torch.set_num_threads(os.cpu_count() or 1)
+    # one thread budget for all three CPU engines (OpenMP oracle, torch, numpy BLAS): more than
+    # ~64 threads only adds fork/join overhead on these sizes
+    threads = min(64, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    O.set_threads(threads)
+    from threadpoolctl import threadpool_limits
+    blas_limit = threadpool_limits(limits=threads)
 
     def one_step():
         with torch.no_grad():
@@ -76,11 +82,12 @@ def cpu_baseline(step, seconds):
 
     one_step()
     n, t0 = 0, time.perf_counter()
-    while n < 2 or time.perf_counter() - t0 < seconds:
+    while n < 1 or time.perf_counter() - t0 < seconds:
         one_step()
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "fragments/s", "cores": O.num_threads(), "kind": "port",
+    blas_limit.restore_original_limits()
+    return {"value": n / dt, "unit": "fragments/s", "cores": threads, "kind": "port",
             "sample": f"{n} whole steps of the same workload (same window, seed {step.seed}) in {dt:.1f} s",
             "ms_per_step": dt / n * 1e3}
 

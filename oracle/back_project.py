@@ -61,3 +61,7 @@ def num_threads():
     fn = lib().eprecon_oracle_num_threads
     fn.restype = ctypes.c_int
     return int(fn())
+
+
+def set_threads(n):
+    lib().eprecon_oracle_set_threads(ctypes.c_int(int(n)))

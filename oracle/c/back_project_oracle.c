@@ -230,6 +230,15 @@ int64_t eprecon_oracle_back_project(const int32_t *coords, int64_t n, const floa
     return n_valid;
 }
 
+void eprecon_oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int eprecon_oracle_num_threads(void)
 {
 #ifdef _OPENMP
