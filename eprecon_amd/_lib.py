@@ -41,6 +41,13 @@ SIGNATURES = {
     "eprecon_rowwise_layernorm_async": (_i, [_vp, _i64, _i, _i, _vp, _i, _vp, _vp, _f, _i, _i, _vp, _i, _vp]),
     "eprecon_init_select_async": (_i, [_vp, _vp, _i64, _f, _i, _i, _i, _vp, _vp, _vp]),
     "eprecon_upsample_async": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp]),
+    "eprecon_aligned_coords_async": (_i, [_vp, _i64, _vp, _i, _f, _vp, _vp, _vp]),
+    "eprecon_point_quantize_async": (_i, [_vp, _i64, _f, _vp, _vp, _vp]),
+    "eprecon_segment_workspace_bytes": (_sz, [_i64]),
+    "eprecon_segment_lists_async": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "eprecon_segment_mean_async": (_i, [_vp, _i, _vp, _vp, _i64, _i, _vp, _i, _vp]),
+    "eprecon_trilinear_map_async": (_i, [_vp, _c.c_uint32, _vp, _i64, _i, _vp, _vp, _vp]),
+    "eprecon_devoxelize_async": (_i, [_vp, _i, _vp, _vp, _i64, _i, _vp, _i, _i, _vp]),
     "eprecon_profile_enable": (_i, [_i]),
     "eprecon_profile_gather_ms": (_f, []),
     "eprecon_nchw_to_nhwc_async": (_i, [_vp, _vp, _i, _i, _i, _vp]),

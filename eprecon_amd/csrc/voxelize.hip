@@ -1,0 +1,271 @@
+// Point <-> voxel transfers of the point-voxel U-Net (SPVCNN) and the sparse ConvGRU on gfx950.
+//
+// Replaces (reference call sites; kernels are in the un-vendored torchsparse, semantics restated
+// in SURVEY.md appendix A.2 and DESIGN.md):
+//   aligned-camera point coordinates                 models/neucon_network.py:387-398, models/gru_fusion.py:332-337
+//   initial_voxelize  (floor, unique, scatter-mean)   ops/torchsparse_utils.py:15-35
+//   point_to_voxel    (hash query + scatter-mean)     ops/torchsparse_utils.py:40-63
+//   voxel_to_point    (8-corner query, trilinear weights, weighted gather)   ops/torchsparse_utils.py:68-105
+//
+// Scatter-mean is done without floating-point atomics: a CSR list of the points of every voxel is
+// built (integer atomics only, then each short list is sorted by point index), and one thread per
+// (voxel, 4 channels) sums its points in index order -> deterministic, and the same lists serve
+// every later point_to_voxel on that voxel set.  All kernels are bandwidth/latency bound.
+#include "hashgrid.hpp"
+
+namespace {
+using namespace ep;
+
+__device__ __forceinline__ int floor_div_i(int a, int q) { return (a >= 0) ? a / q : -((-a + q - 1) / q); }
+
+// r[0:3] = W[:3,:] . [c * vs + origin, 1] with the k-ordered fma chain of a [N,4]@[4,3] matmul
+__global__ void aligned_coords_kernel(const int4 *coords, int n, const float *origin, float vs,
+                                      const float *w2ac, int batch, float4 *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = coords[i];
+    const int b = min(max(c.x, 0), batch - 1);
+    const float X = __fadd_rn(__fmul_rn((float)c.y, vs), origin[3 * b + 0]);
+    const float Y = __fadd_rn(__fmul_rn((float)c.z, vs), origin[3 * b + 1]);
+    const float Z = __fadd_rn(__fmul_rn((float)c.w, vs), origin[3 * b + 2]);
+    const float *M = w2ac + 16 * b;
+    float r[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        r[j] = __fmaf_rn(1.0f, M[4 * j + 3], __fmaf_rn(Z, M[4 * j + 2], __fmaf_rn(Y, M[4 * j + 1], __fmul_rn(X, M[4 * j]))));
+    out[i] = make_float4(r[0], r[1], r[2], (float)c.x);
+}
+
+// pts f32[N,4] (x,y,z,b) -> scaled f32[N,4] (x/res, y/res, z/res, b) and int32[N,4] (b, floor ...)
+__global__ void point_quantize_kernel(const float4 *pts, int n, float res, float4 *scaled, int4 *vox)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    const float x = __fdiv_rn(p.x, res), y = __fdiv_rn(p.y, res), z = __fdiv_rn(p.z, res);
+    scaled[i] = make_float4(x, y, z, p.w);
+    vox[i] = make_int4((int)p.w, (int)floorf(x), (int)floorf(y), (int)floorf(z));
+}
+
+// ---- CSR point lists per voxel ----
+__global__ void seg_count_kernel(const int32_t *idx, int n, int32_t *counts)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && idx[i] >= 0) atomicAdd(&counts[idx[i]], 1);
+}
+__global__ void seg_fill_kernel(const int32_t *idx, int n, const int32_t *offsets, int32_t *cursor,
+                                int32_t *order)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int v = idx[i];
+    if (v < 0) return;
+    order[offsets[v] + atomicAdd(&cursor[v], 1)] = i;
+}
+__global__ void seg_sort_kernel(const int32_t *offsets, int m, int32_t *order)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= m) return;
+    const int a = offsets[v], b = offsets[v + 1];
+    for (int i = a + 1; i < b; ++i) {  // insertion sort; lists are a handful of points long
+        const int key = order[i];
+        int j = i - 1;
+        while (j >= a && order[j] > key) {
+            order[j + 1] = order[j];
+            --j;
+        }
+        order[j + 1] = key;
+    }
+}
+
+// out[v, c] = mean over the points of voxel v (index order) of feat[p, c]
+__global__ __launch_bounds__(256) void seg_mean_kernel(const float *feat, int ld_f, const int32_t *offsets,
+                                                       const int32_t *order, int m, int C, float *out,
+                                                       int ld_o)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)m * C) return;
+    const int v = (int)(e / C), c = (int)(e - (int64_t)v * C);
+    const int a = offsets[v], b = offsets[v + 1];
+    float s = 0.0f;
+    for (int i = a; i < b; ++i) s += feat[(size_t)order[i] * ld_f + c];
+    out[(size_t)v * ld_o + c] = (b > a) ? __fdiv_rn(s, (float)(b - a)) : 0.0f;
+}
+
+// 8-corner lookup + trilinear weights at tensor stride s:
+//   base = floor(p / s) * s, corner k = base + (bx, by, bz) * s with k = 4 bx + 2 by + bz,
+//   w_k = prod over axes of (bit ? p - pf : pc - p), / s^3 when s != 1, 0 for absent corners,
+//   then w /= (sum w + 1e-8).
+__global__ void trilinear_map_kernel(HashTable t, const float4 *pts, int n, int stride, int32_t *idx,
+                                     float *wts)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    const float s = (float)stride;
+    const float xf = floorf(__fdiv_rn(p.x, s)) * s, yf = floorf(__fdiv_rn(p.y, s)) * s,
+                zf = floorf(__fdiv_rn(p.z, s)) * s;
+    const float xc = xf + s, yc = yf + s, zc = zf + s;
+    const int bx = (int)xf, by = (int)yf, bz = (int)zf, b = (int)p.w;
+    float w[8];
+    int id[8];
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int ox = (k >> 2) & 1, oy = (k >> 1) & 1, oz = k & 1;
+        const int x = bx + ox * stride, y = by + oy * stride, z = bz + oz * stride;
+        id[k] = key_in_range(b, x, y, z) ? hash_lookup(t, pack_key(b, x, y, z)) : -1;
+        float wk = (ox ? (p.x - xf) : (xc - p.x)) * (oy ? (p.y - yf) : (yc - p.y)) * (oz ? (p.z - zf) : (zc - p.z));
+        if (stride != 1) wk = __fdiv_rn(wk, s * s * s);
+        if (id[k] < 0) wk = 0.0f;
+        w[k] = wk;
+        sum += wk;
+    }
+    const float den = sum + 1e-8f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        idx[(size_t)i * 8 + k] = id[k];
+        wts[(size_t)i * 8 + k] = __fdiv_rn(w[k], den);
+    }
+}
+
+// out[i, c] (+)= sum_k w[i,k] * feat[idx[i,k], c]
+__global__ __launch_bounds__(256) void devoxelize_kernel(const float *feat, int ld_f, const int32_t *idx,
+                                                         const float *wts, int n, int C, float *out,
+                                                         int ld_o, int accumulate)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)n * C) return;
+    const int i = (int)(e / C), c = (int)(e - (int64_t)i * C);
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int j = idx[(size_t)i * 8 + k];
+        if (j >= 0) s = fmaf(wts[(size_t)i * 8 + k], feat[(size_t)j * ld_f + c], s);
+    }
+    float *o = out + (size_t)i * ld_o + c;
+    *o = accumulate ? (*o + s) : s;
+}
+
+HashTable make_table(const void *mem, uint32_t cap)
+{
+    HashTable t;
+    t.keys = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(const_cast<void *>(mem)) + 256);
+    t.vals = reinterpret_cast<int32_t *>(t.keys + cap);
+    t.mask = cap - 1;
+    return t;
+}
+
+}  // namespace
+
+extern "C" {
+
+int eprecon_aligned_coords_async(const int32_t *coords, int64_t n, const float *origin, int batch,
+                                 float voxel_size, const float *world_to_aligned_camera, float *out_xyzb,
+                                 void *stream)
+{
+    if (n < 0 || batch <= 0 || !origin || !world_to_aligned_camera || (n > 0 && (!coords || !out_xyzb)))
+        return EPRECON_ERR_ARG;
+    if (n == 0) return EPRECON_OK;
+    hipLaunchKernelGGL(aligned_coords_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, reinterpret_cast<const int4 *>(coords), (int)n, origin,
+                       voxel_size, world_to_aligned_camera, batch, reinterpret_cast<float4 *>(out_xyzb));
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_point_quantize_async(const float *points_xyzb, int64_t n, float resolution, float *scaled_xyzb,
+                                 int32_t *voxel_bxyz, void *stream)
+{
+    if (n < 0 || !(resolution > 0.0f) || (n > 0 && (!points_xyzb || !scaled_xyzb || !voxel_bxyz)))
+        return EPRECON_ERR_ARG;
+    if (n == 0) return EPRECON_OK;
+    hipLaunchKernelGGL(point_quantize_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, reinterpret_cast<const float4 *>(points_xyzb), (int)n, resolution,
+                       reinterpret_cast<float4 *>(scaled_xyzb), reinterpret_cast<int4 *>(voxel_bxyz));
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+size_t eprecon_segment_workspace_bytes(int64_t m)
+{
+    return align_up((size_t)(m > 0 ? m : 1) * 4, 256) * 2 + align_up((size_t)ceil_div(m > 0 ? m : 1, 2048) * 4, 256) + 256;
+}
+
+/* CSR lists: offsets int32[m+1], order int32[n] (first offsets[m] entries used) */
+int eprecon_segment_lists_async(const int32_t *idx, int64_t n, int64_t m, int32_t *offsets, int32_t *order,
+                                void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (n < 0 || m < 0 || !offsets || !workspace || (n > 0 && (!idx || !order))) return EPRECON_ERR_ARG;
+    if (workspace_bytes < eprecon_segment_workspace_bytes(m)) return EPRECON_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (m == 0) {
+        EP_HIP_CHECK(hipMemsetAsync(offsets, 0, sizeof(int32_t), st));
+        return EPRECON_OK;
+    }
+    char *ws = reinterpret_cast<char *>(workspace);
+    const size_t seg = align_up((size_t)m * 4, 256);
+    int32_t *counts = reinterpret_cast<int32_t *>(ws);
+    int32_t *cursor = reinterpret_cast<int32_t *>(ws + seg);
+    int32_t *scratch = reinterpret_cast<int32_t *>(ws + 2 * seg);
+    EP_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * seg, st));
+    const dim3 gn((unsigned)ceil_div(n > 0 ? n : 1, 256)), gm((unsigned)ceil_div(m, 256)), blk(256);
+    if (n > 0) {
+        hipLaunchKernelGGL(seg_count_kernel, gn, blk, 0, st, idx, (int)n, counts);
+        EP_LAUNCH_CHECK();
+    }
+    int rc = ep::exclusive_scan_i32(counts, (int)m, offsets, scratch, offsets + m, st);
+    if (rc != EPRECON_OK) return rc;
+    if (n > 0) {
+        hipLaunchKernelGGL(seg_fill_kernel, gn, blk, 0, st, idx, (int)n, (const int32_t *)offsets, cursor, order);
+        EP_LAUNCH_CHECK();
+    }
+    // offsets[m] (grand total) was written by the scan
+    hipLaunchKernelGGL(seg_sort_kernel, gm, blk, 0, st, (const int32_t *)offsets, (int)m, order);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_segment_mean_async(const float *feat, int ld_feat, const int32_t *offsets, const int32_t *order,
+                               int64_t m, int channels, float *out, int ld_out, void *stream)
+{
+    if (m < 0 || channels <= 0 || !offsets || (m > 0 && (!feat || !order || !out)) || ld_feat < channels ||
+        ld_out < channels)
+        return EPRECON_ERR_ARG;
+    if (m == 0) return EPRECON_OK;
+    hipLaunchKernelGGL(seg_mean_kernel, dim3((unsigned)ceil_div(m * channels, 256)), dim3(256), 0,
+                       (hipStream_t)stream, feat, ld_feat, offsets, order, (int)m, channels, out, ld_out);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_trilinear_map_async(const void *table, uint32_t capacity, const float *points_xyzb, int64_t n,
+                                int stride, int32_t *idx8, float *weight8, void *stream)
+{
+    if (!table || capacity < 1024 || (capacity & (capacity - 1)) || n < 0 || stride < 1 ||
+        (n > 0 && (!points_xyzb || !idx8 || !weight8)))
+        return EPRECON_ERR_ARG;
+    if (n == 0) return EPRECON_OK;
+    hipLaunchKernelGGL(trilinear_map_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, make_table(table, capacity),
+                       reinterpret_cast<const float4 *>(points_xyzb), (int)n, stride, idx8, weight8);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_devoxelize_async(const float *voxel_feat, int ld_feat, const int32_t *idx8, const float *weight8,
+                             int64_t n, int channels, float *out, int ld_out, int accumulate, void *stream)
+{
+    if (n < 0 || channels <= 0 || (n > 0 && (!voxel_feat || !idx8 || !weight8 || !out)) ||
+        ld_feat < channels || ld_out < channels)
+        return EPRECON_ERR_ARG;
+    if (n == 0) return EPRECON_OK;
+    hipLaunchKernelGGL(devoxelize_kernel, dim3((unsigned)ceil_div(n * channels, 256)), dim3(256), 0,
+                       (hipStream_t)stream, voxel_feat, ld_feat, idx8, weight8, (int)n, channels, out, ld_out,
+                       accumulate);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+}  // extern "C"

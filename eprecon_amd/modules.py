@@ -295,3 +295,197 @@ class Panoptic_Feat_Fusion(nn.Module):
         for layer in (self.mask_feat_extraction_0, self.mask_feat_extraction_1, self.mask_feat_extraction_2):
             x = layer.run(x, vset)
         return x
+
+
+# ------------------------------------------------------------------------------------------------
+# torchsparse-style layers: point-voxel U-Net (SPVCNN) and sparse ConvGRU
+# ------------------------------------------------------------------------------------------------
+from .tensor import PointTensor, SparseTensor  # noqa: E402
+from .torchsparse_utils import initial_voxelize, point_to_voxel, voxel_to_point  # noqa: E402
+
+__all__ = ["SPVCNN", "SConv3d", "ConvGRU"]
+
+
+class Conv3d(nn.Module):
+    """spnn.Conv3d(inc, outc, kernel_size, stride, transposed), bias-free.  Parameter `kernel` is
+    [K^3, inc, outc] ([inc, outc] when K = 1) like torchsparse's, default init uniform(+-1/sqrt(fan))
+    with fan = K^3 * (outc if transposed else inc)."""
+
+    def __init__(self, inc, outc, kernel_size=3, stride=1, dilation=1, transposed=False):
+        super().__init__()
+        assert dilation == 1 and (kernel_size, stride) in ((1, 1), (3, 1), (2, 2))
+        self.kernel_size, self.stride, self.transposed = kernel_size, stride, transposed
+        kvol = kernel_size ** 3
+        shape = (inc, outc) if kvol == 1 else (kvol, inc, outc)
+        self.kernel = nn.Parameter(torch.empty(shape))
+        std = 1.0 / math.sqrt((outc if transposed else inc) * kvol)
+        with torch.no_grad():
+            self.kernel.uniform_(-std, std)
+
+    def run(self, feats, nbr, out=None):
+        return SP.sparse_conv(feats, self.kernel, nbr, None, out=out)
+
+
+class BasicConvolutionBlock(nn.Module):
+    """conv -> BN -> ReLU (models/modules.py:15-28)"""
+
+    def __init__(self, inc, outc, ks=3, stride=1, dilation=1):
+        super().__init__()
+        self.net = nn.Sequential(Conv3d(inc, outc, ks, stride, dilation), TrainBatchNorm1d(outc), nn.ReLU(True))
+
+    def run(self, feats, nbr, out=None):
+        y = self.net[0].run(feats, nbr, out=out)
+        return self.net[1].run(y, relu=True, out=y)
+
+
+class BasicDeconvolutionBlock(nn.Module):
+    """transposed conv -> BN -> ReLU (models/modules.py:31-43)"""
+
+    def __init__(self, inc, outc, ks=3, stride=1):
+        super().__init__()
+        self.net = nn.Sequential(Conv3d(inc, outc, ks, stride, transposed=True), TrainBatchNorm1d(outc),
+                                 nn.ReLU(True))
+
+    def run(self, feats, nbr, out=None):
+        y = self.net[0].run(feats, nbr, out=out)
+        return self.net[1].run(y, relu=True, out=y)
+
+
+class ResidualBlock(nn.Module):
+    """ReLU( [conv3-BN-ReLU-conv3-BN](x) + [identity | conv1-BN](x) )  (models/modules.py:46-72)"""
+
+    def __init__(self, inc, outc, ks=3, stride=1, dilation=1):
+        super().__init__()
+        assert stride == 1
+        self.net = nn.Sequential(Conv3d(inc, outc, ks, stride, dilation), TrainBatchNorm1d(outc), nn.ReLU(True),
+                                 Conv3d(outc, outc, ks, 1, dilation), TrainBatchNorm1d(outc))
+        self.downsample = nn.Sequential() if inc == outc else nn.Sequential(
+            Conv3d(inc, outc, 1, 1), TrainBatchNorm1d(outc))
+        self.relu = nn.ReLU(True)
+
+    def run(self, feats, nbr, out=None):
+        y = self.net[0].run(feats, nbr)
+        self.net[1].run(y, relu=True, out=y)
+        y2 = self.net[3].run(y, nbr)
+        if len(self.downsample) == 0:
+            skip = feats
+        else:
+            skip = self.downsample[0].run(feats, None)
+            self.downsample[1].run(skip, out=skip)
+        return self.net[4].run(y2, residual=skip, relu=True, out=out if out is not None else y2)
+
+
+class _PointMLP(nn.Sequential):
+    """nn.Linear -> BatchNorm1d (train) -> ReLU on point features (models/modules.py:125-136)"""
+
+    def __init__(self, inc, outc):
+        super().__init__(nn.Linear(inc, outc), TrainBatchNorm1d(outc), nn.ReLU(True))
+
+    def run(self, feats):
+        lin = self[0]
+        y = SP.sparse_conv(feats, lin.weight.t().contiguous(), None, lin.bias)
+        return self[1].run(y, relu=True, out=y)
+
+
+class SPVCNN(nn.Module):
+    """Point-voxel U-Net (models/modules.py:75-175): stem, two k2s2 down stages with residual blocks,
+    two transposed up stages with skip concatenation, three voxel<->point transfers, two point MLPs.
+    Every sparse op runs in libeprecon_hip.so; the three kernel maps (tensor strides 1, 2, 4) and the
+    two strided maps are built once per forward and shared by all 25 convolutions."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.dropout = kwargs["dropout"]
+        cr = kwargs.get("cr", 1.0)
+        cs = [int(cr * c) for c in (32, 64, 128, 96, 96)]
+        self.cs = cs
+        self.pres, self.vres = kwargs["pres"], kwargs["vres"]
+        self.stem = nn.Sequential(Conv3d(kwargs["in_channels"], cs[0], 3, 1), TrainBatchNorm1d(cs[0]), nn.ReLU(True))
+        self.stage1 = nn.Sequential(BasicConvolutionBlock(cs[0], cs[0], ks=2, stride=2),
+                                    ResidualBlock(cs[0], cs[1]), ResidualBlock(cs[1], cs[1]))
+        self.stage2 = nn.Sequential(BasicConvolutionBlock(cs[1], cs[1], ks=2, stride=2),
+                                    ResidualBlock(cs[1], cs[2]), ResidualBlock(cs[2], cs[2]))
+        self.up1 = nn.ModuleList([BasicDeconvolutionBlock(cs[2], cs[3], ks=2, stride=2),
+                                  nn.Sequential(ResidualBlock(cs[3] + cs[1], cs[3]), ResidualBlock(cs[3], cs[3]))])
+        self.up2 = nn.ModuleList([BasicDeconvolutionBlock(cs[3], cs[4], ks=2, stride=2),
+                                  nn.Sequential(ResidualBlock(cs[4] + cs[0], cs[4]), ResidualBlock(cs[4], cs[4]))])
+        self.point_transforms = nn.ModuleList([_PointMLP(cs[0], cs[2]), _PointMLP(cs[2], cs[4])])
+        assert not self.dropout, "SPARSEREG.DROPOUT is False in the reference configs (config/default.py:69)"
+
+    def forward(self, z):
+        cs = self.cs
+        dev = z.F.device
+        x0 = initial_voxelize(z, self.pres, self.vres)
+        s1 = x0.vset
+        s2, down12, up21 = s1.downsample()
+        s4, down24, up42 = s2.downsample()
+        # concat buffers: the skip branches are written in place (torchsparse.cat for free)
+        cat0 = torch.empty((s1.n, cs[4] + cs[0]), dtype=torch.float32, device=dev)
+        cat1 = torch.empty((s2.n, cs[3] + cs[1]), dtype=torch.float32, device=dev)
+
+        f0 = self.stem[0].run(x0.F, s1.kernel_map(3), out=cat0[:, cs[4]:])
+        self.stem[1].run(f0, relu=True, out=f0)
+        x0 = SparseTensor(f0, s1)
+        z0 = voxel_to_point(x0, z)
+
+        x1 = point_to_voxel(x0, z0)
+        f = self.stage1[0].run(x1.F, down12)
+        f = self.stage1[1].run(f, s2.kernel_map(3))
+        f1 = self.stage1[2].run(f, s2.kernel_map(3), out=cat1[:, cs[3]:])
+        f = self.stage2[0].run(f1, down24)
+        f = self.stage2[1].run(f, s4.kernel_map(3))
+        f2 = self.stage2[2].run(f, s4.kernel_map(3))
+        x2 = SparseTensor(f2, s4)
+
+        z1 = voxel_to_point(x2, z0, out=self.point_transforms[0].run(z0.F), accumulate=True)
+        y3 = point_to_voxel(x2, z1)
+        self.up1[0].run(y3.F, up42, out=cat1[:, :cs[3]])
+        f = self.up1[1][0].run(cat1, s2.kernel_map(3))
+        f = self.up1[1][1].run(f, s2.kernel_map(3))
+        self.up2[0].run(f, up21, out=cat0[:, :cs[4]])
+        f = self.up2[1][0].run(cat0, s1.kernel_map(3))
+        f = self.up2[1][1].run(f, s1.kernel_map(3))
+        y4 = SparseTensor(f, s1)
+        z3 = voxel_to_point(y4, z1, out=self.point_transforms[1].run(z1.F), accumulate=True)
+        return z3.F
+
+
+class SConv3d(nn.Module):
+    """voxelise -> Conv3d(k3) -> devoxelise, plus a point-wise Linear skip (models/modules.py:178-197).
+    Like the reference it voxelises its input in place (z.C is overwritten by initial_voxelize)."""
+
+    def __init__(self, inc, outc, pres, vres, ks=3, stride=1, dilation=1):
+        super().__init__()
+        self.net = Conv3d(inc, outc, ks, stride, dilation)
+        self.point_transforms = nn.Sequential(nn.Linear(inc, outc))
+        self.pres, self.vres = pres, vres
+
+    def forward(self, z):
+        x = initial_voxelize(z, self.pres, self.vres)
+        y = SparseTensor(self.net.run(x.F, x.vset.kernel_map(3)), x.vset)
+        lin = self.point_transforms[0]
+        skip = SP.sparse_conv(z.F, lin.weight.t().contiguous(), None, lin.bias)
+        return voxel_to_point(y, z, out=skip, accumulate=True)
+
+
+class ConvGRU(nn.Module):
+    """Sparse convolutional GRU cell (models/modules.py:200-222):
+    z = sigma(convz([h,x])), r = sigma(convr([h,x])), q = tanh(convq([r*h, x])), h' = (1-z) h + z q."""
+
+    def __init__(self, hidden_dim=128, input_dim=192 + 128, pres=1, vres=1):
+        super().__init__()
+        self.convz = SConv3d(hidden_dim + input_dim, hidden_dim, pres, vres, 3)
+        self.convr = SConv3d(hidden_dim + input_dim, hidden_dim, pres, vres, 3)
+        self.convq = SConv3d(hidden_dim + input_dim, hidden_dim, pres, vres, 3)
+
+    def forward(self, h, x):
+        hx = PointTensor(torch.cat([h.F, x.F], dim=1), h.C)
+        z = torch.sigmoid(self.convz(hx).F)
+        # NOTE: convz's initial_voxelize already replaced hx.C by hx.C / vres, so convr voxelises the
+        # coordinates a second time — this is the reference's behaviour (the in-place `z.C = ...` of
+        # ops/torchsparse_utils.py:33 combined with models/modules.py:216-217) and is reproduced.
+        r = torch.sigmoid(self.convr(hx).F)
+        x.F = torch.cat([r * h.F, x.F], dim=1)
+        q = torch.tanh(self.convq(x).F)
+        h.F = (1 - z) * h.F + z * q
+        return h.F

@@ -216,6 +216,38 @@ int eprecon_init_select_async(const float *logit, const int32_t *coords, int64_t
 int eprecon_upsample_async(const float *feat, int ld_feat, const int32_t *coords, int64_t n, int channels,
                            int interval, float *up_feat, int32_t *up_coords, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Point <-> voxel transfers  (K8, K9) and aligned-camera coordinates (a7)
+ *
+ * Replaces  r_coords = W2AC[:3] . [c * vs + origin, 1]   models/neucon_network.py:387-398,
+ *                                                         models/gru_fusion.py:332-337
+ *           initial_voxelize / point_to_voxel / voxel_to_point   ops/torchsparse_utils.py:15-105
+ *           (torchsparse F.spcount, F.spvoxelize, F.calc_ti_weights, F.spdevoxelize)
+ * Points are f32[n,4] rows (x, y, z, batch) like torchsparse's PointTensor.C.
+ * ------------------------------------------------------------------------------------------ */
+int eprecon_aligned_coords_async(const int32_t *coords, int64_t n, const float *origin, int batch,
+                                 float voxel_size, const float *world_to_aligned_camera, float *out_xyzb,
+                                 void *stream);
+/* scaled = (x/res, y/res, z/res, b) (IEEE division); voxel = (b, floor x', floor y', floor z') */
+int eprecon_point_quantize_async(const float *points_xyzb, int64_t n, float resolution, float *scaled_xyzb,
+                                 int32_t *voxel_bxyz, void *stream);
+/* CSR lists of the points of each voxel: idx int32[n] in [-1, m) -> offsets int32[m+1],
+ * order int32[n] (points of voxel v = order[offsets[v] : offsets[v+1]], ascending point index) */
+size_t eprecon_segment_workspace_bytes(int64_t m);
+int eprecon_segment_lists_async(const int32_t *idx, int64_t n, int64_t m, int32_t *offsets, int32_t *order,
+                                void *workspace, size_t workspace_bytes, void *stream);
+/* out[v] = mean of feat[p] over the points p of voxel v (0 for empty voxels) — scatter-mean
+ * without float atomics */
+int eprecon_segment_mean_async(const float *feat, int ld_feat, const int32_t *offsets, const int32_t *order,
+                               int64_t m, int channels, float *out, int ld_out, void *stream);
+/* 8-corner indices int32[n,8] and renormalised trilinear weights f32[n,8] of points (in voxel
+ * units) against the voxel set the table was built on, at tensor stride `stride` */
+int eprecon_trilinear_map_async(const void *table, uint32_t capacity, const float *points_xyzb, int64_t n,
+                                int stride, int32_t *idx8, float *weight8, void *stream);
+/* out[i] (+)= sum_k weight8[i,k] * voxel_feat[idx8[i,k]] */
+int eprecon_devoxelize_async(const float *voxel_feat, int ld_feat, const int32_t *idx8, const float *weight8,
+                             int64_t n, int channels, float *out, int ld_out, int accumulate, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -247,3 +247,22 @@ int eprecon_oracle_num_threads(void)
     return 1;
 #endif
 }
+
+/* r = W2AC[:3,:] . [c * vs + origin, 1]  (models/neucon_network.py:387-398): the reference computes
+ * a [N,4] @ [4,3] matmul; like the projection above it is restated as the k-ordered fma chain.
+ * out f32[n,4] = (x, y, z, batch) — torchsparse PointTensor order. */
+void eprecon_oracle_aligned_coords(const int32_t *coords, int64_t n, const float *origin, int B,
+                                   float voxel_size, const float *w2ac, float *out)
+{
+    (void)B;
+    for (int64_t i = 0; i < n; ++i) {
+        int b = coords[4 * i];
+        float X = (float)coords[4 * i + 1] * voxel_size + origin[3 * b + 0];
+        float Y = (float)coords[4 * i + 2] * voxel_size + origin[3 * b + 1];
+        float Z = (float)coords[4 * i + 3] * voxel_size + origin[3 * b + 2];
+        const float *M = w2ac + 16 * b;
+        for (int j = 0; j < 3; ++j)
+            out[4 * i + j] = fmaf(1.0f, M[4 * j + 3], fmaf(Z, M[4 * j + 2], fmaf(Y, M[4 * j + 1], X * M[4 * j])));
+        out[4 * i + 3] = (float)b;
+    }
+}

@@ -1,0 +1,120 @@
+"""GPU parity of the point-voxel path: aligned-camera coordinates, voxelise / devoxelise, SPVCNN and
+the sparse ConvGRU, against the numpy oracle (restated torchsparse semantics: parity unpinned).
+Integer results (voxel coords, point->voxel ids, corner indices) bit-exact; features within 1e-3."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from eprecon_amd import synthetic as S  # noqa: E402
+from oracle import pointvoxel as PV  # noqa: E402
+from oracle import sparse as OS  # noqa: E402
+from oracle import spvcnn as ON  # noqa: E402
+
+TOL = 1e-3
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def shell_coords(seed, interval, n_target, batch=1):
+    """voxels near the analytic surface of the synthetic scene, raster order, (b,x,y,z) finest units"""
+    window = S.make_window(seed=seed)
+    lvl = {4: 2, 2: 1, 1: 0}[interval]
+    tsdf = S.analytic_tsdf(window, lvl)
+    xyz = np.argwhere(np.abs(tsdf) < 0.9) * interval
+    rng = np.random.default_rng(seed)
+    if len(xyz) > n_target:
+        xyz = xyz[np.sort(rng.choice(len(xyz), n_target, replace=False))]
+    rows = [np.concatenate([np.full((len(xyz), 1), b), xyz], 1) for b in range(batch)]
+    return window, np.concatenate(rows).astype(np.int32)
+
+
+def test_aligned_coords_bit_exact():
+    from eprecon_amd.torchsparse_utils import aligned_camera_coords
+    window, coords = shell_coords(1, 2, 30000, batch=2)
+    origin = np.stack([window["vol_origin_partial"], window["vol_origin_partial"] + 0.08]).astype(np.float32)
+    w2ac = np.stack([window["world_to_aligned_camera"]] * 2)
+    got = aligned_camera_coords(dev(coords), dev(origin), 0.04, dev(w2ac)).cpu().numpy()
+    assert np.array_equal(got, PV.aligned_coords(coords, origin, 0.04, w2ac))
+
+
+@pytest.mark.parametrize("interval,vres", [(4, 0.16), (1, 0.04)])
+def test_voxelize_devoxelize(interval, vres):
+    from eprecon_amd.tensor import PointTensor
+    from eprecon_amd.torchsparse_utils import initial_voxelize, point_to_voxel, voxel_to_point
+    window, coords = shell_coords(2, interval, 20000)
+    pts = PV.aligned_coords(coords, window["vol_origin_partial"][None], 0.04, window["world_to_aligned_camera"][None])
+    rng = np.random.default_rng(0)
+    feat = rng.standard_normal((len(pts), 12)).astype(np.float32)
+    z = PointTensor(dev(feat), dev(pts))
+    x = initial_voxelize(z, 1, vres)
+    zo = PV.Points(feat, pts)
+    c0, f0, inv = PV.initial_voxelize(zo, 1, vres)
+    assert np.array_equal(x.C.cpu().numpy(), c0)
+    assert np.array_equal(z.additional_features["idx_query"][1].cpu().numpy(), inv)
+    assert np.array_equal(z.C.cpu().numpy(), zo.C) and np.array_equal(z.vox.cpu().numpy(), zo.vox)
+    assert np.abs(x.F.cpu().numpy() - f0).max() < 1e-5
+    assert len(c0) < len(pts)  # the rotated frame merges some voxels
+    for stride, vset in ((1, x.vset), (2, x.vset.downsample()[0])):
+        vc = vset.coords.cpu().numpy()
+        idx, w = PV.trilinear(vc, stride, zo.C)
+        from eprecon_amd.tensor import SparseTensor
+        vf = rng.standard_normal((len(vc), 12)).astype(np.float32)
+        zp = voxel_to_point(SparseTensor(dev(vf), vset), z)
+        assert np.array_equal(z.idx_query[stride].cpu().numpy(), idx)
+        assert np.abs(z.weights[stride].cpu().numpy() - w).max() < 1e-6
+        assert np.abs(zp.F.cpu().numpy() - PV.devoxelize(vf, idx, w)).max() < 1e-4
+        back = point_to_voxel(SparseTensor(dev(vf), vset), z)
+        assert np.abs(back.F.cpu().numpy() - PV.point_to_voxel(vc, stride, zo, feat)).max() < 1e-5
+
+
+def _sd(module):
+    return {k: v.detach().cpu().numpy() for k, v in module.state_dict().items()}
+
+
+@pytest.mark.parametrize("stage,cin,n", [(0, 80, 6000), (1, 138, 12000), (2, 74, 20000)])
+def test_spvcnn_matches_oracle(stage, cin, n):
+    from eprecon_amd.modules import SPVCNN
+    from eprecon_amd.tensor import PointTensor
+    interval, vres, cr = 2 ** (2 - stage), 0.04 * 2 ** (2 - stage), 1 / 2 ** stage
+    window, coords = shell_coords(3 + stage, interval, n)
+    pts = PV.aligned_coords(coords, window["vol_origin_partial"][None], 0.04, window["world_to_aligned_camera"][None])
+    rng = np.random.default_rng(stage)
+    feat = rng.standard_normal((len(pts), cin)).astype(np.float32)
+    torch.manual_seed(stage)
+    net = SPVCNN(num_classes=1, in_channels=cin, pres=1, cr=cr, vres=vres, dropout=False).cuda()
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+        out = net(PointTensor(dev(feat), dev(pts))).cpu().numpy()
+    ref = ON.spvcnn_forward(_sd(net), feat, pts, 1, vres)
+    assert out.shape == ref.shape == (len(pts), int(96 * cr))
+    err = np.abs(out - ref).max()
+    assert err < TOL, err
+
+
+@pytest.mark.parametrize("ch,scale", [(96, 0), (24, 2)])
+def test_convgru_matches_oracle(ch, scale):
+    from eprecon_amd.modules import ConvGRU
+    from eprecon_amd.tensor import PointTensor
+    interval, vres = 2 ** (2 - scale), 0.04 * 2 ** (2 - scale)
+    window, coords = shell_coords(7 + scale, interval, 8000)
+    pts = PV.aligned_coords(coords, window["vol_origin_partial"][None], 0.04, window["world_to_aligned_camera"][None])
+    pts[:, 3] = 0
+    rng = np.random.default_rng(ch)
+    h = rng.standard_normal((len(pts), ch)).astype(np.float32)
+    x = rng.standard_normal((len(pts), ch)).astype(np.float32)
+    torch.manual_seed(ch)
+    gru = ConvGRU(hidden_dim=ch, input_dim=ch, pres=1, vres=vres).cuda()
+    with torch.no_grad():
+        coords_t = dev(pts)
+        out = gru(PointTensor(dev(h), coords_t), PointTensor(dev(x), coords_t)).cpu().numpy()
+    ref = ON.convgru(_sd(gru), "", h, x, pts, 1, vres) if False else None
+    sd = {"g." + k: v for k, v in _sd(gru).items()}
+    ref = ON.convgru(sd, "g", h, x, pts, 1, vres)
+    err = np.abs(out - ref).max()
+    assert err < TOL, err
