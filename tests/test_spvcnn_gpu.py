@@ -113,7 +113,6 @@ def test_convgru_matches_oracle(ch, scale):
     with torch.no_grad():
         coords_t = dev(pts)
         out = gru(PointTensor(dev(h), coords_t), PointTensor(dev(x), coords_t)).cpu().numpy()
-    ref = ON.convgru(_sd(gru), "", h, x, pts, 1, vres) if False else None
     sd = {"g." + k: v for k, v in _sd(gru).items()}
     ref = ON.convgru(sd, "g", h, x, pts, 1, vres)
     err = np.abs(out - ref).max()
