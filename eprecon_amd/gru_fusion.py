@@ -1,0 +1,190 @@
+"""GRU fusion of fragment features into a persistent sparse global map — mirror of
+models/gru_fusion.py (GRUFusion, feature mode :259-394) on libeprecon_hip.so.
+
+Per scale the module keeps the global map as {C int32[M,3] (scene-grid voxel units of that
+scale), F f32[M,C]} plus its ground-truth TSDF twin (the reference's test path reads the targets,
+models/neucon_network.py:488).  One fragment step (per batch element):
+
+  relative origin -> union of current voxels and the in-FBV part of the map, raster order
+  (csrc/fbv_union.hip: index volumes + scan, no dense feature volume) -> gather current / global
+  rows -> aligned-camera coordinates -> ConvGRU on the voxel channels and ConvGRU on the image
+  channels (eprecon_amd.modules.ConvGRU) -> write the fused rows back into the map.
+
+`direct_substitute=True` (scene-level TSDF substitution, a15) is not part of this module yet.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .modules import ConvGRU
+from .tensor import PointTensor
+from .torchsparse_utils import aligned_camera_coords
+
+
+def fbv_union(cur_coords, cur_feat, glob_coords, glob_feat, dim, interval, rel):
+    """-> (updated int32[N',3], src_cur int32[N'], src_glob int32[N'], glob_valid bool[M]).
+    One host sync for N' (the reference's torch.nonzero syncs at the same point)."""
+    lib = _lib.load()
+    dev = cur_feat.device
+    n_cur, c = cur_feat.shape
+    n_glob = glob_coords.shape[0]
+    cells = dim ** 3
+    cap = min(cells, n_cur + n_glob)
+    updated = torch.empty((cap, 3), dtype=torch.int32, device=dev)
+    src_cur = torch.empty(cap, dtype=torch.int32, device=dev)
+    src_glob = torch.empty(cap, dtype=torch.int32, device=dev)
+    glob_valid = torch.zeros(max(n_glob, 1), dtype=torch.uint8, device=dev)
+    n_out = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = _lib.workspace(lib.eprecon_fbv_union_workspace_bytes(dim), dev)
+    import ctypes
+    rel_host = (ctypes.c_int32 * 3)(*[int(v) for v in rel])
+    gf = glob_feat if n_glob > 0 else None
+    _lib.check(lib.eprecon_fbv_union_async(
+        _lib.ptr(cur_coords), _lib.ptr(cur_feat), n_cur, cur_feat.stride(0) if n_cur else c,
+        _lib.ptr(glob_coords) if n_glob else None, _lib.ptr(gf), n_glob, glob_feat.stride(0) if n_glob else c,
+        c, dim, interval, ctypes.cast(rel_host, ctypes.c_void_p), _lib.ptr(updated), _lib.ptr(src_cur),
+        _lib.ptr(src_glob), _lib.ptr(glob_valid), _lib.ptr(n_out), _lib.ptr(ws), ws.numel(),
+        _lib.current_stream()), "eprecon_fbv_union_async")
+    n = int(n_out.item())
+    return updated[:n], src_cur[:n], src_glob[:n], glob_valid[:n_glob].bool()
+
+
+def gather_rows(feat, src, channels, fill=0.0):
+    lib = _lib.load()
+    n = src.shape[0]
+    out = torch.empty((n, channels), dtype=torch.float32, device=src.device)
+    has = feat is not None and feat.shape[0] > 0
+    if not has:
+        return out.fill_(fill)
+    _lib.check(lib.eprecon_gather_rows_async(_lib.ptr(feat), feat.stride(0), _lib.ptr(src), n, channels,
+                                             float(fill), _lib.ptr(out), out.stride(0), _lib.current_stream()),
+               "eprecon_gather_rows_async")
+    return out
+
+
+class _Map:
+    def __init__(self, channels, device):
+        self.C = torch.zeros((0, 3), dtype=torch.int32, device=device)
+        self.F = torch.zeros((0, channels), dtype=torch.float32, device=device)
+
+
+class GRUFusion(nn.Module):
+    def __init__(self, cfg, ch_in=None, direct_substitute=False, trianing=True, ch_voxel=None):
+        super().__init__()
+        if direct_substitute:
+            raise NotImplementedError("direct_substitute (scene TSDF substitution) is not built yet")
+        self.cfg = cfg
+        self.direct_substitude = False
+        self.ch_in = list(ch_in)
+        self.feat_init = 0
+        self.ch_voxel = list(ch_voxel)
+        self.ch_img = [a - b for a, b in zip(ch_in, ch_voxel)]
+        self.n_scales = len(cfg.THRESHOLDS) - 1
+        self.scene_name = [None, None, None]
+        self.global_origin = [None, None, None]
+        self.global_volume = [None, None, None]
+        self.target_tsdf_volume = [None, None, None]
+        self.coords_dtype = torch.int32  # the reference returns int64; int32 is this package's coordinate type
+        self.fusion_nets_voxel = nn.ModuleList()
+        self.fusion_nets_img = nn.ModuleList()
+        for i, ch in enumerate(self.ch_voxel):
+            self.fusion_nets_voxel.append(ConvGRU(hidden_dim=ch, input_dim=ch, pres=1,
+                                                  vres=cfg.VOXEL_SIZE * 2 ** (self.n_scales - i)))
+        for i, ch in enumerate(self.ch_img):
+            self.fusion_nets_img.append(ConvGRU(hidden_dim=ch, input_dim=ch, pres=1,
+                                                vres=cfg.VOXEL_SIZE * 2 ** (self.n_scales - i)))
+        self._identity_fusion = False  # tests: skip the ConvGRUs (pins the bookkeeping alone)
+
+    def reset(self, i, device=None):
+        device = device or torch.device("cuda")
+        self.global_volume[i] = _Map(self.ch_in[i], device)
+        self.target_tsdf_volume[i] = _Map(1, device)
+
+    # ---- ground-truth twin (1 channel, dense [D,D,D] is 3.5 MB at most): plain tensor indexing ----
+    def _fuse_targets(self, scale, occ_target, tsdf_volume, rel_t, dim):
+        tmap = self.target_tsdf_volume[scale]
+        local = tmap.C - rel_t
+        tvalid = ((local >= 0) & (local < dim)).all(dim=1)
+        vol = torch.ones((dim, dim, dim), dtype=torch.float32, device=tsdf_volume.device)
+        sel = local[tvalid].long()
+        vol[sel[:, 0], sel[:, 1], sel[:, 2]] = tmap.F[tvalid, 0]
+        vol[occ_target] = tsdf_volume[occ_target]  # the current fragment's ground truth wins
+        return vol, tvalid
+
+    def _update_targets(self, scale, vol, tvalid, rel_t):
+        tmap = self.target_tsdf_volume[scale]
+        keep = vol.abs() < 1
+        tmap.F = torch.cat([tmap.F[~tvalid], vol[keep].unsqueeze(-1)])
+        tmap.C = torch.cat([tmap.C[~tvalid], torch.nonzero(keep).to(torch.int32) + rel_t])
+
+    def forward(self, coords, values_in, inputs, scale=2, outputs=None, save_mesh=False, panoptic_infos=None):
+        """coords int[N,4] (b,x,y,z) finest units, values_in f32[N,C] ->
+        (coords[N',4] raster order per batch element, fused f32[N',C], tsdf_target f32[N',1] | None,
+        occ_target bool[N',1] | None)   (models/gru_fusion.py:259-394)"""
+        cfg = self.cfg
+        batch_size = len(inputs["fragment"])
+        interval = 2 ** (cfg.N_LAYER - scale - 1)
+        dim = cfg.N_VOX[0] // interval
+        voxel_size = cfg.VOXEL_SIZE * interval
+        dev = values_in.device
+        coords = coords if coords.dtype == torch.int32 else coords.to(torch.int32)
+        chv = self.ch_voxel[scale]
+        out_c, out_v, out_t, out_o = [], [], [], []
+        batch_col = coords[:, 0]
+        for i in range(batch_size):
+            scene = inputs["scene"][i]
+            if self.scene_name[scale] is None or scene != self.scene_name[scale]:
+                self.scene_name[scale] = scene
+                self.reset(scale, dev)
+                self.global_origin[scale] = inputs["vol_origin"][i].detach().float().cpu()
+            origin = inputs["vol_origin_partial"][i]
+            # (origin - global_origin) / voxel_size in fp32, truncated toward zero (:292-293)
+            rel = ((origin.detach().float().cpu() - self.global_origin[scale]) / voxel_size).long()
+            rel_t = rel.to(device=dev, dtype=torch.int32)
+            rows = torch.nonzero(batch_col == i).squeeze(1)
+            if rows.numel() == 0:
+                continue
+            lo, hi = int(rows[0]), int(rows[-1]) + 1  # rows of one batch element are contiguous
+            cur_c, cur_f = coords[lo:hi].contiguous(), values_in[lo:hi].contiguous()
+            gmap = self.global_volume[scale]
+            updated, src_cur, src_glob, gvalid = fbv_union(cur_c, cur_f, gmap.C, gmap.F, dim, interval, rel.tolist())
+            values = gather_rows(cur_f, src_cur, self.ch_in[scale])
+            global_values = gather_rows(gmap.F, src_glob, self.ch_in[scale])
+
+            tsdf_target = occ_target = vol = tvalid = None
+            if "occ_list" in inputs:
+                lvl = cfg.N_LAYER - scale - 1
+                occ_gt = inputs["occ_list"][lvl][i]
+                vol, tvalid = self._fuse_targets(scale, occ_gt, inputs["tsdf_list"][lvl][i], rel_t, dim)
+                u = updated.long()
+                tsdf_target = vol[u[:, 0], u[:, 1], u[:, 2]].unsqueeze(-1)
+                occ_target = tsdf_target.abs() < 1
+
+            if not self._identity_fusion:
+                pts_c = torch.cat([torch.zeros_like(updated[:, :1]), updated * interval], dim=1)
+                r_coords = aligned_camera_coords(pts_c, origin.reshape(1, 3), cfg.VOXEL_SIZE,
+                                                 inputs["world_to_aligned_camera"][i].reshape(1, 4, 4))
+                hv = PointTensor(global_values[:, :chv].contiguous(), r_coords)
+                xv = PointTensor(values[:, :chv].contiguous(), r_coords)
+                fused_v = self.fusion_nets_voxel[scale](hv, xv)
+                hi_ = PointTensor(global_values[:, chv:].contiguous(), r_coords)
+                xi_ = PointTensor(values[:, chv:].contiguous(), r_coords)
+                fused_i = self.fusion_nets_img[scale](hi_, xi_)
+                values = torch.cat([fused_v, fused_i], dim=-1)
+
+            # update_map (:195-215)
+            gmap.F = torch.cat([gmap.F[~gvalid], values.detach()])
+            gmap.C = torch.cat([gmap.C[~gvalid], updated + rel_t])
+            if vol is not None:
+                self._update_targets(scale, vol, tvalid, rel_t)
+
+            out_c.append(torch.cat([torch.full_like(updated[:, :1], i), updated * interval], dim=1))
+            out_v.append(values)
+            if tsdf_target is not None:
+                out_t.append(tsdf_target)
+                out_o.append(occ_target)
+        if not out_c:
+            return None, None, None, None
+        coords_all = torch.cat(out_c).to(self.coords_dtype)
+        return (coords_all, torch.cat(out_v), torch.cat(out_t) if out_t else None,
+                torch.cat(out_o) if out_o else None)

@@ -165,7 +165,85 @@ def gen_dense_blocks():
     _save("dense_blocks", **out)
 
 
-GENERATORS = {"back_project": gen_back_project, "grid_ops": gen_grid_ops, "dense_blocks": gen_dense_blocks}
+def gru_sequence_inputs(scale, n_frag=3, seed=77, n_vox=24, ch=(6, 4, 3)):
+    """seeded fragment sequence for the GRU-fusion bookkeeping fixtures (shared with the tests)"""
+    rng = np.random.default_rng(seed + scale)
+    interval = 2 ** (2 - scale)
+    d = n_vox // interval
+    c = ch[scale]
+    shifts = [(0, 0, 0), (8, 0, 0), (8, 8, -8), (0, 16, 0)][:n_frag]
+    frags = []
+    for k, sh in enumerate(shifts):
+        occ = rng.random((d, d, d)) < 0.25
+        xyz = np.argwhere(occ)
+        rng.shuffle(xyz)
+        xyz = xyz[: max(8, len(xyz) // 2)]
+        vals = rng.standard_normal((len(xyz), c)).astype(np.float32)
+        vals[rng.random(len(xyz)) < 0.15] = 0.0          # all-zero rows: the "inactive voxel" quirk
+        tsdf = np.clip(rng.standard_normal((d, d, d)) * 0.8, -1, 1).astype(np.float32)
+        occ_gt = (np.abs(tsdf) < 0.999) & (rng.random((d, d, d)) < 0.5)
+        frags.append({"coords": np.concatenate([np.zeros((len(xyz), 1), np.int64), xyz * interval], 1).astype(np.int32),
+                      "values": vals, "tsdf": tsdf, "occ": occ_gt,
+                      "origin_partial": (np.array([-0.96, 0.2, -0.4]) + np.array(sh) * 0.04).astype(np.float32)})
+    return frags, np.array([-0.96, 0.2, -0.4], np.float32), interval, d, c
+
+
+def gen_gru_fusion():
+    """GRUFusion.convert2dense / update_map (models/gru_fusion.py:67-114,195-215) driven through the
+    glue of GRUFusion.forward (:275-331,366-386) with the ConvGRU replaced by identity (the ConvGRU
+    needs torchsparse).  Three overlapping fragments per scale."""
+    from types import SimpleNamespace
+    import models.gru_fusion as G
+
+    class PT:
+        def __init__(self, F, C):
+            self.F, self.C = F, C
+
+        def cuda(self):
+            return self
+
+        def detach(self):
+            return self
+
+    G.PointTensor = PT
+    cfg = SimpleNamespace(THRESHOLDS=[0, 0, 0], VOXEL_SIZE=0.04, N_VOX=[24, 24, 24], N_LAYER=3,
+                          FUSION=SimpleNamespace(FULL=True))
+    out = {}
+    for scale in (1, 2):
+        fus = G.GRUFusion(cfg, ch_in=[6, 4, 3], ch_voxel=[4, 3, 2])
+        frags, global_origin, interval, d, c = gru_sequence_inputs(scale)
+        fus.reset(scale)
+        fus.global_origin[scale] = torch.from_numpy(global_origin)
+        for k, fr in enumerate(frags):
+            voxel_size = cfg.VOXEL_SIZE * interval
+            rel = ((torch.from_numpy(fr["origin_partial"]) - fus.global_origin[scale]) / voxel_size).long()
+            coords = torch.from_numpy(fr["coords"])
+            coords_b = torch.div(coords[:, 1:].long(), interval, rounding_mode="floor")
+            values = torch.from_numpy(fr["values"])
+            occ_t = torch.from_numpy(fr["occ"])
+            tsdf_t = torch.from_numpy(fr["tsdf"])[occ_t]
+            coords_t = torch.nonzero(occ_t)
+            upd, cur_vol, glob_vol, tgt_vol, valid, valid_t = fus.convert2dense(coords_b, values, coords_t, tsdf_t, rel, scale)
+            vals = cur_vol[upd[:, 0], upd[:, 1], upd[:, 2]]
+            gvals = glob_vol[upd[:, 0], upd[:, 1], upd[:, 2]]
+            tsdf_u = tgt_vol[upd[:, 0], upd[:, 1], upd[:, 2]]
+            fus.update_map(vals, upd, tgt_vol, valid, valid_t, rel, scale)   # identity fusion
+            key = f"s{scale}_f{k}_"
+            out[key + "updated"] = upd.numpy().astype(np.int32)
+            out[key + "values"] = vals.numpy()
+            out[key + "global_values"] = gvals.numpy()
+            out[key + "valid"] = valid.numpy()
+            out[key + "tsdf_target"] = tsdf_u.numpy()
+            out[key + "rel"] = rel.numpy()
+            out[key + "map_C"] = fus.global_volume[scale].C.numpy().astype(np.int32)
+            out[key + "map_F"] = fus.global_volume[scale].F.numpy()
+            out[key + "tgt_C"] = fus.target_tsdf_volume[scale].C.numpy().astype(np.int32)
+            out[key + "tgt_F"] = fus.target_tsdf_volume[scale].F.numpy()
+    _save("gru_fusion", **out)
+
+
+GENERATORS = {"back_project": gen_back_project, "grid_ops": gen_grid_ops, "dense_blocks": gen_dense_blocks,
+              "gru_fusion": gen_gru_fusion}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GENERATORS)
