@@ -1,0 +1,227 @@
+"""Coarse-to-fine 3D path — mirror of NeuConNet (models/neucon_network.py:25-624 of the reference),
+inference path only (losses, target visualisation and the Hungarian criterion are out of scope,
+SURVEY.md section 2a rows 6/11).
+
+forward(features, features_backbone2d_occ_pano, inputs, outputs, ...) keeps the reference's
+signature and early-return conventions:
+  A  occupancy initialisation on the dense 48^3 grid -> stage-0 voxels           (:239-342)
+  B  for i in 0..2: [upsample] -> Back_Project -> SPVCNN -> GRU fusion -> TSDF / occupancy heads
+     -> sparsify                                                                  (:348-511)
+  C  panoptic: ancestor pruning of the coarser levels, 48-channel projections, mask features
+     (three submanifold residual blocks); the mask-transformer decoder is plugged in through
+     `self.panoptic` when available                                               (:516-587)
+Every sparse / gather / scatter step runs in libeprecon_hip.so; the dense heads are PyTorch-ROCm.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import grid_ops as GO
+from . import sparse as SP
+from .back_project import Back_Project
+from .config import (CH_IMG, CH_INIT_DOWN, CH_VOXEL, EXCEED_NUM, INIT_MIN_VIEW, INIT_OCC_THRESHOLD, INIT_STAGE,
+                     N_VIEWS, PANOPTIC_CH, PANOPTIC_SHAPE, STAGE_MIN_OCC)
+from .generate_grids import dense_coords
+from .gru_fusion import GRUFusion
+from .modules import Linear4xTrans, Panoptic_Feat_Fusion, SPVCNN
+from .occupancy_initialization import Occupancy_Initialization
+from .tensor import PointTensor
+from .torchsparse_utils import aligned_camera_coords
+
+
+def _warn(msg):
+    print(f"[eprecon_amd] warning: {msg}")
+
+
+class NeuConNet(nn.Module):
+    def __init__(self, cfg, panoptic_decoder=None):
+        super().__init__()
+        self.cfg = cfg
+        self.n_scales = len(cfg.THRESHOLDS) - 1
+        alpha = int(cfg.ALPHA)
+        # channels entering each SPVCNN: image features (+ previous stage's features, tsdf, occ)
+        ch_in = [80 * alpha, 96 + 40 * alpha + 2, 48 + 24 * alpha + 2, 24 + 24 + 2]
+        channels = list(CH_VOXEL)
+        gru_channels = [a + b for a, b in zip(channels, CH_IMG)]
+        self.channels = channels
+        self.back_projection = nn.ModuleList()
+        if cfg.FUSION.FUSION_ON:
+            self.gru_fusion = GRUFusion(cfg, ch_in=gru_channels, ch_voxel=channels)
+        self.sp_convs = nn.ModuleList()
+        self.tsdf_preds = nn.ModuleList()
+        self.occ_preds = nn.ModuleList()
+        self.panoptic_preds = nn.ModuleList()
+        self.initialization = Occupancy_Initialization(CH_IMG, CH_INIT_DOWN, N_VIEWS)
+        self.panoptic_feat_fusion = Panoptic_Feat_Fusion(channels[2], PANOPTIC_CH, CH_IMG)
+        self.panoptic = panoptic_decoder  # MultiScaleMaskedTransformerDecoder equivalent (PyTorch), optional
+        for i in range(len(cfg.THRESHOLDS)):
+            self.back_projection.append(Back_Project(CH_IMG[i]))
+            self.sp_convs.append(SPVCNN(num_classes=1, in_channels=ch_in[i], pres=1, cr=1 / 2 ** i,
+                                        vres=cfg.VOXEL_SIZE * 2 ** (self.n_scales - i),
+                                        dropout=cfg.SPARSEREG_DROPOUT))
+            self.tsdf_preds.append(Linear4xTrans(channels[i], 1))
+            self.occ_preds.append(Linear4xTrans(channels[i], 1))
+            self.panoptic_preds.append(Linear4xTrans(gru_channels[i], PANOPTIC_CH))
+        self.trace = None  # set to a list to record per-stage intermediates (parity tests)
+
+    # models/neucon_network.py:193-214
+    def upsample(self, pre_feat, pre_coords, interval, num=8):
+        assert num == 8
+        return GO.upsample(pre_feat, pre_coords, interval)
+
+    def _record(self, **kw):
+        if self.trace is not None:
+            self.trace.append(kw)
+
+    def forward(self, features, features_backbone2d_occ_pano, inputs, outputs, only_train_init=False,
+                only_train_occ=False, init_overlap_count=0):
+        cfg = self.cfg
+        bs = features[0][0].shape[0]
+        dev = features[0][0].device
+        loss_dict = {}
+        zero = torch.zeros((), device=dev)
+
+        # ---- A. occupancy initialisation ("depth prior") -------------------------------------
+        interval = 2 ** (self.n_scales - INIT_STAGE)
+        scale = self.n_scales - INIT_STAGE
+        up_coords, shape_init = dense_coords(cfg.N_VOX, interval, bs, device=dev)
+        KRcam = inputs["proj_matrices"][:, :, scale].permute(1, 0, 2, 3).contiguous()
+        init_output = self.initialization(up_coords, inputs["vol_origin_partial"], cfg.VOXEL_SIZE, features,
+                                          KRcam, shape_init, INIT_STAGE, INIT_MIN_VIEW)
+        if init_output is None:
+            loss_dict["occupancy_initialization_loss"] = zero
+            _warn("no valid points in initialization")
+            outputs["init_overlap_count"] = init_overlap_count
+            return outputs, loss_dict
+        occ_init, coord_init, count_init = init_output
+        coord_init_selected, _ = GO.init_select(occ_init, coord_init, bs, dim=shape_init[0] // 2 ** INIT_STAGE,
+                                                cell=2 ** self.n_scales, threshold=INIT_OCC_THRESHOLD)
+        self._record(stage="init", occ_init=occ_init, coord_init=coord_init, selected=coord_init_selected)
+
+        # ---- B. coarse-to-fine surface reconstruction ----------------------------------------
+        pre_feat = pre_coords = None
+        panoptic_voxel_feats, panoptic_coords = [], []
+        occ_target = occupancy = None
+        for i in range(cfg.N_LAYER):
+            interval = 2 ** (self.n_scales - i)
+            scale = self.n_scales - i
+            if i == 0:
+                up_coords = coord_init_selected.contiguous()
+                min_view_number = 2
+                up_feat = None
+            else:
+                up_feat, up_coords = self.upsample(pre_feat, pre_coords, interval)
+                min_view_number = 0
+            feats = torch.stack([f[scale] for f in features_backbone2d_occ_pano])
+            KRcam = inputs["proj_matrices"][:, :, scale].permute(1, 0, 2, 3).contiguous()
+            project_output = self.back_projection[i](up_coords, inputs["vol_origin_partial"], cfg.VOXEL_SIZE,
+                                                     feats, KRcam, min_view_number)
+            if project_output is None:
+                loss_dict[f"tsdf_occ_loss_{i}"] = zero
+                _warn(f"no valid points in back_projection: scale {i}")
+                return outputs, loss_dict
+            volume, up_coords, _, _, count = project_output
+            if i != 0:
+                keep = count >= min_view_number
+                feat = torch.cat([volume, up_feat if bool(keep.all()) else up_feat[keep]], dim=1)
+            else:
+                feat = volume
+
+            r_coords = aligned_camera_coords(up_coords, inputs["vol_origin_partial"], cfg.VOXEL_SIZE,
+                                             inputs["world_to_aligned_camera"])
+            sp_in = feat
+            feat = self.sp_convs[i](PointTensor(feat.contiguous(), r_coords))
+            feat_all = torch.cat([feat, volume], dim=-1)
+            self._record(stage=f"spvcnn{i}", coords=up_coords, feat_in=sp_in, r_coords=r_coords, feat_out=feat,
+                         volume=volume)
+
+            tsdf_target = None
+            if cfg.FUSION.FUSION_ON:
+                voxel_dim = feat.shape[-1]
+                fuse_in = (up_coords, feat_all)
+                up_coords, feat_all, tsdf_target, occ_target = self.gru_fusion(up_coords, feat_all, inputs, i)
+                feat = feat_all[:, :voxel_dim]
+                self._record(stage=f"gru{i}", coords_in=fuse_in[0], feat_in=fuse_in[1], coords=up_coords,
+                             feat_all=feat_all, tsdf_target=tsdf_target)
+            grid_mask = torch.ones_like(feat[:, 0]).bool()
+
+            tsdf = self.tsdf_preds[i](feat)
+            occ = self.occ_preds[i](feat)
+            loss_dict[f"tsdf_occ_loss_{i}"] = zero  # losses are out of scope (inference path)
+
+            # ---- sparsify for the next stage (:454-507) ----
+            occupancy = occ.squeeze(1) > cfg.THRESHOLDS[i]
+            occupancy[grid_mask == False] = False  # noqa: E712
+            for b in range(bs):
+                batch_ind = torch.nonzero(up_coords[:, 0] == b).squeeze(1)
+                num_batch = int(occupancy[batch_ind].sum().item())
+                if num_batch < STAGE_MIN_OCC:
+                    _warn(f"no valid points: scale {i}")
+                    return outputs, loss_dict
+                cap = cfg.TRAIN_NUM_SAMPLE[i]
+                # self.training is True on the reference's test path (main.py:357): the caps are live
+                if self.training and num_batch > cap * EXCEED_NUM:
+                    _warn(f"exceed too many points: scale {i} num_batch {num_batch}")
+                    return outputs, loss_dict
+                elif self.training and num_batch > cap:
+                    _warn(f"choice too many points: scale {i} num_batch {num_batch}")
+                    choice = np.random.choice(num_batch, num_batch - cap, replace=False)
+                    ind = torch.nonzero(occupancy[batch_ind]).squeeze(1)
+                    drop = batch_ind[ind[torch.from_numpy(choice).to(ind.device)]]
+                    occupancy[drop] = False
+            if occ_target is not None:
+                for b in range(bs):
+                    batch_ind = torch.nonzero(up_coords[:, 0] == b).squeeze(1)
+                    if occ_target[batch_ind][occupancy[batch_ind]].sum() == 0:
+                        _warn(f"occ_target is 0: scale {i}")
+                        return outputs, loss_dict
+            pre_coords = up_coords[occupancy]
+            pre_tsdf, pre_occ = tsdf[occupancy], occ[occupancy]
+            panoptic_voxel_feats.append(feat_all[occupancy])
+            panoptic_coords.append(pre_coords)
+            pre_feat = torch.cat([feat[occupancy], pre_tsdf, pre_occ], dim=1)
+            self._record(stage=f"heads{i}", feat=feat, tsdf=tsdf, occ=occ, occupancy=occupancy)
+            if i == cfg.N_LAYER - 1:
+                outputs["coords"] = pre_coords
+                outputs["tsdf"] = pre_tsdf
+
+        # ---- C. panoptic segmentation inputs (:516-561) ----------------------------------------
+        keep1, keep0 = self.prune_to_ancestors(panoptic_coords)
+        panoptic_coords[1], panoptic_voxel_feats[1] = panoptic_coords[1][keep1], panoptic_voxel_feats[1][keep1]
+        panoptic_coords[0], panoptic_voxel_feats[0] = panoptic_coords[0][keep0], panoptic_voxel_feats[0][keep0]
+        for p in range(3):
+            panoptic_voxel_feats[p] = self.panoptic_preds[p](panoptic_voxel_feats[p])
+        outputs["panoptic_levels"] = []
+        panoptic_predictions = []
+        for b in range(bs):
+            rows = [torch.nonzero(panoptic_coords[p][:, 0] == b).squeeze(1) for p in range(3)]
+            c2 = panoptic_coords[2][rows[2]]
+            mask_features = self.panoptic_feat_fusion.generate_mask_features(
+                panoptic_feats=panoptic_voxel_feats[2][rows[2]], coords_b=torch.zeros_like(c2[:, 0]),
+                coords_xyz=c2[:, 1:], batch_size=1, spitial_shape=PANOPTIC_SHAPE)
+            feats_b = [panoptic_voxel_feats[p][rows[p]].unsqueeze(0).permute(0, 2, 1) for p in range(3)]
+            coords_b = [panoptic_coords[p][rows[p]][..., 1:].unsqueeze(0) for p in range(3)]
+            outputs["panoptic_levels"].append({"features": feats_b, "coords": coords_b,
+                                               "mask_features": mask_features})
+            if self.panoptic is not None:
+                out_b = self.panoptic(panoptic_features=feats_b, panoptic_coords=coords_b,
+                                      mask_features=mask_features.unsqueeze(0).permute(0, 2, 1),
+                                      spitial_shape=PANOPTIC_SHAPE)
+                panoptic_predictions.append(out_b)
+        if self.panoptic is not None:
+            outputs["panoptic_out"] = panoptic_predictions
+        self._record(stage="panoptic", coords=panoptic_coords, feats=panoptic_voxel_feats)
+        return outputs, loss_dict
+
+    @staticmethod
+    def prune_to_ancestors(panoptic_coords):
+        """models/neucon_network.py:516-542 (K17): keep the level-1 voxels that are floor(c/2)*2 of some
+        level-2 voxel, and the level-0 voxels that are floor(c/4)*4 of one — a hash-grid membership
+        query instead of the reference's [N1, M, 4] broadcast compare."""
+        fine = panoptic_coords[2].contiguous()
+        dev = fine.device
+        g2 = SP.HashGrid(fine.shape[0], dev).build(fine, quantum=2)
+        keep1 = g2.query(panoptic_coords[1].contiguous()) >= 0
+        g4 = SP.HashGrid(fine.shape[0], dev).build(fine, quantum=4)
+        keep0 = g4.query(panoptic_coords[0].contiguous()) >= 0
+        return keep1, keep0

@@ -155,3 +155,47 @@ def analytic_tsdf(window, level, trunc_voxels=3.0):
         d = np.minimum(d, np.sqrt((x - cx) ** 2 + (y - cy) ** 2 + (z - cz) ** 2) - r)
     t = np.clip(d / (trunc_voxels * vs), -1.0, 1.0)
     return t.astype(F32)
+
+
+def make_model_inputs(windows, feat_seed=0, scene="scene0000_00", fragment_ids=None):
+    """numpy inputs of NeuConNet.forward for a batch of windows (list of make_window dicts):
+    both backbones' pyramids as the reference's list over views of [f4, f8, f16] (each [B,C,H,W]),
+    and the `inputs` dict of datasets/transforms.py (proj_matrices [B,V,3,4,4], origins,
+    world_to_aligned_camera, analytic tsdf_list / occ_list at 0.04 / 0.08 / 0.16 m)."""
+    b = len(windows)
+    h, w = windows[0]["image_hw"]
+    shapes = pyramid_shapes(h, w)
+    rng = np.random.default_rng(feat_seed)
+
+    def pyramid():
+        return [[rng.standard_normal((b,) + shapes[lvl], dtype=F32) for lvl in range(3)] for _ in range(N_VIEWS)]
+
+    features, features_occ_pano = pyramid(), pyramid()
+    tsdf_list, occ_list = [], []
+    for lvl in range(3):
+        t = np.stack([analytic_tsdf(wd, lvl) for wd in windows])
+        tsdf_list.append(t)
+        occ_list.append(np.abs(t) < 0.999)
+    inputs = {
+        "proj_matrices": np.stack([wd["proj_matrices"] for wd in windows]),
+        "vol_origin": np.stack([wd["vol_origin"] for wd in windows]),
+        "vol_origin_partial": np.stack([wd["vol_origin_partial"] for wd in windows]),
+        "world_to_aligned_camera": np.stack([wd["world_to_aligned_camera"] for wd in windows]),
+        "scene": [scene] * b,
+        "fragment": fragment_ids or [f"{scene}_{k}" for k in range(b)],
+        "tsdf_list": tsdf_list,
+        "occ_list": occ_list,
+    }
+    return features, features_occ_pano, inputs
+
+
+def to_device(obj, device):
+    """numpy arrays -> torch tensors on `device`, recursively (lists / dicts; strings pass through)"""
+    import torch
+    if isinstance(obj, np.ndarray):
+        return torch.from_numpy(np.ascontiguousarray(obj)).to(device)
+    if isinstance(obj, dict):
+        return {k: to_device(v, device) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [to_device(v, device) for v in obj]
+    return obj

@@ -1,0 +1,101 @@
+"""GPU: NeuConNet.forward end to end on a synthetic window (random seeded weights), checked stage
+by stage against the CPU oracle on the inputs the HIP path actually fed to each stage.
+Indices bit-exact (given the stage's inputs); features / TSDF within 1e-3."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from eprecon_amd import synthetic as S  # noqa: E402
+from eprecon_amd.config import ModelCfg  # noqa: E402
+from oracle import back_project as OB  # noqa: E402
+from oracle import grid_ops as OG  # noqa: E402
+from oracle import neucon as ONC  # noqa: E402
+
+TOL = 1e-3
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def run():
+    from eprecon_amd.neucon_network import NeuConNet
+    cfg = ModelCfg()
+    torch.manual_seed(7)
+    np.random.seed(7)
+    net = NeuConNet(cfg).cuda()
+    net.train()
+    window = S.make_window(seed=0, width=320, height=240)
+    feats, feats2, inputs = S.make_model_inputs([window], feat_seed=3)
+    dev = torch.device("cuda")
+    net.trace = []
+    with torch.no_grad():
+        outputs, loss = net(S.to_device(feats, dev), S.to_device(feats2, dev), S.to_device(inputs, dev), {})
+    sd = {k: npy(v) for k, v in net.state_dict().items()}
+    return {"net": net, "outputs": outputs, "trace": {t["stage"]: t for t in net.trace}, "sd": sd,
+            "window": window, "feats2": feats2, "inputs": inputs}
+
+
+def test_reaches_the_finest_level(run):
+    out = run["outputs"]
+    assert "coords" in out and "tsdf" in out, "early return: " + str(list(run["trace"]))
+    assert out["coords"].shape[0] > 500 and out["coords"].shape[1] == 4
+    assert out["tsdf"].shape == (out["coords"].shape[0], 1)
+    assert len(out["panoptic_levels"]) == 1
+    assert out["panoptic_levels"][0]["mask_features"].shape == (out["coords"].shape[0], 48)
+
+
+def test_stage0_selection_and_backprojection(run):
+    tr, inputs = run["trace"], run["inputs"]
+    sel = npy(tr["init"]["selected"])
+    assert np.array_equal(sel, OG.init_select(npy(tr["init"]["occ_init"]), npy(tr["init"]["coord_init"]), 1))
+    # stage-0 Back_Project on those voxels
+    f = np.stack([v[2] for v in run["feats2"]])
+    kr = np.ascontiguousarray(inputs["proj_matrices"][:, :, 2].transpose(1, 0, 2, 3))
+    ref = OB.back_project(sel, inputs["vol_origin_partial"], 0.04, f, kr, 2)
+    assert np.array_equal(npy(tr["spvcnn0"]["coords"]), ref["coords"])
+    assert np.abs(npy(tr["spvcnn0"]["volume"]) - ref["feats"]).max() < TOL
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_spvcnn_and_heads_per_stage(run, i):
+    tr, inputs, sd = run["trace"], run["inputs"], run["sd"]
+    t = tr[f"spvcnn{i}"]
+    r, feat = ONC.spvcnn_stage(sd, i, npy(t["coords"]), npy(t["feat_in"]), inputs["vol_origin_partial"],
+                               inputs["world_to_aligned_camera"])
+    assert np.array_equal(npy(t["r_coords"]), r)
+    assert np.abs(npy(t["feat_out"]) - feat).max() < TOL
+    h = tr[f"heads{i}"]
+    tsdf, occ, occupancy = ONC.heads_stage(sd, i, npy(h["feat"]))
+    assert np.abs(npy(h["tsdf"]) - tsdf).max() < TOL and np.abs(npy(h["occ"]) - occ).max() < TOL
+    flips = npy(h["occupancy"]) != occupancy
+    assert np.all(np.abs(occ[flips, 0]) < 1e-4)  # only logits at the threshold may differ
+
+
+@pytest.mark.parametrize("i", [1, 2])
+def test_upsample_chain(run, i):
+    """stage i's input voxels are the 8 children of the voxels stage i-1 kept, in order"""
+    tr = run["trace"]
+    prev, cur = tr[f"heads{i - 1}"], tr[f"spvcnn{i}"]
+    kept = npy(tr[f"gru{i - 1}"]["coords"])[npy(prev["occupancy"])]
+    feat = np.concatenate([npy(prev["feat"]), npy(prev["tsdf"]), npy(prev["occ"])], 1)[npy(prev["occupancy"])]
+    uf, uc = OG.upsample(feat, kept, 2 ** (2 - i))
+    assert np.array_equal(npy(cur["coords"]), uc)        # min_view 0: nothing is filtered
+    c_img = npy(cur["volume"]).shape[1]
+    assert np.array_equal(npy(cur["feat_in"])[:, c_img:], uf)
+
+
+def test_panoptic_pruning(run):
+    tr = run["trace"]
+    kept = [npy(tr[f"gru{i}"]["coords"])[npy(tr[f"heads{i}"]["occupancy"])] for i in range(3)]
+    keep1, keep0 = ONC.prune_to_ancestors(kept[0], kept[1], kept[2])
+    pc = tr["panoptic"]["coords"]
+    assert np.array_equal(npy(pc[1]), kept[1][keep1]) and np.array_equal(npy(pc[0]), kept[0][keep0])
+    assert np.array_equal(npy(pc[2]), kept[2])
+    # brute force on a sample: the definition of the reference's broadcast compare
+    anc = {tuple(r) for r in np.concatenate([kept[2][:, :1], kept[2][:, 1:] // 2 * 2], 1)}
+    for j in np.random.default_rng(0).choice(len(kept[1]), 300):
+        assert (tuple(kept[1][j]) in anc) == bool(keep1[j])
