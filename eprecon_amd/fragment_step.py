@@ -85,3 +85,26 @@ class Cfg2Step:
                 "views": N_VIEWS, "image": "640x480", "n_vox": list(self.window["n_vox"]),
                 "stages": ["occupancy_init48", "init_select"] + [l[0] for l in LEVELS],
                 "weights": "seeded random", "fragments_per_step_per_gpu": 1}
+
+
+@torch.no_grad()
+def calibrate_occupancy_heads(net, features, features_occ_pano, inputs, keep_fraction=(0.5, 0.45, 0.4)):
+    """Random-init occupancy heads may classify (almost) every voxel the same way, which trips the
+    reference's `< 500 occupied voxels` early return.  There is no trained checkpoint in this
+    environment, so benchmarks and end-to-end tests shift each stage's occupancy bias
+    (occ_preds[i].linear3.bias) such that `keep_fraction[i]` of the stage's voxels pass `occ > 0`
+    on the given window — the sparsity regime "random ~50 %" of SURVEY.md section 8d.
+    Runs the forward once per stage; the GRU state is reset afterwards."""
+    old_trace = net.trace
+    for i in range(net.cfg.N_LAYER):
+        net.trace = []
+        net.gru_fusion.scene_name = [None, None, None]
+        net(features, features_occ_pano, inputs, {})
+        rec = {t["stage"]: t for t in net.trace}.get(f"heads{i}")
+        if rec is None:
+            raise RuntimeError(f"stage {i} was not reached while calibrating")
+        occ = rec["occ"][:, 0]
+        q = torch.quantile(occ.float(), 1.0 - keep_fraction[i])
+        net.occ_preds[i].linear3.bias.sub_(q)
+    net.gru_fusion.scene_name = [None, None, None]
+    net.trace = old_trace

@@ -152,6 +152,9 @@ class NeuConNet(nn.Module):
             # ---- sparsify for the next stage (:454-507) ----
             occupancy = occ.squeeze(1) > cfg.THRESHOLDS[i]
             occupancy[grid_mask == False] = False  # noqa: E712
+            # recorded before the guards so that an early return still leaves the logits visible;
+            # `occupancy` is the same tensor object the sub-sampling below edits in place
+            self._record(stage=f"heads{i}", feat=feat, tsdf=tsdf, occ=occ, occupancy=occupancy)
             for b in range(bs):
                 batch_ind = torch.nonzero(up_coords[:, 0] == b).squeeze(1)
                 num_batch = int(occupancy[batch_ind].sum().item())
@@ -180,7 +183,6 @@ class NeuConNet(nn.Module):
             panoptic_voxel_feats.append(feat_all[occupancy])
             panoptic_coords.append(pre_coords)
             pre_feat = torch.cat([feat[occupancy], pre_tsdf, pre_occ], dim=1)
-            self._record(stage=f"heads{i}", feat=feat, tsdf=tsdf, occ=occ, occupancy=occupancy)
             if i == cfg.N_LAYER - 1:
                 outputs["coords"] = pre_coords
                 outputs["tsdf"] = pre_tsdf

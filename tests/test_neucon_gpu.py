@@ -31,9 +31,12 @@ def run():
     window = S.make_window(seed=0, width=320, height=240)
     feats, feats2, inputs = S.make_model_inputs([window], feat_seed=3)
     dev = torch.device("cuda")
+    from eprecon_amd.fragment_step import calibrate_occupancy_heads
+    d_feats, d_feats2, d_inputs = S.to_device(feats, dev), S.to_device(feats2, dev), S.to_device(inputs, dev)
+    calibrate_occupancy_heads(net, d_feats, d_feats2, d_inputs)
     net.trace = []
     with torch.no_grad():
-        outputs, loss = net(S.to_device(feats, dev), S.to_device(feats2, dev), S.to_device(inputs, dev), {})
+        outputs, loss = net(d_feats, d_feats2, d_inputs, {})
     sd = {k: npy(v) for k, v in net.state_dict().items()}
     return {"net": net, "outputs": outputs, "trace": {t["stage"]: t for t in net.trace}, "sd": sd,
             "window": window, "feats2": feats2, "inputs": inputs}
