@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="approximate CPU time to spend on the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4"],
+                    help="cfg2 (default) = BASELINE.json configs[1], the headline metric; cfg4 = the full "
+                         "coarse-to-fine forward over 4 sequential fragments (extra measurement, no roofline)")
     return ap.parse_args()
 
 
@@ -92,6 +95,36 @@ def cpu_baseline(step, seconds):
             "ms_per_step": dt / n * 1e3}
 
 
+def bench_cfg4(args, step, world, rank, dist):
+    """extra measurement: whole-forward fragments/s (not the headline line; no roofline / cpu legs)"""
+    import torch
+    for _ in range(args.warmup):
+        step.run()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step.run()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        n_out = int(step.last["coords"].shape[0]) if step.last and "coords" in step.last else 0
+        print(json.dumps({"metric": "fragments_per_sec", "value": world * args.steps / elapsed,
+                          "unit": "fragments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": step.describe(),
+                          "last_fragment_voxels": n_out}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     import torch
@@ -114,6 +147,9 @@ def main():
 
     lib = _lib.load()
     # every rank owns a different fragment window (seed = rank)
+    if args.workload == "cfg4":
+        from eprecon_amd.fragment_step import Cfg4Step
+        return bench_cfg4(args, Cfg4Step(seed=rank, device=torch.device("cuda", local_rank)), world, rank, dist)
     step = Cfg2Step(seed=rank, device=torch.device("cuda", local_rank))
 
     def barrier():

@@ -108,3 +108,46 @@ def calibrate_occupancy_heads(net, features, features_occ_pano, inputs, keep_fra
         net.occ_preds[i].linear3.bias.sub_(q)
     net.gru_fusion.scene_name = [None, None, None]
     net.trace = old_trace
+
+
+class Cfg4Step:
+    """Configs 3/4: the whole NeuConNet.forward (occupancy initialisation, three coarse-to-fine levels
+    of Back_Project + SPVCNN + GRU fusion + heads, panoptic inputs) over `n_fragments` consecutive
+    windows of one scene (camera arc advanced 0.32 m per fragment, persistent GRU map).
+    One step = one fragment; the scene restarts every `n_fragments` steps."""
+
+    def __init__(self, seed=0, device=None, height=480, width=640, n_fragments=4):
+        from .config import ModelCfg
+        from .neucon_network import NeuConNet
+        self.device = device or torch.device("cuda")
+        self.seed, self.n_fragments = seed, n_fragments
+        torch.manual_seed(4321)
+        self.net = NeuConNet(ModelCfg()).to(self.device)
+        self.net.train()
+        self.frags = []
+        for k in range(n_fragments):
+            # make_window keeps vol_origin fixed and snaps vol_origin_partial to the advanced arc,
+            # so the fragments of one scene share the global origin and overlap by 2/3
+            w = S.make_window(seed=seed * 100 + k, width=width, height=height, advance=0.32 * k)
+            f1, f2, inp = S.make_model_inputs([w], feat_seed=seed * 100 + k, scene=f"scene{seed:04d}")
+            self.frags.append((S.to_device(f1, self.device), S.to_device(f2, self.device),
+                               S.to_device(inp, self.device)))
+        calibrate_occupancy_heads(self.net, *self.frags[0])
+        self.k = 0
+        self.last = None
+
+    @torch.no_grad()
+    def run(self):
+        if self.k == 0:
+            self.net.gru_fusion.scene_name = [None, None, None]
+        f1, f2, inp = self.frags[self.k]
+        self.last, _ = self.net(f1, f2, inp, {})
+        self.k = (self.k + 1) % self.n_fragments
+        return self.last
+
+    def describe(self):
+        return {"workload": f"cfg4: NeuConNet.forward over {self.n_fragments} sequential 9-view 640x480 fragments "
+                            "(occupancy init, 3 x [Back_Project, SPVCNN, GRU fusion, heads], panoptic inputs), "
+                            "96^3 FBV, persistent sparse global map",
+                "views": N_VIEWS, "image": "640x480", "weights": "seeded random, occupancy heads calibrated to "
+                "50/45/40 % keep", "fragments_per_step_per_gpu": 1}
