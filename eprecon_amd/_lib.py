@@ -49,9 +49,10 @@ SIGNATURES = {
     "eprecon_trilinear_map_async": (_i, [_vp, _c.c_uint32, _vp, _i64, _i, _vp, _vp, _vp]),
     "eprecon_devoxelize_async": (_i, [_vp, _i, _vp, _vp, _i64, _i, _vp, _i, _i, _vp]),
     "eprecon_fbv_union_workspace_bytes": (_sz, [_i]),
-    "eprecon_fbv_union_async": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
+    "eprecon_fbv_union_async": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _vp, _sz, _vp]),
     "eprecon_gather_rows_async": (_i, [_vp, _i, _vp, _i64, _i, _f, _vp, _i, _vp]),
+    "eprecon_nearest_voxel_async": (_i, [_vp, _c.c_uint32, _vp, _i64, _vp, _i64, _i, _vp, _vp]),
     "eprecon_profile_enable": (_i, [_i]),
     "eprecon_profile_gather_ms": (_f, []),
     "eprecon_nchw_to_nhwc_async": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -21,17 +21,18 @@ struct UnionParams {
     const int32_t *glob_coords;  // [n_glob,3] scene-grid units of this scale
     const float *glob_feat;      // [n_glob, ld_glob]
     int n_glob, ld_glob;
-    int C, D, interval;
+    int C, D, interval, mode;
     int rel[3];
     int32_t *idx_cur, *idx_glob, *flag;  // [D^3]
     uint8_t *glob_valid;                 // [n_glob] inside the FBV
 };
 
-// 8 lanes per row: is any of the C channels != 0 ?
-__device__ __forceinline__ bool row_nonzero(const float *row, int C, int g)
+// 8 lanes per row: does the row activate its voxel?  mode 0 (features): any channel != 0;
+// mode 1 (TSDF, direct substitution): any |channel| < 1   (models/gru_fusion.py:94-96)
+__device__ __forceinline__ bool row_nonzero(const float *row, int C, int g, int mode)
 {
     bool nz = false;
-    for (int c = g; c < C; c += 8) nz |= (row[c] != 0.0f);
+    for (int c = g; c < C; c += 8) nz |= mode ? (fabsf(row[c]) < 1.0f) : (row[c] != 0.0f);
     unsigned long long m = __ballot(nz);
     const int lane = threadIdx.x & 63;
     return ((m >> (lane & ~7)) & 0xFFull) != 0ull;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void union_scatter_kernel(UnionParams p)
         }
     }
     const bool inside = live && x >= 0 && x < p.D && y >= 0 && y < p.D && z >= 0 && z < p.D;
-    const bool nz = row_nonzero(row, (live ? p.C : 0), g);
+    const bool nz = row_nonzero(row, (live ? p.C : 0), g, p.mode);
     if (live && g == 0) {
         if (!is_cur) p.glob_valid[j] = inside ? 1 : 0;
         if (inside) {
@@ -115,8 +116,8 @@ size_t eprecon_fbv_union_workspace_bytes(int dim)
  */
 int eprecon_fbv_union_async(const int32_t *cur_coords, const float *cur_feat, int64_t n_cur, int ld_cur,
                             const int32_t *glob_coords, const float *glob_feat, int64_t n_glob, int ld_glob,
-                            int channels, int dim, int interval, const int32_t *relative_origin_host,
-                            int32_t *updated, int32_t *src_cur, int32_t *src_glob, uint8_t *glob_valid,
+                            int channels, int dim, int interval, int activity_mode,
+                            const int32_t *relative_origin_host, int32_t *updated, int32_t *src_cur, int32_t *src_glob, uint8_t *glob_valid,
                             int32_t *n_out_dev, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (n_cur < 0 || n_glob < 0 || channels <= 0 || dim <= 0 || dim > 512 || interval <= 0 ||
@@ -131,7 +132,7 @@ int eprecon_fbv_union_async(const int32_t *cur_coords, const float *cur_feat, in
     UnionParams p;
     p.cur_coords = cur_coords; p.cur_feat = cur_feat; p.n_cur = (int)n_cur; p.ld_cur = ld_cur;
     p.glob_coords = glob_coords; p.glob_feat = glob_feat; p.n_glob = (int)n_glob; p.ld_glob = ld_glob;
-    p.C = channels; p.D = dim; p.interval = interval;
+    p.C = channels; p.D = dim; p.interval = interval; p.mode = activity_mode;
     p.rel[0] = relative_origin_host[0]; p.rel[1] = relative_origin_host[1]; p.rel[2] = relative_origin_host[2];
     p.idx_cur = reinterpret_cast<int32_t *>(ws);
     p.idx_glob = reinterpret_cast<int32_t *>(ws + seg);

@@ -10,7 +10,8 @@ models/neucon_network.py:488).  One fragment step (per batch element):
   rows -> aligned-camera coordinates -> ConvGRU on the voxel channels and ConvGRU on the image
   channels (eprecon_amd.modules.ConvGRU) -> write the fused rows back into the map.
 
-`direct_substitute=True` (scene-level TSDF substitution, a15) is not part of this module yet.
+`direct_substitute=True` (scene-level TSDF substitution + instance association, a15) dispatches to
+eprecon_amd/scene_fusion.py.
 """
 import torch
 import torch.nn as nn
@@ -21,7 +22,7 @@ from .tensor import PointTensor
 from .torchsparse_utils import aligned_camera_coords
 
 
-def fbv_union(cur_coords, cur_feat, glob_coords, glob_feat, dim, interval, rel):
+def fbv_union(cur_coords, cur_feat, glob_coords, glob_feat, dim, interval, rel, mode=0):
     """-> (updated int32[N',3], src_cur int32[N'], src_glob int32[N'], glob_valid bool[M]).
     One host sync for N' (the reference's torch.nonzero syncs at the same point)."""
     lib = _lib.load()
@@ -42,7 +43,7 @@ def fbv_union(cur_coords, cur_feat, glob_coords, glob_feat, dim, interval, rel):
     _lib.check(lib.eprecon_fbv_union_async(
         _lib.ptr(cur_coords), _lib.ptr(cur_feat), n_cur, cur_feat.stride(0) if n_cur else c,
         _lib.ptr(glob_coords) if n_glob else None, _lib.ptr(gf), n_glob, glob_feat.stride(0) if n_glob else c,
-        c, dim, interval, ctypes.cast(rel_host, ctypes.c_void_p), _lib.ptr(updated), _lib.ptr(src_cur),
+        c, dim, interval, int(mode), ctypes.cast(rel_host, ctypes.c_void_p), _lib.ptr(updated), _lib.ptr(src_cur),
         _lib.ptr(src_glob), _lib.ptr(glob_valid), _lib.ptr(n_out), _lib.ptr(ws), ws.numel(),
         _lib.current_stream()), "eprecon_fbv_union_async")
     n = int(n_out.item())
@@ -71,10 +72,13 @@ class _Map:
 class GRUFusion(nn.Module):
     def __init__(self, cfg, ch_in=None, direct_substitute=False, trianing=True, ch_voxel=None):
         super().__init__()
-        if direct_substitute:
-            raise NotImplementedError("direct_substitute (scene TSDF substitution) is not built yet")
         self.cfg = cfg
-        self.direct_substitude = False
+        self.direct_substitude = bool(direct_substitute)
+        if direct_substitute:
+            # scene-level TSDF substitution + instance association (NeuralRecon.fuse_to_global)
+            from .scene_fusion import SceneFusion
+            self._scene = SceneFusion(cfg)
+            return
         self.ch_in = list(ch_in)
         self.feat_init = 0
         self.ch_voxel = list(ch_voxel)
@@ -121,6 +125,8 @@ class GRUFusion(nn.Module):
         """coords int[N,4] (b,x,y,z) finest units, values_in f32[N,C] ->
         (coords[N',4] raster order per batch element, fused f32[N',C], tsdf_target f32[N',1] | None,
         occ_target bool[N',1] | None)   (models/gru_fusion.py:259-394)"""
+        if self.direct_substitude:
+            return self._scene.forward(coords, values_in, inputs, scale, outputs, save_mesh, panoptic_infos)
         cfg = self.cfg
         batch_size = len(inputs["fragment"])
         interval = 2 ** (cfg.N_LAYER - scale - 1)

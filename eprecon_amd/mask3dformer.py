@@ -1,0 +1,257 @@
+"""Mask-transformer panoptic head on three voxel levels — mirror of models/mask3dformer.py
+(MultiScaleMaskedTransformerDecoder :198-445, panoptic_post / panoptic_inference :462-581) and of the
+Fourier positional encoding of models/voxel_position_encoding.py:123-152.
+
+The decoder is dense attention over 80 queries and stays PyTorch-ROCm (rocBLAS / SDPA), as
+BASELINE.json prescribes; parameter names follow the reference, so its state_dict loads as is.
+The one quadratic piece, the `cdist` + `argmin` nearest coarser voxel of every finest-level voxel
+(:361-367, [N2 x N0] and [N2 x N1] float distance matrices), is replaced by an exact integer
+nearest-neighbour search over the hash grid of the coarser level (csrc/nearest.hip): first-index
+tie-break like argmin, no N2 x N matrix.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from . import sparse as SP
+
+
+class PositionEmbeddingCoordsSine(nn.Module):
+    """Fourier features of normalised voxel coordinates (pos_type "fourier", normalize=True):
+    sin / cos of 2*pi * x_norm @ gauss_B, gauss_B ~ N(0, gauss_scale) of shape [3, d_pos/2]."""
+
+    def __init__(self, temperature=10000, normalize=False, scale=None, pos_type="fourier", d_pos=None, d_in=3,
+                 gauss_scale=1.0):
+        super().__init__()
+        assert pos_type == "fourier" and d_pos is not None and d_pos % 2 == 0
+        self.d_pos, self.normalize = d_pos, normalize
+        self.register_buffer("gauss_B", torch.randn(d_in, d_pos // 2) * gauss_scale)
+
+    def forward(self, xyz, num_channels=None, input_range=None):
+        """xyz f32[B, N, 3] -> f32[B, d_pos, N]"""
+        with torch.no_grad():
+            x = xyz.clone()
+            if self.normalize:
+                lo, hi = input_range
+                x = (x - lo[:, None, :]) * 1.0 / (hi[:, None, :] - lo[:, None, :]) + 0.0
+            x = x * (2 * math.pi)
+            b, n, _ = x.shape
+            proj = torch.mm(x.view(-1, 3), self.gauss_B).view(b, n, -1)
+            return torch.cat([proj.sin(), proj.cos()], dim=2).permute(0, 2, 1)
+
+
+class _Attention(nn.Module):
+    """post-norm residual attention block; `name` selects the reference's attribute name so that
+    the state_dict keys match (self_attn / multihead_attn)"""
+
+    def __init__(self, d_model, nhead, name):
+        super().__init__()
+        setattr(self, name, nn.MultiheadAttention(d_model, nhead, dropout=0.0))
+        self._name = name
+        self.norm = nn.LayerNorm(d_model)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, tgt, memory, attn_mask, pos, query_pos):
+        attn = getattr(self, self._name)
+        q = tgt + query_pos
+        k = memory if pos is None else memory + pos
+        upd = attn(query=q, key=k, value=memory, attn_mask=attn_mask)[0]
+        return self.norm(tgt + upd)
+
+
+class SelfAttentionLayer(_Attention):
+    def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
+        assert not normalize_before and dropout == 0.0
+        super().__init__(d_model, nhead, "self_attn")
+
+    def forward(self, tgt, tgt_mask=None, tgt_key_padding_mask=None, query_pos=None):
+        q = tgt + query_pos
+        upd = self.self_attn(q, q, value=tgt, attn_mask=tgt_mask)[0]
+        return self.norm(tgt + upd)
+
+
+class CrossAttentionLayer(_Attention):
+    def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
+        assert not normalize_before and dropout == 0.0
+        super().__init__(d_model, nhead, "multihead_attn")
+
+    def forward(self, tgt, memory, memory_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None):
+        return super().forward(tgt, memory, memory_mask, pos, query_pos)
+
+
+class FFNLayer(nn.Module):
+    def __init__(self, d_model, dim_feedforward=2048, dropout=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        assert not normalize_before and dropout == 0.0
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm = nn.LayerNorm(d_model)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, tgt):
+        return self.norm(tgt + self.linear2(F.relu(self.linear1(tgt))))
+
+
+class MLP(nn.Module):
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = layer(x)
+            if i + 1 < len(self.layers):
+                x = F.relu(x)
+        return x
+
+
+def nearest_coarse_index(fine_xyz, coarse_xyz, quantum):
+    """for every fine voxel the row of the nearest coarse voxel (Euclidean on integer coordinates,
+    smallest row on ties) — what argmin(cdist(fine, coarse)) returns when distances are exact.
+    fine int[N,3], coarse int[M,3] on the grid of multiples of `quantum` -> int64[N]"""
+    lib = _lib.load()
+    dev = fine_xyz.device
+
+    def with_batch(c):
+        return torch.cat([torch.zeros_like(c[:, :1]), c], dim=1).to(torch.int32).contiguous()
+
+    fine, coarse = with_batch(fine_xyz), with_batch(coarse_xyz)
+    grid = SP.HashGrid(coarse.shape[0], dev).build(coarse)
+    out = torch.empty(fine.shape[0], dtype=torch.int32, device=dev)
+    _lib.check(lib.eprecon_nearest_voxel_async(_lib.ptr(grid.mem), grid.capacity, _lib.ptr(coarse), coarse.shape[0],
+                                               _lib.ptr(fine), fine.shape[0], int(quantum), _lib.ptr(out),
+                                               _lib.current_stream()), "eprecon_nearest_voxel_async")
+    return out.long()
+
+
+class MultiScaleMaskedTransformerDecoder(nn.Module):
+    def __init__(self, mask_classification=True, *, num_classes, hidden_dim, num_queries, nheads, dim_feedforward,
+                 dec_layers, pre_norm, mask_dim):
+        super().__init__()
+        assert mask_classification and not pre_norm
+        self.num_queries, self.num_heads, self.num_layers = num_queries, nheads, dec_layers
+        self.query_feat = nn.Embedding(num_queries, hidden_dim)
+        self.query_embed = nn.Embedding(num_queries, hidden_dim)
+        self.pos_enc = PositionEmbeddingCoordsSine(pos_type="fourier", d_pos=mask_dim, gauss_scale=1.0, normalize=True)
+        self.transformer_self_attention_layers = nn.ModuleList(
+            SelfAttentionLayer(hidden_dim, nheads) for _ in range(dec_layers))
+        self.transformer_cross_attention_layers = nn.ModuleList(
+            CrossAttentionLayer(hidden_dim, nheads) for _ in range(dec_layers))
+        self.transformer_ffn_layers = nn.ModuleList(
+            FFNLayer(hidden_dim, dim_feedforward) for _ in range(dec_layers))
+        self.decoder_norm = nn.LayerNorm(hidden_dim)
+        self.num_feature_levels = 3
+        self.level_embed = nn.Embedding(self.num_feature_levels, hidden_dim)
+        self.class_embed = nn.Linear(hidden_dim, num_classes + 1)
+        self.mask_embed = MLP(hidden_dim, hidden_dim * 4, mask_dim, 3)
+
+    def get_pos_encs(self, coords, spitial_shape):
+        out = []
+        for level in coords:
+            for c in level:  # batch dimension (always 1 here)
+                lo = torch.zeros((1, 3), dtype=torch.float32, device=c.device)
+                hi = torch.tensor([list(spitial_shape)], dtype=torch.float32, device=c.device)
+                out.append(self.pos_enc(c[None].float(), input_range=[lo, hi]))
+        return out
+
+    def forward_prediction_heads(self, output, mask_features, attn_mask_target_size, mask_indices):
+        dec = self.decoder_norm(output).transpose(0, 1)
+        outputs_class = self.class_embed(dec)
+        outputs_mask = torch.einsum("bqc,bcl->bql", self.mask_embed(dec), mask_features)
+        attn = outputs_mask[..., mask_indices]
+        attn = (attn.sigmoid().unsqueeze(1).repeat(1, self.num_heads, 1, 1).flatten(0, 1) < 0.5).bool().detach()
+        return outputs_class, outputs_mask, attn
+
+    def forward(self, panoptic_features, panoptic_coords, mask_features, spitial_shape):
+        """panoptic_features 3 x [1, C, N_l]; panoptic_coords 3 x [1, N_l, 3]; mask_features [1, C, N_2]"""
+        pos = self.get_pos_encs(panoptic_coords, spitial_shape)
+        src, sizes = [], []
+        for i in range(self.num_feature_levels):
+            sizes.append(panoptic_coords[i].shape[1])
+            src.append((panoptic_features[i] + self.level_embed.weight[i][None, :, None]).permute(2, 0, 1))
+            pos[i] = pos[i].permute(2, 0, 1)
+        fine = panoptic_coords[2].squeeze(0)
+        mask_indices = [nearest_coarse_index(fine, panoptic_coords[0].squeeze(0), 4),
+                        nearest_coarse_index(fine, panoptic_coords[1].squeeze(0), 2),
+                        torch.ones(fine.shape[0], dtype=torch.bool, device=fine.device)]
+        query_embed = self.query_embed.weight.unsqueeze(1)
+        output = self.query_feat.weight.unsqueeze(1)
+        classes, masks = [], []
+        cls, msk, attn_mask = self.forward_prediction_heads(output, mask_features, sizes[0], mask_indices[0])
+        classes.append(cls)
+        masks.append(msk)
+        for j in range(self.num_layers):
+            lvl = j % self.num_feature_levels
+            attn_mask[torch.where(attn_mask.sum(-1) == attn_mask.shape[-1])] = False
+            output = self.transformer_cross_attention_layers[j](output, src[lvl], memory_mask=attn_mask,
+                                                                pos=pos[lvl], query_pos=query_embed)
+            output = self.transformer_self_attention_layers[j](output, query_pos=query_embed)
+            output = self.transformer_ffn_layers[j](output)
+            nxt = (j + 1) % self.num_feature_levels
+            cls, msk, attn_mask = self.forward_prediction_heads(output, mask_features, sizes[nxt], mask_indices[nxt])
+            classes.append(cls)
+            masks.append(msk)
+        return {"pred_logits": classes[-1], "pred_masks": masks[-1],
+                "aux_outputs": [{"pred_logits": a, "pred_masks": b} for a, b in zip(classes[:-1], masks[:-1])]}
+
+
+# ---------------------------------------------------------------------------------------------
+# post-processing (models/mask3dformer.py:462-581)
+# ---------------------------------------------------------------------------------------------
+THING_IDS = tuple(range(3, 21))  # classes 1 (wall) and 2 (floor) are stuff
+
+
+def panoptic_inference(mask_cls, mask_pred, object_mask_threshold=0.3, thing_id=THING_IDS, overlap_threshold=0.5):
+    """mask_cls f32[Q, K+1], mask_pred f32[Q, N] (logits) -> [panoptic_seg int32[N], segments_info]"""
+    scores, labels = F.softmax(mask_cls, dim=-1).max(-1)
+    prob = mask_pred.sigmoid()
+    keep = labels.ne(0) & (scores > object_mask_threshold)
+    cur_scores, cur_classes, cur_masks = scores[keep], labels[keep], prob[keep]
+    n = cur_masks.shape[-1]
+    seg = torch.zeros(n, dtype=torch.int32, device=prob.device)
+    info = []
+    if cur_masks.shape[0] == 0:
+        return [seg, info]
+    owner = (cur_scores.view(-1, 1) * cur_masks).argmax(0)
+    confident = cur_masks >= 0.5
+    # all per-query counts in three reductions (the reference syncs three times per query)
+    q = cur_masks.shape[0]
+    onehot = owner.unsqueeze(0) == torch.arange(q, device=owner.device).unsqueeze(1)
+    stats = torch.stack([onehot.sum(1), confident.sum(1), (onehot & confident).sum(1)]).cpu()
+    classes = cur_classes.cpu().tolist()
+    seg_id, stuff_ids = 0, {}
+    for k in range(q):
+        mask_area, original_area, joint = (int(v) for v in stats[:, k])
+        if mask_area > 0 and original_area > 0 and joint > 0:
+            if mask_area / original_area < overlap_threshold:
+                continue
+            cls = int(classes[k])
+            isthing = cls in thing_id
+            region = onehot[k] & confident[k]
+            if not isthing:
+                if cls in stuff_ids:
+                    seg[region] = stuff_ids[cls]
+                    continue
+                stuff_ids[cls] = seg_id + 1
+            seg_id += 1
+            seg[region] = seg_id
+            info.append({"id": seg_id, "isthing": bool(isthing), "category_id": cls})
+    return [seg, info]
+
+
+def panoptic_post(outputs, semantic_on=False, panoptic_on=True, instance_on=False, occupied=None):
+    assert panoptic_on and not semantic_on and not instance_on
+    cls_all = outputs["pred_logits"]
+    msk_all = outputs["pred_masks"] if occupied is None else outputs["pred_masks"][..., occupied]
+    result = {}
+    for mask_cls, mask_pred in zip(cls_all, msk_all):
+        result["panoptic_seg"] = panoptic_inference(mask_cls, mask_pred)
+    return result

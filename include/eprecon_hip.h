@@ -257,18 +257,31 @@ int eprecon_devoxelize_async(const float *voxel_feat, int ld_feat, const int32_t
  * (cur_coords int32[n_cur,4] (b,x,y,z) finest units of ONE batch element, divided by `interval`)
  * and (b) the global-map voxels (glob_coords int32[n_glob,3], scene grid units of this scale)
  * shifted by -relative_origin that land inside [0,dim)^3.  A voxel is active when its current or
- * its global feature row has a non-zero channel (the reference's `(volume != 0).any(-1)`).
+ * its global feature row has a non-zero channel (activity_mode 0, the reference's
+ * `(volume != 0).any(-1)`) or a channel with |v| < 1 (activity_mode 1, TSDF direct substitution).
  *   updated  int32[n_out,3]   src_cur / src_glob int32[n_out] (row or -1)   glob_valid u8[n_glob]
  * ------------------------------------------------------------------------------------------ */
 size_t eprecon_fbv_union_workspace_bytes(int dim);
 int eprecon_fbv_union_async(const int32_t *cur_coords, const float *cur_feat, int64_t n_cur, int ld_cur,
                             const int32_t *glob_coords, const float *glob_feat, int64_t n_glob, int ld_glob,
-                            int channels, int dim, int interval, const int32_t *relative_origin_host,
-                            int32_t *updated, int32_t *src_cur, int32_t *src_glob, uint8_t *glob_valid,
+                            int channels, int dim, int interval, int activity_mode,
+                            const int32_t *relative_origin_host, int32_t *updated, int32_t *src_cur, int32_t *src_glob, uint8_t *glob_valid,
                             int32_t *n_out_dev, void *workspace, size_t workspace_bytes, void *stream);
 /* out[i] = src[i] >= 0 ? feat[src[i]] : fill   (rows of `channels` floats) */
 int eprecon_gather_rows_async(const float *feat, int ld_feat, const int32_t *src, int64_t n, int channels,
                               float fill, float *out, int ld_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Nearest coarser voxel  (K18)
+ *
+ * Replaces  torch.cdist + argmin                       models/mask3dformer.py:361-367
+ * out_index[i] = row of the coarse voxel (int32[m,4] (b,x,y,z) on the grid of multiples of
+ * `quantum`, hashed in `table`) nearest to fine_coords[i] in exact integer Euclidean distance,
+ * smallest row on ties, same batch element; -1 when the batch element has no coarse voxel.
+ * ------------------------------------------------------------------------------------------ */
+int eprecon_nearest_voxel_async(const void *table, uint32_t capacity, const int32_t *coarse_coords,
+                                int64_t m, const int32_t *fine_coords, int64_t n, int quantum,
+                                int32_t *out_index, void *stream);
 
 #ifdef __cplusplus
 }

@@ -242,8 +242,117 @@ def gen_gru_fusion():
     _save("gru_fusion", **out)
 
 
+def mask3d_inputs(seed=11, c=16):
+    """three voxel levels on the 4-grid (every finest voxel coincides with a coarser voxel, so the
+    reference's float cdist/argmin has no ties to break arbitrarily)"""
+    rng = np.random.default_rng(seed)
+    cells = rng.permutation(np.argwhere(np.ones((10, 10, 10), bool)))[:320] * 4
+    c2 = cells[:300]
+    c1 = rng.permutation(cells)[:220]
+    c1 = np.unique(np.concatenate([c1, c2[:150]]), axis=0)
+    c0 = np.unique(np.concatenate([rng.permutation(cells)[:90], c2[100:200]]), axis=0)
+    feats = [rng.standard_normal((1, c, len(x))).astype(np.float32) for x in (c0, c1, c2)]
+    mask_feat = rng.standard_normal((1, c, len(c2))).astype(np.float32)
+    return [c0, c1, c2], feats, mask_feat
+
+
+def gen_mask3dformer():
+    """MultiScaleMaskedTransformerDecoder.forward + panoptic_post (models/mask3dformer.py:198-581)"""
+    from models.mask3dformer import MultiScaleMaskedTransformerDecoder, panoptic_post
+
+    torch.manual_seed(5)
+    dec = MultiScaleMaskedTransformerDecoder(mask_classification=True, num_classes=20, hidden_dim=16, num_queries=12,
+                                             nheads=4, dim_feedforward=64, dec_layers=4, pre_norm=False, mask_dim=16)
+    with torch.no_grad():
+        dec.class_embed.bias[1:8] += 1.5       # make some queries confident about real classes
+        dec.class_embed.weight.mul_(3.0)
+    coords, feats, mask_feat = mask3d_inputs()
+    out = {}
+    for k, v in dec.state_dict().items():
+        out["sd__" + k] = v.numpy()
+    with torch.no_grad():
+        res = dec([torch.from_numpy(f) for f in feats], [torch.from_numpy(c)[None] for c in coords],
+                  torch.from_numpy(mask_feat), (40, 40, 40))
+        post = panoptic_post({"pred_logits": res["pred_logits"], "pred_masks": res["pred_masks"]})
+    out["pred_logits"] = res["pred_logits"].numpy()
+    out["pred_masks"] = res["pred_masks"].numpy()
+    out["aux_last_masks"] = res["aux_outputs"][-1]["pred_masks"].numpy()
+    out["panoptic_seg"] = post["panoptic_seg"][0].numpy()
+    info = post["panoptic_seg"][1]
+    out["segments"] = np.array([[d["id"], int(d["isthing"]), d["category_id"]] for d in info], np.int64).reshape(-1, 3)
+    _save("mask3dformer", **out)
+
+
+def scene_fusion_inputs(seed=21, n_vox=24, n_frag=3):
+    """fragments for fuse_to_global (direct substitution at the finest scale): coords, tsdf, panoptic ids"""
+    rng = np.random.default_rng(seed)
+    shifts = [(0, 0, 0), (8, 0, 0), (8, 8, 0)][:n_frag]
+    frags = []
+    for k, sh in enumerate(shifts):
+        occ = rng.random((n_vox,) * 3) < 0.2
+        # a solid blob that persists across fragments (in scene coordinates) so that instances re-match
+        gx, gy, gz = np.meshgrid(*[np.arange(n_vox)] * 3, indexing="ij")
+        sx, sy, sz = gx + sh[0], gy + sh[1], gz + sh[2]
+        blob = ((sx - 14) ** 2 + (sy - 10) ** 2 + (sz - 12) ** 2) < 30
+        occ |= blob
+        xyz = np.argwhere(occ)
+        tsdf = np.clip(rng.standard_normal(len(xyz)) * 0.7, -1.2, 1.2).astype(np.float32)[:, None]
+        seg = np.zeros(len(xyz), np.int32)
+        inblob = blob[xyz[:, 0], xyz[:, 1], xyz[:, 2]]
+        seg[inblob] = 1                                     # thing, class 5
+        seg[(~inblob) & (xyz[:, 2] < 3)] = 2                # stuff, class 2 (floor)
+        seg[(~inblob) & (xyz[:, 2] >= 3) & (rng.random(len(xyz)) < 0.2)] = 3   # another thing, class 7
+        info = [{"id": 1, "isthing": True, "category_id": 5}, {"id": 2, "isthing": False, "category_id": 2},
+                {"id": 3, "isthing": True, "category_id": 7}]
+        frags.append({"coords": np.concatenate([np.zeros((len(xyz), 1), np.int64), xyz], 1).astype(np.int32),
+                      "tsdf": tsdf, "seg": seg, "info": info,
+                      "origin_partial": (np.array([-0.96, 0.2, -0.4]) + np.array(sh) * 0.04).astype(np.float32)})
+    return frags, np.array([-0.96, 0.2, -0.4], np.float32)
+
+
+def gen_scene_fusion():
+    """GRUFusion(direct_substitute=True).forward = NeuralRecon.fuse_to_global (models/gru_fusion.py:259-394
+    with panoptic_fusion :133-193 and save_mesh :217-257), three overlapping fragments"""
+    from types import SimpleNamespace
+    import models.gru_fusion as G
+
+    class PT:
+        def __init__(self, F, C):
+            self.F, self.C = F, C
+
+        def cuda(self):
+            return self
+
+        def detach(self):
+            return self
+
+    G.PointTensor = PT
+    cfg = SimpleNamespace(THRESHOLDS=[0, 0, 0], VOXEL_SIZE=0.04, N_VOX=[24, 24, 24], N_LAYER=3,
+                          FUSION=SimpleNamespace(FULL=True))
+    fus = G.GRUFusion(cfg, direct_substitute=True, trianing=False)
+    frags, origin = scene_fusion_inputs()
+    out = {}
+    outputs = {}
+    for k, fr in enumerate(frags):
+        inputs = {"fragment": ["f"], "scene": ["sceneA"], "vol_origin": torch.from_numpy(origin[None]),
+                  "vol_origin_partial": torch.from_numpy(fr["origin_partial"][None])}
+        infos = [{"panoptic_seg": [torch.from_numpy(fr["seg"]), [dict(d) for d in fr["info"]]]}]
+        outputs = fus(torch.from_numpy(fr["coords"]), torch.from_numpy(fr["tsdf"]), inputs, 2, outputs,
+                      save_mesh=(k == len(frags) - 1), panoptic_infos=infos)
+        key = f"f{k}_"
+        out[key + "map_C"] = fus.global_volume[2].C.numpy().astype(np.int32)
+        out[key + "map_F"] = fus.global_volume[2].F.numpy()
+        out[key + "instance"] = fus.global_instance.numpy().reshape(-1).astype(np.int32)
+        out[key + "semantic"] = fus.global_semantic.numpy().reshape(-1).astype(np.int32)
+    out["scene_tsdf"] = outputs["scene_tsdf"][0].numpy()
+    out["scene_instance"] = outputs["scene_instance"][0].numpy().astype(np.int32)
+    out["scene_semantic"] = outputs["scene_semantic"][0].numpy().astype(np.int32)
+    out["scene_origin"] = outputs["origin"][0].numpy()
+    _save("scene_fusion", **out)
+
+
 GENERATORS = {"back_project": gen_back_project, "grid_ops": gen_grid_ops, "dense_blocks": gen_dense_blocks,
-              "gru_fusion": gen_gru_fusion}
+              "gru_fusion": gen_gru_fusion, "mask3dformer": gen_mask3dformer, "scene_fusion": gen_scene_fusion}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GENERATORS)

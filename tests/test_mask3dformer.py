@@ -1,0 +1,87 @@
+"""Mask-transformer head: CPU check of the post-processing against the reference golden vectors;
+GPU checks of the decoder (reference state_dict) and of the exact nearest-voxel kernel."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def mask3d_inputs(seed=11, c=16):
+    rng = np.random.default_rng(seed)
+    cells = rng.permutation(np.argwhere(np.ones((10, 10, 10), bool)))[:320] * 4
+    c2 = cells[:300]
+    c1 = rng.permutation(cells)[:220]
+    c1 = np.unique(np.concatenate([c1, c2[:150]]), axis=0)
+    c0 = np.unique(np.concatenate([rng.permutation(cells)[:90], c2[100:200]]), axis=0)
+    feats = [rng.standard_normal((1, c, len(x))).astype(np.float32) for x in (c0, c1, c2)]
+    mask_feat = rng.standard_normal((1, c, len(c2))).astype(np.float32)
+    return [c0, c1, c2], feats, mask_feat
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "mask3dformer.npz"))
+
+
+def test_panoptic_post_matches_reference(gold):
+    from eprecon_amd.mask3dformer import panoptic_post
+    res = panoptic_post({"pred_logits": torch.from_numpy(gold["pred_logits"]),
+                         "pred_masks": torch.from_numpy(gold["pred_masks"])})
+    seg, info = res["panoptic_seg"]
+    assert seg.dtype == torch.int32 and np.array_equal(seg.numpy(), gold["panoptic_seg"])
+    got = np.array([[d["id"], int(d["isthing"]), d["category_id"]] for d in info], np.int64).reshape(-1, 3)
+    assert np.array_equal(got, gold["segments"])
+
+
+def test_panoptic_inference_stuff_merging_and_overlap_rule():
+    from eprecon_amd.mask3dformer import panoptic_inference
+    q, n = 5, 40
+    cls = torch.full((q, 21), -5.0)
+    for k, c in enumerate([1, 1, 5, 5, 0]):   # two "wall" queries merge, two chairs stay apart, one empty
+        cls[k, c] = 5.0
+    m = torch.full((q, n), -6.0)
+    m[0, 0:10] = 6.0
+    m[1, 10:18] = 6.0
+    m[2, 18:26] = 6.0
+    m[3, 26:30] = 6.0
+    m[3, 18:26] = 5.0   # mostly loses its area to query 2 -> overlap rule drops it? area 4 of 12 < 0.5
+    m[4, 30:40] = 6.0
+    seg, info = panoptic_inference(cls, m)
+    assert [d["category_id"] for d in info] == [1, 5]
+    assert seg[0:18].eq(1).all() and seg[18:26].eq(2).all() and seg[26:40].eq(0).all()
+
+
+@pytest.mark.gpu
+def test_decoder_matches_reference_golden(gold):
+    from eprecon_amd.mask3dformer import MultiScaleMaskedTransformerDecoder
+    dec = MultiScaleMaskedTransformerDecoder(mask_classification=True, num_classes=20, hidden_dim=16, num_queries=12,
+                                             nheads=4, dim_feedforward=64, dec_layers=4, pre_norm=False, mask_dim=16)
+    sd = {k[4:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("sd__")}
+    r = dec.load_state_dict(sd, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    dec = dec.cuda()
+    coords, feats, mask_feat = mask3d_inputs()
+    with torch.no_grad():
+        out = dec([torch.from_numpy(f).cuda() for f in feats], [torch.from_numpy(c)[None].cuda() for c in coords],
+                  torch.from_numpy(mask_feat).cuda(), (40, 40, 40))
+    np.testing.assert_allclose(out["pred_logits"].cpu().numpy(), gold["pred_logits"], atol=2e-4)
+    np.testing.assert_allclose(out["pred_masks"].cpu().numpy(), gold["pred_masks"], atol=2e-4)
+    np.testing.assert_allclose(out["aux_outputs"][-1]["pred_masks"].cpu().numpy(), gold["aux_last_masks"], atol=2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", [2, 4])
+def test_nearest_voxel_is_exact_argmin(q):
+    from eprecon_amd.mask3dformer import nearest_coarse_index
+    rng = np.random.default_rng(q)
+    occ = rng.random((24, 24, 24)) < 0.08
+    fine = np.argwhere(occ)
+    anc = np.unique(fine // q * q, axis=0)
+    keep = rng.random(len(anc)) < 0.6          # 40 % of the ancestors are missing
+    coarse = rng.permutation(anc[keep])
+    far = fine.max(0) + 40                      # plus a far-away fine voxel: forces the full-scan fallback
+    fine = np.concatenate([fine, far[None]])
+    got = nearest_coarse_index(torch.from_numpy(fine).cuda(), torch.from_numpy(coarse).cuda(), q).cpu().numpy()
+    d = ((fine[:, None, :].astype(np.int64) - coarse[None].astype(np.int64)) ** 2).sum(-1)
+    assert np.array_equal(got, d.argmin(1))
