@@ -4,9 +4,9 @@ Fourier positional encoding of models/voxel_position_encoding.py:123-152.
 
 The decoder is dense attention over 80 queries and stays PyTorch-ROCm (rocBLAS / SDPA), as
 BASELINE.json prescribes; parameter names follow the reference, so its state_dict loads as is.
-The one quadratic piece, the `cdist` + `argmin` nearest coarser voxel of every finest-level voxel
+The one quadratic piece, the `cdist` + `argmin` nearest finest-level voxel of every coarser voxel
 (:361-367, [N2 x N0] and [N2 x N1] float distance matrices), is replaced by an exact integer
-nearest-neighbour search over the hash grid of the coarser level (csrc/nearest.hip): first-index
+nearest-neighbour search over the hash grid of the finest level (csrc/nearest.hip): first-index
 tie-break like argmin, no N2 x N matrix.
 """
 import math
@@ -113,10 +113,10 @@ class MLP(nn.Module):
         return x
 
 
-def nearest_coarse_index(fine_xyz, coarse_xyz, quantum):
-    """for every fine voxel the row of the nearest coarse voxel (Euclidean on integer coordinates,
-    smallest row on ties) — what argmin(cdist(fine, coarse)) returns when distances are exact.
-    fine int[N,3], coarse int[M,3] on the grid of multiples of `quantum` -> int64[N]"""
+def nearest_fine_index(coarse_xyz, fine_xyz, quantum):
+    """for every coarse voxel (multiple of `quantum`) the row of the nearest fine voxel (Euclidean on
+    integer coordinates, smallest row on ties) — what argmin(cdist(fine, coarse), dim=0) returns when
+    distances are exact.  coarse int[M,3], fine int[N,3] -> int64[M]"""
     lib = _lib.load()
     dev = fine_xyz.device
 
@@ -124,10 +124,10 @@ def nearest_coarse_index(fine_xyz, coarse_xyz, quantum):
         return torch.cat([torch.zeros_like(c[:, :1]), c], dim=1).to(torch.int32).contiguous()
 
     fine, coarse = with_batch(fine_xyz), with_batch(coarse_xyz)
-    grid = SP.HashGrid(coarse.shape[0], dev).build(coarse)
-    out = torch.empty(fine.shape[0], dtype=torch.int32, device=dev)
-    _lib.check(lib.eprecon_nearest_voxel_async(_lib.ptr(grid.mem), grid.capacity, _lib.ptr(coarse), coarse.shape[0],
-                                               _lib.ptr(fine), fine.shape[0], int(quantum), _lib.ptr(out),
+    grid = SP.HashGrid(fine.shape[0], dev).build(fine)
+    out = torch.empty(coarse.shape[0], dtype=torch.int32, device=dev)
+    _lib.check(lib.eprecon_nearest_voxel_async(_lib.ptr(grid.mem), grid.capacity, _lib.ptr(fine), fine.shape[0],
+                                               _lib.ptr(coarse), coarse.shape[0], int(quantum), _lib.ptr(out),
                                                _lib.current_stream()), "eprecon_nearest_voxel_async")
     return out.long()
 
@@ -179,8 +179,8 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             src.append((panoptic_features[i] + self.level_embed.weight[i][None, :, None]).permute(2, 0, 1))
             pos[i] = pos[i].permute(2, 0, 1)
         fine = panoptic_coords[2].squeeze(0)
-        mask_indices = [nearest_coarse_index(fine, panoptic_coords[0].squeeze(0), 4),
-                        nearest_coarse_index(fine, panoptic_coords[1].squeeze(0), 2),
+        mask_indices = [nearest_fine_index(panoptic_coords[0].squeeze(0), fine, 4),
+                        nearest_fine_index(panoptic_coords[1].squeeze(0), fine, 2),
                         torch.ones(fine.shape[0], dtype=torch.bool, device=fine.device)]
         query_embed = self.query_embed.weight.unsqueeze(1)
         output = self.query_feat.weight.unsqueeze(1)

@@ -272,15 +272,16 @@ int eprecon_gather_rows_async(const float *feat, int ld_feat, const int32_t *src
                               float fill, float *out, int ld_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
- * Nearest coarser voxel  (K18)
+ * Nearest finest-level voxel  (K18)
  *
- * Replaces  torch.cdist + argmin                       models/mask3dformer.py:361-367
- * out_index[i] = row of the coarse voxel (int32[m,4] (b,x,y,z) on the grid of multiples of
- * `quantum`, hashed in `table`) nearest to fine_coords[i] in exact integer Euclidean distance,
- * smallest row on ties, same batch element; -1 when the batch element has no coarse voxel.
+ * Replaces  torch.cdist + argmin(dim=1)                 models/mask3dformer.py:361-367
+ * out_index[i] = row of the reference voxel (ref_coords int32[m,4] (b,x,y,z), hashed in `table`)
+ * nearest to query_coords[i] (a voxel of a coarser level, multiple of `quantum`) in exact integer
+ * Euclidean distance, smallest row on ties, same batch element; -1 when that batch element has no
+ * reference voxel.
  * ------------------------------------------------------------------------------------------ */
-int eprecon_nearest_voxel_async(const void *table, uint32_t capacity, const int32_t *coarse_coords,
-                                int64_t m, const int32_t *fine_coords, int64_t n, int quantum,
+int eprecon_nearest_voxel_async(const void *table, uint32_t capacity, const int32_t *ref_coords,
+                                int64_t m, const int32_t *query_coords, int64_t n, int quantum,
                                 int32_t *out_index, void *stream);
 
 #ifdef __cplusplus

@@ -73,15 +73,14 @@ def test_decoder_matches_reference_golden(gold):
 @pytest.mark.gpu
 @pytest.mark.parametrize("q", [2, 4])
 def test_nearest_voxel_is_exact_argmin(q):
-    from eprecon_amd.mask3dformer import nearest_coarse_index
+    from eprecon_amd.mask3dformer import nearest_fine_index
     rng = np.random.default_rng(q)
-    occ = rng.random((24, 24, 24)) < 0.08
-    fine = np.argwhere(occ)
+    occ = rng.random((24, 24, 24)) < 0.05
+    fine = rng.permutation(np.argwhere(occ))
     anc = np.unique(fine // q * q, axis=0)
-    keep = rng.random(len(anc)) < 0.6          # 40 % of the ancestors are missing
-    coarse = rng.permutation(anc[keep])
-    far = fine.max(0) + 40                      # plus a far-away fine voxel: forces the full-scan fallback
-    fine = np.concatenate([fine, far[None]])
-    got = nearest_coarse_index(torch.from_numpy(fine).cuda(), torch.from_numpy(coarse).cuda(), q).cpu().numpy()
-    d = ((fine[:, None, :].astype(np.int64) - coarse[None].astype(np.int64)) ** 2).sum(-1)
+    # queries: ancestors of fine voxels, plus coarse cells with no descendant (ring / far searches)
+    extra = rng.integers(-3, 9, size=(200, 3)) * q
+    coarse = np.concatenate([rng.permutation(anc), extra, np.array([[400, 400, 400]])])
+    got = nearest_fine_index(torch.from_numpy(coarse).cuda(), torch.from_numpy(fine).cuda(), q).cpu().numpy()
+    d = ((coarse[:, None, :].astype(np.int64) - fine[None].astype(np.int64)) ** 2).sum(-1)
     assert np.array_equal(got, d.argmin(1))
