@@ -8,8 +8,8 @@ signature and early-return conventions:
   B  for i in 0..2: [upsample] -> Back_Project -> SPVCNN -> GRU fusion -> TSDF / occupancy heads
      -> sparsify                                                                  (:348-511)
   C  panoptic: ancestor pruning of the coarser levels, 48-channel projections, mask features
-     (three submanifold residual blocks); the mask-transformer decoder is plugged in through
-     `self.panoptic` when available                                               (:516-587)
+     (three submanifold residual blocks), mask-transformer decoder (PyTorch-ROCm) + panoptic
+     post-processing                                                              (:516-587)
 Every sparse / gather / scatter step runs in libeprecon_hip.so; the dense heads are PyTorch-ROCm.
 """
 import numpy as np
@@ -20,9 +20,10 @@ from . import grid_ops as GO
 from . import sparse as SP
 from .back_project import Back_Project
 from .config import (CH_IMG, CH_INIT_DOWN, CH_VOXEL, EXCEED_NUM, INIT_MIN_VIEW, INIT_OCC_THRESHOLD, INIT_STAGE,
-                     N_VIEWS, PANOPTIC_CH, PANOPTIC_SHAPE, STAGE_MIN_OCC)
+                     N_VIEWS, NUM_CLASSES, NUM_QUERIES, PANOPTIC_CH, PANOPTIC_SHAPE, STAGE_MIN_OCC)
 from .generate_grids import dense_coords
 from .gru_fusion import GRUFusion
+from .mask3dformer import MultiScaleMaskedTransformerDecoder, panoptic_post
 from .modules import Linear4xTrans, Panoptic_Feat_Fusion, SPVCNN
 from .occupancy_initialization import Occupancy_Initialization
 from .tensor import PointTensor
@@ -34,7 +35,7 @@ def _warn(msg):
 
 
 class NeuConNet(nn.Module):
-    def __init__(self, cfg, panoptic_decoder=None):
+    def __init__(self, cfg, panoptic_decoder="default"):
         super().__init__()
         self.cfg = cfg
         self.n_scales = len(cfg.THRESHOLDS) - 1
@@ -53,7 +54,11 @@ class NeuConNet(nn.Module):
         self.panoptic_preds = nn.ModuleList()
         self.initialization = Occupancy_Initialization(CH_IMG, CH_INIT_DOWN, N_VIEWS)
         self.panoptic_feat_fusion = Panoptic_Feat_Fusion(channels[2], PANOPTIC_CH, CH_IMG)
-        self.panoptic = panoptic_decoder  # MultiScaleMaskedTransformerDecoder equivalent (PyTorch), optional
+        if panoptic_decoder == "default":  # models/neucon_network.py:59-71
+            panoptic_decoder = MultiScaleMaskedTransformerDecoder(
+                mask_classification=True, num_classes=NUM_CLASSES, hidden_dim=PANOPTIC_CH, num_queries=NUM_QUERIES,
+                nheads=8, dim_feedforward=4 * PANOPTIC_CH, dec_layers=6, pre_norm=False, mask_dim=PANOPTIC_CH)
+        self.panoptic = panoptic_decoder  # None skips the decoder (outputs['panoptic_levels'] only)
         for i in range(len(cfg.THRESHOLDS)):
             self.back_projection.append(Back_Project(CH_IMG[i]))
             self.sp_convs.append(SPVCNN(num_classes=1, in_channels=ch_in[i], pres=1, cr=1 / 2 ** i,
@@ -212,6 +217,7 @@ class NeuConNet(nn.Module):
                 panoptic_predictions.append(out_b)
         if self.panoptic is not None:
             outputs["panoptic_out"] = panoptic_predictions
+            outputs["panoptic_info"] = [panoptic_post(o) for o in panoptic_predictions]  # :583-587
         self._record(stage="panoptic", coords=panoptic_coords, feats=panoptic_voxel_feats)
         return outputs, loss_dict
 

@@ -1,0 +1,61 @@
+"""The drop-in boundary — mirror of models/neuralrecon.py:19-86 (NeuralRecon):
+normalise the 9 images, run the two MnasMulti backbones per view (PyTorch-ROCm), run the HIP 3D path
+(NeuConNet), and at test time fuse TSDF + panoptic ids into the scene map (fuse_to_global).
+
+forward(inputs: dict, save_mesh=False, training=True) -> (outputs: dict, loss_dict: dict), called the
+way main.py:430-436 calls it.  Losses are out of scope (inference path): loss_dict carries zeros.
+"""
+import torch
+import torch.nn as nn
+
+from .backbone import MnasMulti
+from .gru_fusion import GRUFusion
+from .neucon_network import NeuConNet
+
+PIXEL_MEAN = [103.53, 116.28, 123.675]  # config/default.py:59-61
+PIXEL_STD = [1.0, 1.0, 1.0]
+LOSS_WEIGHTS = [1.0, 0.8, 0.64, 0.8]    # config/test.yaml:42
+
+
+def tocuda(obj, device):
+    """utils.py:74-81: recursive host -> device copy of the input dict"""
+    if isinstance(obj, torch.Tensor):
+        return obj.to(device)
+    if isinstance(obj, dict):
+        return {k: tocuda(v, device) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)) and obj and not isinstance(obj[0], str):
+        return [tocuda(v, device) for v in obj]
+    return obj
+
+
+class NeuralRecon(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.register_buffer("pixel_mean", torch.tensor(PIXEL_MEAN).view(-1, 1, 1), persistent=False)
+        self.register_buffer("pixel_std", torch.tensor(PIXEL_STD).view(-1, 1, 1), persistent=False)
+        self.n_scales = len(cfg.THRESHOLDS) - 1
+        self.backbone2d = MnasMulti(float(cfg.ALPHA))
+        self.backbone_occ_pano = MnasMulti(float(cfg.ALPHA))
+        self.neucon_net = NeuConNet(cfg)
+        self.fuse_to_global = GRUFusion(cfg, direct_substitute=True, trianing=False)
+
+    def normalizer(self, x):
+        return (x - self.pixel_mean.type_as(x)) / self.pixel_std.type_as(x)
+
+    def forward(self, inputs, save_mesh=False, training=True):
+        dev = self.pixel_mean.device
+        inputs = tocuda(inputs, dev)
+        outputs = {}
+        imgs = torch.unbind(inputs["imgs"], 1)
+        features_backbone2d = [self.backbone2d(self.normalizer(img)) for img in imgs]
+        features_occ_pano = [self.backbone_occ_pano(self.normalizer(img)) for img in imgs]
+        outputs, loss_dict = self.neucon_net(features_backbone2d, features_occ_pano, inputs, outputs)
+        if not training and "coords" in outputs and "panoptic_info" in outputs:
+            outputs = self.fuse_to_global(outputs["coords"], outputs["tsdf"], inputs, self.n_scales, outputs,
+                                          save_mesh, panoptic_infos=outputs["panoptic_info"])
+        total = 0
+        for i, (k, v) in enumerate(loss_dict.items()):
+            total = total + v * LOSS_WEIGHTS[min(i, len(LOSS_WEIGHTS) - 1)]
+        loss_dict["total_loss"] = total
+        return outputs, loss_dict

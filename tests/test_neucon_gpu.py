@@ -49,6 +49,35 @@ def test_reaches_the_finest_level(run):
     assert out["tsdf"].shape == (out["coords"].shape[0], 1)
     assert len(out["panoptic_levels"]) == 1
     assert out["panoptic_levels"][0]["mask_features"].shape == (out["coords"].shape[0], 48)
+    seg, info = out["panoptic_info"][0]["panoptic_seg"]
+    assert seg.shape[0] == out["coords"].shape[0] and seg.dtype == torch.int32
+    assert out["panoptic_out"][0]["pred_masks"].shape == (1, 80, out["coords"].shape[0])
+
+
+def test_neuralrecon_boundary_runs_end_to_end():
+    """NeuralRecon.forward(inputs, save_mesh, training=False): images -> backbones -> HIP 3D path ->
+    scene fusion, on a 320x240 window with random weights (shape / plumbing check of the boundary)"""
+    from eprecon_amd.fragment_step import calibrate_occupancy_heads
+    from eprecon_amd.neuralrecon import NeuralRecon
+    torch.manual_seed(11)
+    np.random.seed(11)
+    model = NeuralRecon(ModelCfg()).cuda()
+    model.train()
+    window = S.make_window(seed=2, width=320, height=240)
+    _, _, inputs = S.make_model_inputs([window], feat_seed=5)
+    rng = np.random.default_rng(0)
+    inputs["imgs"] = (rng.random((1, 9, 3, 240, 320), dtype=np.float32) * 255)
+    t_in = S.to_device(inputs, torch.device("cuda"))
+    with torch.no_grad():
+        imgs = torch.unbind(t_in["imgs"], 1)
+        f1 = [model.backbone2d(model.normalizer(i)) for i in imgs]
+        f2 = [model.backbone_occ_pano(model.normalizer(i)) for i in imgs]
+        assert [tuple(x.shape[1:]) for x in f1[0]] == [(24, 60, 80), (40, 30, 40), (80, 15, 20)]
+        calibrate_occupancy_heads(model.neucon_net, f1, f2, t_in)
+        outputs, loss = model(t_in, save_mesh=True, training=False)
+    assert "coords" in outputs and "total_loss" in loss
+    assert outputs["scene_name"] == [inputs["scene"][0]]
+    assert outputs["scene_tsdf"][0].dim() == 3 and outputs["scene_instance"][0].shape == outputs["scene_tsdf"][0].shape
 
 
 def test_stage0_selection_and_backprojection(run):
