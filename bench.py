@@ -149,7 +149,9 @@ def main():
     # every rank owns a different fragment window (seed = rank)
     if args.workload == "cfg4":
         from eprecon_amd.fragment_step import Cfg4Step
-        return bench_cfg4(args, Cfg4Step(seed=rank, device=torch.device("cuda", local_rank)), world, rank, dist)
+        # all ranks work on ONE scene (seed 0), fragments dealt round-robin, boundary voxels exchanged
+        return bench_cfg4(args, Cfg4Step(seed=0, device=torch.device("cuda", local_rank), rank=rank, world=world),
+                          world, rank, dist)
     step = Cfg2Step(seed=rank, device=torch.device("cuda", local_rank))
 
     def barrier():

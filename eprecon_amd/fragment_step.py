@@ -88,7 +88,7 @@ class Cfg2Step:
 
 
 @torch.no_grad()
-def calibrate_occupancy_heads(net, features, features_occ_pano, inputs, keep_fraction=(0.5, 0.45, 0.4)):
+def calibrate_occupancy_heads(net, features, features_occ_pano, inputs, keep_fraction=(0.45, 0.35, 0.25)):
     """Random-init occupancy heads may classify (almost) every voxel the same way, which trips the
     reference's `< 500 occupied voxels` early return.  There is no trained checkpoint in this
     environment, so benchmarks and end-to-end tests shift each stage's occupancy bias
@@ -116,7 +116,7 @@ class Cfg4Step:
     windows of one scene (camera arc advanced 0.32 m per fragment, persistent GRU map).
     One step = one fragment; the scene restarts every `n_fragments` steps."""
 
-    def __init__(self, seed=0, device=None, height=480, width=640, n_fragments=4):
+    def __init__(self, seed=0, device=None, height=480, width=640, n_fragments=4, rank=0, world=1):
         from .config import ModelCfg
         from .neucon_network import NeuConNet
         self.device = device or torch.device("cuda")
@@ -128,11 +128,15 @@ class Cfg4Step:
         for k in range(n_fragments):
             # make_window keeps vol_origin fixed and snaps vol_origin_partial to the advanced arc,
             # so the fragments of one scene share the global origin and overlap by 2/3
-            w = S.make_window(seed=seed * 100 + k, width=width, height=height, advance=0.32 * k)
-            f1, f2, inp = S.make_model_inputs([w], feat_seed=seed * 100 + k, scene=f"scene{seed:04d}")
+            # with `world` ranks the fragments of the scene are dealt round-robin: rank r owns
+            # fragments r, r + world, ... and exchanges boundary voxels with the others every step
+            kk = k * world + rank
+            w = S.make_window(seed=seed * 100 + kk, width=width, height=height, advance=0.32 * kk)
+            f1, f2, inp = S.make_model_inputs([w], feat_seed=seed * 100 + kk, scene=f"scene{seed:04d}")
             self.frags.append((S.to_device(f1, self.device), S.to_device(f2, self.device),
                                S.to_device(inp, self.device)))
         calibrate_occupancy_heads(self.net, *self.frags[0])
+        self.net.distributed_exchange = world > 1
         self.k = 0
         self.last = None
 
@@ -150,4 +154,4 @@ class Cfg4Step:
                             "(occupancy init, 3 x [Back_Project, SPVCNN, GRU fusion, heads], panoptic inputs), "
                             "96^3 FBV, persistent sparse global map",
                 "views": N_VIEWS, "image": "640x480", "weights": "seeded random, occupancy heads calibrated to "
-                "50/45/40 % keep", "fragments_per_step_per_gpu": 1}
+                "45/35/25 % keep", "fragments_per_step_per_gpu": 1}

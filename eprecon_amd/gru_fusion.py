@@ -104,6 +104,30 @@ class GRUFusion(nn.Module):
         self.global_volume[i] = _Map(self.ch_in[i], device)
         self.target_tsdf_volume[i] = _Map(1, device)
 
+    def _begin_fragment(self, scale, inputs, i, dev):
+        """scene bookkeeping of models/gru_fusion.py:280-293 -> relative origin (LongTensor[3], host)"""
+        scene = inputs["scene"][i]
+        if self.scene_name[scale] is None or scene != self.scene_name[scale]:
+            self.scene_name[scale] = scene
+            self.reset(scale, dev)
+            self.global_origin[scale] = inputs["vol_origin"][i].detach().float().cpu()
+        interval = 2 ** (self.cfg.N_LAYER - scale - 1)
+        origin = inputs["vol_origin_partial"][i]
+        # (origin - global_origin) / voxel_size in fp32, truncated toward zero (:292-293)
+        return ((origin.detach().float().cpu() - self.global_origin[scale]) / (self.cfg.VOXEL_SIZE * interval)).long()
+
+    def exchange_boundaries(self, inputs, i=0):
+        """Multi-GPU schedule (eprecon_amd/distributed.py): before this fragment is fused, pull in the
+        map voxels other ranks own inside this fragment's bounding volume, at all three scales.
+        Collective — every rank calls it once per step, outside any data-dependent control flow."""
+        from . import distributed as D
+        dev = inputs["vol_origin_partial"].device
+        for scale in range(self.cfg.N_LAYER):
+            rel = self._begin_fragment(scale, inputs, i, dev)
+            dim = self.cfg.N_VOX[0] // 2 ** (self.cfg.N_LAYER - scale - 1)
+            gmap = self.global_volume[scale]
+            gmap.C, gmap.F = D.exchange_boundary_voxels(gmap.C, gmap.F, rel.tolist(), dim)
+
     # ---- ground-truth twin (1 channel, dense [D,D,D] is 3.5 MB at most): plain tensor indexing ----
     def _fuse_targets(self, scale, occ_target, tsdf_volume, rel_t, dim):
         tmap = self.target_tsdf_volume[scale]
@@ -138,14 +162,8 @@ class GRUFusion(nn.Module):
         out_c, out_v, out_t, out_o = [], [], [], []
         batch_col = coords[:, 0]
         for i in range(batch_size):
-            scene = inputs["scene"][i]
-            if self.scene_name[scale] is None or scene != self.scene_name[scale]:
-                self.scene_name[scale] = scene
-                self.reset(scale, dev)
-                self.global_origin[scale] = inputs["vol_origin"][i].detach().float().cpu()
+            rel = self._begin_fragment(scale, inputs, i, dev)
             origin = inputs["vol_origin_partial"][i]
-            # (origin - global_origin) / voxel_size in fp32, truncated toward zero (:292-293)
-            rel = ((origin.detach().float().cpu() - self.global_origin[scale]) / voxel_size).long()
             rel_t = rel.to(device=dev, dtype=torch.int32)
             rows = torch.nonzero(batch_col == i).squeeze(1)
             if rows.numel() == 0:

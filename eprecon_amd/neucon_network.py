@@ -68,6 +68,7 @@ class NeuConNet(nn.Module):
             self.occ_preds.append(Linear4xTrans(channels[i], 1))
             self.panoptic_preds.append(Linear4xTrans(gru_channels[i], PANOPTIC_CH))
         self.trace = None  # set to a list to record per-stage intermediates (parity tests)
+        self.distributed_exchange = False  # multi-GPU: boundary-voxel all-gather before each fragment
 
     # models/neucon_network.py:193-214
     def upsample(self, pre_feat, pre_coords, interval, num=8):
@@ -85,6 +86,11 @@ class NeuConNet(nn.Module):
         dev = features[0][0].device
         loss_dict = {}
         zero = torch.zeros((), device=dev)
+        if self.distributed_exchange and cfg.FUSION.FUSION_ON:
+            # the one collective of the path (RCCL all-gather of boundary voxels); placed
+            # before every data-dependent early return so that all ranks issue it once per fragment
+            for b in range(bs):
+                self.gru_fusion.exchange_boundaries(inputs, b)
 
         # ---- A. occupancy initialisation ("depth prior") -------------------------------------
         interval = 2 ** (self.n_scales - INIT_STAGE)
