@@ -39,7 +39,8 @@ SIGNATURES = {
     "eprecon_batchnorm_train_async": (_i, [_vp, _i64, _i, _i, _vp, _vp, _f, _vp, _i, _i, _vp, _i, _vp, _vp,
                                            _vp, _sz, _vp]),
     "eprecon_rowwise_layernorm_async": (_i, [_vp, _i64, _i, _i, _vp, _i, _vp, _vp, _f, _i, _i, _vp, _i, _vp]),
-    "eprecon_init_select_async": (_i, [_vp, _vp, _i64, _f, _i, _i, _i, _vp, _vp, _vp]),
+    "eprecon_init_select_workspace_bytes": (_sz, [_i, _i]),
+    "eprecon_init_select_async": (_i, [_vp, _vp, _i64, _f, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "eprecon_upsample_async": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "eprecon_aligned_coords_async": (_i, [_vp, _i64, _vp, _i, _f, _vp, _vp, _vp]),
     "eprecon_point_quantize_async": (_i, [_vp, _i64, _f, _vp, _vp, _vp]),

@@ -2,7 +2,7 @@
 //
 //   init_select   sigmoid(logit) > thr on the valid 48^3 voxels -> OR-pool 2^3 -> erode -> dilate x2
 //                 -> raster-order coordinates * 4           models/neucon_network.py:264,298-318
-//                 (the whole 24^3 occupancy volume lives in LDS; one workgroup)
+//                 (marking is one thread per voxel; the 24^3 morphology runs in LDS, one workgroup)
 //   upsample      every voxel -> its 8 children, parent-major, features replicated
 //                                                            models/neucon_network.py:193-214
 #include "common.hpp"
@@ -25,9 +25,24 @@ __device__ __forceinline__ bool box27(const unsigned char *vol, int D, int x, in
     return want_all ? (s == 27) : (s >= 1);
 }
 
-__global__ __launch_bounds__(kSelThreads) void init_select_kernel(const float *logit, const int4 *coords,
-                                                                  int n, float thr, int batch, int D,
-                                                                  int cell, int out_scale, int4 *out_coords,
+// one thread per valid voxel: mark the coarse cell of every voxel with sigmoid(logit) > thr
+// (byte stores of the same value: race-free)
+__global__ __launch_bounds__(256) void init_mark_kernel(const float *logit, const int4 *coords, int n, float thr,
+                                                        int batch, int D, int cell, unsigned char *marks)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = coords[i];
+    if (c.x < 0 || c.x >= batch) return;
+    const float sig = 1.0f / (1.0f + expf(-logit[i]));
+    if (sig > thr) {
+        const int x = c.y / cell, y = c.z / cell, z = c.w / cell;
+        if (x >= 0 && x < D && y >= 0 && y < D && z >= 0 && z < D) marks[(size_t)c.x * D * D * D + (x * D + y) * D + z] = 1;
+    }
+}
+
+__global__ __launch_bounds__(kSelThreads) void init_select_kernel(const unsigned char *marks, int batch, int D,
+                                                                  int out_scale, int4 *out_coords,
                                                                   int32_t *n_out_dev)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -38,17 +53,7 @@ __global__ __launch_bounds__(kSelThreads) void init_select_kernel(const float *l
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
     int written = 0;
     for (int b = 0; b < batch; ++b) {
-        for (int i = tid; i < cells; i += kSelThreads) va[i] = 0;
-        __syncthreads();
-        for (int i = tid; i < n; i += kSelThreads) {
-            const int4 c = coords[i];
-            if (c.x != b) continue;
-            const float sig = 1.0f / (1.0f + expf(-logit[i]));
-            if (sig > thr) {
-                const int x = c.y / cell, y = c.z / cell, z = c.w / cell;
-                if (x >= 0 && x < D && y >= 0 && y < D && z >= 0 && z < D) va[(x * D + y) * D + z] = 1;
-            }
-        }
+        for (int i = tid; i < cells; i += kSelThreads) va[i] = marks[(size_t)b * cells + i];
         __syncthreads();
         for (int i = tid; i < cells; i += kSelThreads) {  // erode
             const int z = i % D, y = (i / D) % D, x = i / (D * D);
@@ -128,18 +133,31 @@ __global__ __launch_bounds__(256) void upsample_feat_kernel(const float *feat, i
 
 extern "C" {
 
+size_t eprecon_init_select_workspace_bytes(int batch, int dim)
+{
+    return align_up((size_t)batch * dim * dim * dim, 256);
+}
+
 int eprecon_init_select_async(const float *logit, const int32_t *coords, int64_t n, float threshold,
                               int batch, int dim, int cell, int32_t *out_coords, int32_t *n_out_dev,
-                              void *stream)
+                              void *workspace, size_t workspace_bytes, void *stream)
 {
-    if (n < 0 || batch <= 0 || dim <= 0 || dim > 40 || cell <= 0 || !out_coords || !n_out_dev ||
+    if (n < 0 || batch <= 0 || dim <= 0 || dim > 40 || cell <= 0 || !out_coords || !n_out_dev || !workspace ||
         (n > 0 && (!logit || !coords)))
         return EPRECON_ERR_ARG;
+    if (workspace_bytes < eprecon_init_select_workspace_bytes(batch, dim)) return EPRECON_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
     const int cells = dim * dim * dim;
+    unsigned char *marks = reinterpret_cast<unsigned char *>(workspace);
+    EP_HIP_CHECK(hipMemsetAsync(marks, 0, (size_t)batch * cells, st));
+    if (n > 0) {
+        hipLaunchKernelGGL(init_mark_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, logit,
+                           reinterpret_cast<const int4 *>(coords), (int)n, threshold, batch, dim, cell, marks);
+        EP_LAUNCH_CHECK();
+    }
     const size_t lds = 2 * (size_t)((cells + 15) & ~15) + (kSelThreads / kWave) * sizeof(int) + 16;
-    hipLaunchKernelGGL(init_select_kernel, dim3(1), dim3(kSelThreads), lds, (hipStream_t)stream, logit,
-                       reinterpret_cast<const int4 *>(coords), (int)n, threshold, batch, dim, cell, cell,
-                       reinterpret_cast<int4 *>(out_coords), n_out_dev);
+    hipLaunchKernelGGL(init_select_kernel, dim3(1), dim3(kSelThreads), lds, st, (const unsigned char *)marks, batch,
+                       dim, cell, reinterpret_cast<int4 *>(out_coords), n_out_dev);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }

@@ -7,56 +7,96 @@
 //                                                          models/occupancy_initialization.py:29,37
 //           nn.LayerNorm + ReLU + residual epilogues       models/modules.py:447-452,473-482
 //                                                          models/occupancy_initialization.py:141-169
-// Bandwidth-bound column / row reductions; deterministic (fixed-order partials, no float atomics).
+// Bandwidth-bound column / row reductions; deterministic (fixed-order Chan merges, no float atomics).
 #include "common.hpp"
 
 namespace {
 using namespace ep;
 
-constexpr int kBnRows = 1024;  // rows per block in the column-reduction passes
+constexpr int kBnPerThread = 8;  // rows each thread of the statistics kernel keeps in registers
 
-// partial[blk][c] = sum over the block's rows of f(x[r][c]);  SQ: f = (x - mean[c])^2, else f = x
-template <bool SQ>
-__global__ __launch_bounds__(256) void bn_partial_kernel(const float *x, int n, int C, int ld,
-                                                         const float *mean, float *partial)
+// Chan et al. merge of two (count, mean, M2) summaries — exact up to rounding, order fixed by the caller
+__device__ __forceinline__ void chan_merge(float &n_a, float &mean_a, float &m2_a, float n_b, float mean_b, float m2_b)
 {
-    __shared__ float sRed[256];
+    if (n_b == 0.0f) return;
+    if (n_a == 0.0f) {
+        n_a = n_b; mean_a = mean_b; m2_a = m2_b;
+        return;
+    }
+    const float n = n_a + n_b;
+    const float d = mean_b - mean_a;
+    mean_a = mean_a + d * (n_b / n);
+    m2_a = m2_a + m2_b + d * d * (n_a * n_b / n);
+    n_a = n;
+}
+
+// One pass over x: block b summarises rows [b*R, (b+1)*R) with R = kBnPerThread * (256 / C); every
+// thread owns one column and <= 8 rows held in registers (two-pass mean / M2 on those, no
+// cancellation), then the (256/C) row groups are merged through LDS in fixed order.
+// partial[b][0][c] = count, [1][c] = mean, [2][c] = M2.
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float *x, int n, int C, int ld, float *partial)
+{
+    __shared__ float sN[256], sMean[256], sM2[256];
     const int tid = threadIdx.x;
-    const int rpi = 256 / C;  // rows per iteration (C <= 256)
+    const int rpi = 256 / C;
     const int col = tid % C, rsub = tid / C;
     const bool active = rsub < rpi;
-    const int r0 = blockIdx.x * kBnRows;
-    const int r1 = min(n, r0 + kBnRows);
-    const float mu = (SQ && active) ? mean[col] : 0.0f;
-    float acc = 0.0f;
-    if (active) {
-        for (int r = r0 + rsub; r < r1; r += rpi) {
-            const float v = x[(size_t)r * ld + col];
-            if (SQ) {
-                const float d = v - mu;
-                acc = fmaf(d, d, acc);
-            } else {
-                acc += v;
-            }
+    const int r0 = blockIdx.x * (kBnPerThread * rpi);
+    float v[kBnPerThread];
+    float cnt = 0.0f, sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kBnPerThread; ++k) {
+        const int r = r0 + k * rpi + rsub;
+        const bool ok = active && r < n;
+        v[k] = ok ? x[(size_t)r * ld + col] : 0.0f;
+        cnt += ok ? 1.0f : 0.0f;
+        sum += v[k];
+    }
+    const float mean = cnt > 0.0f ? sum / cnt : 0.0f;
+    float m2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kBnPerThread; ++k) {
+        const int r = r0 + k * rpi + rsub;
+        if (active && r < n) {
+            const float d = v[k] - mean;
+            m2 = fmaf(d, d, m2);
         }
     }
-    sRed[tid] = active ? acc : 0.0f;
+    sN[tid] = cnt; sMean[tid] = mean; sM2[tid] = m2;
     __syncthreads();
     if (tid < C) {
-        float s = 0.0f;
-        for (int k = 0; k < rpi; ++k) s += sRed[k * C + tid];
-        partial[(size_t)blockIdx.x * C + tid] = s;
+        float a_n = 0.0f, a_mean = 0.0f, a_m2 = 0.0f;
+        for (int k = 0; k < rpi; ++k) chan_merge(a_n, a_mean, a_m2, sN[k * C + tid], sMean[k * C + tid], sM2[k * C + tid]);
+        float *p = partial + (size_t)blockIdx.x * 3 * C;
+        p[tid] = a_n; p[C + tid] = a_mean; p[2 * C + tid] = a_m2;
     }
 }
 
-// stat[c] = (sum_blk partial[blk][c]) / n
-__global__ void bn_finalize_kernel(const float *partial, int nblk, int C, int n, float *stat)
+// one workgroup per channel: thread t merges partials t, t+256, ... in order, then a fixed LDS tree
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *partial, int nblk, int C, float *mean_out,
+                                                          float *var_out)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.0f;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * C + c];
-    stat[c] = s / (float)n;
+    __shared__ float sN[256], sMean[256], sM2[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    float a_n = 0.0f, a_mean = 0.0f, a_m2 = 0.0f;
+    for (int b = tid; b < nblk; b += 256) {
+        const float *p = partial + (size_t)b * 3 * C;
+        chan_merge(a_n, a_mean, a_m2, p[c], p[C + c], p[2 * C + c]);
+    }
+    sN[tid] = a_n; sMean[tid] = a_mean; sM2[tid] = a_m2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            float n = sN[tid], m = sMean[tid], q = sM2[tid];
+            chan_merge(n, m, q, sN[tid + s], sMean[tid + s], sM2[tid + s]);
+            sN[tid] = n; sMean[tid] = m; sM2[tid] = q;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        mean_out[c] = sMean[0];
+        var_out[c] = sN[0] > 0.0f ? sM2[0] / sN[0] : 0.0f;  // biased variance
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float *x, int n, int C, int ld_x,
@@ -124,13 +164,17 @@ __global__ __launch_bounds__(256) void rowwise_ln_kernel(const float *x, int n, 
 
 extern "C" {
 
+static inline int bn_rows_per_block(int channels) { return kBnPerThread * (256 / channels); }
+
 size_t eprecon_batchnorm_workspace_bytes(int64_t n, int channels)
 {
-    const size_t nblk = (size_t)ceil_div(n > 0 ? n : 1, kBnRows);
-    return align_up(nblk * channels * sizeof(float), 256) + 2 * align_up((size_t)channels * sizeof(float), 256);
+    if (channels <= 0 || channels > 256) return 0;
+    const size_t nblk = (size_t)ceil_div(n > 0 ? n : 1, bn_rows_per_block(channels));
+    return align_up(nblk * 3 * channels * sizeof(float), 256) + 2 * align_up((size_t)channels * sizeof(float), 256);
 }
 
-// Train-mode BatchNorm over the n rows: mean, biased variance (two-pass), affine, optional residual
+// Train-mode BatchNorm over the n rows: one statistics pass (per-block (count, mean, M2) merged
+// with Chan's formula in fixed order -> deterministic, no cancellation), affine, optional residual
 // add and ReLU.  out may alias x.  mean_out / var_out (optional, device) receive the statistics.
 int eprecon_batchnorm_train_async(const float *x, int64_t n, int channels, int ld_x, const float *gamma,
                                   const float *beta, float eps, const float *residual, int ld_res,
@@ -143,23 +187,17 @@ int eprecon_batchnorm_train_async(const float *x, int64_t n, int channels, int l
     if (workspace_bytes < eprecon_batchnorm_workspace_bytes(n, channels)) return EPRECON_ERR_WORKSPACE;
     if (n == 0) return EPRECON_OK;
     hipStream_t st = (hipStream_t)stream;
-    const int nblk = (int)ceil_div(n, kBnRows);
+    const int nblk = (int)ceil_div(n, bn_rows_per_block(channels));
     char *ws = reinterpret_cast<char *>(workspace);
     float *partial = reinterpret_cast<float *>(ws);
-    ws += align_up((size_t)nblk * channels * sizeof(float), 256);
+    ws += align_up((size_t)nblk * 3 * channels * sizeof(float), 256);
     float *mean = mean_out ? mean_out : reinterpret_cast<float *>(ws);
     ws += align_up((size_t)channels * sizeof(float), 256);
     float *var = var_out ? var_out : reinterpret_cast<float *>(ws);
-    const dim3 fgrid((channels + 63) / 64), fblock(64);
-    hipLaunchKernelGGL((bn_partial_kernel<false>), dim3(nblk), dim3(256), 0, st, x, (int)n, channels, ld_x,
-                       (const float *)nullptr, partial);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(256), 0, st, x, (int)n, channels, ld_x, partial);
     EP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_kernel, fgrid, fblock, 0, st, partial, nblk, channels, (int)n, mean);
-    EP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((bn_partial_kernel<true>), dim3(nblk), dim3(256), 0, st, x, (int)n, channels, ld_x,
-                       (const float *)mean, partial);
-    EP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_kernel, fgrid, fblock, 0, st, partial, nblk, channels, (int)n, var);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(channels), dim3(256), 0, st, (const float *)partial, nblk, channels,
+                       mean, var);
     EP_LAUNCH_CHECK();
     const size_t total = (size_t)n * channels;
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div((int64_t)total, 256)), dim3(256), 0, st, x,

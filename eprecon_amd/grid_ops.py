@@ -15,9 +15,10 @@ def init_select(logit, coords, batch_size, dim=24, cell=4, threshold=0.3):
     dev = coords.device
     out = torch.empty((batch_size * dim ** 3, 4), dtype=torch.int32, device=dev)
     counts = torch.zeros(1 + batch_size, dtype=torch.int32, device=dev)
+    ws = _lib.workspace(lib.eprecon_init_select_workspace_bytes(batch_size, dim), dev)
     _lib.check(lib.eprecon_init_select_async(_lib.ptr(logit), _lib.ptr(coords), coords.shape[0],
                                              float(threshold), batch_size, dim, cell, _lib.ptr(out),
-                                             _lib.ptr(counts), _lib.current_stream()),
+                                             _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
                "eprecon_init_select_async")
     host = counts.cpu().tolist()
     return out[: host[0]], host[1:]

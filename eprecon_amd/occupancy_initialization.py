@@ -8,6 +8,8 @@ seen by >= min_view views (HIP: hash-grid kernel map built once, MFMA gather-GEM
 fused normalisation epilogues).  Returns [occupancy logit f32[N_valid,1], coords[N_valid,4],
 count f32[N]] or None when a batch element has fewer than 1000 valid voxels (:107-108).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -44,6 +46,10 @@ class Occupancy_Initialization(nn.Module):
         self.norm3 = _RowLayerNorm(d)
         self.subm4 = SparseSubMConv3d(d, 1, 3)
         self.norm4 = TrainBatchNorm1d(1)
+        # The 2D fusion stack is ~60 small MIOpen / elementwise launches on static shapes: under
+        # torch.no_grad() it is captured once into a HIP graph and replayed (launch-bound otherwise).
+        self.use_hip_graph = os.environ.get("EPRECON_NO_GRAPH", "0") != "1"
+        self._graphs = {}
 
     def feat_fusion_pre(self, feats_1x, feats_2x, feats_4x):
         """[V,80,H/16,W/16], [V,40,H/8,W/8], [V,24,H/4,W/4] -> [V,32,H/8,W/8]  (:41-58)"""
@@ -54,6 +60,32 @@ class Occupancy_Initialization(nn.Module):
         for blk in (self.post_fusion_1, self.post_fusion_2, self.post_fusion_3, self.post_fusion_4):
             x = blk(x)
         return x
+
+    def _fusion_graphed(self, f1, f2, f4):
+        """feat_fusion_pre through a captured HIP graph (inference only; the result buffer is reused
+        by the next call, the caller consumes it immediately)"""
+        key = (tuple(f1.shape), tuple(f2.shape), tuple(f4.shape), f1.device)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static_in = [torch.empty_like(t) for t in (f1, f2, f4)]
+            for s_, t in zip(static_in, (f1, f2, f4)):
+                s_.copy_(t)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):  # MIOpen solver selection happens outside the capture
+                    self.feat_fusion_pre(*static_in)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self.feat_fusion_pre(*static_in)
+            entry = (graph, static_in, static_out)
+            self._graphs[key] = entry
+        graph, static_in, static_out = entry
+        for s_, t in zip(static_in, (f1, f2, f4)):
+            s_.copy_(t)
+        graph.replay()
+        return static_out
 
     def sparse_stack(self, var, vset):
         """variance volume f32[N,32] on the voxel set -> occupancy logit f32[N,1]  (:131-174)"""
@@ -70,8 +102,13 @@ class Occupancy_Initialization(nn.Module):
         feats_2x = torch.stack([f[1] for f in features_all])  # [V,B,40,2h,2w] 1/8
         feats_4x = torch.stack([f[0] for f in features_all])  # [V,B,24,4h,4w] 1/4
         bs = feats_1x.shape[1]
-        fused = torch.stack([self.feat_fusion_pre(feats_1x[:, b], feats_2x[:, b], feats_4x[:, b])
-                             for b in range(bs)], dim=1)       # [V,B,32,H,W] at the `stage` resolution
+        graphed = self.use_hip_graph and not torch.is_grad_enabled() and feats_1x.is_cuda
+        fuse = self._fusion_graphed if graphed else self.feat_fusion_pre
+        if bs == 1:
+            fused = fuse(feats_1x[:, 0], feats_2x[:, 0], feats_4x[:, 0]).unsqueeze(1)  # [V,1,32,H,W] view
+        else:
+            fused = torch.stack([fuse(feats_1x[:, b].contiguous(), feats_2x[:, b].contiguous(),
+                                      feats_4x[:, b].contiguous()).clone() for b in range(bs)], dim=1)
         res = BP.view_variance(coords, origin, voxel_size, fused, KRcam, min_view_number,
                                min_valid=INIT_MIN_VALID)
         if res is None:

@@ -205,9 +205,10 @@ int eprecon_rowwise_layernorm_async(const float *x, int64_t n, int channels, int
  * (b, cell*x, cell*y, cell*z).  coords int32[n,4] are the valid voxels the logits belong to.
  * out_coords int32[batch*dim^3, 4]; n_out_dev int32[1 + batch] ([0] total, [1+b] per batch).
  */
+size_t eprecon_init_select_workspace_bytes(int batch, int dim);
 int eprecon_init_select_async(const float *logit, const int32_t *coords, int64_t n, float threshold,
                               int batch, int dim, int cell, int32_t *out_coords, int32_t *n_out_dev,
-                              void *stream);
+                              void *workspace, size_t workspace_bytes, void *stream);
 /*
  * NeuConNet.upsample (models/neucon_network.py:193-214): up_coords int32[8n,4], up_feat f32[8n,C];
  * children of a voxel are consecutive, in the order 0, +x, +y, +z, +xy, +xz, +yz, +xyz (x `interval`).
