@@ -44,6 +44,8 @@ struct BpParams {
     uint8_t *out_mask;
     int32_t *n_valid_dev;  // [1 + B]
     int32_t *block_offsets;
+    const int32_t *perm;   // brick-sorted voxel order (sorted pipeline) or nullptr
+    const int32_t *slot;   // output row of every voxel (sorted pipeline) or nullptr
 };
 
 struct Proj {
@@ -67,6 +69,43 @@ __device__ __forceinline__ Proj project(const float *P, float X, float Y, float 
     r.pz = pz;
     r.vis = (fabsf(r.gx) <= 1.0f) && (fabsf(r.gy) <= 1.0f) && (pz > 0.0f);
     return r;
+}
+
+// Cheap projection with bit-exact visibility.  The fma chains for (px, py, pz) are the contract's;
+// the three IEEE divisions per axis are replaced by one v_rcp_f32 + Newton step, and the exact
+// sequence is re-evaluated only when the cheap normalised coordinate lands within 1e-4 of the
+// frustum boundary |g| = 1 (the cheap value is within 1e-6 of the exact one, so outside that band
+// both agree).  u, v are the pixel coordinates used for sampling (<= 1e-5 px from the reference's
+// grid -> pixel round trip), clamped into the image.
+struct ProjFast {
+    float u, v, pz;
+    bool vis;
+};
+
+__device__ __forceinline__ ProjFast project_fast(const float *P, float X, float Y, float Z, float wm1, float hm1,
+                                                 float kx, float ky)
+{
+    const float px = __fmaf_rn(P[3], 1.0f, __fmaf_rn(P[2], Z, __fmaf_rn(P[1], Y, __fmul_rn(P[0], X))));
+    const float py = __fmaf_rn(P[7], 1.0f, __fmaf_rn(P[6], Z, __fmaf_rn(P[5], Y, __fmul_rn(P[4], X))));
+    const float pz = __fmaf_rn(P[11], 1.0f, __fmaf_rn(P[10], Z, __fmaf_rn(P[9], Y, __fmul_rn(P[8], X))));
+    float r = __builtin_amdgcn_rcpf(pz);
+    r = r * fmaf(-pz, r, 2.0f);
+    const float u = px * r, v = py * r;
+    const float gx = fmaf(u, kx, -1.0f), gy = fmaf(v, ky, -1.0f);
+    ProjFast o;
+    o.pz = pz;
+    const bool near_edge = fabsf(fabsf(gx) - 1.0f) < 1e-4f || fabsf(fabsf(gy) - 1.0f) < 1e-4f;
+    if (near_edge) {
+        const float ue = __fdiv_rn(px, pz), ve = __fdiv_rn(py, pz);
+        const float gxe = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, ue), wm1), 1.0f);
+        const float gye = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, ve), hm1), 1.0f);
+        o.vis = (fabsf(gxe) <= 1.0f) && (fabsf(gye) <= 1.0f) && (pz > 0.0f);
+    } else {
+        o.vis = (fabsf(gx) <= 1.0f) && (fabsf(gy) <= 1.0f) && (pz > 0.0f);
+    }
+    o.u = fminf(fmaxf(u, 0.0f), wm1);
+    o.v = fminf(fmaxf(v, 0.0f), hm1);
+    return o;
 }
 
 __device__ __forceinline__ void voxel_centre(const int4 c, const float *origin, float vs, float &X,
@@ -115,28 +154,123 @@ __global__ __launch_bounds__(256) void bp_count_kernel(BpParams p, int32_t *tile
             float X, Y, Z;
             voxel_centre(c, p.origin, p.voxel_size, X, Y, Z);
             const float wm1 = (float)(p.W - 1), hm1 = (float)(p.H - 1);
+            const float kx = 2.0f / wm1, ky = 2.0f / hm1;
             for (int v = 0; v < p.V; ++v)
-                cnt += project(sP + (v * p.batch + c.x) * 12, X, Y, Z, wm1, hm1).vis ? 1 : 0;
+                cnt += project_fast(sP + (v * p.batch + c.x) * 12, X, Y, Z, wm1, hm1, kx, ky).vis ? 1 : 0;
         }
         p.count[i] = (float)cnt;
         valid = in_range && cnt >= p.min_view;
         if (valid) atomicAdd(&sBatch[c.x], 1);
     }
-    if (VOX == 256) {
-        int total;
-        block_exclusive_rank<BLOCK>(valid, sWave, total);
-        if (tid == 0) tile_sums[blockIdx.x] = total;
-    } else {
-        const unsigned long long m = __ballot(valid);
-        const int lane = tid & (kWave - 1);
-        if ((lane % VOX) == 0 && i < p.n) {
-            const unsigned long long seg = (VOX == 64) ? m : ((m >> lane) & ((1ull << VOX) - 1ull));
-            tile_sums[i / VOX] = __popcll(seg);
+    const unsigned long long m = __ballot(valid);
+    const int lane = tid & (kWave - 1);
+    if (VOX >= kWave) {
+        // tile = VOX / 64 whole waves: per-wave popcounts through LDS
+        if (lane == 0) sWave[tid / kWave] = __popcll(m);
+        __syncthreads();
+        constexpr int WPT = VOX / kWave;  // waves per tile
+        if (tid < BLOCK / VOX) {
+            int t = 0;
+            for (int w = 0; w < WPT; ++w) t += sWave[tid * WPT + w];
+            const int tile = blockIdx.x * (BLOCK / VOX) + tid;
+            if ((long long)tile * VOX < p.n) tile_sums[tile] = t;
         }
+    } else {
+        if ((lane % VOX) == 0 && i < p.n) tile_sums[i / VOX] = __popcll((m >> lane) & ((1ull << VOX) - 1ull));
         __syncthreads();
     }
     for (int b = tid; b < p.batch; b += BLOCK)
         if (sBatch[b]) atomicAdd(&p.n_valid_dev[1 + b], sBatch[b]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Brick-sorted pipeline (long lists): voxels are binned by 3D brick so that one gather tile holds
+// spatial neighbours.  Bin = (brick coordinate mod 32 per axis, batch); aliasing of far-apart bricks
+// only costs locality, never correctness.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBinsPerBatch = 32 * 32 * 32;
+
+__device__ __forceinline__ int brick_bin(const int4 c, int brick_shift)
+{
+    const int bx = (c.y >> brick_shift) & 31, by = (c.z >> brick_shift) & 31, bz = (c.w >> brick_shift) & 31;
+    return c.x * kBinsPerBatch + (bx * 32 + by) * 32 + bz;
+}
+
+// wave-aggregated atomicAdd(counter[bin], 1): lanes holding the same bin in a run of consecutive
+// lanes (raster-ordered lists give runs of 8+) issue ONE atomic; returns this lane's position
+__device__ __forceinline__ int run_aggregated_add(int32_t *counter, int bin, bool active)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int prev = __shfl_up(bin, 1);
+    const bool prev_active = __shfl_up((int)active, 1) != 0;
+    const bool head = active && (lane == 0 || !prev_active || prev != bin);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long actives = __ballot(active);
+    if (!active) return 0;
+    const unsigned long long below = heads & ((2ull << lane) - 1ull);
+    const int leader = 63 - __clzll(below);
+    // run = [leader, next head or first inactive lane after leader)
+    const unsigned long long after = (heads | ~actives) & ~((2ull << leader) - 1ull);
+    const int run_end = after ? (__ffsll((long long)after) - 1) : kWave;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&counter[bin], run_end - leader);
+    base = __shfl(base, leader);
+    return base + (lane - leader);
+}
+
+__global__ __launch_bounds__(256) void bp_count_sorted_kernel(BpParams p, int brick_shift, int32_t *flag,
+                                                              int32_t *hist)
+{
+    constexpr int BLOCK = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *sP = reinterpret_cast<float *>(smem);
+    int *sBatch = reinterpret_cast<int *>(sP + p.V * p.batch * 12);
+    const int tid = threadIdx.x;
+    stage_matrices(sP, p.krcam, p.V * p.batch, tid, BLOCK);
+    for (int b = tid; b < p.batch; b += BLOCK) sBatch[b] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * BLOCK + tid;
+    bool in_range = false;
+    int bin = 0;
+    if (i < p.n) {
+        const int4 c = reinterpret_cast<const int4 *>(p.coords)[i];
+        int cnt = 0;
+        in_range = c.x >= 0 && c.x < p.batch;
+        if (in_range) {
+            float X, Y, Z;
+            voxel_centre(c, p.origin, p.voxel_size, X, Y, Z);
+            const float wm1 = (float)(p.W - 1), hm1 = (float)(p.H - 1);
+            const float kx = 2.0f / wm1, ky = 2.0f / hm1;
+            for (int v = 0; v < p.V; ++v)
+                cnt += project_fast(sP + (v * p.batch + c.x) * 12, X, Y, Z, wm1, hm1, kx, ky).vis ? 1 : 0;
+            bin = brick_bin(c, brick_shift);
+        }
+        p.count[i] = (float)cnt;
+        const bool valid = in_range && cnt >= p.min_view;
+        flag[i] = valid ? 1 : 0;
+        if (valid) atomicAdd(&sBatch[c.x], 1);
+    }
+    run_aggregated_add(hist, bin, in_range);  // every in-range voxel is binned (invalid ones are cheap)
+    __syncthreads();
+    for (int b = tid; b < p.batch; b += BLOCK)
+        if (sBatch[b]) atomicAdd(&p.n_valid_dev[1 + b], sBatch[b]);
+}
+
+__global__ __launch_bounds__(256) void bp_bin_fill_kernel(const int4 *coords, int n, int batch, int brick_shift,
+                                                          const int32_t *bin_offset, int32_t *cursor,
+                                                          int32_t *perm, int32_t *n_binned)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool in_range = false;
+    int bin = 0;
+    if (i < n) {
+        const int4 c = coords[i];
+        in_range = c.x >= 0 && c.x < batch;
+        if (in_range) bin = brick_bin(c, brick_shift);
+    }
+    const int pos = run_aggregated_add(cursor, bin, in_range);
+    if (in_range) perm[bin_offset[bin] + pos] = i;
+    (void)n_binned;
 }
 
 // exclusive scan of the block totals, one workgroup; also publishes n_valid
@@ -259,7 +393,7 @@ struct Chan<1> {
 };
 
 // QT > 0: channel groups per voxel known at compile time (fast div/mod); QT == 0: runtime
-template <int VOX, int MODE, int VEC, int QT>
+template <int VOX, int MODE, int VEC, int QT, bool SORTED>
 __global__ __launch_bounds__(256) void bp_gather_kernel(BpParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -272,21 +406,25 @@ __global__ __launch_bounds__(256) void bp_gather_kernel(BpParams p)
     float *sDen = reinterpret_cast<float *>(sVis + VOX);                 // [VOX] divisor
     int *sBatch = reinterpret_cast<int *>(sDen + VOX);                   // [VOX] batch index
     int *sSlot = sBatch + VOX;                                           // [VOX] rank -> thread
-    int *sWave = sSlot + VOX;                                            // [BLOCK/64]
+    int *sOut = sSlot + VOX;                                             // [VOX] thread -> output row
+    int *sWave = sOut + VOX;                                             // [BLOCK/64]
 
     const int tid = threadIdx.x;
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
     stage_matrices(sP, p.krcam, p.V * p.batch, tid, BLOCK);
     __syncthreads();
 
-    const int i = lb * VOX + tid;
+    // SORTED: the tile is 256 consecutive entries of the brick-sorted permutation (voxels that are
+    // neighbours in space, so their taps share cache lines); otherwise 256 consecutive input rows
+    const int e = lb * VOX + tid;
+    const int i = (SORTED && tid < VOX && e < p.n) ? p.perm[e] : e;
     const float wm1 = (float)(p.W - 1), hm1 = (float)(p.H - 1);
     bool valid = false;
     int4 c = make_int4(0, 0, 0, 0);
     float X = 0.f, Y = 0.f, Z = 0.f, zsum = 0.f;
     int cnt = 0;
     uint32_t vis = 0;
-    if (tid < VOX && i < p.n) {
+    if (tid < VOX && e < p.n) {
         c = reinterpret_cast<const int4 *>(p.coords)[i];
         if (c.x >= 0 && c.x < p.batch) {
             voxel_centre(c, p.origin, p.voxel_size, X, Y, Z);
@@ -308,12 +446,13 @@ __global__ __launch_bounds__(256) void bp_gather_kernel(BpParams p)
     int nloc;
     const int rank = block_exclusive_rank<BLOCK>(valid, sWave, nloc);
     if (nloc == 0) return;
-    const int base = p.block_offsets[lb];
+    const int base = SORTED ? 0 : p.block_offsets[lb];
     const int n_valid = p.n_valid_dev[0];
     const int cout = (MODE == EPRECON_BP_MEAN_DEPTH) ? p.C + 1 : p.C;
     if (valid) {
-        const int o = base + rank;
+        const int o = SORTED ? p.slot[i] : base + rank;
         sSlot[rank] = tid;
+        sOut[tid] = o;
         sVis[tid] = vis;
         const float den = (float)(cnt > 0 ? cnt : 1);
         sDen[tid] = den;
@@ -351,7 +490,8 @@ __global__ __launch_bounds__(256) void bp_gather_kernel(BpParams p)
                 acc.add(Chan<VEC>::sample(fb + (size_t)v * vstride, tp));
             }
         }
-        float *dst = p.out_feats + (size_t)(base + r) * cout + q * VEC;
+        const int orow = sOut[t];
+        float *dst = p.out_feats + (size_t)orow * cout + q * VEC;
         if (MODE == EPRECON_BP_VARIANCE) {
             // models/occupancy_initialization.py:127-128: population variance over visible views
             const Chan<VEC> mean = acc.div(den);
@@ -364,12 +504,228 @@ __global__ __launch_bounds__(256) void bp_gather_kernel(BpParams p)
                 }
             }
             sq.div(den).store(dst, true);
-            if (p.out_mean) mean.store(p.out_mean + (size_t)(base + r) * p.C + q * VEC, true);
+            if (p.out_mean) mean.store(p.out_mean + (size_t)orow * p.C + q * VEC, true);
         } else {
             acc.div(den).store(dst, aligned16);
         }
     }
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// K2 + K3 (+K4), main variant (C % 8 == 0, lists >= 48k voxels): 128 voxels per 256-thread tile.
+//   phase 1a  one thread per (voxel, view) pair: cheap projection, bilinear tap offset + weights
+//             -> LDS (computed once per pair instead of once per channel group)
+//   phase 1b  one thread per voxel: visible count, validity, stable in-tile compaction / output row
+//   phase 2   one thread per (valid voxel, 8 channels): per visible view 8 x 16-byte buffer loads
+//             with 32-bit offsets and 32 fma into 8 accumulators; mean or two-sweep variance
+// ---------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct Acc8 {
+    float a[8];
+};
+
+__device__ __forceinline__ void tap8(__amdgpu_buffer_rsrc_t rsrc, int byte_off, float w, Acc8 &s)
+{
+    const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+    const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off + 16, 0, 0);
+    s.a[0] = fmaf(__uint_as_float(lo.x), w, s.a[0]);
+    s.a[1] = fmaf(__uint_as_float(lo.y), w, s.a[1]);
+    s.a[2] = fmaf(__uint_as_float(lo.z), w, s.a[2]);
+    s.a[3] = fmaf(__uint_as_float(lo.w), w, s.a[3]);
+    s.a[4] = fmaf(__uint_as_float(hi.x), w, s.a[4]);
+    s.a[5] = fmaf(__uint_as_float(hi.y), w, s.a[5]);
+    s.a[6] = fmaf(__uint_as_float(hi.z), w, s.a[6]);
+    s.a[7] = fmaf(__uint_as_float(hi.w), w, s.a[7]);
+}
+
+template <int MODE, int Q8, bool SORTED>
+__global__ __launch_bounds__(256) void bp_gather8_kernel(BpParams p)
+{
+    constexpr int VOX = 128, BLOCK = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *sW = reinterpret_cast<float4 *>(smem);                        // [VOX*V] tap weights
+    int *sOff = reinterpret_cast<int *>(sW + VOX * p.V);                  // [VOX*V] element offset of tap 00
+    float *sP = reinterpret_cast<float *>(sOff + VOX * p.V);              // [V*B][12]
+    const int nP = (p.V * p.batch * 12 + 3) & ~3;
+    uint32_t *sVis = reinterpret_cast<uint32_t *>(sP + nP);               // [VOX]
+    int *sSlot = reinterpret_cast<int *>(sVis + VOX);                     // [VOX] rank -> voxel
+    int *sOut = sSlot + VOX;                                              // [VOX] voxel -> output row
+    int *sWave = sOut + VOX;                                              // [BLOCK/64]
+
+    const int tid = threadIdx.x;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    stage_matrices(sP, p.krcam, p.V * p.batch, tid, BLOCK);
+    if (tid < VOX) sVis[tid] = 0;
+    __syncthreads();
+
+    const float wm1 = (float)(p.W - 1), hm1 = (float)(p.H - 1);
+    const float kx = 2.0f / wm1, ky = 2.0f / hm1;
+    const int map_elems = p.H * p.W * p.C;
+    const int row_elems = p.W * p.C;
+    // ---- phase 1a ----
+    for (int pr = tid; pr < VOX * p.V; pr += BLOCK) {
+        const int vx = pr / p.V, v = pr - vx * p.V;
+        const int e = lb * VOX + vx;
+        if (e >= p.n) continue;
+        const int i = SORTED ? p.perm[e] : e;
+        const int4 c = reinterpret_cast<const int4 *>(p.coords)[i];
+        if (c.x < 0 || c.x >= p.batch) continue;
+        float X, Y, Z;
+        voxel_centre(c, p.origin, p.voxel_size, X, Y, Z);
+        const ProjFast q = project_fast(sP + (v * p.batch + c.x) * 12, X, Y, Z, wm1, hm1, kx, ky);
+        if (!q.vis) continue;
+        // taps: clamp the base pixel to [0, W-2] so that all four taps are inside the image; at
+        // ix = W-1 this gives weights (0, 1) on (W-2, W-1) = the reference's value
+        const float x0f = fminf(floorf(q.u), wm1 - 1.0f), y0f = fminf(floorf(q.v), hm1 - 1.0f);
+        const float wx1 = q.u - x0f, wx0 = (x0f + 1.0f) - q.u;
+        const float wy1 = q.v - y0f, wy0 = (y0f + 1.0f) - q.v;
+        sW[pr] = make_float4(wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1);
+        sOff[pr] = (v * p.batch + c.x) * map_elems + ((int)y0f * p.W + (int)x0f) * p.C;
+        atomicOr(&sVis[vx], 1u << v);
+    }
+    __syncthreads();
+    // ---- phase 1b ----
+    bool valid = false;
+    int4 c = make_int4(0, 0, 0, 0);
+    int i = 0, cnt = 0;
+    {
+        const int e = lb * VOX + tid;
+        if (tid < VOX && e < p.n) {
+            i = SORTED ? p.perm[e] : e;
+            c = reinterpret_cast<const int4 *>(p.coords)[i];
+            cnt = __popc(sVis[tid]);
+            valid = c.x >= 0 && c.x < p.batch && cnt >= p.min_view;
+        }
+    }
+    int nloc;
+    const int rank = block_exclusive_rank<BLOCK>(valid, sWave, nloc);
+    if (nloc == 0) return;
+    const int n_valid = p.n_valid_dev[0];
+    const int cout = (MODE == EPRECON_BP_MEAN_DEPTH) ? p.C + 1 : p.C;
+    if (valid) {
+        const int o = SORTED ? p.slot[i] : p.block_offsets[lb] + rank;
+        sSlot[rank] = tid;
+        sOut[tid] = o;
+        reinterpret_cast<int4 *>(p.out_coords)[o] = c;
+        if (MODE == EPRECON_BP_MEAN_DEPTH || p.out_grid || p.out_mask) {
+            float X, Y, Z, zsum = 0.0f;
+            voxel_centre(c, p.origin, p.voxel_size, X, Y, Z);
+            for (int v = 0; v < p.V; ++v) {
+                const Proj pr = project(sP + (v * p.batch + c.x) * 12, X, Y, Z, wm1, hm1);
+                if (pr.vis) zsum += pr.pz;
+                if (p.out_grid)
+                    reinterpret_cast<float2 *>(p.out_grid)[(size_t)v * n_valid + o] = make_float2(pr.gx, pr.gy);
+                if (p.out_mask) p.out_mask[(size_t)v * n_valid + o] = pr.vis ? 1 : 0;
+            }
+            if (MODE == EPRECON_BP_MEAN_DEPTH)
+                p.out_feats[(size_t)o * cout + p.C] = __fdiv_rn(zsum, (float)(cnt > 0 ? cnt : 1));
+        }
+    }
+    __syncthreads();
+    // ---- phase 2 ----
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.feats_nhwc), 0, p.V * p.batch * map_elems * 4, 0x00020000);
+    for (int w = tid; w < nloc * Q8; w += BLOCK) {
+        const int r = w / Q8, q = w - r * Q8;
+        const int t = sSlot[r];
+        const uint32_t vm = sVis[t];
+        const float den = (float)max(__popc(vm), 1);
+        Acc8 acc;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc.a[k] = 0.0f;
+        for (int v = 0; v < p.V; ++v) {
+            if (vm & (1u << v)) {
+                const float4 wt = sW[t * p.V + v];
+                const int b0 = (sOff[t * p.V + v] + q * 8) * 4;
+                tap8(rsrc, b0, wt.x, acc);
+                tap8(rsrc, b0 + p.C * 4, wt.y, acc);
+                tap8(rsrc, b0 + row_elems * 4, wt.z, acc);
+                tap8(rsrc, b0 + (row_elems + p.C) * 4, wt.w, acc);
+            }
+        }
+        const int orow = sOut[t];
+        float *dst = p.out_feats + (size_t)orow * cout + q * 8;
+        float res[8];
+        if (MODE == EPRECON_BP_VARIANCE) {
+            float mean[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mean[k] = __fdiv_rn(acc.a[k], den);
+            Acc8 sq;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sq.a[k] = 0.0f;
+            for (int v = 0; v < p.V; ++v) {
+                if (vm & (1u << v)) {
+                    const float4 wt = sW[t * p.V + v];
+                    const int b0 = (sOff[t * p.V + v] + q * 8) * 4;
+                    Acc8 smp;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) smp.a[k] = 0.0f;
+                    tap8(rsrc, b0, wt.x, smp);
+                    tap8(rsrc, b0 + p.C * 4, wt.y, smp);
+                    tap8(rsrc, b0 + row_elems * 4, wt.z, smp);
+                    tap8(rsrc, b0 + (row_elems + p.C) * 4, wt.w, smp);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float d = smp.a[k] - mean[k];
+                        sq.a[k] = fmaf(d, d, sq.a[k]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) res[k] = __fdiv_rn(sq.a[k], den);
+            if (p.out_mean) {
+                float *dm = p.out_mean + (size_t)orow * p.C + q * 8;
+                *reinterpret_cast<float4 *>(dm) = make_float4(mean[0], mean[1], mean[2], mean[3]);
+                *reinterpret_cast<float4 *>(dm + 4) = make_float4(mean[4], mean[5], mean[6], mean[7]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) res[k] = __fdiv_rn(acc.a[k], den);
+        }
+        if (MODE != EPRECON_BP_MEAN_DEPTH) {
+            *reinterpret_cast<float4 *>(dst) = make_float4(res[0], res[1], res[2], res[3]);
+            *reinterpret_cast<float4 *>(dst + 4) = make_float4(res[4], res[5], res[6], res[7]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dst[k] = res[k];
+        }
+    }
+}
+
+size_t gather8_lds_bytes(int V, int B)
+{
+    const size_t nP = ((size_t)V * B * 12 + 3) & ~(size_t)3;
+    return (size_t)128 * V * 20 + nP * 4 + (size_t)128 * 3 * 4 + (256 / kWave) * 4 + 16;
+}
+
+template <int MODE, bool SORTED>
+int launch_gather8(const BpParams &p, hipStream_t st)
+{
+    const int ntile = (int)ceil_div(p.n, 128);
+    const size_t lds = gather8_lds_bytes(p.V, p.batch);
+    const dim3 grid(ntile), block(256);
+    switch (p.C / 8) {
+        case 3: hipLaunchKernelGGL((bp_gather8_kernel<MODE, 3, SORTED>), grid, block, lds, st, p); break;   // C = 24
+        case 4: hipLaunchKernelGGL((bp_gather8_kernel<MODE, 4, SORTED>), grid, block, lds, st, p); break;   // C = 32
+        case 5: hipLaunchKernelGGL((bp_gather8_kernel<MODE, 5, SORTED>), grid, block, lds, st, p); break;   // C = 40
+        case 10: hipLaunchKernelGGL((bp_gather8_kernel<MODE, 10, SORTED>), grid, block, lds, st, p); break; // C = 80
+        default: return EPRECON_ERR_UNSUPPORTED;
+    }
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+template <bool SORTED>
+int launch_gather8_mode(const BpParams &p, int mode, hipStream_t st)
+{
+    return mode == EPRECON_BP_MEAN ? launch_gather8<EPRECON_BP_MEAN, SORTED>(p, st)
+         : mode == EPRECON_BP_MEAN_DEPTH ? launch_gather8<EPRECON_BP_MEAN_DEPTH, SORTED>(p, st)
+                                         : launch_gather8<EPRECON_BP_VARIANCE, SORTED>(p, st);
+}
+
+bool gather8_supported(int C) { return C == 24 || C == 32 || C == 40 || C == 80; }
 
 // ops/back_project.py:69-75 — per batch element: mu = mean(d[d>0]); sigma = ||d[d>0]-mu||_2 + 1e-5;
 // d_hat = (d-mu)/sigma, 0 where d <= 0.  One workgroup per batch element, three sweeps.
@@ -444,20 +800,21 @@ struct ProfileState {
     bool on = false, recorded = false;
     hipEvent_t start = nullptr, stop = nullptr;
 } g_prof;
+bool g_sorted_enabled = true;
 
 size_t gather_lds_bytes(int vox, int V, int B)
 {
     const size_t nP = ((size_t)V * B * 12 + 3) & ~(size_t)3;
-    return (size_t)vox * V * sizeof(float2) + nP * sizeof(float) + (size_t)vox * 4 * 4 +
+    return (size_t)vox * V * sizeof(float2) + nP * sizeof(float) + (size_t)vox * 5 * 4 +
            (size_t)(256 / kWave) * 4 + 16;
 }
 
-template <int VOX, int MODE>
+template <int VOX, int MODE, bool SORTED = false>
 int launch_gather(const BpParams &p, int nblk, hipStream_t st)
 {
     const size_t lds = gather_lds_bytes(VOX, p.V, p.batch);
     const dim3 grid(nblk), block(256);
-#define EP_GATHER(VEC, QT) hipLaunchKernelGGL((bp_gather_kernel<VOX, MODE, VEC, QT>), grid, block, lds, st, p)
+#define EP_GATHER(VEC, QT) hipLaunchKernelGGL((bp_gather_kernel<VOX, MODE, VEC, QT, SORTED>), grid, block, lds, st, p)
     if (p.C % 4 == 0) {
         switch (p.C / 4) {
             case 6: EP_GATHER(4, 6); break;    // C = 24  (1/4-res level)
@@ -485,6 +842,10 @@ size_t eprecon_back_project_workspace_bytes(int64_t n, int batch, int n_views, i
                                             int height, int width, int feats_layout)
 {
     size_t bytes = ep::align_up((size_t)ep::ceil_div(n > 0 ? n : 1, 16) * sizeof(int32_t), 256);
+    // brick-sorted pipeline: flag / slot / perm (N ints each), histogram + bin offsets, scan scratch
+    bytes += 3 * ep::align_up((size_t)(n > 0 ? n : 1) * 4, 256) +
+             2 * ep::align_up((size_t)kBinsPerBatch * (batch > 0 ? batch : 1) * 4, 256) +
+             ep::align_up((size_t)ep::ceil_div((n > 0 ? n : 1), 2048) * 4 + 4096, 256);
     if (feats_layout == EPRECON_LAYOUT_NCHW)
         bytes += ep::align_up((size_t)n_views * batch * channels * height * width * sizeof(float), 256);
     return bytes + 256;
@@ -555,6 +916,7 @@ int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *or
         const int rc = eprecon_nchw_to_nhwc_async(feats, tmp, n_views * batch, channels, height * width, stream);
         if (rc != EPRECON_OK) return rc;
         nhwc = tmp;
+        ws += ep::align_up((size_t)n_views * batch * channels * height * width * sizeof(float), 256);
     } else if (feats_layout != EPRECON_LAYOUT_NHWC) {
         return EPRECON_ERR_ARG;
     }
@@ -565,16 +927,76 @@ int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *or
     p.min_view = min_view; p.out_feats = out_feats; p.out_mean = out_mean; p.out_coords = out_coords;
     p.count = count; p.out_grid = out_grid; p.out_mask = out_mask; p.n_valid_dev = n_valid_dev;
     p.block_offsets = block_sums;
+    p.perm = nullptr;
+    p.slot = nullptr;
+
+    // Long lists take the brick-sorted pipeline; short ones keep input-order tiles.
+    const bool sorted = n >= 192 * 1024 && batch <= 8 && g_sorted_enabled;
+    if (sorted) {
+        // brick edge (finest-voxel units, power of two) sized so that a brick projects to ~16 px:
+        // focal length ~ 0.45 * W pixels, typical depth 2 m  ->  edge ~ 71 / (W * voxel_size) voxels
+        int brick_shift = 0;
+        while ((2 << brick_shift) <= 71.1f / ((float)width * voxel_size) && brick_shift < 6) ++brick_shift;
+        const size_t segN = ep::align_up((size_t)n * 4, 256);
+        const int nbins = kBinsPerBatch * batch;
+        const size_t segB = ep::align_up((size_t)nbins * 4, 256);
+        int32_t *flag = reinterpret_cast<int32_t *>(ws);
+        int32_t *slot = reinterpret_cast<int32_t *>(ws + segN);
+        int32_t *perm = reinterpret_cast<int32_t *>(ws + 2 * segN);
+        int32_t *hist = reinterpret_cast<int32_t *>(ws + 3 * segN);
+        int32_t *binoff = reinterpret_cast<int32_t *>(ws + 3 * segN + segB);
+        int32_t *scratch = reinterpret_cast<int32_t *>(ws + 3 * segN + 2 * segB);
+        EP_HIP_CHECK(hipMemsetAsync(hist, 0, segB, st));
+        const int nblk_count = (int)ep::ceil_div(n, 256);
+        const size_t lds_count = ((size_t)n_views * batch * 12 + batch) * 4 + 16;
+        hipLaunchKernelGGL(bp_count_sorted_kernel, dim3(nblk_count), dim3(256), lds_count, st, p, brick_shift, flag, hist);
+        EP_LAUNCH_CHECK();
+        int rcs = ep::exclusive_scan_i32(flag, (int)n, slot, scratch, n_valid_dev, st);
+        if (rcs != EPRECON_OK) return rcs;
+        rcs = ep::exclusive_scan_i32(hist, nbins, binoff, scratch, nullptr, st);
+        if (rcs != EPRECON_OK) return rcs;
+        EP_HIP_CHECK(hipMemsetAsync(hist, 0, segB, st));  // reused as the per-bin cursor
+        hipLaunchKernelGGL(bp_bin_fill_kernel, dim3(nblk_count), dim3(256), 0, st,
+                           reinterpret_cast<const int4 *>(coords), (int)n, batch, brick_shift,
+                           (const int32_t *)binoff, hist, perm, (int32_t *)nullptr);
+        EP_LAUNCH_CHECK();
+        p.perm = perm;
+        p.slot = slot;
+        const int ntile = (int)ep::ceil_div(n, 256);
+        const bool prof = g_prof.on && g_prof.start;
+        if (prof) EP_HIP_CHECK(hipEventRecord(g_prof.start, st));
+        int rc;
+        if (gather8_supported(channels))
+            rc = launch_gather8_mode<true>(p, mode, st);
+        else
+            rc = mode == EPRECON_BP_MEAN ? launch_gather<256, EPRECON_BP_MEAN, true>(p, ntile, st)
+               : mode == EPRECON_BP_MEAN_DEPTH ? launch_gather<256, EPRECON_BP_MEAN_DEPTH, true>(p, ntile, st)
+                                               : launch_gather<256, EPRECON_BP_VARIANCE, true>(p, ntile, st);
+        if (rc != EPRECON_OK) return rc;
+        if (prof) {
+            EP_HIP_CHECK(hipEventRecord(g_prof.stop, st));
+            g_prof.recorded = true;
+        }
+        if (mode == EPRECON_BP_MEAN_DEPTH) {
+            hipLaunchKernelGGL(bp_depth_norm_kernel, dim3(batch), dim3(1024), 0, st, out_feats, channels + 1,
+                               n_valid_dev);
+            EP_LAUNCH_CHECK();
+        }
+        return EPRECON_OK;
+    }
 
     // Tile = voxels handed to one 256-thread workgroup of the gather kernel.  Short lists get
     // small tiles so that the launch still covers the 256 CUs with several waves each
-    // (13,824 voxels -> 864 workgroups of 16; 110,592 -> 1,728 of 64; 884,736 -> 3,456 of 256).
-    const int vox = n >= 512 * 1024 ? 256 : (n >= 48 * 1024 ? 64 : 16);
+    // (13,824 voxels -> 864 workgroups of 16; 110,592 -> 1,728 of 64).
+    const bool use8 = n >= 48 * 1024 && gather8_supported(channels);
+    const int vox = use8 ? 128 : (n >= 512 * 1024 ? 256 : (n >= 48 * 1024 ? 64 : 16));
     const int ntile = (int)ep::ceil_div(n, vox);
     const int nblk_count = (int)ep::ceil_div(n, 256);
     const size_t lds_count = ((size_t)n_views * batch * 12 + batch + 256 / ep::kWave) * 4 + 16;
     if (vox == 256)
         hipLaunchKernelGGL((bp_count_kernel<256>), dim3(nblk_count), dim3(256), lds_count, st, p, block_sums);
+    else if (vox == 128)
+        hipLaunchKernelGGL((bp_count_kernel<128>), dim3(nblk_count), dim3(256), lds_count, st, p, block_sums);
     else if (vox == 64)
         hipLaunchKernelGGL((bp_count_kernel<64>), dim3(nblk_count), dim3(256), lds_count, st, p, block_sums);
     else
@@ -590,7 +1012,8 @@ int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *or
     rc = mode == EPRECON_BP_MEAN ? launch_gather<VOX, EPRECON_BP_MEAN>(p, ntile, st)                   \
        : mode == EPRECON_BP_MEAN_DEPTH ? launch_gather<VOX, EPRECON_BP_MEAN_DEPTH>(p, ntile, st)       \
                                        : launch_gather<VOX, EPRECON_BP_VARIANCE>(p, ntile, st)
-    if (vox == 256) { EP_MODE_DISPATCH(256); }
+    if (use8) { rc = launch_gather8_mode<false>(p, mode, st); }
+    else if (vox == 256) { EP_MODE_DISPATCH(256); }
     else if (vox == 64) { EP_MODE_DISPATCH(64); }
     else { EP_MODE_DISPATCH(16); }
 #undef EP_MODE_DISPATCH
