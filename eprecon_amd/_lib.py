@@ -54,6 +54,7 @@ SIGNATURES = {
                                      _vp, _vp, _sz, _vp]),
     "eprecon_gather_rows_async": (_i, [_vp, _i, _vp, _i64, _i, _f, _vp, _i, _vp]),
     "eprecon_nearest_voxel_async": (_i, [_vp, _c.c_uint32, _vp, _i64, _vp, _i64, _i, _vp, _vp]),
+    "eprecon_upsample2x_nhwc_async": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "eprecon_profile_enable": (_i, [_i]),
     "eprecon_profile_gather_ms": (_f, []),
     "eprecon_nchw_to_nhwc_async": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -26,8 +26,9 @@ def _prep_feats(feats):
     v, b, c, h, w = feats.shape
     if feats.dtype != torch.float32:
         feats = feats.float()
-    if feats.stride() == (b * h * w * c, h * w * c, 1, w * c, c):
-        return feats, LAYOUT_NHWC
+    want = (b * h * w * c, h * w * c, 1, w * c, c)
+    if all(sz == 1 or st == ws for sz, st, ws in zip(feats.shape, feats.stride(), want)):
+        return feats, LAYOUT_NHWC  # (strides of size-1 dimensions are irrelevant)
     return feats.contiguous(), LAYOUT_NCHW
 
 

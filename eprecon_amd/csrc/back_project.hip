@@ -21,10 +21,35 @@
 // Roofline: HBM/L2 bandwidth (about 2 flop per gathered byte).  Algorithmic bytes per call
 //   16 N (coords in) + 4 N (count out) + 4 V C H W (maps, once) + n_valid (4 C + 16) (rows out).
 // Arithmetic contract (bit-exact indices): see oracle/c/back_project_oracle.c and DESIGN.md.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
 using namespace ep;
+
+// tuning switches (A/B measurements: tools/ab_backproject.py); read once from the environment
+bool g_sorted_enabled = true;
+bool g_gather8_enabled = true;
+int g_pad_mode = 1;
+void read_tuning_env()
+{
+    static bool done = false;
+    if (done) return;
+    done = true;
+    if (const char *e = getenv("EPRECON_BP_SORTED")) g_sorted_enabled = e[0] != '0';
+    if (const char *e = getenv("EPRECON_BP_GATHER8")) g_gather8_enabled = e[0] != '0';
+    if (const char *e = getenv("EPRECON_BP_PAD")) g_pad_mode = atoi(e);
+}
+
+// pixel stride (floats) of the internal channels-last copy
+int padded_stride(int C)
+{
+    if (g_pad_mode == 0) return C;
+    if (C <= 32) return 32;                       // one 128-byte line per tap
+    if (g_pad_mode >= 2) return (C + 31) / 32 * 32;  // whole lines for wider taps too
+    return C;
+}
 
 struct BpParams {
     const int32_t *coords;
@@ -35,6 +60,7 @@ struct BpParams {
     const float *feats_nhwc;  // [V*B][H*W][C]
     const float *krcam;       // [V*B][16]
     int V, C, H, W;
+    int Cs;  // pixel stride of the channels-last maps in floats (>= C; padded to a 128-byte line when re-laid out here)
     int min_view;
     float *out_feats;
     float *out_mean;
@@ -164,7 +190,7 @@ __global__ __launch_bounds__(256) void bp_count_kernel(BpParams p, int32_t *tile
     }
     const unsigned long long m = __ballot(valid);
     const int lane = tid & (kWave - 1);
-    if (VOX >= kWave) {
+    if constexpr (VOX >= kWave) {
         // tile = VOX / 64 whole waves: per-wave popcounts through LDS
         if (lane == 0) sWave[tid / kWave] = __popcll(m);
         __syncthreads();
@@ -471,7 +497,7 @@ __global__ __launch_bounds__(256) void bp_gather_kernel(BpParams p)
     __syncthreads();
 
     const int Q = QT > 0 ? QT : p.C / VEC;
-    const size_t map_elems = (size_t)p.H * p.W * p.C;
+    const size_t map_elems = (size_t)p.H * p.W * p.Cs;
     const bool aligned16 = (MODE != EPRECON_BP_MEAN_DEPTH);
     for (int w = tid; w < nloc * Q; w += BLOCK) {
         const int r = w / Q;
@@ -486,7 +512,7 @@ __global__ __launch_bounds__(256) void bp_gather_kernel(BpParams p)
         for (int v = 0; v < p.V; ++v) {
             if (vm & (1u << v)) {
                 const float2 px = sPix[t * p.V + v];
-                const Taps tp = make_taps(px.x, px.y, p.W, p.H, p.C);
+                const Taps tp = make_taps(px.x, px.y, p.W, p.H, p.Cs);
                 acc.add(Chan<VEC>::sample(fb + (size_t)v * vstride, tp));
             }
         }
@@ -499,7 +525,7 @@ __global__ __launch_bounds__(256) void bp_gather_kernel(BpParams p)
             for (int v = 0; v < p.V; ++v) {
                 if (vm & (1u << v)) {
                     const float2 px = sPix[t * p.V + v];
-                    const Taps tp = make_taps(px.x, px.y, p.W, p.H, p.C);
+                    const Taps tp = make_taps(px.x, px.y, p.W, p.H, p.Cs);
                     sq.add_sqdiff(Chan<VEC>::sample(fb + (size_t)v * vstride, tp), mean);
                 }
             }
@@ -562,8 +588,8 @@ __global__ __launch_bounds__(256) void bp_gather8_kernel(BpParams p)
 
     const float wm1 = (float)(p.W - 1), hm1 = (float)(p.H - 1);
     const float kx = 2.0f / wm1, ky = 2.0f / hm1;
-    const int map_elems = p.H * p.W * p.C;
-    const int row_elems = p.W * p.C;
+    const int map_elems = p.H * p.W * p.Cs;
+    const int row_elems = p.W * p.Cs;
     // ---- phase 1a ----
     for (int pr = tid; pr < VOX * p.V; pr += BLOCK) {
         const int vx = pr / p.V, v = pr - vx * p.V;
@@ -582,7 +608,7 @@ __global__ __launch_bounds__(256) void bp_gather8_kernel(BpParams p)
         const float wx1 = q.u - x0f, wx0 = (x0f + 1.0f) - q.u;
         const float wy1 = q.v - y0f, wy0 = (y0f + 1.0f) - q.v;
         sW[pr] = make_float4(wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1);
-        sOff[pr] = (v * p.batch + c.x) * map_elems + ((int)y0f * p.W + (int)x0f) * p.C;
+        sOff[pr] = (v * p.batch + c.x) * map_elems + ((int)y0f * p.W + (int)x0f) * p.Cs;
         atomicOr(&sVis[vx], 1u << v);
     }
     __syncthreads();
@@ -640,9 +666,9 @@ __global__ __launch_bounds__(256) void bp_gather8_kernel(BpParams p)
                 const float4 wt = sW[t * p.V + v];
                 const int b0 = (sOff[t * p.V + v] + q * 8) * 4;
                 tap8(rsrc, b0, wt.x, acc);
-                tap8(rsrc, b0 + p.C * 4, wt.y, acc);
+                tap8(rsrc, b0 + p.Cs * 4, wt.y, acc);
                 tap8(rsrc, b0 + row_elems * 4, wt.z, acc);
-                tap8(rsrc, b0 + (row_elems + p.C) * 4, wt.w, acc);
+                tap8(rsrc, b0 + (row_elems + p.Cs) * 4, wt.w, acc);
             }
         }
         const int orow = sOut[t];
@@ -663,9 +689,9 @@ __global__ __launch_bounds__(256) void bp_gather8_kernel(BpParams p)
 #pragma unroll
                     for (int k = 0; k < 8; ++k) smp.a[k] = 0.0f;
                     tap8(rsrc, b0, wt.x, smp);
-                    tap8(rsrc, b0 + p.C * 4, wt.y, smp);
+                    tap8(rsrc, b0 + p.Cs * 4, wt.y, smp);
                     tap8(rsrc, b0 + row_elems * 4, wt.z, smp);
-                    tap8(rsrc, b0 + (row_elems + p.C) * 4, wt.w, smp);
+                    tap8(rsrc, b0 + (row_elems + p.Cs) * 4, wt.w, smp);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         const float d = smp.a[k] - mean[k];
@@ -725,7 +751,7 @@ int launch_gather8_mode(const BpParams &p, int mode, hipStream_t st)
                                          : launch_gather8<EPRECON_BP_VARIANCE, SORTED>(p, st);
 }
 
-bool gather8_supported(int C) { return C == 24 || C == 32 || C == 40 || C == 80; }
+bool gather8_supported(int C) { return g_gather8_enabled && (C == 24 || C == 32 || C == 40 || C == 80); }
 
 // ops/back_project.py:69-75 — per batch element: mu = mean(d[d>0]); sigma = ||d[d>0]-mu||_2 + 1e-5;
 // d_hat = (d-mu)/sigma, 0 where d <= 0.  One workgroup per batch element, three sweeps.
@@ -776,7 +802,7 @@ __global__ __launch_bounds__(1024) void bp_depth_norm_kernel(float *out_feats, i
 // ---------------------------------------------------------------------------------------------
 constexpr int kTrPix = 64;
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restrict__ in,
-                                                           float *__restrict__ out, int C, int hw)
+                                                           float *__restrict__ out, int C, int hw, int Cs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *tile = reinterpret_cast<float *>(smem);  // [C][kTrPix + 1]
@@ -784,15 +810,15 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restri
     const int p0 = blockIdx.x * kTrPix;
     const int npix = min(kTrPix, hw - p0);
     const float *src = in + (size_t)map * C * hw;
-    float *dst = out + (size_t)map * hw * C + (size_t)p0 * C;
+    float *dst = out + (size_t)map * hw * Cs + (size_t)p0 * Cs;
     for (int e = threadIdx.x; e < C * kTrPix; e += 256) {
         const int c = e / kTrPix, px = e - c * kTrPix;
         if (px < npix) tile[c * (kTrPix + 1) + px] = src[(size_t)c * hw + p0 + px];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < npix * C; e += 256) {
-        const int px = e / C, c = e - px * C;
-        dst[e] = tile[c * (kTrPix + 1) + px];
+    for (int e = threadIdx.x; e < npix * Cs; e += 256) {  // pad channels (Cs > C) are written as zeros
+        const int px = e / Cs, c = e - px * Cs;
+        dst[e] = c < C ? tile[c * (kTrPix + 1) + px] : 0.0f;
     }
 }
 
@@ -800,7 +826,6 @@ struct ProfileState {
     bool on = false, recorded = false;
     hipEvent_t start = nullptr, stop = nullptr;
 } g_prof;
-bool g_sorted_enabled = true;
 
 size_t gather_lds_bytes(int vox, int V, int B)
 {
@@ -847,7 +872,7 @@ size_t eprecon_back_project_workspace_bytes(int64_t n, int batch, int n_views, i
              2 * ep::align_up((size_t)kBinsPerBatch * (batch > 0 ? batch : 1) * 4, 256) +
              ep::align_up((size_t)ep::ceil_div((n > 0 ? n : 1), 2048) * 4 + 4096, 256);
     if (feats_layout == EPRECON_LAYOUT_NCHW)
-        bytes += ep::align_up((size_t)n_views * batch * channels * height * width * sizeof(float), 256);
+        bytes += ep::align_up((size_t)n_views * batch * 64 * ((channels + 63) / 64) * height * width * sizeof(float), 256);
     return bytes + 256;
 }
 
@@ -879,7 +904,7 @@ int eprecon_nchw_to_nhwc_async(const float *in, float *out, int maps, int channe
     if (lds > 64 * 1024) return EPRECON_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)ep::ceil_div(hw, kTrPix), (unsigned)maps);
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), lds, (hipStream_t)stream, in, out,
-                       channels, hw);
+                       channels, hw, channels);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }
@@ -911,25 +936,34 @@ int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *or
     int32_t *block_sums = reinterpret_cast<int32_t *>(ws);
     ws += ep::align_up((size_t)ep::ceil_div(n, 16) * sizeof(int32_t), 256);
     const float *nhwc = feats;
+    read_tuning_env();
+    int pix_stride = channels;
     if (feats_layout == EPRECON_LAYOUT_NCHW) {
+        // The re-layout is ours, so the pixel stride is too: a tap of C <= 32 channels is padded to one
+        // 128-byte cache line (the gather is bound by the number of lines a load instruction touches)
+        pix_stride = padded_stride(channels);
         float *tmp = reinterpret_cast<float *>(ws);
-        const int rc = eprecon_nchw_to_nhwc_async(feats, tmp, n_views * batch, channels, height * width, stream);
-        if (rc != EPRECON_OK) return rc;
+        const size_t lds_t = (size_t)channels * (kTrPix + 1) * sizeof(float);
+        if (lds_t > 64 * 1024) return EPRECON_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)ep::ceil_div(height * width, kTrPix), (unsigned)(n_views * batch)),
+                           dim3(256), lds_t, st, feats, tmp, channels, height * width, pix_stride);
+        EP_LAUNCH_CHECK();
         nhwc = tmp;
-        ws += ep::align_up((size_t)n_views * batch * channels * height * width * sizeof(float), 256);
+        ws += ep::align_up((size_t)n_views * batch * pix_stride * height * width * sizeof(float), 256);
     } else if (feats_layout != EPRECON_LAYOUT_NHWC) {
         return EPRECON_ERR_ARG;
     }
 
     BpParams p;
     p.coords = coords; p.n = (int)n; p.origin = origin; p.batch = batch; p.voxel_size = voxel_size;
-    p.feats_nhwc = nhwc; p.krcam = krcam; p.V = n_views; p.C = channels; p.H = height; p.W = width;
+    p.feats_nhwc = nhwc; p.krcam = krcam; p.V = n_views; p.C = channels; p.Cs = pix_stride; p.H = height; p.W = width;
     p.min_view = min_view; p.out_feats = out_feats; p.out_mean = out_mean; p.out_coords = out_coords;
     p.count = count; p.out_grid = out_grid; p.out_mask = out_mask; p.n_valid_dev = n_valid_dev;
     p.block_offsets = block_sums;
     p.perm = nullptr;
     p.slot = nullptr;
 
+    read_tuning_env();
     // Long lists take the brick-sorted pipeline; short ones keep input-order tiles.
     const bool sorted = n >= 192 * 1024 && batch <= 8 && g_sorted_enabled;
     if (sorted) {

@@ -183,3 +183,52 @@ int eprecon_upsample_async(const float *feat, int ld_feat, const int32_t *coords
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// x2 bilinear upsampling of channels-last maps (F.interpolate(scale_factor=2, mode="bilinear",
+// align_corners=False) in Occupancy_Initialization.feat_fusion_pre,
+// models/occupancy_initialization.py:46): in f32[n, h, w, c] -> out f32[n, 2h, 2w, c].
+// src = max(0, (dst + 0.5) / 2 - 0.5), taps clamped to the last row / column.
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void upsample2x_nhwc_kernel(const float4 *in, float4 *out, int n, int h, int w,
+                                                              int c4)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)n * 4 * h * w * c4;
+    if (e >= total) return;
+    const int c = (int)(e % c4);
+    size_t r = e / c4;
+    const int ox = (int)(r % (2 * w));
+    r /= 2 * w;
+    const int oy = (int)(r % (2 * h));
+    const int img = (int)(r / (2 * h));
+    const float sx = fmaxf(((float)ox + 0.5f) * 0.5f - 0.5f, 0.0f);
+    const float sy = fmaxf(((float)oy + 0.5f) * 0.5f - 0.5f, 0.0f);
+    const int x0 = (int)sx, y0 = (int)sy;
+    const int x1 = min(x0 + 1, w - 1), y1 = min(y0 + 1, h - 1);
+    const float lx = sx - (float)x0, ly = sy - (float)y0;
+    const float4 *base = in + (size_t)img * h * w * c4;
+    const float4 a = base[((size_t)y0 * w + x0) * c4 + c], b = base[((size_t)y0 * w + x1) * c4 + c];
+    const float4 d = base[((size_t)y1 * w + x0) * c4 + c], f = base[((size_t)y1 * w + x1) * c4 + c];
+    const float w00 = (1.0f - ly) * (1.0f - lx), w01 = (1.0f - ly) * lx, w10 = ly * (1.0f - lx), w11 = ly * lx;
+    float4 o;
+    o.x = w00 * a.x + w01 * b.x + w10 * d.x + w11 * f.x;
+    o.y = w00 * a.y + w01 * b.y + w10 * d.y + w11 * f.y;
+    o.z = w00 * a.z + w01 * b.z + w10 * d.z + w11 * f.z;
+    o.w = w00 * a.w + w01 * b.w + w10 * d.w + w11 * f.w;
+    out[e] = o;
+}
+}  // namespace
+
+extern "C" int eprecon_upsample2x_nhwc_async(const float *in, float *out, int n, int h, int w, int channels,
+                                             void *stream)
+{
+    if (!in || !out || n <= 0 || h <= 0 || w <= 0 || channels <= 0 || channels % 4) return EPRECON_ERR_ARG;
+    const size_t total = (size_t)n * 4 * h * w * (channels / 4);
+    hipLaunchKernelGGL(upsample2x_nhwc_kernel, dim3((unsigned)ceil_div((int64_t)total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, reinterpret_cast<const float4 *>(in), reinterpret_cast<float4 *>(out), n, h,
+                       w, channels / 4);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}

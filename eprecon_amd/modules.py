@@ -168,8 +168,44 @@ class TrainBatchNorm1d(nn.BatchNorm1d):
 
 
 # ------------------------------------------------------------------------------------------------
-# dense blocks (PyTorch-ROCm)
+# dense blocks (PyTorch-ROCm convolutions; on the GPU inference path the train-mode BatchNorm2d of
+# channels-last activations runs on the HIP BatchNorm kernels: a [N,C,H,W] channels-last tensor IS a
+# row-major [N*H*W, C] matrix, and MIOpen's spatial BN costs ~26 us per call on these small maps)
 # ------------------------------------------------------------------------------------------------
+def _rows(x):
+    """channels-last [N,C,H,W] -> its [N*H*W, C] row-major view (no copy)"""
+    n, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(n * h * w, c)
+
+
+def _hip_bn_ok(x):
+    return (x.is_cuda and not torch.is_grad_enabled() and x.dim() == 4 and x.shape[1] <= 256
+            and x.is_contiguous(memory_format=torch.channels_last) and x.dtype == torch.float32)
+
+
+def bn2d_train(bn, x, relu=False):
+    """train-mode BatchNorm2d (+ReLU): HIP kernels for channels-last CUDA tensors under no_grad,
+    else the PyTorch module"""
+    if _hip_bn_ok(x):
+        rows = _rows(x)
+        SP.batchnorm_train(rows, bn.weight, bn.bias, bn.eps, relu=relu, out=rows)
+        return x
+    y = bn(x)
+    return F.relu(y) if relu else y
+
+
+def upsample2x_bilinear(x):
+    """F.interpolate(x, scale_factor=2, mode="bilinear"); HIP kernel for channels-last CUDA tensors"""
+    if x.is_cuda and not torch.is_grad_enabled() and x.shape[1] % 4 == 0 and x.dtype == torch.float32 \
+            and x.is_contiguous(memory_format=torch.channels_last):
+        from . import _lib
+        n, c, h, w = x.shape
+        out = torch.empty((n, c, 2 * h, 2 * w), dtype=x.dtype, device=x.device,
+                          memory_format=torch.channels_last)
+        _lib.check(_lib.load().eprecon_upsample2x_nhwc_async(_lib.ptr(x), _lib.ptr(out), n, h, w, c,
+                                                             _lib.current_stream()), "eprecon_upsample2x_nhwc_async")
+        return out
+    return F.interpolate(x, scale_factor=2, mode="bilinear")
 class Conv2d_Block(nn.Module):
     """conv(k, same) -> BN -> ReLU (models/modules.py:372-383)"""
 
@@ -180,7 +216,7 @@ class Conv2d_Block(nn.Module):
         self.act = nn.ReLU()
 
     def forward(self, x):
-        return self.act(self.bn(self.conv(x)))
+        return bn2d_train(self.bn, self.conv(x), relu=True)
 
 
 class Conv2d_Residual_Block(nn.Module):
@@ -193,7 +229,7 @@ class Conv2d_Residual_Block(nn.Module):
         self.relu = nn.ReLU()
 
     def forward(self, x):
-        return self.bn(x + self.relu(self.conv(x)))
+        return bn2d_train(self.bn, x + self.relu(self.conv(x)))
 
 
 class ELAN(nn.Module):
@@ -230,8 +266,8 @@ class Fusion_Block(nn.Module):
         self.ELAN = ELAN(C)
 
     def forward(self, x):
-        x = self.relu(self.bn1(self.conv1(x)))
-        x = self.relu(self.bn2(self.conv2(x)))
+        x = bn2d_train(self.bn1, self.conv1(x), relu=True)
+        x = bn2d_train(self.bn2, self.conv2(x), relu=True)
         return self.ELAN(x)
 
 

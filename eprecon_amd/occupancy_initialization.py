@@ -18,7 +18,7 @@ from . import back_project as BP
 from . import sparse as SP
 from .config import INIT_MIN_VALID
 from .modules import (Conv2d_Block, Conv2d_Residual_Block, Fusion_Block, SparseSubMConv3d, Spares3dELAN,
-                      TrainBatchNorm1d, _RowLayerNorm)
+                      TrainBatchNorm1d, _RowLayerNorm, upsample2x_bilinear)
 
 
 class Occupancy_Initialization(nn.Module):
@@ -50,10 +50,21 @@ class Occupancy_Initialization(nn.Module):
         # torch.no_grad() it is captured once into a HIP graph and replayed (launch-bound otherwise).
         self.use_hip_graph = os.environ.get("EPRECON_NO_GRAPH", "0") != "1"
         self._graphs = {}
+        self._channels_last = False
 
     def feat_fusion_pre(self, feats_1x, feats_2x, feats_4x):
         """[V,80,H/16,W/16], [V,40,H/8,W/8], [V,24,H/4,W/4] -> [V,32,H/8,W/8]  (:41-58)"""
-        f1 = F.interpolate(self.self_fusion_1x(feats_1x), scale_factor=2, mode="bilinear")
+        if feats_1x.is_cuda and not torch.is_grad_enabled():
+            # inference on the GPU: channels-last activations (MIOpen NHWC convolutions, HIP BatchNorm /
+            # upsampling on the [N*H*W, C] view); the result feeds the back-projection in place
+            if not self._channels_last:
+                for mod in (self.self_fusion_1x, self.self_fusion_2x, self.self_fusion_4x, self.fusion_down,
+                            self.post_fusion_1, self.post_fusion_2, self.post_fusion_3, self.post_fusion_4):
+                    mod.to(memory_format=torch.channels_last)
+                self._channels_last = True
+            feats_1x, feats_2x, feats_4x = (t.contiguous(memory_format=torch.channels_last)
+                                            for t in (feats_1x, feats_2x, feats_4x))
+        f1 = upsample2x_bilinear(self.self_fusion_1x(feats_1x))
         f2 = self.self_fusion_2x(feats_2x)
         f4 = self.pool4x(self.self_fusion_4x(feats_4x))
         x = self.fusion_down(torch.cat([f1, f2, f4], dim=1))

@@ -285,6 +285,12 @@ int eprecon_nearest_voxel_async(const void *table, uint32_t capacity, const int3
                                 int64_t m, const int32_t *query_coords, int64_t n, int quantum,
                                 int32_t *out_index, void *stream);
 
+/* x2 bilinear upsampling of channels-last maps, in f32[n,h,w,c] -> out f32[n,2h,2w,c], c % 4 == 0
+ * (F.interpolate(scale_factor=2, mode="bilinear") in feat_fusion_pre,
+ * models/occupancy_initialization.py:46) */
+int eprecon_upsample2x_nhwc_async(const float *in, float *out, int n, int h, int w, int channels,
+                                  void *stream);
+
 #ifdef __cplusplus
 }
 #endif

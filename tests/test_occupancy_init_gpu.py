@@ -79,3 +79,27 @@ def test_returns_none_below_1000_valid_voxels():
         out = net(torch.from_numpy(coords).cuda(), torch.from_numpy(window["vol_origin_partial"][None]).cuda(),
                   0.04, feats, torch.from_numpy(kr).cuda(), (8, 8, 8), 1, 2)
     assert out is None
+
+
+def test_hip_dense_path_matches_pytorch_path():
+    """feat_fusion_pre on the GPU inference path (channels-last, HIP BatchNorm2d / upsampling, HIP
+    graph replay) against the plain PyTorch modules (grad-enabled path)"""
+    from eprecon_amd.occupancy_initialization import Occupancy_Initialization
+    torch.manual_seed(3)
+    net = Occupancy_Initialization([80, 40, 24], 32, 9).cuda()
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    rng = np.random.default_rng(0)
+    f1 = torch.from_numpy(rng.standard_normal((9, 80, 15, 20), dtype=np.float32)).cuda()
+    f2 = torch.from_numpy(rng.standard_normal((9, 40, 30, 40), dtype=np.float32)).cuda()
+    f4 = torch.from_numpy(rng.standard_normal((9, 24, 60, 80), dtype=np.float32)).cuda()
+    ref = net.feat_fusion_pre(f1, f2, f4).detach()          # grad enabled -> PyTorch BN / interpolate
+    with torch.no_grad():
+        got = net.feat_fusion_pre(f1, f2, f4)
+        assert got.is_contiguous(memory_format=torch.channels_last)
+        graphed = net._fusion_graphed(f1, f2, f4).clone()
+        graphed2 = net._fusion_graphed(f1, f2, f4)
+    assert (got - ref).abs().max().item() < 2e-4
+    assert (graphed - ref).abs().max().item() < 2e-4 and torch.equal(graphed, graphed2)
