@@ -21,6 +21,8 @@
 // slab) and read conflict-free with ds_read_b32.  The neighbour tile int32[K][128] is staged in
 // LDS first; offsets k with no live row in the workgroup are skipped.
 // Roofline: fp32 MFMA (157 TFLOP/s) when Cin*Cout >= 32*32, else L2 gather bandwidth.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -38,6 +40,34 @@ struct ConvParams {
     int relu;            // fused ReLU epilogue
     int accumulate;      // out += result instead of out = result
 };
+
+// Stage `rows` x TN weights (zero padded) from w[row0 + r][0:Cout] (row stride Cout, rows valid
+// while row0 + r < row_end) into LDS.  Branch-free: addresses are clamped into the valid range and
+// the value is selected afterwards, so the compiler can keep many loads in flight (a guarded load
+// per element compiled to load / s_waitcnt vmcnt(0) pairs: ~500 cycles each).
+template <int TN>
+__device__ __forceinline__ void stage_weights(float *dst, const float *w, int row0, int row_end, int Cout,
+                                              int rows, int tid)
+{
+    const int total = rows * TN;
+    if (Cout == TN && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+        // padded layout == source layout: straight 16-byte copies
+        const float4 *src = reinterpret_cast<const float4 *>(w + (size_t)row0 * Cout);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        const int valid4 = max(0, min(rows, row_end - row0)) * (TN / 4);
+#pragma unroll 4
+        for (int e = tid; e < total / 4; e += 256) d4[e] = e < valid4 ? src[min(e, max(valid4 - 1, 0))] : make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+#pragma unroll 4
+    for (int e = tid; e < total; e += 256) {
+        const int r = e / TN, col = e - r * TN;
+        const bool ok = (row0 + r < row_end) && (col < Cout);
+        const int rr = min(row0 + r, row_end - 1), cc = min(col, Cout - 1);
+        const float v = w[(size_t)rr * Cout + cc];
+        dst[e] = ok ? v : 0.0f;
+    }
+}
 
 constexpr int kRowsPerWave = 32;
 constexpr int kWaves = 4;
@@ -90,12 +120,7 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvParams p)
             const int c0 = sl * kSlabC;
             // ---- stage W[k][c0 : c0+32][0 : TN] into sW[buf] (zero padded) ----
             float *dstW = sW + buf * kSlabC * TN;
-            for (int e = tid; e < kSlabC * TN; e += 256) {
-                const int c = e / TN, col = e - c * TN;
-                float v = 0.0f;
-                if (c0 + c < p.Cin && col < p.Cout) v = wk[(size_t)(c0 + c) * p.Cout + col];
-                dstW[e] = v;
-            }
+            stage_weights<TN>(dstW, wk, c0, p.Cin, p.Cout, kSlabC, tid);
             // ---- gather this lane's A values: 4 chunks of 8 channels, 4 floats each ----
             float a[4][4];
 #pragma unroll
@@ -149,6 +174,160 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvParams p)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Group-resident variant for narrow layers (Cin <= 64, Cout <= 64): the weights of a GROUP of
+// kernel offsets (up to 36 KB, e.g. 9 offsets of a 32x32 layer) are staged per barrier instead of
+// one 32-channel slab, so a 27-offset layer needs 3 barriers instead of 27, and four workgroups
+// fit a CU.  Each wave reads its own neighbour indices (coalesced from the [K][N] table), skips
+// offsets with no live row in its 32 rows, and prefetches the gathered rows of offset k+1 while
+// the MFMAs of offset k run.
+// ---------------------------------------------------------------------------------------------
+struct ARows {
+    float v[8][4];  // up to 8 chunks of 8 input channels; this lane's 4 consecutive channels per chunk
+};
+
+template <bool VEC4, int NCH>
+__device__ __forceinline__ void gather_rows(const ConvParams &p, int j, int half, ARows &a)
+{
+    const float *xrow = p.x + (size_t)(j >= 0 ? j : 0) * p.ld_x;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c = ch * 8 + 4 * half;
+        if (VEC4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j >= 0 && c < p.Cin) v = *reinterpret_cast<const float4 *>(xrow + c);
+            a.v[ch][0] = v.x; a.v[ch][1] = v.y; a.v[ch][2] = v.z; a.v[ch][3] = v.w;
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a.v[ch][s] = (j >= 0 && c + s < p.Cin) ? xrow[c + s] : 0.0f;
+        }
+    }
+}
+
+template <int NT, bool VEC4, int NCH>
+__global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int kgroup)
+{
+    constexpr int cin_pad = NCH * 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TN = 32 * NT;
+    float *sW = reinterpret_cast<float *>(smem);  // [kgroup][cin_pad][TN], zero padded
+    constexpr int per_k = cin_pad * TN;
+    int *sNbr = reinterpret_cast<int *>(sW + kgroup * per_k);  // [K][128] neighbour tile
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, half = lane >> 5;
+    const int wrow0 = blockIdx.x * kRowsPerBlock + wave * kRowsPerWave;
+    // the neighbour indices of the whole tile go to LDS up front: the gather of offset k+1 then
+    // depends on ONE memory latency (the rows), not two (index, then rows)
+    for (int e = tid; e < p.K * kRowsPerBlock; e += 256) {
+        const int k = e / kRowsPerBlock, r = e - k * kRowsPerBlock;
+        const int row = blockIdx.x * kRowsPerBlock + r;
+        sNbr[e] = row < p.n_out ? (p.nbr ? p.nbr[(size_t)k * p.n_out + row] : row) : -1;
+    }
+    __syncthreads();
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    auto nbr_of = [&](int k) -> int { return sNbr[k * kRowsPerBlock + wave * kRowsPerWave + r32]; };
+    int j = nbr_of(0);
+    ARows cur;
+    gather_rows<VEC4, NCH>(p, j, half, cur);
+    for (int k0 = 0; k0 < p.K; k0 += kgroup) {
+        const int kn = min(kgroup, p.K - k0);
+        __syncthreads();  // every wave is done with the previous group's weights
+        if (cin_pad == p.Cin) {
+            // rows of consecutive offsets are contiguous in W: one flat [kn * Cin][Cout] block
+            stage_weights<TN>(sW, p.w, k0 * p.Cin, (k0 + kn) * p.Cin, p.Cout, kn * cin_pad, tid);
+        } else {
+            for (int kk = 0; kk < kn; ++kk)
+                stage_weights<TN>(sW + kk * per_k, p.w, (k0 + kk) * p.Cin, (k0 + kk + 1) * p.Cin, p.Cout, cin_pad, tid);
+        }
+        __syncthreads();
+        for (int kk = 0; kk < kn; ++kk) {
+            const int k = k0 + kk;
+            const bool live = __ballot(j >= 0) != 0ull;
+            int jn = -1;
+            ARows nxt;
+            if (k + 1 < p.K) {
+                jn = nbr_of(k + 1);
+                gather_rows<VEC4, NCH>(p, jn, half, nxt);  // in flight during the MFMAs below
+            }
+            if (live) {
+                const float *wk = sW + kk * per_k + r32 + 4 * half * TN;
+                // fully unrolled (NCH, NT compile-time): the B reads of a chunk are issued as a batch
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    float b[4][NT];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) b[s][t] = wk[(ch * 8 + s) * TN + t * 32];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.v[ch][s], b[s][t], acc[t], 0, 0, 0);
+                }
+            }
+            cur = nxt;
+            j = jn;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = t * 32 + r32;
+        if (col >= p.Cout) continue;
+        const float b = p.bias ? p.bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int orow = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (orow < p.n_out) {
+                float *o = p.out + (size_t)orow * p.ld_out + col;
+                float v = acc[t][r] + b;
+                if (p.accumulate) v += *o;
+                if (p.relu) v = fmaxf(v, 0.0f);
+                *o = v;
+            }
+        }
+    }
+}
+
+template <int NT, int NCH>
+int launch_resident_nch(const ConvParams &p, bool vec4, hipStream_t st)
+{
+    // weights of `kgroup` offsets resident at a time (<= 36 KB -> 4 workgroups per CU)
+    const size_t per_k = (size_t)NCH * 8 * 32 * NT * sizeof(float);
+    const int kgroup = (int)max((size_t)1, min((size_t)p.K, (size_t)(24 * 1024) / per_k));
+    const size_t lds = (size_t)kgroup * per_k + (size_t)p.K * kRowsPerBlock * sizeof(int);
+    const int grid = (int)ceil_div(p.n_out, kRowsPerBlock);
+    if (vec4)
+        hipLaunchKernelGGL((spconv_resident_kernel<NT, true, NCH>), dim3(grid), dim3(256), lds, st, p, kgroup);
+    else
+        hipLaunchKernelGGL((spconv_resident_kernel<NT, false, NCH>), dim3(grid), dim3(256), lds, st, p, kgroup);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+template <int NT>
+int launch_resident(const ConvParams &p, bool vec4, int cin_pad, hipStream_t st)
+{
+    switch (cin_pad / 8) {
+        case 1: return launch_resident_nch<NT, 1>(p, vec4, st);
+        case 2: return launch_resident_nch<NT, 2>(p, vec4, st);
+        case 3: return launch_resident_nch<NT, 3>(p, vec4, st);
+        case 4: return launch_resident_nch<NT, 4>(p, vec4, st);
+        case 5: return launch_resident_nch<NT, 5>(p, vec4, st);
+        case 6: return launch_resident_nch<NT, 6>(p, vec4, st);
+        case 7: return launch_resident_nch<NT, 7>(p, vec4, st);
+        default: return launch_resident_nch<NT, 8>(p, vec4, st);
+    }
+}
+
 template <int NT>
 int launch_conv(const ConvParams &p, bool vec4, hipStream_t st)
 {
@@ -182,6 +361,14 @@ extern "C" int eprecon_sparse_conv_async(const float *x, int64_t n_in, int ld_x,
     p.relu = relu; p.accumulate = accumulate;
     const bool vec4 = (cin % 4 == 0) && (ld_x % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
+    // narrow layers: whole weight tensor resident in LDS, persistent barrier-free workgroups
+    {
+        const int cin_pad = (cin + 7) / 8 * 8;
+        const int nt = cout <= 32 ? 1 : 2;
+        static const bool resident_on = !(getenv("EPRECON_CONV_RESIDENT") && getenv("EPRECON_CONV_RESIDENT")[0] == '0');
+        if (resident_on && cin_pad <= 64 && cout <= 64)
+            return nt == 1 ? launch_resident<1>(p, vec4, cin_pad, st) : launch_resident<2>(p, vec4, cin_pad, st);
+    }
     // Cout > 128: two passes over column halves keep the accumulator footprint at <= 64 VGPRs
     if (cout <= 32) return launch_conv<1>(p, vec4, st);
     if (cout <= 64) return launch_conv<2>(p, vec4, st);
