@@ -29,11 +29,19 @@ namespace {
 using namespace ep;
 
 // tuning switches (A/B measurements: tools/ab_backproject.py); read once from the environment
-// measured on MI355X (tools/ab_backproject.py, dense 96^3): the input-order 4-channel kernel is the
-// fastest variant so far (134 us); brick sorting buys 8 % on the gather but costs 35 us of binning,
-// the 8-channel kernel is 35 % slower (strided 32-byte lanes), line padding is neutral -> all off.
+// Variants measured on MI355X (tools/ab_backproject.py, dense 96^3, C = 24, 120x160; gather kernel / whole op):
+//   input-order tiles, 4-channel lanes (default)            134 us / 0.26 ms
+//   brick-sorted tiles, 4-channel lanes                      118 us / 0.27 ms  (binning costs what it saves)
+//   8-channel lanes + per-pair taps in LDS + buffer loads    173-185 us        (strided 32-byte lanes)
+//   128-byte padded pixel stride                             133 us            (neutral)
+//   LDS image patches per view, barrier per view             206 us
+//   LDS image patches, all views staged at once (64 voxels)  313 us
+// The direct-gather kernel moves 2.4 GB through the vector L1 at ~41 B/clk/CU (64 % of its rate); the
+// LDS-patch structures lose more to barriers / occupancy / per-tile overhead than they save.  They stay
+// in the build behind environment switches for the next round's profiling.
 bool g_sorted_enabled = false;
 bool g_gather8_enabled = false;
+bool g_lds_enabled = false;
 int g_pad_mode = 0;
 void read_tuning_env()
 {
@@ -43,6 +51,7 @@ void read_tuning_env()
     if (const char *e = getenv("EPRECON_BP_SORTED")) g_sorted_enabled = e[0] != '0';
     if (const char *e = getenv("EPRECON_BP_GATHER8")) g_gather8_enabled = e[0] != '0';
     if (const char *e = getenv("EPRECON_BP_PAD")) g_pad_mode = atoi(e);
+    if (const char *e = getenv("EPRECON_BP_LDS")) g_lds_enabled = e[0] != '0';
 }
 
 // pixel stride (floats) of the internal channels-last copy
@@ -723,6 +732,239 @@ __global__ __launch_bounds__(256) void bp_gather8_kernel(BpParams p)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// K2 + K3 (+K4), LDS-patch variant for long brick-sorted lists (C % 4 == 0, C <= 40).
+// A tile is 128 consecutive entries of the brick-sorted permutation = a compact 3D block of voxels,
+// whose projections into one view cover a small image rectangle.  Per view the rectangle (+1 for
+// the bilinear neighbours) is copied ONCE from the channels-last map into LDS with coalesced
+// 16-byte loads, and the four taps of every (voxel, 4-channel group) are then read from LDS
+// (ds_read_b128, 256 B/clk/CU) instead of through the vector L1 (64 B/clk/CU), which is what bounds
+// the direct-gather kernels.  A view whose rectangle exceeds the LDS budget (bricks close to the
+// camera) falls back to direct loads for that view only.
+//   phase 1a  one thread per (voxel, view): cheap projection, pixel coords -> LDS, visibility bits
+//   phase 1b  one thread per voxel: validity / output row; per-view bounding boxes (wave min/max)
+//   phase 2   per view: stage patch -> barrier -> accumulate taps of every item -> barrier
+// ---------------------------------------------------------------------------------------------
+constexpr int kPatchFloats = 1280;  // per view: 5 KB (e.g. 7 x 7 pixels of 24 channels)
+constexpr int kLdsVox = 64;          // voxels per tile (one 4 x 4 x 4 brick)
+
+template <int MODE, int QT>
+__global__ __launch_bounds__(256) void bp_gather_lds_kernel(BpParams p)
+{
+    constexpr int VOX = kLdsVox, BLOCK = 256;
+    constexpr int IPT = (VOX * QT + BLOCK - 1) / BLOCK;  // items per thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *sPatch = reinterpret_cast<float4 *>(smem);                              // [V][kPatchFloats / 4]
+    float2 *sPix = reinterpret_cast<float2 *>(sPatch + p.V * (kPatchFloats / 4));   // [VOX*V] pixel coords
+    float *sP = reinterpret_cast<float *>(sPix + VOX * p.V);                        // [V*B][12]
+    const int nP = (p.V * p.batch * 12 + 3) & ~3;
+    uint32_t *sVis = reinterpret_cast<uint32_t *>(sP + nP);                         // [VOX]
+    int *sSlot = reinterpret_cast<int *>(sVis + VOX);                               // [VOX] rank -> voxel
+    int *sOut = sSlot + VOX;                                                        // [VOX] voxel -> output row
+    int *sBatch = sOut + VOX;                                                       // [VOX]
+    int *sBox = sBatch + VOX;                                                       // [V][4] xmin, xmax, ymin, ymax
+    int *sWave = sBox + 4 * 32;                                                     // [BLOCK/64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    stage_matrices(sP, p.krcam, p.V * p.batch, tid, BLOCK);
+    if (tid < VOX) sVis[tid] = 0;
+    if (tid < 4 * p.V) sBox[tid] = ((tid & 1) == 0) ? 0x7fffffff : -1;  // min slots / max slots
+    __syncthreads();
+
+    const float wm1 = (float)(p.W - 1), hm1 = (float)(p.H - 1);
+    const float kx = 2.0f / wm1, ky = 2.0f / hm1;
+    // ---- phase 1a: one thread per (voxel, view) ----
+    for (int pr = tid; pr < VOX * p.V; pr += BLOCK) {
+        const int vx = pr / p.V, v = pr - vx * p.V;
+        const int e = lb * VOX + vx;
+        if (e >= p.n) continue;
+        const int i = p.perm[e];
+        const int4 c = reinterpret_cast<const int4 *>(p.coords)[i];
+        if (c.x < 0 || c.x >= p.batch) continue;
+        float X, Y, Z;
+        voxel_centre(c, p.origin, p.voxel_size, X, Y, Z);
+        const ProjFast q = project_fast(sP + (v * p.batch + c.x) * 12, X, Y, Z, wm1, hm1, kx, ky);
+        if (!q.vis) continue;
+        sPix[pr] = make_float2(q.u, q.v);
+        atomicOr(&sVis[vx], 1u << v);
+    }
+    __syncthreads();
+    // ---- phase 1b: one thread per voxel (the first wave) ----
+    bool valid = false;
+    int4 c = make_int4(0, 0, 0, 0);
+    int i = 0, cnt = 0;
+    uint32_t vis = 0;
+    {
+        const int e = lb * VOX + tid;
+        if (tid < VOX && e < p.n) {
+            i = p.perm[e];
+            c = reinterpret_cast<const int4 *>(p.coords)[i];
+            vis = sVis[tid];
+            cnt = __popc(vis);
+            valid = c.x >= 0 && c.x < p.batch && cnt >= p.min_view;
+        }
+    }
+    int nloc;
+    const int rank = block_exclusive_rank<BLOCK>(valid, sWave, nloc);
+    if (nloc == 0) return;
+    const int n_valid = p.n_valid_dev[0];
+    const int cout = (MODE == EPRECON_BP_MEAN_DEPTH) ? p.C + 1 : p.C;
+    if (valid) {
+        const int o = p.slot[i];
+        sSlot[rank] = tid;
+        sOut[tid] = o;
+        sBatch[tid] = c.x;
+        reinterpret_cast<int4 *>(p.out_coords)[o] = c;
+        if (MODE == EPRECON_BP_MEAN_DEPTH || p.out_grid || p.out_mask) {
+            float X, Y, Z, zsum = 0.0f;
+            voxel_centre(c, p.origin, p.voxel_size, X, Y, Z);
+            for (int v = 0; v < p.V; ++v) {
+                const Proj pr = project(sP + (v * p.batch + c.x) * 12, X, Y, Z, wm1, hm1);
+                if (pr.vis) zsum += pr.pz;
+                if (p.out_grid)
+                    reinterpret_cast<float2 *>(p.out_grid)[(size_t)v * n_valid + o] = make_float2(pr.gx, pr.gy);
+                if (p.out_mask) p.out_mask[(size_t)v * n_valid + o] = pr.vis ? 1 : 0;
+            }
+            if (MODE == EPRECON_BP_MEAN_DEPTH)
+                p.out_feats[(size_t)o * cout + p.C] = __fdiv_rn(zsum, (float)(cnt > 0 ? cnt : 1));
+        }
+    }
+    // per-view bounding box of the base pixels of the valid voxels that see the view (wave 0 only)
+    if (tid < VOX) {
+        for (int v = 0; v < p.V; ++v) {
+            const bool on = valid && ((vis >> v) & 1u);
+            int x0 = 0x7fffffff, x1 = -1, y0 = 0x7fffffff, y1 = -1;
+            if (on) {
+                const float2 px = sPix[tid * p.V + v];
+                x0 = x1 = (int)fminf(floorf(px.x), wm1 - 1.0f);
+                y0 = y1 = (int)fminf(floorf(px.y), hm1 - 1.0f);
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                x0 = min(x0, __shfl_xor(x0, d));
+                x1 = max(x1, __shfl_xor(x1, d));
+                y0 = min(y0, __shfl_xor(y0, d));
+                y1 = max(y1, __shfl_xor(y1, d));
+            }
+            if (lane == 0) {
+                sBox[4 * v + 0] = x0; sBox[4 * v + 1] = x1; sBox[4 * v + 2] = y0; sBox[4 * v + 3] = y1;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- stage the patches of ALL views in one go (many loads in flight, one barrier) ----
+    const int C4 = p.C / 4;
+    const size_t map4 = (size_t)p.H * p.W * C4;  // float4 per map
+    const float4 *maps = reinterpret_cast<const float4 *>(p.feats_nhwc);
+    const int pb = sBatch[sSlot[0]];  // batch element of the tile (voxels of another one use direct loads)
+    uint32_t staged_mask = 0;
+    for (int v = 0; v < p.V; ++v) {
+        const int bx0 = sBox[4 * v + 0], bx1 = sBox[4 * v + 1], by0 = sBox[4 * v + 2], by1 = sBox[4 * v + 3];
+        if (bx1 < 0) continue;
+        const int pw = bx1 - bx0 + 2, ph = by1 - by0 + 2;
+        const int row4 = pw * C4;
+        if (row4 * ph * 4 > kPatchFloats) continue;  // too large for its slice: direct loads for this view
+        staged_mask |= 1u << v;
+        const float4 *vmap = maps + ((size_t)v * p.batch + pb) * map4 + ((size_t)by0 * p.W + bx0) * C4;
+        float4 *dst = sPatch + v * (kPatchFloats / 4);
+        const int total = row4 * ph;
+        for (int e = tid; e < total; e += BLOCK) {
+            const int r = e / row4, cc = e - r * row4;
+            dst[e] = vmap[(size_t)r * p.W * C4 + cc];
+        }
+    }
+    __syncthreads();
+
+    // ---- accumulate: no further barriers ----
+    const int npass = (MODE == EPRECON_BP_VARIANCE) ? 2 : 1;
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int w = tid + k * BLOCK;
+        if (w >= nloc * QT) break;
+        const int r = w / QT, q = w - r * QT;
+        const int t = sSlot[r];
+        const uint32_t vm = sVis[t];
+        const float den = (float)max(__popc(vm), 1);
+        const bool same_batch = sBatch[t] == pb;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), sq = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int pass = 0; pass < npass; ++pass) {
+            for (int v = 0; v < p.V; ++v) {
+                if (!((vm >> v) & 1u)) continue;
+                const float2 px = sPix[t * p.V + v];
+                const float x0f = fminf(floorf(px.x), wm1 - 1.0f), y0f = fminf(floorf(px.y), hm1 - 1.0f);
+                const float wx1 = px.x - x0f, wx0 = (x0f + 1.0f) - px.x;
+                const float wy1 = px.y - y0f, wy0 = (y0f + 1.0f) - px.y;
+                const int x0 = (int)x0f, y0 = (int)y0f;
+                float4 a, b, cc, d;
+                if (((staged_mask >> v) & 1u) && same_batch) {
+                    const int bx0 = sBox[4 * v + 0], by0 = sBox[4 * v + 2];
+                    const int row4 = (sBox[4 * v + 1] - bx0 + 2) * C4;
+                    const float4 *q0 = sPatch + v * (kPatchFloats / 4) + (y0 - by0) * row4 + (x0 - bx0) * C4 + q;
+                    a = q0[0]; b = q0[C4]; cc = q0[row4]; d = q0[row4 + C4];
+                } else {
+                    const float4 *q0 = maps + ((size_t)v * p.batch + sBatch[t]) * map4 + ((size_t)y0 * p.W + x0) * C4 + q;
+                    a = q0[0]; b = q0[C4]; cc = q0[(size_t)p.W * C4]; d = q0[(size_t)p.W * C4 + C4];
+                }
+                const float w00 = wx0 * wy0, w10 = wx1 * wy0, w01 = wx0 * wy1, w11 = wx1 * wy1;
+                float4 s;
+                s.x = fmaf(d.x, w11, fmaf(cc.x, w01, fmaf(b.x, w10, a.x * w00)));
+                s.y = fmaf(d.y, w11, fmaf(cc.y, w01, fmaf(b.y, w10, a.y * w00)));
+                s.z = fmaf(d.z, w11, fmaf(cc.z, w01, fmaf(b.z, w10, a.z * w00)));
+                s.w = fmaf(d.w, w11, fmaf(cc.w, w01, fmaf(b.w, w10, a.w * w00)));
+                if (pass == 0) {
+                    acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
+                } else {  // variance: acc holds the mean now
+                    const float dx = s.x - acc.x, dy = s.y - acc.y, dz = s.z - acc.z, dw = s.w - acc.w;
+                    sq.x = fmaf(dx, dx, sq.x); sq.y = fmaf(dy, dy, sq.y);
+                    sq.z = fmaf(dz, dz, sq.z); sq.w = fmaf(dw, dw, sq.w);
+                }
+            }
+            if (pass == 0)
+                acc = make_float4(__fdiv_rn(acc.x, den), __fdiv_rn(acc.y, den), __fdiv_rn(acc.z, den), __fdiv_rn(acc.w, den));
+        }
+        const int orow = sOut[t];
+        float4 res = acc;
+        if (MODE == EPRECON_BP_VARIANCE) {
+            res = make_float4(__fdiv_rn(sq.x, den), __fdiv_rn(sq.y, den), __fdiv_rn(sq.z, den), __fdiv_rn(sq.w, den));
+            if (p.out_mean) *reinterpret_cast<float4 *>(p.out_mean + (size_t)orow * p.C + q * 4) = acc;
+        }
+        float *dst = p.out_feats + (size_t)orow * cout + q * 4;
+        if (MODE != EPRECON_BP_MEAN_DEPTH) {
+            *reinterpret_cast<float4 *>(dst) = res;
+        } else {
+            dst[0] = res.x; dst[1] = res.y; dst[2] = res.z; dst[3] = res.w;
+        }
+    }
+}
+
+size_t gather_lds_patch_bytes(int V, int B)
+{
+    const size_t nP = ((size_t)V * B * 12 + 3) & ~(size_t)3;
+    return (size_t)V * kPatchFloats * 4 + (size_t)kLdsVox * V * 8 + nP * 4 + (size_t)kLdsVox * 4 * 4 + 4 * 32 * 4 +
+           (256 / kWave) * 4 + 16;
+}
+
+template <int MODE>
+int launch_gather_lds(const BpParams &p, hipStream_t st)
+{
+    const int ntile = (int)ceil_div(p.n, kLdsVox);
+    const size_t lds = gather_lds_patch_bytes(p.V, p.batch);
+    const dim3 grid(ntile), block(256);
+    switch (p.C / 4) {
+        case 6: hipLaunchKernelGGL((bp_gather_lds_kernel<MODE, 6>), grid, block, lds, st, p); break;    // C = 24
+        case 8: hipLaunchKernelGGL((bp_gather_lds_kernel<MODE, 8>), grid, block, lds, st, p); break;    // C = 32
+        case 10: hipLaunchKernelGGL((bp_gather_lds_kernel<MODE, 10>), grid, block, lds, st, p); break;  // C = 40
+        default: return EPRECON_ERR_UNSUPPORTED;
+    }
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+bool gather_lds_supported(int C, int Cs) { return g_lds_enabled && Cs == C && (C == 24 || C == 32 || C == 40); }
+
 size_t gather8_lds_bytes(int V, int B)
 {
     const size_t nP = ((size_t)V * B * 12 + 3) & ~(size_t)3;
@@ -970,10 +1212,11 @@ int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *or
     // Long lists take the brick-sorted pipeline; short ones keep input-order tiles.
     const bool sorted = n >= 192 * 1024 && batch <= 8 && g_sorted_enabled;
     if (sorted) {
-        // brick edge (finest-voxel units, power of two) sized so that a brick projects to ~16 px:
-        // focal length ~ 0.45 * W pixels, typical depth 2 m  ->  edge ~ 71 / (W * voxel_size) voxels
+        // brick edge (finest-voxel units, power of two) sized so that a brick projects to ~8 px:
+        // focal length ~ 0.45 * W pixels, typical depth 2 m  ->  edge ~ 36 / (W * voxel_size) units;
+        // one full brick (64 voxels) is one gather tile of the LDS-patch kernel
         int brick_shift = 0;
-        while ((2 << brick_shift) <= 71.1f / ((float)width * voxel_size) && brick_shift < 6) ++brick_shift;
+        while ((2 << brick_shift) <= 35.6f / ((float)width * voxel_size) && brick_shift < 6) ++brick_shift;
         const size_t segN = ep::align_up((size_t)n * 4, 256);
         const int nbins = kBinsPerBatch * batch;
         const size_t segB = ep::align_up((size_t)nbins * 4, 256);
@@ -1003,7 +1246,11 @@ int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *or
         const bool prof = g_prof.on && g_prof.start;
         if (prof) EP_HIP_CHECK(hipEventRecord(g_prof.start, st));
         int rc;
-        if (gather8_supported(channels))
+        if (gather_lds_supported(channels, p.Cs))
+            rc = mode == EPRECON_BP_MEAN ? launch_gather_lds<EPRECON_BP_MEAN>(p, st)
+               : mode == EPRECON_BP_MEAN_DEPTH ? launch_gather_lds<EPRECON_BP_MEAN_DEPTH>(p, st)
+                                               : launch_gather_lds<EPRECON_BP_VARIANCE>(p, st);
+        else if (gather8_supported(channels))
             rc = launch_gather8_mode<true>(p, mode, st);
         else
             rc = mode == EPRECON_BP_MEAN ? launch_gather<256, EPRECON_BP_MEAN, true>(p, ntile, st)
