@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256) void bp_count_kernel(BpParams p, int32_t *tile
 
     const int i = blockIdx.x * BLOCK + tid;
     bool valid = false;
+    int vbatch = 0;
     if (i < p.n) {
         const int4 c = reinterpret_cast<const int4 *>(p.coords)[i];
         int cnt = 0;
@@ -198,10 +199,20 @@ __global__ __launch_bounds__(256) void bp_count_kernel(BpParams p, int32_t *tile
         }
         p.count[i] = (float)cnt;
         valid = in_range && cnt >= p.min_view;
-        if (valid) atomicAdd(&sBatch[c.x], 1);
+        vbatch = c.x;
     }
     const unsigned long long m = __ballot(valid);
     const int lane = tid & (kWave - 1);
+    {   // per-batch valid counts: lists are grouped by batch, so a wave almost always holds one batch
+        // element -> one LDS atomic per wave instead of one per voxel
+        const int b0 = __shfl(vbatch, m ? (__ffsll((long long)m) - 1) : 0);
+        const bool uniform = __ballot(valid && vbatch != b0) == 0ull;
+        if (uniform) {
+            if (m && lane == (__ffsll((long long)m) - 1)) atomicAdd(&sBatch[b0], __popcll(m));
+        } else if (valid) {
+            atomicAdd(&sBatch[vbatch], 1);
+        }
+    }
     if constexpr (VOX >= kWave) {
         // tile = VOX / 64 whole waves: per-wave popcounts through LDS
         if (lane == 0) sWave[tid / kWave] = __popcll(m);

@@ -2,7 +2,7 @@
 //
 //   init_select   sigmoid(logit) > thr on the valid 48^3 voxels -> OR-pool 2^3 -> erode -> dilate x2
 //                 -> raster-order coordinates * 4           models/neucon_network.py:264,298-318
-//                 (marking is one thread per voxel; the 24^3 morphology runs in LDS, one workgroup)
+//                 (marking is one thread per voxel; the 24^3 morphology runs on bit columns, one workgroup)
 //   upsample      every voxel -> its 8 children, parent-major, features replicated
 //                                                            models/neucon_network.py:193-214
 #include "common.hpp"
@@ -11,19 +11,6 @@ namespace {
 using namespace ep;
 
 constexpr int kSelThreads = 1024;
-
-__device__ __forceinline__ bool box27(const unsigned char *vol, int D, int x, int y, int z, bool want_all)
-{
-    // zero padding: cells outside the volume count as 0 (F.conv3d padding=1 with an all-ones kernel)
-    int s = 0;
-    for (int dx = -1; dx <= 1; ++dx)
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dz = -1; dz <= 1; ++dz) {
-                const int a = x + dx, b = y + dy, c = z + dz;
-                if (a >= 0 && a < D && b >= 0 && b < D && c >= 0 && c < D) s += vol[(a * D + b) * D + c];
-            }
-    return want_all ? (s == 27) : (s >= 1);
-}
 
 // one thread per valid voxel: mark the coarse cell of every voxel with sigmoid(logit) > thr
 // (byte stores of the same value: race-free)
@@ -41,59 +28,69 @@ __global__ __launch_bounds__(256) void init_mark_kernel(const float *logit, cons
     }
 }
 
+// Morphology on bit columns: the D (<= 32) cells of one (x, y) column are one 32-bit word, bit z.
+// A zero-padded 3^3 box erosion is AND over the 9 neighbour columns of (w & w<<1 & w>>1); the
+// dilation is the same with OR.  One thread per column; the whole volume is D*D words in LDS.
+__device__ __forceinline__ uint32_t box_columns(const uint32_t *vol, int D, int x, int y, bool erode, uint32_t zmask)
+{
+    uint32_t r = erode ? zmask : 0u;
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int a = x + dx, b = y + dy;
+            const uint32_t w = (a >= 0 && a < D && b >= 0 && b < D) ? vol[a * D + b] : 0u;
+            if (erode)
+                r &= w & (w << 1) & (w >> 1);
+            else
+                r |= w | (w << 1) | (w >> 1);
+        }
+    return r & zmask;
+}
+
 __global__ __launch_bounds__(kSelThreads) void init_select_kernel(const unsigned char *marks, int batch, int D,
                                                                   int out_scale, int4 *out_coords,
                                                                   int32_t *n_out_dev)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int cells = D * D * D;
-    unsigned char *va = reinterpret_cast<unsigned char *>(smem);
-    unsigned char *vb = va + ((cells + 15) & ~15);
-    int *sWave = reinterpret_cast<int *>(vb + ((cells + 15) & ~15));
+    __shared__ uint32_t va[1024], vb[1024];
+    __shared__ int sWave[kSelThreads / kWave];
+    const int cols = D * D, cells = cols * D;
+    const uint32_t zmask = D >= 32 ? 0xffffffffu : ((1u << D) - 1u);
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+    const int x = tid / D, y = tid - x * D;
+    const bool live = tid < cols;
     int written = 0;
     for (int b = 0; b < batch; ++b) {
-        for (int i = tid; i < cells; i += kSelThreads) va[i] = marks[(size_t)b * cells + i];
+        uint32_t w = 0;
+        if (live)
+            for (int z = 0; z < D; ++z) w |= marks[(size_t)b * cells + tid * D + z] ? (1u << z) : 0u;
+        if (live) va[tid] = w;
         __syncthreads();
-        for (int i = tid; i < cells; i += kSelThreads) {  // erode
-            const int z = i % D, y = (i / D) % D, x = i / (D * D);
-            vb[i] = box27(va, D, x, y, z, true) ? 1 : 0;
-        }
+        if (live) vb[tid] = box_columns(va, D, x, y, true, zmask);   // erode
         __syncthreads();
-        for (int i = tid; i < cells; i += kSelThreads) {  // dilate 1
-            const int z = i % D, y = (i / D) % D, x = i / (D * D);
-            va[i] = box27(vb, D, x, y, z, false) ? 1 : 0;
-        }
+        if (live) va[tid] = box_columns(vb, D, x, y, false, zmask);  // dilate
         __syncthreads();
-        for (int i = tid; i < cells; i += kSelThreads) {  // dilate 2
-            const int z = i % D, y = (i / D) % D, x = i / (D * D);
-            vb[i] = box27(va, D, x, y, z, false) ? 1 : 0;
-        }
-        __syncthreads();
-        // raster-order compaction: thread t owns the contiguous cell range [t*per, (t+1)*per)
-        const int per = (cells + kSelThreads - 1) / kSelThreads;
-        const int c0 = tid * per, c1 = min(cells, c0 + per);
-        int mine = 0;
-        for (int i = c0; i < c1; ++i) mine += vb[i];
-        int x = mine;
+        const uint32_t fin = live ? box_columns(va, D, x, y, false, zmask) : 0u;  // dilate
+        // raster-order compaction: columns in (x, y) order, bits in ascending z
+        const int mine = __popc(fin);
+        int s = mine;
 #pragma unroll
         for (int d = 1; d < kWave; d <<= 1) {
-            const int y = __shfl_up(x, d);
-            if (lane >= d) x += y;
+            const int t = __shfl_up(s, d);
+            if (lane >= d) s += t;
         }
-        if (lane == kWave - 1) sWave[wid] = x;
+        if (lane == kWave - 1) sWave[wid] = s;
         __syncthreads();
-        int off = written + x - mine, tot = 0;
-        for (int w = 0; w < kSelThreads / kWave; ++w) {
-            const int c = sWave[w];
-            if (w < wid) off += c;
+        int off = written + s - mine, tot = 0;
+        for (int k = 0; k < kSelThreads / kWave; ++k) {
+            const int c = sWave[k];
+            if (k < wid) off += c;
             tot += c;
         }
-        for (int i = c0; i < c1; ++i)
-            if (vb[i]) {
-                const int z = i % D, y = (i / D) % D, xx = i / (D * D);
-                out_coords[off++] = make_int4(b, xx * out_scale, y * out_scale, z * out_scale);
-            }
+        uint32_t bits = fin;
+        while (bits) {
+            const int z = __ffs(bits) - 1;
+            bits &= bits - 1;
+            out_coords[off++] = make_int4(b, x * out_scale, y * out_scale, z * out_scale);
+        }
         if (tid == 0) n_out_dev[1 + b] = tot;
         written += tot;
         __syncthreads();
@@ -142,7 +139,7 @@ int eprecon_init_select_async(const float *logit, const int32_t *coords, int64_t
                               int batch, int dim, int cell, int32_t *out_coords, int32_t *n_out_dev,
                               void *workspace, size_t workspace_bytes, void *stream)
 {
-    if (n < 0 || batch <= 0 || dim <= 0 || dim > 40 || cell <= 0 || !out_coords || !n_out_dev || !workspace ||
+    if (n < 0 || batch <= 0 || dim <= 0 || dim > 32 || cell <= 0 || !out_coords || !n_out_dev || !workspace ||
         (n > 0 && (!logit || !coords)))
         return EPRECON_ERR_ARG;
     if (workspace_bytes < eprecon_init_select_workspace_bytes(batch, dim)) return EPRECON_ERR_WORKSPACE;
@@ -155,8 +152,7 @@ int eprecon_init_select_async(const float *logit, const int32_t *coords, int64_t
                            reinterpret_cast<const int4 *>(coords), (int)n, threshold, batch, dim, cell, marks);
         EP_LAUNCH_CHECK();
     }
-    const size_t lds = 2 * (size_t)((cells + 15) & ~15) + (kSelThreads / kWave) * sizeof(int) + 16;
-    hipLaunchKernelGGL(init_select_kernel, dim3(1), dim3(kSelThreads), lds, st, (const unsigned char *)marks, batch,
+    hipLaunchKernelGGL(init_select_kernel, dim3(1), dim3(kSelThreads), 0, st, (const unsigned char *)marks, batch,
                        dim, cell, reinterpret_cast<int4 *>(out_coords), n_out_dev);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
