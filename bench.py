@@ -186,10 +186,18 @@ def main():
         value = world * args.steps / elapsed
         gm = float(np.mean([g for g in gather_ms if g > 0])) if any(g > 0 for g in gather_ms) else None
         alg = step.dominant_kernel_bytes()
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_bp_gather.json")
+        if os.path.exists(pmc):
+            # HBM-side bytes per launch of the same kernel from the committed rocprofv3 --pmc passes
+            # (FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 FETCH_SIZE x2 correction applied);
+            # PMC collection cannot run inside the timed process, so this is the recorded measurement
+            rec = json.load(open(pmc))
+            traffic, traffic_src = rec["traffic_bytes"], "profiles/r01/pmc_traffic_bp_gather.json"
         roof = {"bound": "hbm", "kernel": "bp_gather_kernel<256,MEAN,4,6> (dense 96^3, C=24, 120x160)",
                 "achieved": (alg / (gm * 1e-3) / 1e9) if gm else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (alg / (gm * 1e-3) / 1e9 / HBM_PEAK_GBS) if gm else None,
-                "traffic": None, "algorithmic_bytes": alg, "avg_launch_ms": gm}
+                "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": alg, "avg_launch_ms": gm}
         out = {"metric": "fragments_per_sec", "value": value, "unit": "fragments/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
