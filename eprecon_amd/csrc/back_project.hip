@@ -30,19 +30,24 @@ using namespace ep;
 
 // tuning switches (A/B measurements: tools/ab_backproject.py); read once from the environment
 // Variants measured on MI355X (tools/ab_backproject.py, dense 96^3, C = 24, 120x160; gather kernel / whole op):
-//   input-order tiles, 4-channel lanes (default)            134 us / 0.26 ms
+//   input-order tiles, 4-channel lanes, taps recomputed      134 us / 0.26 ms
+//   + per-pair taps in LDS, cheap projection, buffer loads   122 us           (default, EPRECON_BP_MLP=1)
+//   + 2 / 3 / 4 views of loads in flight per lane            126 / 129 / 138 us (no latency to hide)
 //   brick-sorted tiles, 4-channel lanes                      118 us / 0.27 ms  (binning costs what it saves)
 //   8-channel lanes + per-pair taps in LDS + buffer loads    173-185 us        (strided 32-byte lanes)
 //   128-byte padded pixel stride                             133 us            (neutral)
 //   LDS image patches per view, barrier per view             206 us
 //   LDS image patches, all views staged at once (64 voxels)  313 us
-// The direct-gather kernel moves 2.4 GB through the vector L1 at ~41 B/clk/CU (64 % of its rate); the
-// LDS-patch structures lose more to barriers / occupancy / per-tile overhead than they save.  They stay
-// in the build behind environment switches for the next round's profiling.
+// The direct-gather kernel moves 2.4 GB through the vector L1 at ~41 B/clk/CU.  PMC: 54.7 M L1 accesses for
+// 2.38 M wave loads = 23 per instruction: a 96-byte tap (24 channels) always touches two 64-byte L1 segments,
+// so the L1 access rate (one segment per clock per CU -> >= 89 us) bounds the kernel, not latency (more
+// loads in flight do not help) and not HBM.  The LDS-patch structures lose more to barriers / occupancy /
+// per-tile overhead than they save.  The variants stay in the build behind environment switches.
 bool g_sorted_enabled = false;
 bool g_gather8_enabled = false;
 bool g_lds_enabled = false;
 int g_pad_mode = 0;
+int g_mlp = 1;  // views in flight per lane in the default gather (0 = the older recompute-per-lane kernel)
 void read_tuning_env()
 {
     static bool done = false;
@@ -52,6 +57,7 @@ void read_tuning_env()
     if (const char *e = getenv("EPRECON_BP_GATHER8")) g_gather8_enabled = e[0] != '0';
     if (const char *e = getenv("EPRECON_BP_PAD")) g_pad_mode = atoi(e);
     if (const char *e = getenv("EPRECON_BP_LDS")) g_lds_enabled = e[0] != '0';
+    if (const char *e = getenv("EPRECON_BP_MLP")) g_mlp = atoi(e);
 }
 
 // pixel stride (floats) of the internal channels-last copy
@@ -745,6 +751,178 @@ __global__ __launch_bounds__(256) void bp_gather8_kernel(BpParams p)
 
 
 // ---------------------------------------------------------------------------------------------
+// K2 + K3 (+K4), default for C % 4 == 0: direct gather with per-pair taps in LDS and U views of loads
+// in flight per lane (U = 1 by default: measured, the kernel is bound by the L1 access rate and extra
+// loads in flight only cost registers).
+//   phase 1a  one thread per (voxel, view): cheap bit-exact projection; byte offset of tap (x0, y0)
+//             (base pixel clamped to [0, W-2] x [0, H-2], so all four taps are in the image and the
+//             border weight is exactly 0 where the reference pads with zeros) and the two fractional
+//             weights -> LDS, 12 bytes per pair, computed once instead of once per channel group;
+//   phase 1b  one thread per voxel: visible count, validity, stable in-tile compaction, output row;
+//   phase 2   one thread per (valid voxel, 4 channels): the visible views are walked U at a time:
+//             4 U buffer loads (32-bit offsets; the other three taps are scalar offsets of the
+//             first) are issued before the first fma; slots past the last visible view point out of
+//             the buffer range, which costs no memory traffic.  Views accumulate in ascending order.
+// ---------------------------------------------------------------------------------------------
+constexpr int kOobOffset = (int)0x80000000u;  // >= num_records (maps are limited to < 2 GiB here)
+
+template <int U, class F>
+__device__ __forceinline__ void visit_visible_samples(__amdgpu_buffer_rsrc_t rsrc, const int *sOffRow,
+                                                      const float2 *sWxyRow, uint32_t vm, int qbyte, int s10,
+                                                      int s01, int s11, F &&f)
+{
+    uint32_t m = vm;
+    while (m) {
+        int off[U];
+        float2 wxy[U];
+        bool on[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            on[u] = m != 0;
+            const int v = on[u] ? __builtin_ctz(m) : 0;
+            m &= m - 1;
+            wxy[u] = sWxyRow[v];
+            off[u] = on[u] ? sOffRow[v] + qbyte : kOobOffset;
+        }
+        u32x4 a[U], b[U], c[U], d[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            a[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[u], 0, 0);
+            b[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[u], s10, 0);
+            c[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[u], s01, 0);
+            d[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[u], s11, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float wx1 = wxy[u].x, wy1 = wxy[u].y;
+            const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;  // exact: wx1 is a multiple of ulp(ix) in [0, 1]
+            const float w00 = wx0 * wy0, w10 = wx1 * wy0, w01 = wx0 * wy1, w11 = wx1 * wy1;
+            float4 r;
+#define EP_TAP(k) fmaf(__uint_as_float(d[u].k), w11, fmaf(__uint_as_float(c[u].k), w01, fmaf(__uint_as_float(b[u].k), w10, __uint_as_float(a[u].k) * w00)))
+            r.x = EP_TAP(x); r.y = EP_TAP(y); r.z = EP_TAP(z); r.w = EP_TAP(w);
+#undef EP_TAP
+            if (on[u]) f(r);
+        }
+    }
+}
+
+template <int VOX, int MODE, int QT, int U>
+__global__ __launch_bounds__(256) void bp_gather_mlp_kernel(BpParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BLOCK = 256;
+    constexpr int VPT = BLOCK / VOX;  // threads per voxel in phase 1a (1, 4 or 16)
+    float2 *sWxy = reinterpret_cast<float2 *>(smem);                      // [VOX*V] fractional weights
+    int *sOff = reinterpret_cast<int *>(sWxy + VOX * p.V);                // [VOX*V] byte offset of tap (x0, y0)
+    float *sP = reinterpret_cast<float *>(sOff + VOX * p.V);              // [V*B][12]
+    const int nP = (p.V * p.batch * 12 + 3) & ~3;
+    uint32_t *sVis = reinterpret_cast<uint32_t *>(sP + nP);               // [VOX] view bitmask
+    int *sSlot = reinterpret_cast<int *>(sVis + VOX);                     // [VOX] rank -> voxel
+    int *sOut = sSlot + VOX;                                              // [VOX] voxel -> output row
+    int *sWave = sOut + VOX;                                              // [BLOCK/64]
+
+    const int tid = threadIdx.x;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    stage_matrices(sP, p.krcam, p.V * p.batch, tid, BLOCK);
+    if (VPT > 1 && tid < VOX) sVis[tid] = 0;
+    __syncthreads();
+
+    const float wm1 = (float)(p.W - 1), hm1 = (float)(p.H - 1);
+    const float kx = 2.0f / wm1, ky = 2.0f / hm1;
+    const int map_elems = p.H * p.W * p.Cs;
+    // ---- phase 1a: thread -> (voxel tid % VOX, views tid / VOX, + VPT, ...) ----
+    const int vx = tid % VOX;
+    const int e = lb * VOX + vx;
+    int4 c = make_int4(-1, 0, 0, 0);
+    if (e < p.n) c = reinterpret_cast<const int4 *>(p.coords)[e];
+    const bool in_batch = c.x >= 0 && c.x < p.batch;
+    uint32_t vis = 0;
+    if (in_batch) {
+        float X, Y, Z;
+        voxel_centre(c, p.origin, p.voxel_size, X, Y, Z);
+        for (int v = tid / VOX; v < p.V; v += VPT) {
+            const ProjFast q = project_fast(sP + (v * p.batch + c.x) * 12, X, Y, Z, wm1, hm1, kx, ky);
+            if (!q.vis) continue;
+            const float x0f = fminf(floorf(q.u), wm1 - 1.0f), y0f = fminf(floorf(q.v), hm1 - 1.0f);
+            sWxy[vx * p.V + v] = make_float2(q.u - x0f, q.v - y0f);
+            sOff[vx * p.V + v] = ((v * p.batch + c.x) * map_elems + ((int)y0f * p.W + (int)x0f) * p.Cs) * 4;
+            vis |= 1u << v;
+        }
+        if (VPT > 1 && vis) atomicOr(&sVis[vx], vis);
+    }
+    if (VPT > 1) {
+        __syncthreads();
+        vis = sVis[vx];
+    }
+    // ---- phase 1b ----
+    const int cnt = __popc(vis);
+    const bool valid = tid < VOX && in_batch && cnt >= p.min_view;
+    int nloc;
+    const int rank = block_exclusive_rank<BLOCK>(valid, sWave, nloc);
+    if (nloc == 0) return;
+    const int n_valid = p.n_valid_dev[0];
+    const int cout = (MODE == EPRECON_BP_MEAN_DEPTH) ? p.C + 1 : p.C;
+    if (valid) {
+        const int o = p.block_offsets[lb] + rank;
+        sSlot[rank] = tid;
+        sOut[tid] = o;
+        if (VPT == 1) sVis[tid] = vis;
+        reinterpret_cast<int4 *>(p.out_coords)[o] = c;
+        if (MODE == EPRECON_BP_MEAN_DEPTH || p.out_grid || p.out_mask) {
+            float X, Y, Z, zsum = 0.0f;
+            voxel_centre(c, p.origin, p.voxel_size, X, Y, Z);
+            for (int v = 0; v < p.V; ++v) {
+                const Proj pr = project(sP + (v * p.batch + c.x) * 12, X, Y, Z, wm1, hm1);
+                if (pr.vis) zsum += pr.pz;
+                if (p.out_grid)
+                    reinterpret_cast<float2 *>(p.out_grid)[(size_t)v * n_valid + o] = make_float2(pr.gx, pr.gy);
+                if (p.out_mask) p.out_mask[(size_t)v * n_valid + o] = pr.vis ? 1 : 0;
+            }
+            if (MODE == EPRECON_BP_MEAN_DEPTH)
+                p.out_feats[(size_t)o * cout + p.C] = __fdiv_rn(zsum, (float)(cnt > 0 ? cnt : 1));
+        }
+    }
+    __syncthreads();
+    // ---- phase 2 ----
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.feats_nhwc), 0, p.V * p.batch * map_elems * 4, 0x00020000);
+    const int Q = QT > 0 ? QT : p.C / 4;
+    const int s10 = p.Cs * 4, s01 = p.W * p.Cs * 4, s11 = s01 + s10;
+    for (int w = tid; w < nloc * Q; w += BLOCK) {
+        const int r = w / Q, q = w - r * Q;
+        const int t = sSlot[r];
+        const uint32_t vm = sVis[t];
+        const float den = (float)max(__popc(vm), 1);
+        const int *offRow = sOff + t * p.V;
+        const float2 *wxyRow = sWxy + t * p.V;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        visit_visible_samples<U>(rsrc, offRow, wxyRow, vm, q * 16, s10, s01, s11, [&](const float4 &f) {
+            acc.x += f.x; acc.y += f.y; acc.z += f.z; acc.w += f.w;
+        });
+        const int orow = sOut[t];
+        float *dst = p.out_feats + (size_t)orow * cout + q * 4;
+        const float4 mean = make_float4(__fdiv_rn(acc.x, den), __fdiv_rn(acc.y, den), __fdiv_rn(acc.z, den),
+                                        __fdiv_rn(acc.w, den));
+        if (MODE == EPRECON_BP_VARIANCE) {
+            // models/occupancy_initialization.py:127-128: population variance over visible views
+            float4 sq = make_float4(0.f, 0.f, 0.f, 0.f);
+            visit_visible_samples<U>(rsrc, offRow, wxyRow, vm, q * 16, s10, s01, s11, [&](const float4 &f) {
+                const float dx = f.x - mean.x, dy = f.y - mean.y, dz = f.z - mean.z, dw = f.w - mean.w;
+                sq.x = fmaf(dx, dx, sq.x); sq.y = fmaf(dy, dy, sq.y); sq.z = fmaf(dz, dz, sq.z); sq.w = fmaf(dw, dw, sq.w);
+            });
+            *reinterpret_cast<float4 *>(dst) = make_float4(__fdiv_rn(sq.x, den), __fdiv_rn(sq.y, den),
+                                                           __fdiv_rn(sq.z, den), __fdiv_rn(sq.w, den));
+            if (p.out_mean) *reinterpret_cast<float4 *>(p.out_mean + (size_t)orow * p.C + q * 4) = mean;
+        } else if (MODE == EPRECON_BP_MEAN_DEPTH) {
+            dst[0] = mean.x; dst[1] = mean.y; dst[2] = mean.z; dst[3] = mean.w;  // rows of C + 1 floats
+        } else {
+            *reinterpret_cast<float4 *>(dst) = mean;
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // K2 + K3 (+K4), LDS-patch variant for long brick-sorted lists (C % 4 == 0, C <= 40).
 // A tile is 128 consecutive entries of the brick-sorted permutation = a compact 3D block of voxels,
 // whose projections into one view cover a small image rectangle.  Per view the rectangle (+1 for
@@ -1112,6 +1290,49 @@ int launch_gather(const BpParams &p, int nblk, hipStream_t st)
     return EPRECON_OK;
 }
 
+size_t gather_mlp_lds_bytes(int vox, int V, int B)
+{
+    const size_t nP = ((size_t)V * B * 12 + 3) & ~(size_t)3;
+    return (size_t)vox * V * 12 + nP * sizeof(float) + (size_t)vox * 3 * 4 + (size_t)(256 / kWave) * 4 + 16;
+}
+
+bool gather_mlp_supported(const BpParams &p)
+{
+    return g_mlp > 0 && p.C % 4 == 0 && p.Cs % 4 == 0 && p.V <= 32 &&
+           (size_t)p.V * p.batch * p.H * p.W * p.Cs * 4 < 0x7fff0000ull &&
+           gather_mlp_lds_bytes(256, p.V, p.batch) <= 64 * 1024;
+}
+
+template <int VOX, int MODE, int U>
+int launch_gather_mlp_u(const BpParams &p, int nblk, hipStream_t st)
+{
+    const size_t lds = gather_mlp_lds_bytes(VOX, p.V, p.batch);
+    const dim3 grid(nblk), block(256);
+#define EP_GATHER(QT) hipLaunchKernelGGL((bp_gather_mlp_kernel<VOX, MODE, QT, U>), grid, block, lds, st, p)
+    switch (p.C / 4) {
+        case 6: EP_GATHER(6); break;    // C = 24  (1/4-res level)
+        case 8: EP_GATHER(8); break;    // C = 32  (fused initialisation maps)
+        case 10: EP_GATHER(10); break;  // C = 40  (1/8-res level)
+        case 20: EP_GATHER(20); break;  // C = 80  (1/16-res level)
+        default: EP_GATHER(0); break;
+    }
+#undef EP_GATHER
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+template <int VOX, int MODE>
+int launch_gather_mlp(const BpParams &p, int nblk, hipStream_t st)
+{
+    switch (g_mlp) {
+        case 1: return launch_gather_mlp_u<VOX, MODE, 1>(p, nblk, st);
+        case 2: return launch_gather_mlp_u<VOX, MODE, 2>(p, nblk, st);
+        case 4: return launch_gather_mlp_u<VOX, MODE, 4>(p, nblk, st);
+        case 3: return launch_gather_mlp_u<VOX, MODE, 3>(p, nblk, st);
+        default: return launch_gather_mlp_u<VOX, MODE, 1>(p, nblk, st);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1307,11 +1528,21 @@ int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *or
     rc = mode == EPRECON_BP_MEAN ? launch_gather<VOX, EPRECON_BP_MEAN>(p, ntile, st)                   \
        : mode == EPRECON_BP_MEAN_DEPTH ? launch_gather<VOX, EPRECON_BP_MEAN_DEPTH>(p, ntile, st)       \
                                        : launch_gather<VOX, EPRECON_BP_VARIANCE>(p, ntile, st)
+#define EP_MODE_DISPATCH_MLP(VOX)                                                                    \
+    rc = mode == EPRECON_BP_MEAN ? launch_gather_mlp<VOX, EPRECON_BP_MEAN>(p, ntile, st)               \
+       : mode == EPRECON_BP_MEAN_DEPTH ? launch_gather_mlp<VOX, EPRECON_BP_MEAN_DEPTH>(p, ntile, st)   \
+                                       : launch_gather_mlp<VOX, EPRECON_BP_VARIANCE>(p, ntile, st)
     if (use8) { rc = launch_gather8_mode<false>(p, mode, st); }
+    else if (gather_mlp_supported(p)) {
+        if (vox == 256) { EP_MODE_DISPATCH_MLP(256); }
+        else if (vox == 64) { EP_MODE_DISPATCH_MLP(64); }
+        else { EP_MODE_DISPATCH_MLP(16); }
+    }
     else if (vox == 256) { EP_MODE_DISPATCH(256); }
     else if (vox == 64) { EP_MODE_DISPATCH(64); }
     else { EP_MODE_DISPATCH(16); }
 #undef EP_MODE_DISPATCH
+#undef EP_MODE_DISPATCH_MLP
     if (rc != EPRECON_OK) return rc;
     if (prof) {
         EP_HIP_CHECK(hipEventRecord(g_prof.stop, st));
