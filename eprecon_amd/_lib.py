@@ -35,6 +35,13 @@ SIGNATURES = {
     "eprecon_kernel_map_async": (_i, [_vp, _c.c_uint32, _vp, _i64, _i, _i, _vp, _vp]),
     "eprecon_transpose_map_async": (_i, [_vp, _i64, _vp, _i, _vp, _vp]),
     "eprecon_sparse_conv_async": (_i, [_vp, _i64, _i, _vp, _i, _i64, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "eprecon_conv_bn_partial_bytes": (_sz, [_i64, _i]),
+    "eprecon_sparse_conv_fused_async": (_i, [_vp, _i64, _i, _vp, _i, _i64, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i,
+                                             _vp, _vp]),
+    "eprecon_pixel_map_async": (_i, [_i, _i, _i, _i, _vp, _vp]),
+    "eprecon_batchnorm_apply_workspace_bytes": (_sz, [_i]),
+    "eprecon_batchnorm_apply_partials_async": (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp, _vp, _f, _vp, _i, _i, _vp, _i,
+                                                    _vp, _vp, _vp, _sz, _vp]),
     "eprecon_batchnorm_workspace_bytes": (_sz, [_i64, _i]),
     "eprecon_batchnorm_train_async": (_i, [_vp, _i64, _i, _i, _vp, _vp, _f, _vp, _i, _i, _vp, _i, _vp, _vp,
                                            _vp, _sz, _vp]),

@@ -270,6 +270,24 @@ HashTable make_table(void *mem, uint32_t cap)
 int32_t *table_status(void *mem) { return reinterpret_cast<int32_t *>(mem); }
 bool is_pow2(uint32_t c) { return c >= 1024 && (c & (c - 1)) == 0; }
 
+
+// Kernel map of a dense 2D 'same' convolution over `maps` images of h x w pixels stored row-major
+// ([maps][h][w] rows of a channels-last tensor): nbr[(ky * ks + kx)][i] = row of pixel
+// (y + ky - ks/2, x + kx - ks/2) of the same image, -1 outside it (zero padding).  Closed form, no
+// hash grid: lets the 2D fusion convolutions of Occupancy_Initialization
+// (models/occupancy_initialization.py:22-31, models/modules.py:313-399) run on the gather-GEMM kernel.
+__global__ __launch_bounds__(256) void pixel_map_kernel(int maps, int h, int w, int ks, int32_t *nbr)
+{
+    const int n = maps * h * w;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int k = blockIdx.y;
+    const int dy = k / ks - ks / 2, dx = k % ks - ks / 2;
+    const int x = i % w, y = (i / w) % h;
+    const int yy = y + dy, xx = x + dx;
+    nbr[(size_t)k * n + i] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? i + dy * w + dx : -1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -384,6 +402,18 @@ int eprecon_transpose_map_async(const int32_t *fine_coords, int64_t n, const int
     hipLaunchKernelGGL(transpose_map_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
                        (hipStream_t)stream, reinterpret_cast<const int4 *>(fine_coords), (int)n, parent,
                        fine_stride, up_map);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_pixel_map_async(int maps, int height, int width, int ksize, int32_t *nbr, void *stream)
+{
+    if (maps <= 0 || height <= 0 || width <= 0 || ksize < 1 || ksize > 7 || !(ksize & 1) || !nbr ||
+        (int64_t)maps * height * width > 0x7fffffff)
+        return EPRECON_ERR_ARG;
+    const int n = maps * height * width;
+    hipLaunchKernelGGL(pixel_map_kernel, dim3((unsigned)ceil_div(n, 256), ksize * ksize), dim3(256), 0,
+                       (hipStream_t)stream, maps, height, width, ksize, nbr);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }

@@ -160,6 +160,20 @@ __global__ __launch_bounds__(256) void rowwise_ln_kernel(const float *x, int n, 
         }
 }
 
+int bn_finalize_apply(const float *x, int64_t n, int channels, int ld_x, const float *partial, int nblk,
+                      const float *gamma, const float *beta, float eps, const float *residual, int ld_res,
+                      int relu, float *out, int ld_out, float *mean, float *var, hipStream_t st)
+{
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(channels), dim3(256), 0, st, partial, nblk, channels, mean, var);
+    EP_LAUNCH_CHECK();
+    const size_t total = (size_t)n * channels;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div((int64_t)total, 256)), dim3(256), 0, st, x,
+                       (int)n, channels, ld_x, (const float *)mean, (const float *)var, gamma, beta, eps,
+                       residual, ld_res, relu, out, ld_out);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -196,15 +210,36 @@ int eprecon_batchnorm_train_async(const float *x, int64_t n, int channels, int l
     float *var = var_out ? var_out : reinterpret_cast<float *>(ws);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(256), 0, st, x, (int)n, channels, ld_x, partial);
     EP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(channels), dim3(256), 0, st, (const float *)partial, nblk, channels,
-                       mean, var);
-    EP_LAUNCH_CHECK();
-    const size_t total = (size_t)n * channels;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div((int64_t)total, 256)), dim3(256), 0, st, x,
-                       (int)n, channels, ld_x, (const float *)mean, (const float *)var, gamma, beta, eps,
-                       residual, ld_res, relu, out, ld_out);
-    EP_LAUNCH_CHECK();
-    return EPRECON_OK;
+    return bn_finalize_apply(x, n, channels, ld_x, partial, nblk, gamma, beta, eps, residual, ld_res, relu, out,
+                             ld_out, mean, var, st);
+}
+
+size_t eprecon_batchnorm_apply_workspace_bytes(int channels)
+{
+    return 2 * align_up((size_t)(channels > 0 ? channels : 1) * sizeof(float), 256);
+}
+
+// Second half of the train-mode BatchNorm for a tensor whose per-block (count, mean, M2) summaries
+// were already produced by its producer (eprecon_sparse_conv_fused_async's bn_partial,
+// [nblk][3][channels]): fixed-order merge -> mean / biased variance -> affine [+ residual] [ReLU].
+int eprecon_batchnorm_apply_partials_async(const float *x, int64_t n, int channels, int ld_x,
+                                           const float *partial, int64_t nblk, const float *gamma,
+                                           const float *beta, float eps, const float *residual,
+                                           int ld_res, int relu, float *out, int ld_out, float *mean_out,
+                                           float *var_out, void *workspace, size_t workspace_bytes,
+                                           void *stream)
+{
+    if (!x || !out || !partial || n < 0 || nblk <= 0 || nblk > 0x7fffffff || channels <= 0 || ld_x < channels ||
+        ld_out < channels || !workspace)
+        return EPRECON_ERR_ARG;
+    if (workspace_bytes < eprecon_batchnorm_apply_workspace_bytes(channels)) return EPRECON_ERR_WORKSPACE;
+    if (n == 0) return EPRECON_OK;
+    char *ws = reinterpret_cast<char *>(workspace);
+    float *mean = mean_out ? mean_out : reinterpret_cast<float *>(ws);
+    ws += align_up((size_t)channels * sizeof(float), 256);
+    float *var = var_out ? var_out : reinterpret_cast<float *>(ws);
+    return bn_finalize_apply(x, n, channels, ld_x, partial, (int)nblk, gamma, beta, eps, residual, ld_res, relu,
+                             out, ld_out, mean, var, (hipStream_t)stream);
 }
 
 int eprecon_rowwise_layernorm_async(const float *x, int64_t n, int channels, int ld_x,

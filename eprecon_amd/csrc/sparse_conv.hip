@@ -39,20 +39,24 @@ struct ConvParams {
     int n_out, K, Cin, Cout, ld_x, ld_out;
     int relu;            // fused ReLU epilogue
     int accumulate;      // out += result instead of out = result
+    const float *res;    // optional [n_out, ld_res]: added after the ReLU (x + ReLU(conv(x)) blocks)
+    int ld_res;
+    float *bn_partial;   // optional [gridDim.x][3][Cout]: per-workgroup (count, mean, M2) of the stored values
 };
 
-// Stage `rows` x TN weights (zero padded) from w[row0 + r][0:Cout] (row stride Cout, rows valid
+// Stage `rows` x TN weights (zero padded) from w[row0 + r][0:ncols] (row stride `stride`, rows valid
 // while row0 + r < row_end) into LDS.  Branch-free: addresses are clamped into the valid range and
 // the value is selected afterwards, so the compiler can keep many loads in flight (a guarded load
 // per element compiled to load / s_waitcnt vmcnt(0) pairs: ~500 cycles each).
 template <int TN>
-__device__ __forceinline__ void stage_weights(float *dst, const float *w, int row0, int row_end, int Cout,
-                                              int rows, int tid)
+__device__ __forceinline__ void stage_weights(float *dst, const float *w, int row0, int row_end, int stride,
+                                              int ncols, int rows, int tid)
 {
+    // w points at column col0 of row 0; `stride` floats per row, `ncols` valid columns from there
     const int total = rows * TN;
-    if (Cout == TN && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+    if (stride == TN && ncols >= TN && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
         // padded layout == source layout: straight 16-byte copies
-        const float4 *src = reinterpret_cast<const float4 *>(w + (size_t)row0 * Cout);
+        const float4 *src = reinterpret_cast<const float4 *>(w + (size_t)row0 * stride);
         float4 *d4 = reinterpret_cast<float4 *>(dst);
         const int valid4 = max(0, min(rows, row_end - row0)) * (TN / 4);
 #pragma unroll 4
@@ -62,9 +66,9 @@ __device__ __forceinline__ void stage_weights(float *dst, const float *w, int ro
 #pragma unroll 4
     for (int e = tid; e < total; e += 256) {
         const int r = e / TN, col = e - r * TN;
-        const bool ok = (row0 + r < row_end) && (col < Cout);
-        const int rr = min(row0 + r, row_end - 1), cc = min(col, Cout - 1);
-        const float v = w[(size_t)rr * Cout + cc];
+        const bool ok = (row0 + r < row_end) && (col < ncols);
+        const int rr = min(row0 + r, row_end - 1), cc = min(col, ncols - 1);
+        const float v = w[(size_t)rr * stride + cc];
         dst[e] = ok ? v : 0.0f;
     }
 }
@@ -73,6 +77,95 @@ constexpr int kRowsPerWave = 32;
 constexpr int kWaves = 4;
 constexpr int kRowsPerBlock = kRowsPerWave * kWaves;
 constexpr int kSlabC = 32;  // input channels per staged weight slab
+
+// Chan et al. merge of two (count, mean, M2) summaries; the caller fixes the order
+__device__ __forceinline__ void chan_merge(float &n_a, float &mean_a, float &m2_a, float n_b, float mean_b, float m2_b)
+{
+    if (n_b == 0.0f) return;
+    if (n_a == 0.0f) {
+        n_a = n_b; mean_a = mean_b; m2_a = m2_b;
+        return;
+    }
+    const float n = n_a + n_b;
+    const float d = mean_b - mean_a;
+    mean_a = mean_a + d * (n_b / n);
+    m2_a = m2_a + m2_b + d * d * (n_a * n_b / n);
+    n_a = n;
+}
+
+// Shared epilogue.  C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31,
+// row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+//   v = acc + bias; [v += out]; [v = max(v, 0)]; [v += res]; out = v
+// and, when p.bn_partial is set, the (count, mean, M2) summary of the stored values of this
+// workgroup's rows per column (lane-local two-pass over its 16 rows, then fixed-order Chan merges:
+// lane halves, then the four waves through LDS) -> bn_partial[blockIdx.x][3][Cout]: the
+// statistics pass of the train-mode BatchNorm that follows every convolution of the reference,
+// without re-reading the tensor.  sStat: >= kWaves * 3 * 32 * NT floats of LDS, free to overwrite.
+template <int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)[NT], int wrow0, int col0, int r32,
+                                              int half, int wave, float *sStat)
+{
+    constexpr int TN = 32 * NT;
+    const bool stats = p.bn_partial != nullptr;
+    if (stats) __syncthreads();  // every wave is done reading the weights that sStat overlays
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = col0 + t * 32 + r32;
+        const bool colok = col < p.Cout;
+        const float b = (p.bias && colok) ? p.bias[col] : 0.0f;
+        float vals[16];
+        float cnt = 0.0f, sum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = 0.0f;
+            if (colok && row < p.n_out) {
+                float *o = p.out + (size_t)row * p.ld_out + col;
+                v = acc[t][r] + b;
+                if (p.accumulate) v += *o;
+                if (p.relu) v = fmaxf(v, 0.0f);
+                if (p.res) v += p.res[(size_t)row * p.ld_res + col];
+                *o = v;
+                cnt += 1.0f;
+            }
+            vals[r] = v;
+            sum += v;
+        }
+        if (stats) {
+            float mean = cnt > 0.0f ? sum / cnt : 0.0f;
+            float m2 = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < p.n_out) {
+                    const float d = vals[r] - mean;
+                    m2 = fmaf(d, d, m2);
+                }
+            }
+            // halves: lanes l and l ^ 32 hold the two row sets of one column; merge as (half 0, half 1)
+            const float on = __shfl_xor(cnt, 32), omean = __shfl_xor(mean, 32), om2 = __shfl_xor(m2, 32);
+            float a_n = half ? on : cnt, a_mean = half ? omean : mean, a_m2 = half ? om2 : m2;
+            chan_merge(a_n, a_mean, a_m2, half ? cnt : on, half ? mean : omean, half ? m2 : om2);
+            if (half == 0) {
+                float *d = sStat + (wave * 3) * TN + t * 32 + r32;
+                d[0] = a_n; d[TN] = a_mean; d[2 * TN] = a_m2;
+            }
+        }
+    }
+    if (stats) {
+        __syncthreads();
+        const int tid = threadIdx.x;
+        if (tid < TN && col0 + tid < p.Cout) {
+            float a_n = 0.0f, a_mean = 0.0f, a_m2 = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w)
+                chan_merge(a_n, a_mean, a_m2, sStat[(w * 3) * TN + tid], sStat[(w * 3 + 1) * TN + tid],
+                           sStat[(w * 3 + 2) * TN + tid]);
+            float *dst = p.bn_partial + (size_t)blockIdx.x * 3 * p.Cout + col0 + tid;
+            dst[0] = a_n; dst[p.Cout] = a_mean; dst[2 * p.Cout] = a_m2;
+        }
+    }
+}
 
 template <int NT, bool VEC4>
 __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvParams p)
@@ -87,6 +180,7 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvParams p)
     const int lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, half = lane >> 5;
     const int row0 = blockIdx.x * kRowsPerBlock;
+    const int col0 = blockIdx.y * TN;  // short lists: the output columns are split over blockIdx.y
 
     // neighbour tile + live-offset flags
     for (int k = tid; k < p.K; k += 256) sActive[k] = 0;
@@ -115,12 +209,12 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvParams p)
         if (!sActive[k]) continue;  // block-uniform
         const int j = sNbr[k * kRowsPerBlock + wave * kRowsPerWave + r32];
         const float *xrow = p.x + (size_t)(j >= 0 ? j : 0) * p.ld_x;
-        const float *wk = p.w + (size_t)k * p.Cin * p.Cout;
+        const float *wk = p.w + (size_t)k * p.Cin * p.Cout + col0;
         for (int sl = 0; sl < nslab; ++sl) {
             const int c0 = sl * kSlabC;
             // ---- stage W[k][c0 : c0+32][0 : TN] into sW[buf] (zero padded) ----
             float *dstW = sW + buf * kSlabC * TN;
-            stage_weights<TN>(dstW, wk, c0, p.Cin, p.Cout, kSlabC, tid);
+            stage_weights<TN>(dstW, wk, c0, p.Cin, p.Cout, p.Cout - col0, kSlabC, tid);
             // ---- gather this lane's A values: 4 chunks of 8 channels, 4 floats each ----
             float a[4][4];
 #pragma unroll
@@ -153,25 +247,7 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvParams p)
         }
     }
 
-    // ---- epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
-    const int wrow0 = row0 + wave * kRowsPerWave;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int col = t * 32 + r32;
-        if (col >= p.Cout) continue;
-        const float b = p.bias ? p.bias[col] : 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (row < p.n_out) {
-                float *o = p.out + (size_t)row * p.ld_out + col;
-                float v = acc[t][r] + b;
-                if (p.accumulate) v += *o;
-                if (p.relu) v = fmaxf(v, 0.0f);
-                *o = v;
-            }
-        }
-    }
+    conv_epilogue<NT>(p, acc, row0 + wave * kRowsPerWave, col0, r32, half, wave, sW);
 }
 
 
@@ -218,6 +294,8 @@ __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int 
     const int lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, half = lane >> 5;
     const int wrow0 = blockIdx.x * kRowsPerBlock + wave * kRowsPerWave;
+    const int col0 = blockIdx.y * TN;
+    const float *wbase = p.w + col0;
     // the neighbour indices of the whole tile go to LDS up front: the gather of offset k+1 then
     // depends on ONE memory latency (the rows), not two (index, then rows)
     for (int e = tid; e < p.K * kRowsPerBlock; e += 256) {
@@ -242,10 +320,11 @@ __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int 
         __syncthreads();  // every wave is done with the previous group's weights
         if (cin_pad == p.Cin) {
             // rows of consecutive offsets are contiguous in W: one flat [kn * Cin][Cout] block
-            stage_weights<TN>(sW, p.w, k0 * p.Cin, (k0 + kn) * p.Cin, p.Cout, kn * cin_pad, tid);
+            stage_weights<TN>(sW, wbase, k0 * p.Cin, (k0 + kn) * p.Cin, p.Cout, p.Cout - col0, kn * cin_pad, tid);
         } else {
             for (int kk = 0; kk < kn; ++kk)
-                stage_weights<TN>(sW + kk * per_k, p.w, (k0 + kk) * p.Cin, (k0 + kk + 1) * p.Cin, p.Cout, cin_pad, tid);
+                stage_weights<TN>(sW + kk * per_k, wbase, (k0 + kk) * p.Cin, (k0 + kk + 1) * p.Cin, p.Cout,
+                                  p.Cout - col0, cin_pad, tid);
         }
         __syncthreads();
         for (int kk = 0; kk < kn; ++kk) {
@@ -278,23 +357,7 @@ __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int 
             j = jn;
         }
     }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int col = t * 32 + r32;
-        if (col >= p.Cout) continue;
-        const float b = p.bias ? p.bias[col] : 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int orow = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (orow < p.n_out) {
-                float *o = p.out + (size_t)orow * p.ld_out + col;
-                float v = acc[t][r] + b;
-                if (p.accumulate) v += *o;
-                if (p.relu) v = fmaxf(v, 0.0f);
-                *o = v;
-            }
-        }
-    }
+    conv_epilogue<NT>(p, acc, wrow0, col0, r32, half, wave, sW);
 }
 
 template <int NT, int NCH>
@@ -303,12 +366,13 @@ int launch_resident_nch(const ConvParams &p, bool vec4, hipStream_t st)
     // weights of `kgroup` offsets resident at a time (<= 36 KB -> 4 workgroups per CU)
     const size_t per_k = (size_t)NCH * 8 * 32 * NT * sizeof(float);
     const int kgroup = (int)max((size_t)1, min((size_t)p.K, (size_t)(24 * 1024) / per_k));
-    const size_t lds = (size_t)kgroup * per_k + (size_t)p.K * kRowsPerBlock * sizeof(int);
-    const int grid = (int)ceil_div(p.n_out, kRowsPerBlock);
+    const size_t lds = max((size_t)kgroup * per_k + (size_t)p.K * kRowsPerBlock * sizeof(int),
+                           (size_t)kWaves * 3 * 32 * NT * sizeof(float));
+    const dim3 grid((unsigned)ceil_div(p.n_out, kRowsPerBlock), (unsigned)ceil_div(p.Cout, 32 * NT));
     if (vec4)
-        hipLaunchKernelGGL((spconv_resident_kernel<NT, true, NCH>), dim3(grid), dim3(256), lds, st, p, kgroup);
+        hipLaunchKernelGGL((spconv_resident_kernel<NT, true, NCH>), grid, dim3(256), lds, st, p, kgroup);
     else
-        hipLaunchKernelGGL((spconv_resident_kernel<NT, false, NCH>), dim3(grid), dim3(256), lds, st, p, kgroup);
+        hipLaunchKernelGGL((spconv_resident_kernel<NT, false, NCH>), grid, dim3(256), lds, st, p, kgroup);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }
@@ -331,48 +395,72 @@ int launch_resident(const ConvParams &p, bool vec4, int cin_pad, hipStream_t st)
 template <int NT>
 int launch_conv(const ConvParams &p, bool vec4, hipStream_t st)
 {
-    const int nblk = (int)ceil_div(p.n_out, kRowsPerBlock);
+    const dim3 grid((unsigned)ceil_div(p.n_out, kRowsPerBlock), (unsigned)ceil_div(p.Cout, 32 * NT));
     const size_t lds = (size_t)2 * kSlabC * 32 * NT * sizeof(float) +
                        (size_t)p.K * kRowsPerBlock * sizeof(int) + (size_t)p.K * sizeof(int) + 16;
     if (vec4)
-        hipLaunchKernelGGL((spconv_mfma_kernel<NT, true>), dim3(nblk), dim3(256), lds, st, p);
+        hipLaunchKernelGGL((spconv_mfma_kernel<NT, true>), grid, dim3(256), lds, st, p);
     else
-        hipLaunchKernelGGL((spconv_mfma_kernel<NT, false>), dim3(nblk), dim3(256), lds, st, p);
+        hipLaunchKernelGGL((spconv_mfma_kernel<NT, false>), grid, dim3(256), lds, st, p);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }
 
+int conv_dispatch(ConvParams &p, int64_t n_in, hipStream_t st)
+{
+    const bool vec4 = (p.Cin % 4 == 0) && (p.ld_x % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
+    // Output columns per workgroup: all of them (<= 128) when the row tiles alone fill the chip,
+    // 32-column blocks over blockIdx.y for short lists (10,800 pixels of the 1/16 maps are 85 row
+    // tiles for 256 CUs; the gathered rows are re-read from L2 by each column block).
+    const int nblk = (int)ceil_div(p.n_out, kRowsPerBlock);
+    const int nt_full = (p.Cout + 31) / 32;
+    const bool split = nblk < 256 && nt_full > 1;
+    const int cin_pad = (p.Cin + 7) / 8 * 8;
+    static const bool resident_on = !(getenv("EPRECON_CONV_RESIDENT") && getenv("EPRECON_CONV_RESIDENT")[0] == '0');
+    // narrow layers: the weights of a group of offsets resident in LDS
+    if (resident_on && cin_pad <= 64 && (p.Cout <= 64 || split))
+        return (nt_full == 1 || split) ? launch_resident<1>(p, vec4, cin_pad, st) : launch_resident<2>(p, vec4, cin_pad, st);
+    if (nt_full == 1 || split) return launch_conv<1>(p, vec4, st);
+    if (nt_full == 2) return launch_conv<2>(p, vec4, st);
+    if (nt_full == 3) return launch_conv<3>(p, vec4, st);
+    return launch_conv<4>(p, vec4, st);  // Cout > 128: 128-column blocks over blockIdx.y
+}
+
 }  // namespace
+
+extern "C" size_t eprecon_conv_bn_partial_bytes(int64_t n_out, int cout)
+{
+    return (size_t)ep::ceil_div(n_out > 0 ? n_out : 1, (int64_t)128) * 3 * (size_t)(cout > 0 ? cout : 1) * sizeof(float);
+}
+
+// out = [ReLU]( sum_k x[nbr[k]] @ W[k] + bias [+ out] ) [+ residual]; optionally the per-workgroup
+// BatchNorm summaries of the stored values (see conv_epilogue) -> bn_partial, to be consumed by
+// eprecon_batchnorm_apply_partials_async.
+extern "C" int eprecon_sparse_conv_fused_async(const float *x, int64_t n_in, int ld_x, const int32_t *nbr,
+                                               int kvol, int64_t n_out, const float *weight, int cin,
+                                               int cout, const float *bias, const float *residual,
+                                               int ld_res, float *out, int ld_out, int relu,
+                                               int accumulate, float *bn_partial, void *stream)
+{
+    if (!x || !weight || !out || n_in < 0 || n_out < 0 || kvol <= 0 || kvol > 64 || cin <= 0 ||
+        cout <= 0 || ld_x < cin || ld_out < cout || (residual && ld_res < cout))
+        return EPRECON_ERR_ARG;
+    if (!nbr && (kvol != 1 || n_in != n_out)) return EPRECON_ERR_ARG;
+    if (cout > 4096) return EPRECON_ERR_UNSUPPORTED;
+    if (n_out == 0) return EPRECON_OK;
+    ConvParams p;
+    p.x = x; p.nbr = nbr; p.w = weight; p.bias = bias; p.out = out;
+    p.n_out = (int)n_out; p.K = kvol; p.Cin = cin; p.Cout = cout; p.ld_x = ld_x; p.ld_out = ld_out;
+    p.relu = relu; p.accumulate = accumulate;
+    p.res = residual; p.ld_res = ld_res; p.bn_partial = bn_partial;
+    return conv_dispatch(p, n_in, (hipStream_t)stream);
+}
 
 extern "C" int eprecon_sparse_conv_async(const float *x, int64_t n_in, int ld_x, const int32_t *nbr,
                                          int kvol, int64_t n_out, const float *weight, int cin,
                                          int cout, const float *bias, float *out, int ld_out,
                                          int relu, int accumulate, void *stream)
 {
-    if (!x || !weight || !out || n_in < 0 || n_out < 0 || kvol <= 0 || kvol > 64 || cin <= 0 ||
-        cout <= 0 || ld_x < cin || ld_out < cout)
-        return EPRECON_ERR_ARG;
-    if (!nbr && (kvol != 1 || n_in != n_out)) return EPRECON_ERR_ARG;
-    if (cout > 256) return EPRECON_ERR_UNSUPPORTED;
-    if (n_out == 0) return EPRECON_OK;
-    ConvParams p;
-    p.x = x; p.nbr = nbr; p.w = weight; p.bias = bias; p.out = out;
-    p.n_out = (int)n_out; p.K = kvol; p.Cin = cin; p.Cout = cout; p.ld_x = ld_x; p.ld_out = ld_out;
-    p.relu = relu; p.accumulate = accumulate;
-    const bool vec4 = (cin % 4 == 0) && (ld_x % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-    hipStream_t st = (hipStream_t)stream;
-    // narrow layers: whole weight tensor resident in LDS, persistent barrier-free workgroups
-    {
-        const int cin_pad = (cin + 7) / 8 * 8;
-        const int nt = cout <= 32 ? 1 : 2;
-        static const bool resident_on = !(getenv("EPRECON_CONV_RESIDENT") && getenv("EPRECON_CONV_RESIDENT")[0] == '0');
-        if (resident_on && cin_pad <= 64 && cout <= 64)
-            return nt == 1 ? launch_resident<1>(p, vec4, cin_pad, st) : launch_resident<2>(p, vec4, cin_pad, st);
-    }
-    // Cout > 128: two passes over column halves keep the accumulator footprint at <= 64 VGPRs
-    if (cout <= 32) return launch_conv<1>(p, vec4, st);
-    if (cout <= 64) return launch_conv<2>(p, vec4, st);
-    if (cout <= 96) return launch_conv<3>(p, vec4, st);
-    if (cout <= 128) return launch_conv<4>(p, vec4, st);
-    return EPRECON_ERR_UNSUPPORTED;
+    return eprecon_sparse_conv_fused_async(x, n_in, ld_x, nbr, kvol, n_out, weight, cin, cout, bias, nullptr, 0,
+                                           out, ld_out, relu, accumulate, nullptr, stream);
 }

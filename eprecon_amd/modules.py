@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import dense2d as D2
 from . import sparse as SP
 
 # ------------------------------------------------------------------------------------------------
@@ -218,6 +219,10 @@ class Conv2d_Block(nn.Module):
     def forward(self, x):
         return bn2d_train(self.bn, self.conv(x), relu=True)
 
+    def run_rows(self, x, grid, out=None):
+        """pixel rows [V*H*W, C_in] -> [V*H*W, C_out] on the HIP gather-GEMM path (dense2d.py)"""
+        return D2.conv_bn(self.conv, self.bn, x, grid, out=out, relu=True)
+
 
 class Conv2d_Residual_Block(nn.Module):
     """BN(x + ReLU(conv(x))) (models/modules.py:385-399)"""
@@ -230,6 +235,9 @@ class Conv2d_Residual_Block(nn.Module):
 
     def forward(self, x):
         return bn2d_train(self.bn, x + self.relu(self.conv(x)))
+
+    def run_rows(self, x, grid, out=None):
+        return D2.conv_bn(self.conv, self.bn, x, grid, out=out, relu=False, pre_relu=True, pre_residual=x)
 
 
 class ELAN(nn.Module):
@@ -252,6 +260,18 @@ class ELAN(nn.Module):
             parts.append(layer(parts[-1]))
         return self.conv7(torch.cat(parts, dim=1))
 
+    def run_rows(self, x, grid, out=None):
+        d = x.shape[1]
+        h = d // 2
+        cat = torch.empty((x.shape[0], 4 * d), dtype=torch.float32, device=x.device)  # branches write in place
+        self.conv1.run_rows(x, grid, out=cat[:, 0:d])
+        self.conv2.run_rows(x, grid, out=cat[:, d:2 * d])
+        self.conv3.run_rows(cat[:, d:2 * d], grid, out=cat[:, 2 * d:2 * d + h])
+        self.conv4.run_rows(cat[:, 2 * d:2 * d + h], grid, out=cat[:, 2 * d + h:3 * d])
+        self.conv5.run_rows(cat[:, 2 * d + h:3 * d], grid, out=cat[:, 3 * d:3 * d + h])
+        self.conv6.run_rows(cat[:, 3 * d:3 * d + h], grid, out=cat[:, 3 * d + h:4 * d])
+        return self.conv7.run_rows(cat, grid, out=out)
+
 
 class Fusion_Block(nn.Module):
     """3x3 conv-BN-ReLU, 1x1 conv-BN-ReLU, ELAN (models/modules.py:313-338)"""
@@ -269,6 +289,11 @@ class Fusion_Block(nn.Module):
         x = bn2d_train(self.bn1, self.conv1(x), relu=True)
         x = bn2d_train(self.bn2, self.conv2(x), relu=True)
         return self.ELAN(x)
+
+    def run_rows(self, x, grid, out=None):
+        x = D2.conv_bn(self.conv1, self.bn1, x, grid, relu=True)
+        x = D2.conv_bn(self.conv2, self.bn2, x, grid, relu=True)
+        return self.ELAN.run_rows(x, grid, out=out)
 
 
 class Linear4xTrans(nn.Module):

@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import back_project as BP
+from . import dense2d as D2
 from . import sparse as SP
 from .config import INIT_MIN_VALID
 from .modules import (Conv2d_Block, Conv2d_Residual_Block, Fusion_Block, SparseSubMConv3d, Spares3dELAN,
@@ -50,13 +51,16 @@ class Occupancy_Initialization(nn.Module):
         # torch.no_grad() it is captured once into a HIP graph and replayed (launch-bound otherwise).
         self.use_hip_graph = os.environ.get("EPRECON_NO_GRAPH", "0") != "1"
         self._graphs = {}
+        # EPRECON_MIOPEN_CONV2D=1 keeps the 2D convolutions on PyTorch-ROCm / MIOpen (A/B switch)
+        self.use_hip_conv = os.environ.get("EPRECON_MIOPEN_CONV2D", "0") != "1"
         self._channels_last = False
 
     def feat_fusion_pre(self, feats_1x, feats_2x, feats_4x):
         """[V,80,H/16,W/16], [V,40,H/8,W/8], [V,24,H/4,W/4] -> [V,32,H/8,W/8]  (:41-58)"""
+        if feats_1x.is_cuda and not torch.is_grad_enabled() and self.use_hip_conv:
+            return self._feat_fusion_rows(feats_1x, feats_2x, feats_4x)
         if feats_1x.is_cuda and not torch.is_grad_enabled():
-            # inference on the GPU: channels-last activations (MIOpen NHWC convolutions, HIP BatchNorm /
-            # upsampling on the [N*H*W, C] view); the result feeds the back-projection in place
+            # MIOpen NHWC convolutions + HIP BatchNorm / upsampling on the channels-last view
             if not self._channels_last:
                 for mod in (self.self_fusion_1x, self.self_fusion_2x, self.self_fusion_4x, self.fusion_down,
                             self.post_fusion_1, self.post_fusion_2, self.post_fusion_3, self.post_fusion_4):
@@ -71,6 +75,30 @@ class Occupancy_Initialization(nn.Module):
         for blk in (self.post_fusion_1, self.post_fusion_2, self.post_fusion_3, self.post_fusion_4):
             x = blk(x)
         return x
+
+    def _feat_fusion_rows(self, feats_1x, feats_2x, feats_4x):
+        """Inference on the GPU: the whole 2D stack on pixel-row matrices (channels-last), every
+        convolution + BatchNorm on the HIP gather-GEMM path (dense2d.py); the 32-channel result is
+        returned as a channels-last [V,32,H/8,W/8] view and feeds the back-projection in place."""
+        dev = feats_1x.device
+        rows, grids = [], []
+        for t in (feats_1x, feats_2x, feats_4x):
+            v, c, h, w = t.shape
+            rows.append(D2.rows_of(t.float().contiguous(memory_format=torch.channels_last)))
+            grids.append(D2.PixelGrid.get(v, h, w, dev))
+        g1, g2, g4 = grids
+        c1, c2, c4 = (r.shape[1] for r in rows)
+        f1 = self.self_fusion_1x.run_rows(rows[0], g1)
+        cat = torch.empty((g2.n, c1 + c2 + c4), dtype=torch.float32, device=dev)
+        up = upsample2x_bilinear(D2.maps_of(f1, g1.maps, g1.height, g1.width))
+        cat[:, 0:c1] = D2.rows_of(up)
+        self.self_fusion_2x.run_rows(rows[1], g2, out=cat[:, c1:c1 + c2])
+        f4 = self.self_fusion_4x.run_rows(rows[2], g4)
+        cat[:, c1 + c2:] = D2.rows_of(self.pool4x(D2.maps_of(f4, g4.maps, g4.height, g4.width)))
+        x = self.fusion_down.run_rows(cat, g2)
+        for blk in (self.post_fusion_1, self.post_fusion_2, self.post_fusion_3, self.post_fusion_4):
+            x = blk.run_rows(x, g2)
+        return D2.maps_of(x, g2.maps, g2.height, g2.width)
 
     def _fusion_graphed(self, f1, f2, f4):
         """feat_fusion_pre through a captured HIP graph (inference only; the result buffer is reused

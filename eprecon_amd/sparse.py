@@ -145,6 +145,51 @@ def sparse_conv(x, weight, nbr=None, bias=None, out=None, relu=False, accumulate
     return out
 
 
+def sparse_conv_fused(x, weight, nbr=None, bias=None, out=None, relu=False, residual=None, accumulate=False,
+                      bn_partial=False):
+    """sparse_conv with the fused epilogues: v = conv + bias [+ out]; [relu]; [+ residual]; and, with
+    bn_partial, the per-workgroup BatchNorm summaries f32[ceil(n/128), 3, cout] of the stored values.
+    Returns (out, partial or None)."""
+    lib = _lib.load()
+    if weight.dim() == 2:
+        weight = weight.unsqueeze(0)
+    kvol, cin, cout = weight.shape
+    weight = weight.contiguous()
+    n_out = x.shape[0] if nbr is None else nbr.shape[1]
+    assert x.shape[1] == cin and x.dtype == torch.float32
+    if nbr is not None:
+        assert nbr.dtype == torch.int32 and nbr.shape[0] == kvol and nbr.is_contiguous()
+    if out is None:
+        out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+    assert out.shape == (n_out, cout)
+    partial = None
+    if bn_partial:
+        partial = torch.empty(((n_out + 127) // 128, 3, cout), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        assert residual.shape == (n_out, cout) and residual.dtype == torch.float32
+    _lib.check(lib.eprecon_sparse_conv_fused_async(
+        _lib.ptr(x), x.shape[0], _ld(x), _lib.ptr(nbr), kvol, n_out, _lib.ptr(weight), cin, cout, _lib.ptr(bias),
+        _lib.ptr(residual), _ld(residual) if residual is not None else 0, _lib.ptr(out), _ld(out), int(relu),
+        int(accumulate), _lib.ptr(partial), _lib.current_stream()), "eprecon_sparse_conv_fused_async")
+    return out, partial
+
+
+def batchnorm_apply_partials(x, partial, gamma=None, beta=None, eps=1e-5, residual=None, relu=False, out=None):
+    """second half of the train-mode BatchNorm from producer-side summaries (sparse_conv_fused)"""
+    lib = _lib.load()
+    n, c = x.shape
+    assert partial.shape[1:] == (3, c) and partial.is_contiguous()
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    ws = _lib.workspace(lib.eprecon_batchnorm_apply_workspace_bytes(c), x.device)
+    _lib.check(lib.eprecon_batchnorm_apply_partials_async(
+        _lib.ptr(x), n, c, _ld(x), _lib.ptr(partial), partial.shape[0], _lib.ptr(gamma), _lib.ptr(beta),
+        float(eps), _lib.ptr(residual), _ld(residual) if residual is not None else 0, int(relu), _lib.ptr(out),
+        _ld(out), None, None, _lib.ptr(ws), ws.numel(), _lib.current_stream()),
+        "eprecon_batchnorm_apply_partials_async")
+    return out
+
+
 def batchnorm_train(x, gamma=None, beta=None, eps=1e-5, residual=None, relu=False, out=None):
     """train-mode BatchNorm over all rows (+ optional residual add and ReLU); out may be x"""
     lib = _lib.load()

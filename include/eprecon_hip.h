@@ -166,11 +166,33 @@ int eprecon_transpose_map_async(const int32_t *fine_coords, int64_t n, const int
  * x / out are row-major with leading dimensions ld_x / ld_out (so a layer can read from / write
  * into a channel slice of a wider buffer = torchsparse.cat for free).  nbr == NULL means the
  * identity map (kvol must be 1: a per-voxel linear layer).  relu != 0 fuses ReLU; accumulate != 0
- * adds to the existing contents of out.  cout <= 128.  fp32 MFMA, deterministic.
+ * adds to the existing contents of out.  fp32 MFMA, deterministic.
  */
 int eprecon_sparse_conv_async(const float *x, int64_t n_in, int ld_x, const int32_t *nbr, int kvol,
                               int64_t n_out, const float *weight, int cin, int cout, const float *bias,
                               float *out, int ld_out, int relu, int accumulate, void *stream);
+/*
+ * The same contraction with the epilogues the reference wires around its convolutions:
+ *   v = conv + bias [+ out]; [v = relu(v)]; [v += residual];  out = v
+ * (residual: BN(x + ReLU(conv(x))) blocks, models/modules.py:385-399), and optionally the first
+ * half of the train-mode BatchNorm that follows (models/modules.py:372-383 and every
+ * spnn.BatchNorm): bn_partial f32[ceil(n_out/128)][3][cout] receives per-workgroup
+ * (count, mean, M2) summaries of the stored values (eprecon_conv_bn_partial_bytes bytes), to be
+ * finished by eprecon_batchnorm_apply_partials_async without re-reading the tensor for statistics.
+ */
+size_t eprecon_conv_bn_partial_bytes(int64_t n_out, int cout);
+int eprecon_sparse_conv_fused_async(const float *x, int64_t n_in, int ld_x, const int32_t *nbr, int kvol,
+                                    int64_t n_out, const float *weight, int cin, int cout,
+                                    const float *bias, const float *residual, int ld_res, float *out,
+                                    int ld_out, int relu, int accumulate, float *bn_partial, void *stream);
+/*
+ * Kernel map of a dense 2D 'same' convolution (odd ksize) over `maps` images of height x width
+ * pixels stored as rows [maps][height][width] of a channels-last tensor:
+ * nbr int32[ksize*ksize][maps*height*width], offset index ky * ksize + kx, -1 = zero padding.
+ * With it nn.Conv2d(padding="same") of models/modules.py:313-399 / models/occupancy_initialization.py:22-31
+ * runs on eprecon_sparse_conv_fused_async (weight re-laid out to [ky*ks+kx][cin][cout]).
+ */
+int eprecon_pixel_map_async(int maps, int height, int width, int ksize, int32_t *nbr, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Normalisation epilogues  (K12)
@@ -187,6 +209,15 @@ int eprecon_batchnorm_train_async(const float *x, int64_t n, int channels, int l
                                   const float *beta, float eps, const float *residual, int ld_res,
                                   int relu, float *out, int ld_out, float *mean_out, float *var_out,
                                   void *workspace, size_t workspace_bytes, void *stream);
+/* second half of the same BatchNorm from producer-side summaries partial f32[nblk][3][channels]
+ * (count, mean, M2 per block, merged in block order) */
+size_t eprecon_batchnorm_apply_workspace_bytes(int channels);
+int eprecon_batchnorm_apply_partials_async(const float *x, int64_t n, int channels, int ld_x,
+                                           const float *partial, int64_t nblk, const float *gamma,
+                                           const float *beta, float eps, const float *residual,
+                                           int ld_res, int relu, float *out, int ld_out, float *mean_out,
+                                           float *var_out, void *workspace, size_t workspace_bytes,
+                                           void *stream);
 /* per row: t = x; if pre_relu t = relu(t); if residual t += residual; y = LN(t) * gamma + beta;
  * if post_relu y = relu(y).  out may alias x. */
 int eprecon_rowwise_layernorm_async(const float *x, int64_t n, int channels, int ld_x,
