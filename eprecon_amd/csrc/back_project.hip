@@ -176,7 +176,7 @@ __device__ __forceinline__ void stage_matrices(float *sP, const float *krcam, in
 // One thread per voxel, 256 per workgroup.  The valid totals are produced per TILE of VOX consecutive
 // voxels (VOX = 256, 64 or 16: the tile the gather kernel hands to one workgroup).
 template <int VOX>
-__global__ __launch_bounds__(256) void bp_count_kernel(BpParams p, int32_t *tile_sums)
+__global__ __launch_bounds__(256) void bp_count_kernel(BpParams p, int32_t *tile_sums, int32_t *blk_batch)
 {
     constexpr int BLOCK = 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -234,8 +234,12 @@ __global__ __launch_bounds__(256) void bp_count_kernel(BpParams p, int32_t *tile
         if ((lane % VOX) == 0 && i < p.n) tile_sums[i / VOX] = __popcll((m >> lane) & ((1ull << VOX) - 1ull));
         __syncthreads();
     }
-    for (int b = tid; b < p.batch; b += BLOCK)
-        if (sBatch[b]) atomicAdd(&p.n_valid_dev[1 + b], sBatch[b]);
+    // per-batch totals: per-workgroup rows reduced by bp_scan_kernel (3,456 same-address global atomics
+    // cost ~40 us on the dense 96^3 level: device-scope atomics serialise at the memory side)
+    if (blk_batch) {
+        __syncthreads();
+        for (int b = tid; b < p.batch; b += BLOCK) blk_batch[(size_t)blockIdx.x * p.batch + b] = sBatch[b];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -330,7 +334,8 @@ __global__ __launch_bounds__(256) void bp_bin_fill_kernel(const int4 *coords, in
 
 // exclusive scan of the block totals, one workgroup; also publishes n_valid
 __global__ __launch_bounds__(1024) void bp_scan_kernel(int32_t *block_sums, int nblk,
-                                                       int32_t *n_valid_dev)
+                                                       int32_t *n_valid_dev, const int32_t *blk_batch = nullptr,
+                                                       int nblk_count = 0, int batch = 0)
 {
     __shared__ int sWave[1024 / kWave];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
@@ -358,6 +363,25 @@ __global__ __launch_bounds__(1024) void bp_scan_kernel(int32_t *block_sums, int 
         __syncthreads();
     }
     if (tid == 0) n_valid_dev[0] = carry;
+    // per-batch valid totals from the count kernel's per-workgroup rows
+    if (batch == 1) {
+        if (tid == 0) n_valid_dev[1] = carry;
+    } else if (blk_batch) {
+        for (int b = 0; b < batch; ++b) {
+            int x = 0;
+            for (int i = tid; i < nblk_count; i += 1024) x += blk_batch[(size_t)i * batch + b];
+#pragma unroll
+            for (int d = kWave / 2; d > 0; d >>= 1) x += __shfl_xor(x, d);
+            __syncthreads();
+            if (lane == 0) sWave[wid] = x;
+            __syncthreads();
+            if (tid == 0) {
+                int t = 0;
+                for (int w = 0; w < 1024 / kWave; ++w) t += sWave[w];
+                n_valid_dev[1 + b] = t;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1344,6 +1368,7 @@ size_t eprecon_back_project_workspace_bytes(int64_t n, int batch, int n_views, i
                                             int height, int width, int feats_layout)
 {
     size_t bytes = ep::align_up((size_t)ep::ceil_div(n > 0 ? n : 1, 16) * sizeof(int32_t), 256);
+    bytes += ep::align_up((size_t)ep::ceil_div(n > 0 ? n : 1, 256) * (batch > 0 ? batch : 1) * sizeof(int32_t), 256);
     // brick-sorted pipeline: flag / slot / perm (N ints each), histogram + bin offsets, scan scratch
     bytes += 3 * ep::align_up((size_t)(n > 0 ? n : 1) * 4, 256) +
              2 * ep::align_up((size_t)kBinsPerBatch * (batch > 0 ? batch : 1) * 4, 256) +
@@ -1412,6 +1437,8 @@ int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *or
     char *ws = reinterpret_cast<char *>(workspace);
     int32_t *block_sums = reinterpret_cast<int32_t *>(ws);
     ws += ep::align_up((size_t)ep::ceil_div(n, 16) * sizeof(int32_t), 256);
+    int32_t *blk_batch = reinterpret_cast<int32_t *>(ws);
+    ws += ep::align_up((size_t)ep::ceil_div(n, 256) * batch * sizeof(int32_t), 256);
     const float *nhwc = feats;
     read_tuning_env();
     int pix_stride = channels;
@@ -1509,16 +1536,18 @@ int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *or
     const int ntile = (int)ep::ceil_div(n, vox);
     const int nblk_count = (int)ep::ceil_div(n, 256);
     const size_t lds_count = ((size_t)n_views * batch * 12 + batch + 256 / ep::kWave) * 4 + 16;
+    int32_t *bb = batch > 1 ? blk_batch : nullptr;
     if (vox == 256)
-        hipLaunchKernelGGL((bp_count_kernel<256>), dim3(nblk_count), dim3(256), lds_count, st, p, block_sums);
+        hipLaunchKernelGGL((bp_count_kernel<256>), dim3(nblk_count), dim3(256), lds_count, st, p, block_sums, bb);
     else if (vox == 128)
-        hipLaunchKernelGGL((bp_count_kernel<128>), dim3(nblk_count), dim3(256), lds_count, st, p, block_sums);
+        hipLaunchKernelGGL((bp_count_kernel<128>), dim3(nblk_count), dim3(256), lds_count, st, p, block_sums, bb);
     else if (vox == 64)
-        hipLaunchKernelGGL((bp_count_kernel<64>), dim3(nblk_count), dim3(256), lds_count, st, p, block_sums);
+        hipLaunchKernelGGL((bp_count_kernel<64>), dim3(nblk_count), dim3(256), lds_count, st, p, block_sums, bb);
     else
-        hipLaunchKernelGGL((bp_count_kernel<16>), dim3(nblk_count), dim3(256), lds_count, st, p, block_sums);
+        hipLaunchKernelGGL((bp_count_kernel<16>), dim3(nblk_count), dim3(256), lds_count, st, p, block_sums, bb);
     EP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bp_scan_kernel, dim3(1), dim3(1024), 0, st, block_sums, ntile, n_valid_dev);
+    hipLaunchKernelGGL(bp_scan_kernel, dim3(1), dim3(1024), 0, st, block_sums, ntile, n_valid_dev,
+                       (const int32_t *)bb, nblk_count, batch);
     EP_LAUNCH_CHECK();
 
     const bool prof = g_prof.on && g_prof.start;

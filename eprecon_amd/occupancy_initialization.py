@@ -54,6 +54,7 @@ class Occupancy_Initialization(nn.Module):
         # EPRECON_MIOPEN_CONV2D=1 keeps the 2D convolutions on PyTorch-ROCm / MIOpen (A/B switch)
         self.use_hip_conv = os.environ.get("EPRECON_MIOPEN_CONV2D", "0") != "1"
         self._channels_last = False
+        self._side_streams = None
 
     def feat_fusion_pre(self, feats_1x, feats_2x, feats_4x):
         """[V,80,H/16,W/16], [V,40,H/8,W/8], [V,24,H/4,W/4] -> [V,32,H/8,W/8]  (:41-58)"""
@@ -88,13 +89,26 @@ class Occupancy_Initialization(nn.Module):
             grids.append(D2.PixelGrid.get(v, h, w, dev))
         g1, g2, g4 = grids
         c1, c2, c4 = (r.shape[1] for r in rows)
-        f1 = self.self_fusion_1x.run_rows(rows[0], g1)
         cat = torch.empty((g2.n, c1 + c2 + c4), dtype=torch.float32, device=dev)
-        up = upsample2x_bilinear(D2.maps_of(f1, g1.maps, g1.height, g1.width))
-        cat[:, 0:c1] = D2.rows_of(up)
+        # The three per-level Fusion_Blocks are independent until the concat: the 1/16 level is only 85
+        # row tiles (one wave per SIMD on a third of the CUs), so the levels run on three streams and
+        # join at the concat (under HIP-graph capture this becomes three parallel branches).
+        main = torch.cuda.current_stream()
+        if self._side_streams is None:
+            self._side_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        s1, s4 = self._side_streams
+        s1.wait_stream(main)
+        s4.wait_stream(main)
+        with torch.cuda.stream(s4):
+            f4 = self.self_fusion_4x.run_rows(rows[2], g4)
+            cat[:, c1 + c2:] = D2.rows_of(self.pool4x(D2.maps_of(f4, g4.maps, g4.height, g4.width)))
+        with torch.cuda.stream(s1):
+            f1 = self.self_fusion_1x.run_rows(rows[0], g1)
+            up = upsample2x_bilinear(D2.maps_of(f1, g1.maps, g1.height, g1.width))
+            cat[:, 0:c1] = D2.rows_of(up)
         self.self_fusion_2x.run_rows(rows[1], g2, out=cat[:, c1:c1 + c2])
-        f4 = self.self_fusion_4x.run_rows(rows[2], g4)
-        cat[:, c1 + c2:] = D2.rows_of(self.pool4x(D2.maps_of(f4, g4.maps, g4.height, g4.width)))
+        main.wait_stream(s1)
+        main.wait_stream(s4)
         x = self.fusion_down.run_rows(cat, g2)
         for blk in (self.post_fusion_1, self.post_fusion_2, self.post_fusion_3, self.post_fusion_4):
             x = blk.run_rows(x, g2)

@@ -181,7 +181,9 @@ def batchnorm_apply_partials(x, partial, gamma=None, beta=None, eps=1e-5, residu
     assert partial.shape[1:] == (3, c) and partial.is_contiguous()
     if out is None:
         out = torch.empty((n, c), dtype=torch.float32, device=x.device)
-    ws = _lib.workspace(lib.eprecon_batchnorm_apply_workspace_bytes(c), x.device)
+    # mean / var scratch is a per-call buffer (not the shared grow-only workspace): independent branches
+    # of the 2D stack run concurrently on several streams
+    ws = torch.empty((lib.eprecon_batchnorm_apply_workspace_bytes(c),), dtype=torch.uint8, device=x.device)
     _lib.check(lib.eprecon_batchnorm_apply_partials_async(
         _lib.ptr(x), n, c, _ld(x), _lib.ptr(partial), partial.shape[0], _lib.ptr(gamma), _lib.ptr(beta),
         float(eps), _lib.ptr(residual), _ld(residual) if residual is not None else 0, int(relu), _lib.ptr(out),
