@@ -123,8 +123,9 @@ _WORKSPACES = {}
 
 
 def workspace(nbytes, device):
-    """grow-only per-device scratch buffer (PyTorch-owned device memory)"""
-    key = (device.type, device.index)
+    """grow-only scratch buffer per (device, current stream): operators issued on different streams
+    (the per-level branches of the 2D stack, the pipelined back-projections) never share scratch"""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _WORKSPACES.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)

@@ -32,6 +32,73 @@ def _prep_feats(feats):
     return feats.contiguous(), LAYOUT_NCHW
 
 
+class PendingBackProject:
+    """A back-projection whose kernels are queued on a stream; `result()` waits for the valid counts
+    (pinned host copy + event) and returns what `run()` returns.  Lets independent levels be issued
+    back to back without a host round trip between them."""
+
+    def __init__(self, tensors, n, v, c, batch, min_valid_per_batch, n_valid_pinned, event, want_grid, want_mean):
+        self._t, self._n, self._v, self._c, self._batch = tensors, n, v, c, batch
+        self._min_valid, self._pinned, self._event = min_valid_per_batch, n_valid_pinned, event
+        self._want_grid, self._want_mean = want_grid, want_mean
+
+    def result(self):
+        self._event.synchronize()
+        counts = self._pinned.tolist()
+        if any(x < self._min_valid for x in counts[1:]):
+            return None  # reference: `return None`
+        nv, t, v = counts[0], self._t, self._v
+        res = {"feats": t["feats"][:nv], "coords": t["coords"][:nv], "count": t["count"], "n_valid": nv,
+               "n_valid_per_batch": counts[1:]}
+        if self._want_grid:
+            res["grid"] = t["grid"][: v * nv * 2].view(v, nv, 2)
+            res["mask"] = t["mask"][: v * nv].view(v, nv).bool()
+        if self._want_mean:
+            res["mean"] = t["mean"][:nv]
+        return res
+
+
+def run_async(coords, origin, voxel_size, feats, krcam, min_view, mode=MODE_MEAN, min_valid_per_batch=1,
+              want_grid=False, want_mean=False):
+    """Queue the back-projection on the current stream and return a PendingBackProject."""
+    lib = _lib.load()
+    dev = feats.device
+    if dev.type != "cuda":
+        raise _lib.EpreconError("eprecon_amd operators need device tensors (no CPU fallback)")
+    v, b, c, h, w = feats.shape
+    n = coords.shape[0]
+    coords_i = coords if coords.dtype == torch.int32 else coords.to(torch.int32)
+    coords_i = coords_i.contiguous()
+    origin_f = origin.to(device=dev, dtype=torch.float32).reshape(-1, 3).contiguous()
+    krcam_f = krcam.to(device=dev, dtype=torch.float32).contiguous()
+    assert krcam_f.shape == (v, b, 4, 4) and origin_f.shape[0] == b
+    feats_c, layout = _prep_feats(feats)
+    cout = c + 1 if mode == MODE_MEAN_DEPTH else c
+
+    t = {"feats": torch.empty((n, cout), dtype=torch.float32, device=dev),
+         "coords": torch.empty((n, 4), dtype=torch.int32, device=dev),
+         "count": torch.empty((n,), dtype=torch.float32, device=dev),
+         "mean": torch.empty((n, c), dtype=torch.float32, device=dev) if want_mean else None,
+         "grid": torch.empty((v * n * 2,), dtype=torch.float32, device=dev) if want_grid else None,
+         "mask": torch.empty((v * n,), dtype=torch.uint8, device=dev) if want_grid else None}
+    n_valid_dev = torch.empty((1 + b,), dtype=torch.int32, device=dev)
+    ws_bytes = lib.eprecon_back_project_workspace_bytes(n, b, v, c, h, w, layout)
+    ws = _lib.workspace(ws_bytes, dev)
+    rc = lib.eprecon_back_project_async(
+        _lib.ptr(coords_i), n, _lib.ptr(origin_f), b, float(voxel_size), _lib.ptr(feats_c), layout,
+        _lib.ptr(krcam_f), v, c, h, w, int(min_view), mode, _lib.ptr(t["feats"]), _lib.ptr(t["mean"]),
+        _lib.ptr(t["coords"]), _lib.ptr(t["count"]), _lib.ptr(t["grid"]), _lib.ptr(t["mask"]),
+        _lib.ptr(n_valid_dev), _lib.ptr(ws), ws.numel(), _lib.current_stream())
+    _lib.check(rc, "eprecon_back_project_async")
+    pinned = torch.empty((1 + b,), dtype=torch.int32, pin_memory=True)
+    pinned.copy_(n_valid_dev, non_blocking=True)
+    event = torch.cuda.Event()
+    event.record()
+    # inputs stay referenced until result(): the kernels may still be reading them
+    t["_keep"] = (coords_i, origin_f, krcam_f, feats_c, n_valid_dev)
+    return PendingBackProject(t, n, v, c, b, int(min_valid_per_batch), pinned, event, want_grid, want_mean)
+
+
 def run(coords, origin, voxel_size, feats, krcam, min_view, mode=MODE_MEAN, min_valid_per_batch=1,
         want_grid=False, want_mean=False):
     """Low-level entry: returns None (reference: `return None`) or a dict of device tensors

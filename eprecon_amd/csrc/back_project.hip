@@ -1281,7 +1281,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restri
 }
 
 struct ProfileState {
-    bool on = false, recorded = false;
+    bool on = false, recorded = false, one_shot = false;
     hipEvent_t start = nullptr, stop = nullptr;
 } g_prof;
 
@@ -1385,7 +1385,8 @@ int eprecon_profile_enable(int on)
         EP_HIP_CHECK(hipEventCreate(&g_prof.stop));
     }
     g_prof.on = on != 0;
-    g_prof.recorded = false;
+    g_prof.one_shot = on == 2;
+    if (on != 0) g_prof.recorded = false;  // disabling keeps the last recorded pair readable
     return EPRECON_OK;
 }
 
@@ -1519,6 +1520,7 @@ int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *or
         if (prof) {
             EP_HIP_CHECK(hipEventRecord(g_prof.stop, st));
             g_prof.recorded = true;
+            if (g_prof.one_shot) g_prof.on = false;
         }
         if (mode == EPRECON_BP_MEAN_DEPTH) {
             hipLaunchKernelGGL(bp_depth_norm_kernel, dim3(batch), dim3(1024), 0, st, out_feats, channels + 1,
@@ -1576,6 +1578,7 @@ int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *or
     if (prof) {
         EP_HIP_CHECK(hipEventRecord(g_prof.stop, st));
         g_prof.recorded = true;
+        if (g_prof.one_shot) g_prof.on = false;
     }
     if (mode == EPRECON_BP_MEAN_DEPTH) {
         hipLaunchKernelGGL(bp_depth_norm_kernel, dim3(batch), dim3(1024), 0, st, out_feats,

@@ -252,12 +252,13 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvParams p)
 
 
 // ---------------------------------------------------------------------------------------------
-// Group-resident variant for narrow layers (Cin <= 64, Cout <= 64): the weights of a GROUP of
-// kernel offsets (up to 36 KB, e.g. 9 offsets of a 32x32 layer) are staged per barrier instead of
-// one 32-channel slab, so a 27-offset layer needs 3 barriers instead of 27, and four workgroups
-// fit a CU.  Each wave reads its own neighbour indices (coalesced from the [K][N] table), skips
-// offsets with no live row in its 32 rows, and prefetches the gathered rows of offset k+1 while
-// the MFMAs of offset k run.
+// Group-resident variant for narrow layers (Cin <= 64): the weights of a GROUP of kernel offsets
+// (up to ~24 KB, e.g. 9 offsets of a 32x32 layer) are staged per barrier instead of one 32-channel
+// slab, so a 27-offset layer needs 3 barriers instead of 27, and four workgroups fit a CU.
+// The gathers are issued in BATCHES of KB offsets (KB * NCH 16-byte loads per lane in flight)
+// before the first MFMA of the batch: the per-offset loop with one offset of prefetch paid one
+// memory latency (~1.5 us) per offset - 27 us of the 30 us a 20->20 3x3 layer took on 43,200 pixels,
+// 40 of the 76 us of a 27-offset 32->32 layer.  Offsets with no live row in a wave's 32 rows are skipped.
 // ---------------------------------------------------------------------------------------------
 struct ARows {
     float v[8][4];  // up to 8 chunks of 8 input channels; this lane's 4 consecutive channels per chunk
@@ -281,13 +282,17 @@ __device__ __forceinline__ void gather_rows(const ConvParams &p, int j, int half
     }
 }
 
+// gather batch size: KB * NCH <= 16 float4 per lane in flight (<= 64 VGPRs of A operands)
+constexpr int resident_kb(int nch) { return nch <= 1 ? 9 : nch == 2 ? 8 : nch == 3 ? 5 : nch == 4 ? 4 : nch == 5 ? 3 : 2; }
+
 template <int NT, bool VEC4, int NCH>
 __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int kgroup)
 {
     constexpr int cin_pad = NCH * 8;
+    constexpr int KB = resident_kb(NCH);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TN = 32 * NT;
-    float *sW = reinterpret_cast<float *>(smem);  // [kgroup][cin_pad][TN], zero padded
+    float *sW = reinterpret_cast<float *>(smem);  // [kgroup][cin_pad][TN], zero padded; kgroup % KB == 0
     constexpr int per_k = cin_pad * TN;
     int *sNbr = reinterpret_cast<int *>(sW + kgroup * per_k);  // [K][128] neighbour tile
     const int tid = threadIdx.x;
@@ -296,8 +301,8 @@ __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int 
     const int wrow0 = blockIdx.x * kRowsPerBlock + wave * kRowsPerWave;
     const int col0 = blockIdx.y * TN;
     const float *wbase = p.w + col0;
-    // the neighbour indices of the whole tile go to LDS up front: the gather of offset k+1 then
-    // depends on ONE memory latency (the rows), not two (index, then rows)
+    // the neighbour indices of the whole tile go to LDS up front: a gather then depends on ONE
+    // memory latency (the rows), not two (index, then rows)
     for (int e = tid; e < p.K * kRowsPerBlock; e += 256) {
         const int k = e / kRowsPerBlock, r = e - k * kRowsPerBlock;
         const int row = blockIdx.x * kRowsPerBlock + r;
@@ -311,50 +316,51 @@ __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    auto nbr_of = [&](int k) -> int { return sNbr[k * kRowsPerBlock + wave * kRowsPerWave + r32]; };
-    int j = nbr_of(0);
-    ARows cur;
-    gather_rows<VEC4, NCH>(p, j, half, cur);
-    for (int k0 = 0; k0 < p.K; k0 += kgroup) {
-        const int kn = min(kgroup, p.K - k0);
-        __syncthreads();  // every wave is done with the previous group's weights
-        if (cin_pad == p.Cin) {
-            // rows of consecutive offsets are contiguous in W: one flat [kn * Cin][Cout] block
-            stage_weights<TN>(sW, wbase, k0 * p.Cin, (k0 + kn) * p.Cin, p.Cout, p.Cout - col0, kn * cin_pad, tid);
-        } else {
-            for (int kk = 0; kk < kn; ++kk)
-                stage_weights<TN>(sW + kk * per_k, wbase, (k0 + kk) * p.Cin, (k0 + kk + 1) * p.Cin, p.Cout,
-                                  p.Cout - col0, cin_pad, tid);
+    const int *nbr_row = sNbr + wave * kRowsPerWave + r32;
+    for (int kb = 0; kb < p.K; kb += KB) {
+        // ---- issue the gathers of this batch ----
+        ARows a[KB];
+        int jj[KB];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            jj[u] = (kb + u < p.K) ? nbr_row[(kb + u) * kRowsPerBlock] : -1;
+            gather_rows<VEC4, NCH>(p, jj[u], half, a[u]);
         }
-        __syncthreads();
-        for (int kk = 0; kk < kn; ++kk) {
-            const int k = k0 + kk;
-            const bool live = __ballot(j >= 0) != 0ull;
-            int jn = -1;
-            ARows nxt;
-            if (k + 1 < p.K) {
-                jn = nbr_of(k + 1);
-                gather_rows<VEC4, NCH>(p, jn, half, nxt);  // in flight during the MFMAs below
+        // ---- weights of the group this batch belongs to (loads above stay in flight) ----
+        const int k0 = kb / kgroup * kgroup;
+        if (kb == k0) {
+            const int kn = min(kgroup, p.K - k0);
+            __syncthreads();  // every wave is done with the previous group's weights
+            if (cin_pad == p.Cin) {
+                // rows of consecutive offsets are contiguous in W: one flat [kn * Cin][Cout] block
+                stage_weights<TN>(sW, wbase, k0 * p.Cin, (k0 + kn) * p.Cin, p.Cout, p.Cout - col0, kn * cin_pad, tid);
+            } else {
+                for (int kk = 0; kk < kn; ++kk)
+                    stage_weights<TN>(sW + kk * per_k, wbase, (k0 + kk) * p.Cin, (k0 + kk + 1) * p.Cin, p.Cout,
+                                      p.Cout - col0, cin_pad, tid);
             }
-            if (live) {
-                const float *wk = sW + kk * per_k + r32 + 4 * half * TN;
-                // fully unrolled (NCH, NT compile-time): the B reads of a chunk are issued as a batch
+            __syncthreads();
+        }
+        // ---- MFMAs of the batch ----
 #pragma unroll
-                for (int ch = 0; ch < NCH; ++ch) {
-                    float b[4][NT];
+        for (int u = 0; u < KB; ++u) {
+            if (kb + u >= p.K) break;
+            const bool live = __ballot(jj[u] >= 0) != 0ull;
+            if (!live) continue;
+            const float *wk = sW + (kb + u - k0) * per_k + r32 + 4 * half * TN;
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
+            for (int ch = 0; ch < NCH; ++ch) {
+                float b[4][NT];
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) b[s][t] = wk[(ch * 8 + s) * TN + t * 32];
+                for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
+                    for (int t = 0; t < NT; ++t) b[s][t] = wk[(ch * 8 + s) * TN + t * 32];
 #pragma unroll
-                        for (int t = 0; t < NT; ++t)
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.v[ch][s], b[s][t], acc[t], 0, 0, 0);
-                }
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[ch][s], b[s][t], acc[t], 0, 0, 0);
             }
-            cur = nxt;
-            j = jn;
         }
     }
     conv_epilogue<NT>(p, acc, wrow0, col0, r32, half, wave, sW);
@@ -363,9 +369,11 @@ __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int 
 template <int NT, int NCH>
 int launch_resident_nch(const ConvParams &p, bool vec4, hipStream_t st)
 {
-    // weights of `kgroup` offsets resident at a time (<= 36 KB -> 4 workgroups per CU)
+    // weights of `kgroup` offsets resident at a time (a multiple of the gather batch, ~24 KB -> 4 workgroups per CU)
+    constexpr int KB = resident_kb(NCH);
     const size_t per_k = (size_t)NCH * 8 * 32 * NT * sizeof(float);
-    const int kgroup = (int)max((size_t)1, min((size_t)p.K, (size_t)(24 * 1024) / per_k));
+    int kgroup = (int)max((size_t)KB, (size_t)(24 * 1024) / per_k / KB * KB);
+    kgroup = min(kgroup, (p.K + KB - 1) / KB * KB);
     const size_t lds = max((size_t)kgroup * per_k + (size_t)p.K * kRowsPerBlock * sizeof(int),
                            (size_t)kWaves * 3 * 32 * NT * sizeof(float));
     const dim3 grid((unsigned)ceil_div(p.n_out, kRowsPerBlock), (unsigned)ceil_div(p.Cout, 32 * NT));

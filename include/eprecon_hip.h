@@ -102,6 +102,8 @@ int eprecon_back_project(const int32_t *coords, int64_t n, const float *origin, 
  * eprecon_back_project*_ call brackets its gather kernel with two hipEvents recorded on the
  * caller's stream.  eprecon_profile_gather_ms() synchronises on the last stop event and returns
  * the elapsed milliseconds of that kernel alone (blocking; < 0 when nothing was recorded).
+ * on == 2 arms a one-shot: only the next call's gather kernel is bracketed, later calls leave the
+ * recorded pair alone (how bench.py singles out the dense 96^3 level inside a queued step).
  */
 int eprecon_profile_enable(int on);
 float eprecon_profile_gather_ms(void);

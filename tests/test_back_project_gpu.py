@@ -156,3 +156,27 @@ def test_linearity_and_idempotence_at_full_size():
     # compaction is stable: output rows are the input rows with count >= 2, in input order
     keep = ra["count"] >= 2
     assert torch.equal(ra["coords"], coords[keep])
+
+
+def test_async_queue_matches_blocking_run():
+    """three levels queued back to back (run_async) give the bits of the blocking entry, and the None
+    convention survives the deferred read-back"""
+    from eprecon_amd import back_project as BP
+    window = S.make_window(seed=6)
+    shapes = S.pyramid_shapes(480, 640)
+    origin = _dev(window["vol_origin_partial"][None].copy())
+    args = []
+    for lvl, interval in ((2, 4), (1, 2), (0, 1)):
+        feats = _dev(S.make_features(40 + lvl, 9, shapes[lvl]))
+        kr = _dev(np.ascontiguousarray(window["proj_matrices"][:, lvl][:, None]))
+        args.append((_dev(S.dense_coords((96, 96, 96), interval)), origin, 0.04, feats, kr, 3))
+    pend = [BP.run_async(*a) for a in args]
+    far = origin.clone()
+    far[0, 1] -= 50.0
+    pend_none = BP.run_async(args[0][0], far, 0.04, args[0][3], args[0][4], 1)
+    for a, p in zip(args, pend):
+        ref, got = BP.run(*a), p.result()
+        assert got["n_valid"] == ref["n_valid"] and got["n_valid_per_batch"] == ref["n_valid_per_batch"]
+        for key in ("feats", "coords", "count"):
+            assert torch.equal(got[key], ref[key])
+    assert pend_none.result() is None
