@@ -38,6 +38,9 @@ SIGNATURES = {
     "eprecon_conv_bn_partial_bytes": (_sz, [_i64, _i]),
     "eprecon_sparse_conv_fused_async": (_i, [_vp, _i64, _i, _vp, _i, _i64, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i,
                                              _vp, _vp]),
+    "eprecon_conv_desc_async": (_i, [_vp, _vp]),
+    "eprecon_batchnorm_finalize_affine_async": (_i, [_vp, _i64, _i, _vp, _vp, _f, _vp, _vp, _vp]),
+    "eprecon_affine_rows_async": (_i, [_vp, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "eprecon_pixel_map_async": (_i, [_i, _i, _i, _i, _vp, _vp]),
     "eprecon_batchnorm_apply_workspace_bytes": (_sz, [_i]),
     "eprecon_batchnorm_apply_partials_async": (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp, _vp, _f, _vp, _i, _i, _vp, _i,
@@ -117,6 +120,23 @@ def ptr(t):
 
 def current_stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class ConvDesc(ctypes.Structure):
+    """include/eprecon_hip.h: eprecon_conv_desc"""
+    _fields_ = [("x", ctypes.c_void_p), ("n_in", ctypes.c_int64), ("ld_x", ctypes.c_int),
+                ("nbr", ctypes.c_void_p), ("kvol", ctypes.c_int), ("n_out", ctypes.c_int64),
+                ("weight", ctypes.c_void_p), ("cin", ctypes.c_int), ("cout", ctypes.c_int),
+                ("bias", ctypes.c_void_p),
+                ("residual", ctypes.c_void_p), ("ld_res", ctypes.c_int),
+                ("out", ctypes.c_void_p), ("ld_out", ctypes.c_int),
+                ("relu", ctypes.c_int), ("accumulate", ctypes.c_int),
+                ("in_scale", ctypes.c_void_p), ("in_shift", ctypes.c_void_p), ("in_relu", ctypes.c_int),
+                ("res_scale", ctypes.c_void_p), ("res_shift", ctypes.c_void_p), ("res_relu", ctypes.c_int),
+                ("bn_partial", ctypes.c_void_p),
+                ("bn_scale_out", ctypes.c_void_p), ("bn_shift_out", ctypes.c_void_p),
+                ("bn_gamma", ctypes.c_void_p), ("bn_beta", ctypes.c_void_p), ("bn_eps", ctypes.c_float),
+                ("bn_ticket", ctypes.c_void_p)]
 
 
 _WORKSPACES = {}

@@ -99,6 +99,36 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *partial, 
     }
 }
 
+// the same merge, published in affine form: y = x * scale + shift  ==  (x - mean) / sqrt(var + eps) * gamma + beta
+__global__ __launch_bounds__(256) void bn_finalize_affine_kernel(const float *partial, int nblk, int C, const float *gamma,
+                                                                 const float *beta, float eps, float *scale_out,
+                                                                 float *shift_out)
+{
+    __shared__ float sN[256], sMean[256], sM2[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    float a_n = 0.0f, a_mean = 0.0f, a_m2 = 0.0f;
+    for (int b = tid; b < nblk; b += 256) {
+        const float *p = partial + (size_t)b * 3 * C;
+        chan_merge(a_n, a_mean, a_m2, p[c], p[C + c], p[2 * C + c]);
+    }
+    sN[tid] = a_n; sMean[tid] = a_mean; sM2[tid] = a_m2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            float n = sN[tid], m = sMean[tid], q = sM2[tid];
+            chan_merge(n, m, q, sN[tid + s], sMean[tid + s], sM2[tid + s]);
+            sN[tid] = n; sMean[tid] = m; sM2[tid] = q;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float var = sN[0] > 0.0f ? sM2[0] / sN[0] : 0.0f;  // biased variance
+        const float sc = (gamma ? gamma[c] : 1.0f) / sqrtf(var + eps);
+        scale_out[c] = sc;
+        shift_out[c] = (beta ? beta[c] : 0.0f) - sMean[0] * sc;
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float *x, int n, int C, int ld_x,
                                                        const float *mean, const float *var,
                                                        const float *gamma, const float *beta, float eps,
@@ -158,6 +188,17 @@ __global__ __launch_bounds__(256) void rowwise_ln_kernel(const float *x, int n, 
             if (post_relu) v = fmaxf(v, 0.0f);
             out[(size_t)r * ld_out + c] = v;
         }
+}
+
+__global__ __launch_bounds__(256) void affine_rows_kernel(const float *x, int n, int C, int ld_x, const float *scale,
+                                                          const float *shift, int relu, float *out, int ld_out)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)n * C) return;
+    const int r = (int)(e / C), c = (int)(e - (size_t)r * C);
+    float v = fmaf(x[(size_t)r * ld_x + c], scale[c], shift[c]);
+    if (relu) v = fmaxf(v, 0.0f);
+    out[(size_t)r * ld_out + c] = v;
 }
 
 int bn_finalize_apply(const float *x, int64_t n, int channels, int ld_x, const float *partial, int nblk,
@@ -240,6 +281,30 @@ int eprecon_batchnorm_apply_partials_async(const float *x, int64_t n, int channe
     float *var = var_out ? var_out : reinterpret_cast<float *>(ws);
     return bn_finalize_apply(x, n, channels, ld_x, partial, (int)nblk, gamma, beta, eps, residual, ld_res, relu,
                              out, ld_out, mean, var, (hipStream_t)stream);
+}
+
+int eprecon_batchnorm_finalize_affine_async(const float *partial, int64_t nblk, int channels, const float *gamma,
+                                            const float *beta, float eps, float *scale_out, float *shift_out,
+                                            void *stream)
+{
+    if (!partial || !scale_out || !shift_out || nblk <= 0 || nblk > 0x7fffffff || channels <= 0) return EPRECON_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_affine_kernel, dim3(channels), dim3(256), 0, (hipStream_t)stream, partial, (int)nblk,
+                       channels, gamma, beta, eps, scale_out, shift_out);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_affine_rows_async(const float *x, int64_t n, int channels, int ld_x, const float *scale,
+                              const float *shift, int relu, float *out, int ld_out, void *stream)
+{
+    if (!x || !out || !scale || !shift || n < 0 || channels <= 0 || ld_x < channels || ld_out < channels ||
+        n * channels > 0x7fffffffll * 256)
+        return EPRECON_ERR_ARG;
+    if (n == 0) return EPRECON_OK;
+    hipLaunchKernelGGL(affine_rows_kernel, dim3((unsigned)ceil_div(n * channels, (int64_t)256)), dim3(256), 0,
+                       (hipStream_t)stream, x, (int)n, channels, ld_x, scale, shift, relu, out, ld_out);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
 }
 
 int eprecon_rowwise_layernorm_async(const float *x, int64_t n, int channels, int ld_x,

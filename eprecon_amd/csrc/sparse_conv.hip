@@ -42,6 +42,18 @@ struct ConvParams {
     const float *res;    // optional [n_out, ld_res]: added after the ReLU (x + ReLU(conv(x)) blocks)
     int ld_res;
     float *bn_partial;   // optional [gridDim.x][3][Cout]: per-workgroup (count, mean, M2) of the stored values
+    // BatchNorm of the INPUT applied while gathering: a = [relu](x * in_scale[c] + in_shift[c]) (nullptr: a = x)
+    const float *in_scale, *in_shift;
+    int in_relu;
+    // the same for the residual operand (columns of the output)
+    const float *res_scale, *res_shift;
+    int res_relu;
+    // BatchNorm of the OUTPUT finished by the last workgroup to arrive (needs bn_partial):
+    // scale = gamma / sqrt(var + eps), shift = beta - mean * scale  -> bn_scale_out / bn_shift_out [Cout]
+    float *bn_scale_out, *bn_shift_out;
+    const float *bn_gamma, *bn_beta;
+    float bn_eps;
+    unsigned int *bn_ticket;  // zero-initialised arrival counter, reset by the last workgroup
 };
 
 // Stage `rows` x TN weights (zero padded) from w[row0 + r][0:ncols] (row stride `stride`, rows valid
@@ -93,6 +105,47 @@ __device__ __forceinline__ void chan_merge(float &n_a, float &mean_a, float &m2_
     n_a = n;
 }
 
+// Second half of the fused BatchNorm: the last workgroup to arrive (device-scope ticket) merges the
+// per-workgroup summaries in block order and publishes the affine form of the normalisation.
+// Thread (g, c) = (tid / C, tid % C) merges blocks g, g + G, ... of column c (coalesced over c), the
+// G group results are merged in order by the g == 0 threads.  sScratch: >= 3 * 256 floats of LDS.
+__device__ __forceinline__ void bn_finalize_last_block(const ConvParams &p, float *sScratch)
+{
+    __shared__ int sLast;
+    const int tid = threadIdx.x;
+    __syncthreads();  // this workgroup's summaries are written
+    if (tid == 0) {
+        const unsigned int total = gridDim.x * gridDim.y;
+        const unsigned int t = __hip_atomic_fetch_add(p.bn_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        sLast = (t == total - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!sLast) return;
+    __threadfence();  // acquire: the other workgroups' summaries (other XCDs' L2s) are visible
+    const int C = p.Cout, nblk = gridDim.x;
+    const int G = max(1, 256 / C);
+    const int g = tid / C, c = tid - g * C;
+    float a_n = 0.0f, a_mean = 0.0f, a_m2 = 0.0f;
+    if (g < G) {
+        for (int b = g; b < nblk; b += G) {
+            const float *q = p.bn_partial + (size_t)b * 3 * C + c;
+            chan_merge(a_n, a_mean, a_m2, q[0], q[C], q[2 * C]);
+        }
+        sScratch[tid] = a_n; sScratch[256 + tid] = a_mean; sScratch[512 + tid] = a_m2;
+    }
+    __syncthreads();
+    if (g == 0) {
+        for (int gg = 1; gg < G; ++gg)
+            chan_merge(a_n, a_mean, a_m2, sScratch[gg * C + c], sScratch[256 + gg * C + c], sScratch[512 + gg * C + c]);
+        const float var = a_n > 0.0f ? a_m2 / a_n : 0.0f;  // biased variance
+        const float inv = 1.0f / sqrtf(var + p.bn_eps);
+        const float sc = (p.bn_gamma ? p.bn_gamma[c] : 1.0f) * inv;
+        p.bn_scale_out[c] = sc;
+        p.bn_shift_out[c] = (p.bn_beta ? p.bn_beta[c] : 0.0f) - a_mean * sc;
+    }
+    if (tid == 0) *p.bn_ticket = 0u;
+}
+
 // Shared epilogue.  C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31,
 // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 //   v = acc + bias; [v += out]; [v = max(v, 0)]; [v += res]; out = v
@@ -113,6 +166,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
         const int col = col0 + t * 32 + r32;
         const bool colok = col < p.Cout;
         const float b = (p.bias && colok) ? p.bias[col] : 0.0f;
+        const float rs = (p.res_scale && colok) ? p.res_scale[col] : 1.0f;
+        const float rb = (p.res_scale && colok) ? p.res_shift[col] : 0.0f;
         float vals[16];
         float cnt = 0.0f, sum = 0.0f;
 #pragma unroll
@@ -124,7 +179,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
                 v = acc[t][r] + b;
                 if (p.accumulate) v += *o;
                 if (p.relu) v = fmaxf(v, 0.0f);
-                if (p.res) v += p.res[(size_t)row * p.ld_res + col];
+                if (p.res) {
+                    float rv = p.res[(size_t)row * p.ld_res + col];
+                    if (p.res_scale) {
+                        rv = fmaf(rv, rs, rb);
+                        if (p.res_relu) rv = fmaxf(rv, 0.0f);
+                    }
+                    v += rv;
+                }
                 *o = v;
                 cnt += 1.0f;
             }
@@ -165,6 +227,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
             dst[0] = a_n; dst[p.Cout] = a_mean; dst[2 * p.Cout] = a_m2;
         }
     }
+    if (stats && p.bn_scale_out) bn_finalize_last_block(p, sStat);
 }
 
 template <int NT, bool VEC4>
@@ -175,6 +238,8 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvParams p)
     float *sW = reinterpret_cast<float *>(smem);                     // [2][kSlabC][TN]
     int *sNbr = reinterpret_cast<int *>(sW + 2 * kSlabC * TN);       // [K][128]
     int *sActive = sNbr + p.K * kRowsPerBlock;                       // [K] live-row flags
+    const int cinA = (p.Cin + 3) & ~3;
+    float *sAff = reinterpret_cast<float *>(sActive + ((p.K + 3) & ~3));  // [2][cinA] input scale / shift
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -184,6 +249,11 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvParams p)
 
     // neighbour tile + live-offset flags
     for (int k = tid; k < p.K; k += 256) sActive[k] = 0;
+    if (p.in_scale)
+        for (int c = tid; c < cinA; c += 256) {
+            sAff[c] = c < p.Cin ? p.in_scale[c] : 0.0f;
+            sAff[cinA + c] = c < p.Cin ? p.in_shift[c] : 0.0f;
+        }
     __syncthreads();
     for (int e = tid; e < p.K * kRowsPerBlock; e += 256) {
         const int k = e / kRowsPerBlock, r = e - k * kRowsPerBlock;
@@ -233,6 +303,20 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvParams p)
             (void)have_prev;
             const float *srcW = sW + buf * kSlabC * TN;
             const int nch = min(4, (p.Cin - c0 + 7) / 8);
+            if (p.in_scale) {
+                // BatchNorm (+ReLU) of the producer applied to the gathered values; padding stays 0
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    const int c = c0 + ch * 8 + 4 * half;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const bool ok = j >= 0 && c + s < p.Cin;
+                        float v = fmaf(a[ch][s], sAff[min(c + s, cinA - 1)], sAff[cinA + min(c + s, cinA - 1)]);
+                        if (p.in_relu) v = fmaxf(v, 0.0f);
+                        a[ch][s] = ok ? v : 0.0f;
+                    }
+                }
+            }
             for (int ch = 0; ch < nch; ++ch) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -295,12 +379,17 @@ __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int 
     float *sW = reinterpret_cast<float *>(smem);  // [kgroup][cin_pad][TN], zero padded; kgroup % KB == 0
     constexpr int per_k = cin_pad * TN;
     int *sNbr = reinterpret_cast<int *>(sW + kgroup * per_k);  // [K][128] neighbour tile
+    float *sAff = reinterpret_cast<float *>(sNbr + p.K * kRowsPerBlock);  // [2][cin_pad] input scale / shift
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, half = lane >> 5;
     const int wrow0 = blockIdx.x * kRowsPerBlock + wave * kRowsPerWave;
     const int col0 = blockIdx.y * TN;
     const float *wbase = p.w + col0;
+    if (p.in_scale && tid < cin_pad) {
+        sAff[tid] = tid < p.Cin ? p.in_scale[tid] : 0.0f;
+        sAff[cin_pad + tid] = tid < p.Cin ? p.in_shift[tid] : 0.0f;
+    }
     // the neighbour indices of the whole tile go to LDS up front: a gather then depends on ONE
     // memory latency (the rows), not two (index, then rows)
     for (int e = tid; e < p.K * kRowsPerBlock; e += 256) {
@@ -348,6 +437,22 @@ __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int 
             const bool live = __ballot(jj[u] >= 0) != 0ull;
             if (!live) continue;
             const float *wk = sW + (kb + u - k0) * per_k + r32 + 4 * half * TN;
+            if (p.in_scale) {
+                // BatchNorm (+ReLU) of the producer applied to the gathered values; padding stays 0
+                const bool ok = jj[u] >= 0;
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    const float4 sc = *reinterpret_cast<const float4 *>(sAff + ch * 8 + 4 * half);
+                    const float4 sh = *reinterpret_cast<const float4 *>(sAff + cin_pad + ch * 8 + 4 * half);
+                    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        float v = fmaf(a[u].v[ch][s], scv[s], shv[s]);
+                        if (p.in_relu) v = fmaxf(v, 0.0f);
+                        a[u].v[ch][s] = (ok && ch * 8 + 4 * half + s < p.Cin) ? v : 0.0f;
+                    }
+                }
+            }
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 float b[4][NT];
@@ -374,8 +479,9 @@ int launch_resident_nch(const ConvParams &p, bool vec4, hipStream_t st)
     const size_t per_k = (size_t)NCH * 8 * 32 * NT * sizeof(float);
     int kgroup = (int)max((size_t)KB, (size_t)(24 * 1024) / per_k / KB * KB);
     kgroup = min(kgroup, (p.K + KB - 1) / KB * KB);
-    const size_t lds = max((size_t)kgroup * per_k + (size_t)p.K * kRowsPerBlock * sizeof(int),
-                           (size_t)kWaves * 3 * 32 * NT * sizeof(float));
+    const size_t lds = max((size_t)kgroup * per_k + (size_t)p.K * kRowsPerBlock * sizeof(int) +
+                               (size_t)2 * NCH * 8 * sizeof(float),
+                           max((size_t)kWaves * 3 * 32 * NT, (size_t)3 * 256) * sizeof(float));
     const dim3 grid((unsigned)ceil_div(p.n_out, kRowsPerBlock), (unsigned)ceil_div(p.Cout, 32 * NT));
     if (vec4)
         hipLaunchKernelGGL((spconv_resident_kernel<NT, true, NCH>), grid, dim3(256), lds, st, p, kgroup);
@@ -405,7 +511,8 @@ int launch_conv(const ConvParams &p, bool vec4, hipStream_t st)
 {
     const dim3 grid((unsigned)ceil_div(p.n_out, kRowsPerBlock), (unsigned)ceil_div(p.Cout, 32 * NT));
     const size_t lds = (size_t)2 * kSlabC * 32 * NT * sizeof(float) +
-                       (size_t)p.K * kRowsPerBlock * sizeof(int) + (size_t)p.K * sizeof(int) + 16;
+                       (size_t)p.K * kRowsPerBlock * sizeof(int) + (size_t)((p.K + 3) & ~3) * sizeof(int) +
+                       (size_t)2 * ((p.Cin + 3) & ~3) * sizeof(float) + 16;
     if (vec4)
         hipLaunchKernelGGL((spconv_mfma_kernel<NT, true>), grid, dim3(256), lds, st, p);
     else
@@ -441,6 +548,38 @@ extern "C" size_t eprecon_conv_bn_partial_bytes(int64_t n_out, int cout)
     return (size_t)ep::ceil_div(n_out > 0 ? n_out : 1, (int64_t)128) * 3 * (size_t)(cout > 0 ? cout : 1) * sizeof(float);
 }
 
+static int conv_check_and_run(ConvParams &p, int64_t n_in, int64_t n_out, void *stream)
+{
+    if (!p.x || !p.w || !p.out || n_in < 0 || n_out < 0 || p.K <= 0 || p.K > 64 || p.Cin <= 0 || p.Cout <= 0 ||
+        p.ld_x < p.Cin || p.ld_out < p.Cout || (p.res && p.ld_res < p.Cout))
+        return EPRECON_ERR_ARG;
+    if (!p.nbr && (p.K != 1 || n_in != n_out)) return EPRECON_ERR_ARG;
+    if ((p.in_scale == nullptr) != (p.in_shift == nullptr) || (p.res_scale == nullptr) != (p.res_shift == nullptr))
+        return EPRECON_ERR_ARG;
+    if (p.bn_scale_out && (!p.bn_partial || !p.bn_shift_out || !p.bn_ticket || p.Cout > 256)) return EPRECON_ERR_ARG;
+    if (p.Cout > 4096 || n_out > 0x7fffffff) return EPRECON_ERR_UNSUPPORTED;
+    if (n_out == 0) return EPRECON_OK;
+    p.n_out = (int)n_out;
+    return conv_dispatch(p, n_in, (hipStream_t)stream);
+}
+
+// Descriptor form of the gather-GEMM (include/eprecon_hip.h: eprecon_conv_desc): every fused prologue /
+// epilogue of the convolution blocks of the reference in one launch.
+extern "C" int eprecon_conv_desc_async(const eprecon_conv_desc *d, void *stream)
+{
+    if (!d) return EPRECON_ERR_ARG;
+    ConvParams p;
+    p.x = d->x; p.nbr = d->nbr; p.w = d->weight; p.bias = d->bias; p.out = d->out;
+    p.K = d->kvol; p.Cin = d->cin; p.Cout = d->cout; p.ld_x = d->ld_x; p.ld_out = d->ld_out;
+    p.relu = d->relu; p.accumulate = d->accumulate;
+    p.res = d->residual; p.ld_res = d->ld_res; p.bn_partial = d->bn_partial;
+    p.in_scale = d->in_scale; p.in_shift = d->in_shift; p.in_relu = d->in_relu;
+    p.res_scale = d->res_scale; p.res_shift = d->res_shift; p.res_relu = d->res_relu;
+    p.bn_scale_out = d->bn_scale_out; p.bn_shift_out = d->bn_shift_out; p.bn_gamma = d->bn_gamma;
+    p.bn_beta = d->bn_beta; p.bn_eps = d->bn_eps; p.bn_ticket = d->bn_ticket;
+    return conv_check_and_run(p, d->n_in, d->n_out, stream);
+}
+
 // out = [ReLU]( sum_k x[nbr[k]] @ W[k] + bias [+ out] ) [+ residual]; optionally the per-workgroup
 // BatchNorm summaries of the stored values (see conv_epilogue) -> bn_partial, to be consumed by
 // eprecon_batchnorm_apply_partials_async.
@@ -450,18 +589,12 @@ extern "C" int eprecon_sparse_conv_fused_async(const float *x, int64_t n_in, int
                                                int ld_res, float *out, int ld_out, int relu,
                                                int accumulate, float *bn_partial, void *stream)
 {
-    if (!x || !weight || !out || n_in < 0 || n_out < 0 || kvol <= 0 || kvol > 64 || cin <= 0 ||
-        cout <= 0 || ld_x < cin || ld_out < cout || (residual && ld_res < cout))
-        return EPRECON_ERR_ARG;
-    if (!nbr && (kvol != 1 || n_in != n_out)) return EPRECON_ERR_ARG;
-    if (cout > 4096) return EPRECON_ERR_UNSUPPORTED;
-    if (n_out == 0) return EPRECON_OK;
-    ConvParams p;
+    ConvParams p = {};
     p.x = x; p.nbr = nbr; p.w = weight; p.bias = bias; p.out = out;
-    p.n_out = (int)n_out; p.K = kvol; p.Cin = cin; p.Cout = cout; p.ld_x = ld_x; p.ld_out = ld_out;
+    p.K = kvol; p.Cin = cin; p.Cout = cout; p.ld_x = ld_x; p.ld_out = ld_out;
     p.relu = relu; p.accumulate = accumulate;
     p.res = residual; p.ld_res = ld_res; p.bn_partial = bn_partial;
-    return conv_dispatch(p, n_in, (hipStream_t)stream);
+    return conv_check_and_run(p, n_in, n_out, stream);
 }
 
 extern "C" int eprecon_sparse_conv_async(const float *x, int64_t n_in, int ld_x, const int32_t *nbr,

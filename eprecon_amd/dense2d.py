@@ -12,6 +12,9 @@ matrices (= channels-last tensors); layers write straight into channel slices of
 The nn.Conv2d / nn.BatchNorm2d modules stay the parameter holders (state-dict compatible with the
 reference); weights are re-laid out to [ky*k+kx][C_in][C_out] once per parameter version.
 """
+import ctypes
+import os
+
 import torch
 
 from . import _lib
@@ -72,12 +75,96 @@ def packed_weight(conv):
     return cached[1]
 
 
-def conv_bn(conv, bn, x, grid, out=None, relu=True, pre_relu=False, pre_residual=None):
-    """BN( [ReLU](conv(x) + b) [+ pre_residual] ) [ReLU] on pixel rows: one fused convolution launch
-    (bias, ReLU, residual, BatchNorm summaries in the epilogue) + finalize + apply.  `out` may be a
-    channel slice of a wider buffer; returns it."""
+# EPRECON_BN_TICKET=1: the last workgroup of the convolution finishes the BatchNorm (device-scope ticket)
+# instead of a separate finalize launch.  Measured slower on MI355X (cfg2 step 3.4 ms vs the two-launch form):
+# every workgroup's release makes its XCD's L2 write back, and 1,350 same-address atomics serialise.
+_FUSED_FINALIZE = os.environ.get("EPRECON_BN_TICKET", "0") == "1"
+
+
+class Act:
+    """An activation of the 2D stack: rows f32[N, C] (possibly a channel slice of a concat buffer) plus
+    the BatchNorm of its producer still pending in affine form (scale, shift f32[C], ReLU flag).  The
+    stored rows are the un-normalised convolution output; consumers apply the affine while gathering.
+    scale is None for a materialised tensor."""
+    __slots__ = ("rows", "scale", "shift", "relu")
+
+    def __init__(self, rows, scale=None, shift=None, relu=False):
+        self.rows, self.scale, self.shift, self.relu = rows, scale, shift, relu
+
+
+def _dptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def conv_bn_act(conv, bn, x, grid, out=None, aff=None, relu=True, pre_relu=False, residual=None):
+    """One launch for  BN( [ReLU](conv(x) + b) [+ residual] )  with x / residual given as Acts (their
+    pending BatchNorms are applied on load) and the BatchNorm of the result left pending: returns
+    Act(raw rows, scale, shift, relu).  `out`: rows to write (may be a channel slice), `aff`: the
+    (scale, shift) slices to fill (e.g. of a concat buffer's vectors)."""
+    lib = _lib.load()
     w = packed_weight(conv)
+    kvol, cin, cout = w.shape
     k = conv.kernel_size[0]
-    y, partial = SP.sparse_conv_fused(x, w if k > 1 else w[0], grid.kernel_map(k), conv.bias, out=out,
-                                      relu=pre_relu, residual=pre_residual, bn_partial=True)
-    return SP.batchnorm_apply_partials(y, partial, bn.weight, bn.bias, bn.eps, relu=relu, out=y)
+    rows = x.rows
+    n = rows.shape[0]
+    dev = rows.device
+    assert rows.shape[1] == cin and rows.dtype == torch.float32 and rows.stride(1) == 1
+    nbr = grid.kernel_map(k)
+    if out is None:
+        out = torch.empty((n, cout), dtype=torch.float32, device=dev)
+    if aff is None:
+        a = torch.empty((2, cout), dtype=torch.float32, device=dev)
+        aff = (a[0], a[1])
+    partial = torch.empty(((n + 127) // 128, 3, cout), dtype=torch.float32, device=dev)
+    fused_finalize = _FUSED_FINALIZE
+    ticket = None
+    if fused_finalize:
+        ticket = getattr(conv, "_eprecon_ticket", None)
+        if ticket is None or ticket.device != dev:
+            ticket = conv._eprecon_ticket = torch.zeros((1,), dtype=torch.int32, device=dev)
+    d = _lib.ConvDesc()
+    d.x, d.n_in, d.ld_x = rows.data_ptr(), n, rows.stride(0)
+    d.nbr, d.kvol, d.n_out = _dptr(nbr), kvol, n
+    d.weight, d.cin, d.cout = w.data_ptr(), cin, cout
+    d.bias = _dptr(conv.bias)
+    if residual is not None:
+        assert residual.rows.shape == (n, cout)
+        d.residual, d.ld_res = residual.rows.data_ptr(), residual.rows.stride(0)
+        d.res_scale, d.res_shift, d.res_relu = _dptr(residual.scale), _dptr(residual.shift), int(residual.relu)
+    d.out, d.ld_out = out.data_ptr(), out.stride(0)
+    d.relu, d.accumulate = int(pre_relu), 0
+    d.in_scale, d.in_shift, d.in_relu = _dptr(x.scale), _dptr(x.shift), int(x.relu)
+    d.bn_partial = partial.data_ptr()
+    if fused_finalize:
+        d.bn_scale_out, d.bn_shift_out = aff[0].data_ptr(), aff[1].data_ptr()
+        d.bn_gamma, d.bn_beta, d.bn_eps = _dptr(bn.weight), _dptr(bn.bias), float(bn.eps)
+        d.bn_ticket = ticket.data_ptr()
+    _lib.check(lib.eprecon_conv_desc_async(ctypes.byref(d), _lib.current_stream()), "eprecon_conv_desc_async")
+    if not fused_finalize:
+        _lib.check(lib.eprecon_batchnorm_finalize_affine_async(
+            partial.data_ptr(), partial.shape[0], cout, _dptr(bn.weight), _dptr(bn.bias), float(bn.eps),
+            aff[0].data_ptr(), aff[1].data_ptr(), _lib.current_stream()), "eprecon_batchnorm_finalize_affine_async")
+    return Act(out, aff[0], aff[1], relu)
+
+
+def materialize(act, out=None):
+    """apply the pending BatchNorm (+ReLU): returns plain rows"""
+    if act.scale is None:
+        if out is not None and out.data_ptr() != act.rows.data_ptr():
+            out.copy_(act.rows)
+            return out
+        return act.rows
+    rows = act.rows
+    n, c = rows.shape
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=rows.device)
+    _lib.check(_lib.load().eprecon_affine_rows_async(
+        rows.data_ptr(), n, c, rows.stride(0), act.scale.data_ptr(), act.shift.data_ptr(), int(act.relu),
+        out.data_ptr(), out.stride(0), _lib.current_stream()), "eprecon_affine_rows_async")
+    return out
+
+
+def conv_bn(conv, bn, x, grid, out=None, relu=True, pre_relu=False, pre_residual=None):
+    """BN( [ReLU](conv(x) + b) [+ pre_residual] ) [ReLU] on plain pixel rows, result materialised"""
+    res = Act(pre_residual) if pre_residual is not None else None
+    return materialize(conv_bn_act(conv, bn, Act(x), grid, relu=relu, pre_relu=pre_relu, residual=res), out=out)

@@ -219,9 +219,13 @@ class Conv2d_Block(nn.Module):
     def forward(self, x):
         return bn2d_train(self.bn, self.conv(x), relu=True)
 
+    def run_act(self, x, grid, out=None, aff=None):
+        """D2.Act -> D2.Act on the HIP gather-GEMM path (dense2d.py): one launch, BatchNorm left pending"""
+        return D2.conv_bn_act(self.conv, self.bn, x, grid, out=out, aff=aff, relu=True)
+
     def run_rows(self, x, grid, out=None):
-        """pixel rows [V*H*W, C_in] -> [V*H*W, C_out] on the HIP gather-GEMM path (dense2d.py)"""
-        return D2.conv_bn(self.conv, self.bn, x, grid, out=out, relu=True)
+        """plain pixel rows [V*H*W, C_in] -> materialised [V*H*W, C_out]"""
+        return D2.materialize(self.run_act(D2.Act(x), grid), out=out)
 
 
 class Conv2d_Residual_Block(nn.Module):
@@ -236,8 +240,11 @@ class Conv2d_Residual_Block(nn.Module):
     def forward(self, x):
         return bn2d_train(self.bn, x + self.relu(self.conv(x)))
 
+    def run_act(self, x, grid):
+        return D2.conv_bn_act(self.conv, self.bn, x, grid, relu=False, pre_relu=True, residual=x)
+
     def run_rows(self, x, grid, out=None):
-        return D2.conv_bn(self.conv, self.bn, x, grid, out=out, relu=False, pre_relu=True, pre_residual=x)
+        return D2.materialize(self.run_act(D2.Act(x), grid), out=out)
 
 
 class ELAN(nn.Module):
@@ -260,17 +267,26 @@ class ELAN(nn.Module):
             parts.append(layer(parts[-1]))
         return self.conv7(torch.cat(parts, dim=1))
 
-    def run_rows(self, x, grid, out=None):
-        d = x.shape[1]
+    def run_act(self, x, grid):
+        """the six branches write raw outputs + their pending BatchNorms straight into one concat
+        buffer and its (scale, shift) vectors; conv7 applies them while gathering"""
+        d = x.rows.shape[1]
         h = d // 2
-        cat = torch.empty((x.shape[0], 4 * d), dtype=torch.float32, device=x.device)  # branches write in place
-        self.conv1.run_rows(x, grid, out=cat[:, 0:d])
-        self.conv2.run_rows(x, grid, out=cat[:, d:2 * d])
-        self.conv3.run_rows(cat[:, d:2 * d], grid, out=cat[:, 2 * d:2 * d + h])
-        self.conv4.run_rows(cat[:, 2 * d:2 * d + h], grid, out=cat[:, 2 * d + h:3 * d])
-        self.conv5.run_rows(cat[:, 2 * d + h:3 * d], grid, out=cat[:, 3 * d:3 * d + h])
-        self.conv6.run_rows(cat[:, 3 * d:3 * d + h], grid, out=cat[:, 3 * d + h:4 * d])
-        return self.conv7.run_rows(cat, grid, out=out)
+        dev = x.rows.device
+        cat = torch.empty((x.rows.shape[0], 4 * d), dtype=torch.float32, device=dev)
+        aff = torch.empty((2, 4 * d), dtype=torch.float32, device=dev)
+        part = lambda a, b: D2.Act(cat[:, a:b], aff[0, a:b], aff[1, a:b], True)
+        sl = lambda a, b: dict(out=cat[:, a:b], aff=(aff[0, a:b], aff[1, a:b]))
+        self.conv1.run_act(x, grid, **sl(0, d))
+        self.conv2.run_act(x, grid, **sl(d, 2 * d))
+        self.conv3.run_act(part(d, 2 * d), grid, **sl(2 * d, 2 * d + h))
+        self.conv4.run_act(part(2 * d, 2 * d + h), grid, **sl(2 * d + h, 3 * d))
+        self.conv5.run_act(part(2 * d + h, 3 * d), grid, **sl(3 * d, 3 * d + h))
+        self.conv6.run_act(part(3 * d, 3 * d + h), grid, **sl(3 * d + h, 4 * d))
+        return self.conv7.run_act(part(0, 4 * d), grid)
+
+    def run_rows(self, x, grid, out=None):
+        return D2.materialize(self.run_act(D2.Act(x), grid), out=out)
 
 
 class Fusion_Block(nn.Module):
@@ -291,9 +307,10 @@ class Fusion_Block(nn.Module):
         return self.ELAN(x)
 
     def run_rows(self, x, grid, out=None):
-        x = D2.conv_bn(self.conv1, self.bn1, x, grid, relu=True)
-        x = D2.conv_bn(self.conv2, self.bn2, x, grid, relu=True)
-        return self.ELAN.run_rows(x, grid, out=out)
+        """plain rows in, materialised rows out; 9 convolution launches + 1 affine launch"""
+        a = D2.conv_bn_act(self.conv1, self.bn1, D2.Act(x), grid, relu=True)
+        a = D2.conv_bn_act(self.conv2, self.bn2, a, grid, relu=True)
+        return D2.materialize(self.ELAN.run_act(a, grid), out=out)
 
 
 class Linear4xTrans(nn.Module):

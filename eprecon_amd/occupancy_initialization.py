@@ -109,10 +109,10 @@ class Occupancy_Initialization(nn.Module):
         self.self_fusion_2x.run_rows(rows[1], g2, out=cat[:, c1:c1 + c2])
         main.wait_stream(s1)
         main.wait_stream(s4)
-        x = self.fusion_down.run_rows(cat, g2)
+        a = self.fusion_down.run_act(D2.Act(cat), g2)
         for blk in (self.post_fusion_1, self.post_fusion_2, self.post_fusion_3, self.post_fusion_4):
-            x = blk.run_rows(x, g2)
-        return D2.maps_of(x, g2.maps, g2.height, g2.width)
+            a = blk.run_act(a, g2)
+        return D2.maps_of(D2.materialize(a), g2.maps, g2.height, g2.width)
 
     def _fusion_graphed(self, f1, f2, f4):
         """feat_fusion_pre through a captured HIP graph (inference only; the result buffer is reused

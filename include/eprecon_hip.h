@@ -188,6 +188,44 @@ int eprecon_sparse_conv_fused_async(const float *x, int64_t n_in, int ld_x, cons
                                     const float *bias, const float *residual, int ld_res, float *out,
                                     int ld_out, int relu, int accumulate, float *bn_partial, void *stream);
 /*
+ * Descriptor form with the remaining fusions of a conv -> BatchNorm(train) -> [ReLU] chain, so that
+ * one launch per layer is left (the 2D fusion stack of models/occupancy_initialization.py:22-58 is
+ * ~32 such layers and launch-bound otherwise):
+ *   in_scale / in_shift [cin]   BatchNorm of the producer layer applied while gathering:
+ *                               a = [relu]( x * in_scale[c] + in_shift[c] ), zero padding stays 0
+ *   res_scale / res_shift [cout] the same for the residual operand
+ *   bn_scale_out / bn_shift_out [cout]  the BatchNorm of THIS layer's output in affine form,
+ *                               scale = gamma / sqrt(var + eps), shift = beta - mean * scale, written
+ *                               by the last workgroup to arrive (bn_ticket: zero-initialised device
+ *                               counter, left at zero); needs bn_partial, cout <= 256.
+ * The stored tensor is the un-normalised conv output; consumers apply (scale, shift) on load, or
+ * eprecon_affine_rows_async materialises it.
+ */
+typedef struct eprecon_conv_desc {
+    const float *x; int64_t n_in; int ld_x;
+    const int32_t *nbr; int kvol; int64_t n_out;
+    const float *weight; int cin; int cout;
+    const float *bias;
+    const float *residual; int ld_res;
+    float *out; int ld_out;
+    int relu; int accumulate;
+    const float *in_scale; const float *in_shift; int in_relu;
+    const float *res_scale; const float *res_shift; int res_relu;
+    float *bn_partial;
+    float *bn_scale_out; float *bn_shift_out;
+    const float *bn_gamma; const float *bn_beta; float bn_eps;
+    unsigned int *bn_ticket;
+} eprecon_conv_desc;
+int eprecon_conv_desc_async(const eprecon_conv_desc *desc, void *stream);
+/* producer-side summaries partial f32[nblk][3][channels] -> the BatchNorm in affine form (the
+ * separate-launch alternative to bn_ticket: no cross-workgroup synchronisation inside the convolution) */
+int eprecon_batchnorm_finalize_affine_async(const float *partial, int64_t nblk, int channels, const float *gamma,
+                                            const float *beta, float eps, float *scale_out, float *shift_out,
+                                            void *stream);
+/* out[i, c] = [relu]( x[i, c] * scale[c] + shift[c] ); out may alias x */
+int eprecon_affine_rows_async(const float *x, int64_t n, int channels, int ld_x, const float *scale,
+                              const float *shift, int relu, float *out, int ld_out, void *stream);
+/*
  * Kernel map of a dense 2D 'same' convolution (odd ksize) over `maps` images of height x width
  * pixels stored as rows [maps][height][width] of a channels-last tensor:
  * nbr int32[ksize*ksize][maps*height*width], offset index ky * ksize + kx, -1 = zero padding.
