@@ -25,7 +25,9 @@ with torch.no_grad():
     f = step.features_init
     f1 = torch.stack([v[2][0] for v in f]); f2 = torch.stack([v[1][0] for v in f]); f4 = torch.stack([v[0][0] for v in f])
     t, fused = timed(lambda: net.feat_fusion_pre(f1, f2, f4))
-    print(f"feat_fusion_pre (2D convs, torch)   {t:7.3f} ms")
+    print(f"feat_fusion_pre (direct launches)   {t:7.3f} ms")
+    t, fused = timed(lambda: net._fusion_graphed(f1, f2, f4))
+    print(f"feat_fusion_pre (HIP graph replay)  {t:7.3f} ms")
     fused5 = fused.unsqueeze(1).contiguous()
     t, res = timed(lambda: BP.view_variance(step.coords[2], step.origin, 0.04, fused5, step.krcam[1], 2))
     print(f"view_variance 48^3                  {t:7.3f} ms   n_valid {res['n_valid']}")
