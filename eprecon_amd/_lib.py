@@ -136,7 +136,9 @@ class ConvDesc(ctypes.Structure):
                 ("bn_partial", ctypes.c_void_p),
                 ("bn_scale_out", ctypes.c_void_p), ("bn_shift_out", ctypes.c_void_p),
                 ("bn_gamma", ctypes.c_void_p), ("bn_beta", ctypes.c_void_p), ("bn_eps", ctypes.c_float),
-                ("bn_ticket", ctypes.c_void_p)]
+                ("bn_ticket", ctypes.c_void_p),
+                ("ln", ctypes.c_int), ("ln_gamma", ctypes.c_void_p), ("ln_beta", ctypes.c_void_p),
+                ("ln_eps", ctypes.c_float), ("ln_post_relu", ctypes.c_int)]
 
 
 _WORKSPACES = {}

@@ -64,11 +64,20 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float *x, int n, in
     }
     sN[tid] = cnt; sMean[tid] = mean; sM2[tid] = m2;
     __syncthreads();
+    // fixed-order pairwise tree over the rpi row groups (a serial merge by one thread per column cost
+    // 44 us on the single-channel BatchNorm of the occupancy logit: 256 dependent merges with divisions)
+    for (int s = 1; s < rpi; s <<= 1) {
+        if (active && (rsub % (2 * s)) == 0 && rsub + s < rpi) {
+            float n = sN[tid], m = sMean[tid], q = sM2[tid];
+            const int o = tid + s * C;
+            chan_merge(n, m, q, sN[o], sMean[o], sM2[o]);
+            sN[tid] = n; sMean[tid] = m; sM2[tid] = q;
+        }
+        __syncthreads();
+    }
     if (tid < C) {
-        float a_n = 0.0f, a_mean = 0.0f, a_m2 = 0.0f;
-        for (int k = 0; k < rpi; ++k) chan_merge(a_n, a_mean, a_m2, sN[k * C + tid], sMean[k * C + tid], sM2[k * C + tid]);
         float *p = partial + (size_t)blockIdx.x * 3 * C;
-        p[tid] = a_n; p[C + tid] = a_mean; p[2 * C + tid] = a_m2;
+        p[tid] = sN[tid]; p[C + tid] = sMean[tid]; p[2 * C + tid] = sM2[tid];
     }
 }
 

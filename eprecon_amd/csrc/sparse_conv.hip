@@ -54,6 +54,12 @@ struct ConvParams {
     const float *bn_gamma, *bn_beta;
     float bn_eps;
     unsigned int *bn_ticket;  // zero-initialised arrival counter, reset by the last workgroup
+    // LayerNorm over the Cout channels of every output row, after bias / ReLU / residual (needs all
+    // columns in one workgroup): out = [relu]( LN(v) * ln_gamma + ln_beta )
+    int ln;
+    const float *ln_gamma, *ln_beta;
+    float ln_eps;
+    int ln_post_relu;
 };
 
 // Stage `rows` x TN weights (zero padded) from w[row0 + r][0:ncols] (row stride `stride`, rows valid
@@ -154,11 +160,82 @@ __device__ __forceinline__ void bn_finalize_last_block(const ConvParams &p, floa
 // lane halves, then the four waves through LDS) -> bn_partial[blockIdx.x][3][Cout]: the
 // statistics pass of the train-mode BatchNorm that follows every convolution of the reference,
 // without re-reading the tensor.  sStat: >= kWaves * 3 * 32 * NT floats of LDS, free to overwrite.
+// Epilogue with the row-wise LayerNorm the reference wires behind its spconv layers
+// (models/modules.py:447-452,473-482, models/occupancy_initialization.py:141-169) fused in:
+//   v = acc + bias; [relu]; [+ residual];  y = LN_row(v) * gamma + beta; [relu]
+// A row's Cout values sit in the 32 lanes of one half-wave (column = lane & 31, NT tiles per lane), so
+// the two row reductions are five xor-shuffles each; 16 rows per lane are reduced independently.
+template <int NT>
+__device__ __forceinline__ void conv_epilogue_ln(const ConvParams &p, f32x16 (&acc)[NT], int wrow0, int r32, int half)
+{
+    float gam[NT], bet[NT];
+    bool colok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = t * 32 + r32;
+        colok[t] = col < p.Cout;
+        const float b = (p.bias && colok[t]) ? p.bias[col] : 0.0f;
+        const float rs = (p.res_scale && colok[t]) ? p.res_scale[col] : 1.0f;
+        const float rb = (p.res_scale && colok[t]) ? p.res_shift[col] : 0.0f;
+        gam[t] = (p.ln_gamma && colok[t]) ? p.ln_gamma[col] : 1.0f;
+        bet[t] = (p.ln_beta && colok[t]) ? p.ln_beta[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = 0.0f;
+            if (colok[t] && row < p.n_out) {
+                v = acc[t][r] + b;
+                if (p.relu) v = fmaxf(v, 0.0f);
+                if (p.res) {
+                    float rv = p.res[(size_t)row * p.ld_res + col];
+                    if (p.res_scale) {
+                        rv = fmaf(rv, rs, rb);
+                        if (p.res_relu) rv = fmaxf(rv, 0.0f);
+                    }
+                    v += rv;
+                }
+            }
+            acc[t][r] = v;
+        }
+    }
+    const float inv_c = 1.0f / (float)p.Cout;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float s = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) s += acc[t][r];
+#pragma unroll
+        for (int m = 16; m > 0; m >>= 1) s += __shfl_xor(s, m);
+        const float mean = s * inv_c;
+        float q = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float d = colok[t] ? acc[t][r] - mean : 0.0f;
+            acc[t][r] = d;
+            q = fmaf(d, d, q);
+        }
+#pragma unroll
+        for (int m = 16; m > 0; m >>= 1) q += __shfl_xor(q, m);
+        const float inv = 1.0f / sqrtf(q * inv_c + p.ln_eps);
+        const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float y = fmaf(acc[t][r] * inv, gam[t], bet[t]);
+            if (p.ln_post_relu) y = fmaxf(y, 0.0f);
+            if (colok[t] && row < p.n_out) p.out[(size_t)row * p.ld_out + t * 32 + r32] = y;
+        }
+    }
+}
+
 template <int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)[NT], int wrow0, int col0, int r32,
                                               int half, int wave, float *sStat)
 {
     constexpr int TN = 32 * NT;
+    if (p.ln) {  // uniform; the launcher guarantees a single column block and no BatchNorm summaries
+        conv_epilogue_ln<NT>(p, acc, wrow0, r32, half);
+        return;
+    }
     const bool stats = p.bn_partial != nullptr;
     if (stats) __syncthreads();  // every wave is done reading the weights that sStat overlays
 #pragma unroll
@@ -529,7 +606,8 @@ int conv_dispatch(ConvParams &p, int64_t n_in, hipStream_t st)
     // tiles for 256 CUs; the gathered rows are re-read from L2 by each column block).
     const int nblk = (int)ceil_div(p.n_out, kRowsPerBlock);
     const int nt_full = (p.Cout + 31) / 32;
-    const bool split = nblk < 256 && nt_full > 1;
+    if (p.ln && (nt_full > 4 || p.bn_partial || p.accumulate)) return EPRECON_ERR_UNSUPPORTED;
+    const bool split = nblk < 256 && nt_full > 1 && !p.ln;
     const int cin_pad = (p.Cin + 7) / 8 * 8;
     static const bool resident_on = !(getenv("EPRECON_CONV_RESIDENT") && getenv("EPRECON_CONV_RESIDENT")[0] == '0');
     // narrow layers: the weights of a group of offsets resident in LDS
@@ -577,6 +655,8 @@ extern "C" int eprecon_conv_desc_async(const eprecon_conv_desc *d, void *stream)
     p.res_scale = d->res_scale; p.res_shift = d->res_shift; p.res_relu = d->res_relu;
     p.bn_scale_out = d->bn_scale_out; p.bn_shift_out = d->bn_shift_out; p.bn_gamma = d->bn_gamma;
     p.bn_beta = d->bn_beta; p.bn_eps = d->bn_eps; p.bn_ticket = d->bn_ticket;
+    p.ln = d->ln; p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.ln_eps = d->ln_eps;
+    p.ln_post_relu = d->ln_post_relu;
     return conv_check_and_run(p, d->n_in, d->n_out, stream);
 }
 

@@ -85,6 +85,12 @@ class SparseSubMConv3d(nn.Module):
         nbr = vset.kernel_map(3) if self.kernel == 3 else None
         return SP.sparse_conv(features, self.weight, nbr, self.bias, out=out, relu=relu)
 
+    def run_ln(self, features, vset, ln, out=None, relu=False, residual=None, post_relu=False):
+        """conv [+ReLU] [+residual] -> LayerNorm `ln` [-> ReLU], one launch"""
+        nbr = vset.kernel_map(3) if self.kernel == 3 else None
+        return SP.sparse_conv_ln(features, self.weight, nbr, self.bias, ln.weight, ln.bias, ln.eps, out=out,
+                                 relu=relu, residual=residual, post_relu=post_relu)
+
     def forward(self, features, coords, spitial_shape, bs):
         """features f32[N, C_in]; coords int[N, 4] (b,x,y,z) -> f32[N, C_out]"""
         return self.run(features.contiguous(), voxel_set_for(coords))
@@ -106,8 +112,7 @@ class SubMconv3dBlock(nn.Module):
         self.ln = _RowLayerNorm(C_out)
 
     def run(self, x, vset, out=None):
-        y = self.conv.run(x, vset, out=out)
-        return self.ln.run(y, post_relu=True, out=y)
+        return self.conv.run_ln(x, vset, self.ln, out=out, post_relu=True)
 
 
 class Spares3dELAN(nn.Module):
@@ -152,8 +157,7 @@ class SparseConv3d_Residual(nn.Module):
         self.norm = _RowLayerNorm(dim)
 
     def run(self, x, vset):
-        y = self.SConv3d.run(x, vset)
-        return self.norm.run(y, residual=x, pre_relu=True, out=y)
+        return self.SConv3d.run_ln(x, vset, self.norm, relu=True, residual=x)
 
     def forward(self, x, coords, spitial_shape, bs):
         return self.run(x.contiguous(), voxel_set_for(coords))

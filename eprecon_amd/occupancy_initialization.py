@@ -145,8 +145,7 @@ class Occupancy_Initialization(nn.Module):
         x = self.norm0.run(var)
         x = self.similary_1.run(x, vset)
         for conv, norm in ((self.subm1, self.norm1), (self.subm2, self.norm2), (self.subm3, self.norm3)):
-            y = conv.run(x, vset)
-            x = norm.run(y, residual=x, pre_relu=True, out=y)  # LN(x + ReLU(conv(x)))
+            x = conv.run_ln(x, vset, norm, relu=True, residual=x)  # LN(x + ReLU(conv(x))), one launch
         y = self.subm4.run(x, vset)
         return self.norm4.run(y, out=y)
 

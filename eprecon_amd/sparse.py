@@ -174,6 +174,37 @@ def sparse_conv_fused(x, weight, nbr=None, bias=None, out=None, relu=False, resi
     return out, partial
 
 
+def sparse_conv_ln(x, weight, nbr, bias, ln_weight, ln_bias, ln_eps, out=None, relu=False, residual=None,
+                   post_relu=False):
+    """conv + bias [+ReLU] [+residual] -> row-wise LayerNorm [-> ReLU] in ONE launch (descriptor entry point):
+    the spconv + LayerNorm blocks of the reference without a second pass over the tensor."""
+    lib = _lib.load()
+    if weight.dim() == 2:
+        weight = weight.unsqueeze(0)
+    kvol, cin, cout = weight.shape
+    weight = weight.contiguous()
+    n_out = x.shape[0] if nbr is None else nbr.shape[1]
+    assert x.shape[1] == cin and x.dtype == torch.float32 and cout <= 128
+    if out is None:
+        out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+    d = _lib.ConvDesc()
+    d.x, d.n_in, d.ld_x = x.data_ptr(), x.shape[0], _ld(x)
+    d.nbr, d.kvol, d.n_out = (None if nbr is None else nbr.data_ptr()), kvol, n_out
+    d.weight, d.cin, d.cout = weight.data_ptr(), cin, cout
+    d.bias = None if bias is None else bias.data_ptr()
+    if residual is not None:
+        assert residual.shape == (n_out, cout)
+        d.residual, d.ld_res = residual.data_ptr(), _ld(residual)
+    d.out, d.ld_out = out.data_ptr(), _ld(out)
+    d.relu = int(relu)
+    d.ln = 1
+    d.ln_gamma = None if ln_weight is None else ln_weight.data_ptr()
+    d.ln_beta = None if ln_bias is None else ln_bias.data_ptr()
+    d.ln_eps, d.ln_post_relu = float(ln_eps), int(post_relu)
+    _lib.check(lib.eprecon_conv_desc_async(ctypes.byref(d), _lib.current_stream()), "eprecon_conv_desc_async")
+    return out
+
+
 def batchnorm_apply_partials(x, partial, gamma=None, beta=None, eps=1e-5, residual=None, relu=False, out=None):
     """second half of the train-mode BatchNorm from producer-side summaries (sparse_conv_fused)"""
     lib = _lib.load()

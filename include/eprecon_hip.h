@@ -215,6 +215,10 @@ typedef struct eprecon_conv_desc {
     float *bn_scale_out; float *bn_shift_out;
     const float *bn_gamma; const float *bn_beta; float bn_eps;
     unsigned int *bn_ticket;
+    /* row-wise LayerNorm over the cout channels after bias / ReLU / residual (the spconv + LayerNorm
+     * blocks of models/modules.py:447-452,473-482, models/occupancy_initialization.py:141-169):
+     * out = [relu]( LN(v) * ln_gamma + ln_beta ); cout <= 128, excludes bn_partial / accumulate */
+    int ln; const float *ln_gamma; const float *ln_beta; float ln_eps; int ln_post_relu;
 } eprecon_conv_desc;
 int eprecon_conv_desc_async(const eprecon_conv_desc *desc, void *stream);
 /* producer-side summaries partial f32[nblk][3][channels] -> the BatchNorm in affine form (the

@@ -139,3 +139,34 @@ def test_batchnorm_and_layernorm(n, c):
         assert np.abs(got - OS.layernorm_rows(x, g, b, 1e-5, r, True, False)).max() < TOL
         got = rowwise_layernorm(dev(x), dev(g), dev(b), post_relu=True).cpu().numpy()
         assert np.abs(got - OS.layernorm_rows(x, g, b, post_relu=True)).max() < TOL
+
+
+@pytest.mark.parametrize("cin,cout,k", [(32, 32, 3), (32, 16, 3), (16, 16, 3), (128, 32, 1), (32, 32, 1), (24, 40, 3),
+                                        (8, 100, 1)])
+def test_sparse_conv_with_fused_layernorm(cin, cout, k):
+    """conv [+ReLU] [+residual] -> LayerNorm [-> ReLU] in one launch == the oracle's conv followed by its
+    row-wise LayerNorm (the SubM + LayerNorm blocks of models/modules.py:440-482)"""
+    from eprecon_amd.sparse import VoxelSet, sparse_conv_ln
+    rng = np.random.default_rng(cin * 100 + cout + k)
+    c = random_coords(rng, 2777, extent=9, batch=1)
+    x = rng.standard_normal((len(c), cin)).astype(np.float32)
+    kv = k ** 3
+    w = (rng.standard_normal((kv, cin, cout)) / np.sqrt(kv * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    g = rng.standard_normal(cout).astype(np.float32)
+    be = rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((len(c), cout)).astype(np.float32)
+    vs = VoxelSet(dev(c))
+    nbr_d = vs.kernel_map(3) if k == 3 else None
+    nbr = OS.kernel_map(c, c, 3, 1) if k == 3 else np.arange(len(c), dtype=np.int32)[None]
+    y = OS.sparse_conv(x, nbr, w, b)
+    # SubMconv3dBlock: ReLU(LN(conv))
+    got = sparse_conv_ln(dev(x), dev(w), nbr_d, dev(b), dev(g), dev(be), 1e-5, post_relu=True).cpu().numpy()
+    assert np.abs(got - OS.layernorm_rows(y, g, be, 1e-5, post_relu=True)).max() < TOL
+    # residual blocks: LN(res + ReLU(conv)), written into a channel slice of a wider buffer
+    wide = torch.zeros((len(c), cout + 8), device="cuda")
+    out = sparse_conv_ln(dev(x), dev(w), nbr_d, dev(b), dev(g), dev(be), 1e-5, out=wide[:, 4:4 + cout], relu=True,
+                         residual=dev(res))
+    ref = OS.layernorm_rows(y, g, be, 1e-5, res, True, False)
+    assert np.abs(out.cpu().numpy() - ref).max() < TOL
+    assert not wide[:, :4].any() and not wide[:, 4 + cout:].any()
