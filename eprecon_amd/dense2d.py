@@ -79,6 +79,7 @@ def packed_weight(conv):
 # instead of a separate finalize launch.  Measured slower on MI355X (cfg2 step 3.4 ms vs the two-launch form):
 # every workgroup's release makes its XCD's L2 write back, and 1,350 same-address atomics serialise.
 _FUSED_FINALIZE = os.environ.get("EPRECON_BN_TICKET", "0") == "1"
+MERGE_ELAN_1X1 = os.environ.get("EPRECON_ELAN_MERGE", "0") == "1"  # measured neutral on MI355X
 
 
 class Act:
@@ -97,14 +98,34 @@ def _dptr(t):
 
 
 def conv_bn_act(conv, bn, x, grid, out=None, aff=None, relu=True, pre_relu=False, residual=None):
-    """One launch for  BN( [ReLU](conv(x) + b) [+ residual] )  with x / residual given as Acts (their
-    pending BatchNorms are applied on load) and the BatchNorm of the result left pending: returns
-    Act(raw rows, scale, shift, relu).  `out`: rows to write (may be a channel slice), `aff`: the
+    """One launch (+ a tiny finalize) for  BN( [ReLU](conv(x) + b) [+ residual] )  with x / residual given
+    as Acts (their pending BatchNorms are applied on load) and the BatchNorm of the result left pending:
+    returns Act(raw rows, scale, shift, relu).  `out`: rows to write (may be a channel slice), `aff`: the
     (scale, shift) slices to fill (e.g. of a concat buffer's vectors)."""
+    return conv_bn_launch(packed_weight(conv), conv.bias, bn.weight, bn.bias, bn.eps, conv.kernel_size[0], x, grid,
+                          out=out, aff=aff, relu=relu, pre_relu=pre_relu, residual=residual, ticket_owner=conv)
+
+
+def merged_1x1(conv_a, bn_a, conv_b, bn_b):
+    """two 1x1 conv + BatchNorm layers on the same input as one layer with concatenated output channels
+    (BatchNorm is per channel, so this is exact); cached per parameter version on conv_a"""
+    tag = tuple((t._version, t.data_ptr()) for t in (conv_a.weight, conv_b.weight, conv_a.bias, conv_b.bias,
+                                                     bn_a.weight, bn_b.weight, bn_a.bias, bn_b.bias))
+    cached = getattr(conv_a, "_eprecon_merged", None)
+    if cached is None or cached[0] != tag:
+        assert conv_a.kernel_size == (1, 1) and conv_b.kernel_size == (1, 1) and bn_a.eps == bn_b.eps
+        with torch.no_grad():
+            w = torch.cat([packed_weight(conv_a), packed_weight(conv_b)], dim=2).contiguous()
+            cat = lambda a, b: torch.cat([a.detach(), b.detach()]).contiguous()
+            cached = (tag, w, cat(conv_a.bias, conv_b.bias), cat(bn_a.weight, bn_b.weight), cat(bn_a.bias, bn_b.bias))
+        conv_a._eprecon_merged = cached
+    return cached[1:]
+
+
+def conv_bn_launch(w, bias, gamma, beta, eps, k, x, grid, out=None, aff=None, relu=True, pre_relu=False,
+                   residual=None, ticket_owner=None):
     lib = _lib.load()
-    w = packed_weight(conv)
     kvol, cin, cout = w.shape
-    k = conv.kernel_size[0]
     rows = x.rows
     n = rows.shape[0]
     dev = rows.device
@@ -116,17 +137,17 @@ def conv_bn_act(conv, bn, x, grid, out=None, aff=None, relu=True, pre_relu=False
         a = torch.empty((2, cout), dtype=torch.float32, device=dev)
         aff = (a[0], a[1])
     partial = torch.empty(((n + 127) // 128, 3, cout), dtype=torch.float32, device=dev)
-    fused_finalize = _FUSED_FINALIZE
+    fused_finalize = _FUSED_FINALIZE and ticket_owner is not None
     ticket = None
     if fused_finalize:
-        ticket = getattr(conv, "_eprecon_ticket", None)
+        ticket = getattr(ticket_owner, "_eprecon_ticket", None)
         if ticket is None or ticket.device != dev:
-            ticket = conv._eprecon_ticket = torch.zeros((1,), dtype=torch.int32, device=dev)
+            ticket = ticket_owner._eprecon_ticket = torch.zeros((1,), dtype=torch.int32, device=dev)
     d = _lib.ConvDesc()
     d.x, d.n_in, d.ld_x = rows.data_ptr(), n, rows.stride(0)
     d.nbr, d.kvol, d.n_out = _dptr(nbr), kvol, n
     d.weight, d.cin, d.cout = w.data_ptr(), cin, cout
-    d.bias = _dptr(conv.bias)
+    d.bias = _dptr(bias)
     if residual is not None:
         assert residual.rows.shape == (n, cout)
         d.residual, d.ld_res = residual.rows.data_ptr(), residual.rows.stride(0)
@@ -137,12 +158,12 @@ def conv_bn_act(conv, bn, x, grid, out=None, aff=None, relu=True, pre_relu=False
     d.bn_partial = partial.data_ptr()
     if fused_finalize:
         d.bn_scale_out, d.bn_shift_out = aff[0].data_ptr(), aff[1].data_ptr()
-        d.bn_gamma, d.bn_beta, d.bn_eps = _dptr(bn.weight), _dptr(bn.bias), float(bn.eps)
+        d.bn_gamma, d.bn_beta, d.bn_eps = _dptr(gamma), _dptr(beta), float(eps)
         d.bn_ticket = ticket.data_ptr()
     _lib.check(lib.eprecon_conv_desc_async(ctypes.byref(d), _lib.current_stream()), "eprecon_conv_desc_async")
     if not fused_finalize:
         _lib.check(lib.eprecon_batchnorm_finalize_affine_async(
-            partial.data_ptr(), partial.shape[0], cout, _dptr(bn.weight), _dptr(bn.bias), float(bn.eps),
+            partial.data_ptr(), partial.shape[0], cout, _dptr(gamma), _dptr(beta), float(eps),
             aff[0].data_ptr(), aff[1].data_ptr(), _lib.current_stream()), "eprecon_batchnorm_finalize_affine_async")
     return Act(out, aff[0], aff[1], relu)
 

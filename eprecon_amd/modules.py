@@ -281,8 +281,13 @@ class ELAN(nn.Module):
         aff = torch.empty((2, 4 * d), dtype=torch.float32, device=dev)
         part = lambda a, b: D2.Act(cat[:, a:b], aff[0, a:b], aff[1, a:b], True)
         sl = lambda a, b: dict(out=cat[:, a:b], aff=(aff[0, a:b], aff[1, a:b]))
-        self.conv1.run_act(x, grid, **sl(0, d))
-        self.conv2.run_act(x, grid, **sl(d, 2 * d))
+        if D2.MERGE_ELAN_1X1:
+            # conv1 / conv2 (both 1x1 d -> d on x) as ONE d -> 2d layer writing the first two slices
+            w, b, g, be = D2.merged_1x1(self.conv1.conv, self.conv1.bn, self.conv2.conv, self.conv2.bn)
+            D2.conv_bn_launch(w, b, g, be, self.conv1.bn.eps, 1, x, grid, relu=True, **sl(0, 2 * d))
+        else:
+            self.conv1.run_act(x, grid, **sl(0, d))
+            self.conv2.run_act(x, grid, **sl(d, 2 * d))
         self.conv3.run_act(part(d, 2 * d), grid, **sl(2 * d, 2 * d + h))
         self.conv4.run_act(part(2 * d, 2 * d + h), grid, **sl(2 * d + h, 3 * d))
         self.conv5.run_act(part(2 * d + h, 3 * d), grid, **sl(3 * d, 3 * d + h))
