@@ -141,8 +141,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # EPRECON_BENCH_FORCE_DIST=1 exercises the RCCL path (init, barrier, MAX all-reduce) at world size 1
+    use_dist = world > 1 or os.environ.get("EPRECON_BENCH_FORCE_DIST", "0") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     from eprecon_amd import _lib
@@ -158,7 +161,7 @@ def main():
     step = Cfg2Step(seed=rank, device=torch.device("cuda", local_rank))
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -177,7 +180,7 @@ def main():
     elapsed = time.perf_counter() - t0
     step.profile_dominant = False
     lib.eprecon_profile_enable(0)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -206,7 +209,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(step, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
