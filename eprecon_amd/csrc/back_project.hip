@@ -38,6 +38,8 @@ using namespace ep;
 //   128-byte padded pixel stride                             133 us            (neutral)
 //   LDS image patches per view, barrier per view             206 us
 //   LDS image patches, all views staged at once (64 voxels)  313 us
+//   pixel-pair records [pix x | pix x+1] (192-byte aligned runs, 12 lanes per voxel, 6 instead of 8 L1
+//   segments per (voxel, view); 2x the map footprint)         165 us            (removed again)
 // The direct-gather kernel moves 2.4 GB through the vector L1 at ~41 B/clk/CU.  PMC: 54.7 M L1 accesses for
 // 2.38 M wave loads = 23 per instruction: a 96-byte tap (24 channels) always touches two 64-byte L1 segments,
 // so the L1 access rate (one segment per clock per CU -> >= 89 us) bounds the kernel, not latency (more
