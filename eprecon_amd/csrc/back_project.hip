@@ -28,10 +28,11 @@
 namespace {
 using namespace ep;
 
-// tuning switches (A/B measurements: tools/ab_backproject.py); read once from the environment
-// Variants measured on MI355X (tools/ab_backproject.py, dense 96^3, C = 24, 120x160; gather kernel / whole op):
-//   input-order tiles, 4-channel lanes, taps recomputed      134 us / 0.26 ms
-//   + per-pair taps in LDS, cheap projection, buffer loads   122 us           (default, EPRECON_BP_MLP=1)
+// Variants measured on MI355X (tools/ab_backproject.py, dense 96^3, C = 24, 120x160; gather kernel / whole op).
+// Only the first two are still in the build (EPRECON_BP_MLP = 0 / 1..4); the others were parity-green
+// experiments of round 1 and were removed again (git history: "back_project:" commits):
+//   input-order tiles, 4-channel lanes, taps recomputed      134 us / 0.26 ms  (bp_gather_kernel)
+//   + per-pair taps in LDS, cheap projection, buffer loads   122 us            (bp_gather_mlp_kernel, default)
 //   + 2 / 3 / 4 views of loads in flight per lane            126 / 129 / 138 us (no latency to hide)
 //   brick-sorted tiles, 4-channel lanes                      118 us / 0.27 ms  (binning costs what it saves)
 //   8-channel lanes + per-pair taps in LDS + buffer loads    173-185 us        (strided 32-byte lanes)
@@ -39,36 +40,18 @@ using namespace ep;
 //   LDS image patches per view, barrier per view             206 us
 //   LDS image patches, all views staged at once (64 voxels)  313 us
 //   pixel-pair records [pix x | pix x+1] (192-byte aligned runs, 12 lanes per voxel, 6 instead of 8 L1
-//   segments per (voxel, view); 2x the map footprint)         165 us            (removed again)
-// The direct-gather kernel moves 2.4 GB through the vector L1 at ~41 B/clk/CU.  PMC: 54.7 M L1 accesses for
-// 2.38 M wave loads = 23 per instruction: a 96-byte tap (24 channels) always touches two 64-byte L1 segments,
-// so the L1 access rate (one segment per clock per CU -> >= 89 us) bounds the kernel, not latency (more
-// loads in flight do not help) and not HBM.  The LDS-patch structures lose more to barriers / occupancy /
-// per-tile overhead than they save.  The variants stay in the build behind environment switches.
-bool g_sorted_enabled = false;
-bool g_gather8_enabled = false;
-bool g_lds_enabled = false;
-int g_pad_mode = 0;
+//   segments per (voxel, view); 2x the map footprint)         165 us
+// PMC: 54.7 M vector-L1 accesses for 2.38 M wave loads = 23 per instruction: a 96-byte tap (24 channels)
+// always touches two 64-byte L1 segments, and at one segment per clock per CU that is 89 of the 116 us: the
+// L1 access rate bounds the kernel, not latency (more loads in flight do not help), not VALU (-43 % VALU
+// bought 134 -> 122 us) and not HBM.
 int g_mlp = 1;  // views in flight per lane in the default gather (0 = the older recompute-per-lane kernel)
 void read_tuning_env()
 {
     static bool done = false;
     if (done) return;
     done = true;
-    if (const char *e = getenv("EPRECON_BP_SORTED")) g_sorted_enabled = e[0] != '0';
-    if (const char *e = getenv("EPRECON_BP_GATHER8")) g_gather8_enabled = e[0] != '0';
-    if (const char *e = getenv("EPRECON_BP_PAD")) g_pad_mode = atoi(e);
-    if (const char *e = getenv("EPRECON_BP_LDS")) g_lds_enabled = e[0] != '0';
     if (const char *e = getenv("EPRECON_BP_MLP")) g_mlp = atoi(e);
-}
-
-// pixel stride (floats) of the internal channels-last copy
-int padded_stride(int C)
-{
-    if (g_pad_mode == 0) return C;
-    if (C <= 32) return 32;                       // one 128-byte line per tap
-    if (g_pad_mode >= 2) return (C + 31) / 32 * 32;  // whole lines for wider taps too
-    return C;
 }
 
 struct BpParams {
@@ -80,7 +63,7 @@ struct BpParams {
     const float *feats_nhwc;  // [V*B][H*W][C]
     const float *krcam;       // [V*B][16]
     int V, C, H, W;
-    int Cs;  // pixel stride of the channels-last maps in floats (>= C; padded to a 128-byte line when re-laid out here)
+    int Cs;  // pixel stride of the channels-last maps in floats (>= C)
     int min_view;
     float *out_feats;
     float *out_mean;
@@ -90,8 +73,6 @@ struct BpParams {
     uint8_t *out_mask;
     int32_t *n_valid_dev;  // [1 + B]
     int32_t *block_offsets;
-    const int32_t *perm;   // brick-sorted voxel order (sorted pipeline) or nullptr
-    const int32_t *slot;   // output row of every voxel (sorted pipeline) or nullptr
 };
 
 struct Proj {
@@ -244,96 +225,6 @@ __global__ __launch_bounds__(256) void bp_count_kernel(BpParams p, int32_t *tile
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Brick-sorted pipeline (long lists): voxels are binned by 3D brick so that one gather tile holds
-// spatial neighbours.  Bin = (brick coordinate mod 32 per axis, batch); aliasing of far-apart bricks
-// only costs locality, never correctness.
-// ---------------------------------------------------------------------------------------------
-constexpr int kBinsPerBatch = 32 * 32 * 32;
-
-__device__ __forceinline__ int brick_bin(const int4 c, int brick_shift)
-{
-    const int bx = (c.y >> brick_shift) & 31, by = (c.z >> brick_shift) & 31, bz = (c.w >> brick_shift) & 31;
-    return c.x * kBinsPerBatch + (bx * 32 + by) * 32 + bz;
-}
-
-// wave-aggregated atomicAdd(counter[bin], 1): lanes holding the same bin in a run of consecutive
-// lanes (raster-ordered lists give runs of 8+) issue ONE atomic; returns this lane's position
-__device__ __forceinline__ int run_aggregated_add(int32_t *counter, int bin, bool active)
-{
-    const int lane = threadIdx.x & (kWave - 1);
-    const int prev = __shfl_up(bin, 1);
-    const bool prev_active = __shfl_up((int)active, 1) != 0;
-    const bool head = active && (lane == 0 || !prev_active || prev != bin);
-    const unsigned long long heads = __ballot(head);
-    const unsigned long long actives = __ballot(active);
-    if (!active) return 0;
-    const unsigned long long below = heads & ((2ull << lane) - 1ull);
-    const int leader = 63 - __clzll(below);
-    // run = [leader, next head or first inactive lane after leader)
-    const unsigned long long after = (heads | ~actives) & ~((2ull << leader) - 1ull);
-    const int run_end = after ? (__ffsll((long long)after) - 1) : kWave;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&counter[bin], run_end - leader);
-    base = __shfl(base, leader);
-    return base + (lane - leader);
-}
-
-__global__ __launch_bounds__(256) void bp_count_sorted_kernel(BpParams p, int brick_shift, int32_t *flag,
-                                                              int32_t *hist)
-{
-    constexpr int BLOCK = 256;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *sP = reinterpret_cast<float *>(smem);
-    int *sBatch = reinterpret_cast<int *>(sP + p.V * p.batch * 12);
-    const int tid = threadIdx.x;
-    stage_matrices(sP, p.krcam, p.V * p.batch, tid, BLOCK);
-    for (int b = tid; b < p.batch; b += BLOCK) sBatch[b] = 0;
-    __syncthreads();
-    const int i = blockIdx.x * BLOCK + tid;
-    bool in_range = false;
-    int bin = 0;
-    if (i < p.n) {
-        const int4 c = reinterpret_cast<const int4 *>(p.coords)[i];
-        int cnt = 0;
-        in_range = c.x >= 0 && c.x < p.batch;
-        if (in_range) {
-            float X, Y, Z;
-            voxel_centre(c, p.origin, p.voxel_size, X, Y, Z);
-            const float wm1 = (float)(p.W - 1), hm1 = (float)(p.H - 1);
-            const float kx = 2.0f / wm1, ky = 2.0f / hm1;
-            for (int v = 0; v < p.V; ++v)
-                cnt += project_fast(sP + (v * p.batch + c.x) * 12, X, Y, Z, wm1, hm1, kx, ky).vis ? 1 : 0;
-            bin = brick_bin(c, brick_shift);
-        }
-        p.count[i] = (float)cnt;
-        const bool valid = in_range && cnt >= p.min_view;
-        flag[i] = valid ? 1 : 0;
-        if (valid) atomicAdd(&sBatch[c.x], 1);
-    }
-    run_aggregated_add(hist, bin, in_range);  // every in-range voxel is binned (invalid ones are cheap)
-    __syncthreads();
-    for (int b = tid; b < p.batch; b += BLOCK)
-        if (sBatch[b]) atomicAdd(&p.n_valid_dev[1 + b], sBatch[b]);
-}
-
-__global__ __launch_bounds__(256) void bp_bin_fill_kernel(const int4 *coords, int n, int batch, int brick_shift,
-                                                          const int32_t *bin_offset, int32_t *cursor,
-                                                          int32_t *perm, int32_t *n_binned)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    bool in_range = false;
-    int bin = 0;
-    if (i < n) {
-        const int4 c = coords[i];
-        in_range = c.x >= 0 && c.x < batch;
-        if (in_range) bin = brick_bin(c, brick_shift);
-    }
-    const int pos = run_aggregated_add(cursor, bin, in_range);
-    if (in_range) perm[bin_offset[bin] + pos] = i;
-    (void)n_binned;
-}
-
 // exclusive scan of the block totals, one workgroup; also publishes n_valid
 __global__ __launch_bounds__(1024) void bp_scan_kernel(int32_t *block_sums, int nblk,
                                                        int32_t *n_valid_dev, const int32_t *blk_batch = nullptr,
@@ -474,7 +365,7 @@ struct Chan<1> {
 };
 
 // QT > 0: channel groups per voxel known at compile time (fast div/mod); QT == 0: runtime
-template <int VOX, int MODE, int VEC, int QT, bool SORTED>
+template <int VOX, int MODE, int VEC, int QT>
 __global__ __launch_bounds__(256) void bp_gather_kernel(BpParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -495,10 +386,8 @@ __global__ __launch_bounds__(256) void bp_gather_kernel(BpParams p)
     stage_matrices(sP, p.krcam, p.V * p.batch, tid, BLOCK);
     __syncthreads();
 
-    // SORTED: the tile is 256 consecutive entries of the brick-sorted permutation (voxels that are
-    // neighbours in space, so their taps share cache lines); otherwise 256 consecutive input rows
     const int e = lb * VOX + tid;
-    const int i = (SORTED && tid < VOX && e < p.n) ? p.perm[e] : e;
+    const int i = e;
     const float wm1 = (float)(p.W - 1), hm1 = (float)(p.H - 1);
     bool valid = false;
     int4 c = make_int4(0, 0, 0, 0);
@@ -527,11 +416,11 @@ __global__ __launch_bounds__(256) void bp_gather_kernel(BpParams p)
     int nloc;
     const int rank = block_exclusive_rank<BLOCK>(valid, sWave, nloc);
     if (nloc == 0) return;
-    const int base = SORTED ? 0 : p.block_offsets[lb];
+    const int base = p.block_offsets[lb];
     const int n_valid = p.n_valid_dev[0];
     const int cout = (MODE == EPRECON_BP_MEAN_DEPTH) ? p.C + 1 : p.C;
     if (valid) {
-        const int o = SORTED ? p.slot[i] : base + rank;
+        const int o = base + rank;
         sSlot[rank] = tid;
         sOut[tid] = o;
         sVis[tid] = vis;
@@ -593,188 +482,7 @@ __global__ __launch_bounds__(256) void bp_gather_kernel(BpParams p)
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// K2 + K3 (+K4), main variant (C % 8 == 0, lists >= 48k voxels): 128 voxels per 256-thread tile.
-//   phase 1a  one thread per (voxel, view) pair: cheap projection, bilinear tap offset + weights
-//             -> LDS (computed once per pair instead of once per channel group)
-//   phase 1b  one thread per voxel: visible count, validity, stable in-tile compaction / output row
-//   phase 2   one thread per (valid voxel, 8 channels): per visible view 8 x 16-byte buffer loads
-//             with 32-bit offsets and 32 fma into 8 accumulators; mean or two-sweep variance
-// ---------------------------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-struct Acc8 {
-    float a[8];
-};
-
-__device__ __forceinline__ void tap8(__amdgpu_buffer_rsrc_t rsrc, int byte_off, float w, Acc8 &s)
-{
-    const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
-    const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off + 16, 0, 0);
-    s.a[0] = fmaf(__uint_as_float(lo.x), w, s.a[0]);
-    s.a[1] = fmaf(__uint_as_float(lo.y), w, s.a[1]);
-    s.a[2] = fmaf(__uint_as_float(lo.z), w, s.a[2]);
-    s.a[3] = fmaf(__uint_as_float(lo.w), w, s.a[3]);
-    s.a[4] = fmaf(__uint_as_float(hi.x), w, s.a[4]);
-    s.a[5] = fmaf(__uint_as_float(hi.y), w, s.a[5]);
-    s.a[6] = fmaf(__uint_as_float(hi.z), w, s.a[6]);
-    s.a[7] = fmaf(__uint_as_float(hi.w), w, s.a[7]);
-}
-
-template <int MODE, int Q8, bool SORTED>
-__global__ __launch_bounds__(256) void bp_gather8_kernel(BpParams p)
-{
-    constexpr int VOX = 128, BLOCK = 256;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4 *sW = reinterpret_cast<float4 *>(smem);                        // [VOX*V] tap weights
-    int *sOff = reinterpret_cast<int *>(sW + VOX * p.V);                  // [VOX*V] element offset of tap 00
-    float *sP = reinterpret_cast<float *>(sOff + VOX * p.V);              // [V*B][12]
-    const int nP = (p.V * p.batch * 12 + 3) & ~3;
-    uint32_t *sVis = reinterpret_cast<uint32_t *>(sP + nP);               // [VOX]
-    int *sSlot = reinterpret_cast<int *>(sVis + VOX);                     // [VOX] rank -> voxel
-    int *sOut = sSlot + VOX;                                              // [VOX] voxel -> output row
-    int *sWave = sOut + VOX;                                              // [BLOCK/64]
-
-    const int tid = threadIdx.x;
-    const int lb = xcd_remap(blockIdx.x, gridDim.x);
-    stage_matrices(sP, p.krcam, p.V * p.batch, tid, BLOCK);
-    if (tid < VOX) sVis[tid] = 0;
-    __syncthreads();
-
-    const float wm1 = (float)(p.W - 1), hm1 = (float)(p.H - 1);
-    const float kx = 2.0f / wm1, ky = 2.0f / hm1;
-    const int map_elems = p.H * p.W * p.Cs;
-    const int row_elems = p.W * p.Cs;
-    // ---- phase 1a ----
-    for (int pr = tid; pr < VOX * p.V; pr += BLOCK) {
-        const int vx = pr / p.V, v = pr - vx * p.V;
-        const int e = lb * VOX + vx;
-        if (e >= p.n) continue;
-        const int i = SORTED ? p.perm[e] : e;
-        const int4 c = reinterpret_cast<const int4 *>(p.coords)[i];
-        if (c.x < 0 || c.x >= p.batch) continue;
-        float X, Y, Z;
-        voxel_centre(c, p.origin, p.voxel_size, X, Y, Z);
-        const ProjFast q = project_fast(sP + (v * p.batch + c.x) * 12, X, Y, Z, wm1, hm1, kx, ky);
-        if (!q.vis) continue;
-        // taps: clamp the base pixel to [0, W-2] so that all four taps are inside the image; at
-        // ix = W-1 this gives weights (0, 1) on (W-2, W-1) = the reference's value
-        const float x0f = fminf(floorf(q.u), wm1 - 1.0f), y0f = fminf(floorf(q.v), hm1 - 1.0f);
-        const float wx1 = q.u - x0f, wx0 = (x0f + 1.0f) - q.u;
-        const float wy1 = q.v - y0f, wy0 = (y0f + 1.0f) - q.v;
-        sW[pr] = make_float4(wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1);
-        sOff[pr] = (v * p.batch + c.x) * map_elems + ((int)y0f * p.W + (int)x0f) * p.Cs;
-        atomicOr(&sVis[vx], 1u << v);
-    }
-    __syncthreads();
-    // ---- phase 1b ----
-    bool valid = false;
-    int4 c = make_int4(0, 0, 0, 0);
-    int i = 0, cnt = 0;
-    {
-        const int e = lb * VOX + tid;
-        if (tid < VOX && e < p.n) {
-            i = SORTED ? p.perm[e] : e;
-            c = reinterpret_cast<const int4 *>(p.coords)[i];
-            cnt = __popc(sVis[tid]);
-            valid = c.x >= 0 && c.x < p.batch && cnt >= p.min_view;
-        }
-    }
-    int nloc;
-    const int rank = block_exclusive_rank<BLOCK>(valid, sWave, nloc);
-    if (nloc == 0) return;
-    const int n_valid = p.n_valid_dev[0];
-    const int cout = (MODE == EPRECON_BP_MEAN_DEPTH) ? p.C + 1 : p.C;
-    if (valid) {
-        const int o = SORTED ? p.slot[i] : p.block_offsets[lb] + rank;
-        sSlot[rank] = tid;
-        sOut[tid] = o;
-        reinterpret_cast<int4 *>(p.out_coords)[o] = c;
-        if (MODE == EPRECON_BP_MEAN_DEPTH || p.out_grid || p.out_mask) {
-            float X, Y, Z, zsum = 0.0f;
-            voxel_centre(c, p.origin, p.voxel_size, X, Y, Z);
-            for (int v = 0; v < p.V; ++v) {
-                const Proj pr = project(sP + (v * p.batch + c.x) * 12, X, Y, Z, wm1, hm1);
-                if (pr.vis) zsum += pr.pz;
-                if (p.out_grid)
-                    reinterpret_cast<float2 *>(p.out_grid)[(size_t)v * n_valid + o] = make_float2(pr.gx, pr.gy);
-                if (p.out_mask) p.out_mask[(size_t)v * n_valid + o] = pr.vis ? 1 : 0;
-            }
-            if (MODE == EPRECON_BP_MEAN_DEPTH)
-                p.out_feats[(size_t)o * cout + p.C] = __fdiv_rn(zsum, (float)(cnt > 0 ? cnt : 1));
-        }
-    }
-    __syncthreads();
-    // ---- phase 2 ----
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(p.feats_nhwc), 0, p.V * p.batch * map_elems * 4, 0x00020000);
-    for (int w = tid; w < nloc * Q8; w += BLOCK) {
-        const int r = w / Q8, q = w - r * Q8;
-        const int t = sSlot[r];
-        const uint32_t vm = sVis[t];
-        const float den = (float)max(__popc(vm), 1);
-        Acc8 acc;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc.a[k] = 0.0f;
-        for (int v = 0; v < p.V; ++v) {
-            if (vm & (1u << v)) {
-                const float4 wt = sW[t * p.V + v];
-                const int b0 = (sOff[t * p.V + v] + q * 8) * 4;
-                tap8(rsrc, b0, wt.x, acc);
-                tap8(rsrc, b0 + p.Cs * 4, wt.y, acc);
-                tap8(rsrc, b0 + row_elems * 4, wt.z, acc);
-                tap8(rsrc, b0 + (row_elems + p.Cs) * 4, wt.w, acc);
-            }
-        }
-        const int orow = sOut[t];
-        float *dst = p.out_feats + (size_t)orow * cout + q * 8;
-        float res[8];
-        if (MODE == EPRECON_BP_VARIANCE) {
-            float mean[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) mean[k] = __fdiv_rn(acc.a[k], den);
-            Acc8 sq;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) sq.a[k] = 0.0f;
-            for (int v = 0; v < p.V; ++v) {
-                if (vm & (1u << v)) {
-                    const float4 wt = sW[t * p.V + v];
-                    const int b0 = (sOff[t * p.V + v] + q * 8) * 4;
-                    Acc8 smp;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) smp.a[k] = 0.0f;
-                    tap8(rsrc, b0, wt.x, smp);
-                    tap8(rsrc, b0 + p.Cs * 4, wt.y, smp);
-                    tap8(rsrc, b0 + row_elems * 4, wt.z, smp);
-                    tap8(rsrc, b0 + (row_elems + p.Cs) * 4, wt.w, smp);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const float d = smp.a[k] - mean[k];
-                        sq.a[k] = fmaf(d, d, sq.a[k]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) res[k] = __fdiv_rn(sq.a[k], den);
-            if (p.out_mean) {
-                float *dm = p.out_mean + (size_t)orow * p.C + q * 8;
-                *reinterpret_cast<float4 *>(dm) = make_float4(mean[0], mean[1], mean[2], mean[3]);
-                *reinterpret_cast<float4 *>(dm + 4) = make_float4(mean[4], mean[5], mean[6], mean[7]);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) res[k] = __fdiv_rn(acc.a[k], den);
-        }
-        if (MODE != EPRECON_BP_MEAN_DEPTH) {
-            *reinterpret_cast<float4 *>(dst) = make_float4(res[0], res[1], res[2], res[3]);
-            *reinterpret_cast<float4 *>(dst + 4) = make_float4(res[4], res[5], res[6], res[7]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) dst[k] = res[k];
-        }
-    }
-}
-
 
 // ---------------------------------------------------------------------------------------------
 // K2 + K3 (+K4), default for C % 4 == 0: direct gather with per-pair taps in LDS and U views of loads
@@ -948,271 +656,6 @@ __global__ __launch_bounds__(256) void bp_gather_mlp_kernel(BpParams p)
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// K2 + K3 (+K4), LDS-patch variant for long brick-sorted lists (C % 4 == 0, C <= 40).
-// A tile is 128 consecutive entries of the brick-sorted permutation = a compact 3D block of voxels,
-// whose projections into one view cover a small image rectangle.  Per view the rectangle (+1 for
-// the bilinear neighbours) is copied ONCE from the channels-last map into LDS with coalesced
-// 16-byte loads, and the four taps of every (voxel, 4-channel group) are then read from LDS
-// (ds_read_b128, 256 B/clk/CU) instead of through the vector L1 (64 B/clk/CU), which is what bounds
-// the direct-gather kernels.  A view whose rectangle exceeds the LDS budget (bricks close to the
-// camera) falls back to direct loads for that view only.
-//   phase 1a  one thread per (voxel, view): cheap projection, pixel coords -> LDS, visibility bits
-//   phase 1b  one thread per voxel: validity / output row; per-view bounding boxes (wave min/max)
-//   phase 2   per view: stage patch -> barrier -> accumulate taps of every item -> barrier
-// ---------------------------------------------------------------------------------------------
-constexpr int kPatchFloats = 1280;  // per view: 5 KB (e.g. 7 x 7 pixels of 24 channels)
-constexpr int kLdsVox = 64;          // voxels per tile (one 4 x 4 x 4 brick)
-
-template <int MODE, int QT>
-__global__ __launch_bounds__(256) void bp_gather_lds_kernel(BpParams p)
-{
-    constexpr int VOX = kLdsVox, BLOCK = 256;
-    constexpr int IPT = (VOX * QT + BLOCK - 1) / BLOCK;  // items per thread
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4 *sPatch = reinterpret_cast<float4 *>(smem);                              // [V][kPatchFloats / 4]
-    float2 *sPix = reinterpret_cast<float2 *>(sPatch + p.V * (kPatchFloats / 4));   // [VOX*V] pixel coords
-    float *sP = reinterpret_cast<float *>(sPix + VOX * p.V);                        // [V*B][12]
-    const int nP = (p.V * p.batch * 12 + 3) & ~3;
-    uint32_t *sVis = reinterpret_cast<uint32_t *>(sP + nP);                         // [VOX]
-    int *sSlot = reinterpret_cast<int *>(sVis + VOX);                               // [VOX] rank -> voxel
-    int *sOut = sSlot + VOX;                                                        // [VOX] voxel -> output row
-    int *sBatch = sOut + VOX;                                                       // [VOX]
-    int *sBox = sBatch + VOX;                                                       // [V][4] xmin, xmax, ymin, ymax
-    int *sWave = sBox + 4 * 32;                                                     // [BLOCK/64]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int lb = xcd_remap(blockIdx.x, gridDim.x);
-    stage_matrices(sP, p.krcam, p.V * p.batch, tid, BLOCK);
-    if (tid < VOX) sVis[tid] = 0;
-    if (tid < 4 * p.V) sBox[tid] = ((tid & 1) == 0) ? 0x7fffffff : -1;  // min slots / max slots
-    __syncthreads();
-
-    const float wm1 = (float)(p.W - 1), hm1 = (float)(p.H - 1);
-    const float kx = 2.0f / wm1, ky = 2.0f / hm1;
-    // ---- phase 1a: one thread per (voxel, view) ----
-    for (int pr = tid; pr < VOX * p.V; pr += BLOCK) {
-        const int vx = pr / p.V, v = pr - vx * p.V;
-        const int e = lb * VOX + vx;
-        if (e >= p.n) continue;
-        const int i = p.perm[e];
-        const int4 c = reinterpret_cast<const int4 *>(p.coords)[i];
-        if (c.x < 0 || c.x >= p.batch) continue;
-        float X, Y, Z;
-        voxel_centre(c, p.origin, p.voxel_size, X, Y, Z);
-        const ProjFast q = project_fast(sP + (v * p.batch + c.x) * 12, X, Y, Z, wm1, hm1, kx, ky);
-        if (!q.vis) continue;
-        sPix[pr] = make_float2(q.u, q.v);
-        atomicOr(&sVis[vx], 1u << v);
-    }
-    __syncthreads();
-    // ---- phase 1b: one thread per voxel (the first wave) ----
-    bool valid = false;
-    int4 c = make_int4(0, 0, 0, 0);
-    int i = 0, cnt = 0;
-    uint32_t vis = 0;
-    {
-        const int e = lb * VOX + tid;
-        if (tid < VOX && e < p.n) {
-            i = p.perm[e];
-            c = reinterpret_cast<const int4 *>(p.coords)[i];
-            vis = sVis[tid];
-            cnt = __popc(vis);
-            valid = c.x >= 0 && c.x < p.batch && cnt >= p.min_view;
-        }
-    }
-    int nloc;
-    const int rank = block_exclusive_rank<BLOCK>(valid, sWave, nloc);
-    if (nloc == 0) return;
-    const int n_valid = p.n_valid_dev[0];
-    const int cout = (MODE == EPRECON_BP_MEAN_DEPTH) ? p.C + 1 : p.C;
-    if (valid) {
-        const int o = p.slot[i];
-        sSlot[rank] = tid;
-        sOut[tid] = o;
-        sBatch[tid] = c.x;
-        reinterpret_cast<int4 *>(p.out_coords)[o] = c;
-        if (MODE == EPRECON_BP_MEAN_DEPTH || p.out_grid || p.out_mask) {
-            float X, Y, Z, zsum = 0.0f;
-            voxel_centre(c, p.origin, p.voxel_size, X, Y, Z);
-            for (int v = 0; v < p.V; ++v) {
-                const Proj pr = project(sP + (v * p.batch + c.x) * 12, X, Y, Z, wm1, hm1);
-                if (pr.vis) zsum += pr.pz;
-                if (p.out_grid)
-                    reinterpret_cast<float2 *>(p.out_grid)[(size_t)v * n_valid + o] = make_float2(pr.gx, pr.gy);
-                if (p.out_mask) p.out_mask[(size_t)v * n_valid + o] = pr.vis ? 1 : 0;
-            }
-            if (MODE == EPRECON_BP_MEAN_DEPTH)
-                p.out_feats[(size_t)o * cout + p.C] = __fdiv_rn(zsum, (float)(cnt > 0 ? cnt : 1));
-        }
-    }
-    // per-view bounding box of the base pixels of the valid voxels that see the view (wave 0 only)
-    if (tid < VOX) {
-        for (int v = 0; v < p.V; ++v) {
-            const bool on = valid && ((vis >> v) & 1u);
-            int x0 = 0x7fffffff, x1 = -1, y0 = 0x7fffffff, y1 = -1;
-            if (on) {
-                const float2 px = sPix[tid * p.V + v];
-                x0 = x1 = (int)fminf(floorf(px.x), wm1 - 1.0f);
-                y0 = y1 = (int)fminf(floorf(px.y), hm1 - 1.0f);
-            }
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) {
-                x0 = min(x0, __shfl_xor(x0, d));
-                x1 = max(x1, __shfl_xor(x1, d));
-                y0 = min(y0, __shfl_xor(y0, d));
-                y1 = max(y1, __shfl_xor(y1, d));
-            }
-            if (lane == 0) {
-                sBox[4 * v + 0] = x0; sBox[4 * v + 1] = x1; sBox[4 * v + 2] = y0; sBox[4 * v + 3] = y1;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- stage the patches of ALL views in one go (many loads in flight, one barrier) ----
-    const int C4 = p.C / 4;
-    const size_t map4 = (size_t)p.H * p.W * C4;  // float4 per map
-    const float4 *maps = reinterpret_cast<const float4 *>(p.feats_nhwc);
-    const int pb = sBatch[sSlot[0]];  // batch element of the tile (voxels of another one use direct loads)
-    uint32_t staged_mask = 0;
-    for (int v = 0; v < p.V; ++v) {
-        const int bx0 = sBox[4 * v + 0], bx1 = sBox[4 * v + 1], by0 = sBox[4 * v + 2], by1 = sBox[4 * v + 3];
-        if (bx1 < 0) continue;
-        const int pw = bx1 - bx0 + 2, ph = by1 - by0 + 2;
-        const int row4 = pw * C4;
-        if (row4 * ph * 4 > kPatchFloats) continue;  // too large for its slice: direct loads for this view
-        staged_mask |= 1u << v;
-        const float4 *vmap = maps + ((size_t)v * p.batch + pb) * map4 + ((size_t)by0 * p.W + bx0) * C4;
-        float4 *dst = sPatch + v * (kPatchFloats / 4);
-        const int total = row4 * ph;
-        for (int e = tid; e < total; e += BLOCK) {
-            const int r = e / row4, cc = e - r * row4;
-            dst[e] = vmap[(size_t)r * p.W * C4 + cc];
-        }
-    }
-    __syncthreads();
-
-    // ---- accumulate: no further barriers ----
-    const int npass = (MODE == EPRECON_BP_VARIANCE) ? 2 : 1;
-#pragma unroll
-    for (int k = 0; k < IPT; ++k) {
-        const int w = tid + k * BLOCK;
-        if (w >= nloc * QT) break;
-        const int r = w / QT, q = w - r * QT;
-        const int t = sSlot[r];
-        const uint32_t vm = sVis[t];
-        const float den = (float)max(__popc(vm), 1);
-        const bool same_batch = sBatch[t] == pb;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), sq = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int pass = 0; pass < npass; ++pass) {
-            for (int v = 0; v < p.V; ++v) {
-                if (!((vm >> v) & 1u)) continue;
-                const float2 px = sPix[t * p.V + v];
-                const float x0f = fminf(floorf(px.x), wm1 - 1.0f), y0f = fminf(floorf(px.y), hm1 - 1.0f);
-                const float wx1 = px.x - x0f, wx0 = (x0f + 1.0f) - px.x;
-                const float wy1 = px.y - y0f, wy0 = (y0f + 1.0f) - px.y;
-                const int x0 = (int)x0f, y0 = (int)y0f;
-                float4 a, b, cc, d;
-                if (((staged_mask >> v) & 1u) && same_batch) {
-                    const int bx0 = sBox[4 * v + 0], by0 = sBox[4 * v + 2];
-                    const int row4 = (sBox[4 * v + 1] - bx0 + 2) * C4;
-                    const float4 *q0 = sPatch + v * (kPatchFloats / 4) + (y0 - by0) * row4 + (x0 - bx0) * C4 + q;
-                    a = q0[0]; b = q0[C4]; cc = q0[row4]; d = q0[row4 + C4];
-                } else {
-                    const float4 *q0 = maps + ((size_t)v * p.batch + sBatch[t]) * map4 + ((size_t)y0 * p.W + x0) * C4 + q;
-                    a = q0[0]; b = q0[C4]; cc = q0[(size_t)p.W * C4]; d = q0[(size_t)p.W * C4 + C4];
-                }
-                const float w00 = wx0 * wy0, w10 = wx1 * wy0, w01 = wx0 * wy1, w11 = wx1 * wy1;
-                float4 s;
-                s.x = fmaf(d.x, w11, fmaf(cc.x, w01, fmaf(b.x, w10, a.x * w00)));
-                s.y = fmaf(d.y, w11, fmaf(cc.y, w01, fmaf(b.y, w10, a.y * w00)));
-                s.z = fmaf(d.z, w11, fmaf(cc.z, w01, fmaf(b.z, w10, a.z * w00)));
-                s.w = fmaf(d.w, w11, fmaf(cc.w, w01, fmaf(b.w, w10, a.w * w00)));
-                if (pass == 0) {
-                    acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
-                } else {  // variance: acc holds the mean now
-                    const float dx = s.x - acc.x, dy = s.y - acc.y, dz = s.z - acc.z, dw = s.w - acc.w;
-                    sq.x = fmaf(dx, dx, sq.x); sq.y = fmaf(dy, dy, sq.y);
-                    sq.z = fmaf(dz, dz, sq.z); sq.w = fmaf(dw, dw, sq.w);
-                }
-            }
-            if (pass == 0)
-                acc = make_float4(__fdiv_rn(acc.x, den), __fdiv_rn(acc.y, den), __fdiv_rn(acc.z, den), __fdiv_rn(acc.w, den));
-        }
-        const int orow = sOut[t];
-        float4 res = acc;
-        if (MODE == EPRECON_BP_VARIANCE) {
-            res = make_float4(__fdiv_rn(sq.x, den), __fdiv_rn(sq.y, den), __fdiv_rn(sq.z, den), __fdiv_rn(sq.w, den));
-            if (p.out_mean) *reinterpret_cast<float4 *>(p.out_mean + (size_t)orow * p.C + q * 4) = acc;
-        }
-        float *dst = p.out_feats + (size_t)orow * cout + q * 4;
-        if (MODE != EPRECON_BP_MEAN_DEPTH) {
-            *reinterpret_cast<float4 *>(dst) = res;
-        } else {
-            dst[0] = res.x; dst[1] = res.y; dst[2] = res.z; dst[3] = res.w;
-        }
-    }
-}
-
-size_t gather_lds_patch_bytes(int V, int B)
-{
-    const size_t nP = ((size_t)V * B * 12 + 3) & ~(size_t)3;
-    return (size_t)V * kPatchFloats * 4 + (size_t)kLdsVox * V * 8 + nP * 4 + (size_t)kLdsVox * 4 * 4 + 4 * 32 * 4 +
-           (256 / kWave) * 4 + 16;
-}
-
-template <int MODE>
-int launch_gather_lds(const BpParams &p, hipStream_t st)
-{
-    const int ntile = (int)ceil_div(p.n, kLdsVox);
-    const size_t lds = gather_lds_patch_bytes(p.V, p.batch);
-    const dim3 grid(ntile), block(256);
-    switch (p.C / 4) {
-        case 6: hipLaunchKernelGGL((bp_gather_lds_kernel<MODE, 6>), grid, block, lds, st, p); break;    // C = 24
-        case 8: hipLaunchKernelGGL((bp_gather_lds_kernel<MODE, 8>), grid, block, lds, st, p); break;    // C = 32
-        case 10: hipLaunchKernelGGL((bp_gather_lds_kernel<MODE, 10>), grid, block, lds, st, p); break;  // C = 40
-        default: return EPRECON_ERR_UNSUPPORTED;
-    }
-    EP_LAUNCH_CHECK();
-    return EPRECON_OK;
-}
-
-bool gather_lds_supported(int C, int Cs) { return g_lds_enabled && Cs == C && (C == 24 || C == 32 || C == 40); }
-
-size_t gather8_lds_bytes(int V, int B)
-{
-    const size_t nP = ((size_t)V * B * 12 + 3) & ~(size_t)3;
-    return (size_t)128 * V * 20 + nP * 4 + (size_t)128 * 3 * 4 + (256 / kWave) * 4 + 16;
-}
-
-template <int MODE, bool SORTED>
-int launch_gather8(const BpParams &p, hipStream_t st)
-{
-    const int ntile = (int)ceil_div(p.n, 128);
-    const size_t lds = gather8_lds_bytes(p.V, p.batch);
-    const dim3 grid(ntile), block(256);
-    switch (p.C / 8) {
-        case 3: hipLaunchKernelGGL((bp_gather8_kernel<MODE, 3, SORTED>), grid, block, lds, st, p); break;   // C = 24
-        case 4: hipLaunchKernelGGL((bp_gather8_kernel<MODE, 4, SORTED>), grid, block, lds, st, p); break;   // C = 32
-        case 5: hipLaunchKernelGGL((bp_gather8_kernel<MODE, 5, SORTED>), grid, block, lds, st, p); break;   // C = 40
-        case 10: hipLaunchKernelGGL((bp_gather8_kernel<MODE, 10, SORTED>), grid, block, lds, st, p); break; // C = 80
-        default: return EPRECON_ERR_UNSUPPORTED;
-    }
-    EP_LAUNCH_CHECK();
-    return EPRECON_OK;
-}
-
-template <bool SORTED>
-int launch_gather8_mode(const BpParams &p, int mode, hipStream_t st)
-{
-    return mode == EPRECON_BP_MEAN ? launch_gather8<EPRECON_BP_MEAN, SORTED>(p, st)
-         : mode == EPRECON_BP_MEAN_DEPTH ? launch_gather8<EPRECON_BP_MEAN_DEPTH, SORTED>(p, st)
-                                         : launch_gather8<EPRECON_BP_VARIANCE, SORTED>(p, st);
-}
-
-bool gather8_supported(int C) { return g_gather8_enabled && (C == 24 || C == 32 || C == 40 || C == 80); }
-
 // ops/back_project.py:69-75 — per batch element: mu = mean(d[d>0]); sigma = ||d[d>0]-mu||_2 + 1e-5;
 // d_hat = (d-mu)/sigma, 0 where d <= 0.  One workgroup per batch element, three sweeps.
 __global__ __launch_bounds__(1024) void bp_depth_norm_kernel(float *out_feats, int cout,
@@ -1294,12 +737,12 @@ size_t gather_lds_bytes(int vox, int V, int B)
            (size_t)(256 / kWave) * 4 + 16;
 }
 
-template <int VOX, int MODE, bool SORTED = false>
+template <int VOX, int MODE>
 int launch_gather(const BpParams &p, int nblk, hipStream_t st)
 {
     const size_t lds = gather_lds_bytes(VOX, p.V, p.batch);
     const dim3 grid(nblk), block(256);
-#define EP_GATHER(VEC, QT) hipLaunchKernelGGL((bp_gather_kernel<VOX, MODE, VEC, QT, SORTED>), grid, block, lds, st, p)
+#define EP_GATHER(VEC, QT) hipLaunchKernelGGL((bp_gather_kernel<VOX, MODE, VEC, QT>), grid, block, lds, st, p)
     if (p.C % 4 == 0) {
         switch (p.C / 4) {
             case 6: EP_GATHER(4, 6); break;    // C = 24  (1/4-res level)
@@ -1371,12 +814,8 @@ size_t eprecon_back_project_workspace_bytes(int64_t n, int batch, int n_views, i
 {
     size_t bytes = ep::align_up((size_t)ep::ceil_div(n > 0 ? n : 1, 16) * sizeof(int32_t), 256);
     bytes += ep::align_up((size_t)ep::ceil_div(n > 0 ? n : 1, 256) * (batch > 0 ? batch : 1) * sizeof(int32_t), 256);
-    // brick-sorted pipeline: flag / slot / perm (N ints each), histogram + bin offsets, scan scratch
-    bytes += 3 * ep::align_up((size_t)(n > 0 ? n : 1) * 4, 256) +
-             2 * ep::align_up((size_t)kBinsPerBatch * (batch > 0 ? batch : 1) * 4, 256) +
-             ep::align_up((size_t)ep::ceil_div((n > 0 ? n : 1), 2048) * 4 + 4096, 256);
     if (feats_layout == EPRECON_LAYOUT_NCHW)
-        bytes += ep::align_up((size_t)n_views * batch * 64 * ((channels + 63) / 64) * height * width * sizeof(float), 256);
+        bytes += ep::align_up((size_t)n_views * batch * channels * height * width * sizeof(float), 256);
     return bytes + 256;
 }
 
@@ -1446,9 +885,6 @@ int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *or
     read_tuning_env();
     int pix_stride = channels;
     if (feats_layout == EPRECON_LAYOUT_NCHW) {
-        // The re-layout is ours, so the pixel stride is too: a tap of C <= 32 channels is padded to one
-        // 128-byte cache line (the gather is bound by the number of lines a load instruction touches)
-        pix_stride = padded_stride(channels);
         float *tmp = reinterpret_cast<float *>(ws);
         const size_t lds_t = (size_t)channels * (kTrPix + 1) * sizeof(float);
         if (lds_t > 64 * 1024) return EPRECON_ERR_UNSUPPORTED;
@@ -1467,84 +903,17 @@ int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *or
     p.min_view = min_view; p.out_feats = out_feats; p.out_mean = out_mean; p.out_coords = out_coords;
     p.count = count; p.out_grid = out_grid; p.out_mask = out_mask; p.n_valid_dev = n_valid_dev;
     p.block_offsets = block_sums;
-    p.perm = nullptr;
-    p.slot = nullptr;
-
-    read_tuning_env();
-    // Long lists take the brick-sorted pipeline; short ones keep input-order tiles.
-    const bool sorted = n >= 192 * 1024 && batch <= 8 && g_sorted_enabled;
-    if (sorted) {
-        // brick edge (finest-voxel units, power of two) sized so that a brick projects to ~8 px:
-        // focal length ~ 0.45 * W pixels, typical depth 2 m  ->  edge ~ 36 / (W * voxel_size) units;
-        // one full brick (64 voxels) is one gather tile of the LDS-patch kernel
-        int brick_shift = 0;
-        while ((2 << brick_shift) <= 35.6f / ((float)width * voxel_size) && brick_shift < 6) ++brick_shift;
-        const size_t segN = ep::align_up((size_t)n * 4, 256);
-        const int nbins = kBinsPerBatch * batch;
-        const size_t segB = ep::align_up((size_t)nbins * 4, 256);
-        int32_t *flag = reinterpret_cast<int32_t *>(ws);
-        int32_t *slot = reinterpret_cast<int32_t *>(ws + segN);
-        int32_t *perm = reinterpret_cast<int32_t *>(ws + 2 * segN);
-        int32_t *hist = reinterpret_cast<int32_t *>(ws + 3 * segN);
-        int32_t *binoff = reinterpret_cast<int32_t *>(ws + 3 * segN + segB);
-        int32_t *scratch = reinterpret_cast<int32_t *>(ws + 3 * segN + 2 * segB);
-        EP_HIP_CHECK(hipMemsetAsync(hist, 0, segB, st));
-        const int nblk_count = (int)ep::ceil_div(n, 256);
-        const size_t lds_count = ((size_t)n_views * batch * 12 + batch) * 4 + 16;
-        hipLaunchKernelGGL(bp_count_sorted_kernel, dim3(nblk_count), dim3(256), lds_count, st, p, brick_shift, flag, hist);
-        EP_LAUNCH_CHECK();
-        int rcs = ep::exclusive_scan_i32(flag, (int)n, slot, scratch, n_valid_dev, st);
-        if (rcs != EPRECON_OK) return rcs;
-        rcs = ep::exclusive_scan_i32(hist, nbins, binoff, scratch, nullptr, st);
-        if (rcs != EPRECON_OK) return rcs;
-        EP_HIP_CHECK(hipMemsetAsync(hist, 0, segB, st));  // reused as the per-bin cursor
-        hipLaunchKernelGGL(bp_bin_fill_kernel, dim3(nblk_count), dim3(256), 0, st,
-                           reinterpret_cast<const int4 *>(coords), (int)n, batch, brick_shift,
-                           (const int32_t *)binoff, hist, perm, (int32_t *)nullptr);
-        EP_LAUNCH_CHECK();
-        p.perm = perm;
-        p.slot = slot;
-        const int ntile = (int)ep::ceil_div(n, 256);
-        const bool prof = g_prof.on && g_prof.start;
-        if (prof) EP_HIP_CHECK(hipEventRecord(g_prof.start, st));
-        int rc;
-        if (gather_lds_supported(channels, p.Cs))
-            rc = mode == EPRECON_BP_MEAN ? launch_gather_lds<EPRECON_BP_MEAN>(p, st)
-               : mode == EPRECON_BP_MEAN_DEPTH ? launch_gather_lds<EPRECON_BP_MEAN_DEPTH>(p, st)
-                                               : launch_gather_lds<EPRECON_BP_VARIANCE>(p, st);
-        else if (gather8_supported(channels))
-            rc = launch_gather8_mode<true>(p, mode, st);
-        else
-            rc = mode == EPRECON_BP_MEAN ? launch_gather<256, EPRECON_BP_MEAN, true>(p, ntile, st)
-               : mode == EPRECON_BP_MEAN_DEPTH ? launch_gather<256, EPRECON_BP_MEAN_DEPTH, true>(p, ntile, st)
-                                               : launch_gather<256, EPRECON_BP_VARIANCE, true>(p, ntile, st);
-        if (rc != EPRECON_OK) return rc;
-        if (prof) {
-            EP_HIP_CHECK(hipEventRecord(g_prof.stop, st));
-            g_prof.recorded = true;
-            if (g_prof.one_shot) g_prof.on = false;
-        }
-        if (mode == EPRECON_BP_MEAN_DEPTH) {
-            hipLaunchKernelGGL(bp_depth_norm_kernel, dim3(batch), dim3(1024), 0, st, out_feats, channels + 1,
-                               n_valid_dev);
-            EP_LAUNCH_CHECK();
-        }
-        return EPRECON_OK;
-    }
 
     // Tile = voxels handed to one 256-thread workgroup of the gather kernel.  Short lists get
     // small tiles so that the launch still covers the 256 CUs with several waves each
     // (13,824 voxels -> 864 workgroups of 16; 110,592 -> 1,728 of 64).
-    const bool use8 = n >= 48 * 1024 && gather8_supported(channels);
-    const int vox = use8 ? 128 : (n >= 512 * 1024 ? 256 : (n >= 48 * 1024 ? 64 : 16));
+    const int vox = n >= 512 * 1024 ? 256 : (n >= 48 * 1024 ? 64 : 16);
     const int ntile = (int)ep::ceil_div(n, vox);
     const int nblk_count = (int)ep::ceil_div(n, 256);
     const size_t lds_count = ((size_t)n_views * batch * 12 + batch + 256 / ep::kWave) * 4 + 16;
     int32_t *bb = batch > 1 ? blk_batch : nullptr;
     if (vox == 256)
         hipLaunchKernelGGL((bp_count_kernel<256>), dim3(nblk_count), dim3(256), lds_count, st, p, block_sums, bb);
-    else if (vox == 128)
-        hipLaunchKernelGGL((bp_count_kernel<128>), dim3(nblk_count), dim3(256), lds_count, st, p, block_sums, bb);
     else if (vox == 64)
         hipLaunchKernelGGL((bp_count_kernel<64>), dim3(nblk_count), dim3(256), lds_count, st, p, block_sums, bb);
     else
@@ -1565,8 +934,7 @@ int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *or
     rc = mode == EPRECON_BP_MEAN ? launch_gather_mlp<VOX, EPRECON_BP_MEAN>(p, ntile, st)               \
        : mode == EPRECON_BP_MEAN_DEPTH ? launch_gather_mlp<VOX, EPRECON_BP_MEAN_DEPTH>(p, ntile, st)   \
                                        : launch_gather_mlp<VOX, EPRECON_BP_VARIANCE>(p, ntile, st)
-    if (use8) { rc = launch_gather8_mode<false>(p, mode, st); }
-    else if (gather_mlp_supported(p)) {
+    if (gather_mlp_supported(p)) {
         if (vox == 256) { EP_MODE_DISPATCH_MLP(256); }
         else if (vox == 64) { EP_MODE_DISPATCH_MLP(64); }
         else { EP_MODE_DISPATCH_MLP(16); }

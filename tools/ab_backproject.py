@@ -16,5 +16,5 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(30):
     run(); g.append(lib.eprecon_profile_gather_ms())
 torch.cuda.synchronize()
-print(f"mlp={os.environ.get('EPRECON_BP_MLP','3')} sorted={os.environ.get('EPRECON_BP_SORTED','0')} gather8={os.environ.get('EPRECON_BP_GATHER8','0')} lvl={lvl}: "
+print(f"mlp={os.environ.get('EPRECON_BP_MLP','1')} lvl={lvl}: "
       f"op {(time.perf_counter()-t0)/30*1e3:.3f} ms, gather kernel {sum(g)/len(g)*1e3:.1f} us")
