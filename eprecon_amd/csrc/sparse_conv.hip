@@ -370,6 +370,11 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvParams p)
                 if (VEC4) {
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (j >= 0 && c < p.Cin) v = *reinterpret_cast<const float4 *>(xrow + c);
+                    if (p.Cin & 3) {  // ragged channel count: whatever follows the row's last channel is not input
+                        if (c + 1 >= p.Cin) v.y = 0.0f;
+                        if (c + 2 >= p.Cin) v.z = 0.0f;
+                        if (c + 3 >= p.Cin) v.w = 0.0f;
+                    }
                     a[ch][0] = v.x; a[ch][1] = v.y; a[ch][2] = v.z; a[ch][3] = v.w;
                 } else {
 #pragma unroll
@@ -435,6 +440,11 @@ __device__ __forceinline__ void gather_rows(const ConvParams &p, int j, int half
         if (VEC4) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (j >= 0 && c < p.Cin) v = *reinterpret_cast<const float4 *>(xrow + c);
+            if (p.Cin & 3) {
+                if (c + 1 >= p.Cin) v.y = 0.0f;
+                if (c + 2 >= p.Cin) v.z = 0.0f;
+                if (c + 3 >= p.Cin) v.w = 0.0f;
+            }
             a.v[ch][0] = v.x; a.v[ch][1] = v.y; a.v[ch][2] = v.z; a.v[ch][3] = v.w;
         } else {
 #pragma unroll
@@ -600,7 +610,10 @@ int launch_conv(const ConvParams &p, bool vec4, hipStream_t st)
 
 int conv_dispatch(ConvParams &p, int64_t n_in, hipStream_t st)
 {
-    const bool vec4 = (p.Cin % 4 == 0) && (p.ld_x % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
+    // 16-byte gathers need aligned rows; a channel count that is not a multiple of 4 is fine as long as the
+    // row pitch covers the rounded-up count (the tail lanes are zeroed after the load)
+    const bool vec4 = (p.ld_x % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0) &&
+                      (p.Cin % 4 == 0 || p.ld_x >= ((p.Cin + 3) & ~3));
     // Output columns per workgroup: all of them (<= 128) when the row tiles alone fill the chip,
     // 32-column blocks over blockIdx.y for short lists (10,800 pixels of the 1/16 maps are 85 row
     // tiles for 256 CUs; the gathered rows are re-read from L2 by each column block).

@@ -41,7 +41,10 @@ def _segment_mean(feat, lists, m, out=None):
     offsets, order = lists
     c = feat.shape[1]
     if out is None:
-        out = torch.empty((m, c), dtype=torch.float32, device=feat.device)
+        # row pitch rounded up to 4 floats: the convolution that consumes these rows can then gather with
+        # 16-byte loads even for the ragged channel counts of the SPVCNN stems (81 / 139 / 75 / 51)
+        cp = (c + 3) & ~3
+        out = torch.empty((m, cp), dtype=torch.float32, device=feat.device)[:, :c]
     _lib.check(lib.eprecon_segment_mean_async(_lib.ptr(feat), feat.stride(0), _lib.ptr(offsets),
                                               _lib.ptr(order), m, c, _lib.ptr(out), out.stride(0),
                                               _lib.current_stream()), "eprecon_segment_mean_async")

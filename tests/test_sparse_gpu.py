@@ -170,3 +170,22 @@ def test_sparse_conv_with_fused_layernorm(cin, cout, k):
     ref = OS.layernorm_rows(y, g, be, 1e-5, res, True, False)
     assert np.abs(out.cpu().numpy() - ref).max() < TOL
     assert not wide[:, :4].any() and not wide[:, 4 + cout:].any()
+
+
+@pytest.mark.parametrize("cin,cout", [(81, 32), (139, 96), (75, 48), (51, 24), (5, 8)])
+def test_sparse_conv_ragged_channels_with_padded_pitch(cin, cout):
+    """SPVCNN stem channel counts: rows with a pitch rounded up to 4 floats take the 16-byte gather path;
+    whatever sits in the pad lanes (here NaN) must not reach the result"""
+    from eprecon_amd.sparse import VoxelSet, sparse_conv
+    rng = np.random.default_rng(cin + cout)
+    c = random_coords(rng, 2500, extent=8, batch=1)
+    x = rng.standard_normal((len(c), cin)).astype(np.float32)
+    w = (rng.standard_normal((27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    vs = VoxelSet(dev(c))
+    cp = (cin + 3) & ~3
+    buf = torch.full((len(c), cp), float("nan"), device="cuda")
+    buf[:, :cin] = dev(x)
+    got = sparse_conv(buf[:, :cin], dev(w), vs.kernel_map(3), dev(b)).cpu().numpy()
+    ref = OS.sparse_conv(x, OS.kernel_map(c, c, 3, 1), w, b)
+    assert np.isfinite(got).all() and np.abs(got - ref).max() < TOL
