@@ -39,6 +39,7 @@ SIGNATURES = {
     "eprecon_sparse_conv_fused_async": (_i, [_vp, _i64, _i, _vp, _i, _i64, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i,
                                              _vp, _vp]),
     "eprecon_conv_desc_async": (_i, [_vp, _vp]),
+    "eprecon_conv_desc_partial_rows": (_i64, [_vp]),
     "eprecon_batchnorm_finalize_affine_async": (_i, [_vp, _i64, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "eprecon_affine_rows_async": (_i, [_vp, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "eprecon_pixel_map_async": (_i, [_i, _i, _i, _i, _vp, _vp]),
@@ -138,7 +139,8 @@ class ConvDesc(ctypes.Structure):
                 ("bn_gamma", ctypes.c_void_p), ("bn_beta", ctypes.c_void_p), ("bn_eps", ctypes.c_float),
                 ("bn_ticket", ctypes.c_void_p),
                 ("ln", ctypes.c_int), ("ln_gamma", ctypes.c_void_p), ("ln_beta", ctypes.c_void_p),
-                ("ln_eps", ctypes.c_float), ("ln_post_relu", ctypes.c_int)]
+                ("ln_eps", ctypes.c_float), ("ln_post_relu", ctypes.c_int),
+                ("img_h", ctypes.c_int), ("img_w", ctypes.c_int), ("img_maps", ctypes.c_int)]
 
 
 _WORKSPACES = {}

@@ -136,7 +136,6 @@ def conv_bn_launch(w, bias, gamma, beta, eps, k, x, grid, out=None, aff=None, re
     if aff is None:
         a = torch.empty((2, cout), dtype=torch.float32, device=dev)
         aff = (a[0], a[1])
-    partial = torch.empty(((n + 127) // 128, 3, cout), dtype=torch.float32, device=dev)
     fused_finalize = _FUSED_FINALIZE and ticket_owner is not None
     ticket = None
     if fused_finalize:
@@ -155,6 +154,10 @@ def conv_bn_launch(w, bias, gamma, beta, eps, k, x, grid, out=None, aff=None, re
     d.out, d.ld_out = out.data_ptr(), out.stride(0)
     d.relu, d.accumulate = int(pre_relu), 0
     d.in_scale, d.in_shift, d.in_relu = _dptr(x.scale), _dptr(x.shift), int(x.relu)
+    if k == 3 and not fused_finalize:
+        d.img_h, d.img_w, d.img_maps = grid.height, grid.width, grid.maps  # narrow layers: image-tile kernel
+    # the summaries are per workgroup: 128-row blocks (gather forms) or image tiles (tile kernel)
+    partial = torch.empty((lib.eprecon_conv_desc_partial_rows(ctypes.byref(d)), 3, cout), dtype=torch.float32, device=dev)
     d.bn_partial = partial.data_ptr()
     if fused_finalize:
         d.bn_scale_out, d.bn_shift_out = aff[0].data_ptr(), aff[1].data_ptr()

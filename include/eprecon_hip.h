@@ -219,8 +219,15 @@ typedef struct eprecon_conv_desc {
      * blocks of models/modules.py:447-452,473-482, models/occupancy_initialization.py:141-169):
      * out = [relu]( LN(v) * ln_gamma + ln_beta ); cout <= 128, excludes bn_partial / accumulate */
     int ln; const float *ln_gamma; const float *ln_beta; float ln_eps; int ln_post_relu;
+    /* dense 2D 3x3 'same' convolution over img_maps images of img_h x img_w pixel rows (kvol == 9,
+     * n_out == img_maps * img_h * img_w): narrow layers then run as an implicit GEMM on image tiles
+     * (halo tile + all nine weight matrices in LDS, no kernel map); nbr is still required as the
+     * fallback for shapes the tile kernel does not take */
+    int img_h; int img_w; int img_maps;
 } eprecon_conv_desc;
 int eprecon_conv_desc_async(const eprecon_conv_desc *desc, void *stream);
+/* number of bn_partial rows the launch described by desc writes (nblk of the finalize call) */
+int64_t eprecon_conv_desc_partial_rows(const eprecon_conv_desc *desc);
 /* producer-side summaries partial f32[nblk][3][channels] -> the BatchNorm in affine form (the
  * separate-launch alternative to bn_ticket: no cross-workgroup synchronisation inside the convolution) */
 int eprecon_batchnorm_finalize_affine_async(const float *partial, int64_t nblk, int channels, const float *gamma,
