@@ -108,3 +108,31 @@ def test_feat_fusion_rows_matches_modules(monkeypatch):
         ref = net.feat_fusion_pre(f1, f2, f4)
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("cin,cmid,cout", [(12, 12, 12), (24, 12, 20), (40, 40, 40), (20, 36, 8), (32, 32, 32)])
+def test_tile_kernel_chain_with_ragged_tiles(cin, cmid, cout):
+    """image-tile kernel (3x3, narrow layers, >= 256 tiles): 50 x 70 images leave partial tiles in both
+    directions; two chained layers exercise the pending-BatchNorm-on-load prologue, the second one with a
+    residual; C_in = 40 takes the > 64 KB dynamic-LDS instantiation"""
+    from eprecon_amd import dense2d as D2
+    from eprecon_amd.modules import Conv2d_Block, Conv2d_Residual_Block
+    torch.manual_seed(cin * 100 + cout)
+    dev = _dev()
+    v, h, w = 9, 50, 70
+    a = Conv2d_Block(cin, cmid, 3).to(dev).train()
+    b = Conv2d_Block(cmid, cout, 3).to(dev).train()
+    r = Conv2d_Residual_Block(cout, 3).to(dev).train()
+    for m in (a, b, r):
+        for prm in m.parameters():
+            if prm.dim() == 1:
+                prm.data.uniform_(0.5, 1.5)
+    x = torch.randn(v, cin, h, w, device=dev)
+    g = D2.PixelGrid.get(v, h, w, dev)
+    with torch.no_grad():
+        ref = r(b(a(x)))
+        act = a.run_act(D2.Act(D2.rows_of(_cl(x))), g)
+        act = b.run_act(act, g)
+        act = r.run_act(act, g)
+        got = D2.maps_of(D2.materialize(act), v, h, w)
+    assert (got - ref).abs().max().item() < TOL
