@@ -114,19 +114,18 @@ class Occupancy_Initialization(nn.Module):
             a = blk.run_act(a, g2)
         return D2.maps_of(D2.materialize(a), g2.maps, g2.height, g2.width)
 
-    def _fusion_graphed(self, f1, f2, f4):
+    def _fusion_graphed(self, views):
         """feat_fusion_pre through a captured HIP graph (inference only; the result buffer is reused
-        by the next call, the caller consumes it immediately)"""
-        key = (tuple(f1.shape), tuple(f2.shape), tuple(f4.shape), f1.device)
+        by the next call, the caller consumes it immediately).  `views`: three lists (1/16, 1/8, 1/4 level)
+        of the per-view [C,h,w] maps; they are stacked straight into the graph's input buffers."""
+        key = tuple(tuple(v[0].shape) + (len(v),) for v in views) + (views[0][0].device,)
         entry = self._graphs.get(key)
         if entry is None:
-            static_in = [torch.empty_like(t) for t in (f1, f2, f4)]
-            for s_, t in zip(static_in, (f1, f2, f4)):
-                s_.copy_(t)
+            static_in = [torch.stack(v) for v in views]
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                for _ in range(3):  # MIOpen solver selection happens outside the capture
+                for _ in range(3):  # first-use work (kernel maps, packed weights) happens outside the capture
                     self.feat_fusion_pre(*static_in)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
@@ -135,8 +134,8 @@ class Occupancy_Initialization(nn.Module):
             entry = (graph, static_in, static_out)
             self._graphs[key] = entry
         graph, static_in, static_out = entry
-        for s_, t in zip(static_in, (f1, f2, f4)):
-            s_.copy_(t)
+        for s_, v in zip(static_in, views):
+            torch.stack(v, out=s_)
         graph.replay()
         return static_out
 
@@ -150,17 +149,19 @@ class Occupancy_Initialization(nn.Module):
         return self.norm4.run(y, out=y)
 
     def forward(self, coords, origin, voxel_size, features_all, KRcam, shape, stage, min_view_number):
-        feats_1x = torch.stack([f[2] for f in features_all])  # [V,B,80,h,w]   1/16
-        feats_2x = torch.stack([f[1] for f in features_all])  # [V,B,40,2h,2w] 1/8
-        feats_4x = torch.stack([f[0] for f in features_all])  # [V,B,24,4h,4w] 1/4
-        bs = feats_1x.shape[1]
-        graphed = self.use_hip_graph and not torch.is_grad_enabled() and feats_1x.is_cuda
-        fuse = self._fusion_graphed if graphed else self.feat_fusion_pre
-        if bs == 1:
-            fused = fuse(feats_1x[:, 0], feats_2x[:, 0], feats_4x[:, 0]).unsqueeze(1)  # [V,1,32,H,W] view
-        else:
-            fused = torch.stack([fuse(feats_1x[:, b].contiguous(), feats_2x[:, b].contiguous(),
-                                      feats_4x[:, b].contiguous()).clone() for b in range(bs)], dim=1)
+        bs = features_all[0][0].shape[0]
+        dev = features_all[0][0].device
+        graphed = self.use_hip_graph and not torch.is_grad_enabled() and dev.type == "cuda"
+        per_batch = []
+        for b in range(bs):
+            # per-view maps of batch element b: 1/16 [80,h,w], 1/8 [40,2h,2w], 1/4 [24,4h,4w]
+            views = [[f[l][b] for f in features_all] for l in (2, 1, 0)]
+            if graphed:
+                fused_b = self._fusion_graphed(views)
+                per_batch.append(fused_b if bs == 1 else fused_b.clone())
+            else:
+                per_batch.append(self.feat_fusion_pre(*[torch.stack(v) for v in views]))
+        fused = per_batch[0].unsqueeze(1) if bs == 1 else torch.stack(per_batch, dim=1)  # [V,B,32,H,W]
         res = BP.view_variance(coords, origin, voxel_size, fused, KRcam, min_view_number,
                                min_valid=INIT_MIN_VALID)
         if res is None:

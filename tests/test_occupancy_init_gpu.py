@@ -99,7 +99,8 @@ def test_hip_dense_path_matches_pytorch_path():
     with torch.no_grad():
         got = net.feat_fusion_pre(f1, f2, f4)
         assert got.is_contiguous(memory_format=torch.channels_last)
-        graphed = net._fusion_graphed(f1, f2, f4).clone()
-        graphed2 = net._fusion_graphed(f1, f2, f4)
+        views = [list(t.unbind(0)) for t in (f1, f2, f4)]
+        graphed = net._fusion_graphed(views).clone()
+        graphed2 = net._fusion_graphed(views)
     assert (got - ref).abs().max().item() < 2e-4
     assert (graphed - ref).abs().max().item() < 2e-4 and torch.equal(graphed, graphed2)

@@ -26,7 +26,8 @@ with torch.no_grad():
     f1 = torch.stack([v[2][0] for v in f]); f2 = torch.stack([v[1][0] for v in f]); f4 = torch.stack([v[0][0] for v in f])
     t, fused = timed(lambda: net.feat_fusion_pre(f1, f2, f4))
     print(f"feat_fusion_pre (direct launches)   {t:7.3f} ms")
-    t, fused = timed(lambda: net._fusion_graphed(f1, f2, f4))
+    views = [list(t_.unbind(0)) for t_ in (f1, f2, f4)]
+    t, fused = timed(lambda: net._fusion_graphed(views))
     print(f"feat_fusion_pre (HIP graph replay)  {t:7.3f} ms")
     fused5 = fused.unsqueeze(1).contiguous()
     t, res = timed(lambda: BP.view_variance(step.coords[2], step.origin, 0.04, fused5, step.krcam[1], 2))
