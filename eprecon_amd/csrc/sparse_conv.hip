@@ -63,6 +63,9 @@ struct ConvParams {
     // dense 2D 'same' 3x3 convolution over [maps][img_h][img_w] pixel rows (K == 9): lets narrow layers run
     // on conv2d_tile_kernel, which needs no kernel map
     int img_h, img_w, img_maps;
+    // the caller sizes bn_partial with eprecon_conv_desc_partial_rows (descriptor entry point), so kernels whose
+    // workgroups do not cover 128 rows may be chosen
+    int flex_partial;
 };
 
 // Stage `rows` x TN weights (zero padded) from w[row0 + r][0:ncols] (row stride `stride`, rows valid
@@ -790,6 +793,179 @@ int launch_conv2d_tile(const ConvParams &p, hipStream_t st)
     return EPRECON_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Short lists with wide inputs (a few thousand voxels / the 10,800 pixels of the 1/16 maps, C_in > 64):
+// there are too few 128-row tiles to fill the chip, nothing overlaps, and the slab kernel's time is the
+// LENGTH of its dependent chain: K * ceil(C_in / 32) staged slabs, each a global round trip + barrier
+// (108 for a 27-offset 128-channel layer, ~130 us).  Here a workgroup owns 32 rows x 32 columns and its
+// four waves split the (offset, slab) list round-robin, each staging its own slabs into a wave-private LDS
+// buffer (no workgroup barrier in the loop); the four partial accumulators are summed in fixed order
+// through LDS at the end.  4x the workgroups, 1/4 of the chain.
+// ---------------------------------------------------------------------------------------------
+template <bool VEC4>
+__global__ __launch_bounds__(256) void spconv_splitk_kernel(ConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TN = 32;
+    float *sW = reinterpret_cast<float *>(smem);                  // [4 waves][32][32] wave-private weight slabs
+    float *sRed = sW;                                             // overlay after the loop: [3][16][64] partial accumulators
+    int *sNbr = reinterpret_cast<int *>(sW + kWaves * 32 * TN);   // [K][32]
+    int *sActive = sNbr + p.K * 32;                               // [K]
+    const int cinA = (p.Cin + 3) & ~3;
+    float *sAff = reinterpret_cast<float *>(sActive + ((p.K + 3) & ~3));  // [2][cinA]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, half = lane >> 5;
+    const int row0 = blockIdx.x * 32;
+    const int col0 = blockIdx.y * TN;
+
+    for (int k = tid; k < p.K; k += 256) sActive[k] = 0;
+    if (p.in_scale)
+        for (int c = tid; c < cinA; c += 256) {
+            sAff[c] = c < p.Cin ? p.in_scale[c] : 0.0f;
+            sAff[cinA + c] = c < p.Cin ? p.in_shift[c] : 0.0f;
+        }
+    __syncthreads();
+    for (int e = tid; e < p.K * 32; e += 256) {
+        const int k = e >> 5, r = e & 31;
+        const int row = row0 + r;
+        int j = -1;
+        if (row < p.n_out) j = p.nbr ? p.nbr[(size_t)k * p.n_out + row] : row;
+        sNbr[e] = j;
+        if (j >= 0) sActive[k] = 1;  // benign race: every writer stores 1
+    }
+    __syncthreads();
+
+    f32x16 acc[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
+
+    const int nslab = (p.Cin + 31) / 32;
+    float *myW = sW + wave * 32 * TN;
+    int stage = 0;  // counts (live offset, slab) pairs; this wave takes those with stage % 4 == wave
+    for (int k = 0; k < p.K; ++k) {
+        if (!sActive[k]) continue;  // block-uniform
+        const int j = sNbr[k * 32 + r32];
+        const float *xrow = p.x + (size_t)(j >= 0 ? j : 0) * p.ld_x;
+        const float *wk = p.w + (size_t)k * p.Cin * p.Cout + col0;
+        for (int sl = 0; sl < nslab; ++sl, ++stage) {
+            if ((stage & 3) != wave) continue;  // wave-uniform
+            const int c0 = sl * 32;
+            // ---- this wave's weight slab W[k][c0 : c0+32][col0 : col0+32] -> its private LDS buffer ----
+            {
+                const int ncols = p.Cout - col0;
+                const bool v4 = (p.Cout & 3) == 0 && (ncols & 3) == 0 && (reinterpret_cast<uintptr_t>(wk) & 15) == 0;
+                if (v4) {
+                    const int nq = min(ncols, TN) / 4;
+                    float4 w4[4];
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int e = lane + it * 64, r = e >> 3, q = e & 7;
+                        w4[it] = *reinterpret_cast<const float4 *>(wk + (size_t)min(c0 + r, p.Cin - 1) * p.Cout + 4 * min(q, nq - 1));
+                    }
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int e = lane + it * 64, r = e >> 3, q = e & 7;
+                        reinterpret_cast<float4 *>(myW)[e] = (c0 + r < p.Cin && q < nq) ? w4[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                } else {
+#pragma unroll 4
+                    for (int e = lane; e < 32 * TN; e += 64) {
+                        const int r = e >> 5, col = e & 31;
+                        const float v = wk[(size_t)min(c0 + r, p.Cin - 1) * p.Cout + min(col, ncols - 1)];
+                        myW[e] = (c0 + r < p.Cin && col < ncols) ? v : 0.0f;
+                    }
+                }
+            }
+            // ---- this lane's A values: 4 chunks of 8 channels, 4 floats each ----
+            float a[4][4];
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                const int c = c0 + ch * 8 + 4 * half;
+                if (VEC4) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (j >= 0 && c < p.Cin) v = *reinterpret_cast<const float4 *>(xrow + c);
+                    if (p.Cin & 3) {
+                        if (c + 1 >= p.Cin) v.y = 0.0f;
+                        if (c + 2 >= p.Cin) v.z = 0.0f;
+                        if (c + 3 >= p.Cin) v.w = 0.0f;
+                    }
+                    a[ch][0] = v.x; a[ch][1] = v.y; a[ch][2] = v.z; a[ch][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[ch][q] = (j >= 0 && c + q < p.Cin) ? xrow[c + q] : 0.0f;
+                }
+            }
+            if (p.in_scale) {
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    const int c = c0 + ch * 8 + 4 * half;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool ok = j >= 0 && c + q < p.Cin;
+                        float v = fmaf(a[ch][q], sAff[min(c + q, cinA - 1)], sAff[cinA + min(c + q, cinA - 1)]);
+                        if (p.in_relu) v = fmaxf(v, 0.0f);
+                        a[ch][q] = ok ? v : 0.0f;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();  // the slab stores above precede the loads below (same wave, LDS is in order)
+            const int nch = min(4, (p.Cin - c0 + 7) / 8);
+            for (int ch = 0; ch < nch; ++ch) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ch][q], myW[(ch * 8 + 4 * half + q) * TN + r32], acc[0], 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();  // the next stage overwrites myW
+        }
+    }
+    // ---- fixed-order sum of the four partial accumulators (waves 1..3 -> LDS, wave 0 adds them in order) ----
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sRed[((wave - 1) * 16 + r) * 64 + lane] = acc[0][r];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] += sRed[(w * 16 + r) * 64 + lane];
+    }
+    __syncthreads();  // sRed is read; the epilogue reuses the region for the BatchNorm summaries
+    // waves 1..3 hold no rows: an empty row map keeps them out of the stores and the statistics
+    const LinearRows rm{row0, wave == 0 ? p.n_out : 0};
+    conv_epilogue<1>(p, acc, rm, col0, r32, half, wave, sW, (int)blockIdx.x);
+}
+
+template <bool VEC4>
+int launch_splitk_v(const ConvParams &p, hipStream_t st)
+{
+    const dim3 grid((unsigned)ceil_div(p.n_out, 32), (unsigned)ceil_div(p.Cout, 32));
+    const size_t lds = (size_t)kWaves * 32 * 32 * sizeof(float) + (size_t)p.K * 32 * sizeof(int) +
+                       (size_t)((p.K + 3) & ~3) * sizeof(int) + (size_t)2 * ((p.Cin + 3) & ~3) * sizeof(float) + 16;
+    hipLaunchKernelGGL((spconv_splitk_kernel<VEC4>), grid, dim3(256), lds, st, p);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+// short list + long (offset, slab) chain + a caller that can take 32-row BatchNorm summary blocks
+bool splitk_ok(const ConvParams &p)
+{
+    static const bool on = !(getenv("EPRECON_CONV_SPLITK") && getenv("EPRECON_CONV_SPLITK")[0] == '0');
+    if (!on || p.accumulate || p.bn_scale_out) return false;
+    if (p.bn_partial && !p.flex_partial) return false;
+    const int nt_full = (p.Cout + 31) / 32;
+    if (p.ln && nt_full > 1) return false;
+    const int cin_pad = (p.Cin + 7) / 8 * 8;
+    const int64_t wg128 = ceil_div(p.n_out, kRowsPerBlock) * nt_full;
+    const int stages = p.K * ((p.Cin + 31) / 32);
+    return cin_pad > 64 && wg128 <= 256 && stages >= 8;
+}
+
 int conv_dispatch(ConvParams &p, int64_t n_in, hipStream_t st)
 {
     {
@@ -815,6 +991,7 @@ int conv_dispatch(ConvParams &p, int64_t n_in, hipStream_t st)
     const int nblk = (int)ceil_div(p.n_out, kRowsPerBlock);
     const int nt_full = (p.Cout + 31) / 32;
     if (p.ln && (nt_full > 4 || p.bn_partial || p.accumulate)) return EPRECON_ERR_UNSUPPORTED;
+    if (splitk_ok(p)) return vec4 ? launch_splitk_v<true>(p, st) : launch_splitk_v<false>(p, st);
     const bool split = nblk < 256 && nt_full > 1 && !p.ln;
     const int cin_pad = (p.Cin + 7) / 8 * 8;
     static const bool resident_on = !(getenv("EPRECON_CONV_RESIDENT") && getenv("EPRECON_CONV_RESIDENT")[0] == '0');
@@ -864,6 +1041,7 @@ static void params_from_desc(ConvParams &p, const eprecon_conv_desc *d)
     p.ln = d->ln; p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.ln_eps = d->ln_eps;
     p.ln_post_relu = d->ln_post_relu;
     p.img_h = d->img_h; p.img_w = d->img_w; p.img_maps = d->img_maps;
+    p.flex_partial = 1;
 }
 
 extern "C" int eprecon_conv_desc_async(const eprecon_conv_desc *d, void *stream)
@@ -886,6 +1064,7 @@ extern "C" int64_t eprecon_conv_desc_partial_rows(const eprecon_conv_desc *d)
     int nt, nch;
     int64_t blocks;
     if (conv2d_tile_ok(p, &nt, &nch, &blocks)) return blocks;
+    if (splitk_ok(p)) return ep::ceil_div(d->n_out, (int64_t)32);
     return ep::ceil_div(d->n_out, (int64_t)kRowsPerBlock);
 }
 
