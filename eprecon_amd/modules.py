@@ -322,6 +322,19 @@ class Fusion_Block(nn.Module):
         return D2.materialize(self.ELAN.run_act(a, grid), out=out)
 
 
+def _ln_rows(norm, y, residual=None, pre_relu=False, post_relu=False):
+    """[ReLU]( LayerNorm( [ReLU](y) [+ residual] ) ) for the heads: one HIP row-wise kernel on the GPU inference
+    path (in place on the Linear output), the PyTorch ops otherwise"""
+    if y.is_cuda and not torch.is_grad_enabled() and y.dim() == 2 and y.dtype == torch.float32 and y.is_contiguous() \
+            and (residual is None or (residual.is_contiguous() and residual.dtype == torch.float32)):
+        return SP.rowwise_layernorm(y, norm.weight, norm.bias, norm.eps, residual, pre_relu, post_relu, out=y)
+    t = F.relu(y) if pre_relu else y
+    if residual is not None:
+        t = t + residual
+    t = norm(t)
+    return F.relu(t) if post_relu else t
+
+
 class Linear4xTrans(nn.Module):
     """Linear(C,4C)-LN-ReLU, Linear(4C,C)-LN-ReLU, Linear(C,C_out) (+ skip when C == C_out)
     (models/modules.py:273-311); xavier-uniform weights, zero biases."""
@@ -340,8 +353,8 @@ class Linear4xTrans(nn.Module):
             nn.init.zeros_(lin.bias)
 
     def forward(self, x):
-        h = self.relu(self.norm1(self.linear1(x)))
-        h = self.relu(self.norm2(self.linear2(h)))
+        h = _ln_rows(self.norm1, self.linear1(x), post_relu=True)
+        h = _ln_rows(self.norm2, self.linear2(h), post_relu=True)
         y = self.linear3(h)
         return y + h if self.use_residual else y
 
@@ -356,7 +369,7 @@ class Linear_Residual(nn.Module):
         self.norm = nn.LayerNorm(dim)
 
     def forward(self, x):
-        return self.norm(x + self.activation(self.linear(x)))
+        return _ln_rows(self.norm, self.linear(x), residual=x, pre_relu=True)
 
 
 class Panoptic_Feat_Fusion(nn.Module):
