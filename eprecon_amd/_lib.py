@@ -55,7 +55,7 @@ SIGNATURES = {
     "eprecon_upsample_async": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "eprecon_aligned_coords_async": (_i, [_vp, _i64, _vp, _i, _f, _vp, _vp, _vp]),
     "eprecon_point_quantize_async": (_i, [_vp, _i64, _f, _vp, _vp, _vp]),
-    "eprecon_segment_workspace_bytes": (_sz, [_i64]),
+    "eprecon_segment_workspace_bytes": (_sz, [_i64, _i64]),
     "eprecon_segment_lists_async": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "eprecon_segment_mean_async": (_i, [_vp, _i, _vp, _vp, _i64, _i, _vp, _i, _vp]),
     "eprecon_trilinear_map_async": (_i, [_vp, _c.c_uint32, _vp, _i64, _i, _vp, _vp, _vp]),

@@ -63,20 +63,21 @@ __global__ void seg_fill_kernel(const int32_t *idx, int n, const int32_t *offset
     if (v < 0) return;
     order[offsets[v] + atomicAdd(&cursor[v], 1)] = i;
 }
-__global__ void seg_sort_kernel(const int32_t *offsets, int m, int32_t *order)
+// Rank sort of every voxel's point list, one thread per POINT: its slot is the number of points of the same
+// voxel with a smaller index.  (An insertion sort by one thread per voxel cost 60 us on average and far more at
+// the coarse strides, where a voxel holds up to 512 points: O(L^2) sequential steps.  Here the same
+// comparisons are spread over the L threads of the list, which only read.)
+__global__ void seg_rank_kernel(const int32_t *idx, int n, const int32_t *offsets, const int32_t *unsorted,
+                                int32_t *order)
 {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= m) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int v = idx[i];
+    if (v < 0) return;
     const int a = offsets[v], b = offsets[v + 1];
-    for (int i = a + 1; i < b; ++i) {  // insertion sort; lists are a handful of points long
-        const int key = order[i];
-        int j = i - 1;
-        while (j >= a && order[j] > key) {
-            order[j + 1] = order[j];
-            --j;
-        }
-        order[j + 1] = key;
-    }
+    int rank = 0;
+    for (int t = a; t < b; ++t) rank += unsorted[t] < i ? 1 : 0;
+    order[a + rank] = i;
 }
 
 // out[v, c] = mean over the points of voxel v (index order) of feat[p, c]
@@ -188,9 +189,10 @@ int eprecon_point_quantize_async(const float *points_xyzb, int64_t n, float reso
     return EPRECON_OK;
 }
 
-size_t eprecon_segment_workspace_bytes(int64_t m)
+size_t eprecon_segment_workspace_bytes(int64_t n, int64_t m)
 {
-    return align_up((size_t)(m > 0 ? m : 1) * 4, 256) * 2 + align_up((size_t)ceil_div(m > 0 ? m : 1, 2048) * 4, 256) + 256;
+    return align_up((size_t)(m > 0 ? m : 1) * 4, 256) * 2 + align_up((size_t)ceil_div(m > 0 ? m : 1, 2048) * 4, 256) +
+           align_up((size_t)(n > 0 ? n : 1) * 4, 256) + 256;
 }
 
 /* CSR lists: offsets int32[m+1], order int32[n] (first offsets[m] entries used) */
@@ -198,7 +200,7 @@ int eprecon_segment_lists_async(const int32_t *idx, int64_t n, int64_t m, int32_
                                 void *workspace, size_t workspace_bytes, void *stream)
 {
     if (n < 0 || m < 0 || !offsets || !workspace || (n > 0 && (!idx || !order))) return EPRECON_ERR_ARG;
-    if (workspace_bytes < eprecon_segment_workspace_bytes(m)) return EPRECON_ERR_WORKSPACE;
+    if (workspace_bytes < eprecon_segment_workspace_bytes(n, m)) return EPRECON_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (m == 0) {
         EP_HIP_CHECK(hipMemsetAsync(offsets, 0, sizeof(int32_t), st));
@@ -209,8 +211,9 @@ int eprecon_segment_lists_async(const int32_t *idx, int64_t n, int64_t m, int32_
     int32_t *counts = reinterpret_cast<int32_t *>(ws);
     int32_t *cursor = reinterpret_cast<int32_t *>(ws + seg);
     int32_t *scratch = reinterpret_cast<int32_t *>(ws + 2 * seg);
+    int32_t *unsorted = reinterpret_cast<int32_t *>(ws + 2 * seg + align_up((size_t)ceil_div(m, 2048) * 4, 256));
     EP_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * seg, st));
-    const dim3 gn((unsigned)ceil_div(n > 0 ? n : 1, 256)), gm((unsigned)ceil_div(m, 256)), blk(256);
+    const dim3 gn((unsigned)ceil_div(n > 0 ? n : 1, 256)), blk(256);
     if (n > 0) {
         hipLaunchKernelGGL(seg_count_kernel, gn, blk, 0, st, idx, (int)n, counts);
         EP_LAUNCH_CHECK();
@@ -218,12 +221,13 @@ int eprecon_segment_lists_async(const int32_t *idx, int64_t n, int64_t m, int32_
     int rc = ep::exclusive_scan_i32(counts, (int)m, offsets, scratch, offsets + m, st);
     if (rc != EPRECON_OK) return rc;
     if (n > 0) {
-        hipLaunchKernelGGL(seg_fill_kernel, gn, blk, 0, st, idx, (int)n, (const int32_t *)offsets, cursor, order);
+        hipLaunchKernelGGL(seg_fill_kernel, gn, blk, 0, st, idx, (int)n, (const int32_t *)offsets, cursor, unsorted);
+        EP_LAUNCH_CHECK();
+        // offsets[m] (grand total) was written by the scan
+        hipLaunchKernelGGL(seg_rank_kernel, gn, blk, 0, st, idx, (int)n, (const int32_t *)offsets,
+                           (const int32_t *)unsorted, order);
         EP_LAUNCH_CHECK();
     }
-    // offsets[m] (grand total) was written by the scan
-    hipLaunchKernelGGL(seg_sort_kernel, gm, blk, 0, st, (const int32_t *)offsets, (int)m, order);
-    EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }
 

@@ -29,7 +29,7 @@ def _segment_lists(idx, m):
     n, dev = idx.shape[0], idx.device
     offsets = torch.empty(m + 1, dtype=torch.int32, device=dev)
     order = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-    ws = _lib.workspace(lib.eprecon_segment_workspace_bytes(m), dev)
+    ws = _lib.workspace(lib.eprecon_segment_workspace_bytes(n, m), dev)
     _lib.check(lib.eprecon_segment_lists_async(_lib.ptr(idx), n, m, _lib.ptr(offsets), _lib.ptr(order),
                                                _lib.ptr(ws), ws.numel(), _lib.current_stream()),
                "eprecon_segment_lists_async")

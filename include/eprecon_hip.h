@@ -316,7 +316,7 @@ int eprecon_point_quantize_async(const float *points_xyzb, int64_t n, float reso
                                  int32_t *voxel_bxyz, void *stream);
 /* CSR lists of the points of each voxel: idx int32[n] in [-1, m) -> offsets int32[m+1],
  * order int32[n] (points of voxel v = order[offsets[v] : offsets[v+1]], ascending point index) */
-size_t eprecon_segment_workspace_bytes(int64_t m);
+size_t eprecon_segment_workspace_bytes(int64_t n, int64_t m);
 int eprecon_segment_lists_async(const int32_t *idx, int64_t n, int64_t m, int32_t *offsets, int32_t *order,
                                 void *workspace, size_t workspace_bytes, void *stream);
 /* out[v] = mean of feat[p] over the points p of voxel v (0 for empty voxels) — scatter-mean
