@@ -65,3 +65,23 @@ def test_operators_refuse_cpu_tensors():
     feats = torch.zeros((9, 1, 24, 8, 8))
     with pytest.raises(_lib.EpreconError):
         Back_Project(24)(coords, torch.zeros(1, 3), 0.04, feats, torch.eye(4).expand(9, 1, 4, 4), 0)
+
+
+def test_conv_desc_layout_matches_header(tmp_path):
+    """the ctypes mirror of eprecon_conv_desc has the size and field offsets the C compiler gives the header's
+    struct (a drift here would silently corrupt every fused convolution launch)"""
+    import ctypes
+    import subprocess
+    from eprecon_amd import _lib
+    fields = [f[0] for f in _lib.ConvDesc._fields_]
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "eprecon_hip.h"', 'int main(void) {',
+           '  printf("%zu\\n", sizeof(eprecon_conv_desc));']
+    src += [f'  printf("%zu\\n", offsetof(eprecon_conv_desc, {name}));' for name in fields]
+    src += ['  return 0;', '}']
+    c_file = tmp_path / "layout.c"
+    c_file.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c_file), "-o", str(exe)])
+    out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == ctypes.sizeof(_lib.ConvDesc)
+    assert out[1:] == [getattr(_lib.ConvDesc, name).offset for name in fields]
