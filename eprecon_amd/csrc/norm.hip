@@ -113,28 +113,33 @@ __global__ __launch_bounds__(256) void bn_finalize_affine_kernel(const float *pa
                                                                  const float *beta, float eps, float *scale_out,
                                                                  float *shift_out)
 {
-    __shared__ float sN[256], sMean[256], sM2[256];
+    // one workgroup per channel; fixed merge order: thread t takes rows t, t + 256, ...; lanes merge by
+    // xor-shuffles (lower lane first), the four wave results in wave order -- one barrier in total
+    __shared__ float sN[4], sMean[4], sM2[4];
     const int c = blockIdx.x, tid = threadIdx.x;
     float a_n = 0.0f, a_mean = 0.0f, a_m2 = 0.0f;
     for (int b = tid; b < nblk; b += 256) {
         const float *p = partial + (size_t)b * 3 * C;
         chan_merge(a_n, a_mean, a_m2, p[c], p[C + c], p[2 * C + c]);
     }
-    sN[tid] = a_n; sMean[tid] = a_mean; sM2[tid] = a_m2;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) {
-            float n = sN[tid], m = sMean[tid], q = sM2[tid];
-            chan_merge(n, m, q, sN[tid + s], sMean[tid + s], sM2[tid + s]);
-            sN[tid] = n; sMean[tid] = m; sM2[tid] = q;
-        }
-        __syncthreads();
+    const int lane = tid & 63;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const float on = __shfl_xor(a_n, m), om = __shfl_xor(a_mean, m), oq = __shfl_xor(a_m2, m);
+        // both partners compute the same (lower, upper) merge, so every lane ends with the same value
+        float ln = (lane & m) ? on : a_n, lm = (lane & m) ? om : a_mean, lq = (lane & m) ? oq : a_m2;
+        chan_merge(ln, lm, lq, (lane & m) ? a_n : on, (lane & m) ? a_mean : om, (lane & m) ? a_m2 : oq);
+        a_n = ln; a_mean = lm; a_m2 = lq;
     }
+    if (lane == 0) { sN[tid >> 6] = a_n; sMean[tid >> 6] = a_mean; sM2[tid >> 6] = a_m2; }
+    __syncthreads();
     if (tid == 0) {
-        const float var = sN[0] > 0.0f ? sM2[0] / sN[0] : 0.0f;  // biased variance
+        float n = sN[0], mean = sMean[0], m2 = sM2[0];
+        for (int w = 1; w < 4; ++w) chan_merge(n, mean, m2, sN[w], sMean[w], sM2[w]);
+        const float var = n > 0.0f ? m2 / n : 0.0f;  // biased variance
         const float sc = (gamma ? gamma[c] : 1.0f) / sqrtf(var + eps);
         scale_out[c] = sc;
-        shift_out[c] = (beta ? beta[c] : 0.0f) - sMean[0] * sc;
+        shift_out[c] = (beta ? beta[c] : 0.0f) - mean * sc;
     }
 }
 
