@@ -98,22 +98,22 @@ def cpu_baseline(step, seconds):
             "ms_per_step": dt / n * 1e3}
 
 
-def bench_cfg4(args, step, world, rank, dist):
+def bench_cfg4(args, step, world, rank, dist, use_dist=False):
     """extra measurement: whole-forward fragments/s (not the headline line; no roofline / cpu legs)"""
     import torch
     for _ in range(args.warmup):
         step.run()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step.run()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -124,7 +124,7 @@ def bench_cfg4(args, step, world, rank, dist):
                           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": step.describe(),
                           "last_fragment_voxels": n_out}), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
@@ -157,7 +157,7 @@ def main():
         from eprecon_amd.fragment_step import Cfg4Step
         # all ranks work on ONE scene (seed 0), fragments dealt round-robin, boundary voxels exchanged
         return bench_cfg4(args, Cfg4Step(seed=0, device=torch.device("cuda", local_rank), rank=rank, world=world),
-                          world, rank, dist)
+                          world, rank, dist, use_dist)
     step = Cfg2Step(seed=rank, device=torch.device("cuda", local_rank))
 
     def barrier():

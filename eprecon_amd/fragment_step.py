@@ -17,6 +17,8 @@ SURVEY.md section 8d:
 Inputs (both backbones' feature pyramids, projection matrices, voxel lists) are device-resident
 before run() is called; weights are seeded random (no checkpoint exists in this environment).
 """
+import os
+
 import torch
 
 from . import _lib
@@ -148,7 +150,8 @@ class Cfg4Step:
             self.frags.append((S.to_device(f1, self.device), S.to_device(f2, self.device),
                                S.to_device(inp, self.device)))
         calibrate_occupancy_heads(self.net, *self.frags[0])
-        self.net.distributed_exchange = world > 1
+        # EPRECON_FORCE_EXCHANGE=1: run the boundary all-gather even at world size 1 (exercises the RCCL path on one GPU)
+        self.net.distributed_exchange = world > 1 or os.environ.get("EPRECON_FORCE_EXCHANGE", "0") == "1"
         self.k = 0
         self.last = None
 
