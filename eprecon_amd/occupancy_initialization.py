@@ -129,7 +129,8 @@ class Occupancy_Initialization(nn.Module):
                     self.feat_fusion_pre(*static_in)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: the RCCL watchdog thread of a multi-GPU run may touch the runtime during the capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 static_out = self.feat_fusion_pre(*static_in)
             entry = (graph, static_in, static_out)
             self._graphs[key] = entry
