@@ -488,14 +488,36 @@ __device__ __forceinline__ void gather_rows(const ConvParams &p, int j, int half
     }
 }
 
+// pipelined form: unconditional loads from clamped addresses (a fixed number of loads in flight lets the
+// compiler wait with vmcnt(N) for the older batch only); the made-up values are zeroed by fix_rows at use
+template <int NCH>
+__device__ __forceinline__ void gather_rows_nb(const ConvParams &p, int j, int half, ARows &a)
+{
+    const float *xrow = p.x + (size_t)max(j, 0) * p.ld_x;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const float4 v = *reinterpret_cast<const float4 *>(xrow + min(ch * 8 + 4 * half, p.Cin - 4));
+        a.v[ch][0] = v.x; a.v[ch][1] = v.y; a.v[ch][2] = v.z; a.v[ch][3] = v.w;
+    }
+}
+template <int NCH>
+__device__ __forceinline__ void fix_rows(const ConvParams &p, int j, int half, ARows &a)
+{
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (!(j >= 0 && ch * 8 + 4 * half + s < p.Cin)) a.v[ch][s] = 0.0f;
+}
+
 // gather batch size: KB * NCH <= 16 float4 per lane in flight (<= 64 VGPRs of A operands)
 constexpr int resident_kb(int nch) { return nch <= 1 ? 9 : nch == 2 ? 8 : nch == 3 ? 5 : nch == 4 ? 4 : nch == 5 ? 3 : 2; }
 
-template <int NT, bool VEC4, int NCH>
+template <int NT, bool VEC4, int NCH, bool PIPE>
 __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int kgroup)
 {
     constexpr int cin_pad = NCH * 8;
-    constexpr int KB = resident_kb(NCH);
+    constexpr int KB = PIPE ? (resident_kb(NCH) + 1) / 2 : resident_kb(NCH);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TN = 32 * NT;
     float *sW = reinterpret_cast<float *>(smem);  // [kgroup][cin_pad][TN], zero padded; kgroup % KB == 0
@@ -528,14 +550,19 @@ __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int 
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
     const int *nbr_row = sNbr + wave * kRowsPerWave + r32;
-    for (int kb = 0; kb < p.K; kb += KB) {
-        // ---- issue the gathers of this batch ----
-        ARows a[KB];
-        int jj[KB];
+    auto issue = [&](int kb, ARows(&a)[KB], int(&jj)[KB]) {
+#pragma unroll
+        for (int u = 0; u < KB; ++u) jj[u] = (kb + u < p.K) ? nbr_row[min(kb + u, p.K - 1) * kRowsPerBlock] : -1;
 #pragma unroll
         for (int u = 0; u < KB; ++u) {
-            jj[u] = (kb + u < p.K) ? nbr_row[(kb + u) * kRowsPerBlock] : -1;
-            gather_rows<VEC4, NCH>(p, jj[u], half, a[u]);
+            if (PIPE) gather_rows_nb<NCH>(p, jj[u], half, a[u]);
+            else gather_rows<VEC4, NCH>(p, jj[u], half, a[u]);
+        }
+    };
+    auto consume = [&](int kb, ARows(&a)[KB], int(&jj)[KB]) {
+        if (PIPE) {
+#pragma unroll
+            for (int u = 0; u < KB; ++u) fix_rows<NCH>(p, jj[u], half, a[u]);
         }
         // ---- weights of the group this batch belongs to (loads above stay in flight) ----
         const int k0 = kb / kgroup * kgroup;
@@ -589,6 +616,26 @@ __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int 
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[ch][s], b[s][t], acc[t], 0, 0, 0);
             }
         }
+    };
+    if (PIPE) {
+        // software pipeline: the gathers of batch b+1 are always issued (clamped past the end) before the
+        // MFMAs of batch b, so exactly KB * NCH loads are younger than the ones being waited for
+        ARows a0[KB], a1[KB];
+        int j0[KB], j1[KB];
+        issue(0, a0, j0);
+        for (int kb = 0; kb < p.K; kb += 2 * KB) {
+            issue(kb + KB, a1, j1);
+            consume(kb, a0, j0);
+            issue(kb + 2 * KB, a0, j0);
+            if (kb + KB < p.K) consume(kb + KB, a1, j1);
+        }
+    } else {
+        for (int kb = 0; kb < p.K; kb += KB) {
+            ARows a[KB];
+            int jj[KB];
+            issue(kb, a, jj);
+            consume(kb, a, jj);
+        }
     }
     conv_epilogue<NT>(p, acc, LinearRows{wrow0, p.n_out}, col0, r32, half, wave, sW, (int)blockIdx.x);
 }
@@ -597,7 +644,9 @@ template <int NT, int NCH>
 int launch_resident_nch(const ConvParams &p, bool vec4, hipStream_t st)
 {
     // weights of `kgroup` offsets resident at a time (a multiple of the gather batch, ~24 KB -> 4 workgroups per CU)
-    constexpr int KB = resident_kb(NCH);
+    static const bool pipe_env = !(getenv("EPRECON_CONV_PIPE") && getenv("EPRECON_CONV_PIPE")[0] == '0');  // default on
+    const bool pipe = pipe_env && vec4 && (p.Cin % 4 == 0);
+    const int KB = pipe ? (resident_kb(NCH) + 1) / 2 : resident_kb(NCH);  // the kernel's batch size: kgroup % KB == 0
     const size_t per_k = (size_t)NCH * 8 * 32 * NT * sizeof(float);
     int kgroup = (int)max((size_t)KB, (size_t)(24 * 1024) / per_k / KB * KB);
     kgroup = min(kgroup, (p.K + KB - 1) / KB * KB);
@@ -605,10 +654,12 @@ int launch_resident_nch(const ConvParams &p, bool vec4, hipStream_t st)
                                (size_t)2 * NCH * 8 * sizeof(float),
                            max((size_t)kWaves * 3 * 32 * NT, (size_t)3 * 256) * sizeof(float));
     const dim3 grid((unsigned)ceil_div(p.n_out, kRowsPerBlock), (unsigned)ceil_div(p.Cout, 32 * NT));
-    if (vec4)
-        hipLaunchKernelGGL((spconv_resident_kernel<NT, true, NCH>), grid, dim3(256), lds, st, p, kgroup);
+    if (pipe)
+        hipLaunchKernelGGL((spconv_resident_kernel<NT, true, NCH, true>), grid, dim3(256), lds, st, p, kgroup);
+    else if (vec4)
+        hipLaunchKernelGGL((spconv_resident_kernel<NT, true, NCH, false>), grid, dim3(256), lds, st, p, kgroup);
     else
-        hipLaunchKernelGGL((spconv_resident_kernel<NT, false, NCH>), grid, dim3(256), lds, st, p, kgroup);
+        hipLaunchKernelGGL((spconv_resident_kernel<NT, false, NCH, false>), grid, dim3(256), lds, st, p, kgroup);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }
