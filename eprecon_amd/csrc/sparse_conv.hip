@@ -13,14 +13,23 @@
 // There is no scatter-add and no atomic: every output row is produced by exactly one wave, so the
 // result is deterministic.
 //
-// Mapping to CDNA4: a workgroup = 4 waves = 128 output rows; each wave owns 32 rows x (32*NT)
-// output channels in NT accumulators of v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain).
-// A operand: each lane gathers 4 consecutive input channels of its row straight from global
-// memory (16-byte loads; rows are L2-resident), one VGPR per MFMA step.  B operand: the weight
-// slab W[k][c0:c0+32][:] is staged once per workgroup in LDS (double buffered, one barrier per
-// slab) and read conflict-free with ds_read_b32.  The neighbour tile int32[K][128] is staged in
-// LDS first; offsets k with no live row in the workgroup are skipped.
-// Roofline: fp32 MFMA (157 TFLOP/s) when Cin*Cout >= 32*32, else L2 gather bandwidth.
+// Mapping to CDNA4: a wave owns 32 output rows x (32*NT) output channels in NT accumulators of
+// v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain).  A operand: each lane holds 4 consecutive
+// input channels of its row, one VGPR per MFMA step.  B operand: weights from LDS.  Four kernels share
+// the prologue / epilogue fusions and differ in how the operands reach the wave:
+//   spconv_resident_kernel   C_in <= 64: the weights of a group of offsets resident per barrier, the
+//                            neighbour tile in LDS, rows gathered from global memory in software-pipelined
+//                            batches (a fixed number of loads in flight -> vmcnt(N) waits);
+//   spconv_mfma_kernel       wide layers: 32-channel weight slabs double-buffered in LDS, one barrier per slab;
+//   spconv_splitk_kernel     short lists with wide inputs: 32-row workgroups whose four waves split the
+//                            (offset, slab) chain, wave-private slabs, fixed-order sum of the partials;
+//   conv2d_tile_kernel       dense 2D 3x3 layers with C_in <= 40: halo tile + all nine weight matrices in
+//                            LDS, no kernel map, no global access in the MFMA loop.
+// Prologue: the producer's pending BatchNorm (+ReLU) applied while loading (in_scale / in_shift).
+// Epilogues (conv_epilogue): bias, ReLU, residual (with its own pending BatchNorm), per-workgroup
+// BatchNorm summaries (count, mean, M2) of the stored values, or a row-wise LayerNorm over C_out.
+// Roofline: fp32 MFMA (157 TFLOP/s) for wide layers on long lists (measured 41 % on 32->32, K = 27);
+// narrow or short layers are bound by their dependent chain (staging round trips), see DESIGN.md 3b.
 #include <stdlib.h>
 
 #include "common.hpp"
