@@ -30,6 +30,7 @@
 // BatchNorm summaries (count, mean, M2) of the stored values, or a row-wise LayerNorm over C_out.
 // Roofline: fp32 MFMA (157 TFLOP/s) for wide layers on long lists (measured 41 % on 32->32, K = 27);
 // narrow or short layers are bound by their dependent chain (staging round trips), see DESIGN.md 3b.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.hpp"
@@ -1045,6 +1046,9 @@ int conv_dispatch(ConvParams &p, int64_t n_in, hipStream_t st)
     // row pitch covers the rounded-up count (the tail lanes are zeroed after the load)
     const bool vec4 = (p.ld_x % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0) &&
                       (p.Cin % 4 == 0 || p.ld_x >= ((p.Cin + 3) & ~3));
+    if (!vec4 && getenv("EPRECON_CONV_DEBUG"))
+        fprintf(stderr, "[eprecon] scalar-gather conv: n_out=%d K=%d Cin=%d Cout=%d ld_x=%d x%%16=%d\n", p.n_out, p.K, p.Cin,
+                p.Cout, p.ld_x, (int)(reinterpret_cast<uintptr_t>(p.x) & 15));
     // Output columns per workgroup: all of them (<= 128) when the row tiles alone fill the chip,
     // 32-column blocks over blockIdx.y for short lists (10,800 pixels of the 1/16 maps are 85 row
     // tiles for 256 CUs; the gathered rows are re-read from L2 by each column block).
