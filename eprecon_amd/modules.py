@@ -171,6 +171,10 @@ class TrainBatchNorm1d(nn.BatchNorm1d):
     def run(self, x, residual=None, relu=False, out=None):
         return SP.batchnorm_train(x, self.weight, self.bias, self.eps, residual, relu, out)
 
+    def run_partials(self, x, partial, residual=None, relu=False, out=None):
+        """second half of the BatchNorm from the producing convolution's summaries"""
+        return SP.batchnorm_apply_partials(x, partial, self.weight, self.bias, self.eps, residual, relu, out)
+
 
 # ------------------------------------------------------------------------------------------------
 # dense blocks (PyTorch-ROCm convolutions; on the GPU inference path the train-mode BatchNorm2d of
@@ -406,6 +410,11 @@ from .torchsparse_utils import initial_voxelize, point_to_voxel, voxel_to_point 
 __all__ = ["SPVCNN", "SConv3d", "ConvGRU"]
 
 
+# BatchNorm summaries in the convolution epilogue for the SPVCNN blocks (EPRECON_SPVCNN_FUSED_BN=0: stand-alone
+# three-launch BatchNorm)
+_FUSED_BN_STATS = __import__("os").environ.get("EPRECON_SPVCNN_FUSED_BN", "1") == "1"
+
+
 class Conv3d(nn.Module):
     """spnn.Conv3d(inc, outc, kernel_size, stride, transposed), bias-free.  Parameter `kernel` is
     [K^3, inc, outc] ([inc, outc] when K = 1) like torchsparse's, default init uniform(+-1/sqrt(fan))
@@ -425,6 +434,10 @@ class Conv3d(nn.Module):
     def run(self, feats, nbr, out=None):
         return SP.sparse_conv(feats, self.kernel, nbr, None, out=out)
 
+    def run_stats(self, feats, nbr, out=None, in_affine=None):
+        """conv + the BatchNorm summaries of its output in one launch -> (y, partial)"""
+        return SP.conv_stats(feats, self.kernel, nbr, in_affine=in_affine, out=out)
+
 
 class BasicConvolutionBlock(nn.Module):
     """conv -> BN -> ReLU (models/modules.py:15-28)"""
@@ -434,8 +447,11 @@ class BasicConvolutionBlock(nn.Module):
         self.net = nn.Sequential(Conv3d(inc, outc, ks, stride, dilation), TrainBatchNorm1d(outc), nn.ReLU(True))
 
     def run(self, feats, nbr, out=None):
-        y = self.net[0].run(feats, nbr, out=out)
-        return self.net[1].run(y, relu=True, out=y)
+        if not _FUSED_BN_STATS:
+            y = self.net[0].run(feats, nbr, out=out)
+            return self.net[1].run(y, relu=True, out=y)
+        y, partial = self.net[0].run_stats(feats, nbr, out=out)
+        return self.net[1].run_partials(y, partial, relu=True, out=y)
 
 
 class BasicDeconvolutionBlock(nn.Module):
@@ -447,8 +463,11 @@ class BasicDeconvolutionBlock(nn.Module):
                                  nn.ReLU(True))
 
     def run(self, feats, nbr, out=None):
-        y = self.net[0].run(feats, nbr, out=out)
-        return self.net[1].run(y, relu=True, out=y)
+        if not _FUSED_BN_STATS:
+            y = self.net[0].run(feats, nbr, out=out)
+            return self.net[1].run(y, relu=True, out=y)
+        y, partial = self.net[0].run_stats(feats, nbr, out=out)
+        return self.net[1].run_partials(y, partial, relu=True, out=y)
 
 
 class ResidualBlock(nn.Module):
@@ -464,15 +483,27 @@ class ResidualBlock(nn.Module):
         self.relu = nn.ReLU(True)
 
     def run(self, feats, nbr, out=None):
-        y = self.net[0].run(feats, nbr)
-        self.net[1].run(y, relu=True, out=y)
-        y2 = self.net[3].run(y, nbr)
+        if not _FUSED_BN_STATS:
+            y = self.net[0].run(feats, nbr)
+            self.net[1].run(y, relu=True, out=y)
+            y2 = self.net[3].run(y, nbr)
+            if len(self.downsample) == 0:
+                skip = feats
+            else:
+                skip = self.downsample[0].run(feats, None)
+                self.downsample[1].run(skip, out=skip)
+            return self.net[4].run(y2, residual=skip, relu=True, out=out if out is not None else y2)
+        # conv1's BatchNorm + ReLU stays pending and is applied by conv2 while it gathers
+        y, p1 = self.net[0].run_stats(feats, nbr)
+        bn1 = self.net[1]
+        scale, shift = SP.bn_affine(p1, bn1.weight, bn1.bias, bn1.eps)
+        y2, p2 = self.net[3].run_stats(y, nbr, in_affine=(scale, shift, True))
         if len(self.downsample) == 0:
             skip = feats
         else:
-            skip = self.downsample[0].run(feats, None)
-            self.downsample[1].run(skip, out=skip)
-        return self.net[4].run(y2, residual=skip, relu=True, out=out if out is not None else y2)
+            skip, ps = self.downsample[0].run_stats(feats, None)
+            self.downsample[1].run_partials(skip, ps, out=skip)
+        return self.net[4].run_partials(y2, p2, residual=skip, relu=True, out=out if out is not None else y2)
 
 
 class _PointMLP(nn.Sequential):

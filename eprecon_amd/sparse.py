@@ -205,6 +205,45 @@ def sparse_conv_ln(x, weight, nbr, bias, ln_weight, ln_bias, ln_eps, out=None, r
     return out
 
 
+def conv_stats(x, weight, nbr=None, in_affine=None, out=None):
+    """Bias-free convolution whose epilogue also writes the per-workgroup BatchNorm summaries of its output
+    (descriptor entry point: any kernel of the family may be chosen).  in_affine = (scale, shift, relu): the
+    producer's pending BatchNorm applied while gathering.  Returns (out, partial)."""
+    lib = _lib.load()
+    if weight.dim() == 2:
+        weight = weight.unsqueeze(0)
+    kvol, cin, cout = weight.shape
+    weight = weight.contiguous()
+    n_out = x.shape[0] if nbr is None else nbr.shape[1]
+    assert x.shape[1] == cin and x.dtype == torch.float32
+    if out is None:
+        out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+    d = _lib.ConvDesc()
+    d.x, d.n_in, d.ld_x = x.data_ptr(), x.shape[0], _ld(x)
+    d.nbr, d.kvol, d.n_out = (None if nbr is None else nbr.data_ptr()), kvol, n_out
+    d.weight, d.cin, d.cout = weight.data_ptr(), cin, cout
+    d.out, d.ld_out = out.data_ptr(), _ld(out)
+    if in_affine is not None:
+        d.in_scale, d.in_shift, d.in_relu = in_affine[0].data_ptr(), in_affine[1].data_ptr(), int(in_affine[2])
+    partial = torch.empty((max(int(lib.eprecon_conv_desc_partial_rows(ctypes.byref(d))), 1), 3, cout), dtype=torch.float32,
+                          device=x.device)
+    d.bn_partial = partial.data_ptr()
+    if n_out > 0:
+        _lib.check(lib.eprecon_conv_desc_async(ctypes.byref(d), _lib.current_stream()), "eprecon_conv_desc_async")
+    return out, partial
+
+
+def bn_affine(partial, gamma, beta, eps):
+    """summaries -> the BatchNorm in affine form (scale, shift), to be applied by a consumer on load"""
+    lib = _lib.load()
+    c = partial.shape[2]
+    aff = torch.empty((2, c), dtype=torch.float32, device=partial.device)
+    _lib.check(lib.eprecon_batchnorm_finalize_affine_async(
+        partial.data_ptr(), partial.shape[0], c, _lib.ptr(gamma), _lib.ptr(beta), float(eps), aff[0].data_ptr(),
+        aff[1].data_ptr(), _lib.current_stream()), "eprecon_batchnorm_finalize_affine_async")
+    return aff[0], aff[1]
+
+
 def batchnorm_apply_partials(x, partial, gamma=None, beta=None, eps=1e-5, residual=None, relu=False, out=None):
     """second half of the train-mode BatchNorm from producer-side summaries (sparse_conv_fused)"""
     lib = _lib.load()
