@@ -118,12 +118,13 @@ def bench_cfg4(args, step, world, rank, dist, use_dist=False):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        n_out = int(step.last["coords"].shape[0]) if step.last and "coords" in step.last else 0
+        n_out = int(step.last["coords"].shape[0])   # Cfg4Step.run raises on an early return
         print(json.dumps({"metric": "fragments_per_sec", "value": world * args.steps / elapsed,
                           "unit": "fragments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": step.describe(),
-                          "last_fragment_voxels": n_out}), flush=True)
+                          "last_fragment_voxels": n_out,
+                          "finest_voxels_min_max": [min(step.voxels), max(step.voxels)]}), flush=True)
     if use_dist:
         dist.destroy_process_group()
 

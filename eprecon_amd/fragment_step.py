@@ -154,6 +154,7 @@ class Cfg4Step:
         self.net.distributed_exchange = world > 1 or os.environ.get("EPRECON_FORCE_EXCHANGE", "0") == "1"
         self.k = 0
         self.last = None
+        self.voxels = []  # finest-level voxel count of every fragment run so far
 
     @torch.no_grad()
     def run(self):
@@ -161,6 +162,12 @@ class Cfg4Step:
             self.net.gru_fusion.scene_name = [None, None, None]
         f1, f2, inp = self.frags[self.k]
         self.last, _ = self.net(f1, f2, inp, {})
+        if "coords" not in self.last or "panoptic_levels" not in self.last:
+            # a data-dependent early return of NeuConNet.forward (< 500 occupied voxels, no valid points, over the
+            # cap) would otherwise be timed as a very fast fragment
+            raise RuntimeError(f"fragment {self.k}: NeuConNet.forward returned before the finest level "
+                               f"(outputs: {sorted(self.last)})")
+        self.voxels.append(int(self.last["coords"].shape[0]))
         self.k = (self.k + 1) % self.n_fragments
         return self.last
 

@@ -11,7 +11,7 @@ Two families:
 
 Class names, constructor arguments, forward signatures and parameter names follow the reference so
 that its state_dict keys line up, except the sparse conv weights, whose layout is this build's
-[K^3, C_in, C_out] with x-fastest offset order (spconv stores [C_out, kz, ky, kx, C_in];
+[K^3, C_in, C_out] with x-fastest offset order (spconv stores [C_out, kx, ky, kz, C_in];
 `SparseSubMConv3d.load_spconv_weight` converts).
 """
 import math
@@ -75,11 +75,31 @@ class SparseSubMConv3d(nn.Module):
             self.weight.uniform_(-bound, bound)
             self.bias.zero_()
 
+    @staticmethod
+    def from_spconv_layout(w):
+        """spconv 2.x stores SubMConv3d weights as [C_out, k0, k1, k2, C_in] with k0 acting on the FIRST
+        spatial column of `indices`; the reference passes (b, x, y, z) rows (models/modules.py:267), so
+        k0 = x.  This build's layout is [K^3, C_in, C_out] with flat offset k = (dz*3 + dy)*3 + dx
+        (x fastest, csrc/kernel_map.hip), i.e. weight[k] = w[:, dx, dy, dz, :]^T."""
+        co, k0, k1, k2, ci = w.shape
+        return w.permute(3, 2, 1, 4, 0).reshape(k0 * k1 * k2, ci, co)
+
     def load_spconv_weight(self, w):
-        """w: spconv layout [C_out, kz, ky, kx, C_in] -> [K^3 (x fastest), C_in, C_out]"""
-        k = self.kernel
         with torch.no_grad():
-            self.weight.copy_(w.permute(1, 2, 3, 4, 0).reshape(k ** 3, w.shape[4], w.shape[0]))
+            self.weight.copy_(self.from_spconv_layout(w))
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """accepts the reference's checkpoints: `<name>.sparsesubmconv3d.{weight,bias}`
+        (SparseSubMConv3d, models/modules.py:252) or a 5-D spconv-layout `<name>.weight`
+        (SubMconv3dBlock.conv, models/modules.py:444)"""
+        for leaf in ("weight", "bias"):
+            old = prefix + "sparsesubmconv3d." + leaf
+            if old in state_dict:
+                state_dict[prefix + leaf] = state_dict.pop(old)
+        w = state_dict.get(prefix + "weight")
+        if w is not None and w.dim() == 5:
+            state_dict[prefix + "weight"] = self.from_spconv_layout(w)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def run(self, features, vset, out=None, relu=False):
         nbr = vset.kernel_map(3) if self.kernel == 3 else None

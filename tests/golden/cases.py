@@ -1,0 +1,91 @@
+"""Seeded input generators shared by tests/golden/make_golden.py (build container, reference
+present) and the tests (both boxes, reference absent).  numpy default_rng only, so that the
+inputs are identical on every machine; nothing here touches /root/reference."""
+import numpy as np
+
+from eprecon_amd import synthetic as S
+
+# name -> make_window kwargs; the occupancy initialiser samples the 1/8-resolution fused maps
+# (32 channels) on the dense interval-2 grid of the fragment volume
+OCC_INIT_CASES = {
+    "cfg1": dict(seed=1, width=320, height=240, n_vox=(32, 32, 32)),   # 16^3 = 4,096 voxels, maps 30x40
+    "cfg2": dict(seed=0, width=640, height=480, n_vox=(96, 96, 96)),   # 48^3 = 110,592 voxels, maps 60x80
+}
+OCC_INIT_CH = 32
+ROW_STRIDE = 32
+
+
+def occ_init_case(name):
+    """-> window, coords int32[N,4], origin f32[1,3], fused f32[9,1,32,h,w], krcam f32[9,1,4,4]"""
+    wargs = OCC_INIT_CASES[name]
+    window = S.make_window(**wargs)
+    _, h, w = S.pyramid_shapes(wargs["height"], wargs["width"])[1]
+    fused = S.make_features(4000 + wargs["seed"], 9, (OCC_INIT_CH, h, w))
+    coords = S.dense_coords(window["n_vox"], 2)
+    kr = np.ascontiguousarray(window["proj_matrices"][:, 1][:, None])
+    origin = window["vol_origin_partial"][None].copy()
+    return window, coords, origin, fused, kr
+
+
+def sample_rows(n, k, seed):
+    rng = np.random.default_rng(seed)
+    if n <= k:
+        return np.arange(n, dtype=np.int64)
+    return np.sort(rng.choice(n, size=k, replace=False)).astype(np.int64)
+
+
+def aligned_case(scale, n=3000, seed=55):
+    """voxels of a two-element batch at one scale (interval 4 / 2 / 1 for scale 0 / 1 / 2), grouped by
+    batch index, with per-element fragment origins and world->aligned-camera matrices.
+    -> coords int32[2n,4] (b,x,y,z), origin f32[2,3], w2ac f32[2,4,4]"""
+    interval = 2 ** (2 - scale)
+    rng = np.random.default_rng(seed + scale)
+    wins = [S.make_window(seed=0), S.make_window(seed=5, advance=0.32)]
+    d = 96 // interval
+    rows = []
+    for b in range(2):
+        flat = np.sort(rng.choice(d ** 3, size=n, replace=False))
+        xyz = np.stack(np.unravel_index(flat, (d, d, d)), 1) * interval
+        rows.append(np.concatenate([np.full((n, 1), b), xyz], 1))
+    coords = np.concatenate(rows).astype(np.int32)
+    origin = np.stack([w["vol_origin_partial"] for w in wins]).astype(np.float32)
+    w2ac = np.stack([w["world_to_aligned_camera"] for w in wins]).astype(np.float32)
+    return coords, origin, w2ac, interval
+
+
+FUSION_PRE_CH = (80, 40, 24)
+FUSION_PRE_DOWN = 32
+FUSION_PRE_HW = (6, 8)          # 1/16-level map size; the 1/8 and 1/4 levels are x2 and x4
+
+
+def fusion_pre_inputs(seed=9, views=9):
+    """three pyramid levels [V,80,h,w], [V,40,2h,2w], [V,24,4h,4w]"""
+    rng = np.random.default_rng(seed)
+    h, w = FUSION_PRE_HW
+    return [rng.standard_normal((views, c, h * m, w * m)).astype(np.float32)
+            for c, m in zip(FUSION_PRE_CH, (1, 2, 4))]
+
+
+def seeded_state(module, seed, keys=None):
+    """Fills the parameters `keys` (default: all) of a torch module from numpy default_rng(seed), in
+    sorted key order (weights ~ N(0, 1/fan_in), vectors ~ 1 + 0.2 N or 0.2 N), so that the
+    reference's module and this package's module can be given IDENTICAL weights without storing them."""
+    import torch
+    rng = np.random.default_rng(seed)
+    sd = module.state_dict()
+    new = {}
+    for k in sorted(sd if keys is None else keys):
+        v = sd[k]
+        if not v.dtype.is_floating_point or k.endswith(("running_mean", "running_var")):
+            new[k] = v.clone()
+            continue
+        a = rng.standard_normal(tuple(v.shape)).astype(np.float32)
+        if v.dim() >= 2:
+            a *= 1.0 / np.sqrt(max(int(np.prod(v.shape[1:])), 1))
+        elif k.endswith("weight"):
+            a = 1.0 + 0.2 * a
+        else:
+            a = 0.2 * a
+        new[k] = torch.from_numpy(a.astype(np.float32))
+    module.load_state_dict(new, strict=keys is None)
+    return module

@@ -351,8 +351,133 @@ def gen_scene_fusion():
     _save("scene_fusion", **out)
 
 
+# ------------------------------------------------------------------------------------------------
+# round-2 pins: view mean / variance (G3), aligned-camera coordinates (a7), feat_fusion_pre (G6)
+# ------------------------------------------------------------------------------------------------
+def _ref_lines(path, first, last):
+    """the reference's own source lines between the line containing `first` and the next line
+    containing `last` (inclusive), dedented — executed in place of a function the reference does
+    not factor out.  Read at generation time only; nothing is copied into this repository."""
+    import textwrap
+    src = open(os.path.join(ref_shim.REF, path)).read().splitlines()
+    i0 = next(i for i, l in enumerate(src) if first in l)
+    i1 = next(i for i, l in enumerate(src) if i >= i0 and l.split("#")[0].strip() == last)
+    return textwrap.dedent("\n".join(src[i0:i1 + 1])), (i0 + 1, i1 + 1)
+
+
+def _occ_init_shell(dense=False):
+    """A reference Occupancy_Initialization WITHOUT its spconv layers: the constructor cannot run here
+    (models/modules.py:257 initialises a spconv weight), so the object is allocated bare and given
+    only the dense sub-modules that are importable."""
+    import models.occupancy_initialization as M
+    import cases
+    obj = M.Occupancy_Initialization.__new__(M.Occupancy_Initialization)
+    torch.nn.Module.__init__(obj)
+    if dense:
+        from models.modules import Conv2d_Block, Conv2d_Residual_Block, Fusion_Block
+        ch, d = cases.FUSION_PRE_CH, cases.FUSION_PRE_DOWN
+        obj.self_fusion_1x, obj.self_fusion_2x, obj.self_fusion_4x = (Fusion_Block(c) for c in ch)
+        obj.pool4x = torch.nn.AvgPool2d(2)
+        obj.fusion_down = Conv2d_Block(sum(ch), d, 1)
+        for i in (1, 2, 3, 4):
+            setattr(obj, f"post_fusion_{i}", Conv2d_Residual_Block(d, 3))
+    return obj
+
+
+def gen_occ_init():
+    """(G3) Occupancy_Initialization.forward (models/occupancy_initialization.py:61-135) run up to the
+    first spconv-dependent line on seeded fused maps: visible-view counts, valid set, per-voxel view
+    MEAN and population VARIANCE of the sampled 32-channel features.  `feat_fusion_pre` is replaced
+    by the seeded maps; `norm0` captures the variance volume and stops the forward.
+    (G6) the reference's own feat_fusion_pre (:41-58) as a whole on seeded weights."""
+    import cases
+
+    class _Stop(Exception):
+        pass
+
+    out = {}
+    for name in cases.OCC_INIT_CASES:
+        window, coords, origin, fused, kr = cases.occ_init_case(name)
+        obj = _occ_init_shell()
+        grabbed = {}
+
+        def norm0(var, grabbed=grabbed):
+            grabbed["var"] = var.clone()
+            raise _Stop
+
+        obj.norm0 = norm0
+        tf = torch.from_numpy(fused)
+        obj.feat_fusion_pre = lambda a, b, c, tf=tf: tf[:, 0]
+        v, _, _, h, w = fused.shape
+        # only the SHAPES of the pyramid enter before feat_fusion_pre: [f4, f8, f16] per view
+        views = [[torch.zeros(1, 1, 2 * h, 2 * w), torch.zeros(1, 1, h, w), torch.zeros(1, 1, h // 2, w // 2)]
+                 for _ in range(v)]
+        shape = tuple(n // 2 for n in window["n_vox"])
+        try:
+            obj.forward(torch.from_numpy(coords), torch.from_numpy(origin), window["voxel_size"], views,
+                        torch.from_numpy(kr), shape, 1, 2)
+            raise RuntimeError("forward did not reach norm0")
+        except _Stop as e:
+            tb = e.__traceback__
+            while tb.tb_next is not None and tb.tb_frame.f_code.co_name != "forward":
+                tb = tb.tb_next
+            loc = tb.tb_frame.f_locals
+        var, mean = grabbed["var"].numpy(), loc["mean"].numpy()
+        count = loc["count"].numpy()
+        n_valid = var.shape[0]
+        rows = cases.sample_rows(n_valid, 384, 7)
+        out[name + "_count"] = count.astype(np.uint8)
+        out[name + "_nvalid"] = np.int64(n_valid)
+        out[name + "_rows"] = rows
+        out[name + "_var_rows"], out[name + "_mean_rows"] = var[rows], mean[rows]
+        out[name + "_var_rowsum"] = var.sum(1, dtype=np.float64).astype(np.float32)[::cases.ROW_STRIDE]
+        out[name + "_mean_rowsum"] = mean.sum(1, dtype=np.float64).astype(np.float32)[::cases.ROW_STRIDE]
+        out[name + "_subm_coord_rows"] = loc["subm_coords"].numpy()[rows].astype(np.int32)
+    # G6: the whole 2D fusion stack
+    obj = _occ_init_shell(dense=True)
+    cases.seeded_state(obj, 2024)
+    obj.train()
+    f1, f2, f4 = (torch.from_numpy(a) for a in cases.fusion_pre_inputs())
+    with torch.no_grad():
+        y = obj.feat_fusion_pre(f1, f2, f4)
+    out["fusion_pre_out"] = y.numpy()
+    out["fusion_pre_keys"] = np.array(sorted(obj.state_dict().keys()))
+    _save("occ_init", **out)
+
+
+def gen_aligned_coords():
+    """(a7) the aligned-camera coordinate block of NeuConNet.forward (models/neucon_network.py:387-398)
+    and its twin in GRUFusion.forward (models/gru_fusion.py:332-337), executed from the reference's
+    own source lines on seeded voxel lists."""
+    from types import SimpleNamespace
+    import cases
+
+    code_n, span_n = _ref_lines("models/neucon_network.py", "r_coords = up_coords.detach().clone().float()",
+                                "r_coords = r_coords[:, [1, 2, 3, 0]]")
+    code_g, span_g = _ref_lines("models/gru_fusion.py", "r_coords = updated_coords.detach().clone().float()",
+                                "r_coords = r_coords.permute(1, 0).contiguous()")
+    out = {"neucon_lines": np.array(span_n), "gru_lines": np.array(span_g)}
+    for scale in range(3):
+        coords, origin, w2ac, interval = cases.aligned_case(scale)
+        inputs = {"vol_origin_partial": torch.from_numpy(origin), "world_to_aligned_camera": torch.from_numpy(w2ac)}
+        ns = {"torch": torch, "up_coords": torch.from_numpy(coords), "bs": 2, "inputs": inputs,
+              "self": SimpleNamespace(cfg=SimpleNamespace(VOXEL_SIZE=0.04))}
+        exec(code_n, ns)
+        out[f"s{scale}_r_coords"] = ns["r_coords"].numpy()
+        # GRU-fusion form: batch element i, coordinates in units of this scale's voxel
+        for i in range(2):
+            m = coords[:, 0] == i
+            upd = torch.from_numpy(coords[m][:, 1:].astype(np.int64) // interval)
+            ns = {"torch": torch, "updated_coords": upd, "voxel_size": 0.04 * interval, "i": i,
+                  "origin": inputs["vol_origin_partial"][i], "inputs": inputs}
+            exec(code_g, ns)
+            out[f"s{scale}_b{i}_gru_r_coords"] = ns["r_coords"].numpy()
+    _save("aligned_coords", **out)
+
+
 GENERATORS = {"back_project": gen_back_project, "grid_ops": gen_grid_ops, "dense_blocks": gen_dense_blocks,
-              "gru_fusion": gen_gru_fusion, "mask3dformer": gen_mask3dformer, "scene_fusion": gen_scene_fusion}
+              "gru_fusion": gen_gru_fusion, "mask3dformer": gen_mask3dformer, "scene_fusion": gen_scene_fusion,
+              "occ_init": gen_occ_init, "aligned_coords": gen_aligned_coords}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GENERATORS)

@@ -24,7 +24,8 @@ def make_inputs(seed, height, width, n_vox, batch=1):
     return window, feats
 
 
-@pytest.mark.parametrize("height,width,nvox,batch", [(240, 320, 48, 1), (240, 320, 48, 2)])
+# (480, 640, 96, 1) is BASELINE.json configs[1]: 9 x 640x480 views, dense 48^3 grid = 110,592 voxels
+@pytest.mark.parametrize("height,width,nvox,batch", [(240, 320, 48, 1), (240, 320, 48, 2), (480, 640, 96, 1)])
 def test_occupancy_initialization_matches_oracle(height, width, nvox, batch):
     from eprecon_amd.occupancy_initialization import Occupancy_Initialization
     torch.manual_seed(0)

@@ -86,3 +86,39 @@ def test_norms_match_torch():
     t = torch.relu(torch.from_numpy(x)) + torch.from_numpy(r)
     ref = F.layer_norm(t, (24,), torch.from_numpy(g), torch.from_numpy(b), 1e-5).numpy()
     np.testing.assert_allclose(OS.layernorm_rows(x, g, b, 1e-5, r, True, False), ref, atol=2e-5)
+
+
+def test_spconv_checkpoint_layout_is_converted():
+    """A reference checkpoint stores SubMConv3d weights in spconv's [C_out, kx, ky, kz, C_in] layout
+    (indices are (b, x, y, z) rows, models/modules.py:267) under `.sparsesubmconv3d.weight` or a 5-D
+    `.conv.weight`.  Loading it into this package's layers must reproduce the dense conv3d the
+    spconv layer is equivalent to on an (x, y, z) volume."""
+    from eprecon_amd.modules import SparseSubMConv3d, SubMconv3dBlock
+    rng = np.random.default_rng(4)
+    D, cin, cout = 7, 3, 4
+    w_sp = rng.standard_normal((cout, 3, 3, 3, cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    layer = SparseSubMConv3d(cin, cout, 3)
+    missing = layer.load_state_dict({"sparsesubmconv3d.weight": torch.from_numpy(w_sp),
+                                     "sparsesubmconv3d.bias": torch.from_numpy(b)})
+    assert not missing.missing_keys and not missing.unexpected_keys
+    blk = SubMconv3dBlock(cin, cout, 3, 1, 1)
+    sd = blk.state_dict()
+    sd["conv.weight"], sd["conv.bias"] = torch.from_numpy(w_sp), torch.from_numpy(b)
+    blk.load_state_dict(sd)
+    assert torch.equal(blk.conv.weight, layer.weight)
+    k1 = SparseSubMConv3d(cin, cout, 1)
+    w1 = rng.standard_normal((cout, 1, 1, 1, cin)).astype(np.float32)
+    k1.load_state_dict({"sparsesubmconv3d.weight": torch.from_numpy(w1), "sparsesubmconv3d.bias": torch.from_numpy(b)})
+    assert np.array_equal(k1.weight.detach().numpy()[0], w1[:, 0, 0, 0, :].T)
+    # asymmetric occupancy so that an x/z swap cannot go unnoticed
+    occ = rng.random((D, D + 1, D + 2)) < 0.4
+    xyz = np.argwhere(occ)
+    coords = np.concatenate([np.zeros((len(xyz), 1), int), xyz], 1).astype(np.int32)
+    x = rng.standard_normal((len(xyz), cin)).astype(np.float32)
+    got = OS.sparse_conv(x, OS.kernel_map(coords, coords, 3, 1), layer.weight.detach().numpy(), b)
+    dense = np.zeros((1, cin) + occ.shape, np.float32)
+    dense[0, :, xyz[:, 0], xyz[:, 1], xyz[:, 2]] = x
+    wd = torch.from_numpy(w_sp).permute(0, 4, 1, 2, 3).contiguous()      # [co, ci, kx, ky, kz]
+    ref = F.conv3d(torch.from_numpy(dense), wd, torch.from_numpy(b), padding=1)[0].numpy()
+    np.testing.assert_allclose(got, ref[:, xyz[:, 0], xyz[:, 1], xyz[:, 2]].T, atol=1e-4)
