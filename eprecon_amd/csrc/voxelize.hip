@@ -149,6 +149,37 @@ __global__ __launch_bounds__(256) void devoxelize_kernel(const float *feat, int 
     *o = accumulate ? (*o + s) : s;
 }
 
+// SConv3d's tail inside ConvGRU (models/modules.py:193-196,214-221): v = devoxelise(conv) + Linear(z.F) (the Linear
+// output arrives in `skip`), followed by the gate arithmetic the reference does with separate tensor ops:
+//   mode 1  out = sigmoid(v)                         update gate z
+//   mode 2  out = sigmoid(v) * h                     r * h, written straight into the [r*h, x] concat buffer
+//   mode 3  out = (1 - zg) * h + zg * tanh(v)        new hidden state
+__global__ __launch_bounds__(256) void devoxelize_gate_kernel(const float *feat, int ld_f, const int32_t *idx,
+                                                              const float *wts, int n, int C, const float *skip,
+                                                              int ld_s, int mode, const float *h, int ld_h,
+                                                              const float *zg, int ld_z, float *out, int ld_o)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)n * C) return;
+    const int i = (int)(e / C), c = (int)(e - (int64_t)i * C);
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int j = idx[(size_t)i * 8 + k];
+        if (j >= 0) s = fmaf(wts[(size_t)i * 8 + k], feat[(size_t)j * ld_f + c], s);
+    }
+    const float v = s + skip[(size_t)i * ld_s + c];
+    float r;
+    if (mode == 3) {
+        const float z = zg[(size_t)i * ld_z + c], hv = h[(size_t)i * ld_h + c];
+        r = (1.0f - z) * hv + z * tanhf(v);
+    } else {
+        r = __fdiv_rn(1.0f, 1.0f + expf(-v));
+        if (mode == 2) r *= h[(size_t)i * ld_h + c];
+    }
+    out[(size_t)i * ld_o + c] = r;
+}
+
 HashTable make_table(const void *mem, uint32_t cap)
 {
     HashTable t;
@@ -156,6 +187,44 @@ HashTable make_table(const void *mem, uint32_t cap)
     t.vals = reinterpret_cast<int32_t *>(t.keys + cap);
     t.mask = cap - 1;
     return t;
+}
+
+// torchsparse's coordinate hash (F.sphash, ops/torchsparse_utils.py:19): FNV-1a over the four int32 of a row
+// in (x, y, z, batch) order, folded to 60 bits.  Needed only to reproduce the ORDER in which the
+// reference numbers voxels (`torch.unique(pc_hash)` = ascending hash), see remap_stale_index_kernel.
+__global__ void sphash_kernel(const int4 *coords_bxyz, int n, long long *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = coords_bxyz[i];
+    const int v[4] = {c.y, c.z, c.w, c.x};
+    unsigned long long h = 14695981039346656037ull;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h ^= (unsigned int)v[j];
+        h *= 1099511628211ull;
+    }
+    h = (h >> 60) ^ (h & 0x0FFFFFFFFFFFFFFFull);
+    out[i] = (long long)h;
+}
+
+// ConvGRU's second gate convolution in the reference devoxelises with the corner indices cached by the
+// FIRST voxelisation (ops/torchsparse_utils.py:70-71,97-99) into the SECOND voxel set's feature rows; both
+// sets are numbered by ascending sphash.  With this build's first-occurrence numbering the same rows are
+// reached through  old id -> hash rank in the old set -> id of the voxel with that rank in the new set.
+// Ranks beyond the new set (out-of-bounds reads in the reference) become -1 (no contribution).
+__global__ void remap_stale_index_kernel(const int32_t *idx, long long n, const int32_t *rank_old,
+                                         const int32_t *perm_new, int m_new, int32_t *out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int j = idx[i];
+    int r = -1;
+    if (j >= 0) {
+        const int k = rank_old[j];
+        r = k < m_new ? perm_new[k] : -1;
+    }
+    out[i] = r;
 }
 
 }  // namespace
@@ -268,6 +337,43 @@ int eprecon_devoxelize_async(const float *voxel_feat, int ld_feat, const int32_t
     hipLaunchKernelGGL(devoxelize_kernel, dim3((unsigned)ceil_div(n * channels, 256)), dim3(256), 0,
                        (hipStream_t)stream, voxel_feat, ld_feat, idx8, weight8, (int)n, channels, out, ld_out,
                        accumulate);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_sphash_async(const int32_t *coords, int64_t n, int64_t *out_hash, void *stream)
+{
+    if (n < 0 || (n > 0 && (!coords || !out_hash))) return EPRECON_ERR_ARG;
+    if (n == 0) return EPRECON_OK;
+    hipLaunchKernelGGL(sphash_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const int4 *>(coords), (int)n, reinterpret_cast<long long *>(out_hash));
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_remap_index_async(const int32_t *idx, int64_t n, const int32_t *rank_old, const int32_t *perm_new,
+                              int64_t m_new, int32_t *out, void *stream)
+{
+    if (n < 0 || m_new < 0 || (n > 0 && (!idx || !rank_old || !out || (m_new > 0 && !perm_new)))) return EPRECON_ERR_ARG;
+    if (n == 0) return EPRECON_OK;
+    hipLaunchKernelGGL(remap_stale_index_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       idx, (long long)n, rank_old, perm_new, (int)m_new, out);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+
+int eprecon_devoxelize_gate_async(const float *voxel_feat, int ld_feat, const int32_t *idx8, const float *weight8,
+                                  int64_t n, int channels, const float *skip, int ld_skip, int mode, const float *h,
+                                  int ld_h, const float *zgate, int ld_z, float *out, int ld_out, void *stream)
+{
+    if (n < 0 || channels <= 0 || mode < 1 || mode > 3) return EPRECON_ERR_ARG;
+    if (n == 0) return EPRECON_OK;
+    if (!voxel_feat || !idx8 || !weight8 || !skip || !out || (mode >= 2 && !h) || (mode == 3 && !zgate))
+        return EPRECON_ERR_ARG;
+    hipLaunchKernelGGL(devoxelize_gate_kernel, dim3((unsigned)ceil_div(n * channels, 256)), dim3(256), 0,
+                       (hipStream_t)stream, voxel_feat, ld_feat, idx8, weight8, (int)n, channels, skip, ld_skip, mode,
+                       h, ld_h, zgate, ld_z, out, ld_out);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }

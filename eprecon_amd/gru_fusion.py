@@ -50,10 +50,12 @@ def fbv_union(cur_coords, cur_feat, glob_coords, glob_feat, dim, interval, rel, 
     return updated[:n], src_cur[:n], src_glob[:n], glob_valid[:n_glob].bool()
 
 
-def gather_rows(feat, src, channels, fill=0.0):
+def gather_rows(feat, src, channels, fill=0.0, out=None):
+    """out[i] = feat[src[i]] (or `fill` where src[i] < 0); feat / out may be column slices of wider buffers"""
     lib = _lib.load()
     n = src.shape[0]
-    out = torch.empty((n, channels), dtype=torch.float32, device=src.device)
+    if out is None:
+        out = torch.empty((n, channels), dtype=torch.float32, device=src.device)
     has = feat is not None and feat.shape[0] > 0
     if not has:
         return out.fill_(fill)
@@ -172,8 +174,17 @@ class GRUFusion(nn.Module):
             cur_c, cur_f = coords[lo:hi].contiguous(), values_in[lo:hi].contiguous()
             gmap = self.global_volume[scale]
             updated, src_cur, src_glob, gvalid = fbv_union(cur_c, cur_f, gmap.C, gmap.F, dim, interval, rel.tolist())
-            values = gather_rows(cur_f, src_cur, self.ch_in[scale])
-            global_values = gather_rows(gmap.F, src_glob, self.ch_in[scale])
+            # current / global rows gathered straight into the [h | x] buffers of the two ConvGRUs (voxel channels
+            # and image channels): h = the map's row, x = the fragment's row; no concat / slice copies afterwards
+            n_u, cin = updated.shape[0], self.ch_in[scale]
+            chi = cin - chv
+            hx_v = torch.empty((n_u, 2 * chv), dtype=torch.float32, device=dev)
+            hx_i = torch.empty((n_u, 2 * chi), dtype=torch.float32, device=dev)
+            gF = gmap.F if gmap.F.shape[0] > 0 else None
+            gather_rows(gF[:, :chv] if gF is not None else None, src_glob, chv, out=hx_v[:, :chv])
+            gather_rows(gF[:, chv:] if gF is not None else None, src_glob, chi, out=hx_i[:, :chi])
+            gather_rows(cur_f[:, :chv], src_cur, chv, out=hx_v[:, chv:])
+            gather_rows(cur_f[:, chv:], src_cur, chi, out=hx_i[:, chi:])
 
             tsdf_target = occ_target = vol = tvalid = None
             if "occ_list" in inputs:
@@ -184,17 +195,18 @@ class GRUFusion(nn.Module):
                 tsdf_target = vol[u[:, 0], u[:, 1], u[:, 2]].unsqueeze(-1)
                 occ_target = tsdf_target.abs() < 1
 
+            values = torch.empty((n_u, cin), dtype=torch.float32, device=dev)
             if not self._identity_fusion:
                 pts_c = torch.cat([torch.zeros_like(updated[:, :1]), updated * interval], dim=1)
                 r_coords = aligned_camera_coords(pts_c, origin.reshape(1, 3), cfg.VOXEL_SIZE,
                                                  inputs["world_to_aligned_camera"][i].reshape(1, 4, 4))
-                hv = PointTensor(global_values[:, :chv].contiguous(), r_coords)
-                xv = PointTensor(values[:, :chv].contiguous(), r_coords)
-                fused_v = self.fusion_nets_voxel[scale](hv, xv)
-                hi_ = PointTensor(global_values[:, chv:].contiguous(), r_coords)
-                xi_ = PointTensor(values[:, chv:].contiguous(), r_coords)
-                fused_i = self.fusion_nets_img[scale](hi_, xi_)
-                values = torch.cat([fused_v, fused_i], dim=-1)
+                # both cells see the same points: their six SConv3d share two voxelisations (torchsparse_utils)
+                self.fusion_nets_voxel[scale](PointTensor(hx_v[:, :chv], r_coords), PointTensor(hx_v[:, chv:], r_coords),
+                                              out=values[:, :chv])
+                self.fusion_nets_img[scale](PointTensor(hx_i[:, :chi], r_coords), PointTensor(hx_i[:, chi:], r_coords),
+                                            out=values[:, chv:])
+            else:
+                values[:, :chv], values[:, chv:] = hx_v[:, chv:], hx_i[:, chi:]
 
             # update_map (:195-215)
             gmap.F = torch.cat([gmap.F[~gvalid], values.detach()])

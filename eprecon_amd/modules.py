@@ -425,7 +425,7 @@ class Panoptic_Feat_Fusion(nn.Module):
 # torchsparse-style layers: point-voxel U-Net (SPVCNN) and sparse ConvGRU
 # ------------------------------------------------------------------------------------------------
 from .tensor import PointTensor, SparseTensor  # noqa: E402
-from .torchsparse_utils import initial_voxelize, point_to_voxel, voxel_to_point  # noqa: E402
+from .torchsparse_utils import devoxelize_gate, initial_voxelize, point_to_voxel, voxel_to_point  # noqa: E402
 
 __all__ = ["SPVCNN", "SConv3d", "ConvGRU"]
 
@@ -433,6 +433,16 @@ __all__ = ["SPVCNN", "SConv3d", "ConvGRU"]
 # BatchNorm summaries in the convolution epilogue for the SPVCNN blocks (EPRECON_SPVCNN_FUSED_BN=0: stand-alone
 # three-launch BatchNorm)
 _FUSED_BN_STATS = __import__("os").environ.get("EPRECON_SPVCNN_FUSED_BN", "1") == "1"
+
+
+def _linear_wt(lin):
+    """weight of an nn.Linear as the [C_in, C_out] matrix the per-voxel GEMM takes, transposed once per weight
+    version (the inference path calls every layer thousands of times with the same weights)"""
+    hit = getattr(lin, "_wt_cache", None)
+    if hit is None or hit[0] != lin.weight._version or hit[1].device != lin.weight.device:
+        hit = (lin.weight._version, lin.weight.detach().t().contiguous())
+        lin._wt_cache = hit
+    return hit[1]
 
 
 class Conv3d(nn.Module):
@@ -534,7 +544,7 @@ class _PointMLP(nn.Sequential):
 
     def run(self, feats):
         lin = self[0]
-        y = SP.sparse_conv(feats, lin.weight.t().contiguous(), None, lin.bias)
+        y = SP.sparse_conv(feats, _linear_wt(lin), None, lin.bias)
         return self[1].run(y, relu=True, out=y)
 
 
@@ -615,8 +625,16 @@ class SConv3d(nn.Module):
         x = initial_voxelize(z, self.pres, self.vres)
         y = SparseTensor(self.net.run(x.F, x.vset.kernel_map(3)), x.vset)
         lin = self.point_transforms[0]
-        skip = SP.sparse_conv(z.F, lin.weight.t().contiguous(), None, lin.bias)
+        skip = SP.sparse_conv(z.F, _linear_wt(lin), None, lin.bias)
         return voxel_to_point(y, z, out=skip, accumulate=True)
+
+    def run_gate(self, z, mode, h=None, zgate=None, out=None):
+        """forward(z).F followed by the ConvGRU gate arithmetic of `mode` (torchsparse_utils.devoxelize_gate)"""
+        x = initial_voxelize(z, self.pres, self.vres)
+        y = SparseTensor(self.net.run(x.F, x.vset.kernel_map(3)), x.vset)
+        lin = self.point_transforms[0]
+        skip = SP.sparse_conv(z.F, _linear_wt(lin), None, lin.bias)
+        return devoxelize_gate(y, z, skip, mode, h=h, zgate=zgate, out=out)
 
 
 class ConvGRU(nn.Module):
@@ -629,14 +647,39 @@ class ConvGRU(nn.Module):
         self.convr = SConv3d(hidden_dim + input_dim, hidden_dim, pres, vres, 3)
         self.convq = SConv3d(hidden_dim + input_dim, hidden_dim, pres, vres, 3)
 
-    def forward(self, h, x):
+    def forward(self, h, x, out=None):
+        """`hx` is voxelised twice — convz, then convr on the coordinates convz already divided by vres (the
+        in-place `z.C = ...` of ops/torchsparse_utils.py:33 with models/modules.py:216-217) — and convr
+        devoxelises with convz's cached corner indices (torchsparse_utils.initial_voxelize, LITERAL_CONVR).
+        `out` (optional, beyond the reference's signature): where the new hidden state is written."""
+        if h.F.is_cuda and not torch.is_grad_enabled():
+            return self._forward_fused(h, x, out)
         hx = PointTensor(torch.cat([h.F, x.F], dim=1), h.C)
         z = torch.sigmoid(self.convz(hx).F)
-        # NOTE: convz's initial_voxelize already replaced hx.C by hx.C / vres, so convr voxelises the
-        # coordinates a second time — this is the reference's behaviour (the in-place `z.C = ...` of
-        # ops/torchsparse_utils.py:33 combined with models/modules.py:216-217) and is reproduced.
         r = torch.sigmoid(self.convr(hx).F)
         x.F = torch.cat([r * h.F, x.F], dim=1)
         q = torch.tanh(self.convq(x).F)
         h.F = (1 - z) * h.F + z * q
+        if out is not None:
+            out.copy_(h.F)
+        return h.F
+
+    def _forward_fused(self, h, x, out=None):
+        """the same cell with the gate arithmetic in the devoxelisation kernels: r * h lands directly in the
+        [r*h, x] concat buffer, the GRU mix is the epilogue of convq"""
+        c = h.F.shape[1]
+        hf, xf = h.F, x.F
+        if (hf.stride(0) == hf.shape[1] + xf.shape[1] == xf.stride(0) and hf.stride(1) == 1 == xf.stride(1)
+                and xf.data_ptr() == hf.data_ptr() + 4 * c):
+            # h and x already sit side by side in one [N, c_h + c_x] buffer (GRUFusion gathers them that way)
+            hx_f = torch.as_strided(hf, (hf.shape[0], hf.stride(0)), (hf.stride(0), 1))
+        else:
+            hx_f = torch.cat([hf, xf], dim=1)
+            hf = hx_f[:, :c]
+        hx = PointTensor(hx_f, h.C)
+        z = self.convz.run_gate(hx, 1)
+        rhx = hx_f.clone()
+        self.convr.run_gate(hx, 2, h=hf, out=rhx[:, :c])
+        x.F = rhx
+        h.F = self.convq.run_gate(x, 3, h=hf, zgate=z, out=out)
         return h.F

@@ -154,21 +154,26 @@ class NeuConNet(nn.Module):
                 feat = feat_all[:, :voxel_dim]
                 self._record(stage=f"gru{i}", coords_in=fuse_in[0], feat_in=fuse_in[1], coords=up_coords,
                              feat_all=feat_all, tsdf_target=tsdf_target)
-            grid_mask = torch.ones_like(feat[:, 0]).bool()
-
             tsdf = self.tsdf_preds[i](feat)
             occ = self.occ_preds[i](feat)
             loss_dict[f"tsdf_occ_loss_{i}"] = zero  # losses are out of scope (inference path)
 
             # ---- sparsify for the next stage (:454-507) ----
+            # (the reference's grid_mask is all ones on this path, `occupancy[grid_mask == False] = False` is a no-op)
             occupancy = occ.squeeze(1) > cfg.THRESHOLDS[i]
-            occupancy[grid_mask == False] = False  # noqa: E712
             # recorded before the guards so that an early return still leaves the logits visible;
             # `occupancy` is the same tensor object the sub-sampling below edits in place
             self._record(stage=f"heads{i}", feat=feat, tsdf=tsdf, occ=occ, occupancy=occupancy)
+            # per batch element: occupied voxels, and occupied voxels whose target is occupied — ONE host read
+            # for all the guards below (the reference synchronises once per guard and batch element)
+            bcol = up_coords[:, 0].long()
+            tgt = occ_target.squeeze(1) if occ_target is not None else torch.ones_like(occupancy)
+            count_by_batch = lambda: torch.zeros((2, bs), dtype=torch.int64, device=dev).index_add_(
+                1, bcol, torch.stack([occupancy, occupancy & tgt]).long()).tolist()
+            stats = count_by_batch()
+            dropped = False
             for b in range(bs):
-                batch_ind = torch.nonzero(up_coords[:, 0] == b).squeeze(1)
-                num_batch = int(occupancy[batch_ind].sum().item())
+                num_batch = stats[0][b]
                 if num_batch < STAGE_MIN_OCC:
                     _warn(f"no valid points: scale {i}")
                     return outputs, loss_dict
@@ -179,21 +184,26 @@ class NeuConNet(nn.Module):
                     return outputs, loss_dict
                 elif self.training and num_batch > cap:
                     _warn(f"choice too many points: scale {i} num_batch {num_batch}")
+                    batch_ind = torch.nonzero(up_coords[:, 0] == b).squeeze(1)
                     choice = np.random.choice(num_batch, num_batch - cap, replace=False)
                     ind = torch.nonzero(occupancy[batch_ind]).squeeze(1)
                     drop = batch_ind[ind[torch.from_numpy(choice).to(ind.device)]]
                     occupancy[drop] = False
+                    dropped = True
             if occ_target is not None:
+                if dropped:
+                    stats = count_by_batch()
                 for b in range(bs):
-                    batch_ind = torch.nonzero(up_coords[:, 0] == b).squeeze(1)
-                    if occ_target[batch_ind][occupancy[batch_ind]].sum() == 0:
+                    if stats[1][b] == 0:
                         _warn(f"occ_target is 0: scale {i}")
                         return outputs, loss_dict
-            pre_coords = up_coords[occupancy]
-            pre_tsdf, pre_occ = tsdf[occupancy], occ[occupancy]
-            panoptic_voxel_feats.append(feat_all[occupancy])
+            keep_rows = torch.nonzero(occupancy).squeeze(1)
+            pre_coords = up_coords.index_select(0, keep_rows)
+            pre_tsdf, pre_occ = tsdf.index_select(0, keep_rows), occ.index_select(0, keep_rows)
+            kept_all = feat_all.index_select(0, keep_rows)
+            panoptic_voxel_feats.append(kept_all)
             panoptic_coords.append(pre_coords)
-            pre_feat = torch.cat([feat[occupancy], pre_tsdf, pre_occ], dim=1)
+            pre_feat = torch.cat([kept_all[:, :feat.shape[1]], pre_tsdf, pre_occ], dim=1)
             if i == cfg.N_LAYER - 1:
                 outputs["coords"] = pre_coords
                 outputs["tsdf"] = pre_tsdf

@@ -31,6 +31,9 @@ def tocuda(obj, device):
 class NeuralRecon(nn.Module):
     def __init__(self, cfg):
         super().__init__()
+        # the reference hands over the whole yacs node and reads cfg.MODEL (models/neuralrecon.py:22-33);
+        # a plain ModelCfg is accepted as well
+        cfg = getattr(cfg, "MODEL", cfg)
         self.cfg = cfg
         self.register_buffer("pixel_mean", torch.tensor(PIXEL_MEAN).view(-1, 1, 1), persistent=False)
         self.register_buffer("pixel_std", torch.tensor(PIXEL_STD).view(-1, 1, 1), persistent=False)

@@ -15,6 +15,7 @@ class PointTensor:
         self.idx_query = idx_query if idx_query is not None else {}   # stride -> int32[N,8]
         self.weights = weights if weights is not None else {}         # stride -> f32[N,8]
         self.additional_features = {"idx_query": {}, "lists": {}}     # stride -> point->voxel, CSR lists
+        self._vox_entry = None                            # the voxelisation idx_query[1] / weights[1] belong to
 
     def cuda(self):
         return self

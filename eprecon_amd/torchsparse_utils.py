@@ -1,12 +1,15 @@
 """Point <-> voxel glue of the point-voxel U-Net — mirror of ops/torchsparse_utils.py:15-105 on
 libeprecon_hip.so (csrc/voxelize.hip, csrc/kernel_map.hip)."""
+import os
+
 import torch
 
 from . import _lib
 from . import sparse as SP
 from .tensor import PointTensor, SparseTensor
 
-__all__ = ["initial_voxelize", "point_to_voxel", "voxel_to_point", "aligned_camera_coords"]
+__all__ = ["initial_voxelize", "point_to_voxel", "voxel_to_point", "aligned_camera_coords", "devoxelize_gate",
+           "clear_voxelization_cache"]
 
 
 def aligned_camera_coords(coords, origin, voxel_size, world_to_aligned_camera):
@@ -51,33 +54,112 @@ def _segment_mean(feat, lists, m, out=None):
     return out
 
 
+# ConvGRU's second gate convolution as the reference literally computes it (stale idx_query / weights of the first
+# voxelisation applied to the second voxel set in torchsparse's hash order).  EPRECON_CONVGRU_LITERAL=0: every
+# SConv3d devoxelises with the indices of its own voxelisation.
+LITERAL_CONVR = os.environ.get("EPRECON_CONVGRU_LITERAL", "1") == "1"
+
+
+class _VoxEntry:
+    """One voxelisation of a point set at one resolution: everything that depends on the coordinates only
+    (scaled points, voxel set + hash grid + kernel map, point -> voxel lists, trilinear corners / weights).
+    The six SConv3d of the two ConvGRUs of a scale voxelise the same points: convz and convq of both GRUs
+    share one entry, both convr the entry built on the already-scaled coordinates."""
+    __slots__ = ("key", "pts", "scaled", "vox", "vset", "inverse", "lists", "idx8", "w8", "_order", "_stale")
+
+    def sphash_order(self):
+        """(perm, rank): perm[k] = id of the voxel with the k-th smallest torchsparse hash, rank = its inverse —
+        the order in which the reference numbers the voxels of initial_voxelize (ops/torchsparse_utils.py:19-21)"""
+        if self._order is None:
+            lib = _lib.load()
+            c = self.vset.coords
+            h = torch.empty(c.shape[0], dtype=torch.int64, device=c.device)
+            _lib.check(lib.eprecon_sphash_async(_lib.ptr(c), c.shape[0], _lib.ptr(h), _lib.current_stream()),
+                       "eprecon_sphash_async")
+            perm = torch.sort(h, stable=True)[1].to(torch.int32)
+            rank = torch.empty_like(perm)
+            rank[perm.long()] = torch.arange(perm.shape[0], dtype=torch.int32, device=c.device)
+            self._order = (perm, rank)
+        return self._order
+
+    def stale_from(self, prev):
+        """corner indices cached on `prev` (the first voxelisation of the same PointTensor) as the reference applies
+        them to THIS voxel set: row k of the hash-ordered old set -> row k of the hash-ordered new set"""
+        hit = self._stale.get(id(prev))
+        if hit is None:
+            lib = _lib.load()
+            assert prev.idx8 is not None, "the first SConv3d has not devoxelised yet"
+            perm_new, _ = self.sphash_order()
+            _, rank_old = prev.sphash_order()
+            out = torch.empty_like(prev.idx8)
+            _lib.check(lib.eprecon_remap_index_async(_lib.ptr(prev.idx8), prev.idx8.numel(), _lib.ptr(rank_old),
+                                                     _lib.ptr(perm_new), perm_new.shape[0], _lib.ptr(out),
+                                                     _lib.current_stream()), "eprecon_remap_index_async")
+            hit = (out, prev.w8, prev)   # `prev` kept alive: id() stays unique
+            self._stale[id(prev)] = hit
+        return hit[0], hit[1]
+
+
+_VOX_CACHE = []
+_VOX_CACHE_MAX = 6
+
+
+def clear_voxelization_cache():
+    _VOX_CACHE.clear()
+
+
+def _voxelize_points(pts, res):
+    key = (pts.data_ptr(), pts._version, pts.shape[0], float(res))
+    for e in _VOX_CACHE:
+        if e.key == key and e.pts is pts:
+            return e
+    lib = _lib.load()
+    n = pts.shape[0]
+    e = _VoxEntry()
+    e.key, e.pts = key, pts
+    e.scaled = torch.empty_like(pts)
+    e.vox = torch.empty((n, 4), dtype=torch.int32, device=pts.device)
+    _lib.check(lib.eprecon_point_quantize_async(_lib.ptr(pts), n, float(res), _lib.ptr(e.scaled), _lib.ptr(e.vox),
+                                                _lib.current_stream()), "eprecon_point_quantize_async")
+    uniq, e.inverse, grid = SP.unique_coords(e.vox, 1)
+    e.vset = SP.VoxelSet(uniq, 1, grid=grid)
+    e.lists = _segment_lists(e.inverse, e.vset.n)
+    e.idx8 = e.w8 = e._order = None
+    e._stale = {}
+    _VOX_CACHE.append(e)
+    if len(_VOX_CACHE) > _VOX_CACHE_MAX:
+        _VOX_CACHE.pop(0)
+    return e
+
+
 def initial_voxelize(z, init_res, after_res):
     """ops/torchsparse_utils.py:15-35: floor(z.C * init_res / after_res) -> unique voxels
-    (first-occurrence order) -> scatter-mean of z.F.  Overwrites z.C with the scaled coordinates."""
-    lib = _lib.load()
-    pts = z.C.contiguous()
-    n = pts.shape[0]
+    (first-occurrence order) -> scatter-mean of z.F.  Overwrites z.C with the scaled coordinates.
+
+    A second call on the same PointTensor (ConvGRU: convz then convr on `hx`, models/modules.py:214-217)
+    voxelises the already-scaled coordinates, and — like the reference, whose voxel_to_point finds
+    z.idx_query[1] / z.weights[1] filled by the first call (ops/torchsparse_utils.py:70-71,97-99) — keeps
+    devoxelising with the FIRST call's corner indices and weights, now pointing into the second voxel set
+    in torchsparse's ascending-hash voxel order (LITERAL_CONVR)."""
+    pts = z.C if z.C.is_contiguous() else z.C.contiguous()
     res = float(after_res) / float(init_res) if init_res != 1 else float(after_res)
-    scaled = torch.empty_like(pts)
-    vox = torch.empty((n, 4), dtype=torch.int32, device=pts.device)
-    _lib.check(lib.eprecon_point_quantize_async(_lib.ptr(pts), n, res, _lib.ptr(scaled), _lib.ptr(vox),
-                                                _lib.current_stream()), "eprecon_point_quantize_async")
-    uniq, inverse, grid = SP.unique_coords(vox, 1)
-    vset = SP.VoxelSet(uniq, 1, grid=grid)
-    lists = _segment_lists(inverse, vset.n)
-    feat = _segment_mean(z.F, lists, vset.n)
-    z.C, z.vox = scaled, vox
-    # a new voxel set invalidates every per-stride lookup cached on the points.  (The reference
-    # keeps them: a second SConv3d on the same PointTensor — ConvGRU's convr — devoxelises with the
-    # FIRST voxelisation's indices into the SECOND voxel set, whose order is torchsparse's
-    # hash order.  That cannot be reproduced and is not; see DESIGN.md "Known deviations".)
-    z.idx_query.clear()
-    z.weights.clear()
+    prev = getattr(z, "_vox_entry", None)
+    e = _voxelize_points(pts, res)
+    feat = _segment_mean(z.F, e.lists, e.vset.n)
+    z.C, z.vox = e.scaled, e.vox
+    if prev is not None and LITERAL_CONVR and 1 in z.idx_query:
+        z.idx_query[1], z.weights[1] = e.stale_from(prev)
+    else:
+        z.idx_query.clear()
+        z.weights.clear()
+        if e.idx8 is not None:
+            z.idx_query[1], z.weights[1] = e.idx8, e.w8
     z.additional_features["idx_query"].clear()
     z.additional_features["lists"].clear()
-    z.additional_features["idx_query"][1] = inverse
-    z.additional_features["lists"][1] = lists
-    return SparseTensor(feat, vset)
+    z.additional_features["idx_query"][1] = e.inverse
+    z.additional_features["lists"][1] = e.lists
+    z._vox_entry = e
+    return SparseTensor(feat, e.vset)
 
 
 def point_to_voxel(x, z, out=None):
@@ -92,6 +174,25 @@ def point_to_voxel(x, z, out=None):
     return SparseTensor(_segment_mean(z.F, lists, x.vset.n, out), x.vset)
 
 
+def _corner_tables(vset, s, z):
+    """8-corner indices / renormalised trilinear weights of the points of z against `vset` at tensor stride s,
+    cached on the PointTensor like the reference's z.idx_query / z.weights (ops/torchsparse_utils.py:70-96)"""
+    if s not in z.idx_query:
+        lib = _lib.load()
+        n = z.C.shape[0]
+        idx8 = torch.empty((n, 8), dtype=torch.int32, device=z.C.device)
+        w8 = torch.empty((n, 8), dtype=torch.float32, device=z.C.device)
+        grid = vset.grid
+        _lib.check(lib.eprecon_trilinear_map_async(_lib.ptr(grid.mem), grid.capacity, _lib.ptr(z.C), n, s,
+                                                   _lib.ptr(idx8), _lib.ptr(w8), _lib.current_stream()),
+                   "eprecon_trilinear_map_async")
+        z.idx_query[s], z.weights[s] = idx8, w8
+        e = getattr(z, "_vox_entry", None)
+        if s == 1 and e is not None and e.vset is vset and e.idx8 is None:
+            e.idx8, e.w8 = idx8, w8   # shared with the other SConv3d that voxelise the same points
+    return z.idx_query[s], z.weights[s]
+
+
 def voxel_to_point(x, z, nearest=False, out=None, accumulate=False):
     """ops/torchsparse_utils.py:68-105: trilinear interpolation of the voxel features of x at the
     points of z (weights renormalised over the corners that exist)."""
@@ -99,14 +200,7 @@ def voxel_to_point(x, z, nearest=False, out=None, accumulate=False):
     lib = _lib.load()
     s = x.s
     n = z.C.shape[0]
-    if s not in z.idx_query:
-        idx8 = torch.empty((n, 8), dtype=torch.int32, device=z.C.device)
-        w8 = torch.empty((n, 8), dtype=torch.float32, device=z.C.device)
-        grid = x.vset.grid
-        _lib.check(lib.eprecon_trilinear_map_async(_lib.ptr(grid.mem), grid.capacity, _lib.ptr(z.C), n, s,
-                                                   _lib.ptr(idx8), _lib.ptr(w8), _lib.current_stream()),
-                   "eprecon_trilinear_map_async")
-        z.idx_query[s], z.weights[s] = idx8, w8
+    _corner_tables(x.vset, s, z)
     c = x.F.shape[1]
     if out is None:
         out = torch.empty((n, c), dtype=torch.float32, device=x.F.device)
@@ -116,4 +210,22 @@ def voxel_to_point(x, z, nearest=False, out=None, accumulate=False):
     new = PointTensor(out, z.C, idx_query=z.idx_query, weights=z.weights)
     new.vox = z.vox
     new.additional_features = z.additional_features
+    new._vox_entry = getattr(z, "_vox_entry", None)
     return new
+
+
+def devoxelize_gate(x, z, skip, mode, h=None, zgate=None, out=None):
+    """voxel_to_point(x, z).F + skip followed by the ConvGRU gate arithmetic, one launch
+    (eprecon_devoxelize_gate_async; mode 1 sigmoid, 2 sigmoid * h, 3 (1 - zgate) * h + zgate * tanh)"""
+    lib = _lib.load()
+    s = x.s
+    n, c = z.C.shape[0], x.F.shape[1]
+    _corner_tables(x.vset, s, z)
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=x.F.device)
+    _lib.check(lib.eprecon_devoxelize_gate_async(
+        _lib.ptr(x.F), x.F.stride(0), _lib.ptr(z.idx_query[s]), _lib.ptr(z.weights[s]), n, c, _lib.ptr(skip),
+        skip.stride(0), int(mode), _lib.ptr(h), h.stride(0) if h is not None else 0, _lib.ptr(zgate),
+        zgate.stride(0) if zgate is not None else 0, _lib.ptr(out), out.stride(0), _lib.current_stream()),
+        "eprecon_devoxelize_gate_async")
+    return out

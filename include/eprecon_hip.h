@@ -323,6 +323,19 @@ int eprecon_segment_lists_async(const int32_t *idx, int64_t n, int64_t m, int32_
  * without float atomics */
 int eprecon_segment_mean_async(const float *feat, int ld_feat, const int32_t *offsets, const int32_t *order,
                                int64_t m, int channels, float *out, int ld_out, void *stream);
+/*
+ * Voxel ORDER of the reference.  torchsparse numbers the voxels of initial_voxelize by ascending
+ * F.sphash (`torch.unique(pc_hash)`, ops/torchsparse_utils.py:19-21); nothing depends on that order
+ * except ConvGRU's second gate convolution (models/modules.py:216-217), which devoxelises with the
+ * corner indices cached by the first voxelisation of the same PointTensor into the second voxel
+ * set (ops/torchsparse_utils.py:70-71,97-99).  eprecon_sphash_async returns torchsparse's 60-bit
+ * FNV-1a hash of every (b,x,y,z) row (hashed in x,y,z,b order); the caller sorts it.
+ * eprecon_remap_index_async rewrites cached indices:  out = perm_new[rank_old[idx]]  (-1 stays -1;
+ * a rank >= m_new, an out-of-bounds read in the reference, becomes -1).
+ */
+int eprecon_sphash_async(const int32_t *coords, int64_t n, int64_t *out_hash, void *stream);
+int eprecon_remap_index_async(const int32_t *idx, int64_t n, const int32_t *rank_old, const int32_t *perm_new,
+                              int64_t m_new, int32_t *out, void *stream);
 /* 8-corner indices int32[n,8] and renormalised trilinear weights f32[n,8] of points (in voxel
  * units) against the voxel set the table was built on, at tensor stride `stride` */
 int eprecon_trilinear_map_async(const void *table, uint32_t capacity, const float *points_xyzb, int64_t n,
@@ -330,6 +343,20 @@ int eprecon_trilinear_map_async(const void *table, uint32_t capacity, const floa
 /* out[i] (+)= sum_k weight8[i,k] * voxel_feat[idx8[i,k]] */
 int eprecon_devoxelize_async(const float *voxel_feat, int ld_feat, const int32_t *idx8, const float *weight8,
                              int64_t n, int channels, float *out, int ld_out, int accumulate, void *stream);
+
+/*
+ * The tail of SConv3d inside ConvGRU (models/modules.py:193-196,214-221) in one launch:
+ * v = devoxelise(voxel_feat) + skip  (skip = the point-wise Linear of SConv3d), then
+ *   mode 1: out = sigmoid(v)                    mode 2: out = sigmoid(v) * h
+ *   mode 3: out = (1 - zgate) * h + zgate * tanh(v)
+ * out may be a column slice of the [r*h, x] concat buffer.
+ */
+#define EPRECON_GATE_SIGMOID 1
+#define EPRECON_GATE_SIGMOID_MUL 2
+#define EPRECON_GATE_GRU_MIX 3
+int eprecon_devoxelize_gate_async(const float *voxel_feat, int ld_feat, const int32_t *idx8, const float *weight8,
+                                  int64_t n, int channels, const float *skip, int ld_skip, int mode, const float *h,
+                                  int ld_h, const float *zgate, int ld_z, float *out, int ld_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * GRU-fusion union  (K15)

@@ -81,20 +81,44 @@ def devoxelize(vfeat, idx, w):
     return out
 
 
+def sphash(coords_bxyz):
+    """torchsparse F.sphash (ops/torchsparse_utils.py:19; kernel recalled from torchsparse 1.4,
+    SURVEY.md appendix A.2): 64-bit FNV-1a over the int32 (x, y, z, batch) of a row, folded to 60 bits"""
+    c = np.asarray(coords_bxyz, np.int32)[:, [1, 2, 3, 0]]
+    h = np.full(len(c), 14695981039346656037, np.uint64)
+    with np.errstate(over="ignore"):
+        for j in range(4):
+            h ^= c[:, j].astype(np.uint32).astype(np.uint64)
+            h *= np.uint64(1099511628211)
+    h = (h >> np.uint64(60)) ^ (h & np.uint64(0x0FFFFFFFFFFFFFFF))
+    return h.astype(np.int64)
+
+
 class Points:
     """PointTensor stand-in: F f32[N,C], C f32[N,4] (xyzb) + the voxel-unit coordinates cached by
-    initial_voxelize (which overwrites z.C in the reference, ops/torchsparse_utils.py:33)"""
+    initial_voxelize (which overwrites z.C in the reference, ops/torchsparse_utils.py:33) and the
+    per-stride idx_query / weights caches of voxel_to_point (ops/torchsparse_utils.py:69-71,94-96)"""
 
     def __init__(self, F, C):
         self.F, self.C = np.asarray(F, F32), np.asarray(C, F32)
         self.vox = None  # int32[N,4] bxyz at stride 1 (floor of the scaled coords)
+        self.idx_query, self.weights = {}, {}
 
 
-def initial_voxelize(z, init_res, after_res):
-    """-> (voxel coords int32[M,4], voxel feats f32[M,C], idx_query int32[N]); mutates z.C"""
+def initial_voxelize(z, init_res, after_res, hash_order=False):
+    """-> (voxel coords int32[M,4], voxel feats f32[M,C], idx_query int32[N]); mutates z.C.
+    hash_order: number the voxels by ascending sphash like the reference (`torch.unique(pc_hash)`,
+    ops/torchsparse_utils.py:20) instead of by first occurrence.  The caches on z are NOT cleared (the
+    reference never clears them), which is what makes a second SConv3d on the same points reuse the first
+    one's corner indices."""
     res = F32(after_res) / F32(init_res) if init_res != 1 else F32(after_res)
     scaled, vox = point_quantize(z.C, res)
     uniq, inv = OS.unique_first(vox, 1)
+    if hash_order:
+        perm = np.argsort(sphash(uniq), kind="stable")
+        rank = np.empty_like(perm)
+        rank[perm] = np.arange(len(perm))
+        uniq, inv = uniq[perm], rank[inv]
     z.C, z.vox = scaled, vox
     return uniq, segment_mean(z.F, inv, len(uniq)), inv
 
@@ -105,6 +129,15 @@ def point_to_voxel(vox_coords, stride, z, feat):
     return segment_mean(feat, idx, len(vox_coords))
 
 
-def voxel_to_point(vox_coords, stride, vfeat, z):
-    idx, w = trilinear(vox_coords, stride, z.C)
+def voxel_to_point(vox_coords, stride, vfeat, z, reuse_cached=False):
+    """reuse_cached: behave like the reference's voxel_to_point, which takes z.idx_query[stride] /
+    z.weights[stride] when present (ops/torchsparse_utils.py:69-71,97-99) whatever voxel set they were
+    computed for; indices beyond the current set (out-of-bounds reads in the reference) contribute 0."""
+    if reuse_cached and stride in z.idx_query:
+        idx, w = z.idx_query[stride], z.weights[stride]
+        idx = np.where(idx < len(vfeat), idx, -1)
+    else:
+        idx, w = trilinear(vox_coords, stride, z.C)
+        if reuse_cached:
+            z.idx_query[stride], z.weights[stride] = idx, w
     return devoxelize(vfeat, idx, w)

@@ -76,12 +76,14 @@ def spvcnn_forward(sd, feat, coords_xyzb, pres, vres):
     return PV.voxel_to_point(l1.coords, 1, y4, z) + point_mlp(sd, "point_transforms.1", z1)
 
 
-def sconv3d(sd, p, z, pres, vres):
-    """models/modules.py:178-197: voxelise (overwrites z.C!) -> Conv3d k3 -> devoxelise + Linear(z.F)"""
-    c0, x, _ = PV.initial_voxelize(z, pres, vres)
+def sconv3d(sd, p, z, pres, vres, literal=True):
+    """models/modules.py:178-197: voxelise (overwrites z.C!) -> Conv3d k3 -> devoxelise + Linear(z.F).
+    literal: voxels numbered in torchsparse's hash order and voxel_to_point reusing whatever corner
+    indices are cached on z — what the reference does; False: every call uses its own indices."""
+    c0, x, _ = PV.initial_voxelize(z, pres, vres, hash_order=literal)
     lvl = Level(c0, 1)
     x = OS.sparse_conv(x, lvl.k3, sd[p + ".net.kernel"])
-    out = PV.voxel_to_point(lvl.coords, 1, x, z)
+    out = PV.voxel_to_point(lvl.coords, 1, x, z, reuse_cached=literal)
     return out + z.F @ sd[p + ".point_transforms.0.weight"].T + sd[p + ".point_transforms.0.bias"]
 
 
@@ -89,12 +91,14 @@ def _sigmoid(x):
     return (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(F32)
 
 
-def convgru(sd, p, h, x, coords_xyzb, pres, vres):
+def convgru(sd, p, h, x, coords_xyzb, pres, vres, literal=True):
     """models/modules.py:200-222.  `hx` is voxelised twice (convz, then convr on the coordinates
-    convz already divided by vres) exactly as the reference's in-place z.C update implies."""
+    convz already divided by vres) exactly as the reference's in-place z.C update implies; with
+    `literal`, convr also devoxelises with the corner indices / weights convz cached on hx
+    (ops/torchsparse_utils.py:70-71,97-99), which then address the SECOND voxel set in hash order."""
     hx = PV.Points(np.concatenate([h, x], 1), coords_xyzb)
-    zg = _sigmoid(sconv3d(sd, p + ".convz", hx, pres, vres))
-    rg = _sigmoid(sconv3d(sd, p + ".convr", hx, pres, vres))  # hx.C already scaled once
+    zg = _sigmoid(sconv3d(sd, p + ".convz", hx, pres, vres, literal))
+    rg = _sigmoid(sconv3d(sd, p + ".convr", hx, pres, vres, literal))  # hx.C already scaled once
     xq = PV.Points(np.concatenate([rg * h, x], 1), coords_xyzb)
-    q = np.tanh(sconv3d(sd, p + ".convq", xq, pres, vres).astype(np.float64)).astype(F32)
+    q = np.tanh(sconv3d(sd, p + ".convq", xq, pres, vres, literal).astype(np.float64)).astype(F32)
     return ((1 - zg) * h + zg * q).astype(F32)

@@ -97,10 +97,31 @@ def test_spvcnn_matches_oracle(stage, cin, n):
     assert err < TOL, err
 
 
+def test_sphash_order_matches_oracle():
+    """torchsparse's voxel order (ascending F.sphash): HIP hash == numpy restatement, negative coordinates
+    included; the sorted order is what ConvGRU's stale-index reuse depends on"""
+    from eprecon_amd import _lib
+    rng = np.random.default_rng(12)
+    c = np.unique(np.concatenate([np.zeros((5000, 1), np.int64), rng.integers(-700, 2500, (5000, 3))], 1), axis=0)
+    c = c.astype(np.int32)
+    lib = _lib.load()
+    ct = dev(c)
+    h = torch.empty(len(c), dtype=torch.int64, device="cuda")
+    _lib.check(lib.eprecon_sphash_async(_lib.ptr(ct), len(c), _lib.ptr(h), _lib.current_stream()), "sphash")
+    ref = PV.sphash(c)
+    assert np.array_equal(h.cpu().numpy(), ref) and (ref >= 0).all() and len(np.unique(ref)) == len(ref)
+
+
+@pytest.mark.parametrize("literal", [True, False])
 @pytest.mark.parametrize("ch,scale", [(96, 0), (24, 2)])
-def test_convgru_matches_oracle(ch, scale):
+def test_convgru_matches_oracle(ch, scale, literal, monkeypatch):
+    """literal: convr devoxelises with convz's cached corner indices into its own (finer) voxel set in
+    torchsparse's hash order, as the reference does (ops/torchsparse_utils.py:70-71,97-99)"""
+    from eprecon_amd import torchsparse_utils as TU
     from eprecon_amd.modules import ConvGRU
     from eprecon_amd.tensor import PointTensor
+    monkeypatch.setattr(TU, "LITERAL_CONVR", literal)
+    TU.clear_voxelization_cache()
     interval, vres = 2 ** (2 - scale), 0.04 * 2 ** (2 - scale)
     window, coords = shell_coords(7 + scale, interval, 8000)
     pts = PV.aligned_coords(coords, window["vol_origin_partial"][None], 0.04, window["world_to_aligned_camera"][None])
@@ -114,6 +135,8 @@ def test_convgru_matches_oracle(ch, scale):
         coords_t = dev(pts)
         out = gru(PointTensor(dev(h), coords_t), PointTensor(dev(x), coords_t)).cpu().numpy()
     sd = {"g." + k: v for k, v in _sd(gru).items()}
-    ref = ON.convgru(sd, "g", h, x, pts, 1, vres)
+    ref = ON.convgru(sd, "g", h, x, pts, 1, vres, literal=literal)
     err = np.abs(out - ref).max()
     assert err < TOL, err
+    other = ON.convgru(sd, "g", h, x, pts, 1, vres, literal=not literal)
+    assert np.abs(other - ref).max() > 10 * TOL      # the two behaviours are distinguishable

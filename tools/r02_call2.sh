@@ -1,0 +1,9 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r02b
+mkdir -p $O
+cd $R
+timeout 1800 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+tail -15 $O/pytest.log
+timeout 300 python bench.py --workload cfg4 --steps 24 --warmup 8 > $O/bench_cfg4.json 2> $O/bench_cfg4.err; cat $O/bench_cfg4.json
+timeout 300 python tools/profile_cfg4_stages.py 3 > $O/stages_cfg4.txt 2>&1; cat $O/stages_cfg4.txt
