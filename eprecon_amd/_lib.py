@@ -66,6 +66,17 @@ SIGNATURES = {
     "eprecon_fbv_union_workspace_bytes": (_sz, [_i]),
     "eprecon_fbv_union_async": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _vp, _sz, _vp]),
+    "eprecon_map_create": (_i, [_i, _c.POINTER(_vp)]),
+    "eprecon_map_destroy": (_i, [_vp]),
+    "eprecon_map_reset": (_i, [_vp]),
+    "eprecon_map_size": (_i64, [_vp]),
+    "eprecon_map_channels": (_i, [_vp]),
+    "eprecon_map_export_async": (_i, [_vp, _vp, _vp, _vp]),
+    "eprecon_map_import_async": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "eprecon_map_crop_union": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "eprecon_map_gather_async": (_i, [_vp, _vp, _i64, _i, _i, _f, _vp, _i, _vp]),
+    "eprecon_map_update_async": (_i, [_vp, _vp, _i64, _vp, _i, _vp]),
+    "eprecon_map_target_fuse": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i64, _vp, _vp]),
     "eprecon_gather_rows_async": (_i, [_vp, _i, _vp, _i64, _i, _f, _vp, _i, _vp]),
     "eprecon_nearest_voxel_async": (_i, [_vp, _c.c_uint32, _vp, _i64, _vp, _i64, _i, _vp, _vp]),
     "eprecon_upsample2x_nhwc_async": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -118,12 +129,21 @@ def check(rc, what):
 
 
 def ptr(t):
-    """device pointer of a torch tensor (or None)"""
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    """device pointer of a torch tensor (or None) as the plain int ctypes converts to void*"""
+    return None if t is None else t.data_ptr()
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
 def current_stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """hipStream_t of torch's current stream on the current device, as an int.  The raw getter is used when this
+    torch build has it: torch.cuda.current_stream() builds a Stream object and costs ~8 us per call, which at
+    ~5,000 launches per fragment was 3.7 ms of host time per fragment (tools/hostprof_cfg4.py)."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device()) or None
+    return torch.cuda.current_stream().cuda_stream or None
 
 
 class ConvDesc(ctypes.Structure):
@@ -152,7 +172,7 @@ _WORKSPACES = {}
 def workspace(nbytes, device):
     """grow-only scratch buffer per (device, current stream): operators issued on different streams
     (the per-level branches of the 2D stack, the pipelined back-projections) never share scratch"""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.type, device.index, current_stream())
     buf = _WORKSPACES.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)

@@ -1,0 +1,109 @@
+"""Persistent sparse global map of GRU fusion: Python face of the eprecon_map_* handle
+(csrc/global_map.hip), the one stateful object of the C ABI (SURVEY.md 8b "Ownership").
+
+Mirrors the state the reference keeps in GRUFusion.global_volume[scale] / target_tsdf_volume[scale]
+(models/gru_fusion.py:31-38) and the per-fragment bookkeeping of convert2dense / update_map
+(:67-114,195-215).  `.C` / `.F` export copies of the rows (tests, the multi-GPU boundary exchange);
+`.set(C, F)` replaces the contents.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class GlobalMap:
+    def __init__(self, channels, device):
+        lib = _lib.load()
+        self.channels, self.device = int(channels), device
+        h = ctypes.c_void_p()
+        _lib.check(lib.eprecon_map_create(self.channels, ctypes.byref(h)), "eprecon_map_create")
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.load().eprecon_map_destroy(h)
+            except Exception:  # interpreter shutdown
+                pass
+
+    def reset(self):
+        _lib.check(_lib.load().eprecon_map_reset(self._h), "eprecon_map_reset")
+
+    @property
+    def size(self):
+        return int(_lib.load().eprecon_map_size(self._h))
+
+    def export(self):
+        n = self.size
+        c = torch.empty((n, 3), dtype=torch.int32, device=self.device)
+        f = torch.empty((n, self.channels), dtype=torch.float32, device=self.device)
+        _lib.check(_lib.load().eprecon_map_export_async(self._h, _lib.ptr(c), _lib.ptr(f), _lib.current_stream()),
+                   "eprecon_map_export_async")
+        return c, f
+
+    @property
+    def C(self):
+        return self.export()[0]
+
+    @property
+    def F(self):
+        return self.export()[1]
+
+    @F.setter
+    def F(self, feats):
+        self.set(self.export()[0], feats)
+
+    def set(self, coords, feats):
+        coords = coords.to(device=self.device, dtype=torch.int32).contiguous()
+        feats = feats.to(device=self.device, dtype=torch.float32).contiguous()
+        assert coords.shape[0] == feats.shape[0] and feats.shape[1] == self.channels
+        _lib.check(_lib.load().eprecon_map_import_async(self._h, _lib.ptr(coords), _lib.ptr(feats), coords.shape[0],
+                                                        _lib.current_stream()), "eprecon_map_import_async")
+
+    def crop_union(self, cur_coords, cur_feat, dim, interval, rel, mode=0):
+        """-> (updated int32[N',3], src_cur int32[N'], src_glob int32[N'], rows of the map inside the FBV).
+        Blocking (one host read for N', where the reference's torch.nonzero synchronises too)."""
+        lib = _lib.load()
+        n_cur = cur_feat.shape[0]
+        cap = max(min(dim ** 3, n_cur + self.size), 1)
+        dev = self.device
+        updated = torch.empty((cap, 3), dtype=torch.int32, device=dev)
+        src_cur = torch.empty(cap, dtype=torch.int32, device=dev)
+        src_glob = torch.empty(cap, dtype=torch.int32, device=dev)
+        rel_host = (ctypes.c_int32 * 3)(*[int(v) for v in rel])
+        counts = (ctypes.c_int64 * 2)()
+        _lib.check(lib.eprecon_map_crop_union(
+            self._h, _lib.ptr(cur_coords), _lib.ptr(cur_feat), n_cur, cur_feat.stride(0) if n_cur else self.channels,
+            dim, interval, int(mode), ctypes.cast(rel_host, ctypes.c_void_p), _lib.ptr(updated), _lib.ptr(src_cur),
+            _lib.ptr(src_glob), ctypes.cast(counts, ctypes.c_void_p), _lib.current_stream()), "eprecon_map_crop_union")
+        n = int(counts[0])
+        return updated[:n], src_cur[:n], src_glob[:n], int(counts[1])
+
+    def gather(self, src_glob, col0, channels, out, fill=0.0):
+        """out[i] = map.F[src_glob[i], col0:col0+channels] (fill where src_glob[i] < 0); out may be a column slice"""
+        _lib.check(_lib.load().eprecon_map_gather_async(self._h, _lib.ptr(src_glob), src_glob.shape[0], int(col0),
+                                                        int(channels), float(fill), _lib.ptr(out), out.stride(0),
+                                                        _lib.current_stream()), "eprecon_map_gather_async")
+        return out
+
+    def update(self, updated, values):
+        """update_map (models/gru_fusion.py:195-215) after crop_union: rows inside the FBV are replaced by
+        (updated + relative origin, values)"""
+        _lib.check(_lib.load().eprecon_map_update_async(self._h, _lib.ptr(updated), updated.shape[0], _lib.ptr(values),
+                                                        values.stride(0), _lib.current_stream()),
+                   "eprecon_map_update_async")
+
+    def target_fuse(self, tsdf_gt, occ_gt, dim, rel, updated):
+        """ground-truth twin (1 channel): -> tsdf_target f32[N',1] at the union voxels; the map is updated"""
+        lib = _lib.load()
+        tsdf_gt = tsdf_gt.to(torch.float32).contiguous()
+        occ_u8 = occ_gt.contiguous().view(torch.uint8) if occ_gt.dtype == torch.bool else occ_gt.to(torch.uint8).contiguous()
+        out = torch.empty((updated.shape[0], 1), dtype=torch.float32, device=self.device)
+        rel_host = (ctypes.c_int32 * 3)(*[int(v) for v in rel])
+        _lib.check(lib.eprecon_map_target_fuse(self._h, _lib.ptr(tsdf_gt), _lib.ptr(occ_u8), dim,
+                                               ctypes.cast(rel_host, ctypes.c_void_p), _lib.ptr(updated), updated.shape[0],
+                                               _lib.ptr(out), _lib.current_stream()), "eprecon_map_target_fuse")
+        return out

@@ -6,7 +6,8 @@ scale), F f32[M,C]} plus its ground-truth TSDF twin (the reference's test path r
 models/neucon_network.py:488).  One fragment step (per batch element):
 
   relative origin -> union of current voxels and the in-FBV part of the map, raster order
-  (csrc/fbv_union.hip: index volumes + scan, no dense feature volume) -> gather current / global
+  (the map is a C-ABI handle, eprecon_amd/global_map.py + csrc/global_map.hip: index volumes + scan, no dense
+  feature volume, no per-fragment re-allocation) -> gather current / global
   rows -> aligned-camera coordinates -> ConvGRU on the voxel channels and ConvGRU on the image
   channels (eprecon_amd.modules.ConvGRU) -> write the fused rows back into the map.
 
@@ -17,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .global_map import GlobalMap
 from .modules import ConvGRU
 from .tensor import PointTensor
 from .torchsparse_utils import aligned_camera_coords
@@ -65,12 +67,6 @@ def gather_rows(feat, src, channels, fill=0.0, out=None):
     return out
 
 
-class _Map:
-    def __init__(self, channels, device):
-        self.C = torch.zeros((0, 3), dtype=torch.int32, device=device)
-        self.F = torch.zeros((0, channels), dtype=torch.float32, device=device)
-
-
 class GRUFusion(nn.Module):
     def __init__(self, cfg, ch_in=None, direct_substitute=False, trianing=True, ch_voxel=None):
         super().__init__()
@@ -102,21 +98,37 @@ class GRUFusion(nn.Module):
         self._identity_fusion = False  # tests: skip the ConvGRUs (pins the bookkeeping alone)
 
     def reset(self, i, device=None):
+        """models/gru_fusion.py:59-65: empty maps (the handles keep their device memory)"""
         device = device or torch.device("cuda")
-        self.global_volume[i] = _Map(self.ch_in[i], device)
-        self.target_tsdf_volume[i] = _Map(1, device)
+        if self.global_volume[i] is None or self.global_volume[i].device != device:
+            self.global_volume[i] = GlobalMap(self.ch_in[i], device)
+            self.target_tsdf_volume[i] = GlobalMap(1, device)
+        self.global_volume[i].reset()
+        self.target_tsdf_volume[i].reset()
 
     def _begin_fragment(self, scale, inputs, i, dev):
         """scene bookkeeping of models/gru_fusion.py:280-293 -> relative origin (LongTensor[3], host)"""
         scene = inputs["scene"][i]
+        vol_origin, partial = self._host_origins(inputs)
         if self.scene_name[scale] is None or scene != self.scene_name[scale]:
             self.scene_name[scale] = scene
             self.reset(scale, dev)
-            self.global_origin[scale] = inputs["vol_origin"][i].detach().float().cpu()
+            self.global_origin[scale] = vol_origin[i].clone()
         interval = 2 ** (self.cfg.N_LAYER - scale - 1)
-        origin = inputs["vol_origin_partial"][i]
         # (origin - global_origin) / voxel_size in fp32, truncated toward zero (:292-293)
-        return ((origin.detach().float().cpu() - self.global_origin[scale]) / (self.cfg.VOXEL_SIZE * interval)).long()
+        return ((partial[i] - self.global_origin[scale]) / (self.cfg.VOXEL_SIZE * interval)).long()
+
+    def _host_origins(self, inputs):
+        """host copies of inputs['vol_origin'] / ['vol_origin_partial'] (f32[B,3]), fetched once per fragment
+        instead of once per scale (each .cpu() is a device synchronisation)"""
+        vo, vp = inputs["vol_origin"], inputs["vol_origin_partial"]
+        key = (vo.data_ptr(), vo._version, vp.data_ptr(), vp._version)
+        hit = getattr(self, "_origin_cache", None)
+        if hit is None or hit[0] != key or hit[1] is not vo or hit[2] is not vp:
+            both = torch.stack([vo.detach().float().reshape(-1, 3), vp.detach().float().reshape(-1, 3)]).cpu()
+            hit = (key, vo, vp, both[0], both[1])
+            self._origin_cache = hit
+        return hit[3], hit[4]
 
     def exchange_boundaries(self, inputs, i=0):
         """Multi-GPU schedule (eprecon_amd/distributed.py): before this fragment is fused, pull in the
@@ -128,24 +140,7 @@ class GRUFusion(nn.Module):
             rel = self._begin_fragment(scale, inputs, i, dev)
             dim = self.cfg.N_VOX[0] // 2 ** (self.cfg.N_LAYER - scale - 1)
             gmap = self.global_volume[scale]
-            gmap.C, gmap.F = D.exchange_boundary_voxels(gmap.C, gmap.F, rel.tolist(), dim)
-
-    # ---- ground-truth twin (1 channel, dense [D,D,D] is 3.5 MB at most): plain tensor indexing ----
-    def _fuse_targets(self, scale, occ_target, tsdf_volume, rel_t, dim):
-        tmap = self.target_tsdf_volume[scale]
-        local = tmap.C - rel_t
-        tvalid = ((local >= 0) & (local < dim)).all(dim=1)
-        vol = torch.ones((dim, dim, dim), dtype=torch.float32, device=tsdf_volume.device)
-        sel = local[tvalid].long()
-        vol[sel[:, 0], sel[:, 1], sel[:, 2]] = tmap.F[tvalid, 0]
-        vol[occ_target] = tsdf_volume[occ_target]  # the current fragment's ground truth wins
-        return vol, tvalid
-
-    def _update_targets(self, scale, vol, tvalid, rel_t):
-        tmap = self.target_tsdf_volume[scale]
-        keep = vol.abs() < 1
-        tmap.F = torch.cat([tmap.F[~tvalid], vol[keep].unsqueeze(-1)])
-        tmap.C = torch.cat([tmap.C[~tvalid], torch.nonzero(keep).to(torch.int32) + rel_t])
+            gmap.set(*D.exchange_boundary_voxels(*gmap.export(), rel.tolist(), dim))
 
     def forward(self, coords, values_in, inputs, scale=2, outputs=None, save_mesh=False, panoptic_infos=None):
         """coords int[N,4] (b,x,y,z) finest units, values_in f32[N,C] ->
@@ -162,37 +157,36 @@ class GRUFusion(nn.Module):
         coords = coords if coords.dtype == torch.int32 else coords.to(torch.int32)
         chv = self.ch_voxel[scale]
         out_c, out_v, out_t, out_o = [], [], [], []
-        batch_col = coords[:, 0]
+        if batch_size == 1:
+            bounds = [0, coords.shape[0]]
+        else:  # rows are grouped by ascending batch index (models/neucon_network.py:246-251): one host read
+            bounds = [0] + torch.cumsum(torch.bincount(coords[:, 0].long(), minlength=batch_size), 0).tolist()
         for i in range(batch_size):
             rel = self._begin_fragment(scale, inputs, i, dev)
             origin = inputs["vol_origin_partial"][i]
-            rel_t = rel.to(device=dev, dtype=torch.int32)
-            rows = torch.nonzero(batch_col == i).squeeze(1)
-            if rows.numel() == 0:
+            lo, hi = bounds[i], bounds[i + 1]
+            if hi == lo:
                 continue
-            lo, hi = int(rows[0]), int(rows[-1]) + 1  # rows of one batch element are contiguous
-            cur_c, cur_f = coords[lo:hi].contiguous(), values_in[lo:hi].contiguous()
+            cur_c, cur_f = coords[lo:hi], values_in[lo:hi]
             gmap = self.global_volume[scale]
-            updated, src_cur, src_glob, gvalid = fbv_union(cur_c, cur_f, gmap.C, gmap.F, dim, interval, rel.tolist())
+            rel_l = rel.tolist()
+            updated, src_cur, src_glob, _ = gmap.crop_union(cur_c, cur_f, dim, interval, rel_l)
             # current / global rows gathered straight into the [h | x] buffers of the two ConvGRUs (voxel channels
             # and image channels): h = the map's row, x = the fragment's row; no concat / slice copies afterwards
             n_u, cin = updated.shape[0], self.ch_in[scale]
             chi = cin - chv
             hx_v = torch.empty((n_u, 2 * chv), dtype=torch.float32, device=dev)
             hx_i = torch.empty((n_u, 2 * chi), dtype=torch.float32, device=dev)
-            gF = gmap.F if gmap.F.shape[0] > 0 else None
-            gather_rows(gF[:, :chv] if gF is not None else None, src_glob, chv, out=hx_v[:, :chv])
-            gather_rows(gF[:, chv:] if gF is not None else None, src_glob, chi, out=hx_i[:, :chi])
+            gmap.gather(src_glob, 0, chv, hx_v[:, :chv])
+            gmap.gather(src_glob, chv, chi, hx_i[:, :chi])
             gather_rows(cur_f[:, :chv], src_cur, chv, out=hx_v[:, chv:])
             gather_rows(cur_f[:, chv:], src_cur, chi, out=hx_i[:, chi:])
 
-            tsdf_target = occ_target = vol = tvalid = None
+            tsdf_target = occ_target = None
             if "occ_list" in inputs:
                 lvl = cfg.N_LAYER - scale - 1
-                occ_gt = inputs["occ_list"][lvl][i]
-                vol, tvalid = self._fuse_targets(scale, occ_gt, inputs["tsdf_list"][lvl][i], rel_t, dim)
-                u = updated.long()
-                tsdf_target = vol[u[:, 0], u[:, 1], u[:, 2]].unsqueeze(-1)
+                tsdf_target = self.target_tsdf_volume[scale].target_fuse(
+                    inputs["tsdf_list"][lvl][i], inputs["occ_list"][lvl][i], dim, rel_l, updated)
                 occ_target = tsdf_target.abs() < 1
 
             values = torch.empty((n_u, cin), dtype=torch.float32, device=dev)
@@ -208,11 +202,7 @@ class GRUFusion(nn.Module):
             else:
                 values[:, :chv], values[:, chv:] = hx_v[:, chv:], hx_i[:, chi:]
 
-            # update_map (:195-215)
-            gmap.F = torch.cat([gmap.F[~gvalid], values.detach()])
-            gmap.C = torch.cat([gmap.C[~gvalid], updated + rel_t])
-            if vol is not None:
-                self._update_targets(scale, vol, tvalid, rel_t)
+            gmap.update(updated, values)    # update_map (:195-215)
 
             out_c.append(torch.cat([torch.full_like(updated[:, :1], i), updated * interval], dim=1))
             out_v.append(values)

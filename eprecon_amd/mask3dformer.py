@@ -63,6 +63,32 @@ class _Attention(nn.Module):
         upd = attn(query=q, key=k, value=memory, attn_mask=attn_mask)[0]
         return self.norm(tgt + upd)
 
+    def project_kv(self, key_in, value_in):
+        """in-projection of the keys / values of one level ([N, 1, C] each) -> per-head [1, H, N, C/H] tensors"""
+        attn = getattr(self, self._name)
+        c, h = attn.embed_dim, attn.num_heads
+        w, b = attn.in_proj_weight, attn.in_proj_bias
+        k = F.linear(key_in.squeeze(1), w[c:2 * c], b[c:2 * c])
+        v = F.linear(value_in.squeeze(1), w[2 * c:], b[2 * c:])
+        split = lambda t: t.view(t.shape[0], h, c // h).transpose(0, 1).unsqueeze(0)
+        return split(k), split(v)
+
+    def attend(self, tgt, query_pos, kv, blocked=None):
+        """the same block on pre-projected keys / values with ONE [Q, N] mask shared by all heads (the reference
+        repeats it per head, models/mask3dformer.py:441-443): nn.MultiheadAttention's arithmetic
+        (scaled q . k, blocked logits = -inf, softmax, weighted values, out-projection) through SDPA, without the
+        head-averaged attention weights the module would also return.  blocked: bool[Q, N], True = masked."""
+        attn = getattr(self, self._name)
+        c, h = attn.embed_dim, attn.num_heads
+        w, b = attn.in_proj_weight, attn.in_proj_bias
+        q = F.linear((tgt + query_pos).squeeze(1), w[:c], b[:c])
+        q = q.view(q.shape[0], h, c // h).transpose(0, 1).unsqueeze(0)
+        allowed = None if blocked is None else ~blocked
+        o = F.scaled_dot_product_attention(q, kv[0], kv[1], attn_mask=allowed)
+        o = o.squeeze(0).transpose(0, 1).reshape(-1, c)
+        upd = F.linear(o, attn.out_proj.weight, attn.out_proj.bias).unsqueeze(1)
+        return self.norm(tgt + upd)
+
 
 class SelfAttentionLayer(_Attention):
     def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
@@ -71,7 +97,7 @@ class SelfAttentionLayer(_Attention):
 
     def forward(self, tgt, tgt_mask=None, tgt_key_padding_mask=None, query_pos=None):
         q = tgt + query_pos
-        upd = self.self_attn(q, q, value=tgt, attn_mask=tgt_mask)[0]
+        upd = self.self_attn(q, q, value=tgt, attn_mask=tgt_mask, need_weights=False)[0]
         return self.norm(tgt + upd)
 
 
@@ -163,12 +189,13 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         return out
 
     def forward_prediction_heads(self, output, mask_features, attn_mask_target_size, mask_indices):
+        """models/mask3dformer.py:429-445; the attention mask is returned as ONE bool[Q, N_level] (True = blocked):
+        the reference's per-head copies are identical"""
         dec = self.decoder_norm(output).transpose(0, 1)
         outputs_class = self.class_embed(dec)
         outputs_mask = torch.einsum("bqc,bcl->bql", self.mask_embed(dec), mask_features)
-        attn = outputs_mask[..., mask_indices]
-        attn = (attn.sigmoid().unsqueeze(1).repeat(1, self.num_heads, 1, 1).flatten(0, 1) < 0.5).bool().detach()
-        return outputs_class, outputs_mask, attn
+        attn = outputs_mask[0] if mask_indices is None else outputs_mask[0].index_select(1, mask_indices)
+        return outputs_class, outputs_mask, (attn.sigmoid() < 0.5).detach()
 
     def forward(self, panoptic_features, panoptic_coords, mask_features, spitial_shape):
         """panoptic_features 3 x [1, C, N_l]; panoptic_coords 3 x [1, N_l, 3]; mask_features [1, C, N_2]"""
@@ -179,24 +206,27 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             src.append((panoptic_features[i] + self.level_embed.weight[i][None, :, None]).permute(2, 0, 1))
             pos[i] = pos[i].permute(2, 0, 1)
         fine = panoptic_coords[2].squeeze(0)
+        # level 2 attends over the finest voxels themselves: identity (the reference indexes with an all-True mask)
         mask_indices = [nearest_fine_index(panoptic_coords[0].squeeze(0), fine, 4),
-                        nearest_fine_index(panoptic_coords[1].squeeze(0), fine, 2),
-                        torch.ones(fine.shape[0], dtype=torch.bool, device=fine.device)]
+                        nearest_fine_index(panoptic_coords[1].squeeze(0), fine, 2), None]
+        keys_in = [s_ + p_ for s_, p_ in zip(src, pos)]      # each level serves two layers
         query_embed = self.query_embed.weight.unsqueeze(1)
         output = self.query_feat.weight.unsqueeze(1)
         classes, masks = [], []
-        cls, msk, attn_mask = self.forward_prediction_heads(output, mask_features, sizes[0], mask_indices[0])
+        cls, msk, blocked = self.forward_prediction_heads(output, mask_features, sizes[0], mask_indices[0])
         classes.append(cls)
         masks.append(msk)
         for j in range(self.num_layers):
             lvl = j % self.num_feature_levels
-            attn_mask[torch.where(attn_mask.sum(-1) == attn_mask.shape[-1])] = False
-            output = self.transformer_cross_attention_layers[j](output, src[lvl], memory_mask=attn_mask,
-                                                                pos=pos[lvl], query_pos=query_embed)
+            # a query whose mask blocks every voxel attends to all of them (:388), without the host round trip
+            # of the reference's torch.where
+            blocked = blocked & ~blocked.all(dim=-1, keepdim=True)
+            cross = self.transformer_cross_attention_layers[j]
+            output = cross.attend(output, query_embed, cross.project_kv(keys_in[lvl], src[lvl]), blocked)
             output = self.transformer_self_attention_layers[j](output, query_pos=query_embed)
             output = self.transformer_ffn_layers[j](output)
             nxt = (j + 1) % self.num_feature_levels
-            cls, msk, attn_mask = self.forward_prediction_heads(output, mask_features, sizes[nxt], mask_indices[nxt])
+            cls, msk, blocked = self.forward_prediction_heads(output, mask_features, sizes[nxt], mask_indices[nxt])
             classes.append(cls)
             masks.append(msk)
         return {"pred_logits": classes[-1], "pred_masks": masks[-1],

@@ -382,6 +382,53 @@ int eprecon_gather_rows_async(const float *feat, int ld_feat, const int32_t *src
                               float fill, float *out, int ld_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Persistent global map of GRU fusion behind an opaque handle  (K15, SURVEY.md 8b "Ownership")
+ *
+ * Replaces  GRUFusion.global_volume / target_tsdf_volume state       models/gru_fusion.py:31-38,59-65
+ *           convert2dense (crop to the FBV, union, gathers)          models/gru_fusion.py:67-114,321-326
+ *           update_map  (map = map[outside FBV] ++ fused rows)       models/gru_fusion.py:195-215
+ * A handle owns its device memory (rows int32[M,3] scene-grid coordinates of one scale + f32[M,C]
+ * features, ping-pong buffers with geometric growth) and is the ONE stateful object of the ABI:
+ * create once per scale, reset on scene change (models/gru_fusion.py:283-286), destroy at the end.
+ * One fragment = crop_union -> gather(s) -> [caller fuses] -> update.  Row order after update is the
+ * reference's: rows outside the FBV in their old order, then the union voxels in raster order.
+ * Calls on one handle must be issued from one thread; crop_union / target_fuse synchronise `stream`
+ * (the reference's torch.nonzero synchronises at the same point), the others are stream-ordered.
+ * ------------------------------------------------------------------------------------------ */
+int eprecon_map_create(int channels, void **out_handle);
+int eprecon_map_destroy(void *handle);
+int eprecon_map_reset(void *handle);                 /* size := 0, memory kept */
+int64_t eprecon_map_size(const void *handle);        /* rows (host-side count) */
+int eprecon_map_channels(const void *handle);
+/* copy the rows out (coords int32[size,3], feats f32[size,C], both dense) / replace the contents */
+int eprecon_map_export_async(const void *handle, int32_t *coords_out, float *feats_out, void *stream);
+int eprecon_map_import_async(void *handle, const int32_t *coords, const float *feats, int64_t n, void *stream);
+/*
+ * Union, in raster order of the local dim^3 grid, of the current fragment's voxels (as in
+ * eprecon_fbv_union_async) and the map rows that fall inside the FBV at relative_origin_host.
+ * Outputs have capacity min(dim^3, n_cur + size) rows; counts_host[0] = n_out, [1] = map rows inside.
+ * The rows inside are remembered by the handle for the next eprecon_map_update_async.  Blocking.
+ */
+int eprecon_map_crop_union(void *handle, const int32_t *cur_coords, const float *cur_feat, int64_t n_cur, int ld_cur,
+                           int dim, int interval, int activity_mode, const int32_t *relative_origin_host,
+                           int32_t *updated, int32_t *src_cur, int32_t *src_glob, int64_t *counts_host, void *stream);
+/* out[i, 0:channels] = src_glob[i] >= 0 ? map.feats[src_glob[i], col0 : col0 + channels] : fill */
+int eprecon_map_gather_async(const void *handle, const int32_t *src_glob, int64_t n, int col0, int channels, float fill,
+                             float *out, int ld_out, void *stream);
+/* update_map: drop the rows inside the last crop's FBV, append (updated + relative origin, values) */
+int eprecon_map_update_async(void *handle, const int32_t *updated, int64_t n, const float *values, int ld_values,
+                             void *stream);
+/*
+ * Ground-truth twin (a 1-channel map; the reference's test path reads the targets,
+ * models/neucon_network.py:488): dense volume default 1 <- map rows inside the FBV <- the fragment's
+ * ground truth where occ_gt (tsdf_gt f32[dim^3], occ_gt u8[dim^3]); tsdf_target_out[i] = volume at
+ * updated[i]; then map = map[outside] ++ raster-ordered cells with |v| < 1.  Blocking.
+ */
+int eprecon_map_target_fuse(void *handle, const float *tsdf_gt, const uint8_t *occ_gt, int dim,
+                            const int32_t *relative_origin_host, const int32_t *updated, int64_t n, float *tsdf_target_out,
+                            void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Nearest finest-level voxel  (K18)
  *
  * Replaces  torch.cdist + argmin(dim=1)                 models/mask3dformer.py:361-367
