@@ -12,8 +12,12 @@ own fragment per step (independent fragment windows shard one-per-GPU, SURVEY.md
 value = N * K / max-over-ranks(time) and scaling is "weak".
 
 Prints ONE JSON line on rank 0 with the driver's keys plus
-  roofline     dominant kernel (bp_gather on the dense 96^3 / C=24 / 120x160 level), HIP-event timed
-  cpu_baseline the CPU oracle (C + OpenMP port of the reference algorithm) on the same windows.
+  roofline      the kernel BASELINE.json's metric names (bp_gather on the dense 96^3 / C=24 / 120x160 level), HIP-event
+                timed on its launch stream; `traffic` from the newest committed PMC passes of that kernel
+  roofline_conv one launch of the gather-GEMM convolution family (the largest share of kernel time), HIP-event timed,
+                against the dense fp32-MFMA peak
+  extra         cfg3 / cfg4 (whole NeuConNet.forward per fragment) timed in the same process, launches per fragment
+  cpu_baseline  the CPU oracle (C + OpenMP port of the reference algorithm) on the same windows.
 """
 import argparse
 import json
@@ -27,6 +31,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured streaming ceiling)
+F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, f32 in / f32 accumulate
+DOMINANT_KERNEL = "bp_gather_mlp_kernel<256,MEAN,6,1>"
+
+
+def newest_profile(name):
+    """newest committed profiles/rNN/<name> (the per-round directories sort by round number)"""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", name)))
+    return hits[-1] if hits else None
 
 
 def parse():
@@ -37,6 +50,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="approximate CPU time to spend on the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the cfg3 / cfg4 timings reported under `extra`")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4"],
                     help="cfg2 (default) = BASELINE.json configs[1], the headline metric; cfg4 = the full "
                          "coarse-to-fine forward over 4 sequential fragments (extra measurement, no roofline)")
@@ -95,7 +109,78 @@ def cpu_baseline(step, seconds):
     blas_limit.restore_original_limits()
     return {"value": n / dt, "unit": "fragments/s", "cores": threads, "kind": "port",
             "sample": f"{n} whole steps of the same workload (same window, seed {step.seed}) in {dt:.1f} s",
-            "ms_per_step": dt / n * 1e3}
+            "ms_per_step": dt / n * 1e3,
+            "protocol": "1 warm-up step, then whole steps repeated for a bounded wall time (mean); C + OpenMP "
+                        "back-projection, numpy sparse layers, PyTorch-CPU 2D convolutions; not the 3-warm-up / "
+                        "median-of-10 PyTorch-CPU protocol of SURVEY.md 8d (one step takes seconds)"}
+
+
+def conv_roofline(step, lib, repeats=3):
+    """HIP-event time of ONE launch of the gather-GEMM family: the first 3x3x3 32->32 submanifold layer of the
+    initialisation stack on the ~94k-voxel valid set (the layer DESIGN.md 3b analyses), measured in untimed
+    extra steps.  flops = 2 * (live kernel-map pairs) * C_in * C_out (algorithmic; the output-stationary kernel
+    also issues the MFMAs of empty neighbours: `executed_flops`)."""
+    import ctypes
+    import torch
+    from eprecon_amd import sparse as SP
+    ms, rows, name = [], 0, b""
+    for _ in range(repeats):
+        lib.eprecon_profile_conv_arm(27, 32, 32, 20000)
+        step.run()
+        r, k = ctypes.c_int64(0), ctypes.c_char_p()
+        t = float(lib.eprecon_profile_conv_ms(ctypes.byref(r), ctypes.byref(k)))
+        if t > 0:
+            ms.append(t)
+            rows, name = int(r.value), k.value or b""
+    if not ms or step.last.get("init") is None:
+        return None
+    coords = step.last["init"][1]
+    nbr = SP.VoxelSet(coords.contiguous(), 2).kernel_map(3)
+    pairs = int((nbr >= 0).sum().item())
+    t = float(np.mean(ms))
+    flops = 2.0 * pairs * 32 * 32
+    return {"bound": "mfma", "kernel": name.decode() + " (submanifold 3x3x3, 32->32 + fused LayerNorm epilogue, "
+            f"{rows} voxels of the dense 48^3 grid)", "flops": flops, "executed_flops": 2.0 * rows * 27 * 32 * 32,
+            "live_pairs": pairs, "avg_launch_ms": t, "achieved": flops / (t * 1e-3) / 1e12,
+            "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": flops / (t * 1e-3) / 1e12 / F32_MFMA_PEAK_TF}
+
+
+def extra_workloads(device, steps3=12, steps4=16, warm4=4):
+    """cfg3 / cfg4 (BASELINE.json configs[2] / [3]) timed in the same process after the headline: the whole
+    NeuConNet.forward per fragment.  Not the headline metric (that is cfg2), reported under `extra`."""
+    import torch
+    from eprecon_amd.fragment_step import Cfg4Step
+    step = Cfg4Step(seed=0, device=device)
+    out = {}
+    for _ in range(2):
+        step.run_cfg3()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps3):
+        step.run_cfg3()
+    torch.cuda.synchronize()
+    out["cfg3_ms_per_fragment"] = (time.perf_counter() - t0) / steps3 * 1e3
+    for _ in range(warm4):
+        step.run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps4):
+        step.run()          # raises if a fragment returns before the finest level
+    torch.cuda.synchronize()
+    out["cfg4_ms_per_fragment"] = (time.perf_counter() - t0) / steps4 * 1e3
+    out["cfg4_fragments_per_sec"] = 1e3 / out["cfg4_ms_per_fragment"]
+    out["cfg4_finest_voxels_min_max"] = [min(step.voxels), max(step.voxels)]
+    out["cfg3_workload"] = "one 9-view 640x480 fragment, empty map: occupancy init + 3 x [Back_Project, SPVCNN, GRU " \
+                           "fusion, TSDF / occupancy heads, sparsify], no panoptic decoder"
+    out["cfg4_workload"] = step.describe()["workload"]
+    prof = newest_profile("cfg4_kernel_stats.json")
+    if prof:
+        rec = json.load(open(prof))
+        out["launches_per_fragment"] = rec.get("launches_per_fragment")
+        out["launches_source"] = os.path.relpath(prof, ROOT) + " (rocprofv3 --kernel-trace --stats of bench.py --workload cfg4)"
+    else:
+        out["launches_per_fragment"] = None
+    return out
 
 
 def bench_cfg4(args, step, world, rank, dist, use_dist=False):
@@ -192,14 +277,17 @@ def main():
         gm = float(np.mean([g for g in gather_ms if g > 0])) if any(g > 0 for g in gather_ms) else None
         alg = step.dominant_kernel_bytes()
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_bp_gather.json")
-        if os.path.exists(pmc):
-            # HBM-side bytes per launch of the same kernel from the committed rocprofv3 --pmc passes
-            # (FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 FETCH_SIZE x2 correction applied);
-            # PMC collection cannot run inside the timed process, so this is the recorded measurement
+        pmc = newest_profile("pmc_traffic_bp_gather.json")
+        if pmc:
+            # HBM-side bytes per launch from the newest committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
+            # in separate runs, gfx950 FETCH_SIZE x2 correction applied).  PMC collection cannot run inside the timed
+            # process, so this is a recorded measurement: it is reported only while it names the kernel timed here
             rec = json.load(open(pmc))
-            traffic, traffic_src = rec["traffic_bytes"], "profiles/r01/pmc_traffic_bp_gather.json"
-        roof = {"bound": "hbm", "kernel": "bp_gather_mlp_kernel<256,MEAN,6,1> (dense 96^3, C=24, 120x160)",
+            if rec.get("kernel") == DOMINANT_KERNEL:
+                traffic, traffic_src = rec["traffic_bytes"], os.path.relpath(pmc, ROOT)
+            else:
+                traffic_src = f"{os.path.relpath(pmc, ROOT)} measured {rec.get('kernel')!r}, not this kernel: traffic withheld"
+        roof = {"bound": "hbm", "kernel": DOMINANT_KERNEL + " (dense 96^3, C=24, 120x160)",
                 "achieved": (alg / (gm * 1e-3) / 1e9) if gm else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (alg / (gm * 1e-3) / 1e9 / HBM_PEAK_GBS) if gm else None,
                 "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": alg, "avg_launch_ms": gm}
@@ -207,6 +295,10 @@ def main():
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic", "config": step.describe(), "roofline": roof}
+        if world == 1:
+            out["roofline_conv"] = conv_roofline(step, lib)
+            if not args.no_extra:
+                out["extra"] = extra_workloads(torch.device("cuda", local_rank))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(step, args.cpu_seconds)
         print(json.dumps(out), flush=True)

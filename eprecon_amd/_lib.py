@@ -82,6 +82,8 @@ SIGNATURES = {
     "eprecon_upsample2x_nhwc_async": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "eprecon_profile_enable": (_i, [_i]),
     "eprecon_profile_gather_ms": (_f, []),
+    "eprecon_profile_conv_arm": (_i, [_i, _i, _i, _i64]),
+    "eprecon_profile_conv_ms": (_f, [_c.POINTER(_i64), _c.POINTER(_c.c_char_p)]),
     "eprecon_nchw_to_nhwc_async": (_i, [_vp, _vp, _i, _i, _i, _vp]),
 }
 

@@ -171,6 +171,23 @@ class Cfg4Step:
         self.k = (self.k + 1) % self.n_fragments
         return self.last
 
+    @torch.no_grad()
+    def run_cfg3(self):
+        """BASELINE.json configs[2]: ONE fragment through the full 3-level coarse-to-fine TSDF path with an EMPTY
+        global map (scene restarted) and without the panoptic decoder"""
+        dec, self.net.panoptic = self.net.panoptic, None
+        try:
+            self.net.gru_fusion.scene_name = [None, None, None]
+            f1, f2, inp = self.frags[0]
+            out, _ = self.net(f1, f2, inp, {})
+        finally:
+            self.net.panoptic = dec
+            self.net.gru_fusion.scene_name = [None, None, None]
+            self.k = 0
+        if "coords" not in out:
+            raise RuntimeError("cfg3: NeuConNet.forward returned before the finest level")
+        return out
+
     def describe(self):
         return {"workload": f"cfg4: NeuConNet.forward over {self.n_fragments} sequential 9-view 640x480 fragments "
                             "(occupancy init, 3 x [Back_Project, SPVCNN, GRU fusion, heads], panoptic inputs), "

@@ -108,6 +108,15 @@ int eprecon_back_project(const int32_t *coords, int64_t n, const float *origin, 
 int eprecon_profile_enable(int on);
 float eprecon_profile_gather_ms(void);
 
+/*
+ * The same for the gather-GEMM convolution (bench.py's `roofline_conv`): arm a one-shot — the next
+ * sparse-convolution launch with this (kvol, cin, cout) on a list of at least min_rows rows is
+ * bracketed by two events on its stream.  eprecon_profile_conv_ms blocks on the stop event and returns
+ * the milliseconds (< 0: nothing recorded), the list length and the name of the kernel family chosen.
+ */
+int eprecon_profile_conv_arm(int kvol, int cin, int cout, int64_t min_rows);
+float eprecon_profile_conv_ms(int64_t *rows_out, const char **kernel_out);
+
 /* NCHW -> NHWC re-layout of a stack of feature maps: in f32[maps, C, H*W] -> out f32[maps, H*W, C] */
 int eprecon_nchw_to_nhwc_async(const float *in, float *out, int maps, int channels, int hw,
                                void *stream);
