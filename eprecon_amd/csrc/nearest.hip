@@ -42,11 +42,50 @@ __device__ __forceinline__ void search_cube(const HashTable &t, const int4 &c, i
                 consider(t, c.x, c.y + dx, c.z + dy, c.w + dz, (long long)(dx * dx + dy * dy + dz * dz), best_d, best);
 }
 
+// Fast path: 8 lanes per query walk a table of all integer offsets with |o|^2 <= kShellMax sorted by |o|^2 and
+// stop after the first distance class that contains a voxel (ties inside the class -> smallest row).  After
+// ancestor pruning every query has a descendant within |o|^2 <= 3 (q - 1)^2 <= 27, and most have one at distance 0,
+// so a query costs a handful of probes instead of the q^3 + (2R + 1)^3 sequential ones of the general search.
+constexpr int kShellMax = 27;
+
+__global__ __launch_bounds__(256) void nearest_shell_kernel(HashTable t, const int4 *query, int n, const int4 *shell,
+                                                            int n_shell, int32_t *out)
+{
+    const int g = threadIdx.x & 7;
+    const int i = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int4 c = query[min(i, n - 1)];
+    int best_d = 0x7fffffff, best = 0x7fffffff;
+    for (int base = 0; base < n_shell; base += 8) {
+        if (shell[base].w > best_d) break;          // uniform inside the group: best_d is group-reduced below
+        const int4 o = shell[min(base + g, n_shell - 1)];
+        if (base + g < n_shell && o.w <= best_d) {
+            const int x = c.y + o.x, y = c.z + o.y, z = c.w + o.z;
+            if (key_in_range(c.x, x, y, z)) {
+                const int j = hash_lookup(t, pack_key(c.x, x, y, z));
+                if (j >= 0 && (o.w < best_d || j < best)) {
+                    best_d = o.w;
+                    best = j;
+                }
+            }
+        }
+#pragma unroll
+        for (int msk = 1; msk < 8; msk <<= 1) {     // lexicographic (distance, row) minimum over the 8 lanes
+            const int od = __shfl_xor(best_d, msk), oj = __shfl_xor(best, msk);
+            if (od < best_d || (od == best_d && oj < best)) {
+                best_d = od;
+                best = oj;
+            }
+        }
+    }
+    if (g == 0 && i < n) out[i] = best_d == 0x7fffffff ? -2 : best;   // -2: not found in the table -> general search
+}
+
 __global__ __launch_bounds__(256) void nearest_voxel_kernel(HashTable t, const int4 *ref, int m,
-                                                            const int4 *query, int n, int q, int32_t *out)
+                                                            const int4 *query, int n, int q, int32_t *out, int only_missing)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (only_missing && out[i] != -2) return;
     const int4 c = query[i];
     long long best_d = 0x7fffffffffffffffll;
     int best = -1;
@@ -91,9 +130,29 @@ extern "C" int eprecon_nearest_voxel_async(const void *table, uint32_t capacity,
     t.keys = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(const_cast<void *>(table)) + 256);
     t.vals = reinterpret_cast<int32_t *>(t.keys + capacity);
     t.mask = capacity - 1;
-    hipLaunchKernelGGL(nearest_voxel_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       t, reinterpret_cast<const int4 *>(ref_coords), (int)m,
-                       reinterpret_cast<const int4 *>(query_coords), (int)n, quantum, out_index);
+    // offsets with |o|^2 <= kShellMax, ascending |o|^2 (built once, lives for the process)
+    static int4 *shell_dev = nullptr;
+    static int n_shell = 0;
+    if (!shell_dev) {
+        int4 host[1024];
+        int cnt = 0;
+        for (int d = 0; d <= kShellMax; ++d)
+            for (int x = -5; x <= 5; ++x)
+                for (int y = -5; y <= 5; ++y)
+                    for (int z = -5; z <= 5; ++z)
+                        if (x * x + y * y + z * z == d && cnt < 1024) host[cnt++] = make_int4(x, y, z, d);
+        EP_HIP_CHECK(hipMalloc(&shell_dev, (size_t)cnt * sizeof(int4)));
+        EP_HIP_CHECK(hipMemcpy(shell_dev, host, (size_t)cnt * sizeof(int4), hipMemcpyHostToDevice));
+        n_shell = cnt;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(nearest_shell_kernel, dim3((unsigned)ceil_div(n, 32)), dim3(256), 0, st, t,
+                       reinterpret_cast<const int4 *>(query_coords), (int)n, (const int4 *)shell_dev, n_shell, out_index);
+    EP_LAUNCH_CHECK();
+    // queries with no voxel within sqrt(kShellMax) (none after ancestor pruning; the entry point does not assume it)
+    hipLaunchKernelGGL(nearest_voxel_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, t,
+                       reinterpret_cast<const int4 *>(ref_coords), (int)m, reinterpret_cast<const int4 *>(query_coords),
+                       (int)n, quantum, out_index, 1);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }

@@ -476,12 +476,12 @@ struct ARows {
 };
 
 template <bool VEC4, int NCH>
-__device__ __forceinline__ void gather_rows(const ConvParams &p, int j, int half, ARows &a)
+__device__ __forceinline__ void gather_rows(const ConvParams &p, int j, int half, ARows &a, int cbase = 0)
 {
     const float *xrow = p.x + (size_t)(j >= 0 ? j : 0) * p.ld_x;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-        const int c = ch * 8 + 4 * half;
+        const int c = cbase + ch * 8 + 4 * half;
         if (VEC4) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (j >= 0 && c < p.Cin) v = *reinterpret_cast<const float4 *>(xrow + c);
@@ -500,32 +500,38 @@ __device__ __forceinline__ void gather_rows(const ConvParams &p, int j, int half
 
 // pipelined form: unconditional loads from clamped addresses (a fixed number of loads in flight lets the
 // compiler wait with vmcnt(N) for the older batch only); the made-up values are zeroed by fix_rows at use
+// (the row pitch covers the channel count rounded up to 4 — the launcher checks it — so the last 16-byte group
+// of a ragged row may be loaded; fix_rows zeroes what lies past Cin)
 template <int NCH>
-__device__ __forceinline__ void gather_rows_nb(const ConvParams &p, int j, int half, ARows &a)
+__device__ __forceinline__ void gather_rows_nb(const ConvParams &p, int j, int half, ARows &a, int cbase = 0)
 {
     const float *xrow = p.x + (size_t)max(j, 0) * p.ld_x;
+    const int last = ((p.Cin + 3) & ~3) - 4;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-        const float4 v = *reinterpret_cast<const float4 *>(xrow + min(ch * 8 + 4 * half, p.Cin - 4));
+        const float4 v = *reinterpret_cast<const float4 *>(xrow + min(cbase + ch * 8 + 4 * half, last));
         a.v[ch][0] = v.x; a.v[ch][1] = v.y; a.v[ch][2] = v.z; a.v[ch][3] = v.w;
     }
 }
 template <int NCH>
-__device__ __forceinline__ void fix_rows(const ConvParams &p, int j, int half, ARows &a)
+__device__ __forceinline__ void fix_rows(const ConvParams &p, int j, int half, ARows &a, int cbase = 0)
 {
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
         for (int s = 0; s < 4; ++s)
-            if (!(j >= 0 && ch * 8 + 4 * half + s < p.Cin)) a.v[ch][s] = 0.0f;
+            if (!(j >= 0 && cbase + ch * 8 + 4 * half + s < p.Cin)) a.v[ch][s] = 0.0f;
 }
 
 // gather batch size: KB * NCH <= 16 float4 per lane in flight (<= 64 VGPRs of A operands)
 constexpr int resident_kb(int nch) { return nch <= 1 ? 9 : nch == 2 ? 8 : nch == 3 ? 5 : nch == 4 ? 4 : nch == 5 ? 3 : 2; }
 
 template <int NT, bool VEC4, int NCH, bool PIPE>
-__global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int kgroup)
+__global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int kgroup, int nslab)
 {
+    // nslab > 1: wide inputs.  The input channels are walked in `nslab` slabs of cin_pad = 8 * NCH channels; per
+    // slab the kernel is the narrow-layer kernel (offset groups resident in LDS, software-pipelined gathers), the
+    // accumulators carry over.  One flat sequence of (slab, offset batch) steps, so the gather pipeline never drains.
     constexpr int cin_pad = NCH * 8;
     constexpr int KB = PIPE ? (resident_kb(NCH) + 1) / 2 : resident_kb(NCH);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -533,17 +539,19 @@ __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int 
     float *sW = reinterpret_cast<float *>(smem);  // [kgroup][cin_pad][TN], zero padded; kgroup % KB == 0
     constexpr int per_k = cin_pad * TN;
     int *sNbr = reinterpret_cast<int *>(sW + kgroup * per_k);  // [K][128] neighbour tile
-    float *sAff = reinterpret_cast<float *>(sNbr + p.K * kRowsPerBlock);  // [2][cin_pad] input scale / shift
+    const int cin_all = nslab * cin_pad;
+    float *sAff = reinterpret_cast<float *>(sNbr + p.K * kRowsPerBlock);  // [2][cin_all] input scale / shift
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, half = lane >> 5;
     const int wrow0 = blockIdx.x * kRowsPerBlock + wave * kRowsPerWave;
     const int col0 = blockIdx.y * TN;
     const float *wbase = p.w + col0;
-    if (p.in_scale && tid < cin_pad) {
-        sAff[tid] = tid < p.Cin ? p.in_scale[tid] : 0.0f;
-        sAff[cin_pad + tid] = tid < p.Cin ? p.in_shift[tid] : 0.0f;
-    }
+    if (p.in_scale)
+        for (int c = tid; c < cin_all; c += 256) {
+            sAff[c] = c < p.Cin ? p.in_scale[c] : 0.0f;
+            sAff[cin_all + c] = c < p.Cin ? p.in_shift[c] : 0.0f;
+        }
     // the neighbour indices of the whole tile go to LDS up front: a gather then depends on ONE
     // memory latency (the rows), not two (index, then rows)
     for (int e = tid; e < p.K * kRowsPerBlock; e += 256) {
@@ -559,33 +567,41 @@ __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
+    const int nb = (p.K + KB - 1) / KB;  // offset batches per slab
+    const int total = nb * nslab;
     const int *nbr_row = sNbr + wave * kRowsPerWave + r32;
-    auto issue = [&](int kb, ARows(&a)[KB], int(&jj)[KB]) {
+    auto issue = [&](int b, ARows(&a)[KB], int(&jj)[KB]) {
+        const int sl = min(b / nb, nslab - 1);
+        const int kb = (b - (b / nb) * nb) * KB;
+        const bool in = b < total;
 #pragma unroll
-        for (int u = 0; u < KB; ++u) jj[u] = (kb + u < p.K) ? nbr_row[min(kb + u, p.K - 1) * kRowsPerBlock] : -1;
+        for (int u = 0; u < KB; ++u) jj[u] = (in && kb + u < p.K) ? nbr_row[min(kb + u, p.K - 1) * kRowsPerBlock] : -1;
 #pragma unroll
         for (int u = 0; u < KB; ++u) {
-            if (PIPE) gather_rows_nb<NCH>(p, jj[u], half, a[u]);
-            else gather_rows<VEC4, NCH>(p, jj[u], half, a[u]);
+            if (PIPE) gather_rows_nb<NCH>(p, jj[u], half, a[u], sl * cin_pad);
+            else gather_rows<VEC4, NCH>(p, jj[u], half, a[u], sl * cin_pad);
         }
     };
-    auto consume = [&](int kb, ARows(&a)[KB], int(&jj)[KB]) {
+    auto consume = [&](int b, ARows(&a)[KB], int(&jj)[KB]) {
+        const int sl = b / nb;
+        const int kb = (b - sl * nb) * KB;
+        const int cbase = sl * cin_pad;
         if (PIPE) {
 #pragma unroll
-            for (int u = 0; u < KB; ++u) fix_rows<NCH>(p, jj[u], half, a[u]);
+            for (int u = 0; u < KB; ++u) fix_rows<NCH>(p, jj[u], half, a[u], cbase);
         }
         // ---- weights of the group this batch belongs to (loads above stay in flight) ----
         const int k0 = kb / kgroup * kgroup;
         if (kb == k0) {
             const int kn = min(kgroup, p.K - k0);
             __syncthreads();  // every wave is done with the previous group's weights
-            if (cin_pad == p.Cin) {
+            if (nslab == 1 && cin_pad == p.Cin) {
                 // rows of consecutive offsets are contiguous in W: one flat [kn * Cin][Cout] block
                 stage_weights<TN>(sW, wbase, k0 * p.Cin, (k0 + kn) * p.Cin, p.Cout, p.Cout - col0, kn * cin_pad, tid);
             } else {
                 for (int kk = 0; kk < kn; ++kk)
-                    stage_weights<TN>(sW + kk * per_k, wbase, (k0 + kk) * p.Cin, (k0 + kk + 1) * p.Cin, p.Cout,
-                                      p.Cout - col0, cin_pad, tid);
+                    stage_weights<TN>(sW + kk * per_k, wbase, (k0 + kk) * p.Cin + cbase,
+                                      (k0 + kk) * p.Cin + min(cbase + cin_pad, p.Cin), p.Cout, p.Cout - col0, cin_pad, tid);
             }
             __syncthreads();
         }
@@ -601,75 +617,75 @@ __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int 
                 const bool ok = jj[u] >= 0;
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch) {
-                    const float4 sc = *reinterpret_cast<const float4 *>(sAff + ch * 8 + 4 * half);
-                    const float4 sh = *reinterpret_cast<const float4 *>(sAff + cin_pad + ch * 8 + 4 * half);
+                    const float4 sc = *reinterpret_cast<const float4 *>(sAff + cbase + ch * 8 + 4 * half);
+                    const float4 sh = *reinterpret_cast<const float4 *>(sAff + cin_all + cbase + ch * 8 + 4 * half);
                     const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         float v = fmaf(a[u].v[ch][s], scv[s], shv[s]);
                         if (p.in_relu) v = fmaxf(v, 0.0f);
-                        a[u].v[ch][s] = (ok && ch * 8 + 4 * half + s < p.Cin) ? v : 0.0f;
+                        a[u].v[ch][s] = (ok && cbase + ch * 8 + 4 * half + s < p.Cin) ? v : 0.0f;
                     }
                 }
             }
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
-                float b[4][NT];
+                float b4[4][NT];
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) b[s][t] = wk[(ch * 8 + s) * TN + t * 32];
+                    for (int t = 0; t < NT; ++t) b4[s][t] = wk[(ch * 8 + s) * TN + t * 32];
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[ch][s], b[s][t], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[ch][s], b4[s][t], acc[t], 0, 0, 0);
             }
         }
     };
     if (PIPE) {
-        // software pipeline: the gathers of batch b+1 are always issued (clamped past the end) before the
-        // MFMAs of batch b, so exactly KB * NCH loads are younger than the ones being waited for
+        // software pipeline: the gathers of step b+1 are always issued (clamped past the end) before the
+        // MFMAs of step b, so exactly KB * NCH loads are younger than the ones being waited for
         ARows a0[KB], a1[KB];
         int j0[KB], j1[KB];
         issue(0, a0, j0);
-        for (int kb = 0; kb < p.K; kb += 2 * KB) {
-            issue(kb + KB, a1, j1);
-            consume(kb, a0, j0);
-            issue(kb + 2 * KB, a0, j0);
-            if (kb + KB < p.K) consume(kb + KB, a1, j1);
+        for (int b = 0; b < total; b += 2) {
+            issue(b + 1, a1, j1);
+            consume(b, a0, j0);
+            issue(b + 2, a0, j0);
+            if (b + 1 < total) consume(b + 1, a1, j1);
         }
     } else {
-        for (int kb = 0; kb < p.K; kb += KB) {
+        for (int b = 0; b < total; ++b) {
             ARows a[KB];
             int jj[KB];
-            issue(kb, a, jj);
-            consume(kb, a, jj);
+            issue(b, a, jj);
+            consume(b, a, jj);
         }
     }
     conv_epilogue<NT>(p, acc, LinearRows{wrow0, p.n_out}, col0, r32, half, wave, sW, (int)blockIdx.x);
 }
 
 template <int NT, int NCH>
-int launch_resident_nch(const ConvParams &p, bool vec4, hipStream_t st)
+int launch_resident_nch(const ConvParams &p, bool vec4, hipStream_t st, int nslab = 1)
 {
     // weights of `kgroup` offsets resident at a time (a multiple of the gather batch, ~24 KB -> 4 workgroups per CU)
     static const bool pipe_env = !(getenv("EPRECON_CONV_PIPE") && getenv("EPRECON_CONV_PIPE")[0] == '0');  // default on
-    const bool pipe = pipe_env && vec4 && (p.Cin % 4 == 0);
+    const bool pipe = pipe_env && vec4;   // vec4: 16-byte aligned rows whose pitch covers Cin rounded up to 4
     const int KB = pipe ? (resident_kb(NCH) + 1) / 2 : resident_kb(NCH);  // the kernel's batch size: kgroup % KB == 0
     const size_t per_k = (size_t)NCH * 8 * 32 * NT * sizeof(float);
     int kgroup = (int)max((size_t)KB, (size_t)(24 * 1024) / per_k / KB * KB);
     kgroup = min(kgroup, (p.K + KB - 1) / KB * KB);
     const size_t lds = max((size_t)kgroup * per_k + (size_t)p.K * kRowsPerBlock * sizeof(int) +
-                               (size_t)2 * NCH * 8 * sizeof(float),
+                               (size_t)2 * nslab * NCH * 8 * sizeof(float),
                            max((size_t)kWaves * 3 * 32 * NT, (size_t)3 * 256) * sizeof(float));
     const dim3 grid((unsigned)ceil_div(p.n_out, kRowsPerBlock), (unsigned)ceil_div(p.Cout, 32 * NT));
     if (pipe)
-        hipLaunchKernelGGL((spconv_resident_kernel<NT, true, NCH, true>), grid, dim3(256), lds, st, p, kgroup);
+        hipLaunchKernelGGL((spconv_resident_kernel<NT, true, NCH, true>), grid, dim3(256), lds, st, p, kgroup, nslab);
     else if (vec4)
-        hipLaunchKernelGGL((spconv_resident_kernel<NT, true, NCH, false>), grid, dim3(256), lds, st, p, kgroup);
+        hipLaunchKernelGGL((spconv_resident_kernel<NT, true, NCH, false>), grid, dim3(256), lds, st, p, kgroup, nslab);
     else
-        hipLaunchKernelGGL((spconv_resident_kernel<NT, false, NCH, false>), grid, dim3(256), lds, st, p, kgroup);
+        hipLaunchKernelGGL((spconv_resident_kernel<NT, false, NCH, false>), grid, dim3(256), lds, st, p, kgroup, nslab);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }
@@ -677,15 +693,19 @@ int launch_resident_nch(const ConvParams &p, bool vec4, hipStream_t st)
 template <int NT>
 int launch_resident(const ConvParams &p, bool vec4, int cin_pad, hipStream_t st)
 {
-    switch (cin_pad / 8) {
-        case 1: return launch_resident_nch<NT, 1>(p, vec4, st);
-        case 2: return launch_resident_nch<NT, 2>(p, vec4, st);
-        case 3: return launch_resident_nch<NT, 3>(p, vec4, st);
-        case 4: return launch_resident_nch<NT, 4>(p, vec4, st);
-        case 5: return launch_resident_nch<NT, 5>(p, vec4, st);
-        case 6: return launch_resident_nch<NT, 6>(p, vec4, st);
-        case 7: return launch_resident_nch<NT, 7>(p, vec4, st);
-        default: return launch_resident_nch<NT, 8>(p, vec4, st);
+    // wide inputs: the fewest slabs of at most 64 channels, all of the same width (8 * NCH)
+    const int chunks = cin_pad / 8;
+    const int nslab = (chunks + 7) / 8;
+    const int nch = (chunks + nslab - 1) / nslab;
+    switch (nch) {
+        case 1: return launch_resident_nch<NT, 1>(p, vec4, st, nslab);
+        case 2: return launch_resident_nch<NT, 2>(p, vec4, st, nslab);
+        case 3: return launch_resident_nch<NT, 3>(p, vec4, st, nslab);
+        case 4: return launch_resident_nch<NT, 4>(p, vec4, st, nslab);
+        case 5: return launch_resident_nch<NT, 5>(p, vec4, st, nslab);
+        case 6: return launch_resident_nch<NT, 6>(p, vec4, st, nslab);
+        case 7: return launch_resident_nch<NT, 7>(p, vec4, st, nslab);
+        default: return launch_resident_nch<NT, 8>(p, vec4, st, nslab);
     }
 }
 
@@ -1024,7 +1044,8 @@ bool splitk_ok(const ConvParams &p)
     const int cin_pad = (p.Cin + 7) / 8 * 8;
     const int64_t wg128 = ceil_div(p.n_out, kRowsPerBlock) * nt_full;
     const int stages = p.K * ((p.Cin + 31) / 32);
-    return cin_pad > 64 && wg128 <= 256 && stages >= 8;
+    static const int max_wg = getenv("EPRECON_CONV_SPLITK_MAXWG") ? atoi(getenv("EPRECON_CONV_SPLITK_MAXWG")) : 256;
+    return cin_pad > 64 && wg128 <= max_wg && stages >= 8;
 }
 
 // One-shot timing hook for bench.py's `roofline_conv`: the next launch whose (K, Cin, Cout) match and whose list is
@@ -1095,6 +1116,15 @@ int conv_dispatch_inner(ConvParams &p, int64_t n_in, hipStream_t st)
     if (resident_on && cin_pad <= 64 && (p.Cout <= 64 || split)) {
         g_last_conv_kernel = "spconv_resident_kernel";
         return (nt_full == 1 || split) ? launch_resident<1>(p, vec4, cin_pad, st) : launch_resident<2>(p, vec4, cin_pad, st);
+    }
+    // wide inputs (C_in > 64) on the same pipelined kernel, walked in slabs of <= 64 channels (EPRECON_CONV_WIDE=0:
+    // the 32-channel slab kernel below).  Columns: 64 per workgroup when the row tiles alone fill the chip, else 32.
+    static const bool wide_on = !(getenv("EPRECON_CONV_WIDE") && getenv("EPRECON_CONV_WIDE")[0] == '0');
+    // (3D kernel maps only: the dense 2D layers, K = 1 / 9 on 10,800..43,200 pixel rows, measured faster on the slab kernel)
+    if (resident_on && wide_on && cin_pad > 64 && vec4 && (p.K == 27 || p.K == 8) && !(p.ln && nt_full > 2)) {
+        g_last_conv_kernel = "spconv_resident_kernel(wide)";
+        const bool two = nt_full >= 2 && (p.ln || (int64_t)nblk * ((nt_full + 1) / 2) >= 256);
+        return two ? launch_resident<2>(p, vec4, cin_pad, st) : launch_resident<1>(p, vec4, cin_pad, st);
     }
     g_last_conv_kernel = "spconv_mfma_kernel";
     if (nt_full == 1 || split) return launch_conv<1>(p, vec4, st);

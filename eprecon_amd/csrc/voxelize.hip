@@ -94,6 +94,24 @@ __global__ __launch_bounds__(256) void seg_mean_kernel(const float *feat, int ld
     out[(size_t)v * ld_o + c] = (b > a) ? __fdiv_rn(s, (float)(b - a)) : 0.0f;
 }
 
+// the same with one thread per (voxel, 4 channels): 16-byte loads / stores, the list indices are read once per 4 channels
+__global__ __launch_bounds__(256) void seg_mean4_kernel(const float *feat, int ld_f, const int32_t *offsets,
+                                                        const int32_t *order, int m, int C4, float *out, int ld_o)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)m * C4) return;
+    const int v = (int)(e / C4), c = 4 * (int)(e - (int64_t)v * C4);
+    const int a = offsets[v], b = offsets[v + 1];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = a; i < b; ++i) {
+        const float4 f = *reinterpret_cast<const float4 *>(feat + (size_t)order[i] * ld_f + c);
+        s.x += f.x; s.y += f.y; s.z += f.z; s.w += f.w;
+    }
+    const float n = (float)(b - a);
+    if (b > a) s = make_float4(__fdiv_rn(s.x, n), __fdiv_rn(s.y, n), __fdiv_rn(s.z, n), __fdiv_rn(s.w, n));
+    *reinterpret_cast<float4 *>(out + (size_t)v * ld_o + c) = s;
+}
+
 // 8-corner lookup + trilinear weights at tensor stride s:
 //   base = floor(p / s) * s, corner k = base + (bx, by, bz) * s with k = 4 bx + 2 by + bz,
 //   w_k = prod over axes of (bit ? p - pf : pc - p), / s^3 when s != 1, 0 for absent corners,
@@ -179,6 +197,69 @@ __global__ __launch_bounds__(256) void devoxelize_gate_kernel(const float *feat,
     }
     out[(size_t)i * ld_o + c] = r;
 }
+
+// 4 channels per thread (16-byte loads; the 8 indices / weights of a point are read once per 4 channels)
+__device__ __forceinline__ float4 devox4(const float *feat, int ld_f, const int32_t *idx, const float *wts, int i, int c)
+{
+    const int4 i0 = *reinterpret_cast<const int4 *>(idx + (size_t)i * 8), i1 = *reinterpret_cast<const int4 *>(idx + (size_t)i * 8 + 4);
+    const float4 w0 = *reinterpret_cast<const float4 *>(wts + (size_t)i * 8), w1 = *reinterpret_cast<const float4 *>(wts + (size_t)i * 8 + 4);
+    const int jj[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+    const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (jj[k] >= 0) {
+            const float4 f = *reinterpret_cast<const float4 *>(feat + (size_t)jj[k] * ld_f + c);
+            s.x = fmaf(ww[k], f.x, s.x); s.y = fmaf(ww[k], f.y, s.y); s.z = fmaf(ww[k], f.z, s.z); s.w = fmaf(ww[k], f.w, s.w);
+        }
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(256) void devoxelize4_kernel(const float *feat, int ld_f, const int32_t *idx, const float *wts,
+                                                          int n, int C4, float *out, int ld_o, int accumulate)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)n * C4) return;
+    const int i = (int)(e / C4), c = 4 * (int)(e - (int64_t)i * C4);
+    float4 s = devox4(feat, ld_f, idx, wts, i, c);
+    float4 *o = reinterpret_cast<float4 *>(out + (size_t)i * ld_o + c);
+    if (accumulate) {
+        const float4 p = *o;
+        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+    *o = s;
+}
+
+__device__ __forceinline__ float gate1(float v, int mode, float h, float z)
+{
+    if (mode == 3) return (1.0f - z) * h + z * tanhf(v);
+    const float r = __fdiv_rn(1.0f, 1.0f + expf(-v));
+    return mode == 2 ? r * h : r;
+}
+
+__global__ __launch_bounds__(256) void devoxelize_gate4_kernel(const float *feat, int ld_f, const int32_t *idx,
+                                                               const float *wts, int n, int C4, const float *skip, int ld_s,
+                                                               int mode, const float *h, int ld_h, const float *zg, int ld_z,
+                                                               float *out, int ld_o)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)n * C4) return;
+    const int i = (int)(e / C4), c = 4 * (int)(e - (int64_t)i * C4);
+    const float4 s = devox4(feat, ld_f, idx, wts, i, c);
+    const float4 k = *reinterpret_cast<const float4 *>(skip + (size_t)i * ld_s + c);
+    float4 hv = make_float4(0.f, 0.f, 0.f, 0.f), zv = hv;
+    if (mode >= 2) hv = *reinterpret_cast<const float4 *>(h + (size_t)i * ld_h + c);
+    if (mode == 3) zv = *reinterpret_cast<const float4 *>(zg + (size_t)i * ld_z + c);
+    float4 r;
+    r.x = gate1(s.x + k.x, mode, hv.x, zv.x);
+    r.y = gate1(s.y + k.y, mode, hv.y, zv.y);
+    r.z = gate1(s.z + k.z, mode, hv.z, zv.z);
+    r.w = gate1(s.w + k.w, mode, hv.w, zv.w);
+    *reinterpret_cast<float4 *>(out + (size_t)i * ld_o + c) = r;
+}
+
+__host__ inline bool vec4_ok(const void *p, int ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0; }
 
 HashTable make_table(const void *mem, uint32_t cap)
 {
@@ -307,8 +388,12 @@ int eprecon_segment_mean_async(const float *feat, int ld_feat, const int32_t *of
         ld_out < channels)
         return EPRECON_ERR_ARG;
     if (m == 0) return EPRECON_OK;
-    hipLaunchKernelGGL(seg_mean_kernel, dim3((unsigned)ceil_div(m * channels, 256)), dim3(256), 0,
-                       (hipStream_t)stream, feat, ld_feat, offsets, order, (int)m, channels, out, ld_out);
+    if ((channels & 3) == 0 && vec4_ok(feat, ld_feat) && vec4_ok(out, ld_out))
+        hipLaunchKernelGGL(seg_mean4_kernel, dim3((unsigned)ceil_div(m * (channels / 4), 256)), dim3(256), 0,
+                           (hipStream_t)stream, feat, ld_feat, offsets, order, (int)m, channels / 4, out, ld_out);
+    else
+        hipLaunchKernelGGL(seg_mean_kernel, dim3((unsigned)ceil_div(m * channels, 256)), dim3(256), 0,
+                           (hipStream_t)stream, feat, ld_feat, offsets, order, (int)m, channels, out, ld_out);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }
@@ -334,9 +419,13 @@ int eprecon_devoxelize_async(const float *voxel_feat, int ld_feat, const int32_t
         ld_feat < channels || ld_out < channels)
         return EPRECON_ERR_ARG;
     if (n == 0) return EPRECON_OK;
-    hipLaunchKernelGGL(devoxelize_kernel, dim3((unsigned)ceil_div(n * channels, 256)), dim3(256), 0,
-                       (hipStream_t)stream, voxel_feat, ld_feat, idx8, weight8, (int)n, channels, out, ld_out,
-                       accumulate);
+    if ((channels & 3) == 0 && vec4_ok(voxel_feat, ld_feat) && vec4_ok(out, ld_out) && vec4_ok(idx8, 4) && vec4_ok(weight8, 4))
+        hipLaunchKernelGGL(devoxelize4_kernel, dim3((unsigned)ceil_div(n * (channels / 4), 256)), dim3(256), 0,
+                           (hipStream_t)stream, voxel_feat, ld_feat, idx8, weight8, (int)n, channels / 4, out, ld_out, accumulate);
+    else
+        hipLaunchKernelGGL(devoxelize_kernel, dim3((unsigned)ceil_div(n * channels, 256)), dim3(256), 0,
+                           (hipStream_t)stream, voxel_feat, ld_feat, idx8, weight8, (int)n, channels, out, ld_out,
+                           accumulate);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }
@@ -371,9 +460,16 @@ int eprecon_devoxelize_gate_async(const float *voxel_feat, int ld_feat, const in
     if (n == 0) return EPRECON_OK;
     if (!voxel_feat || !idx8 || !weight8 || !skip || !out || (mode >= 2 && !h) || (mode == 3 && !zgate))
         return EPRECON_ERR_ARG;
-    hipLaunchKernelGGL(devoxelize_gate_kernel, dim3((unsigned)ceil_div(n * channels, 256)), dim3(256), 0,
-                       (hipStream_t)stream, voxel_feat, ld_feat, idx8, weight8, (int)n, channels, skip, ld_skip, mode,
-                       h, ld_h, zgate, ld_z, out, ld_out);
+    const bool v4 = (channels & 3) == 0 && vec4_ok(voxel_feat, ld_feat) && vec4_ok(out, ld_out) && vec4_ok(skip, ld_skip) &&
+                    vec4_ok(idx8, 4) && vec4_ok(weight8, 4) && (mode < 2 || vec4_ok(h, ld_h)) && (mode < 3 || vec4_ok(zgate, ld_z));
+    if (v4)
+        hipLaunchKernelGGL(devoxelize_gate4_kernel, dim3((unsigned)ceil_div(n * (channels / 4), 256)), dim3(256), 0,
+                           (hipStream_t)stream, voxel_feat, ld_feat, idx8, weight8, (int)n, channels / 4, skip, ld_skip, mode,
+                           h, ld_h, zgate, ld_z, out, ld_out);
+    else
+        hipLaunchKernelGGL(devoxelize_gate_kernel, dim3((unsigned)ceil_div(n * channels, 256)), dim3(256), 0,
+                           (hipStream_t)stream, voxel_feat, ld_feat, idx8, weight8, (int)n, channels, skip, ld_skip, mode,
+                           h, ld_h, zgate, ld_z, out, ld_out);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }

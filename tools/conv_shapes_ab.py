@@ -1,0 +1,62 @@
+"""Microbenchmark of the gather-GEMM convolution on the layer shapes of cfg4 (3x3x3, stride 1): kernel time per
+launch from HIP events around 20 back-to-back launches.  Run under different EPRECON_CONV_* switches to A/B.
+    python tools/conv_shapes_ab.py [tag]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from eprecon_amd import sparse as SP  # noqa: E402
+
+SHAPES = [  # (rows, C_in, C_out, what)
+    (10000, 192, 96, "ConvGRU voxel s0"), (10000, 160, 80, "ConvGRU img s0"),
+    (43000, 96, 48, "ConvGRU voxel s1"), (43000, 80, 40, "ConvGRU img s1"),
+    (183000, 48, 24, "ConvGRU s2"),
+    (9000, 80, 32, "SPVCNN0 stem"), (9000, 224, 96, "SPVCNN0 up1"), (9000, 128, 96, "SPVCNN0 up2"),
+    (9000, 96, 96, "SPVCNN0 res"), (3000, 128, 128, "SPVCNN0 stage2"), (5000, 64, 64, "SPVCNN0 stage1"),
+    (40000, 140, 16, "SPVCNN1 stem (138 padded)"), (40000, 64, 48, "SPVCNN1 up2"), (40000, 48, 48, "SPVCNN1 res"),
+    (140000, 76, 8, "SPVCNN2 stem (74 padded)"), (140000, 32, 24, "SPVCNN2 up2"), (140000, 24, 24, "SPVCNN2 res"),
+    (94000, 32, 32, "init subm 32->32"),
+]
+
+
+def coords_for(n, rng, density=0.35):
+    d = int(np.ceil((n / density) ** (1 / 3)))
+    flat = np.sort(rng.choice(d ** 3, size=n, replace=False))
+    xyz = np.stack(np.unravel_index(flat, (d, d, d)), 1)
+    return np.concatenate([np.zeros((n, 1), np.int64), xyz], 1).astype(np.int32)
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "default"
+    rng = np.random.default_rng(0)
+    dev = torch.device("cuda")
+    print(f"# {tag}: " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("EPRECON_CONV")))
+    total = 0.0
+    with torch.no_grad():
+        for n, ci, co, what in SHAPES:
+            vs = SP.VoxelSet(torch.from_numpy(coords_for(n, rng)).to(dev), 1)
+            nbr = vs.kernel_map(3)
+            pairs = int((nbr >= 0).sum())
+            x = torch.randn(n, ci, device=dev)
+            w = torch.randn(27, ci, co, device=dev) * 0.05
+            out = torch.empty(n, co, device=dev)
+            for _ in range(3):
+                SP.conv_stats(x, w, nbr, out=out)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                SP.conv_stats(x, w, nbr, out=out)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / 20 * 1e3
+            tf = 2.0 * pairs * ci * co / (us * 1e-6) / 1e12
+            total += us
+            print(f"{what:28s} N={n:7d} {ci:4d}->{co:3d}  {us:8.1f} us  {tf:6.1f} TF (live pairs)")
+    print(f"sum {total:.0f} us")
+
+
+if __name__ == "__main__":
+    main()
