@@ -183,6 +183,32 @@ def extra_workloads(device, steps3=12, steps4=16, warm4=4):
     return out
 
 
+def bench_cfg5(device, rank, world, dist, steps=8, warmup=4):
+    """whole NeuConNet.forward per fragment with the boundary exchange on; fragments/s over all ranks"""
+    import torch
+    from eprecon_amd.fragment_step import Cfg4Step
+    step = Cfg4Step(seed=0, device=device, rank=rank, world=world)
+    for _ in range(warmup):
+        step.run()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step.run()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0, float(step.early_returns)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t[0].item())
+    xch = step.net.gru_fusion._xchg
+    return {"cfg5_fragments_per_sec": world * steps / elapsed, "cfg5_ms_per_step": elapsed / steps * 1e3,
+            "cfg5_steps": steps, "cfg5_early_returns_max_over_ranks": int(t[1].item()),
+            "cfg5_collectives_per_fragment": (xch.collectives / (steps + warmup)) if xch is not None else 0,
+            "cfg5_workload": f"{world} ranks x 1 fragment per step of one scene (fragments dealt round-robin), whole "
+                             "NeuConNet.forward, RCCL boundary-voxel exchange (3 collectives: boxes, counts, packed "
+                             "payload of all three scales) before every fragment"}
+
+
 def bench_cfg4(args, step, world, rank, dist, use_dist=False):
     """extra measurement: whole-forward fragments/s (not the headline line; no roofline / cpu legs)"""
     import torch
@@ -271,6 +297,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # N > 1: BASELINE.json configs[4] — the fragments of ONE scene dealt round-robin to the ranks, every fragment
+    # preceded by the RCCL boundary-voxel exchange (eprecon_amd/distributed.py).  All ranks take part; reported
+    # under `extra` (the headline stays the cfg2 metric on independent windows).
+    cfg5 = None
+    if world > 1 and not args.no_extra:
+        cfg5 = bench_cfg5(torch.device("cuda", local_rank), rank, world, dist)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
@@ -299,6 +332,8 @@ def main():
             out["roofline_conv"] = conv_roofline(step, lib)
             if not args.no_extra:
                 out["extra"] = extra_workloads(torch.device("cuda", local_rank))
+        elif cfg5 is not None:
+            out["extra"] = cfg5
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(step, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -149,12 +149,24 @@ class Cfg4Step:
             f1, f2, inp = S.make_model_inputs([w], feat_seed=seed * 100 + kk, scene=f"scene{seed:04d}")
             self.frags.append((S.to_device(f1, self.device), S.to_device(f2, self.device),
                                S.to_device(inp, self.device)))
-        calibrate_occupancy_heads(self.net, *self.frags[0])
+        # the occupancy biases are calibrated on rank 0's first fragment and broadcast: every rank must run the
+        # SAME weights (a per-rank calibration would give the ranks of one scene different networks)
+        if world > 1:
+            import torch.distributed as dist
+            if rank == 0:
+                calibrate_occupancy_heads(self.net, *self.frags[0])
+            for p_ in self.net.parameters():
+                dist.broadcast(p_.data, 0)
+        else:
+            calibrate_occupancy_heads(self.net, *self.frags[0])
         # EPRECON_FORCE_EXCHANGE=1: run the boundary all-gather even at world size 1 (exercises the RCCL path on one GPU)
         self.net.distributed_exchange = world > 1 or os.environ.get("EPRECON_FORCE_EXCHANGE", "0") == "1"
         self.k = 0
         self.last = None
         self.voxels = []  # finest-level voxel count of every fragment run so far
+        self.early_returns = 0
+        # multi-GPU: a rank that raised would leave the others waiting in the next collective; count instead
+        self.raise_on_early_return = world == 1
 
     @torch.no_grad()
     def run(self):
@@ -165,9 +177,12 @@ class Cfg4Step:
         if "coords" not in self.last or "panoptic_levels" not in self.last:
             # a data-dependent early return of NeuConNet.forward (< 500 occupied voxels, no valid points, over the
             # cap) would otherwise be timed as a very fast fragment
-            raise RuntimeError(f"fragment {self.k}: NeuConNet.forward returned before the finest level "
-                               f"(outputs: {sorted(self.last)})")
-        self.voxels.append(int(self.last["coords"].shape[0]))
+            if self.raise_on_early_return:
+                raise RuntimeError(f"fragment {self.k}: NeuConNet.forward returned before the finest level "
+                                   f"(outputs: {sorted(self.last)})")
+            self.early_returns += 1
+        else:
+            self.voxels.append(int(self.last["coords"].shape[0]))
         self.k = (self.k + 1) % self.n_fragments
         return self.last
 

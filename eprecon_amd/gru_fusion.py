@@ -96,6 +96,8 @@ class GRUFusion(nn.Module):
             self.fusion_nets_img.append(ConvGRU(hidden_dim=ch, input_dim=ch, pres=1,
                                                 vres=cfg.VOXEL_SIZE * 2 ** (self.n_scales - i)))
         self._identity_fusion = False  # tests: skip the ConvGRUs (pins the bookkeeping alone)
+        self._xchg = None              # multi-GPU: distributed.BoundaryExchange (stamps of the map voxels)
+        self._n_exchanged = self._cur_fragment = 0
 
     def reset(self, i, device=None):
         """models/gru_fusion.py:59-65: empty maps (the handles keep their device memory)"""
@@ -105,6 +107,9 @@ class GRUFusion(nn.Module):
             self.target_tsdf_volume[i] = GlobalMap(1, device)
         self.global_volume[i].reset()
         self.target_tsdf_volume[i].reset()
+        if self._xchg is not None:
+            from .distributed import _Stamps
+            self._xchg.stamps[i] = _Stamps(device)
 
     def _begin_fragment(self, scale, inputs, i, dev):
         """scene bookkeeping of models/gru_fusion.py:280-293 -> relative origin (LongTensor[3], host)"""
@@ -131,16 +136,27 @@ class GRUFusion(nn.Module):
         return hit[3], hit[4]
 
     def exchange_boundaries(self, inputs, i=0):
-        """Multi-GPU schedule (eprecon_amd/distributed.py): before this fragment is fused, pull in the
-        map voxels other ranks own inside this fragment's bounding volume, at all three scales.
-        Collective — every rank calls it once per step, outside any data-dependent control flow."""
+        """Multi-GPU schedule (eprecon_amd/distributed.py): before this fragment is fused, pull in the map voxels
+        other ranks fused inside this fragment's bounding volume — all three scales in one exchange (three
+        collectives, one host read).  Collective: every rank calls it once per fragment, outside any
+        data-dependent control flow."""
+        import torch.distributed as dist
         from . import distributed as D
         dev = inputs["vol_origin_partial"].device
-        for scale in range(self.cfg.N_LAYER):
-            rel = self._begin_fragment(scale, inputs, i, dev)
-            dim = self.cfg.N_VOX[0] // 2 ** (self.cfg.N_LAYER - scale - 1)
-            gmap = self.global_volume[scale]
-            gmap.set(*D.exchange_boundary_voxels(*gmap.export(), rel.tolist(), dim))
+        n = self.cfg.N_LAYER
+        if self._xchg is None:
+            self._xchg = D.BoundaryExchange(n, dev)
+        rels, dims = [], []
+        for scale in range(n):
+            rels.append(self._begin_fragment(scale, inputs, i, dev).tolist())
+            dims.append(self.cfg.N_VOX[0] // 2 ** (n - scale - 1))
+        maps = [self.global_volume[scale].export() for scale in range(n)]
+        for scale, (c, f) in enumerate(self._xchg.exchange(maps, rels, dims)):
+            if c.shape[0] != maps[scale][0].shape[0] or f is not maps[scale][1]:
+                self.global_volume[scale].set(c, f)
+        # global index of the fragment this rank fuses next: ranks take the fragments of a scene round-robin
+        self._cur_fragment = self._n_exchanged * dist.get_world_size() + dist.get_rank()
+        self._n_exchanged += 1
 
     def forward(self, coords, values_in, inputs, scale=2, outputs=None, save_mesh=False, panoptic_infos=None):
         """coords int[N,4] (b,x,y,z) finest units, values_in f32[N,C] ->
@@ -203,6 +219,9 @@ class GRUFusion(nn.Module):
                 values[:, :chv], values[:, chv:] = hx_v[:, chv:], hx_i[:, chi:]
 
             gmap.update(updated, values)    # update_map (:195-215)
+            if self._xchg is not None:      # multi-GPU: these voxels now carry this rank's newest fusion result
+                rel_t = torch.tensor(rel_l, dtype=torch.int32, device=dev)
+                self._xchg.mark_fused(scale, updated + rel_t, self._cur_fragment)
 
             out_c.append(torch.cat([torch.full_like(updated[:, :1], i), updated * interval], dim=1))
             out_v.append(values)

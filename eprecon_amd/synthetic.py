@@ -157,6 +157,45 @@ def analytic_tsdf(window, level, trunc_voxels=3.0):
     return t.astype(F32)
 
 
+SCENE_SPHERES = [(-0.6, 2.0, 0.5, 0.5), (0.7, 2.4, 0.35, 0.35), (0.1, 1.5, 0.25, 0.25)]
+
+
+def scene_sdf(x, y, z):
+    """signed distance (positive in free space) of the analytic scene of analytic_tsdf: floor z = 0, back wall
+    y = 3.4, side walls x = +-1.7, three spheres"""
+    d = np.minimum.reduce([z - 0.0, 3.4 - y, x + 1.7, 1.7 - x])
+    for cx, cy, cz, r in SCENE_SPHERES:
+        d = np.minimum(d, np.sqrt((x - cx) ** 2 + (y - cy) ** 2 + (z - cz) ** 2) - r)
+    return d
+
+
+def render_depth(window, view, max_depth=6.0, holes_seed=None, hole_fraction=0.03):
+    """Synthetic depth image f32[H, W] (camera-frame z in metres, 0 = invalid) of the analytic scene seen from
+    view `view` of the window, by sphere tracing.  Rays that leave the scene (there is no ceiling / front wall)
+    and a seeded random `hole_fraction` of the pixels are invalid — what a real depth sensor hands to the
+    TSDF integration (tools/tsdf_fusion/fusion.py of the reference)."""
+    h, w = window["image_hw"]
+    k = window["intrinsics"].astype(np.float64)
+    pose = window["poses"][view].astype(np.float64)
+    u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    d_cam = np.stack([(u - k[0, 2]) / k[0, 0], (v - k[1, 2]) / k[1, 1], np.ones_like(u)], -1)
+    d = d_cam @ pose[:3, :3].T                       # world direction per unit of camera z
+    speed = np.linalg.norm(d, axis=-1)
+    eye = pose[:3, 3]
+    t = np.full((h, w), 0.05)
+    for _ in range(80):
+        p = eye + t[..., None] * d
+        dist = scene_sdf(p[..., 0], p[..., 1], p[..., 2])
+        t = np.minimum(t + np.maximum(dist, 0.0) / speed, max_depth + 1.0)
+    p = eye + t[..., None] * d
+    ok = (np.abs(scene_sdf(p[..., 0], p[..., 1], p[..., 2])) < 2e-3) & (t < max_depth)
+    depth = np.where(ok, t, 0.0).astype(F32)
+    if holes_seed is not None:
+        rng = np.random.default_rng(holes_seed)
+        depth[rng.random((h, w)) < hole_fraction] = 0.0
+    return depth
+
+
 def make_model_inputs(windows, feat_seed=0, scene="scene0000_00", fragment_ids=None):
     """numpy inputs of NeuConNet.forward for a batch of windows (list of make_window dicts):
     both backbones' pyramids as the reference's list over views of [f4, f8, f16] (each [B,C,H,W]),

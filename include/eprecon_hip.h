@@ -438,6 +438,28 @@ int eprecon_map_target_fuse(void *handle, const float *tsdf_gt, const uint8_t *o
                             void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * TSDF integration of depth frames  (the data-preparation side of the path)
+ *
+ * Replaces  TSDFVolumeTorch.integrate / integrate()     tools/tsdf_fusion/fusion.py:440-485,551-575
+ *           (run on the CPU for every sample: datasets/transforms.py:286-297,375-387)
+ *           and the in-tree PyCUDA kernel `integrate`   tools/tsdf_fusion/fusion.py:67-142
+ * tsdf / weight f32[dims[0], dims[1], dims[2]] (x-major, like the reference's volumes; a fresh volume is
+ * tsdf = 1, weight = 0) are updated in place with ALL n_views frames in one launch (per voxel the views
+ * are applied in order, as n successive integrate() calls would).  depth f32[n_views, height, width]
+ * (metres along the camera z axis, 0 = invalid); intr_host f32[n_views,3,3]; cam_host f32[n_views,4,4]:
+ * variant 0 (TSDFVolumeTorch arithmetic) world->camera matrices (the reference's torch.inverse(cam_pose)),
+ * variant 1 (the PyCUDA kernel's arithmetic) the camera poses themselves.  trunc = margin * voxel_size.
+ * occ_out u8[cells] or NULL: |tsdf| < 0.999 and weight > 1 after the last view (datasets/transforms.py:295-297).
+ * dims_host / origin_host / intr_host / cam_host are HOST pointers.
+ * ------------------------------------------------------------------------------------------ */
+#define EPRECON_TSDF_TORCH 0
+#define EPRECON_TSDF_CUDA 1
+int eprecon_tsdf_integrate_async(float *tsdf, float *weight, const int32_t *dims_host, const float *origin_host,
+                                 float voxel_size, const float *depth, int n_views, int height, int width,
+                                 const float *intr_host, const float *cam_host, float trunc, float obs_weight,
+                                 int variant, uint8_t *occ_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Nearest finest-level voxel  (K18)
  *
  * Replaces  torch.cdist + argmin(dim=1)                 models/mask3dformer.py:361-367

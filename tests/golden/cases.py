@@ -89,3 +89,15 @@ def seeded_state(module, seed, keys=None):
         new[k] = torch.from_numpy(a.astype(np.float32))
     module.load_state_dict(new, strict=keys is None)
     return module
+
+
+TSDF_LEVELS = (0, 1, 2)        # voxel size 0.04 * 2**l on (96 / 2**l)^3 voxels, margin 3 (datasets/transforms.py:286-288)
+
+
+def tsdf_case(seed=0, views=9):
+    """depth images f32[V,480,640] (synthetic scene, seeded holes), intrinsics f32[V,3,3], camera poses f32[V,4,4]
+    and the fragment origin of one 640x480 window"""
+    window = S.make_window(seed=seed)
+    depths = np.stack([S.render_depth(window, v, holes_seed=100 + v) for v in range(views)])
+    intr = np.repeat(window["intrinsics"][None], views, 0).astype(np.float32)
+    return window, depths, intr, window["poses"].astype(np.float32)

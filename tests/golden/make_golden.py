@@ -475,9 +475,36 @@ def gen_aligned_coords():
     _save("aligned_coords", **out)
 
 
+def gen_tsdf_fusion():
+    """(f3) TSDFVolumeTorch.integrate (tools/tsdf_fusion/fusion.py:440-485,488-577), the CPU path the reference's data
+    pipeline runs per sample (datasets/transforms.py:286-297): 9 synthetic depth frames fused at the three levels.
+    Stored: world->camera matrices as torch.inverse produced them (inputs of the restatement), the full weight
+    volumes, the occupancy volumes of :295-297, sampled TSDF values and z-slab checksums."""
+    import cases
+    sys.modules["numba"].njit = lambda *a, **k: (lambda f: f)      # decorators of the unused numba path
+    from tools.tsdf_fusion.fusion import TSDFVolumeTorch
+
+    window, depths, intr, poses = cases.tsdf_case()
+    out = {"world2cam": np.stack([torch.inverse(torch.from_numpy(p).float()).numpy() for p in poses])}
+    for lvl in cases.TSDF_LEVELS:
+        dims = torch.tensor([n // 2 ** lvl for n in window["n_vox"]])
+        vol = TSDFVolumeTorch(dims, torch.from_numpy(window["vol_origin_partial"]), voxel_size=0.04 * 2 ** lvl, margin=3)
+        for v in range(len(depths)):
+            vol.integrate(torch.from_numpy(depths[v]), torch.from_numpy(intr[v]), torch.from_numpy(poses[v]), obs_weight=1.)
+        tsdf, weight = (t.numpy() for t in vol.get_volume())
+        occ = (tsdf < 0.999) & (tsdf > -0.999) & (weight > 1)
+        rows = cases.sample_rows(tsdf.size, 20000, 5 + lvl)
+        out[f"l{lvl}_weight"] = weight.astype(np.uint8)
+        out[f"l{lvl}_occ"] = np.packbits(occ.reshape(-1))
+        out[f"l{lvl}_rows"] = rows
+        out[f"l{lvl}_tsdf_rows"] = tsdf.reshape(-1)[rows]
+        out[f"l{lvl}_tsdf_slab_sums"] = tsdf.sum(axis=(1, 2), dtype=np.float64).astype(np.float32)
+    _save("tsdf_fusion", **out)
+
+
 GENERATORS = {"back_project": gen_back_project, "grid_ops": gen_grid_ops, "dense_blocks": gen_dense_blocks,
               "gru_fusion": gen_gru_fusion, "mask3dformer": gen_mask3dformer, "scene_fusion": gen_scene_fusion,
-              "occ_init": gen_occ_init, "aligned_coords": gen_aligned_coords}
+              "occ_init": gen_occ_init, "aligned_coords": gen_aligned_coords, "tsdf_fusion": gen_tsdf_fusion}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GENERATORS)

@@ -157,3 +157,32 @@ def test_random_drop_branch_is_seeded_like_the_reference(run4):
     expect[np.nonzero(before)[0][choice]] = False
     assert int(expect.sum()) == cap
     assert np.array_equal(npy(rec["occupancy"]), expect)
+
+
+def test_exchange_path_is_a_no_op_at_world_size_1():
+    """the multi-GPU schedule's code path (RCCL process group, GRUFusion.exchange_boundaries: export -> three
+    collectives -> stamp bookkeeping) run in a single-rank group must leave every result bit-identical"""
+    import socket
+    import torch.distributed as dist
+    from eprecon_amd.fragment_step import Cfg4Step
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dev = torch.device("cuda")
+    np.random.seed(3)
+    plain = Cfg4Step(seed=0, device=dev, n_fragments=2)
+    ref = [plain.run() for _ in range(2)]
+    ref = [(npy(o["coords"]), npy(o["tsdf"])) for o in ref]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        np.random.seed(3)
+        step = Cfg4Step(seed=0, device=dev, n_fragments=2)
+        step.net.distributed_exchange = True
+        for k in range(2):
+            out = step.run()
+            assert np.array_equal(npy(out["coords"]), ref[k][0]) and np.array_equal(npy(out["tsdf"]), ref[k][1])
+        xch = step.net.gru_fusion._xchg
+        assert xch is not None and xch.collectives == 6
+        assert int(xch.stamps[2].local.sum()) == step.net.gru_fusion.global_volume[2].size
+    finally:
+        dist.destroy_process_group()

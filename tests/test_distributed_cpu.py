@@ -1,6 +1,11 @@
 """CPU, world_size 2, gloo: the boundary-voxel exchange of the multi-GPU schedule (N > 1 path).
-After the exchange each rank's map restricted to its FBV equals the un-sharded union of all maps
-restricted to that FBV (lower rank wins duplicates); voxels outside the FBV are untouched."""
+
+1. stateless one-scale form: after the exchange each rank's map restricted to its FBV equals the un-sharded
+   union of all maps restricted to that FBV (lower rank wins duplicates); voxels outside are untouched.
+2. the stateful protocol GRUFusion uses (distributed.BoundaryExchange, three scales packed into three collectives
+   per fragment): two ranks stream overlapping fragments of one scene through exchange -> local fusion ->
+   stamp; each rank's maps (coordinates AND features) must equal a single-process simulation of the same
+   "independent windows + exchange" schedule: newest fusion result wins, received voxels are not re-broadcast."""
 import os
 import socket
 
@@ -20,6 +25,85 @@ def rank_map(rank, dim=12, c=5):
     return pts.astype(np.int32), feat, lo
 
 
+# ---- toy fragment stream for the stateful protocol --------------------------------------------------------------
+DIMS = [6, 12, 24]          # FBV edge per scale
+CH = [5, 3, 2]
+STEPS = 4
+
+
+def fragment(rank, step, scale):
+    """(fbv origin int[3], current voxels int32[n,3] scene grid, features f32[n,C]) of fragment step*2+rank"""
+    f = step * 2 + rank
+    rng = np.random.default_rng(1000 * scale + f)
+    d = DIMS[scale]
+    lo = np.array([f * d // 3, (f % 2) * (d // 4), 0])         # consecutive fragments overlap by ~2/3
+    occ = rng.random((d, d, d)) < 0.3
+    xyz = np.argwhere(occ) + lo
+    return lo, xyz.astype(np.int32), rng.standard_normal((len(xyz), CH[scale])).astype(np.float32)
+
+
+def toy_fuse(map_c, map_f, lo, d, cur_c, cur_f):
+    """stand-in for crop/union + ConvGRU + update_map on plain tensors: inside the FBV the fused value is
+    0.5 * old + current (old = 0 where the map had nothing), rows outside stay; returns (C, F, updated coords)"""
+    inside = ((map_c >= lo) & (map_c < lo + d)).all(1)
+    old = {tuple(c): f for c, f in zip(map_c[inside].tolist(), map_f[inside])}
+    cur = {tuple(c): f for c, f in zip(cur_c.tolist(), cur_f)}
+    keys = sorted(set(old) | set(cur))
+    zero = np.zeros(map_f.shape[1], np.float32)
+    fused = np.stack([0.5 * old.get(k, zero) + cur.get(k, zero) for k in keys]) if keys else np.zeros((0, map_f.shape[1]), np.float32)
+    upd = np.array(keys, np.int32).reshape(-1, 3)
+    return (np.concatenate([map_c[~inside], upd]), np.concatenate([map_f[~inside], fused.astype(np.float32)]), upd)
+
+
+def simulate_schedule():
+    """single-process oracle of the 2-rank schedule -> per rank, per scale {coord: feature}"""
+    maps = [[(np.zeros((0, 3), np.int32), np.zeros((0, CH[s]), np.float32)) for s in range(3)] for _ in range(2)]
+    stamps = [[{} for _ in range(3)] for _ in range(2)]           # coord -> (stamp, local)
+    for step in range(STEPS):
+        frs = [[fragment(r, step, s) for s in range(3)] for r in range(2)]
+        sent = [[None] * 3 for _ in range(2)]
+        for r in range(2):                                         # what each rank sends (pre-exchange state)
+            for s in range(3):
+                c, f = maps[r][s]
+                lo_o = frs[1 - r][s][0]
+                out = []
+                for k, row in zip(c.tolist(), f):
+                    st = stamps[r][s].get(tuple(k), (-1, False))
+                    if st[1] and all(lo_o[a] <= k[a] < lo_o[a] + DIMS[s] for a in range(3)):
+                        out.append((tuple(k), st[0], row))
+                sent[r][s] = out
+        for r in range(2):                                         # receive: newer wins, absent appended
+            for s in range(3):
+                c, f = maps[r][s]
+                lo = frs[r][s][0]
+                index = {tuple(k): i for i, k in enumerate(c.tolist())}
+                f = f.copy()
+                add_c, add_f = [], []
+                for k, st, row in sent[1 - r][s]:
+                    if not all(lo[a] <= k[a] < lo[a] + DIMS[s] for a in range(3)):
+                        continue
+                    if k in index:
+                        if st > stamps[r][s].get(k, (-1, False))[0]:
+                            f[index[k]] = row
+                            stamps[r][s][k] = (st, False)
+                    else:
+                        add_c.append(k)
+                        add_f.append(row)
+                        stamps[r][s][k] = (st, False)
+                if add_c:
+                    c = np.concatenate([c, np.array(add_c, np.int32)])
+                    f = np.concatenate([f, np.stack(add_f)])
+                maps[r][s] = (c, f)
+        for r in range(2):                                         # local fusion + stamping
+            for s in range(3):
+                lo, cc, cf = frs[r][s]
+                c, f, upd = toy_fuse(*maps[r][s], lo, DIMS[s], cc, cf)
+                maps[r][s] = (c, f)
+                for k in upd.tolist():
+                    stamps[r][s][tuple(k)] = (step * 2 + r, True)
+    return [[{tuple(k): row for k, row in zip(c.tolist(), f)} for c, f in maps[r]] for r in range(2)]
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -28,12 +112,25 @@ def _worker(rank, world, port, q):
     pts, feat, lo = rank_map(rank)
     c, f = D.exchange_boundary_voxels(torch.from_numpy(pts), torch.from_numpy(feat), lo.tolist(), 12)
     parts = D.all_gather_variable(torch.arange(rank + 2, dtype=torch.float32).reshape(-1, 1))
-    q.put((rank, c.numpy(), f.numpy(), [p.numpy() for p in parts]))
+    # stateful protocol
+    ex = D.BoundaryExchange(3, torch.device("cpu"))
+    maps = [(torch.zeros((0, 3), dtype=torch.int32), torch.zeros((0, CH[s]))) for s in range(3)]
+    for step in range(STEPS):
+        frs = [fragment(rank, step, s) for s in range(3)]
+        maps = ex.exchange(maps, [fr[0].tolist() for fr in frs], DIMS)
+        for s in range(3):
+            lo_s, cc, cf = frs[s]
+            nc, nf, upd = toy_fuse(maps[s][0].numpy(), maps[s][1].numpy(), lo_s, DIMS[s], cc, cf)
+            maps[s] = (torch.from_numpy(nc), torch.from_numpy(nf))
+            ex.mark_fused(s, torch.from_numpy(upd), step * world + rank)
+    q.put((rank, c.numpy(), f.numpy(), [p.numpy() for p in parts], [(m[0].numpy(), m[1].numpy()) for m in maps],
+           ex.collectives))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_boundary_exchange_world2():
+@pytest.fixture(scope="module")
+def world2():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -44,14 +141,18 @@ def test_boundary_exchange_world2():
         p.start()
     res = {}
     for _ in range(2):
-        r, c, f, parts = q.get(timeout=120)
-        res[r] = (c, f, parts)
+        item = q.get(timeout=180)
+        res[item[0]] = item[1:]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    return res
+
+
+def test_boundary_exchange_world2(world2):
     maps = [rank_map(r) for r in range(2)]
     for r in range(2):
-        c, f, parts = res[r]
+        c, f, parts = world2[r][:3]
         assert [len(p) for p in parts] == [2, 3]                     # variable-size all-gather
         own_c, own_f, lo = maps[r]
         other_c, other_f, _ = maps[1 - r]
@@ -63,3 +164,31 @@ def test_boundary_exchange_world2():
         assert len(got) == len(expect) == len(c) - len(own_c) and len(expect) > 5
         for k, v in expect:
             assert np.array_equal(got[k], v)
+
+
+def test_fragment_streams_match_the_schedule_oracle(world2):
+    """coordinates and FEATURES of every rank's maps after 4 steps of exchange -> fuse -> stamp"""
+    expect = simulate_schedule()
+    refreshed = 0
+    for r in range(2):
+        maps, collectives = world2[r][3], world2[r][4]
+        assert collectives == 3 * STEPS                              # three collectives per fragment, all scales
+        for s in range(3):
+            got = {tuple(k): row for k, row in zip(maps[s][0].tolist(), maps[s][1])}
+            assert len(got) == len(maps[s][0])                       # no duplicate voxels
+            assert set(got) == set(expect[r][s])
+            for k, row in got.items():
+                assert np.array_equal(row, expect[r][s][k]), (r, s, k)
+            refreshed += len(got)
+    assert refreshed > 1000
+    # the schedule really shares state: some voxel of rank 0's scale-2 map carries a value rank 1 fused
+    own_only = simulate_no_exchange()
+    assert any(not np.array_equal(expect[0][2][k], own_only[k]) for k in expect[0][2] if k in own_only)
+
+
+def simulate_no_exchange():
+    c, f = np.zeros((0, 3), np.int32), np.zeros((0, CH[2]), np.float32)
+    for step in range(STEPS):
+        lo, cc, cf = fragment(0, step, 2)
+        c, f, _ = toy_fuse(c, f, lo, DIMS[2], cc, cf)
+    return {tuple(k): row for k, row in zip(c.tolist(), f)}
