@@ -19,6 +19,7 @@ import torch.nn as nn
 from . import grid_ops as GO
 from . import sparse as SP
 from .back_project import Back_Project
+from .backbone import stack_views
 from .config import (CH_IMG, CH_INIT_DOWN, CH_VOXEL, EXCEED_NUM, INIT_MIN_VIEW, INIT_OCC_THRESHOLD, INIT_STAGE,
                      N_VIEWS, NUM_CLASSES, NUM_QUERIES, PANOPTIC_CH, PANOPTIC_SHAPE, STAGE_MIN_OCC)
 from .generate_grids import dense_coords
@@ -123,7 +124,7 @@ class NeuConNet(nn.Module):
             else:
                 up_feat, up_coords = self.upsample(pre_feat, pre_coords, interval)
                 min_view_number = 0
-            feats = torch.stack([f[scale] for f in features_backbone2d_occ_pano])
+            feats = stack_views([f[scale] for f in features_backbone2d_occ_pano])   # no copy for batched backbones
             KRcam = inputs["proj_matrices"][:, :, scale].permute(1, 0, 2, 3).contiguous()
             project_output = self.back_projection[i](up_coords, inputs["vol_origin_partial"], cfg.VOXEL_SIZE,
                                                      feats, KRcam, min_view_number)

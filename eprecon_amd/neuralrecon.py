@@ -42,6 +42,7 @@ class NeuralRecon(nn.Module):
         self.backbone_occ_pano = MnasMulti(float(cfg.ALPHA))
         self.neucon_net = NeuConNet(cfg)
         self.fuse_to_global = GRUFusion(cfg, direct_substitute=True, trianing=False)
+        self.batch_views = True   # False: always the reference's per-view backbone loop
 
     def normalizer(self, x):
         return (x - self.pixel_mean.type_as(x)) / self.pixel_std.type_as(x)
@@ -51,8 +52,16 @@ class NeuralRecon(nn.Module):
         inputs = tocuda(inputs, dev)
         outputs = {}
         imgs = torch.unbind(inputs["imgs"], 1)
-        features_backbone2d = [self.backbone2d(self.normalizer(img)) for img in imgs]
-        features_occ_pano = [self.backbone_occ_pano(self.normalizer(img)) for img in imgs]
+        if torch.is_grad_enabled() or not self.batch_views:
+            # the reference's loop (models/neuralrecon.py:53-54): 2 x 9 sequential backbone calls
+            features_backbone2d = [self.backbone2d(self.normalizer(img)) for img in imgs]
+            features_occ_pano = [self.backbone_occ_pano(self.normalizer(img)) for img in imgs]
+        else:
+            # inference: the 9 views as ONE channels-last batch per backbone (per-view BatchNorm statistics, so the
+            # values are those of the loop above); the maps feed the back-projection without a re-layout
+            norm = [self.normalizer(img) for img in imgs]
+            features_backbone2d = self.backbone2d.forward_views(norm)
+            features_occ_pano = self.backbone_occ_pano.forward_views(norm)
         outputs, loss_dict = self.neucon_net(features_backbone2d, features_occ_pano, inputs, outputs)
         if not training and "coords" in outputs and "panoptic_info" in outputs:
             outputs = self.fuse_to_global(outputs["coords"], outputs["tsdf"], inputs, self.n_scales, outputs,
