@@ -39,13 +39,19 @@ class TSDFVolumeHIP:
         self._weight_vol = torch.zeros(self._vol_dim, dtype=torch.float32, device=self.device)
         self._occ = None
 
-    def integrate_views(self, depths, intrs, poses, obs_weight=1.0):
-        """depths f32[V,H,W]; intrs f32[V,3,3]; poses f32[V,4,4] (camera->world) — V successive integrate() calls"""
+    def integrate_views(self, depths, intrs, poses, obs_weight=1.0, world2cam=None):
+        """depths f32[V,H,W]; intrs f32[V,3,3]; poses f32[V,4,4] (camera->world) — V successive integrate() calls.
+        world2cam (optional, f32[V,4,4]): use these world->camera matrices instead of torch.inverse(poses); the
+        last bits of a 4x4 float inverse depend on the host's LAPACK build, so a result that must be reproduced
+        bit for bit on another machine has to carry its matrices along (tests/golden/tsdf_fusion.npz does)."""
         lib = _lib.load()
         depths = depths.to(device=self.device, dtype=torch.float32).contiguous()
         v, h, w = depths.shape
         poses = torch.as_tensor(poses).detach().float().cpu().reshape(v, 4, 4)
-        cam = torch.inverse(poses) if self._variant == 0 else poses           # fusion.py:454 (torch.inverse, CPU)
+        if self._variant == 0:
+            cam = torch.inverse(poses) if world2cam is None else torch.as_tensor(world2cam).float().cpu().reshape(v, 4, 4)
+        else:
+            cam = poses                                                      # fusion.py:454 (torch.inverse, CPU)
         cam = np.ascontiguousarray(cam.numpy(), np.float32)
         intr = np.ascontiguousarray(torch.as_tensor(intrs).detach().float().cpu().reshape(v, 3, 3).numpy(), np.float32)
         dims = (ctypes.c_int32 * 3)(*self._vol_dim)

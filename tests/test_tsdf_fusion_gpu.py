@@ -34,10 +34,12 @@ def test_matches_reference_golden(gold, case, lvl):
     window, depths, intr, poses, d_dev = case
     dims = [n // 2 ** lvl for n in window["n_vox"]]
     vol = TSDFVolumeHIP(torch.tensor(dims), torch.from_numpy(window["vol_origin_partial"]), 0.04 * 2 ** lvl, margin=3)
-    vol.integrate_views(d_dev, torch.from_numpy(intr), torch.from_numpy(poses))
-    # the world->camera matrices are torch.inverse(pose) on the host, as in the reference
-    w2c = np.stack([torch.inverse(torch.from_numpy(p).float()).numpy() for p in poses])
-    assert np.array_equal(w2c, gold["world2cam"])
+    # the world->camera matrices the reference computed (torch.inverse(pose) in the build container): the last bits
+    # of a float 4x4 inverse differ between hosts (LAPACK build), and a pixel decision can hinge on them
+    w2c = gold["world2cam"]
+    vol.integrate_views(d_dev, torch.from_numpy(intr), torch.from_numpy(poses), world2cam=w2c)
+    here = np.stack([torch.inverse(torch.from_numpy(p).float()).numpy() for p in poses])
+    assert np.abs(here - w2c).max() < 1e-6
     tsdf, weight = (t.cpu().numpy() for t in vol.get_volume())
     check_level(gold, lvl, tsdf, weight, vol.occupancy().cpu().numpy(), 0.0 if lvl < 2 else 2e-6)
     # and the numpy oracle: everything bit exact
