@@ -25,6 +25,10 @@ SIGNATURES = {
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "eprecon_back_project": (_i, [_vp, _i64, _vp, _i, _f, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "eprecon_profile_gather_kernel": (_c.c_char_p, []),
+    "eprecon_back_project_dense_workspace_bytes": (_sz, [_i64, _i]),
+    "eprecon_back_project_dense_async": (_i, [_vp, _i, _vp, _i, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
+                                             _vp, _vp, _sz, _vp]),
     "eprecon_hash_capacity": (_c.c_uint32, [_i64]),
     "eprecon_hash_table_bytes": (_sz, [_c.c_uint32]),
     "eprecon_hash_build_async": (_i, [_vp, _i64, _i, _vp, _c.c_uint32, _vp]),

@@ -728,6 +728,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restri
 struct ProfileState {
     bool on = false, recorded = false, one_shot = false;
     hipEvent_t start = nullptr, stop = nullptr;
+    const char *kernel = "";
 } g_prof;
 
 size_t gather_lds_bytes(int vox, int V, int B)
@@ -804,7 +805,27 @@ int launch_gather_mlp(const BpParams &p, int nblk, hipStream_t st)
 
 }  // namespace
 
+namespace ep {
+int profile_bracket_begin(hipStream_t st)
+{
+    if (g_prof.on && g_prof.start) EP_HIP_CHECK(hipEventRecord(g_prof.start, st));
+    return EPRECON_OK;
+}
+int profile_bracket_end(hipStream_t st, const char *kernel)
+{
+    if (g_prof.on && g_prof.start) {
+        EP_HIP_CHECK(hipEventRecord(g_prof.stop, st));
+        g_prof.recorded = true;
+        g_prof.kernel = kernel;
+        if (g_prof.one_shot) g_prof.on = false;
+    }
+    return EPRECON_OK;
+}
+}  // namespace ep
+
 extern "C" {
+
+const char *eprecon_profile_gather_kernel(void) { return g_prof.kernel; }
 
 int eprecon_abi_version(void) { return EPRECON_ABI_VERSION; }
 const char *eprecon_build_arch(void) { return "gfx950"; }
@@ -948,6 +969,7 @@ int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *or
     if (prof) {
         EP_HIP_CHECK(hipEventRecord(g_prof.stop, st));
         g_prof.recorded = true;
+        g_prof.kernel = gather_mlp_supported(p) ? "bp_gather_mlp_kernel" : "bp_gather_kernel";
         if (g_prof.one_shot) g_prof.on = false;
     }
     if (mode == EPRECON_BP_MEAN_DEPTH) {

@@ -63,4 +63,8 @@ __device__ __forceinline__ int block_exclusive_rank(bool pred, int *wave_counts,
 int exclusive_scan_i32(const int32_t *in, int n, int32_t *out, int32_t *scratch, int32_t *total_dev,
                        hipStream_t st);
 
+// the gather-kernel timing hook of eprecon_profile_enable (back_project.hip), for the other gather variants
+int profile_bracket_begin(hipStream_t st);
+int profile_bracket_end(hipStream_t st, const char *kernel);
+
 }  // namespace ep

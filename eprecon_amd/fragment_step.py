@@ -47,7 +47,8 @@ class Cfg2Step:
         # backbone #1 pyramid (initialisation) in the reference's list-of-views form
         f1 = [t(S.make_features(1000 * seed + 20 + l, N_VIEWS, self.shapes[l])) for l in range(3)]
         self.features_init = [[f1[l][v] for l in range(3)] for v in range(N_VIEWS)]
-        self.coords = {iv: t(S.dense_coords(n_vox, iv)) for iv in (4, 2, 1)}
+        # dense x-major rasters of the fragment volume (what generate_grid yields), tagged as such
+        self.coords = {iv: BP.mark_dense(t(S.dense_coords(n_vox, iv)), [n // iv for n in n_vox], iv) for iv in (4, 2, 1)}
         self.shape_init = tuple(n // 2 for n in n_vox)
         torch.manual_seed(1234)
         self.init_net = Occupancy_Initialization(CH_IMG, CH_INIT_DOWN, N_VIEWS).to(dev)

@@ -21,4 +21,5 @@ def dense_coords(n_vox, interval, batch_size, device=None):
     xyz = grid.t().to(torch.int32)
     rows = [torch.cat([torch.full((xyz.shape[0], 1), b, dtype=torch.int32, device=xyz.device), xyz], 1)
             for b in range(batch_size)]
-    return torch.cat(rows, 0).contiguous(), dims
+    from .back_project import mark_dense
+    return mark_dense(torch.cat(rows, 0).contiguous(), dims, interval, batch_size), dims

@@ -107,6 +107,25 @@ int eprecon_back_project(const int32_t *coords, int64_t n, const float *origin, 
  */
 int eprecon_profile_enable(int on);
 float eprecon_profile_gather_ms(void);
+/* family of the gather kernel the recorded pair brackets ("bp_gather_mlp_kernel", "bp_gather_brick_kernel", ...) */
+const char *eprecon_profile_gather_kernel(void);
+
+/*
+ * The same operator for a DENSE grid: the voxel list is the x-major raster of dims_host[3] voxels per batch
+ * element at spacing `interval` (finest-voxel units) — what ops/generate_grids.py:3-10 +
+ * models/neucon_network.py:246-251 build and the occupancy initialisation always back-projects.  The coordinates
+ * are implicit (out_coords is still written for the valid voxels, raster order), and workgroups own bricks of
+ * voxels whose per-view image footprint is staged once in LDS (csrc/back_project_dense.hip).  feats must be
+ * channels-last f32[V, B, H, W, C]; modes EPRECON_BP_MEAN and EPRECON_BP_VARIANCE; C in {24, 32, 40, 80};
+ * dims multiples of 8.  EPRECON_ERR_UNSUPPORTED otherwise (callers fall back to eprecon_back_project_async).
+ * Results are bit-identical to the list entry point.
+ */
+size_t eprecon_back_project_dense_workspace_bytes(int64_t n, int batch);
+int eprecon_back_project_dense_async(const int32_t *dims_host, int interval, const float *origin, int batch,
+                                     float voxel_size, const float *feats_nhwc, const float *krcam, int n_views,
+                                     int channels, int height, int width, int min_view, int mode, float *out_feats,
+                                     float *out_mean, int32_t *out_coords, float *count, int32_t *n_valid_dev,
+                                     void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * The same for the gather-GEMM convolution (bench.py's `roofline_conv`): arm a one-shot — the next
