@@ -83,6 +83,10 @@ SIGNATURES = {
     "eprecon_map_target_fuse": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i64, _vp, _vp]),
     "eprecon_gather_rows_async": (_i, [_vp, _i, _vp, _i64, _i, _f, _vp, _i, _vp]),
     "eprecon_tsdf_integrate_async": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp, _vp, _f, _f, _i, _vp, _vp]),
+    "eprecon_marching_cubes_table": (_i, [_vp]),
+    "eprecon_marching_cubes_workspace_bytes": (_sz, [_i, _i, _i]),
+    "eprecon_marching_cubes_count": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _sz, _vp]),
+    "eprecon_marching_cubes_emit_async": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eprecon_nearest_voxel_async": (_i, [_vp, _c.c_uint32, _vp, _i64, _vp, _i64, _i, _vp, _vp]),
     "eprecon_upsample2x_nhwc_async": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "eprecon_profile_enable": (_i, [_i]),

@@ -1,0 +1,155 @@
+"""Scene output: mesh extraction and export — mirror of SaveScene (utils.py:190-410 of the reference).
+
+The reference copies the dense scene volumes to the host and runs skimage's marching cubes + trimesh export there
+(utils.py:225-241,345-372).  Here the iso-surface, the per-vertex labels and the normals are produced on the GPU
+(csrc/marching_cubes.hip through the C ABI); only the finished mesh (a few MB) is copied to the host, and the .ply /
+.npz files are written without trimesh / skimage (neither is available in this environment):
+
+    mesh = tsdf2mesh(voxel_size, origin, tsdf_vol)                        # utils.py:225-229
+    mesh, labels = tsdf_panoptic2mesh(voxel_size, origin, tsdf, semantic, instance)   # :232-241
+    SaveScene(cfg)(outputs, inputs, epoch_idx)                            # :374-410, SAVE_SCENE_MESH path
+
+A mesh is a plain dict {vertices f32[N,3] (world metres), faces int32[M,3], vertex_normals f32[N,3]} (+ colours).
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+
+# utils.py:243-254 (RGB)
+COLOR_PALETTE = np.array([
+    [255, 192, 203], [128, 128, 128], [144, 238, 144], [0, 0, 255], [255, 255, 0], [0, 255, 255],
+    [0, 128, 255], [128, 0, 255], [255, 0, 128], [255, 0, 0], [255, 255, 255],
+    [255, 192, 203], [75, 0, 130], [255, 165, 0], [0, 100, 0], [255, 20, 147],
+    [100, 149, 237], [255, 105, 180], [205, 92, 92], [186, 85, 211], [124, 252, 0],
+    [70, 130, 180], [255, 215, 0], [0, 255, 255], [255, 69, 0], [138, 43, 226],
+    [255, 105, 180], [70, 130, 180], [255, 192, 203], [219, 112, 147], [128, 128, 0],
+    [255, 105, 180], [255, 20, 147], [255, 99, 71], [255, 69, 0], [255, 215, 0],
+    [255, 182, 193], [0, 255, 0], [0, 255, 127], [34, 139, 34], [255, 240, 245],
+    [255, 0, 255], [128, 0, 0], [0, 128, 0], [0, 0, 128], [128, 128, 0],
+    [0, 128, 128], [128, 0, 128], [255, 128, 0], [128, 255, 0], [0, 255, 128]], dtype=np.uint8)
+
+
+def marching_cubes(volume, level=0.0, labels=()):
+    """volume f32[X,Y,Z] on the GPU -> (verts f32[N,3] voxel coordinates, faces int32[M,3], normals f32[N,3],
+    [per-vertex labels int32[N] for every int32 volume in `labels`]) as device tensors"""
+    lib = _lib.load()
+    if volume.device.type != "cuda":
+        raise _lib.EpreconError("eprecon_amd operators need device tensors (no CPU fallback)")
+    vol = volume.to(torch.float32).contiguous()
+    dx, dy, dz = vol.shape
+    dev = vol.device
+    ws = torch.empty(int(lib.eprecon_marching_cubes_workspace_bytes(dx, dy, dz)), dtype=torch.uint8, device=dev)
+    counts = (ctypes.c_int64 * 2)()
+    _lib.check(lib.eprecon_marching_cubes_count(_lib.ptr(vol), dx, dy, dz, float(level), ctypes.cast(counts, ctypes.c_void_p),
+                                                _lib.ptr(ws), ws.numel(), _lib.current_stream()), "eprecon_marching_cubes_count")
+    nv, nt = int(counts[0]), int(counts[1])
+    verts = torch.empty((nv, 3), dtype=torch.float32, device=dev)
+    normals = torch.empty((nv, 3), dtype=torch.float32, device=dev)
+    faces = torch.empty((nt, 3), dtype=torch.int32, device=dev)
+    labs = [l.to(torch.int32).contiguous() for l in labels]
+    assert len(labs) <= 2 and all(l.shape == vol.shape for l in labs)
+    outs = [torch.empty(nv, dtype=torch.int32, device=dev) for _ in labs]
+    la, lb = (labs + [None, None])[:2]
+    oa, ob = (outs + [None, None])[:2]
+    if nv > 0:
+        _lib.check(lib.eprecon_marching_cubes_emit_async(
+            _lib.ptr(vol), dx, dy, dz, float(level), _lib.ptr(verts), _lib.ptr(normals), _lib.ptr(faces), _lib.ptr(la),
+            _lib.ptr(lb), _lib.ptr(oa), _lib.ptr(ob), _lib.ptr(ws), _lib.current_stream()), "eprecon_marching_cubes_emit_async")
+    return (verts, faces, normals) + tuple(outs)
+
+
+def _mesh(voxel_size, origin, verts, faces, normals):
+    origin = torch.as_tensor(origin, dtype=torch.float32, device=verts.device).reshape(1, 3)
+    return {"vertices": (verts * float(voxel_size) + origin).cpu().numpy(), "faces": faces.cpu().numpy(),
+            "vertex_normals": normals.cpu().numpy()}
+
+
+def tsdf2mesh(voxel_size, origin, tsdf_vol):
+    """utils.py:225-229"""
+    verts, faces, normals = marching_cubes(tsdf_vol, 0.0)
+    return _mesh(voxel_size, origin, verts, faces, normals)
+
+
+def tsdf_panoptic2mesh(voxel_size, origin, tsdf_vol, semantic_vol, instance_vol):
+    """utils.py:232-293 -> (mesh, mesh_semantic, mesh_instance): the same geometry with per-vertex colours from the
+    palette (semantic id; instance id modulo the palette size); `vertex_semantic` / `vertex_instance` keep the ids"""
+    verts, faces, normals, sem, ins = marching_cubes(tsdf_vol, 0.0, labels=(semantic_vol, instance_vol))
+    mesh = _mesh(voxel_size, origin, verts, faces, normals)
+    sem, ins = sem.cpu().numpy(), ins.cpu().numpy()
+    mesh_sem = dict(mesh, vertex_colors=COLOR_PALETTE[sem.astype(np.int64) % len(COLOR_PALETTE)], vertex_semantic=sem)
+    mesh_ins = dict(mesh, vertex_colors=COLOR_PALETTE[ins.astype(np.int64) % len(COLOR_PALETTE)], vertex_instance=ins)
+    return mesh, mesh_sem, mesh_ins
+
+
+def export_ply(mesh, path):
+    """binary little-endian PLY with normals and (when present) RGB vertex colours — what trimesh's mesh.export writes"""
+    v = np.ascontiguousarray(mesh["vertices"], np.float32)
+    n = np.ascontiguousarray(mesh["vertex_normals"], np.float32)
+    f = np.ascontiguousarray(mesh["faces"], np.int32)
+    col = mesh.get("vertex_colors")
+    fields = [("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("nx", "<f4"), ("ny", "<f4"), ("nz", "<f4")]
+    if col is not None:
+        fields += [("red", "u1"), ("green", "u1"), ("blue", "u1")]
+    rec = np.zeros(len(v), dtype=fields)
+    rec["x"], rec["y"], rec["z"] = v[:, 0], v[:, 1], v[:, 2]
+    rec["nx"], rec["ny"], rec["nz"] = n[:, 0], n[:, 1], n[:, 2]
+    if col is not None:
+        rec["red"], rec["green"], rec["blue"] = col[:, 0], col[:, 1], col[:, 2]
+    frec = np.zeros(len(f), dtype=[("n", "u1"), ("a", "<i4"), ("b", "<i4"), ("c", "<i4")])
+    frec["n"], frec["a"], frec["b"], frec["c"] = 3, f[:, 0], f[:, 1], f[:, 2]
+    names = {"<f4": "float", "u1": "uchar"}
+    head = ["ply", "format binary_little_endian 1.0", f"element vertex {len(v)}"]
+    head += [f"property {names[t]} {k}" for k, t in fields]
+    head += [f"element face {len(f)}", "property list uchar int vertex_indices", "end_header"]
+    with open(path, "wb") as fh:
+        fh.write(("\\n".join(head) + "\\n").encode("ascii"))
+        fh.write(rec.tobytes())
+        fh.write(frec.tobytes())
+
+
+class SaveScene:
+    """utils.py:190-410 (SAVE_SCENE_MESH / SAVE_INCREMENTAL paths; the Open3D incremental viewer is out of scope)"""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        log_dir = str(getattr(cfg, "LOGDIR", "logs")).split("/")[-1]
+        self.log_dir = os.path.join("results", "scene_" + str(getattr(cfg, "DATASET", "scannet")) + "_" + log_dir)
+        self.scene_name = None
+        self.keyframe_id = None
+
+    def reset(self):
+        self.keyframe_id = 0
+
+    def _voxel_size(self):
+        model = getattr(self.cfg, "MODEL", self.cfg)
+        return float(model.VOXEL_SIZE)
+
+    def save_scene_eval(self, epoch, outputs, batch_idx=0):
+        """utils.py:345-372: mesh + semantic / instance coloured copies (.ply) and the volumes (.npz)"""
+        tsdf = outputs["scene_tsdf"][batch_idx]
+        if bool((tsdf == 1).all()):
+            print(f"[eprecon_amd] warning: No valid data for scene {self.scene_name}")
+            return None
+        sem, ins, origin = outputs["scene_semantic"][batch_idx], outputs["scene_instance"][batch_idx], outputs["origin"][batch_idx]
+        mesh, mesh_sem, mesh_ins = tsdf_panoptic2mesh(self._voxel_size(), origin, tsdf, sem, ins)
+        save_path = "{}_fusion_eval_{}".format(self.log_dir, epoch)
+        os.makedirs(save_path, exist_ok=True)
+        np.savez_compressed(os.path.join(save_path, "{}.npz".format(self.scene_name)),
+                            origin=origin.cpu().numpy(), voxel_size=self._voxel_size(), tsdf=tsdf.cpu().numpy(),
+                            semantic=sem.cpu().numpy(), instance=ins.cpu().numpy())
+        export_ply(mesh, os.path.join(save_path, "{}.ply".format(self.scene_name)))
+        export_ply(mesh_sem, os.path.join(save_path, "mesh_semantic_{}.ply".format(self.scene_name)))
+        export_ply(mesh_ins, os.path.join(save_path, "mesh_instance_{}.ply".format(self.scene_name)))
+        return save_path
+
+    def __call__(self, outputs, inputs, epoch_idx):
+        if "scene_name" not in outputs:      # no scene saved, skip (utils.py:375-377)
+            return
+        for i, scene in enumerate(outputs["scene_name"]):
+            self.scene_name = scene.replace("/", "-")
+            if getattr(self.cfg, "SAVE_SCENE_MESH", True):
+                self.save_scene_eval(epoch_idx, outputs, i)

@@ -479,6 +479,28 @@ int eprecon_tsdf_integrate_async(float *tsdf, float *weight, const int32_t *dims
                                  int variant, uint8_t *occ_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Scene mesh extraction: marching cubes on the dense scene TSDF  (scene output path)
+ *
+ * Replaces  skimage.measure.marching_cubes(tsdf_vol, level=0) + the vertex label lookups of
+ *           SaveScene.tsdf2mesh / tsdf_panoptic2mesh                       utils.py:225-241
+ * so the dense volumes of GRUFusion.save_mesh (models/gru_fusion.py:217-257) become a mesh on the device.
+ * volume f32[dx,dy,dz] (x-major).  Two phases: _count (blocking: one host read of the sizes, the scanned
+ * offsets stay in `workspace`), then _emit_async into caller buffers: verts f32[nv,3] in voxel
+ * coordinates (the caller applies voxel_size / origin like utils.py:228), normals f32[nv,3] (unit field
+ * gradient) or NULL, faces int32[nt,3] wound along the gradient; vert_label_a/b int32[nv]: labels of the
+ * voxel nearest to each vertex from two optional int32 volumes (semantic / instance).
+ * Vertices are the sign-change points any marching-cubes variant yields; the triangulation table is
+ * generated from one rule (csrc/marching_cubes.hip) — skimage's Lewiner tables are not reproduced.
+ * ------------------------------------------------------------------------------------------ */
+int eprecon_marching_cubes_table(int8_t *out_host /* [256][16] */);
+size_t eprecon_marching_cubes_workspace_bytes(int dx, int dy, int dz);
+int eprecon_marching_cubes_count(const float *volume, int dx, int dy, int dz, float level, int64_t *counts_host,
+                                 void *workspace, size_t workspace_bytes, void *stream);
+int eprecon_marching_cubes_emit_async(const float *volume, int dx, int dy, int dz, float level, float *verts, float *normals,
+                                      int32_t *faces, const int32_t *label_a, const int32_t *label_b, int32_t *vert_label_a,
+                                      int32_t *vert_label_b, const void *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Nearest finest-level voxel  (K18)
  *
  * Replaces  torch.cdist + argmin(dim=1)                 models/mask3dformer.py:361-367
