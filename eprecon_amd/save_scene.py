@@ -106,7 +106,7 @@ def export_ply(mesh, path):
     head += [f"property {names[t]} {k}" for k, t in fields]
     head += [f"element face {len(f)}", "property list uchar int vertex_indices", "end_header"]
     with open(path, "wb") as fh:
-        fh.write(("\\n".join(head) + "\\n").encode("ascii"))
+        fh.write(("\n".join(head) + "\n").encode("ascii"))
         fh.write(rec.tobytes())
         fh.write(frec.tobytes())
 
