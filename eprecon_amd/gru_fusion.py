@@ -21,7 +21,7 @@ from . import _lib
 from .global_map import GlobalMap
 from .modules import ConvGRU
 from .tensor import PointTensor
-from .torchsparse_utils import aligned_camera_coords
+from .torchsparse_utils import aligned_camera_coords, prepare_convgru_voxelizations
 
 
 def fbv_union(cur_coords, cur_feat, glob_coords, glob_feat, dim, interval, rel, mode=0):
@@ -96,6 +96,8 @@ class GRUFusion(nn.Module):
             self.fusion_nets_img.append(ConvGRU(hidden_dim=ch, input_dim=ch, pres=1,
                                                 vres=cfg.VOXEL_SIZE * 2 ** (self.n_scales - i)))
         self._identity_fusion = False  # tests: skip the ConvGRUs (pins the bookkeeping alone)
+        self.two_streams = __import__("os").environ.get("EPRECON_GRU_STREAMS", "1") == "1"
+        self._side = None
         self._xchg = None              # multi-GPU: distributed.BoundaryExchange (stamps of the map voxels)
         self._n_exchanged = self._cur_fragment = 0
 
@@ -211,10 +213,22 @@ class GRUFusion(nn.Module):
                 r_coords = aligned_camera_coords(pts_c, origin.reshape(1, 3), cfg.VOXEL_SIZE,
                                                  inputs["world_to_aligned_camera"][i].reshape(1, 4, 4))
                 # both cells see the same points: their six SConv3d share two voxelisations (torchsparse_utils)
-                self.fusion_nets_voxel[scale](PointTensor(hx_v[:, :chv], r_coords), PointTensor(hx_v[:, chv:], r_coords),
-                                              out=values[:, :chv])
-                self.fusion_nets_img[scale](PointTensor(hx_i[:, :chi], r_coords), PointTensor(hx_i[:, chi:], r_coords),
-                                            out=values[:, chv:])
+                gv, gi = self.fusion_nets_voxel[scale], self.fusion_nets_img[scale]
+                if self.two_streams and dev.type == "cuda" and not torch.is_grad_enabled():
+                    # the shared voxelisations are built first; the two cells (independent channel groups) then run
+                    # on two HIP streams: each is a chain of small kernels that leaves most CUs idle on its own
+                    prepare_convgru_voxelizations(r_coords, gv.convz.pres, gv.convz.vres)
+                    main = torch.cuda.current_stream(dev)
+                    if self._side is None:
+                        self._side = torch.cuda.Stream(device=dev)
+                    self._side.wait_stream(main)
+                    with torch.cuda.stream(self._side):
+                        gi(PointTensor(hx_i[:, :chi], r_coords), PointTensor(hx_i[:, chi:], r_coords), out=values[:, chv:])
+                    gv(PointTensor(hx_v[:, :chv], r_coords), PointTensor(hx_v[:, chv:], r_coords), out=values[:, :chv])
+                    main.wait_stream(self._side)
+                else:
+                    gv(PointTensor(hx_v[:, :chv], r_coords), PointTensor(hx_v[:, chv:], r_coords), out=values[:, :chv])
+                    gi(PointTensor(hx_i[:, :chi], r_coords), PointTensor(hx_i[:, chi:], r_coords), out=values[:, chv:])
             else:
                 values[:, :chv], values[:, chv:] = hx_v[:, chv:], hx_i[:, chi:]
 

@@ -63,7 +63,13 @@ def unique_coords(coords, quantum=1):
                                                grid.capacity, _lib.ptr(inverse), _lib.ptr(uniq),
                                                _lib.ptr(n_unique), _lib.ptr(ws), ws.numel(),
                                                _lib.current_stream()), "eprecon_unique_coords_async")
-    m = int(n_unique.item())
+    # one host read for the voxel count AND the table's status word (bit 0: a key out of the packable range —
+    # |coordinate| >= 2^19 - 1 or batch > 14 —, bit 1: table full): such voxels would otherwise silently drop out of
+    # every kernel map built on this set
+    m, status = torch.cat([n_unique, grid.mem[:4].view(torch.int32)]).tolist()
+    if status:
+        raise _lib.EpreconError(f"hash grid: {'coordinate / batch index out of range' if status & 1 else 'table full'} "
+                                f"(status {status}, EPRECON_ERR_UNSUPPORTED)")
     return uniq[:m], inverse, grid
 
 

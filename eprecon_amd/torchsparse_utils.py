@@ -132,6 +132,41 @@ def _voxelize_points(pts, res):
     return e
 
 
+def _entry_corner_tables(e):
+    """corner indices / weights of an entry's own points against its own voxel set (what the first voxel_to_point of
+    an SConv3d on these points computes)"""
+    if e.idx8 is None:
+        lib = _lib.load()
+        n = e.scaled.shape[0]
+        idx8 = torch.empty((n, 8), dtype=torch.int32, device=e.scaled.device)
+        w8 = torch.empty((n, 8), dtype=torch.float32, device=e.scaled.device)
+        grid = e.vset.grid
+        _lib.check(lib.eprecon_trilinear_map_async(_lib.ptr(grid.mem), grid.capacity, _lib.ptr(e.scaled), n, 1,
+                                                   _lib.ptr(idx8), _lib.ptr(w8), _lib.current_stream()),
+                   "eprecon_trilinear_map_async")
+        e.idx8, e.w8 = idx8, w8
+    return e.idx8, e.w8
+
+
+def prepare_convgru_voxelizations(coords, init_res, after_res):
+    """Everything the six SConv3d of the two ConvGRUs of a scale share, built up front on the current stream: the
+    voxelisation of `coords` (convz / convq) and of the once-scaled coordinates (convr), their kernel maps and corner
+    tables (stale ones in LITERAL_CONVR mode).  Afterwards the two cells only READ these entries and can run on two
+    streams."""
+    res = float(after_res) / float(init_res) if init_res != 1 else float(after_res)
+    pts = coords if coords.is_contiguous() else coords.contiguous()
+    e1 = _voxelize_points(pts, res)
+    e1.vset.kernel_map(3)
+    _entry_corner_tables(e1)
+    e2 = _voxelize_points(e1.scaled, res)
+    e2.vset.kernel_map(3)
+    if LITERAL_CONVR:
+        e2.stale_from(e1)
+    else:
+        _entry_corner_tables(e2)
+    return e1, e2
+
+
 def initial_voxelize(z, init_res, after_res):
     """ops/torchsparse_utils.py:15-35: floor(z.C * init_res / after_res) -> unique voxels
     (first-occurrence order) -> scatter-mean of z.F.  Overwrites z.C with the scaled coordinates.

@@ -38,6 +38,15 @@ def test_hash_rejects_out_of_range_keys():
         g.status_ok()
 
 
+def test_unique_raises_on_out_of_range_voxels():
+    """production path: the status word travels with the voxel count (no extra synchronisation) and raises"""
+    from eprecon_amd import _lib
+    from eprecon_amd.sparse import unique_coords
+    c = np.array([[0, 1, 2, 3], [0, 1, 2, 3], [15, 0, 0, 0]], np.int32)      # batch index 15 cannot be packed
+    with pytest.raises(_lib.EpreconError):
+        unique_coords(dev(c), 1)
+
+
 @pytest.mark.parametrize("q", [1, 2, 4])
 def test_unique_first_occurrence(q):
     from eprecon_amd.sparse import unique_coords
