@@ -6,7 +6,7 @@ os.makedirs(dst, exist_ok=True)
 bench = [l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][-1]
 open(os.path.join(dst, f"bench_cfg2_{tag}.json"), "w").write(bench)
 b = json.loads(bench)
-steps = 35
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 35
 rows = list(csv.DictReader(open(os.path.join(src, "stats", "r_kernel_stats.csv"))))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 out = [f"# MI355X, {tag}: rocprofv3 --kernel-trace --stats -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline",
@@ -28,7 +28,7 @@ for d in sorted(os.listdir(src)):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if "bp_gather_mlp_kernel<256" in n or "spconv_resident_kernel<1, true, 4>" in n:
+        if "bp_gather_mlp_kernel<256" in n or "spconv_resident_kernel<1, true, 4" in n:
             short = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             acc[(short, r["Grid_Size"], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (n, g, c), v in sorted(acc.items()):
