@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured streaming ceiling)
 F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, f32 in / f32 accumulate
 DOMINANT_KERNEL = "bp_gather_mlp_kernel<256,MEAN,6,1>"
+L1_PEAK_LINES = 256 * 2.4e9  # vector-L1 line accesses per second: 256 CUs x 1 line per clock x 2.4 GHz
 
 
 def newest_profile(name):
@@ -309,7 +310,7 @@ def main():
         value = world * args.steps / elapsed
         gm = float(np.mean([g for g in gather_ms if g > 0])) if any(g > 0 for g in gather_ms) else None
         alg = step.dominant_kernel_bytes()
-        traffic, traffic_src = None, None
+        traffic, traffic_src, l1 = None, None, None
         pmc = newest_profile("pmc_traffic_bp_gather.json")
         if pmc:
             # HBM-side bytes per launch from the newest committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
@@ -318,12 +319,19 @@ def main():
             rec = json.load(open(pmc))
             if rec.get("kernel") == DOMINANT_KERNEL:
                 traffic, traffic_src = rec["traffic_bytes"], os.path.relpath(pmc, ROOT)
+                if rec.get("l1_accesses") and gm:
+                    # what actually limits this gather: vector-L1 line accesses per launch (PMC,
+                    # TCP_TOTAL_CACHE_ACCESSES) against 256 CUs x 1 line / clk x 2.4 GHz
+                    rate = rec["l1_accesses"] / (gm * 1e-3)
+                    l1 = {"line_accesses": rec["l1_accesses"], "achieved_glines_per_s": rate / 1e9,
+                          "peak_glines_per_s": L1_PEAK_LINES / 1e9, "frac": rate / L1_PEAK_LINES}
             else:
                 traffic_src = f"{os.path.relpath(pmc, ROOT)} measured {rec.get('kernel')!r}, not this kernel: traffic withheld"
         roof = {"bound": "hbm", "kernel": DOMINANT_KERNEL + " (dense 96^3, C=24, 120x160)",
                 "achieved": (alg / (gm * 1e-3) / 1e9) if gm else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (alg / (gm * 1e-3) / 1e9 / HBM_PEAK_GBS) if gm else None,
-                "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": alg, "avg_launch_ms": gm}
+                "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": alg, "avg_launch_ms": gm,
+                "limiter": "vector-L1 line rate (two 64-byte lines per 96-byte tap), see l1", "l1": l1}
         out = {"metric": "fragments_per_sec", "value": value, "unit": "fragments/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
