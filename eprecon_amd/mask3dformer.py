@@ -178,6 +178,10 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         self.level_embed = nn.Embedding(self.num_feature_levels, hidden_dim)
         self.class_embed = nn.Linear(hidden_dim, num_classes + 1)
         self.mask_embed = MLP(hidden_dim, hidden_dim * 4, mask_dim, 3)
+        # the static-shape query side of every layer replayed from HIP graphs on the GPU inference path
+        _env = __import__("os").environ
+        self.use_hip_graph = _env.get("EPRECON_NO_GRAPH", "0") != "1" and _env.get("EPRECON_DECODER_GRAPH", "1") == "1"
+        self._plan = None
 
     def get_pos_encs(self, coords, spitial_shape):
         out = []
@@ -197,6 +201,71 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         attn = outputs_mask[0] if mask_indices is None else outputs_mask[0].index_select(1, mask_indices)
         return outputs_class, outputs_mask, (attn.sigmoid() < 0.5).detach()
 
+    # ---- query side of a layer: everything between two cross-attentions has the STATIC shape [Q, C] ----------------
+    def _project_q(self, j, output, query_embed):
+        """in-projected, head-split queries of layer j's cross-attention: [1, H, Q, C/H]"""
+        attn = self.transformer_cross_attention_layers[j].multihead_attn
+        c, h = attn.embed_dim, attn.num_heads
+        q = F.linear((output + query_embed).squeeze(1), attn.in_proj_weight[:c], attn.in_proj_bias[:c])
+        return q.view(q.shape[0], h, c // h).transpose(0, 1).unsqueeze(0)
+
+    def _head_static(self, output):
+        dec = self.decoder_norm(output).transpose(0, 1)
+        return self.class_embed(dec), self.mask_embed(dec)
+
+    def _query_side(self, j, o_attn, output, query_embed):
+        """after the scaled-dot-product of layer j's cross-attention (o_attn [1, H, Q, C/H]): out-projection +
+        residual + LayerNorm, self-attention, FFN, the prediction head's class / mask embeddings and the next
+        layer's projected queries"""
+        cross = self.transformer_cross_attention_layers[j]
+        attn = cross.multihead_attn
+        o = o_attn.squeeze(0).transpose(0, 1).reshape(-1, attn.embed_dim)
+        output = cross.norm(output + F.linear(o, attn.out_proj.weight, attn.out_proj.bias).unsqueeze(1))
+        output = self.transformer_self_attention_layers[j](output, query_pos=query_embed)
+        output = self.transformer_ffn_layers[j](output)
+        cls, me = self._head_static(output)
+        q_next = self._project_q(j + 1, output, query_embed) if j + 1 < self.num_layers else None
+        return output, cls, me, q_next
+
+    def _static_plan(self, device):
+        """Inference on the GPU: the query side of every layer captured once into a HIP graph (7 small GEMMs, two
+        LayerNorms, an 80 x 80 attention, ... per layer -> one replay), chained through static tensors; re-captured
+        when a parameter changes.  Returns None when graphs cannot be used (CPU, autograd)."""
+        if device.type != "cuda" or torch.is_grad_enabled() or not self.use_hip_graph:
+            return None
+        key = (device, tuple(p._version for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()))
+        plan = self._plan
+        if plan is not None and plan["key"] == key:
+            return plan
+        qe = self.query_embed.weight.unsqueeze(1)
+        attn0 = self.transformer_cross_attention_layers[0].multihead_attn
+        h, c = attn0.num_heads, attn0.embed_dim
+        state = self.query_feat.weight.unsqueeze(1)
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            cls0, me0 = self._head_static(state)
+            q0 = self._project_q(0, state, qe)
+            o_in = [torch.zeros((1, h, self.num_queries, c // h), device=device) for _ in range(self.num_layers)]
+            for j in range(self.num_layers):     # warm-up outside the capture (first-use work of the libraries)
+                self._query_side(j, o_in[j], state, qe)
+        torch.cuda.current_stream(device).wait_stream(side)
+        layers = []
+        for j in range(self.num_layers):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                state, cls, me, q_next = self._query_side(j, o_in[j], state, qe)
+            layers.append({"graph": g, "o_in": o_in[j], "cls": cls, "me": me, "q_next": q_next})
+        plan = {"key": key, "cls0": cls0, "me0": me0, "q0": q0, "layers": layers}
+        self._plan = plan
+        return plan
+
+    def _mask_and_block(self, me, mask_features, mask_indices):
+        """mask logits [1, Q, N2] of a prediction head and the attention mask bool[Q, N_level] (True = blocked)"""
+        outputs_mask = torch.einsum("bqc,bcl->bql", me, mask_features)
+        attn = outputs_mask[0] if mask_indices is None else outputs_mask[0].index_select(1, mask_indices)
+        return outputs_mask, (attn.sigmoid() < 0.5).detach()
+
     def forward(self, panoptic_features, panoptic_coords, mask_features, spitial_shape):
         """panoptic_features 3 x [1, C, N_l]; panoptic_coords 3 x [1, N_l, 3]; mask_features [1, C, N_2]"""
         pos = self.get_pos_encs(panoptic_coords, spitial_shape)
@@ -211,8 +280,30 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
                         nearest_fine_index(panoptic_coords[1].squeeze(0), fine, 2), None]
         keys_in = [s_ + p_ for s_, p_ in zip(src, pos)]      # each level serves two layers
         query_embed = self.query_embed.weight.unsqueeze(1)
-        output = self.query_feat.weight.unsqueeze(1)
         classes, masks = [], []
+        plan = self._static_plan(mask_features.device)
+        if plan is not None:
+            # ---- GPU inference: per layer only the voxel-count dependent work is issued eagerly (key / value
+            # projections, the masked scaled-dot-product, the mask logits); the query side is one graph replay ----
+            cls, me, q = plan["cls0"], plan["me0"], plan["q0"]
+            msk, blocked = self._mask_and_block(me, mask_features, mask_indices[0])
+            classes.append(cls.clone())
+            masks.append(msk)
+            for j in range(self.num_layers):
+                lvl = j % self.num_feature_levels
+                blocked = blocked & ~blocked.all(dim=-1, keepdim=True)        # :388 without the host round trip
+                kv = self.transformer_cross_attention_layers[j].project_kv(keys_in[lvl], src[lvl])
+                step = plan["layers"][j]
+                step["o_in"].copy_(F.scaled_dot_product_attention(q, kv[0], kv[1], attn_mask=~blocked))
+                step["graph"].replay()
+                nxt = (j + 1) % self.num_feature_levels
+                msk, blocked = self._mask_and_block(step["me"], mask_features, mask_indices[nxt])
+                classes.append(step["cls"].clone())
+                masks.append(msk)
+                q = step["q_next"]
+            return {"pred_logits": classes[-1], "pred_masks": masks[-1],
+                    "aux_outputs": [{"pred_logits": a, "pred_masks": b} for a, b in zip(classes[:-1], masks[:-1])]}
+        output = self.query_feat.weight.unsqueeze(1)
         cls, msk, blocked = self.forward_prediction_heads(output, mask_features, sizes[0], mask_indices[0])
         classes.append(cls)
         masks.append(msk)
