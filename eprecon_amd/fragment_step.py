@@ -55,6 +55,8 @@ class Cfg2Step:
         self.init_net.train()  # the reference tests in train mode (main.py:357)
         self.last = {}
         self.profile_dominant = False  # bench.py: time the dense 96^3 gather with the library's event pair
+        self.bp_side_stream = os.environ.get("EPRECON_CFG2_BP_STREAM", "0") == "1"
+        self._bp_stream = torch.cuda.Stream(device=dev) if self.bp_side_stream else None
 
     @torch.no_grad()
     def run(self):
@@ -65,11 +67,17 @@ class Cfg2Step:
         still run one after the other, only the host gaps between the levels disappear."""
         out = {}
         pending = {}
-        for name, lvl, interval, mv in LEVELS:
-            if self.profile_dominant and name == "bp96":
-                _lib.load().eprecon_profile_enable(2)  # one-shot: bracket this level's gather kernel only
-            pending[name] = BP.run_async(self.coords[interval], self.origin, self.voxel_size, self.feats[lvl],
-                                         self.krcam[lvl], mv)
+        main = torch.cuda.current_stream(self.device)
+        side = self._bp_stream if self.bp_side_stream else main
+        if side is not main:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            # EPRECON_CFG2_BP_STREAM=1: the three levels on their own stream, concurrent with the initialisation branch
+            for name, lvl, interval, mv in LEVELS:
+                if self.profile_dominant and name == "bp96":
+                    _lib.load().eprecon_profile_enable(2)  # one-shot: bracket this level's gather kernel only
+                pending[name] = BP.run_async(self.coords[interval], self.origin, self.voxel_size, self.feats[lvl],
+                                             self.krcam[lvl], mv)
         init = self.init_net(self.coords[2], self.origin, self.voxel_size, self.features_init,
                              self.krcam[1], self.shape_init, 1, 2)
         out["init"] = init
@@ -77,6 +85,8 @@ class Cfg2Step:
             out["stage0_coords"], _ = GO.init_select(init[0], init[1], 1, dim=self.shape_init[0] // 2, cell=4)
         for name in pending:
             out[name] = pending[name].result()
+        if side is not main:
+            main.wait_stream(side)
         self.last = out
         return out
 
