@@ -188,7 +188,8 @@ def bench_cfg5(device, rank, world, dist, steps=8, warmup=4):
     """whole NeuConNet.forward per fragment with the boundary exchange on; fragments/s over all ranks"""
     import torch
     from eprecon_amd.fragment_step import Cfg4Step
-    step = Cfg4Step(seed=0, device=device, rank=rank, world=world)
+    step = Cfg4Step(seed=0, device=device, rank=rank, world=world, force_exchange=True)
+    step.raise_on_early_return = False
     for _ in range(warmup):
         step.run()
     dist.barrier()
@@ -302,7 +303,7 @@ def main():
     # preceded by the RCCL boundary-voxel exchange (eprecon_amd/distributed.py).  All ranks take part; reported
     # under `extra` (the headline stays the cfg2 metric on independent windows).
     cfg5 = None
-    if world > 1 and not args.no_extra:
+    if use_dist and not args.no_extra:   # (EPRECON_BENCH_FORCE_DIST=1 exercises this leg in a single-rank group)
         cfg5 = bench_cfg5(torch.device("cuda", local_rank), rank, world, dist)
 
     if rank == 0:
@@ -340,6 +341,8 @@ def main():
             out["roofline_conv"] = conv_roofline(step, lib)
             if not args.no_extra:
                 out["extra"] = extra_workloads(torch.device("cuda", local_rank))
+                if cfg5 is not None:
+                    out["extra"].update(cfg5)
         elif cfg5 is not None:
             out["extra"] = cfg5
         if world == 1 and not args.no_cpu_baseline:

@@ -141,7 +141,7 @@ class Cfg4Step:
     windows of one scene (camera arc advanced 0.32 m per fragment, persistent GRU map).
     One step = one fragment; the scene restarts every `n_fragments` steps."""
 
-    def __init__(self, seed=0, device=None, height=480, width=640, n_fragments=4, rank=0, world=1):
+    def __init__(self, seed=0, device=None, height=480, width=640, n_fragments=4, rank=0, world=1, force_exchange=False):
         from .config import ModelCfg
         from .neucon_network import NeuConNet
         self.device = device or torch.device("cuda")
@@ -171,7 +171,7 @@ class Cfg4Step:
         else:
             calibrate_occupancy_heads(self.net, *self.frags[0])
         # EPRECON_FORCE_EXCHANGE=1: run the boundary all-gather even at world size 1 (exercises the RCCL path on one GPU)
-        self.net.distributed_exchange = world > 1 or os.environ.get("EPRECON_FORCE_EXCHANGE", "0") == "1"
+        self.net.distributed_exchange = world > 1 or os.environ.get("EPRECON_FORCE_EXCHANGE", "0") == "1" or force_exchange
         self.k = 0
         self.last = None
         self.voxels = []  # finest-level voxel count of every fragment run so far
