@@ -10,6 +10,8 @@
 // and never relied on — SURVEY.md appendix A.2): unique voxels are numbered in order of FIRST
 // OCCURRENCE in the input list.  All kernels are atomic-free in their outputs except the hash
 // insert (atomicCAS on the key, atomicMin on the row index), whose result is order-independent.
+#include <stdlib.h>
+
 #include "hashgrid.hpp"
 
 namespace {
@@ -103,6 +105,50 @@ __global__ __launch_bounds__(kScanBlock) void scan_apply(const int32_t *in, int 
     }
 }
 
+// short inputs: the whole scan in ONE workgroup (1024 threads x 8 items per round, carry between rounds): one launch
+// instead of three for the many scans over a few thousand elements of the voxelisation / union bookkeeping
+constexpr int kSmallScanMax = 32768;
+__global__ __launch_bounds__(1024) void scan_small_kernel(const int32_t *in, int n, int32_t *out, int32_t *total)
+{
+    __shared__ int sWave[1024 / kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+    int carry = 0;
+    for (int base = 0; base < n; base += 1024 * kScanItems) {
+        const int b0 = base + tid * kScanItems;  // blocked arrangement
+        int v[kScanItems];
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            v[k] = (b0 + k < n) ? in[b0 + k] : 0;
+            s += v[k];
+        }
+        int x = s;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == kWave - 1) sWave[wid] = x;
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 1024 / kWave; ++w) {
+            const int c = sWave[w];
+            woff += (w < wid) ? c : 0;
+            tot += c;
+        }
+        int off = carry + woff + x - s;
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            if (b0 + k < n) out[b0 + k] = off;
+            off += v[k];
+        }
+        carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0 && total) *total = carry;
+}
+
 }  // namespace
 
 namespace ep {
@@ -112,6 +158,12 @@ int exclusive_scan_i32(const int32_t *in, int n, int32_t *out, int32_t *scratch,
 {
     if (n <= 0) {
         if (total_dev) EP_HIP_CHECK(hipMemsetAsync(total_dev, 0, sizeof(int32_t), st));
+        return EPRECON_OK;
+    }
+    static const bool small_on = !(getenv("EPRECON_SCAN_SMALL") && getenv("EPRECON_SCAN_SMALL")[0] == '0');
+    if (small_on && n <= kSmallScanMax) {
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in, n, out, total_dev);
+        EP_LAUNCH_CHECK();
         return EPRECON_OK;
     }
     const int nblk = (int)ceil_div(n, kScanTile);

@@ -543,9 +543,11 @@ class _PointMLP(nn.Sequential):
         super().__init__(nn.Linear(inc, outc), TrainBatchNorm1d(outc), nn.ReLU(True))
 
     def run(self, feats):
+        # the Linear's bias cancels in the train-mode BatchNorm that follows (it shifts the batch mean by the same
+        # amount), so the bias-free convolution with the statistics epilogue gives the same result in one pass less
         lin = self[0]
-        y = SP.sparse_conv(feats, _linear_wt(lin), None, lin.bias)
-        return self[1].run(y, relu=True, out=y)
+        y, partial = SP.conv_stats(feats, _linear_wt(lin), None)
+        return self[1].run_partials(y, partial, relu=True, out=y)
 
 
 class SPVCNN(nn.Module):
@@ -584,8 +586,8 @@ class SPVCNN(nn.Module):
         cat0 = torch.empty((s1.n, cs[4] + cs[0]), dtype=torch.float32, device=dev)
         cat1 = torch.empty((s2.n, cs[3] + cs[1]), dtype=torch.float32, device=dev)
 
-        f0 = self.stem[0].run(x0.F, s1.kernel_map(3), out=cat0[:, cs[4]:])
-        self.stem[1].run(f0, relu=True, out=f0)
+        f0, p0 = self.stem[0].run_stats(x0.F, s1.kernel_map(3), out=cat0[:, cs[4]:])
+        self.stem[1].run_partials(f0, p0, relu=True, out=f0)
         x0 = SparseTensor(f0, s1)
         z0 = voxel_to_point(x0, z)
 
