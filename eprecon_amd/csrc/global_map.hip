@@ -338,7 +338,7 @@ int eprecon_map_crop_union(void *handle, const int32_t *cur_coords, const float 
 {
     EpMap *m = as_map(handle);
     if (!m || n_cur < 0 || dim <= 0 || dim > 512 || interval <= 0 || !relative_origin_host || !updated || !src_cur ||
-        !src_glob || !counts_host || (n_cur > 0 && (!cur_coords || !cur_feat)) || ld_cur < m->channels)
+        !src_glob || !counts_host || (n_cur > 0 && (!cur_coords || !cur_feat || ld_cur < m->channels)))
         return EPRECON_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int cells = dim * dim * dim;
@@ -398,7 +398,7 @@ int eprecon_map_update_async(void *handle, const int32_t *updated, int64_t n, co
                              void *stream)
 {
     EpMap *m = as_map(handle);
-    if (!m || n < 0 || (n > 0 && (!updated || !values)) || ld_values < m->channels) return EPRECON_ERR_ARG;
+    if (!m || n < 0 || (n > 0 && (!updated || !values || ld_values < m->channels))) return EPRECON_ERR_ARG;
     if (m->kept < 0) return EPRECON_ERR_ARG;  // no crop_union since the last update / import
     hipStream_t st = (hipStream_t)stream;
     const int64_t new_size = m->kept + n;
