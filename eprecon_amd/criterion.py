@@ -1,0 +1,173 @@
+"""Training losses of the panoptic head and of the TSDF / occupancy heads — mirror of models/criterion.py
+(SetCriterion :85-296, dice_loss :20-39, sigmoid_ce_loss :41-65), models/matcher.py (HungarianMatcher :51-147) and the
+static loss helpers of NeuConNet (models/neucon_network.py:627-700, utils.py apply_log_transform).  SURVEY.md 8f row 4.
+
+Dense PyTorch (autograd does the backward); the Hungarian assignment runs on the host with scipy like the reference's.
+Pinned against the reference's own modules on seeded inputs (tests/golden/criterion.npz).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from scipy.optimize import linear_sum_assignment
+
+# ScanNet ids of the 20 evaluated classes; position + 1 is the class index the network predicts (0 = no object)
+VALID_CLASS_IDS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 24, 28, 33, 34, 36, 39)
+MIN_MASK_VOXELS = 100          # masks with <= 100 voxels are dropped as noise (models/criterion.py:239-246)
+MAX_MASK_POS_WEIGHT = 30.0
+
+
+def apply_log_transform(tsdf):
+    """sign(t) * log(|t| + 1)  (utils.py apply_log_transform)"""
+    return torch.sign(tsdf) * torch.log(torch.abs(tsdf) + 1)
+
+
+def compute_pos_weight(targets):
+    """#negatives / #positives of a {0,1} target"""
+    flat = targets.reshape(-1)
+    n_pos = flat.sum()
+    return (flat.shape[0] - n_pos).float() / n_pos
+
+
+def compute_loss(tsdf, occ, tsdf_target, occ_target, loss_weight=(1, 1), mask=None, pos_weight=1.0):
+    """NeuConNet.compute_loss (models/neucon_network.py:667-700): occupancy BCE with the class-balance weight
+    (#neg / #pos * pos_weight) + L1 of the log-transformed TSDF on the occupied targets"""
+    tsdf, occ, tsdf_target, occ_target = tsdf.reshape(-1), occ.reshape(-1), tsdf_target.reshape(-1), occ_target.reshape(-1)
+    if mask is not None:
+        m = mask.reshape(-1)
+        tsdf, occ, tsdf_target, occ_target = tsdf[m], occ[m], tsdf_target[m], occ_target[m]
+    n_pos = occ_target.sum()
+    if n_pos == 0:
+        return tsdf.sum() * 0.0
+    w = (occ_target.shape[0] - n_pos).float() / n_pos * pos_weight
+    occ_loss = F.binary_cross_entropy_with_logits(occ, occ_target.float(), pos_weight=w)
+    tsdf_loss = (apply_log_transform(tsdf[occ_target]) - apply_log_transform(tsdf_target[occ_target])).abs().mean()
+    return loss_weight[0] * occ_loss + loss_weight[1] * tsdf_loss
+
+
+def compute_loss_init(occ_init, tsdf_init_target, occ_init_target):
+    """NeuConNet.compute_loss_init (models/neucon_network.py:627-664): BCE of the initial occupancy logits against
+    (tsdf_target > 0) on the voxels whose target is observed"""
+    occ_init, t, o = occ_init.reshape(-1), tsdf_init_target.reshape(-1), occ_init_target.reshape(-1)
+    valid = (t == 0) | (o == 1)
+    occ_init, t = occ_init[valid], t[valid]
+    if t.sum() == 0:
+        return occ_init.sum() * 0.0
+    target = (t > 0).float()
+    return F.binary_cross_entropy_with_logits(occ_init, target, pos_weight=compute_pos_weight(target))
+
+
+def dice_loss(inputs, targets, num_masks):
+    p = inputs.sigmoid().flatten(1)
+    num = 2 * (p * targets).sum(-1)
+    den = p.sum(-1) + targets.sum(-1)
+    return (1 - (num + 1) / (den + 1)).sum() / num_masks
+
+
+def sigmoid_ce_loss(inputs, targets, num_masks):
+    """per matched mask: class-balanced BCE (pos_weight = #neg / #pos clamped to 30) averaged over its voxels; mean over masks"""
+    per_mask = []
+    for b in range(targets.shape[0]):
+        w = torch.clamp(compute_pos_weight(targets[b]), max=MAX_MASK_POS_WEIGHT)
+        per_mask.append(F.binary_cross_entropy_with_logits(inputs[b], targets[b], pos_weight=w))
+    return sum(per_mask) / len(per_mask)
+
+
+class HungarianMatcher(nn.Module):
+    """1-to-1 assignment of predicted queries to ground-truth masks minimising
+    cost_mask * BCE + cost_class * (-p[class]) + cost_dice * dice   (models/matcher.py:75-119)"""
+
+    def __init__(self, cost_class=1.0, cost_mask=1.0, cost_dice=1.0):
+        super().__init__()
+        assert cost_class != 0 or cost_mask != 0 or cost_dice != 0
+        self.cost_class, self.cost_mask, self.cost_dice = cost_class, cost_mask, cost_dice
+
+    @torch.no_grad()
+    def forward(self, outputs, targets):
+        out = []
+        for b in range(outputs["pred_logits"].shape[0]):
+            prob = outputs["pred_logits"][b].softmax(-1)
+            c_class = -prob[:, targets[b]["labels"]]
+            logits = outputs["pred_masks"][b].float()
+            gt = targets[b]["masks"].to(logits)
+            n_vox = logits.shape[1]
+            pos = F.binary_cross_entropy_with_logits(logits, torch.ones_like(logits), reduction="none")
+            neg = F.binary_cross_entropy_with_logits(logits, torch.zeros_like(logits), reduction="none")
+            c_mask = (pos @ gt.t() + neg @ (1 - gt).t()) / n_vox
+            p = logits.sigmoid()
+            c_dice = 1 - (2 * p @ gt.t() + 1) / (p.sum(-1)[:, None] + gt.sum(-1)[None, :] + 1)
+            cost = self.cost_mask * c_mask + self.cost_class * c_class + self.cost_dice * c_dice
+            i, j = linear_sum_assignment(cost.reshape(prob.shape[0], -1).cpu())
+            out.append((torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)))
+        return out
+
+
+class SetCriterion(nn.Module):
+    """models/criterion.py:85-296.  forward(outputs, targets) with outputs {'pred_logits' [B,Q,K+1], 'pred_masks' [B,Q,N],
+    'aux_outputs': [...]} and targets [{'labels' int64[T] (ScanNet ids), 'masks' bool[T,N]}] (batch 1, like the reference)
+    -> dict of losses ('loss_ce', 'loss_mask', 'loss_dice' and '<name>_<i>' for the auxiliary heads)."""
+
+    def __init__(self, num_classes, matcher, weight_dict, eos_coef, losses):
+        super().__init__()
+        self.num_classes, self.matcher, self.weight_dict, self.eos_coef, self.losses = num_classes, matcher, weight_dict, eos_coef, losses
+        w = torch.ones(num_classes + 1)
+        w[0] = eos_coef
+        self.register_buffer("empty_weight", w)
+        self.register_buffer("valid_classes", torch.tensor(VALID_CLASS_IDS, dtype=torch.int64), persistent=False)
+
+    @staticmethod
+    def _perm(indices, which):
+        batch = torch.cat([torch.full_like(pair[which], i) for i, pair in enumerate(indices)])
+        return batch, torch.cat([pair[which] for pair in indices])
+
+    def loss_labels(self, outputs, targets, indices, num_masks):
+        logits = outputs["pred_logits"].float()
+        matched = torch.cat([t["labels"][j] for t, (_, j) in zip(targets, indices)])
+        if len(matched) == 0:
+            return {"loss_ce": logits.sum() * 0.0}
+        target = torch.zeros(logits.shape[:2], dtype=torch.int64, device=logits.device)
+        target[self._perm(indices, 0)] = matched
+        return {"loss_ce": F.cross_entropy(logits.transpose(1, 2), target, self.empty_weight)}
+
+    def loss_masks(self, outputs, targets, indices, num_masks):
+        src = outputs["pred_masks"][self._perm(indices, 0)]
+        tgt = targets[0]["masks"].unsqueeze(0).to(src)[self._perm(indices, 1)]
+        if len(src) == 0 or len(tgt) == 0:
+            return {"loss_masks": src.sum() * 0.0, "loss_dice": src.sum() * 0.0}
+        return {"loss_mask": sigmoid_ce_loss(src, tgt, num_masks), "loss_dice": dice_loss(src, tgt, num_masks)}
+
+    def _filter_targets(self, outputs, targets):
+        """keep the 20 evaluated classes (re-indexed 1..20) and the voxels they cover, then drop masks of <= 100 voxels
+        and the voxels only those covered; the predictions are restricted to the surviving voxels (:206-252)"""
+        t = targets[0]
+        for min_voxels in (None, MIN_MASK_VOXELS):
+            if min_voxels is None:
+                keep = torch.isin(t["labels"], self.valid_classes.to(t["labels"].device))
+            else:
+                keep = t["masks"].sum(1) > min_voxels
+            vox = t["masks"][keep].any(0) if keep.any() else torch.zeros_like(t["masks"][0], dtype=torch.bool)
+            labels = t["labels"][keep]
+            if min_voxels is None:   # ScanNet id -> 1 + position in the list of evaluated classes
+                labels = torch.searchsorted(self.valid_classes.to(labels.device), labels) + 1
+            t["labels"], t["masks"] = labels, t["masks"][keep][:, vox]
+            if t["masks"].sum() == 0:
+                return False
+            outputs["pred_masks"] = outputs["pred_masks"][..., vox]
+            for aux in outputs.get("aux_outputs", []):
+                aux["pred_masks"] = aux["pred_masks"][..., vox]
+        return True
+
+    def forward(self, outputs, targets):
+        if not self._filter_targets(outputs, targets):
+            return {"loss_dice": outputs["pred_logits"].sum() * 0.0}
+        main = {k: v for k, v in outputs.items() if k != "aux_outputs"}
+        indices = self.matcher(main, targets)
+        num_masks = float(max(sum(len(t["labels"]) for t in targets), 1))
+        fns = {"labels": self.loss_labels, "masks": self.loss_masks}
+        losses = {}
+        for name in self.losses:
+            losses.update(fns[name](outputs, targets, indices, num_masks))
+        for i, aux in enumerate(outputs.get("aux_outputs", [])):
+            idx = self.matcher(aux, targets)
+            for name in self.losses:
+                losses.update({f"{k}_{i}": v for k, v in fns[name](aux, targets, idx, num_masks).items()})
+        return losses

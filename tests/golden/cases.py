@@ -101,3 +101,31 @@ def tsdf_case(seed=0, views=9):
     depths = np.stack([S.render_depth(window, v, holes_seed=100 + v) for v in range(views)])
     intr = np.repeat(window["intrinsics"][None], views, 0).astype(np.float32)
     return window, depths, intr, window["poses"].astype(np.float32)
+
+
+def criterion_case(seed=3, q=12, n=900, classes=20, n_aux=2):
+    """decoder outputs for q queries over n voxels (+ n_aux auxiliary heads) and ground-truth masks carrying ScanNet
+    ids: evaluated classes, an ignored id (13), a tiny (< 100 voxels) mask"""
+    rng = np.random.default_rng(seed)
+    head = lambda: {"pred_logits": rng.standard_normal((1, q, classes + 1)).astype(np.float32),
+                    "pred_masks": (rng.standard_normal((1, q, n)) * 2).astype(np.float32)}
+    outputs = head()
+    outputs["aux_outputs"] = [head() for _ in range(n_aux)]
+    labels = np.array([3, 13, 39, 5, 1, 24], np.int64)          # 13 is not an evaluated class
+    owner = rng.integers(0, len(labels) + 1, n)                   # some voxels belong to no mask
+    owner[rng.random(n) < 0.5] = 4
+    masks = np.stack([owner == k for k in range(len(labels))])
+    small = np.zeros(n, bool)
+    small[:40] = True
+    masks[3] = small & (owner == 3)                               # class 5 with < 100 voxels: dropped
+    return outputs, [{"labels": labels, "masks": masks}]
+
+
+def loss_case(seed=8, n=5000):
+    """inputs of NeuConNet.compute_loss / compute_loss_init"""
+    rng = np.random.default_rng(seed)
+    return {"tsdf": rng.standard_normal(n).astype(np.float32), "occ": rng.standard_normal(n).astype(np.float32),
+            "tsdf_target": np.clip(rng.standard_normal(n) * 0.7, -1, 1).astype(np.float32), "occ_target": rng.random(n) < 0.3,
+            "mask": rng.random(n) < 0.9, "occ_init": rng.standard_normal(n).astype(np.float32),
+            "tsdf_init_target": ((rng.random(n) < 0.4) & (rng.random(n) < 0.8)).astype(np.float32),
+            "occ_init_target": (rng.random(n) < 0.5).astype(np.float32)}

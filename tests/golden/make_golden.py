@@ -502,9 +502,38 @@ def gen_tsdf_fusion():
     _save("tsdf_fusion", **out)
 
 
+def criterion_case(seed=3, q=12, n=900, classes=20):
+    """seeded decoder outputs + ScanNet-id targets for the set criterion (shared with the tests via cases.py)"""
+    import cases
+    return cases.criterion_case(seed, q, n, classes)
+
+
+def gen_criterion():
+    """(f4) SetCriterion + HungarianMatcher (models/criterion.py:85-296, models/matcher.py:51-147) and NeuConNet's
+    static loss helpers (models/neucon_network.py:627-700) on seeded inputs"""
+    import copy
+    import cases
+    sys.modules["loguru"].logger = type("L", (), {"warning": staticmethod(lambda *a, **k: None)})()
+    from models.criterion import SetCriterion
+    from models.matcher import HungarianMatcher
+    from models.neucon_network import NeuConNet
+
+    outputs, targets = cases.criterion_case()
+    to_t = lambda d: {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else [to_t(a) for a in v]) for k, v in d.items()}
+    out_t, tgt_t = to_t(outputs), [to_t(t) for t in targets]
+    matcher = HungarianMatcher(cost_class=2.0, cost_mask=5.0, cost_dice=5.0)
+    crit = SetCriterion(20, matcher, {}, 0.1, ["labels", "masks"])
+    losses = crit(copy.deepcopy(out_t), copy.deepcopy(tgt_t))
+    out = {"loss_names": np.array(sorted(losses)), "loss_values": np.array([float(losses[k]) for k in sorted(losses)], np.float64)}
+    c = {k: torch.from_numpy(v) for k, v in cases.loss_case().items()}
+    out["compute_loss"] = np.float64(NeuConNet.compute_loss(c["tsdf"], c["occ"], c["tsdf_target"], c["occ_target"], mask=c["mask"], pos_weight=1.5))
+    out["compute_loss_init"] = np.float64(NeuConNet.compute_loss_init(None, c["occ_init"], c["tsdf_init_target"], c["occ_init_target"]))
+    _save("criterion", **out)
+
+
 GENERATORS = {"back_project": gen_back_project, "grid_ops": gen_grid_ops, "dense_blocks": gen_dense_blocks,
               "gru_fusion": gen_gru_fusion, "mask3dformer": gen_mask3dformer, "scene_fusion": gen_scene_fusion,
-              "occ_init": gen_occ_init, "aligned_coords": gen_aligned_coords, "tsdf_fusion": gen_tsdf_fusion}
+              "occ_init": gen_occ_init, "aligned_coords": gen_aligned_coords, "tsdf_fusion": gen_tsdf_fusion, "criterion": gen_criterion}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GENERATORS)
