@@ -66,6 +66,12 @@ SIGNATURES = {
     "eprecon_remap_index_async": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _vp]),
     "eprecon_trilinear_map_async": (_i, [_vp, _c.c_uint32, _vp, _i64, _i, _vp, _vp, _vp]),
     "eprecon_devoxelize_async": (_i, [_vp, _i, _vp, _vp, _i64, _i, _vp, _i, _i, _vp]),
+    "eprecon_sparse_conv_wgrad_workspace_bytes": (_sz, [_i, _i64, _i, _i]),
+    "eprecon_sparse_conv_wgrad_async": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _i, _vp, _vp, _sz, _vp]),
+    "eprecon_invert_map_async": (_i, [_vp, _i, _i64, _i64, _vp, _vp]),
+    "eprecon_devoxelize_backward_async": (_i, [_vp, _i, _vp, _vp, _i64, _i, _i64, _vp, _i, _vp]),
+    "eprecon_gather_rows_scaled_async": (_i, [_vp, _i, _vp, _vp, _i64, _i, _vp, _i, _vp]),
+    "eprecon_back_project_backward_async": (_i, [_vp, _i64, _vp, _i, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "eprecon_devoxelize_gate_async": (_i, [_vp, _i, _vp, _vp, _i64, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "eprecon_fbv_union_workspace_bytes": (_sz, [_i]),
     "eprecon_fbv_union_async": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,

@@ -725,6 +725,80 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restri
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Backward of the back-projection with respect to the image features (training): the
+// transpose of the bilinear gather is a scatter of four weighted taps per (voxel, visible view, channel).
+//   MEAN / MEAN_DEPTH   d f_v = d out / cnt                          (the mean-depth channel has no feature gradient)
+//   VARIANCE            d f_v = 2 (f_v - mean) / cnt * d var + d mean / cnt
+// One thread per (valid voxel, channel): consecutive lanes hit consecutive addresses of one pixel, so the
+// hardware float atomics of a wave coalesce.  Same projection and tap arithmetic as bp_gather_kernel.
+// ---------------------------------------------------------------------------------------------
+struct BpBwdParams {
+    const int32_t *coords; int64_t n;      // the VALID voxels (out_coords of the forward)
+    const float *origin; int batch; float voxel_size;
+    const float *feats_nhwc; const float *krcam;
+    int V, C, H, W, mode;
+    const float *dout; int ld_dout;
+    const float *dmean;                    // VARIANCE only, may be null
+    float *dfeats;                         // [V*B][H*W][C], zeroed by the caller
+};
+
+__global__ __launch_bounds__(256) void bp_backward_kernel(BpBwdParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *sP = reinterpret_cast<float *>(smem);
+    stage_matrices(sP, p.krcam, p.V * p.batch, threadIdx.x, 256);
+    __syncthreads();
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= p.n * p.C) return;
+    const int64_t i = e / p.C;
+    const int ch = (int)(e - i * p.C);
+    const int4 c = reinterpret_cast<const int4 *>(p.coords)[i];
+    if (c.x < 0 || c.x >= p.batch) return;
+    float X, Y, Z;
+    voxel_centre(c, p.origin, p.voxel_size, X, Y, Z);
+    const float wm1 = (float)(p.W - 1), hm1 = (float)(p.H - 1);
+    const size_t map_elems = (size_t)p.H * p.W * p.C;
+    int cnt = 0;
+    for (int v = 0; v < p.V; ++v) cnt += project(sP + (v * p.batch + c.x) * 12, X, Y, Z, wm1, hm1).vis ? 1 : 0;
+    if (cnt == 0) return;
+    const float inv = 1.0f / (float)cnt;
+    const float g = p.dout[i * p.ld_dout + ch];
+    float mean = 0.0f;
+    if (p.mode == EPRECON_BP_VARIANCE) {
+        for (int v = 0; v < p.V; ++v) {
+            const Proj pr = project(sP + (v * p.batch + c.x) * 12, X, Y, Z, wm1, hm1);
+            if (!pr.vis) continue;
+            const float ix = __fmul_rn(__fdiv_rn(__fadd_rn(pr.gx, 1.0f), 2.0f), wm1);
+            const float iy = __fmul_rn(__fdiv_rn(__fadd_rn(pr.gy, 1.0f), 2.0f), hm1);
+            mean += Chan<1>::sample(p.feats_nhwc + ((size_t)v * p.batch + c.x) * map_elems + ch, make_taps(ix, iy, p.W, p.H, p.C)).v;
+        }
+        mean *= inv;
+    }
+    const float gm = (p.mode == EPRECON_BP_VARIANCE && p.dmean) ? p.dmean[i * p.C + ch] * inv : 0.0f;
+    for (int v = 0; v < p.V; ++v) {
+        const Proj pr = project(sP + (v * p.batch + c.x) * 12, X, Y, Z, wm1, hm1);
+        if (!pr.vis) continue;
+        const float ix = __fmul_rn(__fdiv_rn(__fadd_rn(pr.gx, 1.0f), 2.0f), wm1);
+        const float iy = __fmul_rn(__fdiv_rn(__fadd_rn(pr.gy, 1.0f), 2.0f), hm1);
+        const Taps t = make_taps(ix, iy, p.W, p.H, p.C);
+        const size_t mo = ((size_t)v * p.batch + c.x) * map_elems + ch;
+        float gv;
+        if (p.mode == EPRECON_BP_VARIANCE) {
+            const float f = Chan<1>::sample(p.feats_nhwc + mo, t).v;
+            gv = 2.0f * (f - mean) * inv * g + gm;
+        } else {
+            gv = g * inv;
+        }
+        float *d = p.dfeats + mo;
+        if (t.w00 != 0.0f) unsafeAtomicAdd(d + t.o00, t.w00 * gv);
+        if (t.w10 != 0.0f) unsafeAtomicAdd(d + t.o10, t.w10 * gv);
+        if (t.w01 != 0.0f) unsafeAtomicAdd(d + t.o01, t.w01 * gv);
+        if (t.w11 != 0.0f) unsafeAtomicAdd(d + t.o11, t.w11 * gv);
+    }
+}
+
 struct ProfileState {
     bool on = false, recorded = false, one_shot = false;
     hipEvent_t start = nullptr, stop = nullptr;
@@ -1000,6 +1074,27 @@ int eprecon_back_project(const int32_t *coords, int64_t n, const float *origin, 
     EP_HIP_CHECK(hipStreamSynchronize(st));
     for (int b = 0; b < batch; ++b)
         if (n_valid_host[1 + b] < min_valid_per_batch) return EPRECON_EMPTY;
+    return EPRECON_OK;
+}
+
+int eprecon_back_project_backward_async(const int32_t *coords_valid, int64_t n_valid, const float *origin, int batch,
+                                        float voxel_size, const float *feats_nhwc, const float *krcam, int n_views,
+                                        int channels, int height, int width, int mode, const float *dout, int ld_dout,
+                                        const float *dmean, float *dfeats_nhwc, void *stream)
+{
+    if (n_valid < 0 || batch < 1 || n_views < 1 || channels < 1 || !dfeats_nhwc || !krcam || !origin) return EPRECON_ERR_ARG;
+    if (mode == EPRECON_BP_VARIANCE && !feats_nhwc) return EPRECON_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    EP_HIP_CHECK(hipMemsetAsync(dfeats_nhwc, 0, (size_t)n_views * batch * height * width * channels * sizeof(float), st));
+    if (n_valid == 0) return EPRECON_OK;
+    if (!coords_valid || !dout) return EPRECON_ERR_ARG;
+    BpBwdParams p;
+    p.coords = coords_valid; p.n = n_valid; p.origin = origin; p.batch = batch; p.voxel_size = voxel_size;
+    p.feats_nhwc = feats_nhwc; p.krcam = krcam; p.V = n_views; p.C = channels; p.H = height; p.W = width; p.mode = mode;
+    p.dout = dout; p.ld_dout = ld_dout; p.dmean = dmean; p.dfeats = dfeats_nhwc;
+    const size_t lds = (((size_t)n_views * batch * 12 + 3) & ~(size_t)3) * sizeof(float);
+    hipLaunchKernelGGL(bp_backward_kernel, dim3((unsigned)ceil_div(n_valid * channels, 256)), dim3(256), lds, st, p);
+    EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }
 

@@ -20,8 +20,16 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import autograd as AG
 from . import dense2d as D2
 from . import sparse as SP
+
+
+def recording():
+    """True on the training path: the recording operators of eprecon_amd/autograd.py run instead of the fused
+    inference launches (which write in place and keep no graph).  The reference's inference loop runs under
+    torch.no_grad() (main.py:351-365), and so does every inference entry point of this package."""
+    return torch.is_grad_enabled()
 
 # ------------------------------------------------------------------------------------------------
 # coordinate-set cache: the reference hands raw `coords` tensors to every layer; spconv rebuilds
@@ -103,11 +111,22 @@ class SparseSubMConv3d(nn.Module):
 
     def run(self, features, vset, out=None, relu=False):
         nbr = vset.kernel_map(3) if self.kernel == 3 else None
+        if recording():
+            y = AG.sparse_conv(features, self.weight, nbr, self.bias)
+            y = F.relu(y) if relu else y
+            return y if out is None else out.copy_(y)
         return SP.sparse_conv(features, self.weight, nbr, self.bias, out=out, relu=relu)
 
     def run_ln(self, features, vset, ln, out=None, relu=False, residual=None, post_relu=False):
         """conv [+ReLU] [+residual] -> LayerNorm `ln` [-> ReLU], one launch"""
         nbr = vset.kernel_map(3) if self.kernel == 3 else None
+        if recording():
+            y = AG.sparse_conv(features, self.weight, nbr, self.bias)
+            y = F.relu(y) if relu else y
+            y = y + residual if residual is not None else y
+            y = F.layer_norm(y, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
+            y = F.relu(y) if post_relu else y
+            return y if out is None else out.copy_(y)
         return SP.sparse_conv_ln(features, self.weight, nbr, self.bias, ln.weight, ln.bias, ln.eps, out=out,
                                  relu=relu, residual=residual, post_relu=post_relu)
 
@@ -120,6 +139,12 @@ class _RowLayerNorm(nn.LayerNorm):
     """nn.LayerNorm parameters, evaluated by the fused row-wise HIP epilogue"""
 
     def run(self, x, residual=None, pre_relu=False, post_relu=False, out=None):
+        if recording():
+            y = F.relu(x) if pre_relu else x
+            y = y + residual if residual is not None else y
+            y = F.layer_norm(y, self.normalized_shape, self.weight, self.bias, self.eps)
+            y = F.relu(y) if post_relu else y
+            return y if out is None else out.copy_(y)
         return SP.rowwise_layernorm(x, self.weight, self.bias, self.eps, residual, pre_relu, post_relu, out)
 
 
@@ -154,6 +179,13 @@ class Spares3dELAN(nn.Module):
     def run(self, x, vset):
         d, h = self.dim, self.dim // 2
         n = x.shape[0]
+        if recording():
+            x1, x2 = self.conv1.run(x, vset), self.conv2.run(x, vset)
+            x3 = self.conv3.run(x2, vset)
+            x4 = self.conv4.run(x3, vset)
+            x5 = self.conv5.run(x4, vset)
+            x6 = self.conv6.run(x5, vset)
+            return self.conv7.run(torch.cat([x1, x2, x3, x4, x5, x6], dim=1), vset)
         # the concat buffer is written in place by each branch (no torch.cat copies)
         cat = torch.empty((n, 4 * d), dtype=torch.float32, device=x.device)
         self.conv1.run(x, vset, out=cat[:, 0:d])
@@ -189,6 +221,12 @@ class TrainBatchNorm1d(nn.BatchNorm1d):
     statistics are therefore never read and are not tracked here."""
 
     def run(self, x, residual=None, relu=False, out=None):
+        if recording():
+            # like the reference in train mode the running statistics are updated (and never read)
+            y = F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True, self.momentum, self.eps)
+            y = y + residual if residual is not None else y
+            y = F.relu(y) if relu else y
+            return y if out is None else out.copy_(y)
         return SP.batchnorm_train(x, self.weight, self.bias, self.eps, residual, relu, out)
 
     def run_partials(self, x, partial, residual=None, relu=False, out=None):
@@ -462,6 +500,9 @@ class Conv3d(nn.Module):
             self.kernel.uniform_(-std, std)
 
     def run(self, feats, nbr, out=None):
+        if recording():
+            y = AG.sparse_conv(feats, self.kernel, nbr)
+            return y if out is None else out.copy_(y)
         return SP.sparse_conv(feats, self.kernel, nbr, None, out=out)
 
     def run_stats(self, feats, nbr, out=None, in_affine=None):
@@ -477,6 +518,8 @@ class BasicConvolutionBlock(nn.Module):
         self.net = nn.Sequential(Conv3d(inc, outc, ks, stride, dilation), TrainBatchNorm1d(outc), nn.ReLU(True))
 
     def run(self, feats, nbr, out=None):
+        if recording():
+            return self.net[1].run(self.net[0].run(feats, nbr), relu=True)
         if not _FUSED_BN_STATS:
             y = self.net[0].run(feats, nbr, out=out)
             return self.net[1].run(y, relu=True, out=y)
@@ -493,6 +536,8 @@ class BasicDeconvolutionBlock(nn.Module):
                                  nn.ReLU(True))
 
     def run(self, feats, nbr, out=None):
+        if recording():
+            return self.net[1].run(self.net[0].run(feats, nbr), relu=True)
         if not _FUSED_BN_STATS:
             y = self.net[0].run(feats, nbr, out=out)
             return self.net[1].run(y, relu=True, out=y)
@@ -513,6 +558,11 @@ class ResidualBlock(nn.Module):
         self.relu = nn.ReLU(True)
 
     def run(self, feats, nbr, out=None):
+        if recording():
+            y = self.net[1].run(self.net[0].run(feats, nbr), relu=True)
+            y = self.net[3].run(y, nbr)
+            skip = feats if len(self.downsample) == 0 else self.downsample[1].run(self.downsample[0].run(feats, None))
+            return self.net[4].run(y, residual=skip, relu=True)
         if not _FUSED_BN_STATS:
             y = self.net[0].run(feats, nbr)
             self.net[1].run(y, relu=True, out=y)
@@ -546,6 +596,8 @@ class _PointMLP(nn.Sequential):
         # the Linear's bias cancels in the train-mode BatchNorm that follows (it shifts the batch mean by the same
         # amount), so the bias-free convolution with the statistics epilogue gives the same result in one pass less
         lin = self[0]
+        if recording():
+            return self[1].run(F.linear(feats, lin.weight, lin.bias), relu=True)
         y, partial = SP.conv_stats(feats, _linear_wt(lin), None)
         return self[1].run_partials(y, partial, relu=True, out=y)
 
@@ -575,7 +627,33 @@ class SPVCNN(nn.Module):
         self.point_transforms = nn.ModuleList([_PointMLP(cs[0], cs[2]), _PointMLP(cs[2], cs[4])])
         assert not self.dropout, "SPARSEREG.DROPOUT is False in the reference configs (config/default.py:69)"
 
+    def _forward_recording(self, z):
+        """the same network through the recording operators (training): concatenations are torch.cat, every
+        sparse op is an autograd Function over the HIP kernels"""
+        x0 = initial_voxelize(z, self.pres, self.vres)
+        s1 = x0.vset
+        s2, down12, up21 = s1.downsample()
+        s4, down24, up42 = s2.downsample()
+        k1, k2, k4 = s1.kernel_map(3), s2.kernel_map(3), s4.kernel_map(3)
+        f0 = self.stem[1].run(self.stem[0].run(x0.F, k1), relu=True)
+        x0 = SparseTensor(f0, s1)
+        z0 = voxel_to_point(x0, z)
+        x1 = point_to_voxel(x0, z0)
+        f1 = self.stage1[2].run(self.stage1[1].run(self.stage1[0].run(x1.F, down12), k2), k2)
+        f2 = self.stage2[2].run(self.stage2[1].run(self.stage2[0].run(f1, down24), k4), k4)
+        x2 = SparseTensor(f2, s4)
+        z1 = voxel_to_point(x2, z0, out=self.point_transforms[0].run(z0.F), accumulate=True)
+        y3 = point_to_voxel(x2, z1)
+        f = torch.cat([self.up1[0].run(y3.F, up42), f1], dim=1)
+        f = self.up1[1][1].run(self.up1[1][0].run(f, k2), k2)
+        f = torch.cat([self.up2[0].run(f, up21), f0], dim=1)
+        f = self.up2[1][1].run(self.up2[1][0].run(f, k1), k1)
+        z3 = voxel_to_point(SparseTensor(f, s1), z1, out=self.point_transforms[1].run(z1.F), accumulate=True)
+        return z3.F
+
     def forward(self, z):
+        if recording():
+            return self._forward_recording(z)
         cs = self.cs
         dev = z.F.device
         x0 = initial_voxelize(z, self.pres, self.vres)
@@ -627,7 +705,10 @@ class SConv3d(nn.Module):
         x = initial_voxelize(z, self.pres, self.vres)
         y = SparseTensor(self.net.run(x.F, x.vset.kernel_map(3)), x.vset)
         lin = self.point_transforms[0]
-        skip = SP.sparse_conv(z.F, _linear_wt(lin), None, lin.bias)
+        if recording():
+            skip = F.linear(z.F, lin.weight, lin.bias)
+        else:
+            skip = SP.sparse_conv(z.F, _linear_wt(lin), None, lin.bias)
         return voxel_to_point(y, z, out=skip, accumulate=True)
 
     def run_gate(self, z, mode, h=None, zgate=None, out=None):

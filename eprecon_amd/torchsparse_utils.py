@@ -5,6 +5,7 @@ import os
 import torch
 
 from . import _lib
+from . import autograd as AG
 from . import sparse as SP
 from .tensor import PointTensor, SparseTensor
 
@@ -39,7 +40,12 @@ def _segment_lists(idx, m):
     return offsets, order
 
 
-def _segment_mean(feat, lists, m, out=None):
+def _segment_mean(feat, lists, m, out=None, idx=None):
+    if torch.is_grad_enabled() and feat.requires_grad:
+        # training: the recording form (eprecon_amd/autograd.py); `out` is a fusion of the inference path only
+        assert idx is not None
+        res = AG.segment_mean(feat, idx, lists, m)
+        return res if out is None else out.copy_(res)
     lib = _lib.load()
     offsets, order = lists
     c = feat.shape[1]
@@ -180,7 +186,7 @@ def initial_voxelize(z, init_res, after_res):
     res = float(after_res) / float(init_res) if init_res != 1 else float(after_res)
     prev = getattr(z, "_vox_entry", None)
     e = _voxelize_points(pts, res)
-    feat = _segment_mean(z.F, e.lists, e.vset.n)
+    feat = _segment_mean(z.F, e.lists, e.vset.n, idx=e.inverse)
     z.C, z.vox = e.scaled, e.vox
     if prev is not None and LITERAL_CONVR and 1 in z.idx_query:
         z.idx_query[1], z.weights[1] = e.stale_from(prev)
@@ -206,7 +212,7 @@ def point_to_voxel(x, z, out=None):
         lists = _segment_lists(idx, x.vset.n)
         z.additional_features["idx_query"][s] = idx
         z.additional_features["lists"][s] = lists
-    return SparseTensor(_segment_mean(z.F, lists, x.vset.n, out), x.vset)
+    return SparseTensor(_segment_mean(z.F, lists, x.vset.n, out, idx=z.additional_features["idx_query"][s]), x.vset)
 
 
 def _corner_tables(vset, s, z):
@@ -237,11 +243,15 @@ def voxel_to_point(x, z, nearest=False, out=None, accumulate=False):
     n = z.C.shape[0]
     _corner_tables(x.vset, s, z)
     c = x.F.shape[1]
-    if out is None:
-        out = torch.empty((n, c), dtype=torch.float32, device=x.F.device)
-    _lib.check(lib.eprecon_devoxelize_async(_lib.ptr(x.F), x.F.stride(0), _lib.ptr(z.idx_query[s]),
-                                            _lib.ptr(z.weights[s]), n, c, _lib.ptr(out), out.stride(0),
-                                            int(accumulate), _lib.current_stream()), "eprecon_devoxelize_async")
+    if torch.is_grad_enabled() and (x.F.requires_grad or (out is not None and out.requires_grad)):
+        res = AG.devoxelize(x.F, z.idx_query[s], z.weights[s])
+        out = res if out is None else (out + res if accumulate else out.copy_(res))
+    else:
+        if out is None:
+            out = torch.empty((n, c), dtype=torch.float32, device=x.F.device)
+        _lib.check(lib.eprecon_devoxelize_async(_lib.ptr(x.F), x.F.stride(0), _lib.ptr(z.idx_query[s]),
+                                                _lib.ptr(z.weights[s]), n, c, _lib.ptr(out), out.stride(0),
+                                                int(accumulate), _lib.current_stream()), "eprecon_devoxelize_async")
     new = PointTensor(out, z.C, idx_query=z.idx_query, weights=z.weights)
     new.vox = z.vox
     new.additional_features = z.additional_features

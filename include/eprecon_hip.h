@@ -519,6 +519,39 @@ int eprecon_nearest_voxel_async(const void *table, uint32_t capacity, const int3
 int eprecon_upsample2x_nhwc_async(const float *in, float *out, int n, int h, int w, int channels,
                                   void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Backward of the sparse operators  (training, main.py:181-313 loss.backward())
+ *
+ * Replaces  the autograd of spnn.Conv3d / spconv SubMConv3d, torchsparse.nn.functional.spdevoxelize and
+ *           spvoxelize (ops/torchsparse_utils.py:35,63,100), which the reference gets from the two libraries.
+ *
+ * For y[i] = bias + sum_k x[nbr[k][i]] @ W[k]:
+ *   dW[k]  = sum_i x[nbr[k][i]]^T dy[i]                eprecon_sparse_conv_wgrad_async (fp32 MFMA, deterministic:
+ *                                                       row chunks reduced in chunk order through `workspace`)
+ *   dx[j]  = sum_k dy[inv[k][j]] @ W[k]^T              eprecon_sparse_conv_async on the inverted map
+ *   inv[k][j] = i  <=>  nbr[k][i] = j                  eprecon_invert_map_async (a kernel map is injective per offset)
+ *   dbias  = column sums of dy                          (host: one reduction)
+ * devoxelize:  d voxel_feat[idx8[p][c]] += weight8[p][c] * d out[p]   (hardware float atomics; dvoxel_feat is zeroed)
+ * segment mean (voxelize): d point_feat[p] = d mean[idx[p]] * scale[idx[p]], scale = 1 / count
+ * ------------------------------------------------------------------------------------------ */
+size_t eprecon_sparse_conv_wgrad_workspace_bytes(int kvol, int64_t n_out, int cin, int cout);
+int eprecon_sparse_conv_wgrad_async(const float *x, int ld_x, const float *dy, int ld_dy, const int32_t *nbr, int kvol,
+                                    int64_t n_out, int cin, int cout, float *dweight, void *workspace,
+                                    size_t workspace_bytes, void *stream);
+int eprecon_invert_map_async(const int32_t *nbr, int kvol, int64_t n_out, int64_t n_in, int32_t *inv, void *stream);
+int eprecon_devoxelize_backward_async(const float *dout, int ld_out, const int32_t *idx8, const float *weight8, int64_t n,
+                                      int channels, int64_t n_voxels, float *dvoxel_feat, int ld_feat, void *stream);
+int eprecon_gather_rows_scaled_async(const float *src, int ld_src, const int32_t *idx, const float *scale, int64_t n,
+                                     int channels, float *dst, int ld_dst, void *stream);
+/* back-projection: d feats[view][b][y][x][c] (channels-last, zeroed here) from d out f32[n_valid, ld_dout] (and, mode
+ * VARIANCE, the optional d mean f32[n_valid, C]) at the VALID voxels `coords_valid` the forward returned
+ * (ops/back_project.py:47-61 / models/occupancy_initialization.py:113-128 under autograd: grid_sample's backward,
+ * the masked mean / variance).  Hardware float atomics. */
+int eprecon_back_project_backward_async(const int32_t *coords_valid, int64_t n_valid, const float *origin, int batch,
+                                        float voxel_size, const float *feats_nhwc, const float *krcam, int n_views,
+                                        int channels, int height, int width, int mode, const float *dout, int ld_dout,
+                                        const float *dmean, float *dfeats_nhwc, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

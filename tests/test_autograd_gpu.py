@@ -1,0 +1,270 @@
+"""f4: gradients of the HIP operators (eprecon_amd/autograd.py) against plain PyTorch references of the same ops.
+fp32 both sides; the accumulation orders differ, tolerance 2e-4 relative to the gradient's scale."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import torch.nn.functional as F  # noqa: E402
+from test_oracle_sparse import random_coords  # noqa: E402
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def close(a, b, tol=2e-4):
+    scale = max(float(b.abs().max()), 1e-6)
+    err = float((a - b).abs().max()) / scale
+    assert err < tol, err
+
+
+def ref_conv(x, w, nbr, bias):
+    w3 = w if w.dim() == 3 else w.unsqueeze(0)
+    if nbr is None:
+        y = x @ w3[0]
+    else:
+        pad = torch.cat([x, x.new_zeros(1, x.shape[1])])
+        idx = torch.where(nbr >= 0, nbr, torch.full_like(nbr, x.shape[0])).long()
+        y = torch.einsum("kni,kio->no", pad[idx], w3)
+    return y if bias is None else y + bias
+
+
+def conv_case(n, cin, cout, kind, seed):
+    from eprecon_amd.sparse import VoxelSet
+    rng = np.random.default_rng(seed)
+    c = random_coords(rng, n, extent=18, batch=2)
+    vs = VoxelSet(dev(c), 1)
+    if kind == "k3":
+        nbr, n_in, n_out, kvol = vs.kernel_map(3), vs.n, vs.n, 27
+    elif kind == "down":
+        coarse, down, up = vs.downsample()
+        nbr, n_in, n_out, kvol = down, vs.n, coarse.n, 8
+    elif kind == "up":
+        coarse, down, up = vs.downsample()
+        nbr, n_in, n_out, kvol = up, coarse.n, vs.n, 8
+    else:
+        nbr, n_in, n_out, kvol = None, vs.n, vs.n, 1
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.randn(n_in, cin, device="cuda", generator=g)
+    w = torch.randn((kvol, cin, cout) if kvol > 1 else (cin, cout), device="cuda", generator=g) / np.sqrt(cin * kvol)
+    b = torch.randn(cout, device="cuda", generator=g)
+    dy = torch.randn(n_out, cout, device="cuda", generator=g)
+    return x, w, b, nbr, dy
+
+
+@pytest.mark.parametrize("n,cin,cout,kind", [(3000, 32, 32, "k3"), (5000, 81, 32, "k3"), (2500, 139, 64, "k3"), (4000, 128, 128, "k3"),
+                                             (1500, 320, 128, "k3"), (6000, 32, 32, "down"), (6000, 64, 64, "down"),
+                                             (6000, 128, 96, "up"), (6000, 96, 96, "up"), (7000, 32, 128, "lin"), (333, 176, 1, "lin"),
+                                             (1, 8, 8, "k3")])
+def test_sparse_conv_gradients(n, cin, cout, kind):
+    from eprecon_amd import autograd as AG
+    x, w, b, nbr, dy = conv_case(n, cin, cout, kind, seed=n + cin)
+    got, ref = [], []
+    for fn, sink in ((AG.sparse_conv, got), (lambda x_, w_, nbr_, b_: ref_conv(x_, w_, nbr_, b_), ref)):
+        xs, ws, bs = (t.clone().requires_grad_() for t in (x, w, b))
+        y = fn(xs, ws, nbr, bs)
+        y.backward(dy)
+        sink.extend([y.detach(), xs.grad, ws.grad, bs.grad])
+    for a, r in zip(got, ref):
+        close(a, r)
+
+
+def test_weight_gradient_is_deterministic():
+    from eprecon_amd import autograd as AG
+    x, w, b, nbr, dy = conv_case(20000, 64, 64, "k3", seed=9)
+    a = AG.conv_weight_grad(x, dy, nbr, 27, 64, 64)
+    c = AG.conv_weight_grad(x, dy, nbr, 27, 64, 64)
+    assert torch.equal(a, c)
+
+
+def test_inverse_map_is_the_transpose():
+    from eprecon_amd import autograd as AG
+    _, _, _, nbr, _ = conv_case(4000, 8, 8, "k3", seed=2)
+    inv = AG.inverse_map(nbr, nbr.shape[1])
+    assert torch.equal(inv, nbr.flip(0))            # a submanifold map is symmetric: offset k <-> offset 26 - k
+    _, _, _, down, _ = conv_case(4000, 8, 8, "down", seed=2)
+    _, _, _, up, _ = conv_case(4000, 8, 8, "up", seed=2)
+    assert torch.equal(AG.inverse_map(down, up.shape[1]), up)
+
+
+def point_case(n, c, seed):
+    from eprecon_amd.tensor import PointTensor
+    from eprecon_amd.torchsparse_utils import initial_voxelize, voxel_to_point, clear_voxelization_cache
+    clear_voxelization_cache()
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    pts = torch.rand(n, 4, device="cuda", generator=g) * 12
+    pts[:, 3] = 0
+    z = PointTensor(torch.randn(n, c, device="cuda", generator=g), pts)
+    with torch.no_grad():
+        x = initial_voxelize(z, 1, 1.7)
+        voxel_to_point(x, z)          # fills z.idx_query / z.weights
+    return z, x
+
+
+def test_devoxelize_and_segment_mean_gradients():
+    from eprecon_amd import autograd as AG
+    z, x = point_case(6000, 37, seed=4)
+    idx8, w8 = z.idx_query[1], z.weights[1]
+    m = x.F.shape[0]
+    g = torch.Generator(device="cuda").manual_seed(1)
+    vf = torch.randn(m, 37, device="cuda", generator=g)
+    dout = torch.randn(6000, 37, device="cuda", generator=g)
+    a = vf.clone().requires_grad_()
+    AG.devoxelize(a, idx8, w8).backward(dout)
+    r = vf.clone().requires_grad_()
+    pad = torch.cat([r, r.new_zeros(1, 37)])
+    idx = torch.where(idx8 >= 0, idx8, torch.full_like(idx8, m)).long()
+    ((pad[idx] * w8[:, :, None]).sum(1)).backward(dout)
+    close(a.grad, r.grad)
+
+    inverse, lists = z.additional_features["idx_query"][1], z.additional_features["lists"][1]
+    dvox = torch.randn(m, 37, device="cuda", generator=g)
+    a = z.F.clone().requires_grad_()
+    out = AG.segment_mean(a, inverse, lists, m)
+    out.backward(dvox)
+    r = z.F.clone().requires_grad_()
+    counts = torch.bincount(inverse.long(), minlength=m).float()
+    ref = torch.zeros(m, 37, device="cuda").index_add_(0, inverse.long(), r) / counts[:, None]
+    ref.backward(dvox)
+    close(out.detach(), ref.detach())
+    close(a.grad, r.grad)
+
+
+def _grid_sample_reference(feats, grid, mask, mode):
+    """feats [V,B=1,C,H,W], grid [V,N,2], mask bool[V,N] -> the reference's masked mean / variance"""
+    v = feats.shape[0]
+    samples = F.grid_sample(feats[:, 0], grid.view(v, 1, -1, 2), padding_mode="zeros", align_corners=True)[:, :, 0]   # [V,C,N]
+    samples = samples * mask[:, None, :]
+    cnt = mask.sum(0).clamp(min=1).float()
+    mean = samples.sum(0) / cnt
+    if mode == "mean":
+        return mean.t(), None
+    var = (((samples - mean[None]) * mask[:, None, :]) ** 2).sum(0) / cnt
+    return var.t(), mean.t()
+
+
+@pytest.mark.parametrize("mode,c", [("mean", 24), ("mean_depth", 40), ("variance", 32)])
+def test_back_project_gradients(mode, c):
+    from eprecon_amd import autograd as AG
+    from eprecon_amd import back_project as BP
+    from eprecon_amd import synthetic as S
+    window = S.make_window(seed=4)
+    coords = dev(S.dense_coords((96, 96, 96), 4))
+    feats = dev(S.make_features(9, 9, (c, 30, 40)))
+    krcam = dev(window["proj_matrices"][:, 2][:, None])
+    origin, vs = dev(window["vol_origin_partial"][None]), 0.04
+    hip_mode = {"mean": BP.MODE_MEAN, "mean_depth": BP.MODE_MEAN_DEPTH, "variance": BP.MODE_VARIANCE}[mode]
+    with torch.no_grad():
+        aux = BP.run(coords, origin, vs, feats, krcam, 2, hip_mode, want_grid=True)
+    a = feats.clone().requires_grad_()
+    res = AG.back_project(coords, origin, vs, a, krcam, 2, hip_mode, want_mean=(mode == "variance"))
+    g = torch.Generator(device="cuda").manual_seed(3)
+    dout = torch.randn(res["feats"].shape, device="cuda", generator=g)
+    dmean = torch.randn(res["n_valid"], c, device="cuda", generator=g)
+    loss = (res["feats"] * dout).sum() + ((res["mean"] * dmean).sum() if mode == "variance" else 0)
+    loss.backward()
+    r = feats.clone().requires_grad_()
+    out, mean = _grid_sample_reference(r, aux["grid"], aux["mask"], "variance" if mode == "variance" else "mean")
+    loss = (out * dout[:, :c]).sum() + ((mean * dmean).sum() if mode == "variance" else 0)
+    loss.backward()
+    close(res["feats"][:, :c].detach(), out.detach(), 1e-4)
+    close(a.grad, r.grad, 5e-4)
+
+
+def _spvcnn_case(stage=1, cin=138, n=6000):
+    from eprecon_amd import synthetic as S  # noqa: F401
+    from eprecon_amd.modules import SPVCNN
+    from oracle import pointvoxel as PV
+    from test_spvcnn_gpu import shell_coords
+    interval, vres, cr = 2 ** (2 - stage), 0.04 * 2 ** (2 - stage), 1 / 2 ** stage
+    window, coords = shell_coords(3 + stage, interval, n)
+    pts = PV.aligned_coords(coords, window["vol_origin_partial"][None], 0.04, window["world_to_aligned_camera"][None])
+    rng = np.random.default_rng(stage)
+    feat = rng.standard_normal((len(pts), cin)).astype(np.float32)
+    torch.manual_seed(stage)
+    net = SPVCNN(num_classes=1, in_channels=cin, pres=1, cr=cr, vres=vres, dropout=False).cuda()
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    return net, feat, pts, vres
+
+
+def test_spvcnn_recording_forward_matches_oracle_and_inference():
+    from eprecon_amd.tensor import PointTensor
+    from oracle import spvcnn as ON
+    net, feat, pts, vres = _spvcnn_case()
+    out = net(PointTensor(dev(feat), dev(pts)))
+    assert out.requires_grad
+    ref = ON.spvcnn_forward({k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}, feat, pts, 1, vres)
+    assert np.abs(out.detach().cpu().numpy() - ref).max() < 1e-3
+    with torch.no_grad():
+        inf = net(PointTensor(dev(feat), dev(pts)))
+    close(out.detach(), inf, 1e-4)
+
+
+def test_spvcnn_gradient_matches_finite_difference():
+    """directional derivative of a smooth scalar of the output along a random parameter direction"""
+    from eprecon_amd.tensor import PointTensor
+    net, feat, pts, vres = _spvcnn_case(stage=2, cin=74, n=3000)
+    x = dev(feat).requires_grad_()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    probe = None
+
+    def loss_of():
+        nonlocal probe
+        out = net(PointTensor(x, dev(pts)))
+        if probe is None:
+            probe = torch.randn(out.shape, device="cuda", generator=g) / out.numel() ** 0.5
+        return (torch.tanh(out) * probe).sum()
+
+    loss = loss_of()
+    loss.backward()
+    params = [p for p in net.parameters()]
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params) and torch.isfinite(x.grad).all()
+    assert sum(float(p.grad.abs().sum()) > 0 for p in params) == len(params)
+    dirs = [torch.randn(p.shape, device="cuda", generator=g) * p.detach().abs().mean().clamp(min=1e-3) for p in params]
+    analytic = sum(float((p.grad * d).sum()) for p, d in zip(params, dirs))
+    eps = 2e-3
+    vals = []
+    with torch.no_grad():
+        for sign in (1, -1):
+            for p, d in zip(params, dirs):
+                p.add_(sign * eps * d)
+            with torch.enable_grad():
+                vals.append(float(loss_of()))
+            for p, d in zip(params, dirs):
+                p.sub_(sign * eps * d)
+    numeric = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(numeric - analytic) < 0.05 * max(abs(analytic), 1e-3), (numeric, analytic)
+
+
+def test_convgru_recording_matches_oracle_and_trains():
+    from eprecon_amd import torchsparse_utils as TU
+    from eprecon_amd.modules import ConvGRU
+    from eprecon_amd.tensor import PointTensor
+    from oracle import pointvoxel as PV
+    from oracle import spvcnn as ON
+    from test_spvcnn_gpu import shell_coords
+    TU.clear_voxelization_cache()
+    ch, scale = 24, 2
+    interval, vres = 2 ** (2 - scale), 0.04 * 2 ** (2 - scale)
+    window, coords = shell_coords(7 + scale, interval, 5000)
+    pts = PV.aligned_coords(coords, window["vol_origin_partial"][None], 0.04, window["world_to_aligned_camera"][None])
+    pts[:, 3] = 0
+    rng = np.random.default_rng(ch)
+    h = rng.standard_normal((len(pts), ch)).astype(np.float32)
+    x = rng.standard_normal((len(pts), ch)).astype(np.float32)
+    torch.manual_seed(ch)
+    gru = ConvGRU(hidden_dim=ch, input_dim=ch, pres=1, vres=vres).cuda()
+    coords_t = dev(pts)
+    ht, xt = dev(h).requires_grad_(), dev(x).requires_grad_()
+    out = gru(PointTensor(ht, coords_t), PointTensor(xt, coords_t))
+    sd = {"g." + k: v.detach().cpu().numpy() for k, v in gru.state_dict().items()}
+    ref = ON.convgru(sd, "g", h, x, pts, 1, vres, literal=TU.LITERAL_CONVR)
+    assert np.abs(out.detach().cpu().numpy() - ref).max() < 1e-3
+    out.square().mean().backward()
+    for t in [ht, xt] + list(gru.parameters()):
+        assert t.grad is not None and torch.isfinite(t.grad).all() and float(t.grad.abs().sum()) > 0
