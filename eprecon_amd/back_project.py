@@ -228,8 +228,12 @@ class Back_Project(nn.Module):
         self.return_projection = return_projection
 
     def forward(self, coords, origin, voxel_size, feats, KRcam, min_view_number):
-        res = run(coords, origin, voxel_size, feats, KRcam, min_view_number, MODE_MEAN,
-                  want_grid=self.return_projection)
+        if torch.is_grad_enabled() and feats.requires_grad:
+            from . import autograd as AG    # training: the gathered features carry the gradient to the image maps
+            res = AG.back_project(coords, origin, voxel_size, feats, KRcam, min_view_number, MODE_MEAN)
+        else:
+            res = run(coords, origin, voxel_size, feats, KRcam, min_view_number, MODE_MEAN,
+                      want_grid=self.return_projection)
         if res is None:
             return None
         out_coords = res["coords"] if coords.dtype == torch.int32 else res["coords"].to(coords.dtype)
@@ -240,8 +244,13 @@ def view_variance(coords, origin, voxel_size, feats_fused, KRcam, min_view_numbe
     """Per-voxel population variance over the visible views of the fused 32-channel maps
     (models/occupancy_initialization.py:79-128).  Returns None when fewer than `min_valid` voxels
     are valid (:107-108), else dict(var, mean, coords, count, n_valid)."""
-    res = run(coords, origin, voxel_size, feats_fused, KRcam, min_view_number, MODE_VARIANCE,
-              min_valid_per_batch=min_valid, want_mean=True)
+    if torch.is_grad_enabled() and feats_fused.requires_grad:
+        from . import autograd as AG
+        res = AG.back_project(coords, origin, voxel_size, feats_fused, KRcam, min_view_number, MODE_VARIANCE,
+                              min_valid_per_batch=min_valid, want_mean=True)
+    else:
+        res = run(coords, origin, voxel_size, feats_fused, KRcam, min_view_number, MODE_VARIANCE,
+                  min_valid_per_batch=min_valid, want_mean=True)
     if res is None:
         return None
     res["var"] = res.pop("feats")

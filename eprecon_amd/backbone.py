@@ -127,6 +127,8 @@ def stack_views(maps):
     """torch.stack(maps) for V tensors [B,C,h,w] WITHOUT a copy when they are consecutive slices of one tensor
     (forward_views): the result aliases that tensor as [V,B,C,h,w]."""
     m0 = maps[0]
+    if torch.is_grad_enabled() and any(m.requires_grad for m in maps):
+        return torch.stack(list(maps))      # training: a recorded copy instead of an alias
     step = m0.shape[0] * m0.stride(0)
     base = m0.untyped_storage().data_ptr()
     if step > 0 and all(m.shape == m0.shape and m.stride() == m0.stride() and m.dtype == m0.dtype

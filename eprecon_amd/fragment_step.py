@@ -220,3 +220,60 @@ class Cfg4Step:
                             "96^3 FBV, persistent sparse global map",
                 "views": N_VIEWS, "image": "640x480", "weights": "seeded random, occupancy heads calibrated to "
                 "45/35/25 % keep", "fragments_per_step_per_gpu": 1}
+
+
+class TrainStep:
+    """One optimisation step of the 3D path the way main.py:297-313 takes it: NeuConNet.forward with autograd on one
+    fragment (recording operators of eprecon_amd/autograd.py), the LW-weighted total loss (models/neuralrecon.py:76-84),
+    loss.backward(), clip_grad_norm_(1.0), Adam (main.py:164: lr, betas (0.9, 0.999)).  With `world` > 1 the network is
+    wrapped in DistributedDataParallel over RCCL exactly as main.py:155-162 does (broadcast_buffers=False,
+    find_unused_parameters=True): one gradient all-reduce per step, bucketed by torch.
+
+    The image pyramids are leaf tensors standing in for the two 2D backbones (their gradient is what the backbones
+    would receive); the scene map is reset before every step so that each step sees the same fragment."""
+
+    LW = (1.0, 0.8, 0.64, 1.2)       # config/train.yaml:44
+
+    def __init__(self, seed=0, device=None, height=480, width=640, lr=1e-4, rank=0, world=1):
+        from .config import ModelCfg
+        from .neucon_network import NeuConNet
+        self.device = device or torch.device("cuda")
+        torch.manual_seed(4321)
+        self.net = NeuConNet(ModelCfg()).to(self.device)
+        self.net.train()
+        w = S.make_window(seed=seed * 100 + rank, width=width, height=height, advance=0.32 * rank)
+        f1, f2, inp = S.make_model_inputs([w], feat_seed=seed * 100 + rank, scene=f"scene{seed:04d}", panoptic=True)
+        self.f1, self.f2, self.inputs = (S.to_device(x, self.device) for x in (f1, f2, inp))
+        calibrate_occupancy_heads(self.net, self.f1, self.f2, self.inputs)
+        for views in (self.f1, self.f2):
+            for levels in views:
+                for t in levels:
+                    t.requires_grad_()
+        self.model = self.net
+        if world > 1:
+            import torch.distributed as dist
+            from torch.nn.parallel import DistributedDataParallel
+            for p_ in self.net.parameters():
+                dist.broadcast(p_.data, 0)
+            self.model = DistributedDataParallel(self.net, device_ids=[self.device.index], output_device=self.device.index,
+                                                 broadcast_buffers=False, find_unused_parameters=True)
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, betas=(0.9, 0.999))
+        self.last = None
+
+    def loss(self):
+        self.net.gru_fusion.scene_name = [None, None, None]
+        outputs, loss_dict = self.model(self.f1, self.f2, self.inputs, {})
+        total = 0
+        for i, (k, v) in enumerate(loss_dict.items()):
+            total = total + v * self.LW[min(i, len(self.LW) - 1)]
+        loss_dict["total_loss"] = total
+        return outputs, loss_dict
+
+    def run(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        outputs, loss_dict = self.loss()
+        loss_dict["total_loss"].backward()
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1.0)
+        self.optimizer.step()
+        self.last = {k: float(v) for k, v in loss_dict.items()}
+        return self.last

@@ -32,6 +32,12 @@ def upsample(pre_feat, pre_coords, interval):
     coords = coords.contiguous()
     feat = pre_feat.contiguous()
     c = feat.shape[1]
+    if torch.is_grad_enabled() and feat.requires_grad:
+        # training: children are parent-major (row 8 i + k), i.e. each row repeated 8 times; autograd sums them back
+        up_coords = torch.empty((8 * n, 4), dtype=torch.int32, device=feat.device)
+        _lib.check(lib.eprecon_upsample_async(None, 0, _lib.ptr(coords), n, 0, int(interval), None, _lib.ptr(up_coords),
+                                              _lib.current_stream()), "eprecon_upsample_async")
+        return feat.repeat_interleave(8, dim=0), up_coords
     up_feat = torch.empty((8 * n, c), dtype=torch.float32, device=feat.device)
     up_coords = torch.empty((8 * n, 4), dtype=torch.int32, device=feat.device)
     _lib.check(lib.eprecon_upsample_async(_lib.ptr(feat), feat.stride(0), _lib.ptr(coords), n, c,

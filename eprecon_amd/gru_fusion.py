@@ -189,16 +189,24 @@ class GRUFusion(nn.Module):
             gmap = self.global_volume[scale]
             rel_l = rel.tolist()
             updated, src_cur, src_glob, _ = gmap.crop_union(cur_c, cur_f, dim, interval, rel_l)
-            # current / global rows gathered straight into the [h | x] buffers of the two ConvGRUs (voxel channels
-            # and image channels): h = the map's row, x = the fragment's row; no concat / slice copies afterwards
             n_u, cin = updated.shape[0], self.ch_in[scale]
             chi = cin - chv
-            hx_v = torch.empty((n_u, 2 * chv), dtype=torch.float32, device=dev)
-            hx_i = torch.empty((n_u, 2 * chi), dtype=torch.float32, device=dev)
-            gmap.gather(src_glob, 0, chv, hx_v[:, :chv])
-            gmap.gather(src_glob, chv, chi, hx_i[:, :chi])
-            gather_rows(cur_f[:, :chv], src_cur, chv, out=hx_v[:, chv:])
-            gather_rows(cur_f[:, chv:], src_cur, chi, out=hx_i[:, chi:])
+            recording = torch.is_grad_enabled() and values_in.requires_grad
+            if recording:
+                # training: the map rows are state (the reference detaches the map at the start of every forward,
+                # models/gru_fusion.py:260-263); the fragment's rows keep their graph through an index gather
+                h_all = gmap.gather(src_glob, 0, cin, torch.empty((n_u, cin), dtype=torch.float32, device=dev))
+                pad = torch.cat([cur_f, cur_f.new_zeros((1, cin))])
+                x_all = pad[torch.where(src_cur >= 0, src_cur, torch.full_like(src_cur, cur_f.shape[0])).long()]
+            else:
+                # current / global rows gathered straight into the [h | x] buffers of the two ConvGRUs (voxel
+                # channels and image channels): h = the map's row, x = the fragment's row; no concat / slice copies
+                hx_v = torch.empty((n_u, 2 * chv), dtype=torch.float32, device=dev)
+                hx_i = torch.empty((n_u, 2 * chi), dtype=torch.float32, device=dev)
+                gmap.gather(src_glob, 0, chv, hx_v[:, :chv])
+                gmap.gather(src_glob, chv, chi, hx_i[:, :chi])
+                gather_rows(cur_f[:, :chv], src_cur, chv, out=hx_v[:, chv:])
+                gather_rows(cur_f[:, chv:], src_cur, chi, out=hx_i[:, chi:])
 
             tsdf_target = occ_target = None
             if "occ_list" in inputs:
@@ -207,8 +215,18 @@ class GRUFusion(nn.Module):
                     inputs["tsdf_list"][lvl][i], inputs["occ_list"][lvl][i], dim, rel_l, updated)
                 occ_target = tsdf_target.abs() < 1
 
-            values = torch.empty((n_u, cin), dtype=torch.float32, device=dev)
-            if not self._identity_fusion:
+            values = None if recording else torch.empty((n_u, cin), dtype=torch.float32, device=dev)
+            if recording and self._identity_fusion:
+                values = x_all
+            elif recording:
+                pts_c = torch.cat([torch.zeros_like(updated[:, :1]), updated * interval], dim=1)
+                r_coords = aligned_camera_coords(pts_c, origin.reshape(1, 3), cfg.VOXEL_SIZE,
+                                                 inputs["world_to_aligned_camera"][i].reshape(1, 4, 4))
+                gv, gi = self.fusion_nets_voxel[scale], self.fusion_nets_img[scale]
+                vv = gv(PointTensor(h_all[:, :chv], r_coords), PointTensor(x_all[:, :chv], r_coords))
+                vi = gi(PointTensor(h_all[:, chv:], r_coords), PointTensor(x_all[:, chv:], r_coords))
+                values = torch.cat([vv, vi], dim=1)
+            elif not self._identity_fusion:
                 pts_c = torch.cat([torch.zeros_like(updated[:, :1]), updated * interval], dim=1)
                 r_coords = aligned_camera_coords(pts_c, origin.reshape(1, 3), cfg.VOXEL_SIZE,
                                                  inputs["world_to_aligned_camera"][i].reshape(1, 4, 4))
@@ -232,7 +250,7 @@ class GRUFusion(nn.Module):
             else:
                 values[:, :chv], values[:, chv:] = hx_v[:, chv:], hx_i[:, chi:]
 
-            gmap.update(updated, values)    # update_map (:195-215)
+            gmap.update(updated, values.detach().contiguous() if recording else values)    # update_map (:195-215)
             if self._xchg is not None:      # multi-GPU: these voxels now carry this rank's newest fusion result
                 rel_t = torch.tensor(rel_l, dtype=torch.int32, device=dev)
                 self._xchg.mark_fused(scale, updated + rel_t, self._cur_fragment)

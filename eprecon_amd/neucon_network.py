@@ -1,6 +1,8 @@
-"""Coarse-to-fine 3D path — mirror of NeuConNet (models/neucon_network.py:25-624 of the reference),
-inference path only (losses, target visualisation and the Hungarian criterion are out of scope,
-SURVEY.md section 2a rows 6/11).
+"""Coarse-to-fine 3D path — mirror of NeuConNet (models/neucon_network.py:25-624 of the reference).
+Under torch.no_grad() this is the fused inference path; with autograd enabled the same forward runs through the
+recording operators (eprecon_amd/autograd.py) and fills loss_dict like the reference: the initial-occupancy loss
+(only_train_init), the per-scale TSDF / occupancy losses against the fused ground truth and the panoptic set
+criterion (eprecon_amd/criterion.py).  Target visualisation is out of scope.
 
 forward(features, features_backbone2d_occ_pano, inputs, outputs, ...) keeps the reference's
 signature and early-return conventions:
@@ -20,6 +22,7 @@ from . import grid_ops as GO
 from . import sparse as SP
 from .back_project import Back_Project
 from .backbone import stack_views
+from .criterion import HungarianMatcher, SetCriterion, compute_loss, compute_loss_init
 from .config import (CH_IMG, CH_INIT_DOWN, CH_VOXEL, EXCEED_NUM, INIT_MIN_VIEW, INIT_OCC_THRESHOLD, INIT_STAGE,
                      N_VIEWS, NUM_CLASSES, NUM_QUERIES, PANOPTIC_CH, PANOPTIC_SHAPE, STAGE_MIN_OCC)
 from .generate_grids import dense_coords
@@ -68,8 +71,48 @@ class NeuConNet(nn.Module):
             self.tsdf_preds.append(Linear4xTrans(channels[i], 1))
             self.occ_preds.append(Linear4xTrans(channels[i], 1))
             self.panoptic_preds.append(Linear4xTrans(gru_channels[i], PANOPTIC_CH))
+        # criterion (models/neucon_network.py:73-99): class / mask / dice weights 0.2 / 0.8 / 0.8, one copy per decoder layer
+        class_w, mask_w, dice_w = 0.2, 0.8, 0.8
+        weight_dict = {"loss_ce": class_w, "loss_mask": mask_w, "loss_dice": dice_w}
+        for j in range(6):
+            weight_dict.update({f"{k}_{j}": v for k, v in (("loss_ce", class_w), ("loss_mask", mask_w), ("loss_dice", dice_w))})
+        self.criterion = SetCriterion(NUM_CLASSES, HungarianMatcher(class_w, mask_w, dice_w), weight_dict, eos_coef=0.1,
+                                      losses=["labels", "masks"])
         self.trace = None  # set to a list to record per-stage intermediates (parity tests)
         self.distributed_exchange = False  # multi-GPU: boundary-voxel all-gather before each fragment
+
+    @staticmethod
+    def _lookup(volume, coords, scale):
+        c = coords.long()
+        return volume[c[:, 0], c[:, 1] // 2 ** scale, c[:, 2] // 2 ** scale, c[:, 3] // 2 ** scale]
+
+    @torch.no_grad()
+    def get_target(self, coords, inputs, scale):
+        """models/neucon_network.py:117-126 (fusion off): ground truth at the voxels"""
+        return self._lookup(inputs["tsdf_list"][scale], coords, scale), self._lookup(inputs["occ_list"][scale], coords, scale)
+
+    @torch.no_grad()
+    def get_target_init(self, coords, inputs, scale):
+        """models/neucon_network.py:128-143: (clamp(1 - |tsdf|, 0, 1), occ) at the voxels"""
+        tsdf, occ = self.get_target(coords, inputs, scale)
+        return torch.clamp(1 - tsdf.abs(), min=0, max=1), occ
+
+    @torch.no_grad()
+    def get_panoptic_targets(self, coords, inputs, scale, bs):
+        """models/neucon_network.py:157-191: per batch element the instance masks over its voxels and, per instance, the
+        most frequent semantic label"""
+        semantic = self._lookup(inputs["semantic_list"][scale], coords, scale)
+        instance = self._lookup(inputs["instance_list"][scale], coords, scale)
+        targets = []
+        for b in range(bs):
+            rows = coords[:, 0] == b
+            sem, ins = semantic[rows].long(), instance[rows]
+            ids, inv = torch.unique(ins, return_inverse=True)
+            masks = inv.unsqueeze(0) == torch.arange(ids.shape[0], device=ins.device).unsqueeze(1)
+            votes = torch.zeros((ids.shape[0], int(sem.max()) + 1 if sem.numel() else 1), dtype=torch.int64, device=ins.device)
+            votes.index_put_((inv, sem), torch.ones_like(sem), accumulate=True)
+            targets.append({"labels": votes.argmax(1), "masks": masks})
+        return targets
 
     # models/neucon_network.py:193-214
     def upsample(self, pre_feat, pre_coords, interval, num=8):
@@ -86,7 +129,9 @@ class NeuConNet(nn.Module):
         bs = features[0][0].shape[0]
         dev = features[0][0].device
         loss_dict = {}
-        zero = torch.zeros((), device=dev)
+        recording = torch.is_grad_enabled()
+        # the reference's placeholder losses stay attached to the graph (0 * features.sum(), :255,377)
+        zero = features[0][0].sum() * 0.0 if recording and features[0][0].requires_grad else torch.zeros((), device=dev)
         if self.distributed_exchange and cfg.FUSION.FUSION_ON:
             # the one collective of the path (RCCL all-gather of boundary voxels); placed
             # before every data-dependent early return so that all ranks issue it once per fragment
@@ -106,6 +151,18 @@ class NeuConNet(nn.Module):
             outputs["init_overlap_count"] = init_overlap_count
             return outputs, loss_dict
         occ_init, coord_init, count_init = init_output
+        if only_train_init:    # :267-292
+            tsdf_init_target, occ_init_target = self.get_target_init(coord_init, inputs, scale)
+            hit = occ_init.detach().sigmoid().reshape(-1) > INIT_OCC_THRESHOLD
+            losses = []
+            for b in range(bs):
+                rows = coord_init[:, 0] == b
+                pred, tgt = hit[rows], tsdf_init_target[rows] > 0
+                init_overlap_count = init_overlap_count + (pred & tgt).sum() / (pred | tgt).sum()
+                losses.append(compute_loss_init(occ_init[rows], tsdf_init_target[rows], occ_init_target[rows]))
+            outputs["init_overlap_count"] = init_overlap_count
+            loss_dict["occupancy_initialization_loss"] = sum(losses) / len(losses)
+            return outputs, loss_dict
         coord_init_selected, _ = GO.init_select(occ_init, coord_init, bs, dim=shape_init[0] // 2 ** INIT_STAGE,
                                                 cell=2 ** self.n_scales, threshold=INIT_OCC_THRESHOLD)
         self._record(stage="init", occ_init=occ_init, coord_init=coord_init, selected=coord_init_selected)
@@ -148,6 +205,8 @@ class NeuConNet(nn.Module):
                          volume=volume)
 
             tsdf_target = None
+            if not cfg.FUSION.FUSION_ON and "occ_list" in inputs:
+                tsdf_target, occ_target = self.get_target(up_coords, inputs, scale)
             if cfg.FUSION.FUSION_ON:
                 voxel_dim = feat.shape[-1]
                 fuse_in = (up_coords, feat_all)
@@ -157,7 +216,10 @@ class NeuConNet(nn.Module):
                              feat_all=feat_all, tsdf_target=tsdf_target)
             tsdf = self.tsdf_preds[i](feat)
             occ = self.occ_preds[i](feat)
-            loss_dict[f"tsdf_occ_loss_{i}"] = zero  # losses are out of scope (inference path)
+            if recording and tsdf_target is not None:   # :441-449 (grid_mask is all ones with FUSION.FULL)
+                loss_dict[f"tsdf_occ_loss_{i}"] = compute_loss(tsdf, occ, tsdf_target, occ_target, pos_weight=cfg.POS_WEIGHT)
+            else:
+                loss_dict[f"tsdf_occ_loss_{i}"] = zero
 
             # ---- sparsify for the next stage (:454-507) ----
             # (the reference's grid_mask is all ones on this path, `occupancy[grid_mask == False] = False` is a no-op)
@@ -235,8 +297,28 @@ class NeuConNet(nn.Module):
         if self.panoptic is not None:
             outputs["panoptic_out"] = panoptic_predictions
             outputs["panoptic_info"] = [panoptic_post(o) for o in panoptic_predictions]  # :583-587
+            if recording and "rgb_list" in inputs and occ_target is not None:
+                loss_dict["panoptic_loss"] = self._panoptic_loss(panoptic_predictions, panoptic_coords[2], occ_target, occupancy,
+                                                                 inputs, bs)
         self._record(stage="panoptic", coords=panoptic_coords, feats=panoptic_voxel_feats)
         return outputs, loss_dict
+
+    def _panoptic_loss(self, panoptic_outs, coords_fine, occ_target, occupancy, inputs, bs):
+        """models/neucon_network.py:589-622: the set criterion on the voxels whose ground truth is observed; the
+        weighted terms are summed and divided by 3, then averaged over the batch"""
+        supervised = occ_target[occupancy].view(-1)
+        for b in range(bs):
+            rows = coords_fine[:, 0] == b
+            keep = supervised[rows]
+            panoptic_outs[b]["pred_masks"] = panoptic_outs[b]["pred_masks"][..., keep]
+            for aux in panoptic_outs[b]["aux_outputs"]:
+                aux["pred_masks"] = aux["pred_masks"][..., keep]
+        targets = self.get_panoptic_targets(coords_fine[supervised], inputs, 0, bs)
+        total = []
+        for b in range(bs):
+            losses = self.criterion(panoptic_outs[b], [targets[b]])
+            total.append(sum(v * self.criterion.weight_dict[k] for k, v in losses.items() if k in self.criterion.weight_dict) / 3)
+        return sum(total) / len(total)
 
     @staticmethod
     def prune_to_ancestors(panoptic_coords):

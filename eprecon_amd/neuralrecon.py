@@ -3,7 +3,8 @@ normalise the 9 images, run the two MnasMulti backbones per view (PyTorch-ROCm),
 (NeuConNet), and at test time fuse TSDF + panoptic ids into the scene map (fuse_to_global).
 
 forward(inputs: dict, save_mesh=False, training=True) -> (outputs: dict, loss_dict: dict), called the
-way main.py:430-436 calls it.  Losses are out of scope (inference path): loss_dict carries zeros.
+way main.py:430-436 calls it.  With autograd enabled loss_dict carries the training losses and their LW-weighted
+'total_loss' (models/neuralrecon.py:76-84); under torch.no_grad() it carries zeros.
 """
 import torch
 import torch.nn as nn
@@ -33,6 +34,7 @@ class NeuralRecon(nn.Module):
         super().__init__()
         # the reference hands over the whole yacs node and reads cfg.MODEL (models/neuralrecon.py:22-33);
         # a plain ModelCfg is accepted as well
+        train_cfg = getattr(cfg, "TRAIN", None)     # config/default.py:36-38
         cfg = getattr(cfg, "MODEL", cfg)
         self.cfg = cfg
         self.register_buffer("pixel_mean", torch.tensor(PIXEL_MEAN).view(-1, 1, 1), persistent=False)
@@ -42,6 +44,10 @@ class NeuralRecon(nn.Module):
         self.backbone_occ_pano = MnasMulti(float(cfg.ALPHA))
         self.neucon_net = NeuConNet(cfg)
         self.fuse_to_global = GRUFusion(cfg, direct_substitute=True, trianing=False)
+        self.only_train_init = bool(getattr(train_cfg, "ONLY_INIT", False))
+        self.only_train_occ = bool(getattr(train_cfg, "ONLY_OCC", False))
+        self.init_overlap_count = 0
+        self.loss_weights = list(getattr(cfg, "LW", LOSS_WEIGHTS))
         self.batch_views = True   # False: always the reference's per-view backbone loop
 
     def normalizer(self, x):
@@ -62,12 +68,16 @@ class NeuralRecon(nn.Module):
             norm = [self.normalizer(img) for img in imgs]
             features_backbone2d = self.backbone2d.forward_views(norm)
             features_occ_pano = self.backbone_occ_pano.forward_views(norm)
-        outputs, loss_dict = self.neucon_net(features_backbone2d, features_occ_pano, inputs, outputs)
+        outputs, loss_dict = self.neucon_net(features_backbone2d, features_occ_pano, inputs, outputs,
+                                             only_train_init=self.only_train_init, only_train_occ=self.only_train_occ,
+                                             init_overlap_count=self.init_overlap_count)
+        if self.only_train_init:
+            self.init_overlap_count = outputs["init_overlap_count"]
         if not training and "coords" in outputs and "panoptic_info" in outputs:
             outputs = self.fuse_to_global(outputs["coords"], outputs["tsdf"], inputs, self.n_scales, outputs,
                                           save_mesh, panoptic_infos=outputs["panoptic_info"])
         total = 0
         for i, (k, v) in enumerate(loss_dict.items()):
-            total = total + v * LOSS_WEIGHTS[min(i, len(LOSS_WEIGHTS) - 1)]
+            total = total + v * self.loss_weights[min(i, len(self.loss_weights) - 1)]
         loss_dict["total_loss"] = total
         return outputs, loss_dict

@@ -147,7 +147,7 @@ class Occupancy_Initialization(nn.Module):
         for conv, norm in ((self.subm1, self.norm1), (self.subm2, self.norm2), (self.subm3, self.norm3)):
             x = conv.run_ln(x, vset, norm, relu=True, residual=x)  # LN(x + ReLU(conv(x))), one launch
         y = self.subm4.run(x, vset)
-        return self.norm4.run(y, out=y)
+        return self.norm4.run(y, out=None if torch.is_grad_enabled() else y)
 
     def forward(self, coords, origin, voxel_size, features_all, KRcam, shape, stage, min_view_number):
         bs = features_all[0][0].shape[0]
@@ -169,13 +169,14 @@ class Occupancy_Initialization(nn.Module):
             return None
         interval = 2 ** (2 - stage)
         coord_valid = res["coords"]
-        occ = torch.empty((res["n_valid"], 1), dtype=torch.float32, device=fused.device)
+        parts = []
         start = 0
         for b in range(bs):  # statistics of norm0 / norm4 are per batch element, as in the reference
             nb = res["n_valid_per_batch"][b]
             seg = slice(start, start + nb)
             vset = SP.VoxelSet(coord_valid[seg], interval)
-            occ[seg] = self.sparse_stack(res["var"][seg], vset)
+            parts.append(self.sparse_stack(res["var"][seg], vset))
             start += nb
+        occ = parts[0] if bs == 1 else torch.cat(parts)
         out_coords = coord_valid if coords.dtype == torch.int32 else coord_valid.to(coords.dtype)
         return [occ, out_coords, res["count"]]

@@ -169,6 +169,23 @@ def scene_sdf(x, y, z):
     return d
 
 
+def analytic_panoptic(window, level=0):
+    """(semantic, instance) int64 grids of the analytic scene: each voxel takes the label of the nearest surface
+    primitive — floor (ScanNet id 2), the three walls (id 1, one instance each), the three spheres (chair 5, sofa 6,
+    table 7).  Instance ids are 1-based and unique per primitive; what datasets/transforms.py hands the criterion
+    as inputs['semantic_list'] / ['instance_list']."""
+    vs = window["voxel_size"] * 2 ** level
+    dims = [n // 2 ** level for n in window["n_vox"]]
+    o = window["vol_origin_partial"].astype(np.float64)
+    ax = [o[a] + np.arange(dims[a]) * vs for a in range(3)]
+    x, y, z = np.meshgrid(ax[0], ax[1], ax[2], indexing="ij")
+    prims = [z - 0.0, 3.4 - y, x + 1.7, 1.7 - x]
+    prims += [np.sqrt((x - cx) ** 2 + (y - cy) ** 2 + (z - cz) ** 2) - r for cx, cy, cz, r in SCENE_SPHERES]
+    nearest = np.argmin(np.abs(np.stack(prims)), axis=0)
+    semantic_of = np.array([2, 1, 1, 1, 5, 6, 7], np.int64)
+    return semantic_of[nearest], (nearest + 1).astype(np.int64)
+
+
 def render_depth(window, view, max_depth=6.0, holes_seed=None, hole_fraction=0.03):
     """Synthetic depth image f32[H, W] (camera-frame z in metres, 0 = invalid) of the analytic scene seen from
     view `view` of the window, by sphere tracing.  Rays that leave the scene (there is no ceiling / front wall)
@@ -196,7 +213,7 @@ def render_depth(window, view, max_depth=6.0, holes_seed=None, hole_fraction=0.0
     return depth
 
 
-def make_model_inputs(windows, feat_seed=0, scene="scene0000_00", fragment_ids=None):
+def make_model_inputs(windows, feat_seed=0, scene="scene0000_00", fragment_ids=None, panoptic=False):
     """numpy inputs of NeuConNet.forward for a batch of windows (list of make_window dicts):
     both backbones' pyramids as the reference's list over views of [f4, f8, f16] (each [B,C,H,W]),
     and the `inputs` dict of datasets/transforms.py (proj_matrices [B,V,3,4,4], origins,
@@ -225,6 +242,11 @@ def make_model_inputs(windows, feat_seed=0, scene="scene0000_00", fragment_ids=N
         "tsdf_list": tsdf_list,
         "occ_list": occ_list,
     }
+    if panoptic:   # ground truth of the panoptic criterion (training); 'rgb_list' is the key the reference tests for
+        labels = [[analytic_panoptic(wd, lvl) for wd in windows] for lvl in range(3)]
+        inputs["semantic_list"] = [np.stack([sem for sem, _ in lv]) for lv in labels]
+        inputs["instance_list"] = [np.stack([ins for _, ins in lv]) for lv in labels]
+        inputs["rgb_list"] = [np.zeros(t.shape + (3,), np.uint8) for t in tsdf_list]
     return features, features_occ_pano, inputs
 
 

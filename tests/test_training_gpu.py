@@ -1,0 +1,89 @@
+"""f4: the whole 3D path under autograd — losses, gradients, optimisation steps (eprecon_amd.fragment_step.TrainStep)."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def step():
+    from eprecon_amd.fragment_step import TrainStep
+    return TrainStep(seed=0, lr=2e-4)
+
+
+def test_recording_forward_equals_inference_forward(step):
+    """same weights, same fragment: the recording operators and the fused inference launches give the same network"""
+    net = step.net
+    net.gru_fusion.scene_name = [None, None, None]
+    with torch.no_grad():
+        out_inf, _ = net(step.f1, step.f2, step.inputs, {})
+    out_rec, losses = step.loss()
+    assert torch.equal(out_inf["coords"], out_rec["coords"])
+    assert float((out_inf["tsdf"] - out_rec["tsdf"].detach()).abs().max()) < 2e-3
+    assert set(losses) == {"tsdf_occ_loss_0", "tsdf_occ_loss_1", "tsdf_occ_loss_2", "panoptic_loss", "total_loss"}
+    assert all(torch.isfinite(v).all() and float(v.detach()) > 0 for v in losses.values())
+
+
+def test_every_used_parameter_and_the_image_features_receive_gradients(step):
+    step.optimizer.zero_grad(set_to_none=True)
+    _, losses = step.loss()
+    losses["total_loss"].backward()
+    named = dict(step.net.named_parameters())
+    missing = [n for n, p in named.items() if p.grad is None]
+    # without a gradient in the reference as well (hence its find_unused_parameters=True, main.py:160): the occupancy
+    # initialisation only SELECTS voxels on this path (it is trained on its own with TRAIN.ONLY_INIT), and
+    # Panoptic_Feat_Fusion's linear layers are never called (only generate_mask_features is)
+    assert all(n.startswith(("initialization.", "panoptic_feat_fusion.img2panoptic", "panoptic_feat_fusion.occ2panoptic",
+                             "panoptic_feat_fusion.pre_fusion")) for n in missing), missing
+    bad = [n for n, p in named.items() if p.grad is not None and not torch.isfinite(p.grad).all()]
+    assert not bad, bad
+    for group in ("sp_convs.0.", "sp_convs.2.", "gru_fusion.", "tsdf_preds.", "occ_preds.", "panoptic_preds.",
+                  "panoptic."):
+        assert any(float(p.grad.abs().sum()) > 0 for n, p in named.items() if n.startswith(group) and p.grad is not None), group
+    # the surface / panoptic backbone's pyramid receives the gradient of all three back-projections
+    for lvl in range(3):
+        grads = [levels[lvl].grad for levels in step.f2]
+        assert all(g is not None and torch.isfinite(g).all() for g in grads) and sum(float(g.abs().sum()) for g in grads) > 0
+
+
+def test_optimisation_steps_reduce_the_loss(step):
+    first = step.run()["total_loss"]
+    for _ in range(5):
+        last = step.run()["total_loss"]
+    assert np.isfinite(last) and last < first, (first, last)
+
+
+def test_only_train_init_loss(step):
+    step.net.gru_fusion.scene_name = [None, None, None]
+    outputs, losses = step.net(step.f1, step.f2, step.inputs, {}, only_train_init=True)
+    assert list(losses) == ["occupancy_initialization_loss"] and float(losses["occupancy_initialization_loss"]) > 0
+    assert 0 <= float(outputs["init_overlap_count"]) <= 1
+    losses["occupancy_initialization_loss"].backward()
+    assert any(p.grad is not None and float(p.grad.abs().sum()) > 0 for p in step.net.initialization.parameters())
+
+
+def test_ddp_wraps_the_training_step_single_rank():
+    """DistributedDataParallel over RCCL with one rank: the reference's wrapper (main.py:155-162) around the recording
+    path; the all-reduce hooks fire on the HIP Functions' gradients"""
+    import torch.distributed as dist
+    from eprecon_amd.fragment_step import TrainStep
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        from torch.nn.parallel import DistributedDataParallel
+        s = TrainStep(seed=1, lr=1e-4)
+        s.model = DistributedDataParallel(s.net, device_ids=[0], output_device=0, broadcast_buffers=False,
+                                          find_unused_parameters=True)
+        s.optimizer = torch.optim.Adam(s.model.parameters(), lr=1e-4)
+        a = s.run()
+        b = s.run()
+        assert np.isfinite(a["total_loss"]) and np.isfinite(b["total_loss"])
+    finally:
+        if created:
+            dist.destroy_process_group()
