@@ -31,20 +31,29 @@ struct WgradParams {
     float *partial;  // [nchunks][kvol][cin][cout]
 };
 
-// NI x NJ 32x32 tiles per wave, 2 x 2 waves: the workgroup owns a (64 NI) x (64 NJ) block of dW[k]
-template <int NI, int NJ>
+// The workgroup owns a (32 NI WI) x (32 NJ WJ) block of dW[k]: WI x WJ x WR = 4 waves, each with NI x NJ 32x32 MFMA tiles;
+// the WR waves that share a tile split the rows of every stage (k-steps r = wr mod WR) and are summed through LDS in
+// wave order at the end.  Narrow layers (the finest level runs 48 -> 24 channels over > 100k voxels) therefore keep all
+// four waves on useful MFMAs instead of padding a 64 x 64 tile.  Global loads of the next row block are issued before
+// the MFMA loop of the current one (register prefetch).
+template <int NI, int NJ, int WI, int WJ, int WR>
 __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradParams p)
 {
-    constexpr int TI = 64 * NI, TJ = 64 * NJ;
+    static_assert(WI * WJ * WR == 4, "four waves");
+    constexpr int TI = 32 * NI * WI, TJ = 32 * NJ * WJ;
     constexpr int SA = TI + 32, SG = TJ + 32;  // row pitches: the two half-waves read rows 32 banks apart
-    __shared__ __align__(16) float sA[kRowBlock * SA];
-    __shared__ __align__(16) float sG[kRowBlock * SG];
+    constexpr int LA = kRowBlock * (TI / 4) / 256, LG = kRowBlock * (TJ / 4) / 256;  // float4 loads per thread and stage
+    static_assert(LA >= 1 && LG >= 1, "tile too small for the staging loop");
+    constexpr int RED = (WR > 1) ? (WR - 1) * WI * WJ * NI * NJ * 1024 : 1;
+    constexpr int STAGE = kRowBlock * (SA + SG);
+    __shared__ __align__(16) float sBuf[STAGE > RED ? STAGE : RED];
+    float *sA = sBuf, *sG = sBuf + kRowBlock * SA;
     __shared__ int sIn[kSubChunk], sOut[kSubChunk];
     __shared__ int sWave[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r32 = lane & 31, half = lane >> 5;
-    const int wi = wid >> 1, wj = wid & 1;
+    const int wr = wid % WR, wj = (wid / WR) % WJ, wi = wid / (WR * WJ);
     const int k = blockIdx.x % p.kvol, chunk = blockIdx.x / p.kvol;
     const int ci0 = blockIdx.y * TI, co0 = blockIdx.z * TJ;
     const int64_t row0 = (int64_t)chunk * p.chunk_rows;
@@ -57,6 +66,21 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradParams p)
         for (int b = 0; b < NJ; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    auto load_row = [&](const float *base, int64_t row, int ld, int c0, int climit) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float *src = base + row * ld + c0;
+        const int left = climit - c0;
+        if (left >= 4 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+            v = *reinterpret_cast<const float4 *>(src);
+        } else {
+            if (left > 0) v.x = src[0];
+            if (left > 1) v.y = src[1];
+            if (left > 2) v.z = src[2];
+            if (left > 3) v.w = src[3];
+        }
+        return v;
+    };
 
     for (int64_t sub0 = row0; sub0 < row1; sub0 += kSubChunk) {
         // ---- compaction of the valid (input row, output row) pairs of this sub-chunk, in row order ----
@@ -76,44 +100,39 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradParams p)
             __syncthreads();
         }
         // ---- contraction over the compacted rows ----
-        for (int rb = 0; rb < cnt; rb += kRowBlock) {
-            for (int e = tid; e < kRowBlock * (TI / 4); e += 256) {
+        float4 ra[LA], rg[LG];
+        auto fetch = [&](int rb) {
+#pragma unroll
+            for (int u = 0; u < LA; ++u) {
+                const int e = tid + u * 256;
                 const int r = e / (TI / 4), c4 = (e - r * (TI / 4)) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rb + r < cnt) {
-                    const float *src = p.x + (int64_t)sIn[rb + r] * p.ld_x + ci0 + c4;
-                    const int left = p.cin - (ci0 + c4);
-                    if (left >= 4 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-                        v = *reinterpret_cast<const float4 *>(src);
-                    } else {
-                        if (left > 0) v.x = src[0];
-                        if (left > 1) v.y = src[1];
-                        if (left > 2) v.z = src[2];
-                        if (left > 3) v.w = src[3];
-                    }
-                }
-                *reinterpret_cast<float4 *>(&sA[r * SA + c4]) = v;
+                ra[u] = rb + r < cnt ? load_row(p.x, sIn[rb + r], p.ld_x, ci0 + c4, p.cin) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            for (int e = tid; e < kRowBlock * (TJ / 4); e += 256) {
+#pragma unroll
+            for (int u = 0; u < LG; ++u) {
+                const int e = tid + u * 256;
                 const int r = e / (TJ / 4), c4 = (e - r * (TJ / 4)) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rb + r < cnt) {
-                    const float *src = p.dy + (int64_t)sOut[rb + r] * p.ld_dy + co0 + c4;
-                    const int left = p.cout - (co0 + c4);
-                    if (left >= 4 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-                        v = *reinterpret_cast<const float4 *>(src);
-                    } else {
-                        if (left > 0) v.x = src[0];
-                        if (left > 1) v.y = src[1];
-                        if (left > 2) v.z = src[2];
-                        if (left > 3) v.w = src[3];
-                    }
-                }
-                *reinterpret_cast<float4 *>(&sG[r * SG + c4]) = v;
+                rg[u] = rb + r < cnt ? load_row(p.dy, sOut[rb + r], p.ld_dy, co0 + c4, p.cout) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        if (cnt > 0) fetch(0);
+        for (int rb = 0; rb < cnt; rb += kRowBlock) {
+#pragma unroll
+            for (int u = 0; u < LA; ++u) {
+                const int e = tid + u * 256;
+                const int r = e / (TI / 4), c4 = (e - r * (TI / 4)) * 4;
+                *reinterpret_cast<float4 *>(&sA[r * SA + c4]) = ra[u];
+            }
+#pragma unroll
+            for (int u = 0; u < LG; ++u) {
+                const int e = tid + u * 256;
+                const int r = e / (TJ / 4), c4 = (e - r * (TJ / 4)) * 4;
+                *reinterpret_cast<float4 *>(&sG[r * SG + c4]) = rg[u];
             }
             __syncthreads();
+            if (rb + kRowBlock < cnt) fetch(rb + kRowBlock);
 #pragma unroll 4
-            for (int kk = 0; kk < kRowBlock / 2; ++kk) {
+            for (int kk = wr; kk < kRowBlock / 2; kk += WR) {
                 const int r = 2 * kk + half;
                 float a[NI], b[NJ];
 #pragma unroll
@@ -127,6 +146,28 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradParams p)
                         acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
             }
             __syncthreads();
+        }
+    }
+    if (WR > 1) {  // the row groups of a tile are summed in wave order: wr = 1, 2, .. into wr = 0
+        float *slot = sBuf + ((size_t)((wr - 1) * WI * WJ + wi * WJ + wj) * NI * NJ) * 1024;
+        if (wr > 0) {
+#pragma unroll
+            for (int ti = 0; ti < NI; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < NJ; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) slot[((ti * NJ + tj) * 16 + r) * 64 + lane] = acc[ti][tj][r];
+        }
+        __syncthreads();
+        if (wr > 0) return;
+        for (int g = 1; g < WR; ++g) {
+            const float *src = sBuf + ((size_t)((g - 1) * WI * WJ + wi * WJ + wj) * NI * NJ) * 1024;
+#pragma unroll
+            for (int ti = 0; ti < NI; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < NJ; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[ti][tj][r] += src[((ti * NJ + tj) * 16 + r) * 64 + lane];
         }
     }
     // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -191,10 +232,18 @@ __global__ __launch_bounds__(256) void gather_rows_scaled_kernel(const float *sr
     dst[pt * ld_d + c] = v >= 0 ? src[(int64_t)v * ld_s + c] * (scale ? scale[v] : 1.0f) : 0.0f;
 }
 
-int wgrad_chunks(int kvol, int64_t n_out, int cin, int cout, int big)
+// tile of dW[k] one workgroup owns, by layer width
+void wgrad_tile(int cin, int cout, int &ti, int &tj)
 {
-    const int t = big ? 128 : 64;
-    const int64_t tiles = ep::ceil_div(cin, t) * ep::ceil_div(cout, t);
+    tj = cout <= 32 ? 32 : (cout <= 64 ? 64 : 128);
+    ti = cin <= 32 ? 32 : ((cin <= 64 || tj < 128) ? 64 : 128);
+}
+
+int wgrad_chunks(int kvol, int64_t n_out, int cin, int cout)
+{
+    int ti, tj;
+    wgrad_tile(cin, cout, ti, tj);
+    const int64_t tiles = ep::ceil_div(cin, ti) * ep::ceil_div(cout, tj);
     int64_t want = ep::ceil_div(1024, (int64_t)kvol * tiles);
     const int64_t most = ep::ceil_div(n_out, 256);
     if (want > most) want = most;
@@ -202,15 +251,13 @@ int wgrad_chunks(int kvol, int64_t n_out, int cin, int cout, int big)
     return (int)want;
 }
 
-bool wgrad_big(int cin, int cout) { return cin > 64 && cout > 64; }
-
 }  // namespace
 
 extern "C" {
 
 size_t eprecon_sparse_conv_wgrad_workspace_bytes(int kvol, int64_t n_out, int cin, int cout)
 {
-    const int nch = wgrad_chunks(kvol, n_out, cin, cout, wgrad_big(cin, cout));
+    const int nch = wgrad_chunks(kvol, n_out, cin, cout);
     return (size_t)nch * kvol * cin * cout * sizeof(float);
 }
 
@@ -227,20 +274,25 @@ int eprecon_sparse_conv_wgrad_async(const float *x, int ld_x, const float *dy, i
     }
     if (workspace_bytes < eprecon_sparse_conv_wgrad_workspace_bytes(kvol, n_out, cin, cout) || !workspace)
         return EPRECON_ERR_WORKSPACE;
-    const bool big = wgrad_big(cin, cout);
+    int ti, tj;
+    wgrad_tile(cin, cout, ti, tj);
     WgradParams p;
     p.x = x; p.ld_x = ld_x; p.dy = dy; p.ld_dy = ld_dy; p.nbr = nbr; p.kvol = kvol; p.n_out = n_out;
     p.cin = cin; p.cout = cout;
-    p.nchunks = wgrad_chunks(kvol, n_out, cin, cout, big);
+    p.nchunks = wgrad_chunks(kvol, n_out, cin, cout);
     p.chunk_rows = ep::ceil_div(ep::ceil_div(n_out, p.nchunks), 256) * 256;
     p.nchunks = (int)ep::ceil_div(n_out, p.chunk_rows);
     p.partial = (float *)workspace;
-    const int t = big ? 128 : 64;
-    dim3 grid((unsigned)(p.nchunks * kvol), (unsigned)ep::ceil_div(cin, t), (unsigned)ep::ceil_div(cout, t));
-    if (big)
-        hipLaunchKernelGGL((spconv_wgrad_kernel<2, 2>), grid, dim3(256), 0, st, p);
-    else
-        hipLaunchKernelGGL((spconv_wgrad_kernel<1, 1>), grid, dim3(256), 0, st, p);
+    dim3 grid((unsigned)(p.nchunks * kvol), (unsigned)ep::ceil_div(cin, ti), (unsigned)ep::ceil_div(cout, tj));
+#define EP_WGRAD(NI, NJ, WI, WJ, WR) hipLaunchKernelGGL((spconv_wgrad_kernel<NI, NJ, WI, WJ, WR>), grid, dim3(256), 0, st, p)
+    if (ti == 32 && tj == 32) EP_WGRAD(1, 1, 1, 1, 4);
+    else if (ti == 64 && tj == 32) EP_WGRAD(1, 1, 2, 1, 2);
+    else if (ti == 32 && tj == 64) EP_WGRAD(1, 1, 1, 2, 2);
+    else if (ti == 64 && tj == 64) EP_WGRAD(1, 1, 2, 2, 1);
+    else if (ti == 32 && tj == 128) EP_WGRAD(1, 2, 1, 2, 2);
+    else if (ti == 64 && tj == 128) EP_WGRAD(1, 2, 2, 2, 1);
+    else EP_WGRAD(2, 2, 2, 2, 1);
+#undef EP_WGRAD
     EP_LAUNCH_CHECK();
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ep::ceil_div(elems, 256)), dim3(256), 0, st, p.partial,
                        p.nchunks, elems, dweight);

@@ -415,9 +415,15 @@ class Linear4xTrans(nn.Module):
             nn.init.zeros_(lin.bias)
 
     def forward(self, x):
-        h = _ln_rows(self.norm1, self.linear1(x), post_relu=True)
-        h = _ln_rows(self.norm2, self.linear2(h), post_relu=True)
-        y = self.linear3(h)
+        if recording() and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32:
+            # training: the three per-voxel GEMMs and their weight gradients ([C, N] x [N, C'] with N > 100k rows, which
+            # rocBLAS runs on 32 x 32 tiles) on the HIP gather-GEMM / wgrad kernels
+            lin = lambda layer, t: AG.sparse_conv(t, layer.weight.t(), None, layer.bias)
+        else:
+            lin = lambda layer, t: layer(t)
+        h = _ln_rows(self.norm1, lin(self.linear1, x), post_relu=True)
+        h = _ln_rows(self.norm2, lin(self.linear2, h), post_relu=True)
+        y = lin(self.linear3, h)
         return y + h if self.use_residual else y
 
 
@@ -596,8 +602,8 @@ class _PointMLP(nn.Sequential):
         # the Linear's bias cancels in the train-mode BatchNorm that follows (it shifts the batch mean by the same
         # amount), so the bias-free convolution with the statistics epilogue gives the same result in one pass less
         lin = self[0]
-        if recording():
-            return self[1].run(F.linear(feats, lin.weight, lin.bias), relu=True)
+        if recording():   # (per-point GEMM on the HIP kernel: rocBLAS picks 32x32 tiles for these [N, <100] x [<100, <100] shapes)
+            return self[1].run(AG.sparse_conv(feats, lin.weight.t(), None, lin.bias), relu=True)
         y, partial = SP.conv_stats(feats, _linear_wt(lin), None)
         return self[1].run_partials(y, partial, relu=True, out=y)
 
@@ -706,7 +712,7 @@ class SConv3d(nn.Module):
         y = SparseTensor(self.net.run(x.F, x.vset.kernel_map(3)), x.vset)
         lin = self.point_transforms[0]
         if recording():
-            skip = F.linear(z.F, lin.weight, lin.bias)
+            skip = AG.sparse_conv(z.F, lin.weight.t(), None, lin.bias)
         else:
             skip = SP.sparse_conv(z.F, _linear_wt(lin), None, lin.bias)
         return voxel_to_point(y, z, out=skip, accumulate=True)

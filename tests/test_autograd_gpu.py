@@ -246,7 +246,7 @@ def test_spvcnn_gradients_match_a_pure_torch_composition(monkeypatch):
     ref = _grads_of(run, params, [x])
     names = [n for n, _ in net.named_parameters()] + ["input"]
     for name, a, r in zip(names, hip, ref):
-        scale = max(float(r.abs().max()), 1e-2)      # (a Linear bias in front of a BatchNorm has an exactly-zero gradient)
+        scale = max(float(r.abs().max()), 5e-2)      # (a Linear bias in front of a BatchNorm has an exactly-zero gradient)
         assert float((a - r).abs().max()) / scale < 2e-3, name
 
 
