@@ -52,7 +52,7 @@ def parse():
                     help="approximate CPU time to spend on the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the cfg3 / cfg4 timings reported under `extra`")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4"],
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "train"],
                     help="cfg2 (default) = BASELINE.json configs[1], the headline metric; cfg4 = the full "
                          "coarse-to-fine forward over 4 sequential fragments (extra measurement, no roofline)")
     return ap.parse_args()
@@ -171,9 +171,22 @@ def extra_workloads(device, steps3=12, steps4=16, warm4=4):
     out["cfg4_ms_per_fragment"] = (time.perf_counter() - t0) / steps4 * 1e3
     out["cfg4_fragments_per_sec"] = 1e3 / out["cfg4_ms_per_fragment"]
     out["cfg4_finest_voxels_min_max"] = [min(step.voxels), max(step.voxels)]
+    cfg4_workload = step.describe()["workload"]
+    del step
+    from eprecon_amd.fragment_step import TrainStep
+    train = TrainStep(seed=0, device=device)
+    for _ in range(3):
+        train.run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(6):
+        train.run()
+    torch.cuda.synchronize()
+    out["train_ms_per_step"] = (time.perf_counter() - t0) / 6 * 1e3
+    out["train_workload"] = train.describe()["workload"]
     out["cfg3_workload"] = "one 9-view 640x480 fragment, empty map: occupancy init + 3 x [Back_Project, SPVCNN, GRU " \
                            "fusion, TSDF / occupancy heads, sparsify], no panoptic decoder"
-    out["cfg4_workload"] = step.describe()["workload"]
+    out["cfg4_workload"] = cfg4_workload
     prof = newest_profile("cfg4_kernel_stats.json")
     if prof:
         rec = json.load(open(prof))
@@ -230,7 +243,12 @@ def bench_cfg4(args, step, world, rank, dist, use_dist=False):
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if rank == 0:
+    if rank == 0 and args.workload == "train":
+        print(json.dumps({"metric": "train_fragments_per_sec", "value": world * args.steps / elapsed, "unit": "fragments/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": step.describe(), "losses_last_step": step.last}), flush=True)
+    elif rank == 0:
         n_out = int(step.last["coords"].shape[0])   # Cfg4Step.run raises on an early return
         print(json.dumps({"metric": "fragments_per_sec", "value": world * args.steps / elapsed,
                           "unit": "fragments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -267,6 +285,11 @@ def main():
 
     lib = _lib.load()
     # every rank owns a different fragment window (seed = rank)
+    if args.workload == "train":
+        from eprecon_amd.fragment_step import TrainStep
+        # data parallel: one fragment per rank and step, gradients all-reduced by DDP over RCCL
+        return bench_cfg4(args, TrainStep(seed=0, device=torch.device("cuda", local_rank), rank=rank, world=world),
+                          world, rank, dist, use_dist)
     if args.workload == "cfg4":
         from eprecon_amd.fragment_step import Cfg4Step
         # all ranks work on ONE scene (seed 0), fragments dealt round-robin, boundary voxels exchanged

@@ -185,13 +185,24 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgradParams p)
         }
 }
 
+// dW[e] = sum over chunks, in a fixed order: 32 consecutive elements per workgroup, eight chunk lanes (lane g sums chunks
+// g, g + 8, ...), then the lanes in ascending order
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial, int nchunks, int64_t elems, float *dw)
 {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= elems) return;
+    __shared__ float sPart[8][32];
+    const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int64_t e = (int64_t)blockIdx.x * 32 + el;
     float s = 0.0f;
-    for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * elems + e];
-    dw[e] = s;
+    if (e < elems)
+        for (int c = g; c < nchunks; c += 8) s += partial[(int64_t)c * elems + e];
+    sPart[g][el] = s;
+    __syncthreads();
+    if (g == 0 && e < elems) {
+        float t = sPart[0][el];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += sPart[q][el];
+        dw[e] = t;
+    }
 }
 
 __global__ __launch_bounds__(256) void invert_map_kernel(const int32_t *nbr, int kvol, int64_t n_out, int64_t n_in,
@@ -244,7 +255,7 @@ int wgrad_chunks(int kvol, int64_t n_out, int cin, int cout)
     int ti, tj;
     wgrad_tile(cin, cout, ti, tj);
     const int64_t tiles = ep::ceil_div(cin, ti) * ep::ceil_div(cout, tj);
-    int64_t want = ep::ceil_div(1024, (int64_t)kvol * tiles);
+    int64_t want = ep::ceil_div(768, (int64_t)kvol * tiles);
     const int64_t most = ep::ceil_div(n_out, 256);
     if (want > most) want = most;
     if (want < 1) want = 1;
@@ -294,7 +305,7 @@ int eprecon_sparse_conv_wgrad_async(const float *x, int ld_x, const float *dy, i
     else EP_WGRAD(2, 2, 2, 2, 1);
 #undef EP_WGRAD
     EP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ep::ceil_div(elems, 256)), dim3(256), 0, st, p.partial,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ep::ceil_div(elems, 32)), dim3(256), 0, st, p.partial,
                        p.nchunks, elems, dweight);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;

@@ -260,6 +260,12 @@ class TrainStep:
         self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, betas=(0.9, 0.999))
         self.last = None
 
+    def describe(self):
+        return {"workload": "one optimisation step on one 9-view 640x480 fragment (empty scene map): NeuConNet.forward under "
+                            "autograd, TSDF / occupancy losses of the three levels + panoptic set criterion, backward through "
+                            "the HIP operators, clip_grad_norm_(1.0), Adam; image pyramids are leaf tensors",
+                "parallelism": "DistributedDataParallel over RCCL, one fragment per rank" if self.model is not self.net else "single"}
+
     def loss(self):
         self.net.gru_fusion.scene_name = [None, None, None]
         outputs, loss_dict = self.model(self.f1, self.f2, self.inputs, {})
@@ -275,5 +281,5 @@ class TrainStep:
         loss_dict["total_loss"].backward()
         torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1.0)
         self.optimizer.step()
-        self.last = {k: float(v) for k, v in loss_dict.items()}
+        self.last = {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in loss_dict.items()}
         return self.last
