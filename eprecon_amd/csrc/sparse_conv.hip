@@ -47,6 +47,7 @@ struct ConvParams {
     const float *bias;   // [Cout] or nullptr
     float *out;          // [n_out, ld_out]
     int n_out, K, Cin, Cout, ld_x, ld_out;
+    int64_t x_bytes;     // bytes addressable from x (buffer-load gathers: rows past it read as zeros)
     int relu;            // fused ReLU epilogue
     int accumulate;      // out += result instead of out = result
     const float *res;    // optional [n_out, ld_res]: added after the ReLU (x + ReLU(conv(x)) blocks)
@@ -523,6 +524,61 @@ __device__ __forceinline__ void fix_rows(const ConvParams &p, int j, int half, A
             if (!(j >= 0 && cbase + ch * 8 + 4 * half + s < p.Cin)) a.v[ch][s] = 0.0f;
 }
 
+// Gather through a buffer resource over x: the byte offset of a row is ONE 24-bit multiply, the chunk offsets are
+// instruction immediates and the slab offset is the scalar offset, and a missing neighbour (j < 0) is sent past the end
+// of the buffer, where the hardware returns zeros — no 64-bit address arithmetic and no per-value select afterwards.
+// (PMC, 27-offset 32 -> 32 layer: 11 VALU instructions per MFMA with pointer gathers + fix_rows.)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int NCH>
+__device__ __forceinline__ void gather_rows_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned row_bytes, unsigned oob, int j, int half,
+                                                ARows &a, int cbase_bytes)
+{
+    const unsigned off = (j >= 0 ? __umul24((unsigned)j, row_bytes) : oob) + 16u * half;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32u * ch, cbase_bytes, 0);
+        a.v[ch][0] = __uint_as_float(v.x); a.v[ch][1] = __uint_as_float(v.y);
+        a.v[ch][2] = __uint_as_float(v.z); a.v[ch][3] = __uint_as_float(v.w);
+    }
+}
+
+// Weights of `kn` offsets for the resident kernel, laid out for 16-byte B-operand reads: a lane (half, column) uses the
+// four consecutive input channels ch*8 + 4*half + {0..3} of its column for four consecutive MFMAs, so they sit together:
+//   sW[((((kk * NCH + ch) * 2 + half) * NT + t) * 32 + col) * 4 + s]  =  W[k0 + kk][cbase + ch*8 + 4*half + s][col0 + 32 t + col]
+// (zero where the channel or the column does not exist).  One ds_read_b128 per (chunk, column block) instead of four
+// ds_read_b32; branch-free clamped global loads, 16 bytes along the columns when the pitch allows it.
+template <int NT, int NCH>
+__device__ __forceinline__ void stage_weights_quads(float *dst, const ConvParams &p, int k0, int kn, int cbase, int col0, int tid)
+{
+    constexpr int TN = 32 * NT, cin_pad = NCH * 8;
+    const int ncols = p.Cout - col0;
+    const bool v4 = (p.Cout & 3) == 0 && (col0 & 3) == 0 && (reinterpret_cast<uintptr_t>(p.w) & 15) == 0;
+    if (v4) {
+        constexpr int Q = TN / 4;
+        for (int e = tid; e < kn * cin_pad * Q; e += 256) {
+            const int q = e % Q, rc = e / Q;
+            const int c = rc % cin_pad, kk = rc / cin_pad;
+            const bool ok = (cbase + c < p.Cin) && (4 * q < ncols);
+            const size_t row = (size_t)(k0 + kk) * p.Cin + min(cbase + c, p.Cin - 1);
+            const float4 v = *reinterpret_cast<const float4 *>(p.w + row * p.Cout + col0 + min(4 * q, max(ncols - 4, 0)));
+            const int ch = c >> 3, half = (c >> 2) & 1, sidx = c & 3;
+            const int t = (4 * q) >> 5, col = (4 * q) & 31;
+            float *d = dst + ((((size_t)(kk * NCH + ch) * 2 + half) * NT + t) * 32 + col) * 4 + sidx;
+            d[0] = ok ? v.x : 0.0f; d[4] = ok ? v.y : 0.0f; d[8] = ok ? v.z : 0.0f; d[12] = ok ? v.w : 0.0f;
+        }
+        return;
+    }
+    for (int e = tid; e < kn * cin_pad * TN; e += 256) {
+        const int cg = e % TN, rc = e / TN;
+        const int c = rc % cin_pad, kk = rc / cin_pad;
+        const bool ok = (cbase + c < p.Cin) && (cg < ncols);
+        const size_t row = (size_t)(k0 + kk) * p.Cin + min(cbase + c, p.Cin - 1);
+        const float v = p.w[row * p.Cout + col0 + min(cg, max(ncols - 1, 0))];
+        const int ch = c >> 3, half = (c >> 2) & 1, sidx = c & 3;
+        dst[((((size_t)(kk * NCH + ch) * 2 + half) * NT + (cg >> 5)) * 32 + (cg & 31)) * 4 + sidx] = ok ? v : 0.0f;
+    }
+}
+
 // gather batch size: KB * NCH <= 16 float4 per lane in flight (<= 64 VGPRs of A operands)
 constexpr int resident_kb(int nch) { return nch <= 1 ? 9 : nch == 2 ? 8 : nch == 3 ? 5 : nch == 4 ? 4 : nch == 5 ? 3 : 2; }
 
@@ -570,6 +626,9 @@ __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int 
     const int nb = (p.K + KB - 1) / KB;  // offset batches per slab
     const int total = nb * nslab;
     const int *nbr_row = sNbr + wave * kRowsPerWave + r32;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, PIPE ? (int)p.x_bytes : 0, 0x00020000);
+    const unsigned row_bytes = (unsigned)p.ld_x * 4u, oob = (unsigned)p.x_bytes;
     auto issue = [&](int b, ARows(&a)[KB], int(&jj)[KB]) {
         const int sl = min(b / nb, nslab - 1);
         const int kb = (b - (b / nb) * nb) * KB;
@@ -578,7 +637,7 @@ __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int 
         for (int u = 0; u < KB; ++u) jj[u] = (in && kb + u < p.K) ? nbr_row[min(kb + u, p.K - 1) * kRowsPerBlock] : -1;
 #pragma unroll
         for (int u = 0; u < KB; ++u) {
-            if (PIPE) gather_rows_nb<NCH>(p, jj[u], half, a[u], sl * cin_pad);
+            if (PIPE) gather_rows_buf<NCH>(rsrc, row_bytes, oob, jj[u], half, a[u], sl * cin_pad * 4);
             else gather_rows<VEC4, NCH>(p, jj[u], half, a[u], sl * cin_pad);
         }
     };
@@ -586,7 +645,7 @@ __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int 
         const int sl = b / nb;
         const int kb = (b - sl * nb) * KB;
         const int cbase = sl * cin_pad;
-        if (PIPE) {
+        if (PIPE && cbase + cin_pad > p.Cin) {  // ragged channel count: what the last chunk read past C_in is not data
 #pragma unroll
             for (int u = 0; u < KB; ++u) fix_rows<NCH>(p, jj[u], half, a[u], cbase);
         }
@@ -595,14 +654,7 @@ __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int 
         if (kb == k0) {
             const int kn = min(kgroup, p.K - k0);
             __syncthreads();  // every wave is done with the previous group's weights
-            if (nslab == 1 && cin_pad == p.Cin) {
-                // rows of consecutive offsets are contiguous in W: one flat [kn * Cin][Cout] block
-                stage_weights<TN>(sW, wbase, k0 * p.Cin, (k0 + kn) * p.Cin, p.Cout, p.Cout - col0, kn * cin_pad, tid);
-            } else {
-                for (int kk = 0; kk < kn; ++kk)
-                    stage_weights<TN>(sW + kk * per_k, wbase, (k0 + kk) * p.Cin + cbase,
-                                      (k0 + kk) * p.Cin + min(cbase + cin_pad, p.Cin), p.Cout, p.Cout - col0, cin_pad, tid);
-            }
+            stage_weights_quads<NT, NCH>(sW, p, k0, kn, cbase, col0, tid);
             __syncthreads();
         }
         // ---- MFMAs of the batch ----
@@ -611,7 +663,7 @@ __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int 
             if (kb + u >= p.K) break;
             const bool live = __ballot(jj[u] >= 0) != 0ull;
             if (!live) continue;
-            const float *wk = sW + (kb + u - k0) * per_k + r32 + 4 * half * TN;
+            const float *wk = sW + (kb + u - k0) * per_k + (half * NT * 32 + r32) * 4;
             if (p.in_scale) {
                 // BatchNorm (+ReLU) of the producer applied to the gathered values; padding stays 0
                 const bool ok = jj[u] >= 0;
@@ -628,18 +680,30 @@ __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int 
                     }
                 }
             }
+            // B operands: one 16-byte LDS read per (chunk, column block) gives the four channel steps of this lane.  The
+            // reads of the first two chunks are issued ahead of the first MFMAs and the rest between MFMA groups
+            // (sched_group_barrier: left alone the scheduler sinks each read to just in front of its MFMA pair and
+            // every pair then sits behind an LDS round trip).
+            float4 bq[NCH][NT];
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    bq[ch][t] = *reinterpret_cast<const float4 *>(wk + (ch * 2 * NT + t) * 128);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[ch][0], bq[ch][t].x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[ch][1], bq[ch][t].y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[ch][2], bq[ch][t].z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[ch][3], bq[ch][t].w, acc[t], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_group_barrier(0x100, NCH >= 2 ? 2 * NT : NT, 0);   // DS reads of the first two chunks
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
-                float b4[4][NT];
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) b4[s][t] = wk[(ch * 8 + s) * TN + t * 32];
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[ch][s], b4[s][t], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);               // MFMAs of chunk ch
+                if (ch + 2 < NCH) __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);   // reads of chunk ch + 2
             }
         }
     };
@@ -671,10 +735,14 @@ int launch_resident_nch(const ConvParams &p, bool vec4, hipStream_t st, int nsla
 {
     // weights of `kgroup` offsets resident at a time (a multiple of the gather batch, ~24 KB -> 4 workgroups per CU)
     static const bool pipe_env = !(getenv("EPRECON_CONV_PIPE") && getenv("EPRECON_CONV_PIPE")[0] == '0');  // default on
-    const bool pipe = pipe_env && vec4;   // vec4: 16-byte aligned rows whose pitch covers Cin rounded up to 4
+    // vec4: 16-byte aligned rows whose pitch covers Cin rounded up to 4; the buffer-load gathers address x with
+    // 32-bit byte offsets formed by a 24-bit multiply
+    const bool pipe = pipe_env && vec4 && p.x_bytes > 0 && p.x_bytes < 0x7fffffffll && (int64_t)p.ld_x * 4 < (1 << 24) &&
+                      p.x_bytes / ((int64_t)p.ld_x * 4) < (1 << 24);
     const int KB = pipe ? (resident_kb(NCH) + 1) / 2 : resident_kb(NCH);  // the kernel's batch size: kgroup % KB == 0
     const size_t per_k = (size_t)NCH * 8 * 32 * NT * sizeof(float);
-    int kgroup = (int)max((size_t)KB, (size_t)(24 * 1024) / per_k / KB * KB);
+    static const int group_kb = getenv("EPRECON_CONV_GROUP_KB") ? atoi(getenv("EPRECON_CONV_GROUP_KB")) : 24;
+    int kgroup = (int)max((size_t)KB, (size_t)(group_kb * 1024) / per_k / KB * KB);
     kgroup = min(kgroup, (p.K + KB - 1) / KB * KB);
     const size_t lds = max((size_t)kgroup * per_k + (size_t)p.K * kRowsPerBlock * sizeof(int) +
                                (size_t)2 * nslab * NCH * 8 * sizeof(float),
@@ -1176,6 +1244,7 @@ static int conv_check_and_run(ConvParams &p, int64_t n_in, int64_t n_out, void *
     if (p.Cout > 4096 || n_out > 0x7fffffff) return EPRECON_ERR_UNSUPPORTED;
     if (n_out == 0) return EPRECON_OK;
     p.n_out = (int)n_out;
+    p.x_bytes = n_in > 0 ? ((n_in - 1) * (int64_t)p.ld_x + ((p.Cin + 3) & ~3)) * 4 : 0;
     return conv_dispatch(p, n_in, (hipStream_t)stream);
 }
 

@@ -14,6 +14,8 @@ signature and early-return conventions:
      post-processing                                                              (:516-587)
 Every sparse / gather / scatter step runs in libeprecon_hip.so; the dense heads are PyTorch-ROCm.
 """
+import sys
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -35,7 +37,7 @@ from .torchsparse_utils import aligned_camera_coords
 
 
 def _warn(msg):
-    print(f"[eprecon_amd] warning: {msg}")
+    print(f"[eprecon_amd] warning: {msg}", file=sys.stderr)
 
 
 class NeuConNet(nn.Module):
