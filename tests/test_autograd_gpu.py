@@ -277,3 +277,28 @@ def test_convgru_recording_matches_oracle_and_trains():
     out.square().mean().backward()
     for t in [ht, xt] + list(gru.parameters()):
         assert t.grad is not None and torch.isfinite(t.grad).all() and float(t.grad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("n,cin,cout", [(94000, 32, 32), (140000, 48, 24)])
+def test_conv_adjoint_identities_at_full_size(n, cin, cout):
+    """size-independent property at BASELINE's list sizes: the backward operators are the adjoints of the forward one,
+    <conv(x; W), dy> = <x, dgrad(dy; W)> = <W, wgrad(x, dy)>  (fp32 sums of ~10^7 products: 2e-4 relative)"""
+    from eprecon_amd import autograd as AG
+    from eprecon_amd import synthetic as S
+    from eprecon_amd.sparse import VoxelSet
+    rng = np.random.default_rng(n)
+    coords = S.dense_coords((96, 96, 96), 2 if n < 110592 else 1)
+    keep = np.sort(rng.choice(len(coords), n, replace=False))
+    vs = VoxelSet(dev(coords[keep]), 2 if n < 110592 else 1)
+    nbr = vs.kernel_map(3)
+    g = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.randn(n, cin, device="cuda", generator=g).requires_grad_()
+    w = (torch.randn(27, cin, cout, device="cuda", generator=g) / np.sqrt(27 * cin)).requires_grad_()
+    dy = torch.randn(n, cout, device="cuda", generator=g)
+    y = AG.sparse_conv(x, w, nbr)
+    y.backward(dy)
+    lhs = float((y.detach().double() * dy.double()).sum())
+    via_x = float((x.detach().double() * x.grad.double()).sum())
+    via_w = float((w.detach().double() * w.grad.double()).sum())
+    scale = float((y.detach().double() * dy.double()).abs().sum())
+    assert abs(lhs - via_x) < 2e-4 * scale and abs(lhs - via_w) < 2e-4 * scale, (lhs, via_x, via_w, scale)
