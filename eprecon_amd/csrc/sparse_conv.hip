@@ -951,22 +951,27 @@ int launch_conv2d_tile(const ConvParams &p, hipStream_t st)
 // buffer (no workgroup barrier in the loop); the four partial accumulators are summed in fixed order
 // through LDS at the end.  4x the workgroups, 1/4 of the chain.
 // ---------------------------------------------------------------------------------------------
-template <bool VEC4>
+// RT = 2: the workgroup owns 64 rows (two 32-row tiles per wave, two accumulators) and every staged weight slab feeds
+// both — half the slab round trips per row and half the weight traffic; taken when the list is still long enough to
+// fill the chip with 64-row workgroups.
+template <bool VEC4, int RT>
 __global__ __launch_bounds__(256) void spconv_splitk_kernel(ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TN = 32;
+    constexpr int ROWS = 32 * RT;
     float *sW = reinterpret_cast<float *>(smem);                  // [4 waves][32][32] wave-private weight slabs
-    float *sRed = sW;                                             // overlay after the loop: [3][16][64] partial accumulators
-    int *sNbr = reinterpret_cast<int *>(sW + kWaves * 32 * TN);   // [K][32]
-    int *sActive = sNbr + p.K * 32;                               // [K]
+    float *sRed = sW;                                             // overlay after the loop: [RT][3][16][64] partial accumulators
+    constexpr int w_floats = RT * 3 * 16 * 64 > kWaves * 32 * TN ? RT * 3 * 16 * 64 : kWaves * 32 * TN;
+    int *sNbr = reinterpret_cast<int *>(sW + w_floats);           // [K][ROWS]
+    int *sActive = sNbr + p.K * ROWS;                             // [K]
     const int cinA = (p.Cin + 3) & ~3;
     float *sAff = reinterpret_cast<float *>(sActive + ((p.K + 3) & ~3));  // [2][cinA]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, half = lane >> 5;
-    const int row0 = blockIdx.x * 32;
+    const int row0 = blockIdx.x * ROWS;
     const int col0 = blockIdx.y * TN;
 
     for (int k = tid; k < p.K; k += 256) sActive[k] = 0;
@@ -976,8 +981,8 @@ __global__ __launch_bounds__(256) void spconv_splitk_kernel(ConvParams p)
             sAff[cinA + c] = c < p.Cin ? p.in_shift[c] : 0.0f;
         }
     __syncthreads();
-    for (int e = tid; e < p.K * 32; e += 256) {
-        const int k = e >> 5, r = e & 31;
+    for (int e = tid; e < p.K * ROWS; e += 256) {
+        const int k = e / ROWS, r = e - k * ROWS;
         const int row = row0 + r;
         int j = -1;
         if (row < p.n_out) j = p.nbr ? p.nbr[(size_t)k * p.n_out + row] : row;
@@ -986,17 +991,24 @@ __global__ __launch_bounds__(256) void spconv_splitk_kernel(ConvParams p)
     }
     __syncthreads();
 
-    f32x16 acc[1];
+    f32x16 acc[RT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
     const int nslab = (p.Cin + 31) / 32;
     float *myW = sW + wave * 32 * TN;
     int stage = 0;  // counts (live offset, slab) pairs; this wave takes those with stage % 4 == wave
     for (int k = 0; k < p.K; ++k) {
         if (!sActive[k]) continue;  // block-uniform
-        const int j = sNbr[k * 32 + r32];
-        const float *xrow = p.x + (size_t)(j >= 0 ? j : 0) * p.ld_x;
+        int j[RT];
+        const float *xrow[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            j[t] = sNbr[k * ROWS + t * 32 + r32];
+            xrow[t] = p.x + (size_t)(j[t] >= 0 ? j[t] : 0) * p.ld_x;
+        }
         const float *wk = p.w + (size_t)k * p.Cin * p.Cout + col0;
         for (int sl = 0; sl < nslab; ++sl, ++stage) {
             if ((stage & 3) != wave) continue;  // wave-uniform
@@ -1027,44 +1039,51 @@ __global__ __launch_bounds__(256) void spconv_splitk_kernel(ConvParams p)
                     }
                 }
             }
-            // ---- this lane's A values: 4 chunks of 8 channels, 4 floats each ----
-            float a[4][4];
+            // ---- this lane's A values: per row tile 4 chunks of 8 channels, 4 floats each ----
+            float a[RT][4][4];
 #pragma unroll
-            for (int ch = 0; ch < 4; ++ch) {
-                const int c = c0 + ch * 8 + 4 * half;
-                if (VEC4) {
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (j >= 0 && c < p.Cin) v = *reinterpret_cast<const float4 *>(xrow + c);
-                    if (p.Cin & 3) {
-                        if (c + 1 >= p.Cin) v.y = 0.0f;
-                        if (c + 2 >= p.Cin) v.z = 0.0f;
-                        if (c + 3 >= p.Cin) v.w = 0.0f;
-                    }
-                    a[ch][0] = v.x; a[ch][1] = v.y; a[ch][2] = v.z; a[ch][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) a[ch][q] = (j >= 0 && c + q < p.Cin) ? xrow[c + q] : 0.0f;
-                }
-            }
-            if (p.in_scale) {
+            for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int ch = 0; ch < 4; ++ch) {
                     const int c = c0 + ch * 8 + 4 * half;
+                    if (VEC4) {
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (j[t] >= 0 && c < p.Cin) v = *reinterpret_cast<const float4 *>(xrow[t] + c);
+                        if (p.Cin & 3) {
+                            if (c + 1 >= p.Cin) v.y = 0.0f;
+                            if (c + 2 >= p.Cin) v.z = 0.0f;
+                            if (c + 3 >= p.Cin) v.w = 0.0f;
+                        }
+                        a[t][ch][0] = v.x; a[t][ch][1] = v.y; a[t][ch][2] = v.z; a[t][ch][3] = v.w;
+                    } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const bool ok = j >= 0 && c + q < p.Cin;
-                        float v = fmaf(a[ch][q], sAff[min(c + q, cinA - 1)], sAff[cinA + min(c + q, cinA - 1)]);
-                        if (p.in_relu) v = fmaxf(v, 0.0f);
-                        a[ch][q] = ok ? v : 0.0f;
+                        for (int q = 0; q < 4; ++q) a[t][ch][q] = (j[t] >= 0 && c + q < p.Cin) ? xrow[t][c + q] : 0.0f;
                     }
                 }
+            if (p.in_scale) {
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) {
+                        const int c = c0 + ch * 8 + 4 * half;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const bool ok = j[t] >= 0 && c + q < p.Cin;
+                            float v = fmaf(a[t][ch][q], sAff[min(c + q, cinA - 1)], sAff[cinA + min(c + q, cinA - 1)]);
+                            if (p.in_relu) v = fmaxf(v, 0.0f);
+                            a[t][ch][q] = ok ? v : 0.0f;
+                        }
+                    }
             }
             __builtin_amdgcn_wave_barrier();  // the slab stores above precede the loads below (same wave, LDS is in order)
             const int nch = min(4, (p.Cin - c0 + 7) / 8);
             for (int ch = 0; ch < nch; ++ch) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ch][q], myW[(ch * 8 + 4 * half + q) * TN + r32], acc[0], 0, 0, 0);
+                for (int q = 0; q < 4; ++q) {
+                    const float bw = myW[(ch * 8 + 4 * half + q) * TN + r32];
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][ch][q], bw, acc[t], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_wave_barrier();  // the next stage overwrites myW
         }
@@ -1073,30 +1092,49 @@ __global__ __launch_bounds__(256) void spconv_splitk_kernel(ConvParams p)
     __syncthreads();
     if (wave > 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sRed[((wave - 1) * 16 + r) * 64 + lane] = acc[0][r];
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) {
+                sRed[((t * 3 + wave - 1) * 16 + r) * 64 + lane] = acc[t][r];
+                acc[t][r] = 0.0f;
+            }
     }
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
-        for (int w = 0; w < 3; ++w)
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][r] += sRed[(w * 16 + r) * 64 + lane];
+            for (int w = 0; w < 3; ++w)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += sRed[((t * 3 + w) * 16 + r) * 64 + lane];
     }
     __syncthreads();  // sRed is read; the epilogue reuses the region for the BatchNorm summaries
     // waves 1..3 hold no rows: an empty row map keeps them out of the stores and the statistics
-    const LinearRows rm{row0, wave == 0 ? p.n_out : 0};
-    conv_epilogue<1>(p, acc, rm, col0, r32, half, wave, sW, (int)blockIdx.x);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        if (t > 0 && row0 + 32 * t >= p.n_out) break;  // (block-uniform) no second tile in the last workgroup
+        f32x16 one[1] = {acc[t]};
+        const LinearRows rm{row0 + 32 * t, wave == 0 ? p.n_out : 0};
+        conv_epilogue<1>(p, one, rm, col0, r32, half, wave, sW, (int)blockIdx.x * RT + t);
+        if (t + 1 < RT) __syncthreads();  // the next tile's summaries reuse the scratch
+    }
 }
 
 template <bool VEC4>
 int launch_splitk_v(const ConvParams &p, hipStream_t st)
 {
-    const dim3 grid((unsigned)ceil_div(p.n_out, 32), (unsigned)ceil_div(p.Cout, 32));
-    const size_t lds = (size_t)kWaves * 32 * 32 * sizeof(float) + (size_t)p.K * 32 * sizeof(int) +
+    static const bool rt2_on = !(getenv("EPRECON_CONV_SPLITK_RT2") && getenv("EPRECON_CONV_SPLITK_RT2")[0] == '0');
+    const int colb = (int)ceil_div(p.Cout, 32);
+    const bool rt2 = rt2_on && ceil_div(p.n_out, 64) * colb >= 320;
+    const int rows = rt2 ? 64 : 32;
+    const size_t w_floats = max((size_t)kWaves * 32 * 32, (size_t)(rt2 ? 2 : 1) * 3 * 16 * 64);
+    const size_t lds = w_floats * sizeof(float) + (size_t)p.K * rows * sizeof(int) +
                        (size_t)((p.K + 3) & ~3) * sizeof(int) + (size_t)2 * ((p.Cin + 3) & ~3) * sizeof(float) + 16;
-    hipLaunchKernelGGL((spconv_splitk_kernel<VEC4>), grid, dim3(256), lds, st, p);
+    const dim3 grid((unsigned)ceil_div(p.n_out, rows), (unsigned)colb);
+    if (rt2)
+        hipLaunchKernelGGL((spconv_splitk_kernel<VEC4, 2>), grid, dim3(256), lds, st, p);
+    else
+        hipLaunchKernelGGL((spconv_splitk_kernel<VEC4, 1>), grid, dim3(256), lds, st, p);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }
