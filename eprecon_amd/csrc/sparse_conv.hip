@@ -1125,7 +1125,8 @@ int launch_splitk_v(const ConvParams &p, hipStream_t st)
 {
     static const bool rt2_on = !(getenv("EPRECON_CONV_SPLITK_RT2") && getenv("EPRECON_CONV_SPLITK_RT2")[0] == '0');
     const int colb = (int)ceil_div(p.Cout, 32);
-    const bool rt2 = rt2_on && ceil_div(p.n_out, 64) * colb >= 320;
+    // (3D kernel maps only: the K = 9 layers of the 10,800-pixel maps measured slower with 64-row workgroups, 52 vs 47 us)
+    const bool rt2 = rt2_on && p.K >= 27 && ceil_div(p.n_out, 64) * colb >= 320;
     const int rows = rt2 ? 64 : 32;
     const size_t w_floats = max((size_t)kWaves * 32 * 32, (size_t)(rt2 ? 2 : 1) * 3 * 16 * 64);
     const size_t lds = w_floats * sizeof(float) + (size_t)p.K * rows * sizeof(int) +
