@@ -160,7 +160,6 @@ class _BackProjectGrad(torch.autograd.Function):
         ctx.save_for_backward(feats)
         ctx.args = (coords_valid, origin, float(voxel_size), krcam, mode)
         ctx.has_mean = mean is not None
-        ctx.mark_non_differentiable()
         return (out.view_as(out), mean.view_as(mean)) if mean is not None else (out.view_as(out), None)
 
     @staticmethod

@@ -131,7 +131,7 @@ class SetCriterion(nn.Module):
     def loss_masks(self, outputs, targets, indices, num_masks):
         src = outputs["pred_masks"][self._perm(indices, 0)]
         tgt = targets[0]["masks"].unsqueeze(0).to(src)[self._perm(indices, 1)]
-        if len(src) == 0 or len(tgt) == 0:
+        if len(src) == 0 or len(tgt) == 0:   # ("loss_masks" is the reference's key on this branch, models/criterion.py:160-164)
             return {"loss_masks": src.sum() * 0.0, "loss_dice": src.sum() * 0.0}
         return {"loss_mask": sigmoid_ce_loss(src, tgt, num_masks), "loss_dice": dice_loss(src, tgt, num_masks)}
 

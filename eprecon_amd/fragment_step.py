@@ -156,7 +156,10 @@ class Cfg4Step:
             # with `world` ranks the fragments of the scene are dealt round-robin: rank r owns
             # fragments r, r + world, ... and exchanges boundary voxels with the others every step
             kk = k * world + rank
-            w = S.make_window(seed=seed * 100 + kk, width=width, height=height, advance=0.32 * kk)
+            # the camera arc advances 0.32 m per fragment on one GPU (2/3 overlap); with more ranks the same 0.96 m of
+            # the synthetic room is covered in proportionally smaller steps, so no fragment leaves the geometry
+            advance = min(0.32, 0.96 / max(n_fragments * world - 1, 1))
+            w = S.make_window(seed=seed * 100 + kk, width=width, height=height, advance=advance * kk)
             f1, f2, inp = S.make_model_inputs([w], feat_seed=seed * 100 + kk, scene=f"scene{seed:04d}")
             self.frags.append((S.to_device(f1, self.device), S.to_device(f2, self.device),
                                S.to_device(inp, self.device)))
