@@ -218,3 +218,14 @@ def test_dense_brick_variance_is_bit_identical(case, monkeypatch):
     for k in ("var", "mean", "coords", "count"):
         assert torch.equal(got[k], ref[k]), k
     assert got["n_valid"] == ref["n_valid"]
+
+
+def test_more_than_32_views_is_rejected_loudly():
+    """the visible-view bitmask is 32 bits wide: 33 views must raise, not wrap"""
+    from eprecon_amd import _lib
+    window = S.make_window(seed=4)
+    feats = np.zeros((33, 1, 8, 30, 40), np.float32)
+    kr = np.repeat(window["proj_matrices"][:1, 2][:, None], 33, axis=0)
+    coords = S.dense_coords((96, 96, 96), 4)[:1000]
+    with pytest.raises(_lib.EpreconError):
+        hip_run(coords, window["vol_origin_partial"][None], 0.04, feats, np.ascontiguousarray(kr), 1)
