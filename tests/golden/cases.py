@@ -129,3 +129,15 @@ def loss_case(seed=8, n=5000):
             "mask": rng.random(n) < 0.9, "occ_init": rng.standard_normal(n).astype(np.float32),
             "tsdf_init_target": ((rng.random(n) < 0.4) & (rng.random(n) < 0.8)).astype(np.float32),
             "occ_init_target": (rng.random(n) < 0.5).astype(np.float32)}
+
+
+def target_case(seed=21, n=4000, dim=24, scale=1, batch=2):
+    """voxel coords (b, x, y, z in finest units, multiples of 2**scale) + ground-truth volumes at that scale for the target
+    look-ups of NeuConNet (get_target, get_target_init, get_panoptic_targets)"""
+    rng = np.random.default_rng(seed)
+    coords = np.concatenate([np.sort(rng.integers(0, batch, (n, 1)), axis=0), rng.integers(0, dim, (n, 3)) * 2 ** scale], 1).astype(np.int32)
+    vols = {"tsdf": np.clip(rng.standard_normal((batch, dim, dim, dim)), -1, 1).astype(np.float32),
+            "occ": rng.random((batch, dim, dim, dim)) < 0.4,
+            "semantic": rng.integers(0, 41, (batch, dim, dim, dim)).astype(np.int64),
+            "instance": rng.integers(0, 9, (batch, dim, dim, dim)).astype(np.int64)}
+    return coords, vols

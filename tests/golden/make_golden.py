@@ -528,6 +528,20 @@ def gen_criterion():
     c = {k: torch.from_numpy(v) for k, v in cases.loss_case().items()}
     out["compute_loss"] = np.float64(NeuConNet.compute_loss(c["tsdf"], c["occ"], c["tsdf_target"], c["occ_target"], mask=c["mask"], pos_weight=1.5))
     out["compute_loss_init"] = np.float64(NeuConNet.compute_loss_init(None, c["occ_init"], c["tsdf_init_target"], c["occ_init_target"]))
+    # target look-ups (models/neucon_network.py:117-191) on a bare instance: they read nothing from self
+    coords, vols = cases.target_case()
+    scale, bs = 1, 2
+    lists = lambda v: [None, torch.from_numpy(v), None]
+    tin = {"tsdf_list": lists(vols["tsdf"]), "occ_list": lists(vols["occ"]), "semantic_list": lists(vols["semantic"]),
+           "instance_list": lists(vols["instance"])}
+    bare = NeuConNet.__new__(NeuConNet)
+    ct = torch.from_numpy(coords)
+    t, o = NeuConNet.get_target(bare, ct, tin, scale)
+    ti, oi = NeuConNet.get_target_init(bare, ct, tin, scale)
+    out.update(target_tsdf=t.numpy(), target_occ=o.numpy(), target_init_tsdf=ti.numpy(), target_init_occ=oi.numpy())
+    for b, tgt in enumerate(NeuConNet.get_panoptic_targets(bare, ct, tin, scale, bs)):
+        out[f"panoptic_labels_{b}"] = tgt["labels"].numpy()
+        out[f"panoptic_masks_{b}"] = tgt["masks"].numpy()
     _save("criterion", **out)
 
 
