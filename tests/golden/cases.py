@@ -141,3 +141,28 @@ def target_case(seed=21, n=4000, dim=24, scale=1, batch=2):
             "semantic": rng.integers(0, 41, (batch, dim, dim, dim)).astype(np.int64),
             "instance": rng.integers(0, 9, (batch, dim, dim, dim)).astype(np.int64)}
     return coords, vols
+
+
+def panoptic_loss_case(seed=5, m=2600, n_keep=1800, q=10, dim=24, n_aux=2):
+    """the tail of NeuConNet.forward (models/neucon_network.py:589-622): finest-level voxels of one fragment (m candidates,
+    n_keep of them occupied), their observed-ground-truth flags, decoder outputs over the occupied voxels, label volumes"""
+    rng = np.random.default_rng(seed)
+    flat = np.sort(rng.choice(dim ** 3, m, replace=False))
+    xyz = np.stack(np.unravel_index(flat, (dim, dim, dim)), 1)
+    coords_all = np.concatenate([np.zeros((m, 1), np.int64), xyz], 1).astype(np.int32)
+    occupancy = np.zeros(m, bool)
+    occupancy[np.sort(rng.choice(m, n_keep, replace=False))] = True
+    occ_target = (rng.random((m, 1)) < 0.8)
+    head = lambda: {"pred_logits": rng.standard_normal((1, q, 21)).astype(np.float32),
+                    "pred_masks": (rng.standard_normal((1, q, n_keep)) * 2).astype(np.float32)}
+    outs = head()
+    outs["aux_outputs"] = [head() for _ in range(n_aux)]
+    # a few big instances with evaluated classes so that masks survive the > 100 voxel filter
+    blocks = (xyz[:, 0] // 8) + 3 * (xyz[:, 1] // 12)
+    instance = np.zeros((1, dim, dim, dim), np.int64)
+    semantic = np.zeros((1, dim, dim, dim), np.int64)
+    class_of = np.array([3, 5, 7, 13, 24, 39])
+    instance[0, xyz[:, 0], xyz[:, 1], xyz[:, 2]] = blocks + 1
+    semantic[0, xyz[:, 0], xyz[:, 1], xyz[:, 2]] = class_of[blocks]
+    return {"coords_fine": coords_all[occupancy], "occupancy": occupancy, "occ_target": occ_target, "outs": outs,
+            "semantic": semantic, "instance": instance}

@@ -542,6 +542,22 @@ def gen_criterion():
     for b, tgt in enumerate(NeuConNet.get_panoptic_targets(bare, ct, tin, scale, bs)):
         out[f"panoptic_labels_{b}"] = tgt["labels"].numpy()
         out[f"panoptic_masks_{b}"] = tgt["masks"].numpy()
+    # the panoptic-loss tail of NeuConNet.forward, executed from the reference's own lines
+    pc = cases.panoptic_loss_case()
+    code, span = _ref_lines("models/neucon_network.py", "occ_target_occupancy = occ_target[occupancy].view(-1)",
+                            "loss_dict.update({f'panoptic_loss': panoptic_losses})")
+    weight_dict = {"loss_ce": 0.2, "loss_mask": 0.8, "loss_dice": 0.8}
+    weight_dict.update({f"{k}_{i}": v for i in range(6) for k, v in (("loss_ce", 0.2), ("loss_mask", 0.8), ("loss_dice", 0.8))})
+    torch.nn.Module.__init__(bare)
+    bare.criterion = SetCriterion(20, HungarianMatcher(cost_class=0.2, cost_mask=0.8, cost_dice=0.8), weight_dict, 0.1, ["labels", "masks"])
+    ns = {"torch": torch, "np": np, "self": bare, "bs": 1, "scale": 0, "loss_dict": {}, "panoptic_losses": [], "panoptic_predictions": [],
+          "logger": sys.modules["loguru"].logger, "occ_target": torch.from_numpy(pc["occ_target"]),
+          "occupancy": torch.from_numpy(pc["occupancy"]), "panoptic_coords": [None, None, torch.from_numpy(pc["coords_fine"])],
+          "panoptic_outs": [to_t(pc["outs"])],
+          "inputs": {"rgb_list": True, "semantic_list": [torch.from_numpy(pc["semantic"])], "instance_list": [torch.from_numpy(pc["instance"])]}}
+    exec(code, ns)
+    out["panoptic_loss"] = np.float64(ns["loss_dict"]["panoptic_loss"])
+    out["panoptic_loss_lines"] = np.array(span)
     _save("criterion", **out)
 
 
