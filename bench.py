@@ -36,6 +36,12 @@ DOMINANT_KERNEL = "bp_gather_mlp_kernel<256,MEAN,6,1>"
 L1_PEAK_LINES = 256 * 2.4e9  # vector-L1 line accesses per second: 256 CUs x 1 line per clock x 2.4 GHz
 
 
+# EPRECON_CFG4_PIPELINE=1: the panoptic branch of fragment k runs on its own stream and overlaps fragment k + 1
+# (NeuConNet.panoptic_stream).  Measured neutral on MI355X (22.94 vs 22.98 ms per fragment): the host enqueues launches
+# about as fast as the GPU retires them, so the branch has finished before the next fragment's first launch arrives.
+PIPELINE = os.environ.get("EPRECON_CFG4_PIPELINE", "0") == "1"
+
+
 def newest_profile(name):
     """newest committed profiles/rNN/<name> (the per-round directories sort by round number)"""
     import glob
@@ -151,7 +157,7 @@ def extra_workloads(device, steps3=12, steps4=16, warm4=4):
     NeuConNet.forward per fragment.  Not the headline metric (that is cfg2), reported under `extra`."""
     import torch
     from eprecon_amd.fragment_step import Cfg4Step
-    step = Cfg4Step(seed=0, device=device)
+    step = Cfg4Step(seed=0, device=device, pipeline=PIPELINE)
     out = {}
     for _ in range(2):
         step.run_cfg3()
@@ -167,6 +173,7 @@ def extra_workloads(device, steps3=12, steps4=16, warm4=4):
     t0 = time.perf_counter()
     for _ in range(steps4):
         step.run()          # raises if a fragment returns before the finest level
+    step.flush()            # pipelined mode: the last fragment's panoptic branch belongs to the timed region
     torch.cuda.synchronize()
     out["cfg4_ms_per_fragment"] = (time.perf_counter() - t0) / steps4 * 1e3
     out["cfg4_fragments_per_sec"] = 1e3 / out["cfg4_ms_per_fragment"]
@@ -201,7 +208,7 @@ def bench_cfg5(device, rank, world, dist, steps=8, warmup=4):
     """whole NeuConNet.forward per fragment with the boundary exchange on; fragments/s over all ranks"""
     import torch
     from eprecon_amd.fragment_step import Cfg4Step
-    step = Cfg4Step(seed=0, device=device, rank=rank, world=world, force_exchange=True)
+    step = Cfg4Step(seed=0, device=device, rank=rank, world=world, force_exchange=True, pipeline=PIPELINE)
     step.raise_on_early_return = False
     for _ in range(warmup):
         step.run()
@@ -210,6 +217,7 @@ def bench_cfg5(device, rank, world, dist, steps=8, warmup=4):
     t0 = time.perf_counter()
     for _ in range(steps):
         step.run()
+    step.flush()
     dist.barrier()
     torch.cuda.synchronize()
     t = torch.tensor([time.perf_counter() - t0, float(step.early_returns)], dtype=torch.float64, device=device)
@@ -235,6 +243,8 @@ def bench_cfg4(args, step, world, rank, dist, use_dist=False):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step.run()
+    if hasattr(step, "flush"):
+        step.flush()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -293,7 +303,7 @@ def main():
     if args.workload == "cfg4":
         from eprecon_amd.fragment_step import Cfg4Step
         # all ranks work on ONE scene (seed 0), fragments dealt round-robin, boundary voxels exchanged
-        return bench_cfg4(args, Cfg4Step(seed=0, device=torch.device("cuda", local_rank), rank=rank, world=world),
+        return bench_cfg4(args, Cfg4Step(seed=0, device=torch.device("cuda", local_rank), rank=rank, world=world, pipeline=PIPELINE),
                           world, rank, dist, use_dist)
     step = Cfg2Step(seed=rank, device=torch.device("cuda", local_rank))
 

@@ -141,7 +141,8 @@ class Cfg4Step:
     windows of one scene (camera arc advanced 0.32 m per fragment, persistent GRU map).
     One step = one fragment; the scene restarts every `n_fragments` steps."""
 
-    def __init__(self, seed=0, device=None, height=480, width=640, n_fragments=4, rank=0, world=1, force_exchange=False):
+    def __init__(self, seed=0, device=None, height=480, width=640, n_fragments=4, rank=0, world=1, force_exchange=False,
+                 pipeline=False):
         from .config import ModelCfg
         from .neucon_network import NeuConNet
         self.device = device or torch.device("cuda")
@@ -175,6 +176,12 @@ class Cfg4Step:
             calibrate_occupancy_heads(self.net, *self.frags[0])
         # EPRECON_FORCE_EXCHANGE=1: run the boundary all-gather even at world size 1 (exercises the RCCL path on one GPU)
         self.net.distributed_exchange = world > 1 or os.environ.get("EPRECON_FORCE_EXCHANGE", "0") == "1" or force_exchange
+        # pipeline: the panoptic branch of fragment k runs on its own stream and overlaps the front of fragment k + 1; its
+        # host-side post-processing is finished one step later (NeuConNet.panoptic_stream)
+        self.pipeline = pipeline
+        if pipeline:
+            self.net.panoptic_stream = torch.cuda.Stream(device=self.device)
+        self._pending = None
         self.k = 0
         self.last = None
         self.voxels = []  # finest-level voxel count of every fragment run so far
@@ -188,6 +195,8 @@ class Cfg4Step:
             self.net.gru_fusion.scene_name = [None, None, None]
         f1, f2, inp = self.frags[self.k]
         self.last, _ = self.net(f1, f2, inp, {})
+        self.flush()                                           # the PREVIOUS fragment's panoptic branch (long finished)
+        self._pending = self.last.get("panoptic_finish")
         if "coords" not in self.last or "panoptic_levels" not in self.last:
             # a data-dependent early return of NeuConNet.forward (< 500 occupied voxels, no valid points, over the
             # cap) would otherwise be timed as a very fast fragment
@@ -200,10 +209,17 @@ class Cfg4Step:
         self.k = (self.k + 1) % self.n_fragments
         return self.last
 
+    def flush(self):
+        """finish the deferred panoptic post-processing of the last fragment (pipelined mode; no-op otherwise)"""
+        if self._pending is not None:
+            self._pending()
+            self._pending = None
+
     @torch.no_grad()
     def run_cfg3(self):
         """BASELINE.json configs[2]: ONE fragment through the full 3-level coarse-to-fine TSDF path with an EMPTY
         global map (scene restarted) and without the panoptic decoder"""
+        self.flush()
         dec, self.net.panoptic = self.net.panoptic, None
         try:
             self.net.gru_fusion.scene_name = [None, None, None]
@@ -222,7 +238,8 @@ class Cfg4Step:
                             "(occupancy init, 3 x [Back_Project, SPVCNN, GRU fusion, heads], panoptic inputs), "
                             "96^3 FBV, persistent sparse global map",
                 "views": N_VIEWS, "image": "640x480", "weights": "seeded random, occupancy heads calibrated to "
-                "45/35/25 % keep", "fragments_per_step_per_gpu": 1}
+                "45/35/25 % keep", "fragments_per_step_per_gpu": 1,
+                "pipelined": "panoptic branch of fragment k on its own stream, overlapping fragment k + 1" if self.pipeline else "no"}
 
 
 class TrainStep:

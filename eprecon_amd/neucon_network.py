@@ -81,6 +81,7 @@ class NeuConNet(nn.Module):
         self.criterion = SetCriterion(NUM_CLASSES, HungarianMatcher(class_w, mask_w, dice_w), weight_dict, eos_coef=0.1,
                                       losses=["labels", "masks"])
         self.trace = None  # set to a list to record per-stage intermediates (parity tests)
+        self.panoptic_stream = None        # a torch.cuda.Stream: pipelined serving (forward, section C)
         self.distributed_exchange = False  # multi-GPU: boundary-voxel all-gather before each fragment
 
     @staticmethod
@@ -273,7 +274,42 @@ class NeuConNet(nn.Module):
                 outputs["coords"] = pre_coords
                 outputs["tsdf"] = pre_tsdf
 
-        # ---- C. panoptic segmentation inputs (:516-561) ----------------------------------------
+        # ---- C. panoptic segmentation (:516-587) ---------------------------------------------------
+        side = self.panoptic_stream if (not recording and dev.type == "cuda" and self.panoptic is not None) else None
+        if side is None:
+            self._panoptic_branch(panoptic_coords, panoptic_voxel_feats, bs, outputs)
+            if self.panoptic is not None:
+                outputs["panoptic_info"] = [panoptic_post(o) for o in outputs["panoptic_out"]]  # :583-587
+                if recording and "rgb_list" in inputs and occ_target is not None:
+                    loss_dict["panoptic_loss"] = self._panoptic_loss(outputs["panoptic_out"], panoptic_coords[2], occ_target,
+                                                                     occupancy, inputs, bs)
+        else:
+            # Pipelined serving (opt-in, NeuConNet.panoptic_stream): the panoptic branch of THIS fragment is queued on its
+            # own stream and the call returns; its ~400 small launches then overlap with the front of the NEXT fragment
+            # (it reads only this fragment's tensors, never the scene map).  The host-synchronising post-processing is
+            # deferred: outputs["panoptic_finish"]() waits for the branch, fills outputs["panoptic_info"] and returns outputs.
+            main = torch.cuda.current_stream(dev)
+            side.wait_stream(main)
+            for t in list(panoptic_voxel_feats) + list(panoptic_coords):
+                t.record_stream(side)       # allocated on the main stream, read on the side stream after this call returns
+            with torch.cuda.stream(side):
+                self._panoptic_branch(panoptic_coords, panoptic_voxel_feats, bs, outputs)
+                done = side.record_event()
+
+            def finish(outputs=outputs, done=done, side=side):
+                done.synchronize()
+                with torch.cuda.stream(side):
+                    outputs["panoptic_info"] = [panoptic_post(o) for o in outputs["panoptic_out"]]
+                side.synchronize()
+                outputs.pop("panoptic_finish", None)
+                return outputs
+            outputs["panoptic_finish"] = finish
+        self._record(stage="panoptic", coords=panoptic_coords, feats=panoptic_voxel_feats)
+        return outputs, loss_dict
+
+    def _panoptic_branch(self, panoptic_coords, panoptic_voxel_feats, bs, outputs):
+        """ancestor pruning of the coarser levels, 48-channel projections, mask features, decoder (:516-581); fills
+        outputs['panoptic_levels'] and outputs['panoptic_out'] on the current stream"""
         keep1, keep0 = self.prune_to_ancestors(panoptic_coords)
         panoptic_coords[1], panoptic_voxel_feats[1] = panoptic_coords[1][keep1], panoptic_voxel_feats[1][keep1]
         panoptic_coords[0], panoptic_voxel_feats[0] = panoptic_coords[0][keep0], panoptic_voxel_feats[0][keep0]
@@ -298,12 +334,6 @@ class NeuConNet(nn.Module):
                 panoptic_predictions.append(out_b)
         if self.panoptic is not None:
             outputs["panoptic_out"] = panoptic_predictions
-            outputs["panoptic_info"] = [panoptic_post(o) for o in panoptic_predictions]  # :583-587
-            if recording and "rgb_list" in inputs and occ_target is not None:
-                loss_dict["panoptic_loss"] = self._panoptic_loss(panoptic_predictions, panoptic_coords[2], occ_target, occupancy,
-                                                                 inputs, bs)
-        self._record(stage="panoptic", coords=panoptic_coords, feats=panoptic_voxel_feats)
-        return outputs, loss_dict
 
     def _panoptic_loss(self, panoptic_outs, coords_fine, occ_target, occupancy, inputs, bs):
         """models/neucon_network.py:589-622: the set criterion on the voxels whose ground truth is observed; the

@@ -186,3 +186,27 @@ def test_exchange_path_is_a_no_op_at_world_size_1():
         assert int(xch.stamps[2].local.sum()) >= step.net.gru_fusion.global_volume[2].size > 0
     finally:
         dist.destroy_process_group()
+
+
+def test_pipelined_panoptic_branch_gives_identical_fragments():
+    """NeuConNet.panoptic_stream (the panoptic branch of fragment k on its own stream, overlapping fragment k + 1, its
+    post-processing finished one step later) changes WHEN things run, not what they compute"""
+    from eprecon_amd.fragment_step import Cfg4Step
+    ref = Cfg4Step(seed=3, n_fragments=3)
+    expected = []
+    for _ in range(3):
+        out = ref.run()
+        expected.append({"coords": out["coords"].clone(), "tsdf": out["tsdf"].clone(),
+                         "logits": out["panoptic_out"][0]["pred_logits"].clone(), "masks": out["panoptic_out"][0]["pred_masks"].clone(),
+                         "seg": out["panoptic_info"][0]["panoptic_seg"][0].clone()})
+    piped = Cfg4Step(seed=3, n_fragments=3, pipeline=True)
+    outs = [piped.run() for _ in range(3)]
+    assert "panoptic_info" not in outs[-1] and "panoptic_finish" in outs[-1]      # still pending
+    assert "panoptic_info" in outs[0] and "panoptic_finish" not in outs[0]        # finished one step later
+    piped.flush()
+    torch.cuda.synchronize()
+    for exp, out in zip(expected, outs):
+        assert torch.equal(exp["coords"], out["coords"]) and torch.equal(exp["tsdf"], out["tsdf"])
+        assert torch.equal(exp["logits"], out["panoptic_out"][0]["pred_logits"])
+        assert torch.equal(exp["masks"], out["panoptic_out"][0]["pred_masks"])
+        assert torch.equal(exp["seg"], out["panoptic_info"][0]["panoptic_seg"][0])
