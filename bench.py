@@ -36,10 +36,12 @@ DOMINANT_KERNEL = "bp_gather_mlp_kernel<256,MEAN,6,1>"
 L1_PEAK_LINES = 256 * 2.4e9  # vector-L1 line accesses per second: 256 CUs x 1 line per clock x 2.4 GHz
 
 
-# EPRECON_CFG4_PIPELINE=1: the panoptic branch of fragment k runs on its own stream and overlaps fragment k + 1
-# (NeuConNet.panoptic_stream).  Measured neutral on MI355X (22.94 vs 22.98 ms per fragment): the host enqueues launches
-# about as fast as the GPU retires them, so the branch has finished before the next fragment's first launch arrives.
-PIPELINE = os.environ.get("EPRECON_CFG4_PIPELINE", "0") == "1"
+# EPRECON_CFG4_PIPELINE=0: the panoptic branch of every fragment is issued inline and finished before the next fragment.
+# Default: the branch of fragment k is issued by a worker thread on its own stream while the main thread sits in the
+# blocking count reads of fragment k + 1 (NeuConNet.panoptic_stream / panoptic_worker); identical results
+# (tests/test_cfg4_gpu.py), 22.95 -> 20.6 ms per fragment on MI355X.  Without the thread (EPRECON_PIPELINE_THREAD=0) the
+# stream alone is neutral: the host issues the branch's small launches about as fast as the GPU retires them.
+PIPELINE = os.environ.get("EPRECON_CFG4_PIPELINE", "1") == "1"
 
 
 def newest_profile(name):

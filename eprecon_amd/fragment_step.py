@@ -181,6 +181,9 @@ class Cfg4Step:
         self.pipeline = pipeline
         if pipeline:
             self.net.panoptic_stream = torch.cuda.Stream(device=self.device)
+            if os.environ.get("EPRECON_PIPELINE_THREAD", "1") == "1":
+                from concurrent.futures import ThreadPoolExecutor
+                self.net.panoptic_worker = ThreadPoolExecutor(max_workers=1, thread_name_prefix="eprecon-panoptic")
         self._pending = None
         self.k = 0
         self.last = None
@@ -197,7 +200,7 @@ class Cfg4Step:
         self.last, _ = self.net(f1, f2, inp, {})
         self.flush()                                           # the PREVIOUS fragment's panoptic branch (long finished)
         self._pending = self.last.get("panoptic_finish")
-        if "coords" not in self.last or "panoptic_levels" not in self.last:
+        if "coords" not in self.last or ("panoptic_levels" not in self.last and "panoptic_finish" not in self.last):
             # a data-dependent early return of NeuConNet.forward (< 500 occupied voxels, no valid points, over the
             # cap) would otherwise be timed as a very fast fragment
             if self.raise_on_early_return:

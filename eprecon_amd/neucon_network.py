@@ -82,6 +82,7 @@ class NeuConNet(nn.Module):
                                       losses=["labels", "masks"])
         self.trace = None  # set to a list to record per-stage intermediates (parity tests)
         self.panoptic_stream = None        # a torch.cuda.Stream: pipelined serving (forward, section C)
+        self.panoptic_worker = None        # a concurrent.futures.ThreadPoolExecutor(1): issues that branch's launches
         self.distributed_exchange = False  # multi-GPU: boundary-voxel all-gather before each fragment
 
     @staticmethod
@@ -292,12 +293,19 @@ class NeuConNet(nn.Module):
             side.wait_stream(main)
             for t in list(panoptic_voxel_feats) + list(panoptic_coords):
                 t.record_stream(side)       # allocated on the main stream, read on the side stream after this call returns
-            with torch.cuda.stream(side):
-                self._panoptic_branch(panoptic_coords, panoptic_voxel_feats, bs, outputs)
-                done = side.record_event()
+            def branch(outputs=outputs, coords=panoptic_coords, feats=panoptic_voxel_feats, side=side):
+                # (grad mode and the current stream are thread-local: both are set here)
+                with torch.no_grad(), torch.cuda.stream(side):
+                    self._panoptic_branch(coords, feats, bs, outputs)
+                    return side.record_event()
 
-            def finish(outputs=outputs, done=done, side=side):
-                done.synchronize()
+            # With a worker thread the ~400 launches of the branch are issued while the main thread sits in the blocking
+            # count reads of the NEXT fragment (the GIL is released there); without one they are issued inline.
+            job = self.panoptic_worker.submit(branch) if self.panoptic_worker is not None else None
+            done = None if job is not None else branch()
+
+            def finish(outputs=outputs, job=job, done=done, side=side):
+                (job.result() if job is not None else done).synchronize()
                 with torch.cuda.stream(side):
                     outputs["panoptic_info"] = [panoptic_post(o) for o in outputs["panoptic_out"]]
                 side.synchronize()
