@@ -127,6 +127,23 @@ class NeuConNet(nn.Module):
         if self.trace is not None:
             self.trace.append(kw)
 
+    def _init_stage(self, features, inputs, bs, dev, select=True):
+        """stage A of forward (:239-318): occupancy initialisation on the dense 48^3 grid and the stage-0 voxel selection ->
+        (init_output | None, coord_init_selected | None, shape_init)"""
+        cfg = self.cfg
+        interval = 2 ** (self.n_scales - INIT_STAGE)
+        scale = self.n_scales - INIT_STAGE
+        up_coords, shape_init = dense_coords(cfg.N_VOX, interval, bs, device=dev)
+        KRcam = inputs["proj_matrices"][:, :, scale].permute(1, 0, 2, 3).contiguous()
+        init_output = self.initialization(up_coords, inputs["vol_origin_partial"], cfg.VOXEL_SIZE, features,
+                                          KRcam, shape_init, INIT_STAGE, INIT_MIN_VIEW)
+        if init_output is None or not select:
+            return init_output, None, shape_init
+        occ_init, coord_init, _ = init_output
+        selected, _ = GO.init_select(occ_init, coord_init, bs, dim=shape_init[0] // 2 ** INIT_STAGE,
+                                     cell=2 ** self.n_scales, threshold=INIT_OCC_THRESHOLD)
+        return init_output, selected, shape_init
+
     def forward(self, features, features_backbone2d_occ_pano, inputs, outputs, only_train_init=False,
                 only_train_occ=False, init_overlap_count=0):
         cfg = self.cfg
@@ -143,12 +160,8 @@ class NeuConNet(nn.Module):
                 self.gru_fusion.exchange_boundaries(inputs, b)
 
         # ---- A. occupancy initialisation ("depth prior") -------------------------------------
-        interval = 2 ** (self.n_scales - INIT_STAGE)
         scale = self.n_scales - INIT_STAGE
-        up_coords, shape_init = dense_coords(cfg.N_VOX, interval, bs, device=dev)
-        KRcam = inputs["proj_matrices"][:, :, scale].permute(1, 0, 2, 3).contiguous()
-        init_output = self.initialization(up_coords, inputs["vol_origin_partial"], cfg.VOXEL_SIZE, features,
-                                          KRcam, shape_init, INIT_STAGE, INIT_MIN_VIEW)
+        init_output, coord_init_selected, shape_init = self._init_stage(features, inputs, bs, dev, select=not only_train_init)
         if init_output is None:
             loss_dict["occupancy_initialization_loss"] = zero
             _warn("no valid points in initialization")
@@ -167,8 +180,6 @@ class NeuConNet(nn.Module):
             outputs["init_overlap_count"] = init_overlap_count
             loss_dict["occupancy_initialization_loss"] = sum(losses) / len(losses)
             return outputs, loss_dict
-        coord_init_selected, _ = GO.init_select(occ_init, coord_init, bs, dim=shape_init[0] // 2 ** INIT_STAGE,
-                                                cell=2 ** self.n_scales, threshold=INIT_OCC_THRESHOLD)
         self._record(stage="init", occ_init=occ_init, coord_init=coord_init, selected=coord_init_selected)
 
         # ---- B. coarse-to-fine surface reconstruction ----------------------------------------
