@@ -182,6 +182,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         _env = __import__("os").environ
         self.use_hip_graph = _env.get("EPRECON_NO_GRAPH", "0") != "1" and _env.get("EPRECON_DECODER_GRAPH", "1") == "1"
         self._plan = None
+        self._plan_params = None
 
     def get_pos_encs(self, coords, spitial_shape):
         out = []
@@ -227,13 +228,20 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         q_next = self._project_q(j + 1, output, query_embed) if j + 1 < self.num_layers else None
         return output, cls, me, q_next
 
+    def _apply(self, fn, *args, **kwargs):
+        self._plan_params = None        # .to() / .cuda() may replace the parameter objects
+        return super()._apply(fn, *args, **kwargs)
+
     def _static_plan(self, device):
         """Inference on the GPU: the query side of every layer captured once into a HIP graph (7 small GEMMs, two
         LayerNorms, an 80 x 80 attention, ... per layer -> one replay), chained through static tensors; re-captured
         when a parameter changes.  Returns None when graphs cannot be used (CPU, autograd)."""
         if device.type != "cuda" or torch.is_grad_enabled() or not self.use_hip_graph:
             return None
-        key = (device, tuple(p._version for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()))
+        params = self._plan_params          # (self.parameters() walks the module tree: 0.6 ms per call on 150 modules)
+        if params is None:
+            params = self._plan_params = list(self.parameters())
+        key = (device, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
         plan = self._plan
         if plan is not None and plan["key"] == key:
             return plan
