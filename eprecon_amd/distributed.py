@@ -56,54 +56,66 @@ def _inside(c, lo, dim):
 
 
 class _Stamps:
-    """per scale: sorted voxel keys with the index of the fragment that produced the voxel's current features
-    and whether this rank fused it itself"""
+    """Per scale: a dense int32 volume over the scene grid holding, for every voxel, the index of the fragment that
+    produced its current features and whether this rank fused it itself: 0 = unknown, +(stamp + 1) = fused here,
+    -(stamp + 1) = received.  (A sorted key table cost three sorts of the whole key set per fragment; 288 GB of HBM make the
+    dense form the cheap one: `extent`^3 x 4 bytes, 512 MB for a 20 m scene at 4 cm, allocated on first use.)
+    Coordinates outside [-extent/2, extent/2) set `bad`, which the exchange reports at its one host read."""
 
-    def __init__(self, device):
-        self.keys = torch.zeros(0, dtype=torch.int64, device=device)
-        self.stamp = torch.zeros(0, dtype=torch.int32, device=device)
-        self.local = torch.zeros(0, dtype=torch.bool, device=device)
+    def __init__(self, device, extent=None):
+        self.device = device
+        self.extent = int(extent or (512 if device.type == "cuda" else 128))
+        self.grid = None
+        self.bad = torch.zeros((), dtype=torch.bool, device=device)
+
+    def _index(self, coords):
+        e, h = self.extent, self.extent // 2
+        c = coords.to(torch.int64) + h
+        ok = ((c >= 0) & (c < e)).all(dim=1)
+        idx = (c[:, 0] * e + c[:, 1]) * e + c[:, 2]
+        return torch.where(ok, idx, torch.zeros_like(idx)), ok
 
     def put(self, coords, stamp, local):
-        """coords int32[n,3]; stamp int32[n] or int; entries of existing keys are overwritten"""
+        """coords int32[n,3] (distinct); stamp int32[n] or int; existing entries are overwritten"""
         n = coords.shape[0]
         if n == 0:
             return
-        dev = self.keys.device
-        k_new = pack_key(coords)
-        s_new = stamp if torch.is_tensor(stamp) else torch.full((n,), int(stamp), dtype=torch.int32, device=dev)
-        l_new = torch.full((n,), bool(local), dtype=torch.bool, device=dev)
-        keys = torch.cat([k_new, self.keys])
-        order = torch.sort(keys, stable=True)[1]          # equal keys: the new entry comes first
-        keys = keys[order]
-        first = torch.ones_like(keys, dtype=torch.bool)
-        first[1:] = keys[1:] != keys[:-1]
-        self.keys = keys[first]
-        self.stamp = torch.cat([s_new.to(torch.int32), self.stamp])[order][first]
-        self.local = torch.cat([l_new, self.local])[order][first]
+        if self.grid is None:
+            self.grid = torch.zeros(self.extent ** 3, dtype=torch.int32, device=self.device)
+        idx, ok = self._index(coords)
+        self.bad |= ~ok.all()
+        val = (stamp.to(torch.int32) if torch.is_tensor(stamp) else torch.full((n,), int(stamp), dtype=torch.int32, device=self.device)) + 1
+        val = val if local else -val
+        self.grid[idx] = torch.where(ok, val, self.grid[idx])
 
     def get(self, coords):
         """-> (stamp int32[n] (-1 when unknown), local bool[n])"""
         n = coords.shape[0]
-        dev = self.keys.device
-        if n == 0 or self.keys.numel() == 0:
-            return (torch.full((n,), -1, dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.bool, device=dev))
-        k = pack_key(coords)
-        pos = torch.searchsorted(self.keys, k).clamp(max=self.keys.numel() - 1)
-        hit = self.keys[pos] == k
-        return torch.where(hit, self.stamp[pos], torch.full_like(self.stamp[pos], -1)), self.local[pos] & hit
+        if n == 0 or self.grid is None:
+            return (torch.full((n,), -1, dtype=torch.int32, device=self.device), torch.zeros(n, dtype=torch.bool, device=self.device))
+        idx, ok = self._index(coords)
+        v = torch.where(ok, self.grid[idx], torch.zeros_like(self.grid[idx]))
+        return v.abs() - 1, v > 0
+
+    def local_count(self):
+        return 0 if self.grid is None else int((self.grid > 0).sum())
 
 
 class BoundaryExchange:
     """State and protocol of the boundary-voxel exchange for one GRUFusion (all scales)."""
 
-    def __init__(self, n_scales, device, group=None):
+    def __init__(self, n_scales, device, group=None, extent=None):
+        """extent: edge of the finest scale's stamp volume in voxels (coarser scales halve it), default 512 on a GPU"""
         self.n_scales, self.device, self.group = n_scales, device, group
-        self.stamps = [_Stamps(device) for _ in range(n_scales)]
+        self.extent = int(extent or (512 if device.type == "cuda" else 128))
+        self.stamps = [self.new_stamps(s) for s in range(n_scales)]
         self.collectives = 0        # issued so far (tests / bench reporting)
 
+    def new_stamps(self, scale):
+        return _Stamps(self.device, max(self.extent >> (self.n_scales - 1 - scale), 32))
+
     def reset(self):
-        self.stamps = [_Stamps(self.device) for _ in range(self.n_scales)]
+        self.stamps = [self.new_stamps(s) for s in range(self.n_scales)]
 
     def mark_fused(self, scale, coords, fragment_index):
         """the voxels `coords` (int32[n,3], scene grid of `scale`) were just fused locally by fragment `fragment_index`"""
@@ -118,7 +130,7 @@ class BoundaryExchange:
         lo = torch.as_tensor(boxes_lo, dtype=torch.int32, device=dev).reshape(ns, 3)
         boxes = [torch.zeros_like(lo) for _ in range(world)]
         dist.all_gather(boxes, lo, group=self.group)                                   # collective 1
-        send, counts = [], torch.zeros(ns, dtype=torch.int64, device=dev)
+        send, counts = [], torch.zeros(ns + 1, dtype=torch.int64, device=dev)   # last slot: a stamp volume overflowed
         for s, (c, f) in enumerate(maps):
             stamp, local = self.stamps[s].get(c)
             wanted = torch.zeros(c.shape[0], dtype=torch.bool, device=dev)
@@ -131,9 +143,13 @@ class BoundaryExchange:
                                fs.float()], dim=1)                                     # [n, 4 + C_s], ints bit-cast
             send.append(block.reshape(-1))
             counts[s] = cs.shape[0]
+            counts[ns] += self.stamps[s].bad.to(torch.int64)
         all_counts = [torch.zeros_like(counts) for _ in range(world)]
         dist.all_gather(all_counts, counts, group=self.group)                          # collective 2
         all_counts = torch.stack(all_counts).tolist()                                  # the one host read
+        if any(row[ns] for row in all_counts):   # every rank sees it and raises: no one is left waiting in a collective
+            raise RuntimeError("boundary exchange: a map voxel lies outside the stamp volume (scene larger than "
+                               f"{self.extent} finest voxels per axis); construct BoundaryExchange with a larger extent")
         widths = [4 + f.shape[1] for _, f in maps]
         sizes = [sum(all_counts[r][s] * widths[s] for s in range(ns)) for r in range(world)]
         cap = max(max(sizes), 1)

@@ -110,8 +110,7 @@ class GRUFusion(nn.Module):
         self.global_volume[i].reset()
         self.target_tsdf_volume[i].reset()
         if self._xchg is not None:
-            from .distributed import _Stamps
-            self._xchg.stamps[i] = _Stamps(device)
+            self._xchg.stamps[i] = self._xchg.new_stamps(i)
 
     def _begin_fragment(self, scale, inputs, i, dev):
         """scene bookkeeping of models/gru_fusion.py:280-293 -> relative origin (LongTensor[3], host)"""
