@@ -3,8 +3,7 @@
 Two families:
   * sparse layers, executed by libeprecon_hip.so through eprecon_amd.sparse:
       SparseSubMConv3d, SubMconv3dBlock, Spares3dELAN, SparseConv3d_Residual     (spconv in the reference)
-      SPVCNN, SConv3d, ConvGRU and their blocks                                  (torchsparse in the reference;
-                                                                                  see eprecon_amd/spvcnn.py)
+      SPVCNN, SConv3d, ConvGRU and their blocks                                  (torchsparse in the reference)
   * small dense blocks that stay PyTorch-ROCm (MIOpen / rocBLAS), as BASELINE.json's north_star
     prescribes for the 2D side and the heads: Conv2d_Block, Conv2d_Residual_Block, ELAN,
     Fusion_Block, Linear4xTrans, Linear_Residual.
@@ -13,6 +12,10 @@ Class names, constructor arguments, forward signatures and parameter names follo
 that its state_dict keys line up, except the sparse conv weights, whose layout is this build's
 [K^3, C_in, C_out] with x-fastest offset order (spconv stores [C_out, kx, ky, kz, C_in];
 `SparseSubMConv3d.load_spconv_weight` converts).
+
+Every sparse module has two wirings over the same parameters: the fused inference launches (in-place concat buffers,
+pending BatchNorms applied on load, gate epilogues) under torch.no_grad(), and, with autograd enabled, the recording
+operators of eprecon_amd/autograd.py whose backward runs on the HIP kernels as well (`recording()`).
 """
 import math
 
