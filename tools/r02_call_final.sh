@@ -25,3 +25,4 @@ print("cfg2", round(d["value"], 1), round(d["ms_per_step"], 3), "roofline", roun
       {k: round(v, 2) for k, v in d["extra"].items() if isinstance(v, float)})
 print("cfg4", json.load(open(o + "/bench_cfg4.json"))["ms_per_step"], "train", json.load(open(o + "/bench_train.json"))["ms_per_step"])
 PY
+bash tools/r02_train_prof.sh > gpurun_out/r02_final2/train_prof.txt 2>&1; head -3 gpurun_out/r02_final2/train_prof.txt
