@@ -308,6 +308,9 @@ class NeuConNet(nn.Module):
                 # (grad mode and the current stream are thread-local: both are set here)
                 with torch.no_grad(), torch.cuda.stream(side):
                     self._panoptic_branch(coords, feats, bs, outputs)
+                    if self.panoptic_worker is not None:
+                        # the host-synchronising post-processing too: it is the worker that waits for the decoder
+                        outputs["panoptic_info"] = [panoptic_post(o) for o in outputs["panoptic_out"]]
                     return side.record_event()
 
             # With a worker thread the ~400 launches of the branch are issued while the main thread sits in the blocking
@@ -317,9 +320,10 @@ class NeuConNet(nn.Module):
 
             def finish(outputs=outputs, job=job, done=done, side=side):
                 (job.result() if job is not None else done).synchronize()
-                with torch.cuda.stream(side):
-                    outputs["panoptic_info"] = [panoptic_post(o) for o in outputs["panoptic_out"]]
-                side.synchronize()
+                if "panoptic_info" not in outputs:      # inline mode: deferred to here so that forward() did not block
+                    with torch.cuda.stream(side):
+                        outputs["panoptic_info"] = [panoptic_post(o) for o in outputs["panoptic_out"]]
+                    side.synchronize()
                 outputs.pop("panoptic_finish", None)
                 return outputs
             outputs["panoptic_finish"] = finish

@@ -201,9 +201,10 @@ def test_pipelined_panoptic_branch_gives_identical_fragments():
                          "seg": out["panoptic_info"][0]["panoptic_seg"][0].clone()})
     piped = Cfg4Step(seed=3, n_fragments=3, pipeline=True)
     outs = [piped.run() for _ in range(3)]
-    assert "panoptic_info" not in outs[-1] and "panoptic_finish" in outs[-1]      # still pending
+    assert "panoptic_finish" in outs[-1]                                          # still pending
     assert "panoptic_info" in outs[0] and "panoptic_finish" not in outs[0]        # finished one step later
     piped.flush()
+    assert "panoptic_finish" not in outs[-1]
     torch.cuda.synchronize()
     for exp, out in zip(expected, outs):
         assert torch.equal(exp["coords"], out["coords"]) and torch.equal(exp["tsdf"], out["tsdf"])
