@@ -133,6 +133,22 @@ def test_panoptic_pruning(run):
         assert (tuple(kept[1][j]) in anc) == bool(keep1[j])
 
 
+def test_mask_features_match_oracle(run):
+    """a13: Panoptic_Feat_Fusion.generate_mask_features = three LN(x + ReLU(SubM3(x))) blocks on the finest kept voxels
+    (models/modules.py:469-482,574-580), numerically against the numpy restatement (48 channels, fused LN epilogue)"""
+    from oracle import sparse as OSP
+    tr, sd = run["trace"], run["sd"]
+    coords, x = npy(tr["panoptic"]["coords"][2]), npy(tr["panoptic"]["feats"][2])
+    assert x.shape[1] == 48 and len(np.unique(coords[:, 0])) == 1
+    nbr = OSP.kernel_map(coords, coords, 3, 1)
+    for i in range(3):
+        pre = f"panoptic_feat_fusion.mask_feat_extraction_{i}."
+        y = OSP.sparse_conv(x, nbr, sd[pre + "SConv3d.weight"], sd[pre + "SConv3d.bias"])
+        x = OSP.layernorm_rows(y, sd[pre + "norm.weight"], sd[pre + "norm.bias"], residual=x, pre_relu=True)
+    got = npy(run["outputs"]["panoptic_levels"][0]["mask_features"])
+    assert got.shape == x.shape and np.abs(got - x).max() < 1e-3
+
+
 def test_batched_backbone_feeds_back_projection_in_place():
     """f2: the batched channels-last backbone pass == the per-view loop on the GPU, and its stacked maps reach the
     back-projection without a torch.stack copy"""
