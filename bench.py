@@ -375,7 +375,10 @@ def main():
         if world == 1:
             out["roofline_conv"] = conv_roofline(step, lib)
             if not args.no_extra:
-                out["extra"] = extra_workloads(torch.device("cuda", local_rank))
+                try:   # the extras must never cost the headline line (Cfg4Step.run raises on an early-returning fragment)
+                    out["extra"] = extra_workloads(torch.device("cuda", local_rank))
+                except Exception as exc:  # noqa: BLE001
+                    out["extra"] = {"error": f"{type(exc).__name__}: {exc}"}
                 if cfg5 is not None:
                     out["extra"].update(cfg5)
         elif cfg5 is not None:
