@@ -181,6 +181,7 @@ def extra_workloads(device, steps3=12, steps4=16, warm4=4):
     out["cfg4_fragments_per_sec"] = 1e3 / out["cfg4_ms_per_fragment"]
     out["cfg4_finest_voxels_min_max"] = [min(step.voxels), max(step.voxels)]
     cfg4_workload = step.describe()["workload"]
+    out["cfg4_pipelined"] = step.describe()["pipelined"]
     del step
     from eprecon_amd.fragment_step import TrainStep
     train = TrainStep(seed=0, device=device)
