@@ -302,3 +302,18 @@ def test_conv_adjoint_identities_at_full_size(n, cin, cout):
     via_w = float((w.detach().double() * w.grad.double()).sum())
     scale = float((y.detach().double() * dy.double()).abs().sum())
     assert abs(lhs - via_x) < 2e-4 * scale and abs(lhs - via_w) < 2e-4 * scale, (lhs, via_x, via_w, scale)
+
+
+@pytest.mark.parametrize("kind,cin,cout", [("k3", 48, 24), ("down", 32, 32), ("up", 64, 48)])
+def test_conv_backward_matches_numpy_oracle(kind, cin, cout):
+    """HIP dgrad / wgrad / inverted map against oracle/backward.py (the adjoint written out in numpy)"""
+    from eprecon_amd import autograd as AG
+    from oracle import backward as OB
+    x, w, b, nbr, dy = conv_case(3000, cin, cout, kind, seed=17)
+    xs, ws = x.clone().requires_grad_(), w.clone().requires_grad_()
+    AG.sparse_conv(xs, ws, nbr).backward(dy)
+    nbr_h = nbr.cpu().numpy()
+    assert np.array_equal(AG.inverse_map(nbr, x.shape[0]).cpu().numpy(), OB.invert_map(nbr_h, x.shape[0]))
+    dx, dw, _ = OB.conv_backward(x.cpu().numpy(), w.cpu().numpy(), nbr_h, dy.cpu().numpy())
+    close(xs.grad.cpu(), torch.from_numpy(dx))
+    close(ws.grad.cpu(), torch.from_numpy(dw))
