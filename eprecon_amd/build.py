@@ -30,7 +30,7 @@ def build(force=False, verbose=False):
             os.path.getmtime(d) <= os.path.getmtime(OUT) for d in _deps()):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
+    objs, jobs = [], []
     for src in sources():
         obj = os.path.join(CSRC, os.path.basename(src)[:-4] + ".o")
         if force or not os.path.exists(obj) or any(
@@ -40,8 +40,12 @@ def build(force=False, verbose=False):
             if verbose:
                 cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
                 print(" ".join(cmd))
-            subprocess.check_call(cmd)
+            jobs.append(cmd)
         objs.append(obj)
+    # the translation units are independent: compile them side by side
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1) or 1) as pool:
+        list(pool.map(subprocess.check_call, jobs))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
     if verbose:
         print(" ".join(cmd))
