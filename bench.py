@@ -124,79 +124,135 @@ def cpu_baseline(step, seconds):
                         "median-of-10 PyTorch-CPU protocol of SURVEY.md 8d (one step takes seconds)"}
 
 
-def conv_roofline(step, lib, repeats=3):
-    """HIP-event time of ONE launch of the gather-GEMM family: the first 3x3x3 32->32 submanifold layer of the
-    initialisation stack on the ~94k-voxel valid set (the layer DESIGN.md 3b analyses), measured in untimed
-    extra steps.  flops = 2 * (live kernel-map pairs) * C_in * C_out (algorithmic; the output-stationary kernel
-    also issues the MFMAs of empty neighbours: `executed_flops`)."""
+def _conv_roofline_record(lib, ms, rows, name, kvol, cin, cout, what):
+    """one armed launch of the gather-GEMM family -> the roofline record; live kernel-map pairs are counted by the
+    library on the launch stream right behind the timed launch (eprecon_profile_conv_pairs)"""
+    pairs = int(lib.eprecon_profile_conv_pairs())
+    t = float(np.mean(ms))
+    flops = 2.0 * pairs * cin * cout
+    return {"bound": "mfma", "kernel": f"{name.decode()} ({what}, {rows} voxels)", "flops": flops,
+            "executed_flops": 2.0 * rows * kvol * cin * cout, "live_pairs": pairs, "avg_launch_ms": t,
+            "achieved": flops / (t * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            "frac": flops / (t * 1e-3) / 1e12 / F32_MFMA_PEAK_TF}
+
+
+def _armed_conv_ms(lib, run, kvol, cin, cout, min_rows, repeats):
     import ctypes
-    import torch
-    from eprecon_amd import sparse as SP
     ms, rows, name = [], 0, b""
     for _ in range(repeats):
-        lib.eprecon_profile_conv_arm(27, 32, 32, 20000)
-        step.run()
+        lib.eprecon_profile_conv_arm(kvol, cin, cout, min_rows)
+        run()
         r, k = ctypes.c_int64(0), ctypes.c_char_p()
         t = float(lib.eprecon_profile_conv_ms(ctypes.byref(r), ctypes.byref(k)))
         if t > 0:
             ms.append(t)
             rows, name = int(r.value), k.value or b""
+    return ms, rows, name
+
+
+def conv_roofline(step, lib, repeats=3):
+    """HIP-event time of ONE launch of the convolution family: the first 3x3x3 32->32 submanifold layer of the
+    initialisation stack on the ~94k-voxel valid set (the layer DESIGN.md 3b analyses), measured in untimed
+    extra steps.  flops = 2 * (live kernel-map pairs) * C_in * C_out (algorithmic; the output-stationary kernels
+    also issue the MFMAs of empty neighbours: `executed_flops`)."""
+    ms, rows, name = _armed_conv_ms(lib, step.run, 27, 32, 32, 20000, repeats)
     if not ms or step.last.get("init") is None:
         return None
-    coords = step.last["init"][1]
-    nbr = SP.VoxelSet(coords.contiguous(), 2).kernel_map(3)
-    pairs = int((nbr >= 0).sum().item())
-    t = float(np.mean(ms))
-    flops = 2.0 * pairs * 32 * 32
-    return {"bound": "mfma", "kernel": name.decode() + " (submanifold 3x3x3, 32->32 + fused LayerNorm epilogue, "
-            f"{rows} voxels of the dense 48^3 grid)", "flops": flops, "executed_flops": 2.0 * rows * 27 * 32 * 32,
-            "live_pairs": pairs, "avg_launch_ms": t, "achieved": flops / (t * 1e-3) / 1e12,
-            "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": flops / (t * 1e-3) / 1e12 / F32_MFMA_PEAK_TF}
+    return _conv_roofline_record(lib, ms, rows, name, 27, 32, 32,
+                                 "submanifold 3x3x3, 32->32 + fused LayerNorm epilogue, valid set of the dense 48^3 grid")
 
 
-def extra_workloads(device, steps3=12, steps4=16, warm4=4):
-    """cfg3 / cfg4 (BASELINE.json configs[2] / [3]) timed in the same process after the headline: the whole
-    NeuConNet.forward per fragment.  Not the headline metric (that is cfg2), reported under `extra`."""
+def conv_roofline_cfg4(step, lib, repeats=4):
+    """the same for the instance that leads the cfg4 profile: the 3x3x3 48->24 convolutions of the finest-level ConvGRU
+    ([h, x] -> gate, models/modules.py:178-222) on the fragment's finest voxel set (first launch of a fragment that
+    matches; one fragment per repeat)"""
+    ms, rows, name = _armed_conv_ms(lib, step.run, 27, 48, 24, 20000, repeats)
+    if not ms:
+        return None
+    return _conv_roofline_record(lib, ms, rows, name, 27, 48, 24, "ConvGRU gate convolution 3x3x3, 48->24, finest level")
+
+
+def _timed(run, steps, sync, after=None):
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    if after is not None:
+        after()
+    sync()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def extra_workloads(device, lib, steps3=12, steps4=16, warm4=4):
+    """cfg3 / cfg4 (BASELINE.json configs[2] / [3]), the whole drop-in boundary (NeuralRecon.forward) and one optimisation
+    step, timed in the same process after the headline.  Not the headline metric (that is cfg2), reported under `extra`.
+    Every leg is guarded on its own: a failing leg reports `<leg>_error` and never costs the others."""
     import torch
-    from eprecon_amd.fragment_step import Cfg4Step
-    step = Cfg4Step(seed=0, device=device, pipeline=PIPELINE)
+    from eprecon_amd.fragment_step import Cfg4Step, E2EStep, TrainStep
+    sync = torch.cuda.synchronize
     out = {}
-    for _ in range(2):
-        step.run_cfg3()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps3):
-        step.run_cfg3()
-    torch.cuda.synchronize()
-    out["cfg3_ms_per_fragment"] = (time.perf_counter() - t0) / steps3 * 1e3
-    for _ in range(warm4):
-        step.run()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps4):
-        step.run()          # raises if a fragment returns before the finest level
-    step.flush()            # pipelined mode: the last fragment's panoptic branch belongs to the timed region
-    torch.cuda.synchronize()
-    out["cfg4_ms_per_fragment"] = (time.perf_counter() - t0) / steps4 * 1e3
-    out["cfg4_fragments_per_sec"] = 1e3 / out["cfg4_ms_per_fragment"]
-    out["cfg4_finest_voxels_min_max"] = [min(step.voxels), max(step.voxels)]
-    cfg4_workload = step.describe()["workload"]
-    out["cfg4_pipelined"] = step.describe()["pipelined"]
-    del step
-    from eprecon_amd.fragment_step import TrainStep
-    train = TrainStep(seed=0, device=device)
-    for _ in range(3):
-        train.run()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(6):
-        train.run()
-    torch.cuda.synchronize()
-    out["train_ms_per_step"] = (time.perf_counter() - t0) / 6 * 1e3
-    out["train_workload"] = train.describe()["workload"]
-    out["cfg3_workload"] = "one 9-view 640x480 fragment, empty map: occupancy init + 3 x [Back_Project, SPVCNN, GRU " \
-                           "fusion, TSDF / occupancy heads, sparsify], no panoptic decoder"
-    out["cfg4_workload"] = cfg4_workload
+
+    def leg(name, fn):
+        try:
+            fn()
+        except Exception as exc:  # noqa: BLE001
+            out[f"{name}_error"] = f"{type(exc).__name__}: {exc}"
+
+    def cfg34():
+        step = Cfg4Step(seed=0, device=device, pipeline=PIPELINE)
+        for _ in range(2):
+            step.run_cfg3()
+        out["cfg3_ms_per_fragment"] = _timed(step.run_cfg3, steps3, sync)
+        out["cfg3_workload"] = "one 9-view 640x480 fragment, empty map: occupancy init + 3 x [Back_Project, SPVCNN, GRU " \
+                               "fusion, TSDF / occupancy heads, sparsify], no panoptic decoder"
+        for _ in range(warm4):
+            step.run()
+        step.voxels.clear()
+        # step.run raises if a fragment returns before the finest level; pipelined mode: the last fragment's panoptic
+        # branch belongs to the timed region (flush)
+        out["cfg4_ms_per_fragment"] = _timed(step.run, steps4, sync, after=step.flush)
+        out["cfg4_fragments_per_sec"] = 1e3 / out["cfg4_ms_per_fragment"]
+        out["cfg4_finest_voxels_min_max"] = [min(step.voxels), max(step.voxels)]
+        out["cfg4_early_returns"] = step.early_returns
+        out["cfg4_workload"] = step.describe()["workload"]
+        out["cfg4_pipelined"] = step.describe()["pipelined"]
+        step.flush()
+        out["roofline_conv_cfg4"] = conv_roofline_cfg4(step, lib)
+        step.flush()
+
+    def e2e():
+        step = E2EStep(seed=0, device=device)
+        for _ in range(4):
+            step.run()
+        step.voxels.clear()
+        step.early_returns = 0
+        out["e2e_ms_per_fragment"] = _timed(step.run, 12, sync)
+        out["e2e_early_returns"] = step.early_returns
+        out["e2e_finest_voxels_min_max"] = [min(step.voxels), max(step.voxels)] if step.voxels else None
+        out["e2e_workload"] = step.describe()["workload"]
+
+    def train():
+        step = TrainStep(seed=0, device=device)
+        step.raise_on_early_return = False     # counted instead: the number below is reported only over FULL steps
+        for _ in range(3):
+            step.run()
+        full_ms, n_early = [], 0
+        for _ in range(6):
+            before = step.early_returns
+            ms = _timed(step.run, 1, sync)
+            if step.early_returns == before:
+                full_ms.append(ms)
+            else:
+                n_early += 1
+        out["train_ms_per_step"] = float(np.mean(full_ms)) if full_ms else None
+        out["train_full_steps"] = len(full_ms)
+        out["train_early_returns"] = n_early
+        out["train_finest_voxels_min_max"] = [min(step.voxels), max(step.voxels)] if step.voxels else None
+        out["train_workload"] = step.describe()["workload"]
+
+    leg("cfg34", cfg34)
+    leg("e2e", e2e)
+    leg("train", train)
     prof = newest_profile("cfg4_kernel_stats.json")
     if prof:
         rec = json.load(open(prof))
@@ -377,7 +433,7 @@ def main():
             out["roofline_conv"] = conv_roofline(step, lib)
             if not args.no_extra:
                 try:   # the extras must never cost the headline line (Cfg4Step.run raises on an early-returning fragment)
-                    out["extra"] = extra_workloads(torch.device("cuda", local_rank))
+                    out["extra"] = extra_workloads(torch.device("cuda", local_rank), lib)
                 except Exception as exc:  # noqa: BLE001
                     out["extra"] = {"error": f"{type(exc).__name__}: {exc}"}
                 if cfg5 is not None:

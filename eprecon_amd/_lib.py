@@ -99,6 +99,10 @@ SIGNATURES = {
     "eprecon_profile_gather_ms": (_f, []),
     "eprecon_profile_conv_arm": (_i, [_i, _i, _i, _i64]),
     "eprecon_profile_conv_ms": (_f, [_c.POINTER(_i64), _c.POINTER(_c.c_char_p)]),
+    "eprecon_profile_conv_pairs": (_i64, []),
+    "eprecon_grid_rank_async": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
+    "eprecon_conv_pack_weight_floats": (_sz, [_i, _i, _i]),
+    "eprecon_conv_pack_weight_async": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "eprecon_nchw_to_nhwc_async": (_i, [_vp, _vp, _i, _i, _i, _vp]),
 }
 
@@ -180,7 +184,9 @@ class ConvDesc(ctypes.Structure):
                 ("bn_ticket", ctypes.c_void_p),
                 ("ln", ctypes.c_int), ("ln_gamma", ctypes.c_void_p), ("ln_beta", ctypes.c_void_p),
                 ("ln_eps", ctypes.c_float), ("ln_post_relu", ctypes.c_int),
-                ("img_h", ctypes.c_int), ("img_w", ctypes.c_int), ("img_maps", ctypes.c_int)]
+                ("img_h", ctypes.c_int), ("img_w", ctypes.c_int), ("img_maps", ctypes.c_int),
+                ("vox_rank", ctypes.c_void_p), ("grid_x", ctypes.c_int), ("grid_y", ctypes.c_int), ("grid_z", ctypes.c_int),
+                ("packed_weight", ctypes.c_void_p)]
 
 
 _WORKSPACES = {}

@@ -311,6 +311,19 @@ __global__ void transpose_map_kernel(const int4 *fine, int n, const int32_t *par
     for (int k = 0; k < 8; ++k) up[(size_t)k * n + i] = (k == kk) ? par : -1;
 }
 
+// rank volume of a voxel set on a dense grid: rank[(x/stride * gy + y/stride) * gz + z/stride] = row (cells start at -1)
+__global__ void grid_rank_kernel(const int4 *coords, int n, int stride, int gx, int gy, int gz, int32_t *rank, int32_t *bad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = coords[i];
+    const int x = c.y / stride, y = c.z / stride, z = c.w / stride;
+    const bool ok = c.y >= 0 && c.z >= 0 && c.w >= 0 && x < gx && y < gy && z < gz && x * stride == c.y && y * stride == c.z &&
+                    z * stride == c.w;
+    if (ok) rank[((size_t)x * gy + y) * gz + z] = i;
+    else atomicAdd(bad, 1);
+}
+
 HashTable make_table(void *mem, uint32_t cap)
 {
     HashTable t;
@@ -454,6 +467,23 @@ int eprecon_transpose_map_async(const int32_t *fine_coords, int64_t n, const int
     hipLaunchKernelGGL(transpose_map_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
                        (hipStream_t)stream, reinterpret_cast<const int4 *>(fine_coords), (int)n, parent,
                        fine_stride, up_map);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_grid_rank_async(const int32_t *coords, int64_t n, int stride, int grid_x, int grid_y, int grid_z, int32_t *rank,
+                            void *stream)
+{
+    if (n < 0 || stride < 1 || grid_x <= 0 || grid_y <= 0 || grid_z <= 0 || !rank || (n > 0 && !coords) ||
+        (int64_t)grid_x * grid_y * grid_z > 0x7ffffff0 || n > 0x7fffffff)
+        return EPRECON_ERR_ARG;
+    // rank[cells] then one int32: voxels off the grid (must stay 0; the caller may read it back)
+    const size_t cells = (size_t)grid_x * grid_y * grid_z;
+    EP_HIP_CHECK(hipMemsetAsync(rank, 0xff, cells * sizeof(int32_t), (hipStream_t)stream));
+    EP_HIP_CHECK(hipMemsetAsync(rank + cells, 0, sizeof(int32_t), (hipStream_t)stream));
+    if (n == 0) return EPRECON_OK;
+    hipLaunchKernelGGL(grid_rank_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const int4 *>(coords), (int)n, stride, grid_x, grid_y, grid_z, rank, rank + cells);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }

@@ -77,6 +77,11 @@ struct ConvParams {
     // the caller sizes bn_partial with eprecon_conv_desc_partial_rows (descriptor entry point), so kernels whose
     // workgroups do not cover 128 rows may be chosen
     int flex_partial;
+    // dense-grid form of the 3x3x3 stride-1 convolution (conv3d_tile_kernel): vox_rank int32[gx][gy][gz] (z fastest) holds
+    // the row of the voxel in a grid cell or -1; wq = the weights in MFMA operand order (pack_weights_kernel)
+    const int32_t *vox_rank;
+    int gx, gy, gz;
+    const float *wq;
 };
 
 // Stage `rows` x TN weights (zero padded) from w[row0 + r][0:ncols] (row stride `stride`, rows valid
@@ -943,6 +948,392 @@ int launch_conv2d_tile(const ConvParams &p, hipStream_t st)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Dense-grid 3x3x3 stride-1 convolution: the 3D twin of conv2d_tile_kernel, for voxel sets that fill most of their
+// bounding grid (the initialisation stack runs on 85 % of the dense 48^3 grid, models/occupancy_initialization.py:131-174).
+// The gather form re-reads every input row 27 times through L1/L2 behind a [27][N] kernel map and pays a memory
+// latency per batch of offsets (73 us for 32 -> 32 on 94k voxels, 0.40 of the MFMA bound; ablation: gathers alone 53 us).
+// Here a workgroup owns a 4 x 4 x 8 block of grid cells (x slowest, z fastest = the row order of a raster-ordered set):
+//   1. the rank volume gives the row of each of the 6 x 6 x 10 halo cells (-1: no voxel)          -> LDS (360 ints)
+//   2. the halo rows are staged ONCE with coalesced 16-byte loads, the producer's pending BatchNorm (+ReLU) applied on
+//      the way in, zeros where there is no voxel                                                   -> LDS (360 x (C_in + 4) floats)
+//   3. the 27 offsets read their A operands from LDS with one ds_read_b128 per 8-channel chunk at compile-time offsets
+//      (no address arithmetic in the loop).  B operands do NOT go through LDS: the weights are pre-packed in operand
+//      order (pack_weights_kernel), so a wave fetches the four channel steps of a chunk with ONE coalesced 1 KB
+//      global_load_dwordx4 (L1 / L2 hits: every wave of the chip reads the same 27 * C_in * C_out * 4 bytes), issued two
+//      chunks ahead of its MFMAs.  No weight staging, no barrier inside the MFMA loop, 53 KB of LDS at C_in = 32:
+//      three workgroups per CU, so one workgroup's staging overlaps the others' MFMAs.
+//   4. the shared epilogue (bias, ReLU, residual, BatchNorm summaries or row-wise LayerNorm); rows are addressed
+//      through the ranks, cells without a voxel are computed and dropped.
+// Bit-identical to the gather kernels: the same k-ordered fma chain per output element, zeros for missing neighbours.
+// No kernel map and no hash grid are needed for such layers.
+//   wave w -> x = x0 + w; MFMA row r32 -> (y, z) = (y0 + r32 / 8, z0 + r32 % 8)
+// ---------------------------------------------------------------------------------------------
+constexpr int kD3X = 4, kD3Y = 4, kD3Z = 8;
+constexpr int kD3HX = kD3X + 2, kD3HY = kD3Y + 2, kD3HZ = kD3Z + 2;
+constexpr int kD3Halo = kD3HX * kD3HY * kD3HZ;  // 360
+
+struct RankRows {  // output rows of a wave's 32 grid cells, from LDS
+    const int *r;
+    __device__ __forceinline__ int operator()(int i) const { return r[i]; }
+};
+
+// Weights [K][Cin][Cout] -> MFMA operand order, zero padded, one slab per block of 32 * nt output columns:
+//   wq[(((((cb * K + k) * NCH + ch) * 2 + half) * NT + t) * 32 + col) * 4 + s] = W[k][ch*8 + 4*half + s][cb*32*NT + 32 t + col]
+// (the float4 a lane (half, col) multiplies with its four consecutive input channels of chunk ch)
+__global__ void pack_weights_kernel(const float *w, int K, int Cin, int Cout, int nch, int nt, int ncb, float *wq)
+{
+    const int total = ncb * K * nch * 2 * nt * 32 * 4;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int sidx = e & 3, col = (e >> 2) & 31;
+        int r = e >> 7;
+        const int t = r % nt; r /= nt;
+        const int half = r & 1; r >>= 1;
+        const int ch = r % nch; r /= nch;
+        const int k = r % K, cb = r / K;
+        const int c = ch * 8 + 4 * half + sidx, co = (cb * nt + t) * 32 + col;
+        wq[e] = (c < Cin && co < Cout) ? w[((size_t)k * Cin + c) * Cout + co] : 0.0f;
+    }
+}
+// the (NT, column blocks) the dense-grid kernel uses for C_out output channels; the packing follows it
+inline void d3_columns(int cout, int *nt, int *ncb) { *nt = cout <= 32 ? 1 : 2; *ncb = (cout + 32 * *nt - 1) / (32 * *nt); }
+
+__device__ __forceinline__ void d3_tile_origin(int tile, int tiles_y, int tiles_z, int &x0, int &y0, int &z0)
+{
+    const int tz = tile % tiles_z, ty = (tile / tiles_z) % tiles_y, tx = tile / (tiles_z * tiles_y);
+    x0 = tx * kD3X; y0 = ty * kD3Y; z0 = tz * kD3Z;
+}
+
+// steps 1 + 2 of the tile kernels: ranks of the halo cells -> sRank, halo rows -> sX (pitch P floats).
+// Returns false (block-uniform) when no cell of the tile holds a voxel.
+template <int NCH>
+__device__ __forceinline__ bool d3_stage_halo(const ConvParams &p, int x0, int y0, int z0, float *sX, int *sRank, int tid)
+{
+    constexpr int cin_pad = NCH * 8, P = cin_pad + 4, C4 = cin_pad / 4;
+    for (int e = tid; e < kD3Halo; e += 256) {
+        const int hz = e % kD3HZ, hy = (e / kD3HZ) % kD3HY, hx = e / (kD3HZ * kD3HY);
+        const int x = x0 - 1 + hx, y = y0 - 1 + hy, z = z0 - 1 + hz;
+        const bool in = x >= 0 && x < p.gx && y >= 0 && y < p.gy && z >= 0 && z < p.gz;
+        sRank[e] = in ? p.vox_rank[((size_t)x * p.gy + y) * p.gz + z] : -1;
+    }
+    __syncthreads();
+    // this thread's output cell (256 threads cover the 128 cells twice)
+    const int v = tid & 127;
+    const int own = sRank[(((v >> 5) + 1) * kD3HY + ((v >> 3) & 3) + 1) * kD3HZ + (v & 7) + 1];
+    if (!__syncthreads_or(own >= 0)) return false;
+    constexpr int kItems = kD3Halo * C4;
+    constexpr int kIter = (kItems + 255) / 256;
+    float4 hv[kIter];
+    const int last4 = ((p.Cin + 3) & ~3) - 4;
+    // the channel group of an item is tid % C4 in every iteration when C4 divides 256: its scale / shift are loaded once
+    constexpr bool kFixedGroup = 256 % C4 == 0;
+    float4 sc0 = make_float4(1.f, 1.f, 1.f, 1.f), sh0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kFixedGroup && p.in_scale) {
+        sc0 = *reinterpret_cast<const float4 *>(p.in_scale + min((tid % C4) * 4, last4));
+        sh0 = *reinterpret_cast<const float4 *>(p.in_shift + min((tid % C4) * 4, last4));
+    }
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {  // all loads first (clamped addresses), then the fix-ups and LDS stores
+        const int e = min(tid + it * 256, kItems - 1);
+        const int cell = e / C4, c4 = e - cell * C4;
+        const int r = sRank[cell];
+        hv[it] = *reinterpret_cast<const float4 *>(p.x + (size_t)max(r, 0) * p.ld_x + min(c4 * 4, last4));
+    }
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+        const int e = tid + it * 256;
+        if (e >= kItems) break;
+        const int cell = e / C4, c4 = e - cell * C4;
+        const int c = c4 * 4;
+        float4 v4 = hv[it];
+        if (p.in_scale) {
+            float4 sc = sc0, sh = sh0;
+            if (!kFixedGroup) {
+                sc = *reinterpret_cast<const float4 *>(p.in_scale + min(c, last4));
+                sh = *reinterpret_cast<const float4 *>(p.in_shift + min(c, last4));
+            }
+            v4.x = fmaf(v4.x, sc.x, sh.x); v4.y = fmaf(v4.y, sc.y, sh.y);
+            v4.z = fmaf(v4.z, sc.z, sh.z); v4.w = fmaf(v4.w, sc.w, sh.w);
+            if (p.in_relu) {
+                v4.x = fmaxf(v4.x, 0.f); v4.y = fmaxf(v4.y, 0.f); v4.z = fmaxf(v4.z, 0.f); v4.w = fmaxf(v4.w, 0.f);
+            }
+        }
+        if (sRank[cell] < 0 || c >= p.Cin) v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(sX + cell * P + c) = v4;
+    }
+    __syncthreads();
+    return true;
+}
+
+template <int NT, int NCH>
+__global__ __launch_bounds__(256) void conv3d_tile_kernel(ConvParams p, int tiles_y, int tiles_z, int ntiles)
+{
+    constexpr int cin_pad = NCH * 8;
+    constexpr int P = cin_pad + 4;  // LDS cell pitch in floats: an odd number of 16-byte units
+    constexpr int TN = 32 * NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *sX = reinterpret_cast<float *>(smem);             // [kD3Halo][P]
+    int *sRank = reinterpret_cast<int *>(sX + kD3Halo * P);  // [kD3Halo] rows of the halo cells
+    int *sOut = sRank + kD3Halo;                             // [128] rows of the tile's own cells, wave-major
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, half = lane >> 5;
+    const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    if (tile >= ntiles) return;
+    const int col0 = blockIdx.y * TN;
+    int x0, y0, z0;
+    d3_tile_origin(tile, tiles_y, tiles_z, x0, y0, z0);
+
+    if (!d3_stage_halo<NCH>(p, x0, y0, z0, sX, sRank, tid)) {
+        if (p.bn_partial && tid < TN && col0 + tid < p.Cout) {  // an empty summary row: the finalize skips count 0
+            float *dst = p.bn_partial + (size_t)tile * 3 * p.Cout + col0 + tid;
+            dst[0] = 0.0f; dst[p.Cout] = 0.0f; dst[2 * p.Cout] = 0.0f;
+        }
+        return;
+    }
+    const int cell0 = ((wave + 1) * kD3HY + (r32 >> 3) + 1) * kD3HZ + (r32 & 7) + 1;  // this lane's own cell in the halo
+    const int own = sRank[cell0];
+    if (half == 0) sOut[wave * 32 + r32] = own;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    if (__ballot(own >= 0) != 0ull) {  // (wave-uniform) a wave without a voxel has nothing to accumulate
+        // A operands: LDS address of the halo cell at offset (-1, -1, -1) of this lane's cell; offset k adds a
+        // wave-uniform multiple of the cell pitch, the chunks are immediates of the ds_read
+        const float *xa = sX + (cell0 - (kD3HY + 1) * kD3HZ - 1) * P + 4 * half;
+        // B operands through a buffer resource over the packed weights of this column block: byte offset
+        // ((k * NCH + ch) * 2 + half) * NT * 512 + t * 512 + r32 * 16 -> the lane part is one VGPR, the offset a scalar
+        constexpr unsigned kStepBytes = 2u * NT * 512u;      // one (offset, chunk) step
+        constexpr unsigned kOffBytes = NCH * kStepBytes;     // one kernel offset
+        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(p.wq) + (size_t)blockIdx.y * 27 * (kOffBytes / 4), 0, (int)(27 * kOffBytes), 0x00020000);
+        const unsigned wlane = (unsigned)half * NT * 512u + (unsigned)r32 * 16u;
+        float4 bc[NCH][NT], bn[NCH][NT];
+        auto load_b = [&](int k, float4(&dst)[NCH][NT]) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + (unsigned)ch * kStepBytes + (unsigned)t * 512u,
+                                                                          (unsigned)k * kOffBytes, 0);
+                    dst[ch][t] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                }
+        };
+        load_b(0, bc);
+#pragma unroll 1
+        for (int k = 0; k < 27; ++k) {
+            // the weights of the NEXT offset are requested before this offset's MFMAs (a whole offset = 4 * NCH * NT MFMAs of
+            // cover for the L2 round trip); the scheduling barrier keeps the compiler from sinking them behind the MFMAs
+            load_b(min(k + 1, 26), bn);
+            __builtin_amdgcn_sched_barrier(0);
+            const int dx = k % 3, dy = (k / 3) % 3, dz = k / 9;
+            const float *xk = xa + ((dx * kD3HY + dy) * kD3HZ + dz) * P;
+            float4 av[NCH];
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) av[ch] = *reinterpret_cast<const float4 *>(xk + ch * 8);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ch].x, bc[ch][t].x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ch].y, bc[ch][t].y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ch].z, bc[ch][t].z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ch].w, bc[ch][t].w, acc[t], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bc[ch][t] = bn[ch][t];
+        }
+    }
+    __syncthreads();  // every wave is done with the halo (the epilogue's scratch overlays it); sOut is written
+    conv_epilogue<NT>(p, acc, RankRows{sOut + wave * 32}, col0, r32, half, wave, sX, tile);
+}
+
+// C_out == 1 (the occupancy-logit layer, models/occupancy_initialization.py:171): a 32-column MFMA tile would spend 31/32
+// of its work on padding.  Same halo staging; two lanes per cell split the 16-byte channel groups, the weights of the one
+// output column come from LDS as broadcasts, plain fma chains, the BatchNorm summary of the tile by Chan merges in
+// lane / wave order.
+template <int NCH>
+__global__ __launch_bounds__(256) void conv3d_tile_narrow_kernel(ConvParams p, int tiles_y, int tiles_z, int ntiles)
+{
+    constexpr int cin_pad = NCH * 8, P = cin_pad + 4, C4 = cin_pad / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *sX = reinterpret_cast<float *>(smem);
+    int *sRank = reinterpret_cast<int *>(sX + kD3Halo * P);
+    float *sWn = reinterpret_cast<float *>(sRank + kD3Halo);  // [27][cin_pad] weights of the single column, zero padded
+    float *sRed = sWn + 27 * cin_pad;                          // [4][3] wave summaries
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    if (tile >= ntiles) return;
+    int x0, y0, z0;
+    d3_tile_origin(tile, tiles_y, tiles_z, x0, y0, z0);
+    for (int e = tid; e < 27 * cin_pad; e += 256) {
+        const int k = e / cin_pad, c = e - k * cin_pad;
+        sWn[e] = c < p.Cin ? p.w[((size_t)k * p.Cin + c) * p.Cout] : 0.0f;
+    }
+    if (!d3_stage_halo<NCH>(p, x0, y0, z0, sX, sRank, tid)) {  // (its barriers also publish sWn)
+        if (p.bn_partial && tid == 0) {
+            float *dst = p.bn_partial + (size_t)tile * 3 * p.Cout;
+            dst[0] = 0.0f; dst[p.Cout] = 0.0f; dst[2 * p.Cout] = 0.0f;
+        }
+        return;
+    }
+    const int v = tid >> 1, part = tid & 1;  // cell (x = v / 32, y = (v / 8) % 4, z = v % 8), half of the channel groups
+    const int cell0 = (((v >> 5) + 1) * kD3HY + ((v >> 3) & 3) + 1) * kD3HZ + (v & 7) + 1;
+    const int row = sRank[cell0];
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
+        const float *xk = sX + (cell0 + (dx * kD3HY + dy) * kD3HZ + dz) * P;
+#pragma unroll
+        for (int j = 0; j < C4 / 2; ++j) {
+            const int c = (2 * j + part) * 4;
+            const float4 a = *reinterpret_cast<const float4 *>(xk + c);
+            const float4 w = *reinterpret_cast<const float4 *>(sWn + k * cin_pad + c);
+            acc = fmaf(a.x, w.x, acc); acc = fmaf(a.y, w.y, acc); acc = fmaf(a.z, w.z, acc); acc = fmaf(a.w, w.w, acc);
+        }
+    }
+    acc += __shfl_xor(acc, 1);
+    float n = 0.0f, mean = 0.0f, m2 = 0.0f;
+    if (part == 0 && row >= 0) {
+        float *o = p.out + (size_t)row * p.ld_out;
+        float val = acc + (p.bias ? p.bias[0] : 0.0f);
+        if (p.accumulate) val += *o;
+        if (p.relu) val = fmaxf(val, 0.0f);
+        if (p.res) {
+            float rv = p.res[(size_t)row * p.ld_res];
+            if (p.res_scale) {
+                rv = fmaf(rv, p.res_scale[0], p.res_shift[0]);
+                if (p.res_relu) rv = fmaxf(rv, 0.0f);
+            }
+            val += rv;
+        }
+        *o = val;
+        n = 1.0f; mean = val;
+    }
+    if (p.bn_partial) {  // (uniform)
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {  // lane-order tree: the lower lane of a pair is the left operand
+            const float on = __shfl_xor(n, m), omean = __shfl_xor(mean, m), om2 = __shfl_xor(m2, m);
+            const bool lower = (lane & m) == 0;
+            float a_n = lower ? n : on, a_mean = lower ? mean : omean, a_m2 = lower ? m2 : om2;
+            chan_merge(a_n, a_mean, a_m2, lower ? on : n, lower ? omean : mean, lower ? om2 : m2);
+            n = a_n; mean = a_mean; m2 = a_m2;
+        }
+        if (lane == 0) { sRed[wave * 3] = n; sRed[wave * 3 + 1] = mean; sRed[wave * 3 + 2] = m2; }
+        __syncthreads();
+        if (tid == 0) {
+            float a_n = 0.0f, a_mean = 0.0f, a_m2 = 0.0f;
+            for (int w = 0; w < kWaves; ++w) chan_merge(a_n, a_mean, a_m2, sRed[w * 3], sRed[w * 3 + 1], sRed[w * 3 + 2]);
+            float *dst = p.bn_partial + (size_t)tile * 3 * p.Cout;
+            dst[0] = a_n; dst[p.Cout] = a_mean; dst[2 * p.Cout] = a_m2;
+        }
+    }
+}
+
+int d3_tiles(const ConvParams &p, int *ty = nullptr, int *tz = nullptr)
+{
+    const int tx = (p.gx + kD3X - 1) / kD3X, tyy = (p.gy + kD3Y - 1) / kD3Y, tzz = (p.gz + kD3Z - 1) / kD3Z;
+    if (ty) *ty = tyy;
+    if (tz) *tz = tzz;
+    return tx * tyy * tzz;
+}
+size_t conv3d_tile_lds(int nch, bool narrow)
+{
+    const size_t base = ((size_t)kD3Halo * (nch * 8 + 4)) * sizeof(float) + (size_t)kD3Halo * sizeof(int);
+    return base + (narrow ? ((size_t)27 * nch * 8 + 16) * sizeof(float) : (size_t)128 * sizeof(int));
+}
+
+// eligibility of the dense-grid kernels (independent of the data: shapes, alignment, fusions)
+bool conv3d_tile_ok(const ConvParams &p, bool *narrow)
+{
+    static const bool on = !(getenv("EPRECON_CONV_DENSE3D") && getenv("EPRECON_CONV_DENSE3D")[0] == '0');
+    if (!on || !p.vox_rank || p.K != 27 || p.gx <= 0 || p.gy <= 0 || p.gz <= 0 || p.bn_scale_out) return false;
+    if (p.Cin % 4 != 0 || p.Cin > 64 || p.ld_x % 4 != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0) return false;
+    if (p.in_scale && ((reinterpret_cast<uintptr_t>(p.in_scale) & 15) != 0 || (reinterpret_cast<uintptr_t>(p.in_shift) & 15) != 0))
+        return false;
+    *narrow = p.Cout == 1 && !p.ln;
+    if (*narrow) return true;
+    if (!p.wq || (reinterpret_cast<uintptr_t>(p.wq) & 15) != 0 || p.accumulate) return false;
+    if (p.ln && (p.Cout > 64 || p.bn_partial)) return false;
+    return true;
+}
+
+template <int NT, int NCH>
+int launch_conv3d_tile(const ConvParams &p, hipStream_t st)
+{
+    int ty, tz;
+    const int ntiles = d3_tiles(p, &ty, &tz);
+    const size_t lds = max(conv3d_tile_lds(NCH, false), (size_t)max(kWaves * 3 * 32 * NT, 3 * 256) * sizeof(float));
+    if (lds > 64 * 1024) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_tile_kernel<NT, NCH>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (attr != hipSuccess) return EPRECON_ERR_HIP_BASE - (int)attr;
+    }
+    const dim3 grid((unsigned)ntiles, (unsigned)ceil_div(p.Cout, 32 * NT));  // == d3_columns' ncb
+    hipLaunchKernelGGL((conv3d_tile_kernel<NT, NCH>), grid, dim3(256), lds, st, p, ty, tz, ntiles);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+template <int NCH>
+int launch_conv3d_narrow(const ConvParams &p, hipStream_t st)
+{
+    int ty, tz;
+    const int ntiles = d3_tiles(p, &ty, &tz);
+    const size_t lds = conv3d_tile_lds(NCH, true);
+    if (lds > 64 * 1024) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_tile_narrow_kernel<NCH>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (attr != hipSuccess) return EPRECON_ERR_HIP_BASE - (int)attr;
+    }
+    hipLaunchKernelGGL((conv3d_tile_narrow_kernel<NCH>), dim3((unsigned)ntiles), dim3(256), lds, st, p, ty, tz, ntiles);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+template <int NT>
+int launch_conv3d_nt(const ConvParams &p, hipStream_t st)
+{
+    switch ((p.Cin + 7) / 8) {
+        case 1: return launch_conv3d_tile<NT, 1>(p, st);
+        case 2: return launch_conv3d_tile<NT, 2>(p, st);
+        case 3: return launch_conv3d_tile<NT, 3>(p, st);
+        case 4: return launch_conv3d_tile<NT, 4>(p, st);
+        case 5: return launch_conv3d_tile<NT, 5>(p, st);
+        case 6: return launch_conv3d_tile<NT, 6>(p, st);
+        case 7: return launch_conv3d_tile<NT, 7>(p, st);
+        default: return launch_conv3d_tile<NT, 8>(p, st);
+    }
+}
+
+int launch_conv3d(const ConvParams &p, bool narrow, hipStream_t st)
+{
+    if (narrow) {
+        switch ((p.Cin + 7) / 8) {
+            case 1: return launch_conv3d_narrow<1>(p, st);
+            case 2: return launch_conv3d_narrow<2>(p, st);
+            case 3: return launch_conv3d_narrow<3>(p, st);
+            case 4: return launch_conv3d_narrow<4>(p, st);
+            case 5: return launch_conv3d_narrow<5>(p, st);
+            case 6: return launch_conv3d_narrow<6>(p, st);
+            case 7: return launch_conv3d_narrow<7>(p, st);
+            default: return launch_conv3d_narrow<8>(p, st);
+        }
+    }
+    int nt, ncb;
+    d3_columns(p.Cout, &nt, &ncb);
+    return nt == 1 ? launch_conv3d_nt<1>(p, st) : launch_conv3d_nt<2>(p, st);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Short lists with wide inputs (a few thousand voxels / the 10,800 pixels of the 1/16 maps, C_in > 64):
 // there are too few 128-row tiles to fill the chip, nothing overlaps, and the slab kernel's time is the
 // LENGTH of its dependent chain: K * ceil(C_in / 32) staged slabs, each a global round trip + barrier
@@ -1163,7 +1554,32 @@ struct ConvProf {
     int64_t min_rows = 0, rows = 0;
     const char *kernel = "";
     hipEvent_t start = nullptr, stop = nullptr;
+    unsigned long long *pairs_dev = nullptr;  // live (output row, offset) pairs of the bracketed launch
 } g_conv_prof;
+
+// live pairs of a launch = what its algorithmic flop count rests on; counted on the launch stream BEHIND the stop event
+__global__ void count_map_pairs_kernel(const int32_t *nbr, size_t total, unsigned long long *out)
+{
+    unsigned long long c = 0;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) c += nbr[e] >= 0;
+    for (int m = 32; m > 0; m >>= 1) c += __shfl_xor(c, m);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+__global__ void count_grid_pairs_kernel(const int32_t *rank, int gx, int gy, int gz, unsigned long long *out)
+{
+    unsigned long long c = 0;
+    const int total = gx * gy * gz;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        if (rank[e] < 0) continue;
+        const int z = e % gz, y = (e / gz) % gy, x = e / (gz * gy);
+        for (int k = 0; k < 27; ++k) {
+            const int xx = x + k % 3 - 1, yy = y + (k / 3) % 3 - 1, zz = z + k / 9 - 1;
+            if (xx >= 0 && xx < gx && yy >= 0 && yy < gy && zz >= 0 && zz < gz) c += rank[(xx * gy + yy) * gz + zz] >= 0;
+        }
+    }
+    for (int m = 32; m > 0; m >>= 1) c += __shfl_xor(c, m);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
 const char *g_last_conv_kernel = "";
 
 int conv_dispatch_inner(ConvParams &p, int64_t n_in, hipStream_t st);
@@ -1180,11 +1596,30 @@ int conv_dispatch(ConvParams &p, int64_t n_in, hipStream_t st)
     g.recorded = rc == EPRECON_OK;
     g.rows = p.n_out;
     g.kernel = g_last_conv_kernel;
+    if (g.pairs_dev) {
+        EP_HIP_CHECK(hipMemsetAsync(g.pairs_dev, 0, sizeof(unsigned long long), st));
+        bool narrow;
+        if (conv3d_tile_ok(p, &narrow))
+            hipLaunchKernelGGL(count_grid_pairs_kernel, dim3(256), dim3(256), 0, st, p.vox_rank, p.gx, p.gy, p.gz, g.pairs_dev);
+        else if (p.nbr)
+            hipLaunchKernelGGL(count_map_pairs_kernel, dim3(256), dim3(256), 0, st, p.nbr, (size_t)p.K * p.n_out, g.pairs_dev);
+        else  // identity map
+            EP_HIP_CHECK(hipMemcpyAsync(g.pairs_dev, &g.rows, sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+        EP_LAUNCH_CHECK();
+    }
     return rc;
 }
 
 int conv_dispatch_inner(ConvParams &p, int64_t n_in, hipStream_t st)
 {
+    {
+        bool narrow;
+        if (conv3d_tile_ok(p, &narrow)) {
+            g_last_conv_kernel = narrow ? "conv3d_tile_narrow_kernel" : "conv3d_tile_kernel";
+            return launch_conv3d(p, narrow, st);
+        }
+        if (!p.nbr && p.K != 1) return EPRECON_ERR_ARG;  // dense-grid form requested for a shape it does not take, no map given
+    }
     {
         int nt, nch;
         int64_t blocks;
@@ -1248,6 +1683,7 @@ extern "C" int eprecon_profile_conv_arm(int kvol, int cin, int cout, int64_t min
     if (!g.start) {
         EP_HIP_CHECK(hipEventCreate(&g.start));
         EP_HIP_CHECK(hipEventCreate(&g.stop));
+        EP_HIP_CHECK(hipMalloc(&g.pairs_dev, sizeof(unsigned long long)));
     }
     g.K = kvol; g.cin = cin; g.cout = cout; g.min_rows = min_rows;
     g.armed = true;
@@ -1266,6 +1702,35 @@ extern "C" float eprecon_profile_conv_ms(int64_t *rows_out, const char **kernel_
     return ms;
 }
 
+extern "C" int64_t eprecon_profile_conv_pairs(void)
+{
+    ConvProf &g = g_conv_prof;
+    if (!g.recorded || !g.pairs_dev || hipEventSynchronize(g.stop) != hipSuccess) return -1;
+    unsigned long long v = 0;
+    if (hipMemcpy(&v, g.pairs_dev, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int64_t)v;
+}
+
+extern "C" size_t eprecon_conv_pack_weight_floats(int kvol, int cin, int cout)
+{
+    if (kvol <= 0 || cin <= 0 || cout <= 0) return 0;
+    int nt, ncb;
+    d3_columns(cout, &nt, &ncb);
+    return (size_t)ncb * kvol * ((cin + 7) / 8) * 2 * nt * 32 * 4;
+}
+
+extern "C" int eprecon_conv_pack_weight_async(const float *weight, int kvol, int cin, int cout, float *packed, void *stream)
+{
+    if (!weight || !packed || kvol <= 0 || cin <= 0 || cout <= 0) return EPRECON_ERR_ARG;
+    int nt, ncb;
+    d3_columns(cout, &nt, &ncb);
+    const size_t total = eprecon_conv_pack_weight_floats(kvol, cin, cout);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)min((size_t)1024, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       weight, kvol, cin, cout, (cin + 7) / 8, nt, ncb, packed);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
 extern "C" size_t eprecon_conv_bn_partial_bytes(int64_t n_out, int cout)
 {
     return (size_t)ep::ceil_div(n_out > 0 ? n_out : 1, (int64_t)128) * 3 * (size_t)(cout > 0 ? cout : 1) * sizeof(float);
@@ -1276,7 +1741,8 @@ static int conv_check_and_run(ConvParams &p, int64_t n_in, int64_t n_out, void *
     if (!p.x || !p.w || !p.out || n_in < 0 || n_out < 0 || p.K <= 0 || p.K > 64 || p.Cin <= 0 || p.Cout <= 0 ||
         p.ld_x < p.Cin || p.ld_out < p.Cout || (p.res && p.ld_res < p.Cout))
         return EPRECON_ERR_ARG;
-    if (!p.nbr && (p.K != 1 || n_in != n_out)) return EPRECON_ERR_ARG;
+    if (!p.nbr && !p.vox_rank && p.K != 1) return EPRECON_ERR_ARG;
+    if (!p.nbr && n_in != n_out) return EPRECON_ERR_ARG;
     if ((p.in_scale == nullptr) != (p.in_shift == nullptr) || (p.res_scale == nullptr) != (p.res_shift == nullptr))
         return EPRECON_ERR_ARG;
     if (p.bn_scale_out && (!p.bn_partial || !p.bn_shift_out || !p.bn_ticket || p.Cout > 256)) return EPRECON_ERR_ARG;
@@ -1302,13 +1768,14 @@ static void params_from_desc(ConvParams &p, const eprecon_conv_desc *d)
     p.ln = d->ln; p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.ln_eps = d->ln_eps;
     p.ln_post_relu = d->ln_post_relu;
     p.img_h = d->img_h; p.img_w = d->img_w; p.img_maps = d->img_maps;
+    p.vox_rank = d->vox_rank; p.gx = d->grid_x; p.gy = d->grid_y; p.gz = d->grid_z; p.wq = d->packed_weight;
     p.flex_partial = 1;
 }
 
 extern "C" int eprecon_conv_desc_async(const eprecon_conv_desc *d, void *stream)
 {
     if (!d) return EPRECON_ERR_ARG;
-    ConvParams p;
+    ConvParams p = {};
     params_from_desc(p, d);
     return conv_check_and_run(p, d->n_in, d->n_out, stream);
 }
@@ -1319,11 +1786,13 @@ extern "C" int eprecon_conv_desc_async(const eprecon_conv_desc *d, void *stream)
 extern "C" int64_t eprecon_conv_desc_partial_rows(const eprecon_conv_desc *d)
 {
     if (!d || d->n_out <= 0) return 0;
-    ConvParams p;
+    ConvParams p = {};
     params_from_desc(p, d);
     p.n_out = (int)d->n_out;
     int nt, nch;
     int64_t blocks;
+    bool narrow;
+    if (conv3d_tile_ok(p, &narrow)) return d3_tiles(p);
     if (conv2d_tile_ok(p, &nt, &nch, &blocks)) return blocks;
     if (splitk_ok(p)) return ep::ceil_div(d->n_out, (int64_t)32);
     return ep::ceil_div(d->n_out, (int64_t)kRowsPerBlock);

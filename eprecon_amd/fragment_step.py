@@ -112,25 +112,52 @@ class Cfg2Step:
                 "weights": "seeded random", "fragments_per_step_per_gpu": 1}
 
 
+WORKLOAD_SEED = 20240  # np.random state of every calibration and workload forward (the reference's sub-sampling draws from it)
+
+
+def seed_subsampling(k=0):
+    """The reference sub-samples over-full levels with np.random.choice (models/neucon_network.py:478-484).  Synthetic
+    workloads fix that generator's state before every forward, so calibration and timed runs draw the SAME subsets and the
+    sparsity of a workload is a controlled regime, not an accident of how many forwards ran before it."""
+    import numpy as np
+    np.random.seed(WORKLOAD_SEED + int(k))
+
+
 @torch.no_grad()
-def calibrate_occupancy_heads(net, features, features_occ_pano, inputs, keep_fraction=(0.45, 0.35, 0.25)):
+def calibrate_occupancy_heads(net, features, features_occ_pano=None, inputs=None, keep_fraction=(0.45, 0.35, 0.25)):
     """Random-init occupancy heads may classify (almost) every voxel the same way, which trips the
     reference's `< 500 occupied voxels` early return.  There is no trained checkpoint in this
-    environment, so benchmarks and end-to-end tests shift each stage's occupancy bias
-    (occ_preds[i].linear3.bias) such that `keep_fraction[i]` of the stage's voxels pass `occ > 0`
-    on the given window — the sparsity regime "random ~50 %" of SURVEY.md section 8d.
-    Runs the forward once per stage; the GRU state is reset afterwards."""
+    environment, so benchmarks and end-to-end tests rescale each stage's occupancy logit
+    (occ_preds[i].linear3: logit' = (logit - q) / sigma, q the (1 - keep_fraction[i]) quantile and sigma the standard
+    deviation over the stage's voxels) such that `keep_fraction[i]` of the stage's voxels pass `occ > 0` — the sparsity
+    regime "random ~50 %" of SURVEY.md section 8d.  Unit-variance logits make the fraction insensitive to the last
+    bits of the weights (an Adam step, another GRU state): seeded-random heads give a logit spread of ~1e-2, where a
+    bias set on one forward kept 66-71 % instead of 25 % on the next.
+    `features` may also be a list of (features, features_occ_pano, inputs) fragments of ONE scene: they are run in
+    sequence (live GRU state) and the statistics pooled.  One pass over the fragments per stage; the GRU state is
+    reset afterwards."""
+    frags = features if features_occ_pano is None else [(features, features_occ_pano, inputs)]
     old_trace = net.trace
     for i in range(net.cfg.N_LAYER):
-        net.trace = []
         net.gru_fusion.scene_name = [None, None, None]
-        net(features, features_occ_pano, inputs, {})
-        rec = {t["stage"]: t for t in net.trace}.get(f"heads{i}")
-        if rec is None:
+        occs = []
+        for k, (f1, f2, inp) in enumerate(frags):
+            net.trace = []
+            seed_subsampling(k)
+            net(f1, f2, inp, {})
+            rec = {t["stage"]: t for t in net.trace}.get(f"heads{i}")
+            if rec is not None:
+                occs.append(rec["occ"][:, 0].float())
+        if not occs:
             raise RuntimeError(f"stage {i} was not reached while calibrating")
-        occ = rec["occ"][:, 0]
-        q = torch.quantile(occ.float(), 1.0 - keep_fraction[i])
-        net.occ_preds[i].linear3.bias.sub_(q)
+        occ = torch.cat(occs)
+        if occ.numel() > 4_000_000:  # torch.quantile's input limit is 16 M elements; a strided sample is plenty
+            occ = occ[:: occ.numel() // 4_000_000 + 1]
+        q = torch.quantile(occ, 1.0 - keep_fraction[i])
+        sigma = occ.std().clamp_min(1e-12)
+        lin = net.occ_preds[i].linear3
+        lin.bias.sub_(q).div_(sigma)
+        lin.weight.div_(sigma)
     net.gru_fusion.scene_name = [None, None, None]
     net.trace = old_trace
 
@@ -169,11 +196,11 @@ class Cfg4Step:
         if world > 1:
             import torch.distributed as dist
             if rank == 0:
-                calibrate_occupancy_heads(self.net, *self.frags[0])
+                calibrate_occupancy_heads(self.net, self.frags)
             for p_ in self.net.parameters():
                 dist.broadcast(p_.data, 0)
         else:
-            calibrate_occupancy_heads(self.net, *self.frags[0])
+            calibrate_occupancy_heads(self.net, self.frags)
         # EPRECON_FORCE_EXCHANGE=1: run the boundary all-gather even at world size 1 (exercises the RCCL path on one GPU)
         self.net.distributed_exchange = world > 1 or os.environ.get("EPRECON_FORCE_EXCHANGE", "0") == "1" or force_exchange
         # pipeline: the panoptic branch of fragment k runs on its own stream and overlaps the front of fragment k + 1; its
@@ -197,6 +224,7 @@ class Cfg4Step:
         if self.k == 0:
             self.net.gru_fusion.scene_name = [None, None, None]
         f1, f2, inp = self.frags[self.k]
+        seed_subsampling(self.k)
         self.last, _ = self.net(f1, f2, inp, {})
         self.flush()                                           # the PREVIOUS fragment's panoptic branch (long finished)
         self._pending = self.last.get("panoptic_finish")
@@ -227,6 +255,7 @@ class Cfg4Step:
         try:
             self.net.gru_fusion.scene_name = [None, None, None]
             f1, f2, inp = self.frags[0]
+            seed_subsampling(0)
             out, _ = self.net(f1, f2, inp, {})
         finally:
             self.net.panoptic = dec
@@ -243,6 +272,60 @@ class Cfg4Step:
                 "views": N_VIEWS, "image": "640x480", "weights": "seeded random, occupancy heads calibrated to "
                 "45/35/25 % keep", "fragments_per_step_per_gpu": 1,
                 "pipelined": "panoptic branch of fragment k on its own stream, overlapping fragment k + 1" if self.pipeline else "no"}
+
+
+class E2EStep:
+    """The drop-in boundary itself: NeuralRecon.forward(inputs, save_mesh=False, training=False) the way main.py:430-436
+    calls it at test time (models/neuralrecon.py:46-86) — image normalisation, BOTH MnasMulti backbones on the nine 640x480
+    images, the whole HIP 3D path (NeuConNet.forward incl. the panoptic decoder) and fuse_to_global — over `n_fragments`
+    consecutive windows of one scene.  One step = one fragment; nothing is pipelined across fragments (outputs carry
+    `panoptic_info` and the fused scene state when the call returns, the reference's contract)."""
+
+    def __init__(self, seed=0, device=None, height=480, width=640, n_fragments=4):
+        import numpy as np
+        from .config import ModelCfg
+        from .neuralrecon import NeuralRecon
+        self.device = device or torch.device("cuda")
+        self.n_fragments = n_fragments
+        torch.manual_seed(4321)
+        self.model = NeuralRecon(ModelCfg()).to(self.device)
+        self.model.train()     # main.py:357
+        self.inputs = []
+        for k in range(n_fragments):
+            w = S.make_window(seed=seed * 100 + k, width=width, height=height, advance=0.32 * k)
+            _, _, inp = S.make_model_inputs([w], feat_seed=seed * 100 + k, scene=f"scene{seed:04d}")
+            rng = np.random.default_rng(seed * 100 + k + 7)
+            inp["imgs"] = rng.random((1, N_VIEWS, 3, height, width), dtype=np.float32) * 255.0   # 0..255 like main.py:113
+            self.inputs.append(S.to_device(inp, self.device))
+        with torch.no_grad():
+            frags = []
+            for inp in self.inputs:
+                norm = [self.model.normalizer(img) for img in torch.unbind(inp["imgs"], 1)]
+                frags.append((self.model.backbone2d.forward_views(norm), self.model.backbone_occ_pano.forward_views(norm), inp))
+            calibrate_occupancy_heads(self.model.neucon_net, frags)
+        self.k = 0
+        self.last = None
+        self.voxels = []
+        self.early_returns = 0
+
+    @torch.no_grad()
+    def run(self):
+        if self.k == 0:   # scene restart: both persistent maps (GRU features, fused TSDF / instances)
+            self.model.neucon_net.gru_fusion.scene_name = [None, None, None]
+            self.model.fuse_to_global.scene_name = [None, None, None]
+        seed_subsampling(self.k)
+        self.last, _ = self.model(self.inputs[self.k], save_mesh=False, training=False)
+        if "coords" not in self.last or "panoptic_info" not in self.last:
+            self.early_returns += 1
+        else:
+            self.voxels.append(int(self.last["coords"].shape[0]))
+        self.k = (self.k + 1) % self.n_fragments
+        return self.last
+
+    def describe(self):
+        return {"workload": f"NeuralRecon.forward(inputs, save_mesh=False, training=False) over {self.n_fragments} sequential "
+                            "9-view 640x480 fragments of one scene: normalisation + 2 x MnasMulti on the images + "
+                            "NeuConNet.forward (panoptic decoder included) + fuse_to_global; images resident in HBM"}
 
 
 class TrainStep:
@@ -282,6 +365,12 @@ class TrainStep:
                                                  broadcast_buffers=False, find_unused_parameters=True)
         self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, betas=(0.9, 0.999))
         self.last = None
+        self.steps = 0
+        self.early_returns = 0      # steps whose forward returned before the finest level / the panoptic criterion
+        self.voxels = []            # finest-level voxel count of every full step
+        # a truncated step (the reference's guards, models/neucon_network.py:463-497) is not an optimisation step of this
+        # workload: raise on one GPU; under DDP a raising rank would strand the others in the gradient all-reduce -> count
+        self.raise_on_early_return = world == 1
 
     def describe(self):
         return {"workload": "one optimisation step on one 9-view 640x480 fragment (empty scene map): NeuConNet.forward under "
@@ -291,6 +380,7 @@ class TrainStep:
 
     def loss(self):
         self.net.gru_fusion.scene_name = [None, None, None]
+        seed_subsampling(0)
         outputs, loss_dict = self.model(self.f1, self.f2, self.inputs, {})
         total = 0
         for i, (k, v) in enumerate(loss_dict.items()):
@@ -301,6 +391,15 @@ class TrainStep:
     def run(self):
         self.optimizer.zero_grad(set_to_none=True)
         outputs, loss_dict = self.loss()
+        self.steps += 1
+        if "coords" not in outputs or "panoptic_loss" not in loss_dict:
+            # the forward hit one of the reference's data-dependent early returns: the levels behind it and the set
+            # criterion did not run, so this is NOT the step the workload describes
+            if self.raise_on_early_return:
+                raise RuntimeError(f"train step {self.steps}: NeuConNet.forward returned early (losses: {sorted(loss_dict)})")
+            self.early_returns += 1
+        else:
+            self.voxels.append(int(outputs["coords"].shape[0]))
         loss_dict["total_loss"].backward()
         torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1.0)
         self.optimizer.step()

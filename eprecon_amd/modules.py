@@ -113,23 +113,30 @@ class SparseSubMConv3d(nn.Module):
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def run(self, features, vset, out=None, relu=False):
-        nbr = vset.kernel_map(3) if self.kernel == 3 else None
         if recording():
+            nbr = vset.kernel_map(3) if self.kernel == 3 else None
             y = AG.sparse_conv(features, self.weight, nbr, self.bias)
             y = F.relu(y) if relu else y
             return y if out is None else out.copy_(y)
+        nbr = vset.conv_map(3) if self.kernel == 3 else None   # dense-grid form on well-filled grids, else the kernel map
         return SP.sparse_conv(features, self.weight, nbr, self.bias, out=out, relu=relu)
+
+    def run_stats(self, features, vset, out=None):
+        """conv + bias and the BatchNorm summaries of its output in one launch -> (y, partial)"""
+        nbr = vset.conv_map(3) if self.kernel == 3 else None
+        return SP.sparse_conv_fused(features, self.weight, nbr, self.bias, out=out, bn_partial=True)
 
     def run_ln(self, features, vset, ln, out=None, relu=False, residual=None, post_relu=False):
         """conv [+ReLU] [+residual] -> LayerNorm `ln` [-> ReLU], one launch"""
-        nbr = vset.kernel_map(3) if self.kernel == 3 else None
         if recording():
+            nbr = vset.kernel_map(3) if self.kernel == 3 else None
             y = AG.sparse_conv(features, self.weight, nbr, self.bias)
             y = F.relu(y) if relu else y
             y = y + residual if residual is not None else y
             y = F.layer_norm(y, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
             y = F.relu(y) if post_relu else y
             return y if out is None else out.copy_(y)
+        nbr = vset.conv_map(3) if self.kernel == 3 else None
         return SP.sparse_conv_ln(features, self.weight, nbr, self.bias, ln.weight, ln.bias, ln.eps, out=out,
                                  relu=relu, residual=residual, post_relu=post_relu)
 

@@ -245,7 +245,7 @@ class NeuConNet(nn.Module):
             # per batch element: occupied voxels, and occupied voxels whose target is occupied — ONE host read
             # for all the guards below (the reference synchronises once per guard and batch element)
             bcol = up_coords[:, 0].long()
-            tgt = occ_target.squeeze(1) if occ_target is not None else torch.ones_like(occupancy)
+            tgt = occ_target.reshape(-1) if occ_target is not None else torch.ones_like(occupancy)   # [N] (get_target) or [N,1] (fusion)
             count_by_batch = lambda: torch.zeros((2, bs), dtype=torch.int64, device=dev).index_add_(
                 1, bcol, torch.stack([occupancy, occupancy & tgt]).long()).tolist()
             stats = count_by_batch()

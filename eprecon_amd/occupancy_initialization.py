@@ -146,8 +146,10 @@ class Occupancy_Initialization(nn.Module):
         x = self.similary_1.run(x, vset)
         for conv, norm in ((self.subm1, self.norm1), (self.subm2, self.norm2), (self.subm3, self.norm3)):
             x = conv.run_ln(x, vset, norm, relu=True, residual=x)  # LN(x + ReLU(conv(x))), one launch
-        y = self.subm4.run(x, vset)
-        return self.norm4.run(y, out=None if torch.is_grad_enabled() else y)
+        if torch.is_grad_enabled():
+            return self.norm4.run(self.subm4.run(x, vset))
+        y, partial = self.subm4.run_stats(x, vset)      # the logit layer writes norm4's batch statistics itself
+        return self.norm4.run_partials(y, partial, out=y)
 
     def forward(self, coords, origin, voxel_size, features_all, KRcam, shape, stage, min_view_number):
         bs = features_all[0][0].shape[0]
@@ -174,7 +176,9 @@ class Occupancy_Initialization(nn.Module):
         for b in range(bs):  # statistics of norm0 / norm4 are per batch element, as in the reference
             nb = res["n_valid_per_batch"][b]
             seg = slice(start, start + nb)
-            vset = SP.VoxelSet(coord_valid[seg], interval)
+            # the valid voxels are a raster-ordered subset of the dense `shape` grid (generate_grid): well filled, so the
+            # 3x3x3 layers of the stack take the dense-grid kernel (no hash grid, no kernel map)
+            vset = SP.VoxelSet(coord_valid[seg], interval, dims=shape)
             parts.append(self.sparse_stack(res["var"][seg], vset))
             start += nb
         occ = parts[0] if bs == 1 else torch.cat(parts)

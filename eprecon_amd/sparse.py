@@ -12,6 +12,11 @@ import torch
 from . import _lib
 
 
+import os
+
+_DENSE3D_ON = os.environ.get("EPRECON_CONV_DENSE3D", "1") != "0"
+
+
 def _ld(t):
     assert t.dim() == 2 and t.stride(1) == 1, "row-major 2-D tensor expected"
     return t.stride(0)
@@ -73,17 +78,100 @@ def unique_coords(coords, quantum=1):
     return uniq[:m], inverse, grid
 
 
+DENSE_MIN_FILL = 0.4   # a set that fills at least this share of its bounding grid takes the dense-grid convolution
+
+
+class DenseMap:
+    """What a 3x3x3 stride-1 convolution needs on a voxel set that lives on a dense grid: the rank volume
+    int32[gx*gy*gz (+1)] (cell -> row or -1, eprecon_grid_rank_async) instead of a hash grid + [27, N] kernel map.
+    Layers whose shape the tile kernel does not take fall back to the set's kernel map (built on first use)."""
+
+    def __init__(self, vset, dims):
+        lib = _lib.load()
+        self.vset, self.dims = vset, tuple(int(d) for d in dims)
+        gx, gy, gz = self.dims
+        self.rank = torch.empty(gx * gy * gz + 1, dtype=torch.int32, device=vset.coords.device)
+        _lib.check(lib.eprecon_grid_rank_async(_lib.ptr(vset.coords), vset.n, vset.stride, gx, gy, gz, _lib.ptr(self.rank),
+                                               _lib.current_stream()), "eprecon_grid_rank_async")
+
+    @property
+    def shape(self):          # (K, N) like the kernel-map tensor it stands in for
+        return (27, self.vset.n)
+
+    def off_grid(self):
+        """blocking: number of voxels that were not on the grid (0 for a valid set)"""
+        return int(self.rank[-1].item())
+
+    def takes(self, x, cin, cout, accumulate=False, ln=False, stats=False):
+        """mirror of the library's eligibility rule (conv3d_tile_ok, csrc/sparse_conv.hip)"""
+        if cin % 4 or cin > 64 or x.stride(0) % 4 or x.data_ptr() % 16 or accumulate:
+            return False
+        if cout == 1 and not ln:
+            return True
+        return not (ln and (cout > 64 or stats))
+
+
+def packed_weight(weight):
+    """`weight` f32[27, Cin, Cout] in the operand order of the dense-grid kernel, packed once per weight version"""
+    hit = getattr(weight, "_d3_pack", None)
+    if hit is None or hit[0] != weight._version or hit[1].device != weight.device:
+        lib = _lib.load()
+        kvol, cin, cout = weight.shape
+        w = weight.detach().contiguous()
+        packed = torch.empty(int(lib.eprecon_conv_pack_weight_floats(kvol, cin, cout)), dtype=torch.float32, device=weight.device)
+        _lib.check(lib.eprecon_conv_pack_weight_async(_lib.ptr(w), kvol, cin, cout, _lib.ptr(packed), _lib.current_stream()),
+                   "eprecon_conv_pack_weight_async")
+        hit = (weight._version, packed)
+        weight._d3_pack = hit
+    return hit[1]
+
+
+def _resolve_map(nbr, x, weight, desc, accumulate=False, ln=False, stats=False):
+    """nbr: None (identity), an int32[K, N] kernel map, or a DenseMap -> fills the map fields of `desc`; returns the
+    objects that must stay alive until the launch is queued"""
+    if isinstance(nbr, DenseMap):
+        kvol, cin, cout = weight.shape
+        if kvol == 27 and nbr.takes(x, cin, cout, accumulate, ln, stats):
+            desc.vox_rank = nbr.rank.data_ptr()
+            desc.grid_x, desc.grid_y, desc.grid_z = nbr.dims
+            keep = [nbr.rank]
+            if cout > 1 or ln:
+                pw = packed_weight(weight)
+                desc.packed_weight = pw.data_ptr()
+                keep.append(pw)
+            desc.nbr = None
+            return keep
+        nbr = nbr.vset.kernel_map(3)
+    desc.nbr = None if nbr is None else nbr.data_ptr()
+    return [nbr]
+
+
 class VoxelSet:
     """A set of active voxels at one tensor stride: coords int32[N,4] (b,x,y,z), its hash grid and
-    the kernel maps built on it.  Maps are built once and reused by every layer on the set."""
+    the kernel maps built on it.  Maps are built once and reused by every layer on the set.
+    `dims` (optional): the set lives on the dense grid of dims cells of `stride` voxels starting at 0 (a raster of
+    generate_grid, ops/generate_grids.py:3-10) — its 3x3x3 layers then run on the dense-grid kernel when it is full enough."""
 
-    def __init__(self, coords, stride=1, grid=None):
+    def __init__(self, coords, stride=1, grid=None, dims=None):
         assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
         self.coords = coords.contiguous()
         self.stride = int(stride)
+        self.dims = None if dims is None else tuple(int(d) for d in dims)
         self._grid = grid
         self._k3 = None
         self._down = None
+        self._dense = None
+
+    def conv_map(self, ksize=3):
+        """what a stride-1 k=3 layer on this set takes as its map: a DenseMap for a well-filled dense grid, else the
+        [27, N] kernel map"""
+        assert ksize == 3
+        if self.dims is not None and self.n >= DENSE_MIN_FILL * self.dims[0] * self.dims[1] * self.dims[2] \
+                and _DENSE3D_ON and self.coords.is_cuda:
+            if self._dense is None:
+                self._dense = DenseMap(self, self.dims)
+            return self._dense
+        return self.kernel_map(3)
 
     @property
     def n(self):
@@ -139,6 +227,8 @@ def sparse_conv(x, weight, nbr=None, bias=None, out=None, relu=False, accumulate
     weight = weight.contiguous()
     n_out = x.shape[0] if nbr is None else nbr.shape[1]
     assert x.shape[1] == cin and x.dtype == torch.float32
+    if isinstance(nbr, DenseMap):
+        return sparse_conv_fused(x, weight, nbr, bias, out, relu, None, accumulate)[0]
     if nbr is not None:
         assert nbr.dtype == torch.int32 and nbr.shape[0] == kvol and nbr.is_contiguous()
     if out is None:
@@ -163,6 +253,28 @@ def sparse_conv_fused(x, weight, nbr=None, bias=None, out=None, relu=False, resi
     weight = weight.contiguous()
     n_out = x.shape[0] if nbr is None else nbr.shape[1]
     assert x.shape[1] == cin and x.dtype == torch.float32
+    if isinstance(nbr, DenseMap):
+        if out is None:
+            out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+        d = _lib.ConvDesc()
+        d.x, d.n_in, d.ld_x = x.data_ptr(), x.shape[0], _ld(x)
+        d.kvol, d.n_out = kvol, n_out
+        d.weight, d.cin, d.cout = weight.data_ptr(), cin, cout
+        d.bias = None if bias is None else bias.data_ptr()
+        if residual is not None:
+            assert residual.shape == (n_out, cout)
+            d.residual, d.ld_res = residual.data_ptr(), _ld(residual)
+        d.out, d.ld_out = out.data_ptr(), _ld(out)
+        d.relu, d.accumulate = int(relu), int(accumulate)
+        keep = _resolve_map(nbr, x, weight, d, accumulate=accumulate, stats=bn_partial)
+        partial = None
+        if bn_partial:
+            partial = torch.empty((max(int(lib.eprecon_conv_desc_partial_rows(ctypes.byref(d))), 1), 3, cout),
+                                  dtype=torch.float32, device=x.device)
+            d.bn_partial = partial.data_ptr()
+        _lib.check(lib.eprecon_conv_desc_async(ctypes.byref(d), _lib.current_stream()), "eprecon_conv_desc_async")
+        del keep
+        return out, partial
     if nbr is not None:
         assert nbr.dtype == torch.int32 and nbr.shape[0] == kvol and nbr.is_contiguous()
     if out is None:
@@ -195,7 +307,8 @@ def sparse_conv_ln(x, weight, nbr, bias, ln_weight, ln_bias, ln_eps, out=None, r
         out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
     d = _lib.ConvDesc()
     d.x, d.n_in, d.ld_x = x.data_ptr(), x.shape[0], _ld(x)
-    d.nbr, d.kvol, d.n_out = (None if nbr is None else nbr.data_ptr()), kvol, n_out
+    d.kvol, d.n_out = kvol, n_out
+    keep = _resolve_map(nbr, x, weight, d, ln=True)  # noqa: F841  (alive until the launch is queued)
     d.weight, d.cin, d.cout = weight.data_ptr(), cin, cout
     d.bias = None if bias is None else bias.data_ptr()
     if residual is not None:
@@ -226,7 +339,8 @@ def conv_stats(x, weight, nbr=None, in_affine=None, out=None):
         out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
     d = _lib.ConvDesc()
     d.x, d.n_in, d.ld_x = x.data_ptr(), x.shape[0], _ld(x)
-    d.nbr, d.kvol, d.n_out = (None if nbr is None else nbr.data_ptr()), kvol, n_out
+    d.kvol, d.n_out = kvol, n_out
+    keep = _resolve_map(nbr, x, weight, d, stats=True)  # noqa: F841
     d.weight, d.cin, d.cout = weight.data_ptr(), cin, cout
     d.out, d.ld_out = out.data_ptr(), _ld(out)
     if in_affine is not None:

@@ -135,6 +135,9 @@ int eprecon_back_project_dense_async(const int32_t *dims_host, int interval, con
  */
 int eprecon_profile_conv_arm(int kvol, int cin, int cout, int64_t min_rows);
 float eprecon_profile_conv_ms(int64_t *rows_out, const char **kernel_out);
+/* live (output row, kernel offset) pairs of the bracketed launch (2 * pairs * cin * cout = its algorithmic flops),
+ * counted on the launch stream behind the stop event; blocks; -1 when nothing was recorded */
+int64_t eprecon_profile_conv_pairs(void);
 
 /* NCHW -> NHWC re-layout of a stack of feature maps: in f32[maps, C, H*W] -> out f32[maps, H*W, C] */
 int eprecon_nchw_to_nhwc_async(const float *in, float *out, int maps, int channels, int hw,
@@ -252,6 +255,15 @@ typedef struct eprecon_conv_desc {
      * (halo tile + all nine weight matrices in LDS, no kernel map); nbr is still required as the
      * fallback for shapes the tile kernel does not take */
     int img_h; int img_w; int img_maps;
+    /* dense-grid form of a 3x3x3 stride-1 convolution (kvol == 27) for voxel sets that fill most of their bounding
+     * grid (the submanifold stack of models/occupancy_initialization.py:131-174 on the dense 48^3 grid): vox_rank
+     * int32[grid_x*grid_y*grid_z] from eprecon_grid_rank_async maps a grid cell to its voxel's row (-1: none),
+     * packed_weight from eprecon_conv_pack_weight_async holds `weight` in MFMA operand order.  Layers the tile kernel
+     * takes (cin % 4 == 0, cin <= 64; cout == 1 needs no packed weights) run as an implicit GEMM on 4x4x8-cell tiles
+     * with the halo rows staged once in LDS: no kernel map, nbr may be NULL.  Results are bit-identical to the gather
+     * form (cout == 1: same sums in another order).  Other shapes fall back to nbr (EPRECON_ERR_ARG when it is NULL). */
+    const int32_t *vox_rank; int grid_x; int grid_y; int grid_z;
+    const float *packed_weight;
 } eprecon_conv_desc;
 int eprecon_conv_desc_async(const eprecon_conv_desc *desc, void *stream);
 /* number of bn_partial rows the launch described by desc writes (nblk of the finalize call) */
@@ -272,6 +284,18 @@ int eprecon_affine_rows_async(const float *x, int64_t n, int channels, int ld_x,
  * runs on eprecon_sparse_conv_fused_async (weight re-laid out to [ky*ks+kx][cin][cout]).
  */
 int eprecon_pixel_map_async(int maps, int height, int width, int ksize, int32_t *nbr, void *stream);
+/*
+ * Rank volume of a voxel set that lives on a dense grid (coords int32[n,4] (b,x,y,z), multiples of `stride`,
+ * 0 <= x / stride < grid_x ...): rank int32[grid_x*grid_y*grid_z + 1], z fastest; rank[cell] = row of the voxel or -1,
+ * the last element counts voxels off the grid (0 for a valid set).  Replaces the hash grid + 27-offset kernel map
+ * for the dense-grid convolution form of eprecon_conv_desc (the role spconv's indice pairs play at
+ * models/modules.py:260-271 for the reference).
+ */
+int eprecon_grid_rank_async(const int32_t *coords, int64_t n, int stride, int grid_x, int grid_y, int grid_z, int32_t *rank,
+                            void *stream);
+/* weight f32[kvol][cin][cout] -> the operand order of the dense-grid kernel (eprecon_conv_pack_weight_floats floats) */
+size_t eprecon_conv_pack_weight_floats(int kvol, int cin, int cout);
+int eprecon_conv_pack_weight_async(const float *weight, int kvol, int cin, int cout, float *packed, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Normalisation epilogues  (K12)
