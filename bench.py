@@ -232,7 +232,12 @@ def extra_workloads(device, lib, steps3=12, steps4=16, warm4=4):
         out["e2e_workload"] = step.describe()["workload"]
 
     def train():
-        step = TrainStep(seed=0, device=device)
+        # lr 1e-6: with seeded-random weights on noise features the occupancy logits of a level differ by ~1e-2 between
+        # voxels, so ONE Adam step at the reference's 1e-4 (every parameter moves by lr in a coherent direction) shifts
+        # them all by about a standard deviation and the next forward keeps 80 % instead of 35 % of a level (measured:
+        # step 2 runs into the reference's 1.5 x cap guard).  Adam's arithmetic does not depend on lr; a small one keeps
+        # the nine steps in the calibrated sparsity regime so that every timed step is the full workload.
+        step = TrainStep(seed=0, device=device, lr=1e-6)
         step.raise_on_early_return = False     # counted instead: the number below is reported only over FULL steps
         for _ in range(3):
             step.run()
@@ -248,7 +253,7 @@ def extra_workloads(device, lib, steps3=12, steps4=16, warm4=4):
         out["train_full_steps"] = len(full_ms)
         out["train_early_returns"] = n_early
         out["train_finest_voxels_min_max"] = [min(step.voxels), max(step.voxels)] if step.voxels else None
-        out["train_workload"] = step.describe()["workload"]
+        out["train_workload"] = step.describe()["workload"] + " (lr 1e-6, see bench.py)"
 
     leg("cfg34", cfg34)
     leg("e2e", e2e)

@@ -82,6 +82,7 @@ struct ConvParams {
     const int32_t *vox_rank;
     int gx, gy, gz;
     const float *wq;
+    int debug;  // EPRECON_D3_ABLATE (timing experiments only): 1 no MFMA loop, 4 no halo row loads
 };
 
 // Stage `rows` x TN weights (zero padded) from w[row0 + r][0:ncols] (row stride `stride`, rows valid
@@ -968,13 +969,29 @@ int launch_conv2d_tile(const ConvParams &p, hipStream_t st)
 // No kernel map and no hash grid are needed for such layers.
 //   wave w -> x = x0 + w; MFMA row r32 -> (y, z) = (y0 + r32 / 8, z0 + r32 % 8)
 // ---------------------------------------------------------------------------------------------
-constexpr int kD3X = 4, kD3Y = 4, kD3Z = 8;
-constexpr int kD3HX = kD3X + 2, kD3HY = kD3Y + 2, kD3HZ = kD3Z + 2;
-constexpr int kD3Halo = kD3HX * kD3HY * kD3HZ;  // 360
+// tile = WV x 4 x 8 cells, one wave per x slice (WV waves per workgroup).  WV = 2 for the MFMA kernel: what balances the
+// chip is the number of 32-row wave jobs (11.5 us of MFMAs each at C_in = C_out = 32) per SIMD, and 64-cell workgroups
+// with a 35 KB halo fit four to a CU where 128-cell workgroups with 52 KB fit three and ran the 94k-voxel layer in two
+// rounds (measured 88 us against 73 us for the gather form; profiles/r03/conv3d_probe.txt)
+constexpr int kD3Y = 4, kD3Z = 8;
+constexpr int kD3HY = kD3Y + 2, kD3HZ = kD3Z + 2;
+constexpr int d3_halo(int wv) { return (wv + 2) * kD3HY * kD3HZ; }
+constexpr int kD3WvNarrow = 4;
+// x extent (= waves) of the MFMA kernel's tile: 2 by default, EPRECON_D3_WV=4 for A/B runs
+inline int d3_wv_mfma()
+{
+    static const int wv = (getenv("EPRECON_D3_WV") && atoi(getenv("EPRECON_D3_WV")) == 4) ? 4 : 2;
+    return wv;
+}
 
-struct RankRows {  // output rows of a wave's 32 grid cells, from LDS
-    const int *r;
-    __device__ __forceinline__ int operator()(int i) const { return r[i]; }
+struct RegRows {  // output rows of a lane's 16 accumulator rows, held in registers: tile row i = (r & 3) + 8 (r >> 2) + 4 half
+    const int (&row)[16];
+    int half;
+    __device__ __forceinline__ int operator()(int i) const
+    {
+        const int j = i - 4 * half;  // (the epilogues only ask for this lane's rows; i is a compile-time function of r)
+        return row[(j & 3) + 4 * (j >> 3)];
+    }
 };
 
 // Weights [K][Cin][Cout] -> MFMA operand order, zero padded, one slab per block of 32 * nt output columns:
@@ -997,35 +1014,41 @@ __global__ void pack_weights_kernel(const float *w, int K, int Cin, int Cout, in
 // the (NT, column blocks) the dense-grid kernel uses for C_out output channels; the packing follows it
 inline void d3_columns(int cout, int *nt, int *ncb) { *nt = cout <= 32 ? 1 : 2; *ncb = (cout + 32 * *nt - 1) / (32 * *nt); }
 
+template <int WV>
 __device__ __forceinline__ void d3_tile_origin(int tile, int tiles_y, int tiles_z, int &x0, int &y0, int &z0)
 {
     const int tz = tile % tiles_z, ty = (tile / tiles_z) % tiles_y, tx = tile / (tiles_z * tiles_y);
-    x0 = tx * kD3X; y0 = ty * kD3Y; z0 = tz * kD3Z;
+    x0 = tx * WV; y0 = ty * kD3Y; z0 = tz * kD3Z;
 }
 
-// steps 1 + 2 of the tile kernels: ranks of the halo cells -> sRank, halo rows -> sX (pitch P floats).
+// steps 1 + 2 of the tile kernels: the row (rank) of every halo cell -> the first pad word of the cell, halo rows -> sX
+// (pitch P = cin_pad + 4 floats; no separate rank array: 51,840 bytes at C_in = 32, three workgroups per CU).
 // Returns false (block-uniform) when no cell of the tile holds a voxel.
-template <int NCH>
-__device__ __forceinline__ bool d3_stage_halo(const ConvParams &p, int x0, int y0, int z0, float *sX, int *sRank, int tid)
+__device__ __forceinline__ int d3_rank(const float *sX, int cell, int P, int cin_pad) { return __float_as_int(sX[cell * P + cin_pad]); }
+
+template <int NCH, int WV>
+__device__ __forceinline__ bool d3_stage_halo(const ConvParams &p, int x0, int y0, int z0, float *sX, int tid, int dbg)
 {
     constexpr int cin_pad = NCH * 8, P = cin_pad + 4, C4 = cin_pad / 4;
-    for (int e = tid; e < kD3Halo; e += 256) {
+    constexpr int kThreads = 64 * WV, kD3Halo = d3_halo(WV);
+    for (int e = tid; e < kD3Halo; e += kThreads) {
         const int hz = e % kD3HZ, hy = (e / kD3HZ) % kD3HY, hx = e / (kD3HZ * kD3HY);
         const int x = x0 - 1 + hx, y = y0 - 1 + hy, z = z0 - 1 + hz;
         const bool in = x >= 0 && x < p.gx && y >= 0 && y < p.gy && z >= 0 && z < p.gz;
-        sRank[e] = in ? p.vox_rank[((size_t)x * p.gy + y) * p.gz + z] : -1;
+        sX[e * P + cin_pad] = __int_as_float(in ? p.vox_rank[((size_t)x * p.gy + y) * p.gz + z] : -1);
     }
     __syncthreads();
-    // this thread's output cell (256 threads cover the 128 cells twice)
-    const int v = tid & 127;
-    const int own = sRank[(((v >> 5) + 1) * kD3HY + ((v >> 3) & 3) + 1) * kD3HZ + (v & 7) + 1];
+    // this thread's output cell (the 64 WV threads cover the 32 WV cells twice)
+    const int v = tid % (32 * WV);
+    const int own = d3_rank(sX, (((v >> 5) + 1) * kD3HY + ((v >> 3) & 3) + 1) * kD3HZ + (v & 7) + 1, P, cin_pad);
     if (!__syncthreads_or(own >= 0)) return false;
     constexpr int kItems = kD3Halo * C4;
-    constexpr int kIter = (kItems + 255) / 256;
+    constexpr int kIter = (kItems + kThreads - 1) / kThreads;
     float4 hv[kIter];
+    int hr[kIter];
     const int last4 = ((p.Cin + 3) & ~3) - 4;
-    // the channel group of an item is tid % C4 in every iteration when C4 divides 256: its scale / shift are loaded once
-    constexpr bool kFixedGroup = 256 % C4 == 0;
+    // the channel group of an item is tid % C4 in every iteration when C4 divides the block size: its scale / shift are loaded once
+    constexpr bool kFixedGroup = kThreads % C4 == 0;
     float4 sc0 = make_float4(1.f, 1.f, 1.f, 1.f), sh0 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (kFixedGroup && p.in_scale) {
         sc0 = *reinterpret_cast<const float4 *>(p.in_scale + min((tid % C4) * 4, last4));
@@ -1033,14 +1056,15 @@ __device__ __forceinline__ bool d3_stage_halo(const ConvParams &p, int x0, int y
     }
 #pragma unroll
     for (int it = 0; it < kIter; ++it) {  // all loads first (clamped addresses), then the fix-ups and LDS stores
-        const int e = min(tid + it * 256, kItems - 1);
+        const int e = min(tid + it * kThreads, kItems - 1);
         const int cell = e / C4, c4 = e - cell * C4;
-        const int r = sRank[cell];
-        hv[it] = *reinterpret_cast<const float4 *>(p.x + (size_t)max(r, 0) * p.ld_x + min(c4 * 4, last4));
+        hr[it] = d3_rank(sX, cell, P, cin_pad);
+        if (dbg & 4) hv[it] = make_float4(1.f, 1.f, 1.f, 1.f);
+        else hv[it] = *reinterpret_cast<const float4 *>(p.x + (size_t)max(hr[it], 0) * p.ld_x + min(c4 * 4, last4));
     }
 #pragma unroll
     for (int it = 0; it < kIter; ++it) {
-        const int e = tid + it * 256;
+        const int e = tid + it * kThreads;
         if (e >= kItems) break;
         const int cell = e / C4, c4 = e - cell * C4;
         const int c = c4 * 4;
@@ -1057,23 +1081,21 @@ __device__ __forceinline__ bool d3_stage_halo(const ConvParams &p, int x0, int y
                 v4.x = fmaxf(v4.x, 0.f); v4.y = fmaxf(v4.y, 0.f); v4.z = fmaxf(v4.z, 0.f); v4.w = fmaxf(v4.w, 0.f);
             }
         }
-        if (sRank[cell] < 0 || c >= p.Cin) v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (hr[it] < 0 || c >= p.Cin) v4 = make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4 *>(sX + cell * P + c) = v4;
     }
     __syncthreads();
     return true;
 }
 
-template <int NT, int NCH>
-__global__ __launch_bounds__(256) void conv3d_tile_kernel(ConvParams p, int tiles_y, int tiles_z, int ntiles)
+template <int NT, int NCH, int WV>
+__global__ __launch_bounds__(64 * WV) void conv3d_tile_kernel(ConvParams p, int tiles_y, int tiles_z, int ntiles)
 {
     constexpr int cin_pad = NCH * 8;
     constexpr int P = cin_pad + 4;  // LDS cell pitch in floats: an odd number of 16-byte units
     constexpr int TN = 32 * NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *sX = reinterpret_cast<float *>(smem);             // [kD3Halo][P]
-    int *sRank = reinterpret_cast<int *>(sX + kD3Halo * P);  // [kD3Halo] rows of the halo cells
-    int *sOut = sRank + kD3Halo;                             // [128] rows of the tile's own cells, wave-major
+    float *sX = reinterpret_cast<float *>(smem);             // [d3_halo(WV)][P]: cin_pad channels + the cell's row + 3 pad words
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, half = lane >> 5;
@@ -1081,9 +1103,10 @@ __global__ __launch_bounds__(256) void conv3d_tile_kernel(ConvParams p, int tile
     if (tile >= ntiles) return;
     const int col0 = blockIdx.y * TN;
     int x0, y0, z0;
-    d3_tile_origin(tile, tiles_y, tiles_z, x0, y0, z0);
+    d3_tile_origin<WV>(tile, tiles_y, tiles_z, x0, y0, z0);
 
-    if (!d3_stage_halo<NCH>(p, x0, y0, z0, sX, sRank, tid)) {
+    const int dbg = p.debug;
+    if (!d3_stage_halo<NCH, WV>(p, x0, y0, z0, sX, tid, dbg)) {
         if (p.bn_partial && tid < TN && col0 + tid < p.Cout) {  // an empty summary row: the finalize skips count 0
             float *dst = p.bn_partial + (size_t)tile * 3 * p.Cout + col0 + tid;
             dst[0] = 0.0f; dst[p.Cout] = 0.0f; dst[2 * p.Cout] = 0.0f;
@@ -1091,8 +1114,15 @@ __global__ __launch_bounds__(256) void conv3d_tile_kernel(ConvParams p, int tile
         return;
     }
     const int cell0 = ((wave + 1) * kD3HY + (r32 >> 3) + 1) * kD3HZ + (r32 & 7) + 1;  // this lane's own cell in the halo
-    const int own = sRank[cell0];
-    if (half == 0) sOut[wave * 32 + r32] = own;
+    const int own = d3_rank(sX, cell0, P, cin_pad);
+    // rows of this lane's 16 accumulator rows (tile row i -> cell (wave, i / 8, i % 8)), read before the epilogue's
+    // scratch may overlay the halo
+    int orow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        orow[r] = d3_rank(sX, ((wave + 1) * kD3HY + (i >> 3) + 1) * kD3HZ + (i & 7) + 1, P, cin_pad);
+    }
 
     f32x16 acc[NT];
 #pragma unroll
@@ -1100,7 +1130,7 @@ __global__ __launch_bounds__(256) void conv3d_tile_kernel(ConvParams p, int tile
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    if (__ballot(own >= 0) != 0ull) {  // (wave-uniform) a wave without a voxel has nothing to accumulate
+    if (__ballot(own >= 0) != 0ull && !(dbg & 1)) {  // (wave-uniform) a wave without a voxel has nothing to accumulate
         // A operands: LDS address of the halo cell at offset (-1, -1, -1) of this lane's cell; offset k adds a
         // wave-uniform multiple of the cell pitch, the chunks are immediates of the ds_read
         const float *xa = sX + (cell0 - (kD3HY + 1) * kD3HZ - 1) * P + 4 * half;
@@ -1111,7 +1141,13 @@ __global__ __launch_bounds__(256) void conv3d_tile_kernel(ConvParams p, int tile
         const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(p.wq) + (size_t)blockIdx.y * 27 * (kOffBytes / 4), 0, (int)(27 * kOffBytes), 0x00020000);
         const unsigned wlane = (unsigned)half * NT * 512u + (unsigned)r32 * 16u;
-        float4 bc[NCH][NT], bn[NCH][NT];
+        // Software pipeline over the 27 offsets, fully unrolled (every LDS / weight offset is an immediate): the weights of
+        // offset k + kAheadB and the A operands of offset k + 1 are requested BEFORE the MFMAs of offset k, and scheduling
+        // fences keep the compiler from sinking them (a weight fetch is an L2 round trip of ~1 us under load: with one
+        // offset of cover the loop ran at 55 % of the MFMA rate, profiles/r03/conv3d_probe.txt).
+        constexpr int kAheadB = (NCH * NT <= 8) ? 2 : 1;
+        float4 bq[kAheadB + 1][NCH][NT];
+        float4 aq[2][NCH];
         auto load_b = [&](int k, float4(&dst)[NCH][NT]) {
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch)
@@ -1122,36 +1158,39 @@ __global__ __launch_bounds__(256) void conv3d_tile_kernel(ConvParams p, int tile
                     dst[ch][t] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
                 }
         };
-        load_b(0, bc);
-#pragma unroll 1
-        for (int k = 0; k < 27; ++k) {
-            // the weights of the NEXT offset are requested before this offset's MFMAs (a whole offset = 4 * NCH * NT MFMAs of
-            // cover for the L2 round trip); the scheduling barrier keeps the compiler from sinking them behind the MFMAs
-            load_b(min(k + 1, 26), bn);
-            __builtin_amdgcn_sched_barrier(0);
+        auto load_a = [&](int k, float4(&dst)[NCH]) {
             const int dx = k % 3, dy = (k / 3) % 3, dz = k / 9;
             const float *xk = xa + ((dx * kD3HY + dy) * kD3HZ + dz) * P;
-            float4 av[NCH];
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) av[ch] = *reinterpret_cast<const float4 *>(xk + ch * 8);
+            for (int ch = 0; ch < NCH; ++ch) dst[ch] = *reinterpret_cast<const float4 *>(xk + ch * 8);
+        };
+#pragma unroll
+        for (int k = 0; k < kAheadB; ++k) load_b(k, bq[k]);
+        load_a(0, aq[0]);
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            if (k + kAheadB < 27) load_b(k + kAheadB, bq[(k + kAheadB) % (kAheadB + 1)]);
+            if (k + 1 < 27) load_a(k + 1, aq[(k + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const float4(&av)[NCH] = aq[k & 1];
+            const float4(&bk)[NCH][NT] = bq[k % (kAheadB + 1)];
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ch].x, bc[ch][t].x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ch].y, bc[ch][t].y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ch].z, bc[ch][t].z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ch].w, bc[ch][t].w, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ch].x, bk[ch][t].x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ch].y, bk[ch][t].y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ch].z, bk[ch][t].z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ch].w, bk[ch][t].w, acc[t], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) bc[ch][t] = bn[ch][t];
         }
     }
-    __syncthreads();  // every wave is done with the halo (the epilogue's scratch overlays it); sOut is written
-    conv_epilogue<NT>(p, acc, RankRows{sOut + wave * 32}, col0, r32, half, wave, sX, tile);
+    __syncthreads();  // every wave is done with the halo (the epilogue's scratch overlays it)
+    if (p.bn_partial) {   // the shared epilogue merges kWaves wave summaries: the slots of the waves this block does not have are empty
+        for (int e = tid; e < (kWaves - WV) * 3 * TN; e += 64 * WV) sX[WV * 3 * TN + e] = 0.0f;
+    }
+    conv_epilogue<NT>(p, acc, RegRows{orow, half}, col0, r32, half, wave, sX, tile);
 }
 
 // C_out == 1 (the occupancy-logit layer, models/occupancy_initialization.py:171): a 32-column MFMA tile would spend 31/32
@@ -1162,22 +1201,23 @@ template <int NCH>
 __global__ __launch_bounds__(256) void conv3d_tile_narrow_kernel(ConvParams p, int tiles_y, int tiles_z, int ntiles)
 {
     constexpr int cin_pad = NCH * 8, P = cin_pad + 4, C4 = cin_pad / 4;
+    constexpr int WV = kD3WvNarrow, kD3Halo = d3_halo(WV);
+    static_assert(WV == 4, "the cell mapping below covers 128 cells with 256 threads");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *sX = reinterpret_cast<float *>(smem);
-    int *sRank = reinterpret_cast<int *>(sX + kD3Halo * P);
-    float *sWn = reinterpret_cast<float *>(sRank + kD3Halo);  // [27][cin_pad] weights of the single column, zero padded
+    float *sWn = sX + kD3Halo * P;                            // [27][cin_pad] weights of the single column, zero padded
     float *sRed = sWn + 27 * cin_pad;                          // [4][3] wave summaries
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     if (tile >= ntiles) return;
     int x0, y0, z0;
-    d3_tile_origin(tile, tiles_y, tiles_z, x0, y0, z0);
+    d3_tile_origin<WV>(tile, tiles_y, tiles_z, x0, y0, z0);
     for (int e = tid; e < 27 * cin_pad; e += 256) {
         const int k = e / cin_pad, c = e - k * cin_pad;
         sWn[e] = c < p.Cin ? p.w[((size_t)k * p.Cin + c) * p.Cout] : 0.0f;
     }
-    if (!d3_stage_halo<NCH>(p, x0, y0, z0, sX, sRank, tid)) {  // (its barriers also publish sWn)
+    if (!d3_stage_halo<NCH, WV>(p, x0, y0, z0, sX, tid, p.debug)) {  // (its barriers also publish sWn)
         if (p.bn_partial && tid == 0) {
             float *dst = p.bn_partial + (size_t)tile * 3 * p.Cout;
             dst[0] = 0.0f; dst[p.Cout] = 0.0f; dst[2 * p.Cout] = 0.0f;
@@ -1186,7 +1226,7 @@ __global__ __launch_bounds__(256) void conv3d_tile_narrow_kernel(ConvParams p, i
     }
     const int v = tid >> 1, part = tid & 1;  // cell (x = v / 32, y = (v / 8) % 4, z = v % 8), half of the channel groups
     const int cell0 = (((v >> 5) + 1) * kD3HY + ((v >> 3) & 3) + 1) * kD3HZ + (v & 7) + 1;
-    const int row = sRank[cell0];
+    const int row = d3_rank(sX, cell0, P, cin_pad);
     float acc = 0.0f;
 #pragma unroll
     for (int k = 0; k < 27; ++k) {
@@ -1238,56 +1278,75 @@ __global__ __launch_bounds__(256) void conv3d_tile_narrow_kernel(ConvParams p, i
     }
 }
 
-int d3_tiles(const ConvParams &p, int *ty = nullptr, int *tz = nullptr)
+int d3_tiles(const ConvParams &p, bool narrow, int *ty = nullptr, int *tz = nullptr)
 {
-    const int tx = (p.gx + kD3X - 1) / kD3X, tyy = (p.gy + kD3Y - 1) / kD3Y, tzz = (p.gz + kD3Z - 1) / kD3Z;
+    const int wv = narrow ? kD3WvNarrow : d3_wv_mfma();
+    const int tx = (p.gx + wv - 1) / wv, tyy = (p.gy + kD3Y - 1) / kD3Y, tzz = (p.gz + kD3Z - 1) / kD3Z;
     if (ty) *ty = tyy;
     if (tz) *tz = tzz;
     return tx * tyy * tzz;
 }
 size_t conv3d_tile_lds(int nch, bool narrow)
 {
-    const size_t base = ((size_t)kD3Halo * (nch * 8 + 4)) * sizeof(float) + (size_t)kD3Halo * sizeof(int);
-    return base + (narrow ? ((size_t)27 * nch * 8 + 16) * sizeof(float) : (size_t)128 * sizeof(int));
+    const size_t base = ((size_t)d3_halo(narrow ? kD3WvNarrow : d3_wv_mfma()) * (nch * 8 + 4)) * sizeof(float);
+    return base + (narrow ? ((size_t)27 * nch * 8 + 16) * sizeof(float) : 0);
 }
 
 // eligibility of the dense-grid kernels (independent of the data: shapes, alignment, fusions)
+// EPRECON_CONV_DENSE3D: 0 off; 1 (default) the single-column kernel only; 2 the MFMA tile kernel as well.  Measured on the
+// 94k-voxel initialisation set (profiles/r03/conv3d_*): 32 -> 1 24 us against 82 us for the gather form; 32 -> 32 97 us
+// against 78 us — 3,185 non-empty 32-row wave jobs of 11.5 us on 1,024 SIMDs are 3.1 per SIMD, i.e. FOUR rounds (46 us
+// of MFMAs at best) where the gather form's 2,937 compacted jobs need three; see DESIGN.md 3b.
+inline int d3_level()
+{
+    const char *e = getenv("EPRECON_CONV_DENSE3D");   // (read per launch: tests and probes flip it)
+    return e ? atoi(e) : 1;
+}
+
 bool conv3d_tile_ok(const ConvParams &p, bool *narrow)
 {
-    static const bool on = !(getenv("EPRECON_CONV_DENSE3D") && getenv("EPRECON_CONV_DENSE3D")[0] == '0');
-    if (!on || !p.vox_rank || p.K != 27 || p.gx <= 0 || p.gy <= 0 || p.gz <= 0 || p.bn_scale_out) return false;
+    const int level = d3_level();
+    *narrow = false;
+    if (level <= 0 || !p.vox_rank || p.K != 27 || p.gx <= 0 || p.gy <= 0 || p.gz <= 0 || p.bn_scale_out) return false;
     if (p.Cin % 4 != 0 || p.Cin > 64 || p.ld_x % 4 != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0) return false;
     if (p.in_scale && ((reinterpret_cast<uintptr_t>(p.in_scale) & 15) != 0 || (reinterpret_cast<uintptr_t>(p.in_shift) & 15) != 0))
         return false;
     *narrow = p.Cout == 1 && !p.ln;
     if (*narrow) return true;
+    if (level < 2) return false;
     if (!p.wq || (reinterpret_cast<uintptr_t>(p.wq) & 15) != 0 || p.accumulate) return false;
     if (p.ln && (p.Cout > 64 || p.bn_partial)) return false;
     return true;
 }
 
-template <int NT, int NCH>
-int launch_conv3d_tile(const ConvParams &p, hipStream_t st)
+template <int NT, int NCH, int WV>
+int launch_conv3d_tile_wv(const ConvParams &p, hipStream_t st)
 {
     int ty, tz;
-    const int ntiles = d3_tiles(p, &ty, &tz);
+    const int ntiles = d3_tiles(p, false, &ty, &tz);
     const size_t lds = max(conv3d_tile_lds(NCH, false), (size_t)max(kWaves * 3 * 32 * NT, 3 * 256) * sizeof(float));
     if (lds > 64 * 1024) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_tile_kernel<NT, NCH>),
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_tile_kernel<NT, NCH, WV>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (attr != hipSuccess) return EPRECON_ERR_HIP_BASE - (int)attr;
     }
     const dim3 grid((unsigned)ntiles, (unsigned)ceil_div(p.Cout, 32 * NT));  // == d3_columns' ncb
-    hipLaunchKernelGGL((conv3d_tile_kernel<NT, NCH>), grid, dim3(256), lds, st, p, ty, tz, ntiles);
+    hipLaunchKernelGGL((conv3d_tile_kernel<NT, NCH, WV>), grid, dim3(64 * WV), lds, st, p, ty, tz, ntiles);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
+}
+
+template <int NT, int NCH>
+int launch_conv3d_tile(const ConvParams &p, hipStream_t st)
+{
+    return d3_wv_mfma() == 4 ? launch_conv3d_tile_wv<NT, NCH, 4>(p, st) : launch_conv3d_tile_wv<NT, NCH, 2>(p, st);
 }
 
 template <int NCH>
 int launch_conv3d_narrow(const ConvParams &p, hipStream_t st)
 {
     int ty, tz;
-    const int ntiles = d3_tiles(p, &ty, &tz);
+    const int ntiles = d3_tiles(p, true, &ty, &tz);
     const size_t lds = conv3d_tile_lds(NCH, true);
     if (lds > 64 * 1024) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_tile_narrow_kernel<NCH>),
@@ -1616,6 +1675,7 @@ int conv_dispatch_inner(ConvParams &p, int64_t n_in, hipStream_t st)
         bool narrow;
         if (conv3d_tile_ok(p, &narrow)) {
             g_last_conv_kernel = narrow ? "conv3d_tile_narrow_kernel" : "conv3d_tile_kernel";
+            p.debug = getenv("EPRECON_D3_ABLATE") ? atoi(getenv("EPRECON_D3_ABLATE")) : 0;  // (read per launch: probes flip it)
             return launch_conv3d(p, narrow, st);
         }
         if (!p.nbr && p.K != 1) return EPRECON_ERR_ARG;  // dense-grid form requested for a shape it does not take, no map given
@@ -1792,7 +1852,7 @@ extern "C" int64_t eprecon_conv_desc_partial_rows(const eprecon_conv_desc *d)
     int nt, nch;
     int64_t blocks;
     bool narrow;
-    if (conv3d_tile_ok(p, &narrow)) return d3_tiles(p);
+    if (conv3d_tile_ok(p, &narrow)) return d3_tiles(p, narrow);
     if (conv2d_tile_ok(p, &nt, &nch, &blocks)) return blocks;
     if (splitk_ok(p)) return ep::ceil_div(d->n_out, (int64_t)32);
     return ep::ceil_div(d->n_out, (int64_t)kRowsPerBlock);

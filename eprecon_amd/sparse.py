@@ -14,7 +14,10 @@ from . import _lib
 
 import os
 
-_DENSE3D_ON = os.environ.get("EPRECON_CONV_DENSE3D", "1") != "0"
+def _dense3d_level():
+    """EPRECON_CONV_DENSE3D: 0 off, 1 (default) the single-column (C_out == 1) kernel only, 2 the MFMA tile kernel too
+    (bit-identical to the gather form but slower on the 94k-voxel initialisation set: csrc/sparse_conv.hip, d3_level)"""
+    return int(os.environ.get("EPRECON_CONV_DENSE3D", "1"))
 
 
 def _ld(t):
@@ -104,11 +107,12 @@ class DenseMap:
 
     def takes(self, x, cin, cout, accumulate=False, ln=False, stats=False):
         """mirror of the library's eligibility rule (conv3d_tile_ok, csrc/sparse_conv.hip)"""
-        if cin % 4 or cin > 64 or x.stride(0) % 4 or x.data_ptr() % 16 or accumulate:
+        level = _dense3d_level()
+        if level <= 0 or cin % 4 or cin > 64 or x.stride(0) % 4 or x.data_ptr() % 16:
             return False
         if cout == 1 and not ln:
             return True
-        return not (ln and (cout > 64 or stats))
+        return level >= 2 and not accumulate and not (ln and (cout > 64 or stats))
 
 
 def packed_weight(weight):
@@ -167,7 +171,7 @@ class VoxelSet:
         [27, N] kernel map"""
         assert ksize == 3
         if self.dims is not None and self.n >= DENSE_MIN_FILL * self.dims[0] * self.dims[1] * self.dims[2] \
-                and _DENSE3D_ON and self.coords.is_cuda:
+                and _dense3d_level() > 0 and self.coords.is_cuda:
             if self._dense is None:
                 self._dense = DenseMap(self, self.dims)
             return self._dense

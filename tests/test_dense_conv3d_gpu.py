@@ -13,6 +13,12 @@ from oracle import sparse as OS  # noqa: E402
 TOL = 1e-3
 
 
+@pytest.fixture(autouse=True)
+def all_dense_kernels(monkeypatch):
+    """by default only the single-column kernel is taken (EPRECON_CONV_DENSE3D=1); these tests cover the MFMA tile kernel too"""
+    monkeypatch.setenv("EPRECON_CONV_DENSE3D", "2")
+
+
 def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
@@ -136,6 +142,16 @@ def test_single_column_kernel(dims, stride, fill, cin):
     m2 = (p[:, 2, 0] + cnt * (p[:, 1, 0] - mean) ** 2).sum()
     yv = y.cpu().numpy().astype(np.float64)[:, 0]
     assert abs(mean - yv.mean()) < 1e-5 and abs(m2 / n - yv.var()) < 1e-5 * max(1.0, yv.var())
+
+
+def test_default_level_takes_only_the_single_column_kernel(monkeypatch):
+    from eprecon_amd import sparse as SP
+    monkeypatch.setenv("EPRECON_CONV_DENSE3D", "1")
+    rng, c, vs, dm = sets((16, 16, 16), 1, 1.0, 11)
+    x = dev(rng.standard_normal((len(c), 32)).astype(np.float32))
+    assert dm.takes(x, 32, 1) and not dm.takes(x, 32, 32)
+    w = dev((rng.standard_normal((27, 32, 32)) / 30).astype(np.float32))
+    assert torch.equal(SP.sparse_conv(x, w, dm), SP.sparse_conv(x, w, vs.kernel_map(3)))   # falls back to the map
 
 
 def test_sparse_set_falls_back_to_the_kernel_map():

@@ -11,7 +11,11 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def step():
     from eprecon_amd.fragment_step import TrainStep
-    return TrainStep(seed=0, lr=2e-4)
+    # lr: one Adam step moves every parameter by lr in a coherent direction; on seeded-random weights and noise features
+    # 2e-4 shifts all occupancy logits of a level by about their standard deviation and the next forward trips the
+    # reference's 1.5 x cap guard (models/neucon_network.py:473-475); at 2e-5 the finest level still grows by a quarter per step.
+    # 2e-6 keeps six steps inside the calibrated regime (the loss still falls monotonically: same fragment, seeded sub-sampling).
+    return TrainStep(seed=0, lr=2e-6)
 
 
 def test_recording_forward_equals_inference_forward(step):
@@ -50,9 +54,10 @@ def test_every_used_parameter_and_the_image_features_receive_gradients(step):
 
 
 def test_optimisation_steps_reduce_the_loss(step):
-    first = step.run()["total_loss"]
+    first = step.run()["total_loss"]          # (TrainStep.run raises when a forward returns before the set criterion)
     for _ in range(5):
         last = step.run()["total_loss"]
+    assert step.early_returns == 0 and len(step.voxels) >= 6
     assert np.isfinite(last) and last < first, (first, last)
 
 
@@ -77,10 +82,10 @@ def test_ddp_wraps_the_training_step_single_rank():
         dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         from torch.nn.parallel import DistributedDataParallel
-        s = TrainStep(seed=1, lr=1e-4)
+        s = TrainStep(seed=1, lr=2e-6)   # (lr: see the `step` fixture)
         s.model = DistributedDataParallel(s.net, device_ids=[0], output_device=0, broadcast_buffers=False,
                                           find_unused_parameters=True)
-        s.optimizer = torch.optim.Adam(s.model.parameters(), lr=1e-4)
+        s.optimizer = torch.optim.Adam(s.model.parameters(), lr=2e-6)
         a = s.run()
         b = s.run()
         assert np.isfinite(a["total_loss"]) and np.isfinite(b["total_loss"])
