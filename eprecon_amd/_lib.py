@@ -44,6 +44,8 @@ SIGNATURES = {
                                              _vp, _vp]),
     "eprecon_conv_desc_async": (_i, [_vp, _vp]),
     "eprecon_conv_desc_partial_rows": (_i64, [_vp]),
+    "eprecon_conv_bn_finalize_workspace_bytes": (_sz, [_i64, _i]),
+    "eprecon_affine_rows_res_async": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "eprecon_batchnorm_finalize_affine_async": (_i, [_vp, _i64, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "eprecon_affine_rows_async": (_i, [_vp, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "eprecon_pixel_map_async": (_i, [_i, _i, _i, _i, _vp, _vp]),

@@ -215,6 +215,19 @@ __global__ __launch_bounds__(256) void affine_rows_kernel(const float *x, int n,
     out[(size_t)r * ld_out + c] = v;
 }
 
+__global__ __launch_bounds__(256) void affine_rows_res_kernel(const float *x, int n, int C, int ld_x, const float *scale,
+                                                              const float *shift, const float *res, int ld_res, int relu,
+                                                              float *out, int ld_out)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)n * C) return;
+    const int r = (int)(e / C), c = (int)(e - (size_t)r * C);
+    float v = fmaf(x[(size_t)r * ld_x + c], scale[c], shift[c]);
+    if (res) v += res[(size_t)r * ld_res + c];
+    if (relu) v = fmaxf(v, 0.0f);
+    out[(size_t)r * ld_out + c] = v;
+}
+
 int bn_finalize_apply(const float *x, int64_t n, int channels, int ld_x, const float *partial, int nblk,
                       const float *gamma, const float *beta, float eps, const float *residual, int ld_res,
                       int relu, float *out, int ld_out, float *mean, float *var, hipStream_t st)
@@ -317,6 +330,20 @@ int eprecon_affine_rows_async(const float *x, int64_t n, int channels, int ld_x,
     if (n == 0) return EPRECON_OK;
     hipLaunchKernelGGL(affine_rows_kernel, dim3((unsigned)ceil_div(n * channels, (int64_t)256)), dim3(256), 0,
                        (hipStream_t)stream, x, (int)n, channels, ld_x, scale, shift, relu, out, ld_out);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_affine_rows_res_async(const float *x, int64_t n, int channels, int ld_x, const float *scale,
+                                  const float *shift, const float *residual, int ld_res, int relu, float *out,
+                                  int ld_out, void *stream)
+{
+    if (!x || !out || !scale || !shift || n < 0 || channels <= 0 || ld_x < channels || ld_out < channels ||
+        (residual && ld_res < channels) || n * channels > 0x7fffffffll * 256)
+        return EPRECON_ERR_ARG;
+    if (n == 0) return EPRECON_OK;
+    hipLaunchKernelGGL(affine_rows_res_kernel, dim3((unsigned)ceil_div(n * channels, (int64_t)256)), dim3(256), 0,
+                       (hipStream_t)stream, x, (int)n, channels, ld_x, scale, shift, residual, ld_res, relu, out, ld_out);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }

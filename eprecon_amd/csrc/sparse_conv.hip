@@ -64,7 +64,8 @@ struct ConvParams {
     float *bn_scale_out, *bn_shift_out;
     const float *bn_gamma, *bn_beta;
     float bn_eps;
-    unsigned int *bn_ticket;  // zero-initialised arrival counter, reset by the last workgroup
+    unsigned int *bn_ticket;  // workspace of the in-kernel finalize (counters zero on entry and on exit + group rows)
+    int bn_rows;              // rows of bn_partial this launch writes (set by the dispatcher)
     // LayerNorm over the Cout channels of every output row, after bias / ReLU / residual (needs all
     // columns in one workgroup): out = [relu]( LN(v) * ln_gamma + ln_beta )
     int ln;
@@ -149,31 +150,81 @@ __device__ __forceinline__ void chan_merge(float &n_a, float &mean_a, float &m2_
     n_a = n;
 }
 
-// Second half of the fused BatchNorm: the last workgroup to arrive (device-scope ticket) merges the
-// per-workgroup summaries in block order and publishes the affine form of the normalisation.
-// Thread (g, c) = (tid / C, tid % C) merges blocks g, g + G, ... of column c (coalesced over c), the
-// G group results are merged in order by the g == 0 threads.  sScratch: >= 3 * 256 floats of LDS.
-__device__ __forceinline__ void bn_finalize_last_block(const ConvParams &p, float *sScratch)
+// Second half of the fused BatchNorm, inside the convolution launch (no bn_finalize launch, no host round trip).
+// Visibility between workgroups without fences (MI355X guide, "publish-large": a release fence makes the XCD's L2 write
+// back everything dirty, and the round-1 form — one ticket, __threadfence() per workgroup — ran cfg2 at 3.4 ms instead of
+// 2.3 ms): the summaries are stored WRITE-THROUGH (relaxed agent-scope atomic stores = global_store sc1), the stores are
+// drained (s_waitcnt vmcnt(0)) before the arrival is counted, and the merging workgroup reads them with sc1 loads that
+// bypass its L1.  Two levels, so that no counter sees more than 16 * (column blocks) or (rows / 16) arrivals and the last
+// arriver's serial part is short:
+//   group g = summary rows 16 g .. 16 g + 15: its last arriver merges them in row order -> group row g (write-through)
+//   the last group to finish merges the group rows in order -> (scale, shift); every counter is reset by its last arriver
+// The merge order is fixed by row / group index, not by arrival: deterministic.
+// Workspace (bn_ticket): [1 + ngroups] counters (zero on entry, zero again on exit), padded to 256 bytes, then the group
+// rows f32[ngroups][3][Cout]  (eprecon_conv_bn_finalize_workspace_bytes).
+constexpr int kBnGroupRows = 16;
+__device__ __forceinline__ void st_wt(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_l2(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__host__ __device__ inline size_t bn_ws_ticket_bytes(int nrows)
+{
+    const size_t ngroups = (size_t)(nrows + kBnGroupRows - 1) / kBnGroupRows;
+    return ((1 + ngroups) * sizeof(unsigned int) + 255) / 256 * 256;
+}
+
+// every thread of the workgroup calls this after the workgroup's slice of summary row `partial_row` was stored with st_wt;
+// `ncb` workgroups (column blocks) contribute to a row.  sScratch: >= 3 * 256 floats of LDS.  Cout <= 128.
+__device__ __forceinline__ void bn_finalize_in_kernel(const ConvParams &p, float *sScratch, int partial_row, int ncb)
 {
     __shared__ int sLast;
-    const int tid = threadIdx.x;
-    __syncthreads();  // this workgroup's summaries are written
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int C = p.Cout, nrows = p.bn_rows;
+    const int ngroups = (nrows + kBnGroupRows - 1) / kBnGroupRows;
+    unsigned int *tick = p.bn_ticket;
+    float *grow = reinterpret_cast<float *>(reinterpret_cast<char *>(p.bn_ticket) + bn_ws_ticket_bytes(nrows));
+    const int grp = partial_row / kBnGroupRows;
+    const int r0 = grp * kBnGroupRows, r1 = min(r0 + kBnGroupRows, nrows);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through stores have left
+    __syncthreads();
     if (tid == 0) {
-        const unsigned int total = gridDim.x * gridDim.y;
-        const unsigned int t = __hip_atomic_fetch_add(p.bn_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        sLast = (t == total - 1) ? 1 : 0;
+        const unsigned int t = __hip_atomic_fetch_add(tick + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sLast = t == (unsigned int)((r1 - r0) * ncb - 1);
+        if (sLast) __hip_atomic_store(tick + 1 + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (!sLast) return;
-    __threadfence();  // acquire: the other workgroups' summaries (other XCDs' L2s) are visible
-    const int C = p.Cout, nblk = gridDim.x;
-    const int G = max(1, 256 / C);
+    for (int c = tid; c < C; c += nthr) {  // the group's rows in order; 3 * (r1 - r0) independent L2 loads per thread
+        float vn[kBnGroupRows], vm[kBnGroupRows], vq[kBnGroupRows];
+#pragma unroll
+        for (int i = 0; i < kBnGroupRows; ++i) {
+            const int r = min(r0 + i, r1 - 1);
+            const float *q = p.bn_partial + (size_t)r * 3 * C + c;
+            vn[i] = ld_l2(q); vm[i] = ld_l2(q + C); vq[i] = ld_l2(q + 2 * C);
+        }
+        float a_n = 0.0f, a_mean = 0.0f, a_m2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kBnGroupRows; ++i)
+            if (r0 + i < r1) chan_merge(a_n, a_mean, a_m2, vn[i], vm[i], vq[i]);
+        float *g = grow + (size_t)grp * 3 * C + c;
+        st_wt(g, a_n); st_wt(g + C, a_mean); st_wt(g + 2 * C, a_m2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sLast = t == (unsigned int)(ngroups - 1);
+        if (sLast) __hip_atomic_store(tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!sLast) return;
+    // the last group: thread (g, c) merges group rows g, g + G, ... of column c, the G results are merged in order
+    const int G = max(1, min(nthr, 256) / C);
     const int g = tid / C, c = tid - g * C;
     float a_n = 0.0f, a_mean = 0.0f, a_m2 = 0.0f;
     if (g < G) {
-        for (int b = g; b < nblk; b += G) {
-            const float *q = p.bn_partial + (size_t)b * 3 * C + c;
-            chan_merge(a_n, a_mean, a_m2, q[0], q[C], q[2 * C]);
+        for (int b = g; b < ngroups; b += G) {
+            const float *q = grow + (size_t)b * 3 * C + c;
+            chan_merge(a_n, a_mean, a_m2, ld_l2(q), ld_l2(q + C), ld_l2(q + 2 * C));
         }
         sScratch[tid] = a_n; sScratch[256 + tid] = a_mean; sScratch[512 + tid] = a_m2;
     }
@@ -182,12 +233,10 @@ __device__ __forceinline__ void bn_finalize_last_block(const ConvParams &p, floa
         for (int gg = 1; gg < G; ++gg)
             chan_merge(a_n, a_mean, a_m2, sScratch[gg * C + c], sScratch[256 + gg * C + c], sScratch[512 + gg * C + c]);
         const float var = a_n > 0.0f ? a_m2 / a_n : 0.0f;  // biased variance
-        const float inv = 1.0f / sqrtf(var + p.bn_eps);
-        const float sc = (p.bn_gamma ? p.bn_gamma[c] : 1.0f) * inv;
+        const float sc = (p.bn_gamma ? p.bn_gamma[c] : 1.0f) / sqrtf(var + p.bn_eps);
         p.bn_scale_out[c] = sc;
         p.bn_shift_out[c] = (p.bn_beta ? p.bn_beta[c] : 0.0f) - a_mean * sc;
     }
-    if (tid == 0) *p.bn_ticket = 0u;
 }
 
 // Shared epilogue.  C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31,
@@ -281,7 +330,7 @@ __device__ __forceinline__ void conv_epilogue_ln(const ConvParams &p, f32x16 (&a
 
 template <int NT, class RowMap>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)[NT], RowMap rm, int col0, int r32,
-                                              int half, int wave, float *sStat, int partial_row)
+                                              int half, int wave, float *sStat, int partial_row, int ncb)
 {
     constexpr int TN = 32 * NT;
     if (p.ln) {  // uniform; the launcher guarantees a single column block and no BatchNorm summaries
@@ -353,10 +402,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
                 chan_merge(a_n, a_mean, a_m2, sStat[(w * 3) * TN + tid], sStat[(w * 3 + 1) * TN + tid],
                            sStat[(w * 3 + 2) * TN + tid]);
             float *dst = p.bn_partial + (size_t)partial_row * 3 * p.Cout + col0 + tid;
-            dst[0] = a_n; dst[p.Cout] = a_mean; dst[2 * p.Cout] = a_m2;
+            if (p.bn_scale_out) {   // (uniform) read by another workgroup of this launch: write-through
+                st_wt(dst, a_n); st_wt(dst + p.Cout, a_mean); st_wt(dst + 2 * p.Cout, a_m2);
+            } else {
+                dst[0] = a_n; dst[p.Cout] = a_mean; dst[2 * p.Cout] = a_m2;
+            }
         }
     }
-    if (stats && p.bn_scale_out) bn_finalize_last_block(p, sStat);
+    if (stats && p.bn_scale_out) {
+        __syncthreads();  // the summary scratch is read; bn_finalize_in_kernel reuses it
+        bn_finalize_in_kernel(p, sStat, partial_row, ncb);
+    }
 }
 
 template <int NT, bool VEC4>
@@ -465,7 +521,7 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvParams p)
         }
     }
 
-    conv_epilogue<NT>(p, acc, LinearRows{row0 + wave * kRowsPerWave, p.n_out}, col0, r32, half, wave, sW, (int)blockIdx.x);
+    conv_epilogue<NT>(p, acc, LinearRows{row0 + wave * kRowsPerWave, p.n_out}, col0, r32, half, wave, sW, (int)blockIdx.x, (int)gridDim.y);
 }
 
 
@@ -733,7 +789,7 @@ __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int 
             consume(b, a, jj);
         }
     }
-    conv_epilogue<NT>(p, acc, LinearRows{wrow0, p.n_out}, col0, r32, half, wave, sW, (int)blockIdx.x);
+    conv_epilogue<NT>(p, acc, LinearRows{wrow0, p.n_out}, col0, r32, half, wave, sW, (int)blockIdx.x, (int)gridDim.y);
 }
 
 template <int NT, int NCH>
@@ -907,7 +963,7 @@ __global__ __launch_bounds__(256) void conv2d_tile_kernel(ConvParams p, int tile
     const int wy0 = y0 + 2 * wave;
     const ImageRows rm{(int)(map_row0 + (size_t)wy0 * p.img_w + x0), wy0, x0, p.img_h, p.img_w};
     const int partial_row = ((int)blockIdx.y * tiles_y + ty) * tiles_x + tx;
-    conv_epilogue<NT>(p, acc, rm, col0, r32, half, wave, sW, partial_row);
+    conv_epilogue<NT>(p, acc, rm, col0, r32, half, wave, sW, partial_row, (int)gridDim.z);
 }
 
 size_t conv2d_tile_lds(int nt, int nch) { return ((size_t)9 * nch * 8 * 32 * nt + (size_t)kHaloH * kHaloW * (nch * 8 + 4)) * sizeof(float); }
@@ -916,7 +972,7 @@ size_t conv2d_tile_lds(int nt, int nch) { return ((size_t)9 * nch * 8 * 32 * nt 
 bool conv2d_tile_ok(const ConvParams &p, int *nt_out, int *nch_out, int64_t *blocks)
 {
     static const bool on = !(getenv("EPRECON_CONV_TILE") && getenv("EPRECON_CONV_TILE")[0] == '0');
-    if (!on || p.K != 9 || p.img_h <= 0 || p.img_w <= 0 || p.img_maps <= 0 || p.ln || p.accumulate || p.bn_scale_out)
+    if (!on || p.K != 9 || p.img_h <= 0 || p.img_w <= 0 || p.img_maps <= 0 || p.ln || p.accumulate)
         return false;
     if ((int64_t)p.img_maps * p.img_h * p.img_w != p.n_out) return false;
     if (p.Cin % 4 != 0 || p.ld_x % 4 != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0) return false;
@@ -1107,10 +1163,12 @@ __global__ __launch_bounds__(64 * WV) void conv3d_tile_kernel(ConvParams p, int 
 
     const int dbg = p.debug;
     if (!d3_stage_halo<NCH, WV>(p, x0, y0, z0, sX, tid, dbg)) {
-        if (p.bn_partial && tid < TN && col0 + tid < p.Cout) {  // an empty summary row: the finalize skips count 0
+        if (p.bn_partial && tid < TN && col0 + tid < p.Cout) {  // an empty summary row: the merges skip count 0
             float *dst = p.bn_partial + (size_t)tile * 3 * p.Cout + col0 + tid;
-            dst[0] = 0.0f; dst[p.Cout] = 0.0f; dst[2 * p.Cout] = 0.0f;
+            if (p.bn_scale_out) { st_wt(dst, 0.0f); st_wt(dst + p.Cout, 0.0f); st_wt(dst + 2 * p.Cout, 0.0f); }
+            else { dst[0] = 0.0f; dst[p.Cout] = 0.0f; dst[2 * p.Cout] = 0.0f; }
         }
+        if (p.bn_partial && p.bn_scale_out) bn_finalize_in_kernel(p, sX, tile, (int)gridDim.y);  // it still counts as an arrival
         return;
     }
     const int cell0 = ((wave + 1) * kD3HY + (r32 >> 3) + 1) * kD3HZ + (r32 & 7) + 1;  // this lane's own cell in the halo
@@ -1190,7 +1248,7 @@ __global__ __launch_bounds__(64 * WV) void conv3d_tile_kernel(ConvParams p, int 
     if (p.bn_partial) {   // the shared epilogue merges kWaves wave summaries: the slots of the waves this block does not have are empty
         for (int e = tid; e < (kWaves - WV) * 3 * TN; e += 64 * WV) sX[WV * 3 * TN + e] = 0.0f;
     }
-    conv_epilogue<NT>(p, acc, RegRows{orow, half}, col0, r32, half, wave, sX, tile);
+    conv_epilogue<NT>(p, acc, RegRows{orow, half}, col0, r32, half, wave, sX, tile, (int)gridDim.y);
 }
 
 // C_out == 1 (the occupancy-logit layer, models/occupancy_initialization.py:171): a 32-column MFMA tile would spend 31/32
@@ -1220,8 +1278,10 @@ __global__ __launch_bounds__(256) void conv3d_tile_narrow_kernel(ConvParams p, i
     if (!d3_stage_halo<NCH, WV>(p, x0, y0, z0, sX, tid, p.debug)) {  // (its barriers also publish sWn)
         if (p.bn_partial && tid == 0) {
             float *dst = p.bn_partial + (size_t)tile * 3 * p.Cout;
-            dst[0] = 0.0f; dst[p.Cout] = 0.0f; dst[2 * p.Cout] = 0.0f;
+            if (p.bn_scale_out) { st_wt(dst, 0.0f); st_wt(dst + p.Cout, 0.0f); st_wt(dst + 2 * p.Cout, 0.0f); }
+            else { dst[0] = 0.0f; dst[p.Cout] = 0.0f; dst[2 * p.Cout] = 0.0f; }
         }
+        if (p.bn_partial && p.bn_scale_out) bn_finalize_in_kernel(p, sX, tile, 1);
         return;
     }
     const int v = tid >> 1, part = tid & 1;  // cell (x = v / 32, y = (v / 8) % 4, z = v % 8), half of the channel groups
@@ -1273,7 +1333,12 @@ __global__ __launch_bounds__(256) void conv3d_tile_narrow_kernel(ConvParams p, i
             float a_n = 0.0f, a_mean = 0.0f, a_m2 = 0.0f;
             for (int w = 0; w < kWaves; ++w) chan_merge(a_n, a_mean, a_m2, sRed[w * 3], sRed[w * 3 + 1], sRed[w * 3 + 2]);
             float *dst = p.bn_partial + (size_t)tile * 3 * p.Cout;
-            dst[0] = a_n; dst[p.Cout] = a_mean; dst[2 * p.Cout] = a_m2;
+            if (p.bn_scale_out) { st_wt(dst, a_n); st_wt(dst + p.Cout, a_mean); st_wt(dst + 2 * p.Cout, a_m2); }
+            else { dst[0] = a_n; dst[p.Cout] = a_mean; dst[2 * p.Cout] = a_m2; }
+        }
+        if (p.bn_scale_out) {
+            __syncthreads();  // (sX is free: every thread is past its operand reads)
+            bn_finalize_in_kernel(p, sX, tile, 1);
         }
     }
 }
@@ -1307,7 +1372,7 @@ bool conv3d_tile_ok(const ConvParams &p, bool *narrow)
 {
     const int level = d3_level();
     *narrow = false;
-    if (level <= 0 || !p.vox_rank || p.K != 27 || p.gx <= 0 || p.gy <= 0 || p.gz <= 0 || p.bn_scale_out) return false;
+    if (level <= 0 || !p.vox_rank || p.K != 27 || p.gx <= 0 || p.gy <= 0 || p.gz <= 0) return false;
     if (p.Cin % 4 != 0 || p.Cin > 64 || p.ld_x % 4 != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0) return false;
     if (p.in_scale && ((reinterpret_cast<uintptr_t>(p.in_scale) & 15) != 0 || (reinterpret_cast<uintptr_t>(p.in_shift) & 15) != 0))
         return false;
@@ -1565,7 +1630,7 @@ __global__ __launch_bounds__(256) void spconv_splitk_kernel(ConvParams p)
         if (t > 0 && row0 + 32 * t >= p.n_out) break;  // (block-uniform) no second tile in the last workgroup
         f32x16 one[1] = {acc[t]};
         const LinearRows rm{row0 + 32 * t, wave == 0 ? p.n_out : 0};
-        conv_epilogue<1>(p, one, rm, col0, r32, half, wave, sW, (int)blockIdx.x * RT + t);
+        conv_epilogue<1>(p, one, rm, col0, r32, half, wave, sW, (int)blockIdx.x * RT + t, (int)gridDim.y);
         if (t + 1 < RT) __syncthreads();  // the next tile's summaries reuse the scratch
     }
 }
@@ -1594,7 +1659,7 @@ int launch_splitk_v(const ConvParams &p, hipStream_t st)
 bool splitk_ok(const ConvParams &p)
 {
     static const bool on = !(getenv("EPRECON_CONV_SPLITK") && getenv("EPRECON_CONV_SPLITK")[0] == '0');
-    if (!on || p.accumulate || p.bn_scale_out) return false;
+    if (!on || p.accumulate) return false;
     if (p.bn_partial && !p.flex_partial) return false;
     const int nt_full = (p.Cout + 31) / 32;
     if (p.ln && nt_full > 1) return false;
@@ -1676,6 +1741,7 @@ int conv_dispatch_inner(ConvParams &p, int64_t n_in, hipStream_t st)
         if (conv3d_tile_ok(p, &narrow)) {
             g_last_conv_kernel = narrow ? "conv3d_tile_narrow_kernel" : "conv3d_tile_kernel";
             p.debug = getenv("EPRECON_D3_ABLATE") ? atoi(getenv("EPRECON_D3_ABLATE")) : 0;  // (read per launch: probes flip it)
+            p.bn_rows = d3_tiles(p, narrow);
             return launch_conv3d(p, narrow, st);
         }
         if (!p.nbr && p.K != 1) return EPRECON_ERR_ARG;  // dense-grid form requested for a shape it does not take, no map given
@@ -1685,6 +1751,7 @@ int conv_dispatch_inner(ConvParams &p, int64_t n_in, hipStream_t st)
         int64_t blocks;
         if (conv2d_tile_ok(p, &nt, &nch, &blocks)) {
             g_last_conv_kernel = "conv2d_tile_kernel";
+            p.bn_rows = (int)blocks;
             switch (nch) {
                 case 1: return launch_conv2d_tile<1>(p, st);
                 case 2: return launch_conv2d_tile<2>(p, st);
@@ -1707,8 +1774,10 @@ int conv_dispatch_inner(ConvParams &p, int64_t n_in, hipStream_t st)
     const int nblk = (int)ceil_div(p.n_out, kRowsPerBlock);
     const int nt_full = (p.Cout + 31) / 32;
     if (p.ln && (nt_full > 4 || p.bn_partial || p.accumulate)) return EPRECON_ERR_UNSUPPORTED;
+    p.bn_rows = (int)ceil_div(p.n_out, kRowsPerBlock);  // the gather forms: 128-row blocks (split-K: 32-row blocks)
     if (splitk_ok(p)) {
         g_last_conv_kernel = "spconv_splitk_kernel";
+        p.bn_rows = (int)ceil_div(p.n_out, 32);
         return vec4 ? launch_splitk_v<true>(p, st) : launch_splitk_v<false>(p, st);
     }
     const bool split = nblk < 256 && nt_full > 1 && !p.ln;
@@ -1771,6 +1840,13 @@ extern "C" int64_t eprecon_profile_conv_pairs(void)
     return (int64_t)v;
 }
 
+extern "C" size_t eprecon_conv_bn_finalize_workspace_bytes(int64_t partial_rows, int cout)
+{
+    if (partial_rows <= 0 || cout <= 0) return 0;
+    const size_t ngroups = (size_t)(partial_rows + kBnGroupRows - 1) / kBnGroupRows;
+    return bn_ws_ticket_bytes((int)partial_rows) + ngroups * 3 * (size_t)cout * sizeof(float);
+}
+
 extern "C" size_t eprecon_conv_pack_weight_floats(int kvol, int cin, int cout)
 {
     if (kvol <= 0 || cin <= 0 || cout <= 0) return 0;
@@ -1805,7 +1881,7 @@ static int conv_check_and_run(ConvParams &p, int64_t n_in, int64_t n_out, void *
     if (!p.nbr && n_in != n_out) return EPRECON_ERR_ARG;
     if ((p.in_scale == nullptr) != (p.in_shift == nullptr) || (p.res_scale == nullptr) != (p.res_shift == nullptr))
         return EPRECON_ERR_ARG;
-    if (p.bn_scale_out && (!p.bn_partial || !p.bn_shift_out || !p.bn_ticket || p.Cout > 256)) return EPRECON_ERR_ARG;
+    if (p.bn_scale_out && (!p.bn_partial || !p.bn_shift_out || !p.bn_ticket || p.Cout > 128)) return EPRECON_ERR_ARG;
     if (p.Cout > 4096 || n_out > 0x7fffffff) return EPRECON_ERR_UNSUPPORTED;
     if (n_out == 0) return EPRECON_OK;
     p.n_out = (int)n_out;

@@ -75,10 +75,10 @@ def packed_weight(conv):
     return cached[1]
 
 
-# EPRECON_BN_TICKET=1: the last workgroup of the convolution finishes the BatchNorm (device-scope ticket)
-# instead of a separate finalize launch.  Measured slower on MI355X (cfg2 step 3.4 ms vs the two-launch form):
-# every workgroup's release makes its XCD's L2 write back, and 1,350 same-address atomics serialise.
-_FUSED_FINALIZE = os.environ.get("EPRECON_BN_TICKET", "0") == "1"
+# EPRECON_BN_TICKET=0: a separate bn_finalize_affine launch per layer instead of finishing the BatchNorm inside the
+# convolution (sparse.FUSED_FINALIZE; round 1's first form of it — one counter, a release fence per workgroup — was slower
+# than the extra launch: 3.4 vs 2.3 ms per cfg2 step; the current form stores the summaries write-through, no fences)
+from .sparse import FUSED_FINALIZE as _FUSED_FINALIZE, FUSED_FINALIZE_MAX_C, finalize_workspace  # noqa: E402
 MERGE_ELAN_1X1 = os.environ.get("EPRECON_ELAN_MERGE", "0") == "1"  # measured neutral on MI355X
 
 
@@ -136,12 +136,7 @@ def conv_bn_launch(w, bias, gamma, beta, eps, k, x, grid, out=None, aff=None, re
     if aff is None:
         a = torch.empty((2, cout), dtype=torch.float32, device=dev)
         aff = (a[0], a[1])
-    fused_finalize = _FUSED_FINALIZE and ticket_owner is not None
-    ticket = None
-    if fused_finalize:
-        ticket = getattr(ticket_owner, "_eprecon_ticket", None)
-        if ticket is None or ticket.device != dev:
-            ticket = ticket_owner._eprecon_ticket = torch.zeros((1,), dtype=torch.int32, device=dev)
+    fused_finalize = _FUSED_FINALIZE and ticket_owner is not None and cout <= FUSED_FINALIZE_MAX_C
     d = _lib.ConvDesc()
     d.x, d.n_in, d.ld_x = rows.data_ptr(), n, rows.stride(0)
     d.nbr, d.kvol, d.n_out = _dptr(nbr), kvol, n
@@ -154,7 +149,7 @@ def conv_bn_launch(w, bias, gamma, beta, eps, k, x, grid, out=None, aff=None, re
     d.out, d.ld_out = out.data_ptr(), out.stride(0)
     d.relu, d.accumulate = int(pre_relu), 0
     d.in_scale, d.in_shift, d.in_relu = _dptr(x.scale), _dptr(x.shift), int(x.relu)
-    if k == 3 and not fused_finalize:
+    if k == 3:
         d.img_h, d.img_w, d.img_maps = grid.height, grid.width, grid.maps  # narrow layers: image-tile kernel
     # the summaries are per workgroup: 128-row blocks (gather forms) or image tiles (tile kernel)
     partial = torch.empty((lib.eprecon_conv_desc_partial_rows(ctypes.byref(d)), 3, cout), dtype=torch.float32, device=dev)
@@ -162,7 +157,7 @@ def conv_bn_launch(w, bias, gamma, beta, eps, k, x, grid, out=None, aff=None, re
     if fused_finalize:
         d.bn_scale_out, d.bn_shift_out = aff[0].data_ptr(), aff[1].data_ptr()
         d.bn_gamma, d.bn_beta, d.bn_eps = _dptr(gamma), _dptr(beta), float(eps)
-        d.bn_ticket = ticket.data_ptr()
+        d.bn_ticket = finalize_workspace(ticket_owner, partial.shape[0], cout, dev).data_ptr()
     _lib.check(lib.eprecon_conv_desc_async(ctypes.byref(d), _lib.current_stream()), "eprecon_conv_desc_async")
     if not fused_finalize:
         _lib.check(lib.eprecon_batchnorm_finalize_affine_async(

@@ -121,10 +121,13 @@ class SparseSubMConv3d(nn.Module):
         nbr = vset.conv_map(3) if self.kernel == 3 else None   # dense-grid form on well-filled grids, else the kernel map
         return SP.sparse_conv(features, self.weight, nbr, self.bias, out=out, relu=relu)
 
-    def run_stats(self, features, vset, out=None):
-        """conv + bias and the BatchNorm summaries of its output in one launch -> (y, partial)"""
+    def run_stats(self, features, vset, out=None, bn=None):
+        """conv + bias and the BatchNorm summaries of its output in one launch -> (y, partial[, (scale, shift) | None]);
+        bn: the TrainBatchNorm1d that follows (its statistics are then finished inside the launch)"""
         nbr = vset.conv_map(3) if self.kernel == 3 else None
-        return SP.sparse_conv_fused(features, self.weight, nbr, self.bias, out=out, bn_partial=True)
+        if bn is None:
+            return SP.sparse_conv_fused(features, self.weight, nbr, self.bias, out=out, bn_partial=True)
+        return SP.conv_stats(features, self.weight, nbr, out=out, bias=self.bias, bn=bn.bn_args(), owner=bn)
 
     def run_ln(self, features, vset, ln, out=None, relu=False, residual=None, post_relu=False):
         """conv [+ReLU] [+residual] -> LayerNorm `ln` [-> ReLU], one launch"""
@@ -242,6 +245,16 @@ class TrainBatchNorm1d(nn.BatchNorm1d):
     def run_partials(self, x, partial, residual=None, relu=False, out=None):
         """second half of the BatchNorm from the producing convolution's summaries"""
         return SP.batchnorm_apply_partials(x, partial, self.weight, self.bias, self.eps, residual, relu, out)
+
+    def finish(self, x, partial, aff, residual=None, relu=False, out=None):
+        """the same when the producer may already have finished the statistics inside its launch (aff = (scale, shift)):
+        then one affine pass, else finalize + apply from the summaries"""
+        if aff is None:
+            return self.run_partials(x, partial, residual=residual, relu=relu, out=out)
+        return SP.affine_rows(x, aff[0], aff[1], residual=residual, relu=relu, out=out)
+
+    def bn_args(self):
+        return (self.weight, self.bias, self.eps)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -521,9 +534,12 @@ class Conv3d(nn.Module):
             return y if out is None else out.copy_(y)
         return SP.sparse_conv(feats, self.kernel, nbr, None, out=out)
 
-    def run_stats(self, feats, nbr, out=None, in_affine=None):
-        """conv + the BatchNorm summaries of its output in one launch -> (y, partial)"""
-        return SP.conv_stats(feats, self.kernel, nbr, in_affine=in_affine, out=out)
+    def run_stats(self, feats, nbr, out=None, in_affine=None, bn=None):
+        """conv + the BatchNorm summaries of its output in one launch -> (y, partial[, (scale, shift) | None]);
+        bn: the TrainBatchNorm1d that follows (its statistics are then finished inside the launch)"""
+        if bn is None:
+            return SP.conv_stats(feats, self.kernel, nbr, in_affine=in_affine, out=out)
+        return SP.conv_stats(feats, self.kernel, nbr, in_affine=in_affine, out=out, bn=bn.bn_args(), owner=bn)
 
 
 class BasicConvolutionBlock(nn.Module):
@@ -539,8 +555,8 @@ class BasicConvolutionBlock(nn.Module):
         if not _FUSED_BN_STATS:
             y = self.net[0].run(feats, nbr, out=out)
             return self.net[1].run(y, relu=True, out=y)
-        y, partial = self.net[0].run_stats(feats, nbr, out=out)
-        return self.net[1].run_partials(y, partial, relu=True, out=y)
+        y, partial, aff = self.net[0].run_stats(feats, nbr, out=out, bn=self.net[1])
+        return self.net[1].finish(y, partial, aff, relu=True, out=y)
 
 
 class BasicDeconvolutionBlock(nn.Module):
@@ -557,8 +573,8 @@ class BasicDeconvolutionBlock(nn.Module):
         if not _FUSED_BN_STATS:
             y = self.net[0].run(feats, nbr, out=out)
             return self.net[1].run(y, relu=True, out=y)
-        y, partial = self.net[0].run_stats(feats, nbr, out=out)
-        return self.net[1].run_partials(y, partial, relu=True, out=y)
+        y, partial, aff = self.net[0].run_stats(feats, nbr, out=out, bn=self.net[1])
+        return self.net[1].finish(y, partial, aff, relu=True, out=y)
 
 
 class ResidualBlock(nn.Module):
@@ -590,16 +606,16 @@ class ResidualBlock(nn.Module):
                 self.downsample[1].run(skip, out=skip)
             return self.net[4].run(y2, residual=skip, relu=True, out=out if out is not None else y2)
         # conv1's BatchNorm + ReLU stays pending and is applied by conv2 while it gathers
-        y, p1 = self.net[0].run_stats(feats, nbr)
         bn1 = self.net[1]
-        scale, shift = SP.bn_affine(p1, bn1.weight, bn1.bias, bn1.eps)
-        y2, p2 = self.net[3].run_stats(y, nbr, in_affine=(scale, shift, True))
+        y, p1, a1 = self.net[0].run_stats(feats, nbr, bn=bn1)
+        scale, shift = a1 if a1 is not None else SP.bn_affine(p1, bn1.weight, bn1.bias, bn1.eps)
+        y2, p2, a2 = self.net[3].run_stats(y, nbr, in_affine=(scale, shift, True), bn=self.net[4])
         if len(self.downsample) == 0:
             skip = feats
         else:
-            skip, ps = self.downsample[0].run_stats(feats, None)
-            self.downsample[1].run_partials(skip, ps, out=skip)
-        return self.net[4].run_partials(y2, p2, residual=skip, relu=True, out=out if out is not None else y2)
+            skip, ps, a_s = self.downsample[0].run_stats(feats, None, bn=self.downsample[1])
+            self.downsample[1].finish(skip, ps, a_s, out=skip)
+        return self.net[4].finish(y2, p2, a2, residual=skip, relu=True, out=out if out is not None else y2)
 
 
 class _PointMLP(nn.Sequential):
@@ -614,8 +630,8 @@ class _PointMLP(nn.Sequential):
         lin = self[0]
         if recording():   # (per-point GEMM on the HIP kernel: rocBLAS picks 32x32 tiles for these [N, <100] x [<100, <100] shapes)
             return self[1].run(AG.sparse_conv(feats, lin.weight.t(), None, lin.bias), relu=True)
-        y, partial = SP.conv_stats(feats, _linear_wt(lin), None)
-        return self[1].run_partials(y, partial, relu=True, out=y)
+        y, partial, aff = SP.conv_stats(feats, _linear_wt(lin), None, bn=self[1].bn_args(), owner=self[1])
+        return self[1].finish(y, partial, aff, relu=True, out=y)
 
 
 class SPVCNN(nn.Module):
@@ -680,8 +696,8 @@ class SPVCNN(nn.Module):
         cat0 = torch.empty((s1.n, cs[4] + cs[0]), dtype=torch.float32, device=dev)
         cat1 = torch.empty((s2.n, cs[3] + cs[1]), dtype=torch.float32, device=dev)
 
-        f0, p0 = self.stem[0].run_stats(x0.F, s1.kernel_map(3), out=cat0[:, cs[4]:])
-        self.stem[1].run_partials(f0, p0, relu=True, out=f0)
+        f0, p0, a0 = self.stem[0].run_stats(x0.F, s1.kernel_map(3), out=cat0[:, cs[4]:], bn=self.stem[1])
+        self.stem[1].finish(f0, p0, a0, relu=True, out=f0)
         x0 = SparseTensor(f0, s1)
         z0 = voxel_to_point(x0, z)
 

@@ -148,8 +148,8 @@ class Occupancy_Initialization(nn.Module):
             x = conv.run_ln(x, vset, norm, relu=True, residual=x)  # LN(x + ReLU(conv(x))), one launch
         if torch.is_grad_enabled():
             return self.norm4.run(self.subm4.run(x, vset))
-        y, partial = self.subm4.run_stats(x, vset)      # the logit layer writes norm4's batch statistics itself
-        return self.norm4.run_partials(y, partial, out=y)
+        y, partial, aff = self.subm4.run_stats(x, vset, bn=self.norm4)   # the logit layer finishes norm4's statistics itself
+        return self.norm4.finish(y, partial, aff, out=y)
 
     def forward(self, coords, origin, voxel_size, features_all, KRcam, shape, stage, min_view_number):
         bs = features_all[0][0].shape[0]

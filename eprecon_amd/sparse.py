@@ -328,10 +328,43 @@ def sparse_conv_ln(x, weight, nbr, bias, ln_weight, ln_bias, ln_eps, out=None, r
     return out
 
 
-def conv_stats(x, weight, nbr=None, in_affine=None, out=None):
-    """Bias-free convolution whose epilogue also writes the per-workgroup BatchNorm summaries of its output
+# EPRECON_BN_TICKET=0: BatchNorm statistics finished by a separate launch (bn_finalize / bn_finalize_affine) instead of
+# inside the producing convolution (csrc/sparse_conv.hip, bn_finalize_in_kernel)
+FUSED_FINALIZE = os.environ.get("EPRECON_BN_TICKET", "1") == "1"
+FUSED_FINALIZE_MAX_C = 128
+
+
+def finalize_workspace(owner, rows, cout, device):
+    """The in-kernel finalize's workspace (arrival counters zero between launches + group rows), kept on the layer that
+    owns the BatchNorm: one launch of a layer is in flight at a time, different layers may run on different streams."""
+    need = int(_lib.load().eprecon_conv_bn_finalize_workspace_bytes(int(rows), int(cout)))
+    ws = getattr(owner, "_eprecon_fin_ws", None)
+    if ws is None or ws.numel() < need or ws.device != device:
+        ws = torch.zeros(max(2 * need, 4096), dtype=torch.uint8, device=device)
+        owner._eprecon_fin_ws = ws
+    return ws
+
+
+def affine_rows(x, scale, shift, residual=None, relu=False, out=None):
+    """out = [relu]( x * scale + shift [+ residual] ): a BatchNorm whose statistics its producer finished; out may be x"""
+    lib = _lib.load()
+    n, c = x.shape
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    _lib.check(lib.eprecon_affine_rows_res_async(
+        _lib.ptr(x), n, c, _ld(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual),
+        _ld(residual) if residual is not None else 0, int(relu), _lib.ptr(out), _ld(out), _lib.current_stream()),
+        "eprecon_affine_rows_res_async")
+    return out
+
+
+def conv_stats(x, weight, nbr=None, in_affine=None, out=None, bias=None, bn=None, owner=None):
+    """Convolution whose epilogue also writes the per-workgroup BatchNorm summaries of its output
     (descriptor entry point: any kernel of the family may be chosen).  in_affine = (scale, shift, relu): the
-    producer's pending BatchNorm applied while gathering.  Returns (out, partial)."""
+    producer's pending BatchNorm applied while gathering.  Returns (out, partial).
+    With bn = (gamma, beta, eps) and `owner` (the layer object that keeps the workspace) the BatchNorm is finished
+    inside the launch: returns (out, partial, (scale, shift)) — (scale, shift) is None when the shape is not taken
+    (C_out > 128) or EPRECON_BN_TICKET=0, and the caller finishes from `partial`."""
     lib = _lib.load()
     if weight.dim() == 2:
         weight = weight.unsqueeze(0)
@@ -346,15 +379,25 @@ def conv_stats(x, weight, nbr=None, in_affine=None, out=None):
     d.kvol, d.n_out = kvol, n_out
     keep = _resolve_map(nbr, x, weight, d, stats=True)  # noqa: F841
     d.weight, d.cin, d.cout = weight.data_ptr(), cin, cout
+    d.bias = None if bias is None else bias.data_ptr()
     d.out, d.ld_out = out.data_ptr(), _ld(out)
     if in_affine is not None:
         d.in_scale, d.in_shift, d.in_relu = in_affine[0].data_ptr(), in_affine[1].data_ptr(), int(in_affine[2])
-    partial = torch.empty((max(int(lib.eprecon_conv_desc_partial_rows(ctypes.byref(d))), 1), 3, cout), dtype=torch.float32,
-                          device=x.device)
+    rows = max(int(lib.eprecon_conv_desc_partial_rows(ctypes.byref(d))), 1)
+    partial = torch.empty((rows, 3, cout), dtype=torch.float32, device=x.device)
     d.bn_partial = partial.data_ptr()
+    aff = None
+    if bn is not None and owner is not None and FUSED_FINALIZE and cout <= FUSED_FINALIZE_MAX_C and n_out > 0:
+        gamma, beta, eps = bn
+        a = torch.empty((2, cout), dtype=torch.float32, device=x.device)
+        aff = (a[0], a[1])
+        ws = finalize_workspace(owner, rows, cout, x.device)
+        d.bn_scale_out, d.bn_shift_out = a[0].data_ptr(), a[1].data_ptr()
+        d.bn_gamma, d.bn_beta, d.bn_eps = _lib.ptr(gamma), _lib.ptr(beta), float(eps)
+        d.bn_ticket = ws.data_ptr()
     if n_out > 0:
         _lib.check(lib.eprecon_conv_desc_async(ctypes.byref(d), _lib.current_stream()), "eprecon_conv_desc_async")
-    return out, partial
+    return (out, partial) if bn is None else (out, partial, aff)
 
 
 def bn_affine(partial, gamma, beta, eps):

@@ -226,9 +226,13 @@ int eprecon_sparse_conv_fused_async(const float *x, int64_t n_in, int ld_x, cons
  *                               a = [relu]( x * in_scale[c] + in_shift[c] ), zero padding stays 0
  *   res_scale / res_shift [cout] the same for the residual operand
  *   bn_scale_out / bn_shift_out [cout]  the BatchNorm of THIS layer's output in affine form,
- *                               scale = gamma / sqrt(var + eps), shift = beta - mean * scale, written
- *                               by the last workgroup to arrive (bn_ticket: zero-initialised device
- *                               counter, left at zero); needs bn_partial, cout <= 256.
+ *                               scale = gamma / sqrt(var + eps), shift = beta - mean * scale, finished INSIDE
+ *                               the launch: summaries stored write-through, two levels of arrival counters,
+ *                               the last arrivers merge in row / group order (deterministic, no fences).
+ *                               bn_ticket: workspace of eprecon_conv_bn_finalize_workspace_bytes(rows, cout)
+ *                               bytes (rows = eprecon_conv_desc_partial_rows) whose counters — the first
+ *                               256-byte-padded (1 + ceil(rows / 16)) uint32 — are zero on entry and are left at
+ *                               zero; one workspace per launch in flight.  Needs bn_partial, cout <= 128.
  * The stored tensor is the un-normalised conv output; consumers apply (scale, shift) on load, or
  * eprecon_affine_rows_async materialises it.
  */
@@ -266,6 +270,7 @@ typedef struct eprecon_conv_desc {
     const float *packed_weight;
 } eprecon_conv_desc;
 int eprecon_conv_desc_async(const eprecon_conv_desc *desc, void *stream);
+size_t eprecon_conv_bn_finalize_workspace_bytes(int64_t partial_rows, int cout);
 /* number of bn_partial rows the launch described by desc writes (nblk of the finalize call) */
 int64_t eprecon_conv_desc_partial_rows(const eprecon_conv_desc *desc);
 /* producer-side summaries partial f32[nblk][3][channels] -> the BatchNorm in affine form (the
@@ -276,6 +281,11 @@ int eprecon_batchnorm_finalize_affine_async(const float *partial, int64_t nblk, 
 /* out[i, c] = [relu]( x[i, c] * scale[c] + shift[c] ); out may alias x */
 int eprecon_affine_rows_async(const float *x, int64_t n, int channels, int ld_x, const float *scale,
                               const float *shift, int relu, float *out, int ld_out, void *stream);
+/* out[i, c] = [relu]( x[i, c] * scale[c] + shift[c] + residual[i, c] ): the tail of the residual blocks
+ * (models/modules.py:46-72) from a producer-finished BatchNorm; residual may be NULL; out may alias x */
+int eprecon_affine_rows_res_async(const float *x, int64_t n, int channels, int ld_x, const float *scale,
+                                  const float *shift, const float *residual, int ld_res, int relu, float *out,
+                                  int ld_out, void *stream);
 /*
  * Kernel map of a dense 2D 'same' convolution (odd ksize) over `maps` images of height x width
  * pixels stored as rows [maps][height][width] of a channels-last tensor:
