@@ -160,17 +160,16 @@ __device__ __forceinline__ void chan_merge(float &n_a, float &mean_a, float &m2_
 //   group g = summary rows 16 g .. 16 g + 15: its last arriver merges them in row order -> group row g (write-through)
 //   the last group to finish merges the group rows in order -> (scale, shift); every counter is reset by its last arriver
 // The merge order is fixed by row / group index, not by arrival: deterministic.
-// Workspace (bn_ticket): [1 + ngroups] counters (zero on entry, zero again on exit), padded to 256 bytes, then the group
-// rows f32[ngroups][3][Cout]  (eprecon_conv_bn_finalize_workspace_bytes).
+// Workspace (bn_ticket): a FIXED 16 KB region of counters ([0] top level, [1 + g] group g; zero on entry, zero again on
+// exit) followed by the group rows f32[ngroups][3][Cout]  (eprecon_conv_bn_finalize_workspace_bytes).  The counter region
+// does not depend on the launch: a layer's workspace is reused by launches of different sizes, and group rows written by
+// one launch must never land where a later, longer launch keeps its counters.
 constexpr int kBnGroupRows = 16;
 __device__ __forceinline__ void st_wt(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_l2(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__host__ __device__ inline size_t bn_ws_ticket_bytes(int nrows)
-{
-    const size_t ngroups = (size_t)(nrows + kBnGroupRows - 1) / kBnGroupRows;
-    return ((1 + ngroups) * sizeof(unsigned int) + 255) / 256 * 256;
-}
+constexpr size_t kBnTicketBytes = 16384;                               // 4,096 counters
+constexpr int kBnMaxRows = (int)(kBnTicketBytes / 4 - 1) * kBnGroupRows;  // 65,520 summary rows (8.4 M voxels at 128 rows each)
 
 // every thread of the workgroup calls this after the workgroup's slice of summary row `partial_row` was stored with st_wt;
 // `ncb` workgroups (column blocks) contribute to a row.  sScratch: >= 3 * 256 floats of LDS.  Cout <= 128.
@@ -181,7 +180,7 @@ __device__ __forceinline__ void bn_finalize_in_kernel(const ConvParams &p, float
     const int C = p.Cout, nrows = p.bn_rows;
     const int ngroups = (nrows + kBnGroupRows - 1) / kBnGroupRows;
     unsigned int *tick = p.bn_ticket;
-    float *grow = reinterpret_cast<float *>(reinterpret_cast<char *>(p.bn_ticket) + bn_ws_ticket_bytes(nrows));
+    float *grow = reinterpret_cast<float *>(reinterpret_cast<char *>(p.bn_ticket) + kBnTicketBytes);
     const int grp = partial_row / kBnGroupRows;
     const int r0 = grp * kBnGroupRows, r1 = min(r0 + kBnGroupRows, nrows);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through stores have left
@@ -1710,6 +1709,8 @@ int conv_dispatch_inner(ConvParams &p, int64_t n_in, hipStream_t st);
 
 int conv_dispatch(ConvParams &p, int64_t n_in, hipStream_t st)
 {
+    // (the in-kernel BatchNorm finalize keeps one counter per 16 summary rows in a fixed region)
+    if (p.bn_scale_out && ceil_div(p.n_out, 32) > kBnMaxRows) return EPRECON_ERR_UNSUPPORTED;
     ConvProf &g = g_conv_prof;
     const bool hit = g.armed && p.K == g.K && p.Cin == g.cin && p.Cout == g.cout && p.n_out >= g.min_rows;
     if (!hit) return conv_dispatch_inner(p, n_in, st);
@@ -1844,7 +1845,7 @@ extern "C" size_t eprecon_conv_bn_finalize_workspace_bytes(int64_t partial_rows,
 {
     if (partial_rows <= 0 || cout <= 0) return 0;
     const size_t ngroups = (size_t)(partial_rows + kBnGroupRows - 1) / kBnGroupRows;
-    return bn_ws_ticket_bytes((int)partial_rows) + ngroups * 3 * (size_t)cout * sizeof(float);
+    return kBnTicketBytes + ngroups * 3 * (size_t)cout * sizeof(float);
 }
 
 extern "C" size_t eprecon_conv_pack_weight_floats(int kvol, int cin, int cout)

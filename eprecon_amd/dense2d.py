@@ -78,7 +78,11 @@ def packed_weight(conv):
 # EPRECON_BN_TICKET=0: a separate bn_finalize_affine launch per layer instead of finishing the BatchNorm inside the
 # convolution (sparse.FUSED_FINALIZE; round 1's first form of it — one counter, a release fence per workgroup — was slower
 # than the extra launch: 3.4 vs 2.3 ms per cfg2 step; the current form stores the summaries write-through, no fences)
-from .sparse import FUSED_FINALIZE as _FUSED_FINALIZE, FUSED_FINALIZE_MAX_C, finalize_workspace  # noqa: E402
+from .sparse import FUSED_FINALIZE_MAX_C, finalize_workspace  # noqa: E402
+# The 2D stack is replayed from a HIP graph, where a finalize node costs ~1.5 us of boundary + 7 us of kernel on a side
+# branch, while the in-kernel form adds a store drain + an atomic round trip to EVERY workgroup's tail: measured 2.04 vs
+# 1.95 ms per cfg2 step (profiles/r03/bn_ticket_ab.txt).  Off here by default; EPRECON_BN_TICKET_2D=1 turns it on.
+_FUSED_FINALIZE = os.environ.get("EPRECON_BN_TICKET_2D", "0") == "1"
 MERGE_ELAN_1X1 = os.environ.get("EPRECON_ELAN_MERGE", "0") == "1"  # measured neutral on MI355X
 
 

@@ -328,9 +328,13 @@ def sparse_conv_ln(x, weight, nbr, bias, ln_weight, ln_bias, ln_eps, out=None, r
     return out
 
 
-# EPRECON_BN_TICKET=0: BatchNorm statistics finished by a separate launch (bn_finalize / bn_finalize_affine) instead of
-# inside the producing convolution (csrc/sparse_conv.hip, bn_finalize_in_kernel)
-FUSED_FINALIZE = os.environ.get("EPRECON_BN_TICKET", "1") == "1"
+# EPRECON_BN_TICKET=1: BatchNorm statistics finished INSIDE the producing convolution (csrc/sparse_conv.hip,
+# bn_finalize_in_kernel) instead of by a separate bn_finalize / bn_finalize_affine launch.  Correct (tests/test_bn_fused_gpu.py)
+# and 74 launches per fragment fewer (1,609 -> 1,536), but not faster: the store drain + atomic round trip at the tail of EVERY
+# workgroup costs what the small launches cost — cfg4 20.7 / 24.8 ms per fragment (thread / no thread) against 21.7 / 24.2 ms,
+# cfg2 +50 us through the one layer that used it (profiles/r03/bn_ticket_ab.txt).  The path is GPU-bound (25.1 ms of kernel
+# time per 24.1 ms fragment), not launch-bound.  Off by default.
+FUSED_FINALIZE = os.environ.get("EPRECON_BN_TICKET", "0") == "1"
 FUSED_FINALIZE_MAX_C = 128
 
 

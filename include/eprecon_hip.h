@@ -231,8 +231,8 @@ int eprecon_sparse_conv_fused_async(const float *x, int64_t n_in, int ld_x, cons
  *                               the last arrivers merge in row / group order (deterministic, no fences).
  *                               bn_ticket: workspace of eprecon_conv_bn_finalize_workspace_bytes(rows, cout)
  *                               bytes (rows = eprecon_conv_desc_partial_rows) whose counters — the first
- *                               256-byte-padded (1 + ceil(rows / 16)) uint32 — are zero on entry and are left at
- *                               zero; one workspace per launch in flight.  Needs bn_partial, cout <= 128.
+ *                               16,384 bytes, whatever the launch — are zero on entry and are left at zero;
+ *                               one workspace per launch in flight.  Needs bn_partial, cout <= 128.
  * The stored tensor is the un-normalised conv output; consumers apply (scale, shift) on load, or
  * eprecon_affine_rows_async materialises it.
  */

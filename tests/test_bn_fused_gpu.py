@@ -13,6 +13,13 @@ class Owner:   # stands in for the layer object that keeps the workspace
     pass
 
 
+@pytest.fixture(autouse=True)
+def fused_on(monkeypatch):
+    """the in-kernel finalize is off by default (EPRECON_BN_TICKET, eprecon_amd/sparse.py): these tests turn it on"""
+    from eprecon_amd import sparse as SP
+    monkeypatch.setattr(SP, "FUSED_FINALIZE", True)
+
+
 def reference_affine(partial, gamma, beta, eps):
     from eprecon_amd import sparse as SP
     return SP.bn_affine(partial, gamma, beta, eps)
@@ -42,6 +49,7 @@ def check(out, partial, aff, gamma, beta, eps, n):
     (20000, 1, 96, 128),       # per-point linear layer (identity map)
     (70000, 8, 64, 64),        # strided map shape
     (33000, 27, 80, 40),       # wide input
+    (203000, 27, 16, 8),       # SPVCNN's finest level: > 1,008 summary rows, narrow output
 ])
 def test_finalize_inside_the_gather_kernels(n, k, cin, cout):
     from eprecon_amd import sparse as SP
@@ -50,7 +58,7 @@ def test_finalize_inside_the_gather_kernels(n, k, cin, cout):
     beta = torch.randn(cout, device="cuda", generator=g)
     owner = Owner()
     for rep in range(6):     # the workspace is reused: counters must be back at zero, sizes change
-        m = n if rep % 2 == 0 else max(1, n // 3 + 17 * rep)
+        m = n if rep % 2 == 1 else max(1, n // 3 + 17 * rep)   # short launches first: their group rows must not reach the counters
         x = torch.randn((m, cin), device="cuda", generator=g) * (1 + rep)
         w = torch.randn((k, cin, cout), device="cuda", generator=g) / (k * cin) ** 0.5
         nbr = None
@@ -65,6 +73,7 @@ def test_finalize_inside_the_image_tile_kernel_and_hip_graph_replay():
     replayed from a captured HIP graph (the counters must come back to zero after every replay)"""
     import torch.nn as nn
     from eprecon_amd import dense2d as D2
+    D2._FUSED_FINALIZE = True      # (off by default for the 2D stack: EPRECON_BN_TICKET_2D)
     torch.manual_seed(0)
     for cin, cout, ks, (v, h, w) in ((24, 24, 3, (9, 120, 160)), (40, 20, 3, (9, 60, 80)), (80, 80, 1, (9, 30, 40)),
                                       (96, 24, 1, (9, 120, 160))):
@@ -93,6 +102,7 @@ def test_finalize_inside_the_image_tile_kernel_and_hip_graph_replay():
                 graph.replay()
                 ref = torch.relu(bn(conv(D2.maps_of(x, v, h, w).contiguous())))
                 assert float((D2.maps_of(rows, v, h, w) - ref).abs().max()) < 1e-3 * (rep + 1)
+    D2._FUSED_FINALIZE = False
 
 
 def test_finalize_inside_the_dense_grid_kernels(monkeypatch):
