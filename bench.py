@@ -292,7 +292,7 @@ def bench_cfg5(device, rank, world, dist, steps=8, warmup=4):
             "cfg5_steps": steps, "cfg5_early_returns_max_over_ranks": int(t[1].item()),
             "cfg5_collectives_per_fragment": (xch.collectives / (steps + warmup)) if xch is not None else 0,
             "cfg5_workload": f"{world} ranks x 1 fragment per step of one scene (fragments dealt round-robin), whole "
-                             "NeuConNet.forward, RCCL boundary-voxel exchange (3 collectives: boxes, counts, packed "
+                             "NeuConNet.forward, RCCL boundary-voxel exchange (boxes, counts, and when any rank has rows to send the packed "
                              "payload of all three scales) before every fragment"}
 
 

@@ -78,6 +78,11 @@ SIGNATURES = {
     "eprecon_fbv_union_workspace_bytes": (_sz, [_i]),
     "eprecon_fbv_union_async": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _vp, _sz, _vp]),
+    "eprecon_map_set_fragment": (_i, [_vp, _i]),
+    "eprecon_map_stamps_async": (_i, [_vp, _vp, _vp, _i, _c.c_int32, _vp]),
+    "eprecon_map_select_boundary_async": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "eprecon_map_pack_boundary_async": (_i, [_vp, _vp, _i64, _vp]),
+    "eprecon_map_merge_boundary": (_i, [_vp, _vp, _i64, _vp, _i, _vp, _vp]),
     "eprecon_map_create": (_i, [_i, _c.POINTER(_vp)]),
     "eprecon_map_destroy": (_i, [_vp]),
     "eprecon_map_reset": (_i, [_vp]),

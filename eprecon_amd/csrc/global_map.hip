@@ -35,6 +35,15 @@ struct EpMap {
     size_t dense_bytes = 0;
     int64_t kept = -1;  // rows outside the FBV of the last crop (-1: no crop pending)
     int rel[3] = {0, 0, 0};
+    // multi-GPU boundary exchange: per row, which fragment produced its features and whether THIS rank
+    // fused it: 0 unknown, +(fragment + 1) fused here, -(fragment + 1) received from another rank
+    int32_t *stamps[2] = {nullptr, nullptr};  // [cap], allocated with the rows
+    int fuse_stamp = 0;                       // what eprecon_map_update_async writes for the rows it appends
+    int32_t *sel = nullptr, *sel_rank = nullptr, *sel_aux = nullptr;  // [sel_cap] selection flags of the exchange, their scan, merge scratch
+    int64_t sel_cap = 0;
+    int32_t *sel_scratch = nullptr;
+    int64_t sel_scratch_cap = 0;
+    int64_t n_selected = -1;
 };
 
 int ensure_rows(EpMap *m, int64_t rows)
@@ -43,19 +52,24 @@ int ensure_rows(EpMap *m, int64_t rows)
     int64_t cap = m->cap > 0 ? m->cap : 4096;
     while (cap < rows) cap *= 2;
     for (int b = 0; b < 2; ++b) {
-        int32_t *c = nullptr;
+        int32_t *c = nullptr, *s = nullptr;
         float *f = nullptr;
         EP_HIP_CHECK(hipMalloc(&c, (size_t)cap * 3 * sizeof(int32_t)));
         EP_HIP_CHECK(hipMalloc(&f, (size_t)cap * m->channels * sizeof(float)));
+        EP_HIP_CHECK(hipMalloc(&s, (size_t)cap * sizeof(int32_t)));
+        EP_HIP_CHECK(hipMemset(s, 0, (size_t)cap * sizeof(int32_t)));
         if (b == m->cur && m->size > 0) {  // only the live buffer carries data
             EP_HIP_CHECK(hipMemcpy(c, m->coords[b], (size_t)m->size * 3 * sizeof(int32_t), hipMemcpyDeviceToDevice));
             EP_HIP_CHECK(hipMemcpy(f, m->feats[b], (size_t)m->size * m->channels * sizeof(float),
                                    hipMemcpyDeviceToDevice));
+            EP_HIP_CHECK(hipMemcpy(s, m->stamps[b], (size_t)m->size * sizeof(int32_t), hipMemcpyDeviceToDevice));
         }
         if (m->coords[b]) EP_HIP_CHECK(hipFree(m->coords[b]));
         if (m->feats[b]) EP_HIP_CHECK(hipFree(m->feats[b]));
+        if (m->stamps[b]) EP_HIP_CHECK(hipFree(m->stamps[b]));
         m->coords[b] = c;
         m->feats[b] = f;
+        m->stamps[b] = s;
     }
     m->cap = cap;
     return EPRECON_OK;
@@ -176,8 +190,8 @@ __global__ __launch_bounds__(256) void map_gather_kernel(const float *feat, int 
 
 // stable compaction of the kept rows (old order) into the other buffer
 __global__ __launch_bounds__(256) void map_compact_kernel(const int32_t *keep, const int32_t *keep_rank, int n,
-                                                          const int32_t *c_in, const float *f_in, int C,
-                                                          int32_t *c_out, float *f_out)
+                                                          const int32_t *c_in, const float *f_in, const int32_t *s_in, int C,
+                                                          int32_t *c_out, float *f_out, int32_t *s_out)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int W = C + 3;
@@ -185,24 +199,154 @@ __global__ __launch_bounds__(256) void map_compact_kernel(const int32_t *keep, c
     const int j = (int)(e / W), c = (int)(e - (int64_t)j * W);
     if (!keep[j]) return;
     const int o = keep_rank[j];
-    if (c < 3)
+    if (c < 3) {
         c_out[3 * (size_t)o + c] = c_in[3 * (size_t)j + c];
-    else
+        if (c == 0) s_out[o] = s_in[j];
+    } else {
         f_out[(size_t)o * C + (c - 3)] = f_in[(size_t)j * C + (c - 3)];
+    }
 }
 
 __global__ __launch_bounds__(256) void map_append_kernel(const int32_t *updated, const float *values, int ld_v, int n, int C,
-                                                         int rx, int ry, int rz, int64_t base, int32_t *c_out, float *f_out)
+                                                         int rx, int ry, int rz, int64_t base, int stamp, int32_t *c_out,
+                                                         float *f_out, int32_t *s_out)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int W = C + 3;
     if (e >= (int64_t)n * W) return;
     const int i = (int)(e / W), c = (int)(e - (int64_t)i * W);
     const size_t o = (size_t)(base + i);
-    if (c < 3)
+    if (c < 3) {
         c_out[3 * o + c] = updated[3 * (size_t)i + c] + (c == 0 ? rx : (c == 1 ? ry : rz));
-    else
+        if (c == 0) s_out[o] = stamp;
+    } else {
         f_out[o * C + (c - 3)] = values[(size_t)i * ld_v + (c - 3)];
+    }
+}
+
+// ---- boundary exchange: selection, packing, merge (replace the boolean-indexing / sort / searchsorted glue) ----
+// flag the rows this rank fused itself that lie inside any OTHER rank's fragment bounding volume
+__global__ __launch_bounds__(256) void map_select_kernel(const int32_t *coords, const int32_t *stamps, int n,
+                                                         const int32_t *boxes, int nbox, int skip_box, int D, int32_t *sel)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    int hit = 0;
+    if (stamps[j] > 0) {
+        const int x = coords[3 * j], y = coords[3 * j + 1], z = coords[3 * j + 2];
+        for (int b = 0; b < nbox && !hit; ++b) {
+            if (b == skip_box) continue;
+            const int lx = boxes[3 * b], ly = boxes[3 * b + 1], lz = boxes[3 * b + 2];
+            hit = x >= lx && x < lx + D && y >= ly && y < ly + D && z >= lz && z < lz + D;
+        }
+    }
+    sel[j] = hit;
+}
+// payload row = (x, y, z, fragment index: int32 bit patterns | C feature floats), selected rows in map order
+__global__ __launch_bounds__(256) void map_pack_kernel(const int32_t *sel, const int32_t *sel_rank, int n, const int32_t *coords,
+                                                       const float *feats, const int32_t *stamps, int C, float *payload)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int W = C + 4;
+    if (e >= (int64_t)n * W) return;
+    const int j = (int)(e / W), c = (int)(e - (int64_t)j * W);
+    if (!sel[j]) return;
+    float *row = payload + (size_t)sel_rank[j] * W;
+    if (c < 3) row[c] = __int_as_float(coords[3 * (size_t)j + c]);
+    else if (c == 3) row[3] = __int_as_float(stamps[j] - 1);
+    else row[c] = feats[(size_t)j * C + (c - 4)];
+}
+__global__ void map_index_kernel(const int32_t *coords, int n, int D, int lx, int ly, int lz, int32_t *idx)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int x = coords[3 * j] - lx, y = coords[3 * j + 1] - ly, z = coords[3 * j + 2] - lz;
+    if (x >= 0 && x < D && y >= 0 && y < D && z >= 0 && z < D) idx[(x * D + y) * D + z] = j;
+}
+__device__ __forceinline__ int payload_cell(const float *row, int D, int lx, int ly, int lz)
+{
+    const int x = __float_as_int(row[0]) - lx, y = __float_as_int(row[1]) - ly, z = __float_as_int(row[2]) - lz;
+    return (x >= 0 && x < D && y >= 0 && y < D && z >= 0 && z < D) ? (x * D + y) * D + z : -1;
+}
+// newest received copy per cell: best[cell] = max(fragment + 1)
+__global__ void merge_best_kernel(const float *payload, int n, int W, int D, int lx, int ly, int lz, int32_t *best)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *row = payload + (size_t)i * W;
+    const int cell = payload_cell(row, D, lx, ly, lz);
+    if (cell >= 0) atomicMax(best + cell, __float_as_int(row[3]) + 1);
+}
+// the (unique) newest copy of a cell: overwrites the local row when it is newer, or is flagged for appending
+__global__ void merge_claim_kernel(const float *payload, int n, int W, int D, int lx, int ly, int lz, int32_t *best,
+                                   const int32_t *idx, const int32_t *stamps, int32_t *action)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *row = payload + (size_t)i * W;
+    const int cell = payload_cell(row, D, lx, ly, lz);
+    int act = 0;  // 0 drop, 1 append, 2 + row: overwrite that row
+    if (cell >= 0) {
+        const int v = __float_as_int(row[3]) + 1;
+        if (atomicCAS(best + cell, v, -v) == v) {  // first claimant of the newest stamp
+            const int j = idx[cell];
+            if (j < 0) act = 1;
+            else if (v > abs(stamps[j])) act = 2 + j;
+        }
+    }
+    action[i] = act;
+}
+__global__ __launch_bounds__(256) void merge_apply_kernel(const float *payload, int n, int C, const int32_t *action,
+                                                          const int32_t *add_rank, int64_t base, int32_t *coords, float *feats,
+                                                          int32_t *stamps)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int W = C + 4;
+    if (e >= (int64_t)n * W) return;
+    const int i = (int)(e / W), c = (int)(e - (int64_t)i * W);
+    const int act = action[i];
+    if (act == 0) return;
+    const float *row = payload + (size_t)i * W;
+    const size_t o = act == 1 ? (size_t)(base + add_rank[i]) : (size_t)(act - 2);
+    if (c < 3) {
+        if (act == 1) coords[3 * o + c] = __float_as_int(row[c]);
+    } else if (c == 3) {
+        stamps[o] = -(__float_as_int(row[3]) + 1);  // received, not to be re-broadcast
+    } else {
+        feats[o * C + (c - 4)] = row[c];
+    }
+}
+__global__ void action_to_flag_kernel(const int32_t *action, int n, int32_t *flag)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = action[i] == 1;
+}
+__global__ void fill_i32_kernel(int32_t *p, int64_t n, int32_t v)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+int ensure_sel(EpMap *m, int64_t rows)
+{
+    if (rows > m->sel_cap) {
+        int64_t cap = m->sel_cap > 0 ? m->sel_cap : 4096;
+        while (cap < rows) cap *= 2;
+        if (m->sel) EP_HIP_CHECK(hipFree(m->sel));
+        if (m->sel_rank) EP_HIP_CHECK(hipFree(m->sel_rank));
+        if (m->sel_aux) EP_HIP_CHECK(hipFree(m->sel_aux));
+        EP_HIP_CHECK(hipMalloc(&m->sel, (size_t)cap * sizeof(int32_t)));
+        EP_HIP_CHECK(hipMalloc(&m->sel_rank, (size_t)cap * sizeof(int32_t)));
+        EP_HIP_CHECK(hipMalloc(&m->sel_aux, (size_t)cap * sizeof(int32_t)));
+        m->sel_cap = cap;
+    }
+    const int64_t need = ceil_div(rows, 2048) + 8;
+    if (need > m->sel_scratch_cap) {
+        if (m->sel_scratch) EP_HIP_CHECK(hipFree(m->sel_scratch));
+        EP_HIP_CHECK(hipMalloc(&m->sel_scratch, (size_t)need * sizeof(int32_t)));
+        m->sel_scratch_cap = need;
+    }
+    return EPRECON_OK;
 }
 
 // ---- ground-truth twin ----
@@ -277,7 +421,12 @@ int eprecon_map_destroy(void *handle)
     for (int b = 0; b < 2; ++b) {
         if (m->coords[b]) (void)hipFree(m->coords[b]);
         if (m->feats[b]) (void)hipFree(m->feats[b]);
+        if (m->stamps[b]) (void)hipFree(m->stamps[b]);
     }
+    if (m->sel) (void)hipFree(m->sel);
+    if (m->sel_rank) (void)hipFree(m->sel_rank);
+    if (m->sel_aux) (void)hipFree(m->sel_aux);
+    if (m->sel_scratch) (void)hipFree(m->sel_scratch);
     if (m->keep) (void)hipFree(m->keep);
     if (m->keep_rank) (void)hipFree(m->keep_rank);
     if (m->scan_scratch) (void)hipFree(m->scan_scratch);
@@ -326,9 +475,124 @@ int eprecon_map_import_async(void *handle, const int32_t *coords, const float *f
         EP_HIP_CHECK(hipMemcpyAsync(m->coords[m->cur], coords, (size_t)n * 3 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
         EP_HIP_CHECK(hipMemcpyAsync(m->feats[m->cur], feats, (size_t)n * m->channels * sizeof(float),
                                     hipMemcpyDeviceToDevice, st));
+        EP_HIP_CHECK(hipMemsetAsync(m->stamps[m->cur], 0, (size_t)n * sizeof(int32_t), st));  // origin unknown
     }
     m->size = n;
     m->kept = -1;
+    return EPRECON_OK;
+}
+
+int eprecon_map_set_fragment(void *handle, int fragment_index)
+{
+    EpMap *m = as_map(handle);
+    if (!m || fragment_index < -1 || fragment_index > 0x3ffffffe) return EPRECON_ERR_ARG;
+    m->fuse_stamp = fragment_index + 1;  // -1: rows appended by update carry no origin (single-GPU default)
+    return EPRECON_OK;
+}
+
+int eprecon_map_stamps_async(void *handle, int32_t *export_to, const int32_t *import_from, int fill_all, int32_t fill_value,
+                             void *stream)
+{
+    EpMap *m = as_map(handle);
+    if (!m) return EPRECON_ERR_ARG;
+    if (m->size == 0) return EPRECON_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (import_from)
+        EP_HIP_CHECK(hipMemcpyAsync(m->stamps[m->cur], import_from, (size_t)m->size * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    if (fill_all) {
+        hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)ceil_div(m->size, 256)), dim3(256), 0, st, m->stamps[m->cur], m->size,
+                           fill_value);
+        EP_LAUNCH_CHECK();
+    }
+    if (export_to)
+        EP_HIP_CHECK(hipMemcpyAsync(export_to, m->stamps[m->cur], (size_t)m->size * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    return EPRECON_OK;
+}
+
+int eprecon_map_select_boundary_async(void *handle, const int32_t *boxes_lo, int n_boxes, int own_box, int dim,
+                                      int32_t *count_out, void *stream)
+{
+    EpMap *m = as_map(handle);
+    if (!m || n_boxes < 0 || n_boxes > 4096 || dim <= 0 || !count_out || (n_boxes > 0 && !boxes_lo)) return EPRECON_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    m->n_selected = -1;
+    if (m->size == 0 || n_boxes == 0) {
+        EP_HIP_CHECK(hipMemsetAsync(count_out, 0, sizeof(int32_t), st));
+        m->n_selected = 0;
+        return EPRECON_OK;
+    }
+    int rc = ensure_sel(m, m->size);
+    if (rc != EPRECON_OK) return rc;
+    hipLaunchKernelGGL(map_select_kernel, dim3((unsigned)ceil_div(m->size, 256)), dim3(256), 0, st,
+                       (const int32_t *)m->coords[m->cur], (const int32_t *)m->stamps[m->cur], (int)m->size, boxes_lo, n_boxes,
+                       own_box, dim, m->sel);
+    EP_LAUNCH_CHECK();
+    return ep::exclusive_scan_i32(m->sel, (int)m->size, m->sel_rank, m->sel_scratch, count_out, st);
+}
+
+int eprecon_map_pack_boundary_async(void *handle, float *payload, int64_t n_rows, void *stream)
+{
+    EpMap *m = as_map(handle);
+    if (!m || n_rows < 0 || (n_rows > 0 && !payload)) return EPRECON_ERR_ARG;
+    if (n_rows == 0 || m->size == 0) return EPRECON_OK;
+    if (m->n_selected == 0) return EPRECON_ERR_ARG;  // nothing was selected, yet rows are asked for
+    const int W = m->channels + 4;
+    hipLaunchKernelGGL(map_pack_kernel, dim3((unsigned)ceil_div(m->size * W, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const int32_t *)m->sel, (const int32_t *)m->sel_rank, (int)m->size, (const int32_t *)m->coords[m->cur],
+                       (const float *)m->feats[m->cur], (const int32_t *)m->stamps[m->cur], m->channels, payload);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_map_merge_boundary(void *handle, const float *payload, int64_t n_rows, const int32_t *box_lo_host, int dim,
+                               int64_t *n_added_host, void *stream)
+{
+    EpMap *m = as_map(handle);
+    if (!m || n_rows < 0 || dim <= 0 || dim > 512 || !box_lo_host || (n_rows > 0 && !payload)) return EPRECON_ERR_ARG;
+    if (n_added_host) *n_added_host = 0;
+    if (n_rows == 0) return EPRECON_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int cells = dim * dim * dim;
+    if (m->size + n_rows > m->cap) {
+        EP_HIP_CHECK(hipStreamSynchronize(st));
+        int rc = ensure_rows(m, m->size + n_rows);
+        if (rc != EPRECON_OK) return rc;
+    }
+    int rc = ensure_dense(m, dim);
+    if (rc == EPRECON_OK) rc = ensure_sel(m, n_rows);
+    if (rc != EPRECON_OK) return rc;
+    const size_t seg = align_up((size_t)cells * 4, 256);
+    int32_t *idx = reinterpret_cast<int32_t *>(m->dense);          // local row of a cell, -1 = none
+    int32_t *best = reinterpret_cast<int32_t *>(m->dense + seg);   // newest received fragment + 1, 0 = none
+    EP_HIP_CHECK(hipMemsetAsync(idx, 0xFF, seg, st));
+    EP_HIP_CHECK(hipMemsetAsync(best, 0, seg, st));
+    const int lx = box_lo_host[0], ly = box_lo_host[1], lz = box_lo_host[2], W = m->channels + 4;
+    const dim3 blk(256), grows((unsigned)ceil_div(n_rows, 256));
+    if (m->size > 0) {
+        hipLaunchKernelGGL(map_index_kernel, dim3((unsigned)ceil_div(m->size, 256)), blk, 0, st, (const int32_t *)m->coords[m->cur],
+                           (int)m->size, dim, lx, ly, lz, idx);
+        EP_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(merge_best_kernel, grows, blk, 0, st, payload, (int)n_rows, W, dim, lx, ly, lz, best);
+    EP_LAUNCH_CHECK();
+    int32_t *action = m->sel_rank, *flag = m->sel;   // (selection scratch: the send side of this exchange is over)
+    hipLaunchKernelGGL(merge_claim_kernel, grows, blk, 0, st, payload, (int)n_rows, W, dim, lx, ly, lz, best, (const int32_t *)idx,
+                       (const int32_t *)m->stamps[m->cur], action);
+    EP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(action_to_flag_kernel, grows, blk, 0, st, (const int32_t *)action, (int)n_rows, flag);
+    EP_LAUNCH_CHECK();
+    int32_t *add_rank = m->sel_aux;  // ranks of the appended rows, payload order
+    rc = ep::exclusive_scan_i32(flag, (int)n_rows, add_rank, m->sel_scratch, m->counts_dev + 2, st);
+    if (rc != EPRECON_OK) return rc;
+    hipLaunchKernelGGL(merge_apply_kernel, dim3((unsigned)ceil_div(n_rows * W, 256)), blk, 0, st, payload, (int)n_rows, m->channels,
+                       (const int32_t *)action, (const int32_t *)add_rank, m->size, m->coords[m->cur], m->feats[m->cur],
+                       m->stamps[m->cur]);
+    EP_LAUNCH_CHECK();
+    EP_HIP_CHECK(hipMemcpyAsync(m->counts_host + 2, m->counts_dev + 2, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    EP_HIP_CHECK(hipStreamSynchronize(st));
+    m->size += m->counts_host[2];
+    m->kept = -1;
+    if (n_added_host) *n_added_host = m->counts_host[2];
     return EPRECON_OK;
 }
 
@@ -412,14 +676,14 @@ int eprecon_map_update_async(void *handle, const int32_t *updated, int64_t n, co
     if (m->size > 0) {
         hipLaunchKernelGGL(map_compact_kernel, dim3((unsigned)ceil_div(m->size * W, 256)), dim3(256), 0, st,
                            (const int32_t *)m->keep, (const int32_t *)m->keep_rank, (int)m->size,
-                           (const int32_t *)m->coords[src], (const float *)m->feats[src], m->channels, m->coords[dst],
-                           m->feats[dst]);
+                           (const int32_t *)m->coords[src], (const float *)m->feats[src], (const int32_t *)m->stamps[src],
+                           m->channels, m->coords[dst], m->feats[dst], m->stamps[dst]);
         EP_LAUNCH_CHECK();
     }
     if (n > 0) {
         hipLaunchKernelGGL(map_append_kernel, dim3((unsigned)ceil_div(n * W, 256)), dim3(256), 0, st, updated, values,
-                           ld_values, (int)n, m->channels, m->rel[0], m->rel[1], m->rel[2], m->kept, m->coords[dst],
-                           m->feats[dst]);
+                           ld_values, (int)n, m->channels, m->rel[0], m->rel[1], m->rel[2], m->kept, m->fuse_stamp,
+                           m->coords[dst], m->feats[dst], m->stamps[dst]);
         EP_LAUNCH_CHECK();
     }
     m->cur = dst;
@@ -476,7 +740,8 @@ int eprecon_map_target_fuse(void *handle, const float *tsdf_gt, const uint8_t *o
     if (m->size > 0) {
         hipLaunchKernelGGL(map_compact_kernel, dim3((unsigned)ceil_div(m->size * 4, 256)), blk, 0, st,
                            (const int32_t *)m->keep, (const int32_t *)m->keep_rank, (int)m->size,
-                           (const int32_t *)m->coords[src], (const float *)m->feats[src], 1, m->coords[dst], m->feats[dst]);
+                           (const int32_t *)m->coords[src], (const float *)m->feats[src], (const int32_t *)m->stamps[src], 1,
+                           m->coords[dst], m->feats[dst], m->stamps[dst]);
         EP_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(target_append_kernel, gcells, blk, 0, st, (const float *)vol, (const int32_t *)flag,

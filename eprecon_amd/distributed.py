@@ -56,23 +56,47 @@ def _inside(c, lo, dim):
 
 
 class _Stamps:
-    """Per scale: a dense int32 volume over the scene grid holding, for every voxel, the index of the fragment that
-    produced its current features and whether this rank fused it itself: 0 = unknown, +(stamp + 1) = fused here,
-    -(stamp + 1) = received.  (A sorted key table cost three sorts of the whole key set per fragment; 288 GB of HBM make the
-    dense form the cheap one: `extent`^3 x 4 bytes, 512 MB for a 20 m scene at 4 cm, allocated on first use.)
-    Coordinates outside [-extent/2, extent/2) set `bad`, which the exchange reports at its one host read."""
+    """Reference (torch) form of the per-voxel origin stamps, used by the CPU / gloo tests and the stateless wrapper; on the
+    GPU the stamps are a column of the map handle (csrc/global_map.hip) and no volume exists.
+    Per scale: a dense int32 volume holding, for every voxel, the index of the fragment that produced its current features
+    and whether this rank fused it itself: 0 = unknown, +(stamp + 1) = fused here, -(stamp + 1) = received.
+    The volume is anchored at the first voxels it sees (lower corner minus a margin) and GROWS when a later voxel falls
+    outside (re-allocation + copy; one host read per put, acceptable on this path): no scene-size limit, no wasted half
+    range for the mostly non-negative map coordinates."""
+
+    MARGIN = 16
 
     def __init__(self, device, extent=None):
         self.device = device
-        self.extent = int(extent or (512 if device.type == "cuda" else 128))
+        self.extent = int(extent or 64)         # edge of the first allocation; doubles on overflow
+        self.origin = None                      # int64[3] lower corner (host list)
+        self.shape = None
         self.grid = None
-        self.bad = torch.zeros((), dtype=torch.bool, device=device)
+
+    def _fit(self, coords):
+        lo = coords.min(dim=0).values.tolist()
+        hi = coords.max(dim=0).values.tolist()
+        if self.grid is None:
+            self.origin = [int(v) - self.MARGIN for v in lo]
+            self.shape = [max(self.extent, int(h) - int(l) + 1 + 2 * self.MARGIN) for l, h in zip(lo, hi)]
+            self.grid = torch.zeros(self.shape, dtype=torch.int32, device=self.device)
+            return
+        new_lo = [min(o, int(v) - self.MARGIN) if int(v) < o else o for o, v in zip(self.origin, lo)]
+        new_hi = [max(o + n, int(v) + 1 + self.MARGIN) if int(v) >= o + n else o + n for o, n, v in zip(self.origin, self.shape, hi)]
+        if new_lo == self.origin and all(h == o + n for h, o, n in zip(new_hi, self.origin, self.shape)):
+            return
+        # grow geometrically so that a scene scanned along one axis re-allocates O(log) times
+        shape = [max(h - l, 2 * n if (h - l) > n else n) for l, h, n in zip(new_lo, new_hi, self.shape)]
+        grid = torch.zeros(shape, dtype=torch.int32, device=self.device)
+        off = [o - l for o, l in zip(self.origin, new_lo)]
+        grid[off[0]:off[0] + self.shape[0], off[1]:off[1] + self.shape[1], off[2]:off[2] + self.shape[2]] = self.grid
+        self.origin, self.shape, self.grid = new_lo, shape, grid
 
     def _index(self, coords):
-        e, h = self.extent, self.extent // 2
-        c = coords.to(torch.int64) + h
-        ok = ((c >= 0) & (c < e)).all(dim=1)
-        idx = (c[:, 0] * e + c[:, 1]) * e + c[:, 2]
+        c = coords.to(torch.int64) - torch.tensor(self.origin, dtype=torch.int64, device=self.device)
+        dims = torch.tensor(self.shape, dtype=torch.int64, device=self.device)
+        ok = ((c >= 0) & (c < dims)).all(dim=1)
+        idx = (c[:, 0] * self.shape[1] + c[:, 1]) * self.shape[2] + c[:, 2]
         return torch.where(ok, idx, torch.zeros_like(idx)), ok
 
     def put(self, coords, stamp, local):
@@ -80,13 +104,10 @@ class _Stamps:
         n = coords.shape[0]
         if n == 0:
             return
-        if self.grid is None:
-            self.grid = torch.zeros(self.extent ** 3, dtype=torch.int32, device=self.device)
-        idx, ok = self._index(coords)
-        self.bad |= ~ok.all()
+        self._fit(coords)
+        idx, _ = self._index(coords)
         val = (stamp.to(torch.int32) if torch.is_tensor(stamp) else torch.full((n,), int(stamp), dtype=torch.int32, device=self.device)) + 1
-        val = val if local else -val
-        self.grid[idx] = torch.where(ok, val, self.grid[idx])
+        self.grid.view(-1)[idx] = val if local else -val
 
     def get(self, coords):
         """-> (stamp int32[n] (-1 when unknown), local bool[n])"""
@@ -94,7 +115,7 @@ class _Stamps:
         if n == 0 or self.grid is None:
             return (torch.full((n,), -1, dtype=torch.int32, device=self.device), torch.zeros(n, dtype=torch.bool, device=self.device))
         idx, ok = self._index(coords)
-        v = torch.where(ok, self.grid[idx], torch.zeros_like(self.grid[idx]))
+        v = torch.where(ok, self.grid.view(-1)[idx], torch.zeros(n, dtype=torch.int32, device=self.device))
         return v.abs() - 1, v > 0
 
     def local_count(self):
@@ -105,14 +126,58 @@ class BoundaryExchange:
     """State and protocol of the boundary-voxel exchange for one GRUFusion (all scales)."""
 
     def __init__(self, n_scales, device, group=None, extent=None):
-        """extent: edge of the finest scale's stamp volume in voxels (coarser scales halve it), default 512 on a GPU"""
+        """extent: edge of the first allocation of the finest scale's reference stamp volume (it grows on demand)"""
         self.n_scales, self.device, self.group = n_scales, device, group
-        self.extent = int(extent or (512 if device.type == "cuda" else 128))
+        self.extent = int(extent or 128)
         self.stamps = [self.new_stamps(s) for s in range(n_scales)]
         self.collectives = 0        # issued so far (tests / bench reporting)
+        self.rows_sent = 0          # payload rows this rank contributed so far
 
     def new_stamps(self, scale):
         return _Stamps(self.device, max(self.extent >> (self.n_scales - 1 - scale), 32))
+
+    def exchange_handles(self, gmaps, boxes_lo, dims):
+        """The exchange on the map HANDLES (GPU): selection, packing and merge are kernels of libeprecon_hip.so
+        (eprecon_map_select_boundary_async / pack / merge); the stamps are a column of the map, no full-map export, no
+        boolean indexing / sort / searchsorted.  Same protocol and collectives as `exchange`; when no rank has anything to
+        send (every rank sees the same counts) the payload all-gather is skipped.  gmaps: per scale a GlobalMap."""
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        dev, ns = self.device, self.n_scales
+        lo = torch.as_tensor(boxes_lo, dtype=torch.int32, device=dev).reshape(ns, 3)
+        boxes = [torch.zeros_like(lo) for _ in range(world)]
+        dist.all_gather(boxes, lo, group=self.group)                                   # collective 1
+        all_boxes = torch.stack(boxes)                                                 # [world, ns, 3]
+        counts = torch.zeros(ns, dtype=torch.int32, device=dev)
+        for s, g in enumerate(gmaps):
+            g.select_boundary(all_boxes[:, s].contiguous(), rank, dims[s], counts[s:s + 1])
+        all_counts = [torch.zeros_like(counts) for _ in range(world)]
+        dist.all_gather(all_counts, counts, group=self.group)                          # collective 2
+        all_counts = torch.stack(all_counts).tolist()                                  # the one host read
+        self.collectives += 2
+        widths = [4 + g.channels for g in gmaps]
+        sizes = [sum(all_counts[r][s] * widths[s] for s in range(ns)) for r in range(world)]
+        if max(sizes) == 0:
+            return 0
+        payload = torch.empty(max(sizes), dtype=torch.float32, device=dev)
+        off = 0
+        for s, g in enumerate(gmaps):
+            n = all_counts[rank][s]
+            g.pack_boundary(payload[off:], n)
+            off += n * widths[s]
+        self.rows_sent += sum(all_counts[rank])
+        bufs = [torch.empty_like(payload) for _ in range(world)]
+        dist.all_gather(bufs, payload, group=self.group)                               # collective 3
+        self.collectives += 1
+        added = 0
+        lo_host = [list(map(int, b)) for b in boxes_lo]
+        for s, g in enumerate(gmaps):
+            for r in range(world):                                                     # rank order: deterministic appends
+                n = all_counts[r][s]
+                if r == rank or n == 0:
+                    continue
+                off = sum(all_counts[r][t] * widths[t] for t in range(s))
+                added += g.merge_boundary(bufs[r][off: off + n * widths[s]], n, lo_host[s], dims[s])
+        return added
 
     def reset(self):
         self.stamps = [self.new_stamps(s) for s in range(self.n_scales)]
@@ -130,7 +195,7 @@ class BoundaryExchange:
         lo = torch.as_tensor(boxes_lo, dtype=torch.int32, device=dev).reshape(ns, 3)
         boxes = [torch.zeros_like(lo) for _ in range(world)]
         dist.all_gather(boxes, lo, group=self.group)                                   # collective 1
-        send, counts = [], torch.zeros(ns + 1, dtype=torch.int64, device=dev)   # last slot: a stamp volume overflowed
+        send, counts = [], torch.zeros(ns, dtype=torch.int64, device=dev)
         for s, (c, f) in enumerate(maps):
             stamp, local = self.stamps[s].get(c)
             wanted = torch.zeros(c.shape[0], dtype=torch.bool, device=dev)
@@ -143,13 +208,9 @@ class BoundaryExchange:
                                fs.float()], dim=1)                                     # [n, 4 + C_s], ints bit-cast
             send.append(block.reshape(-1))
             counts[s] = cs.shape[0]
-            counts[ns] += self.stamps[s].bad.to(torch.int64)
         all_counts = [torch.zeros_like(counts) for _ in range(world)]
         dist.all_gather(all_counts, counts, group=self.group)                          # collective 2
         all_counts = torch.stack(all_counts).tolist()                                  # the one host read
-        if any(row[ns] for row in all_counts):   # every rank sees it and raises: no one is left waiting in a collective
-            raise RuntimeError("boundary exchange: a map voxel lies outside the stamp volume (scene larger than "
-                               f"{self.extent} finest voxels per axis); construct BoundaryExchange with a larger extent")
         widths = [4 + f.shape[1] for _, f in maps]
         sizes = [sum(all_counts[r][s] * widths[s] for s in range(ns)) for r in range(world)]
         cap = max(max(sizes), 1)
@@ -213,7 +274,7 @@ def exchange_boundary_voxels(map_c, map_f, fbv_lo, dim, group=None):
     """One-scale, stateless form kept for callers that hold a plain (C, F) map: every voxel counts as locally
     fused with stamp 0, so voxels already present locally are left alone (first owner wins) and missing ones
     inside the local FBV are appended."""
-    ex = BoundaryExchange(1, map_f.device, group)
+    ex = BoundaryExchange(1, map_f.device, group, extent=32)   # (anchored at the map's own lower corner, grows on demand)
     ex.stamps[0].put(map_c, 0, True)
     (c, f), = ex.exchange([(map_c, map_f)], [list(fbv_lo)], [dim])
     return c, f

@@ -96,6 +96,44 @@ class GlobalMap:
                                                         values.stride(0), _lib.current_stream()),
                    "eprecon_map_update_async")
 
+    # ---- multi-GPU boundary exchange (eprecon_amd/distributed.py) ----
+    def set_fragment(self, fragment_index):
+        """global index of the fragment whose fusion the next update() appends (-1: rows carry no origin)"""
+        _lib.check(_lib.load().eprecon_map_set_fragment(self._h, int(fragment_index)), "eprecon_map_set_fragment")
+
+    def stamps(self):
+        """int32[size]: 0 unknown, +(fragment + 1) fused by this rank, -(fragment + 1) received"""
+        out = torch.empty(self.size, dtype=torch.int32, device=self.device)
+        _lib.check(_lib.load().eprecon_map_stamps_async(self._h, _lib.ptr(out), None, 0, 0, _lib.current_stream()),
+                   "eprecon_map_stamps_async")
+        return out
+
+    def set_stamps(self, stamps=None, fill=None):
+        src = None if stamps is None else stamps.to(device=self.device, dtype=torch.int32).contiguous()
+        assert src is None or src.shape[0] == self.size
+        _lib.check(_lib.load().eprecon_map_stamps_async(self._h, None, _lib.ptr(src), int(fill is not None), int(fill or 0),
+                                                        _lib.current_stream()), "eprecon_map_stamps_async")
+
+    def select_boundary(self, boxes_lo, own_box, dim, count_out):
+        """boxes_lo int32[n_boxes,3] on the device; count_out: a device int32 element that receives the number of rows"""
+        _lib.check(_lib.load().eprecon_map_select_boundary_async(self._h, _lib.ptr(boxes_lo), boxes_lo.shape[0], int(own_box), int(dim),
+                                                                 _lib.ptr(count_out), _lib.current_stream()),
+                   "eprecon_map_select_boundary_async")
+
+    def pack_boundary(self, payload, n_rows):
+        """payload: f32 buffer with room for n_rows x (4 + channels)"""
+        _lib.check(_lib.load().eprecon_map_pack_boundary_async(self._h, _lib.ptr(payload), int(n_rows), _lib.current_stream()),
+                   "eprecon_map_pack_boundary_async")
+
+    def merge_boundary(self, payload, n_rows, box_lo, dim):
+        """-> number of rows appended (blocking)"""
+        lo = (ctypes.c_int32 * 3)(*[int(v) for v in box_lo])
+        added = ctypes.c_int64(0)
+        _lib.check(_lib.load().eprecon_map_merge_boundary(self._h, _lib.ptr(payload), int(n_rows), ctypes.cast(lo, ctypes.c_void_p),
+                                                          int(dim), ctypes.cast(ctypes.byref(added), ctypes.c_void_p),
+                                                          _lib.current_stream()), "eprecon_map_merge_boundary")
+        return int(added.value)
+
     def target_fuse(self, tsdf_gt, occ_gt, dim, rel, updated):
         """ground-truth twin (1 channel): -> tsdf_target f32[N',1] at the union voxels; the map is updated"""
         lib = _lib.load()

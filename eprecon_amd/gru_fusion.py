@@ -151,13 +151,19 @@ class GRUFusion(nn.Module):
         for scale in range(n):
             rels.append(self._begin_fragment(scale, inputs, i, dev).tolist())
             dims.append(self.cfg.N_VOX[0] // 2 ** (n - scale - 1))
+        # global index of the fragment this rank fuses next: ranks take the fragments of a scene round-robin
+        self._cur_fragment = self._n_exchanged * dist.get_world_size() + dist.get_rank()
+        self._n_exchanged += 1
+        if dev.type == "cuda":
+            # selection / packing / merge as kernels on the map handles; the stamps are a column of the map
+            self._xchg.exchange_handles([self.global_volume[scale] for scale in range(n)], rels, dims)
+            for scale in range(n):
+                self.global_volume[scale].set_fragment(self._cur_fragment)
+            return
         maps = [self.global_volume[scale].export() for scale in range(n)]
         for scale, (c, f) in enumerate(self._xchg.exchange(maps, rels, dims)):
             if c.shape[0] != maps[scale][0].shape[0] or f is not maps[scale][1]:
                 self.global_volume[scale].set(c, f)
-        # global index of the fragment this rank fuses next: ranks take the fragments of a scene round-robin
-        self._cur_fragment = self._n_exchanged * dist.get_world_size() + dist.get_rank()
-        self._n_exchanged += 1
 
     def forward(self, coords, values_in, inputs, scale=2, outputs=None, save_mesh=False, panoptic_infos=None):
         """coords int[N,4] (b,x,y,z) finest units, values_in f32[N,C] ->
@@ -250,7 +256,7 @@ class GRUFusion(nn.Module):
                 values[:, :chv], values[:, chv:] = hx_v[:, chv:], hx_i[:, chi:]
 
             gmap.update(updated, values.detach().contiguous() if recording else values)    # update_map (:195-215)
-            if self._xchg is not None:      # multi-GPU: these voxels now carry this rank's newest fusion result
+            if self._xchg is not None and dev.type != "cuda":   # (reference path; on the GPU update() stamps the rows itself)
                 rel_t = torch.tensor(rel_l, dtype=torch.int32, device=dev)
                 self._xchg.mark_fused(scale, updated + rel_t, self._cur_fragment)
 

@@ -489,6 +489,28 @@ int eprecon_map_update_async(void *handle, const int32_t *updated, int64_t n, co
 int eprecon_map_target_fuse(void *handle, const float *tsdf_gt, const uint8_t *occ_gt, int dim,
                             const int32_t *relative_origin_host, const int32_t *updated, int64_t n, float *tsdf_target_out,
                             void *stream);
+/*
+ * Multi-GPU boundary exchange on the handle (the schedule of eprecon_amd/distributed.py, which emulates the
+ * sequential map updates of models/gru_fusion.py:195-215,275 across ranks).  Every row carries a stamp: 0 unknown,
+ * +(fragment + 1) fused by THIS rank, -(fragment + 1) received.  eprecon_map_set_fragment: the global fragment index
+ * eprecon_map_update_async stamps its appended rows with (-1: none).  eprecon_map_stamps_async: import / fill / export the
+ * int32[size] stamps (in that order; NULL / 0 skips a step).
+ *   select  flags the rows fused here that lie inside any box boxes_lo[b] + [0, dim)^3 with b != own_box (device int32[n_boxes,3],
+ *           scene-grid units of this scale) and writes their number to count_out (device int32); asynchronous
+ *   pack    writes the selected rows in map order as payload f32[n_rows][4 + channels]: (x, y, z, fragment) as int32 bit
+ *           patterns, then the features; n_rows = the count select produced (read back by the caller with the other scales')
+ *   merge   applies received payload rows that fall inside the local box: per cell the newest copy wins (atomicMax + one
+ *           claim), it overwrites the local row when newer than it or is appended in payload order; received rows are
+ *           stamped negative so they are not re-broadcast.  Blocking (one host read: the number of appended rows).
+ */
+int eprecon_map_set_fragment(void *handle, int fragment_index);
+int eprecon_map_stamps_async(void *handle, int32_t *export_to, const int32_t *import_from, int fill_all, int32_t fill_value,
+                             void *stream);
+int eprecon_map_select_boundary_async(void *handle, const int32_t *boxes_lo, int n_boxes, int own_box, int dim,
+                                      int32_t *count_out, void *stream);
+int eprecon_map_pack_boundary_async(void *handle, float *payload, int64_t n_rows, void *stream);
+int eprecon_map_merge_boundary(void *handle, const float *payload, int64_t n_rows, const int32_t *box_lo_host, int dim,
+                               int64_t *n_added_host, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * TSDF integration of depth frames  (the data-preparation side of the path)
