@@ -100,6 +100,8 @@ class GRUFusion(nn.Module):
         self._side = None
         self._xchg = None              # multi-GPU: distributed.BoundaryExchange (stamps of the map voxels)
         self._n_exchanged = self._cur_fragment = 0
+        self._xchg_stream = None       # the exchange's own stream: its one host read must not drain the main stream
+        self._map_ready = None         # event behind the last map update (what the exchange has to wait for)
 
     def reset(self, i, device=None):
         """models/gru_fusion.py:59-65: empty maps (the handles keep their device memory)"""
@@ -147,6 +149,25 @@ class GRUFusion(nn.Module):
         n = self.cfg.N_LAYER
         if self._xchg is None:
             self._xchg = D.BoundaryExchange(n, dev)
+        if dev.type == "cuda" and __import__("os").environ.get("EPRECON_XCHG_STREAM", "1") == "1":
+            # The exchange reads the maps as the PREVIOUS fragment's last update left them and needs one host read (the
+            # counts).  On the main stream that read would wait for everything queued there — the host runs milliseconds
+            # ahead of the GPU — and end the run-ahead at the start of every fragment.  On its own stream it waits only for
+            # the event behind the last map update; the main stream joins it afterwards (the merges change the maps).
+            if self._xchg_stream is None:
+                self._xchg_stream = torch.cuda.Stream(device=dev)
+            main = torch.cuda.current_stream(dev)
+            if self._map_ready is not None:
+                self._xchg_stream.wait_event(self._map_ready)
+            else:
+                self._xchg_stream.wait_stream(main)
+            with torch.cuda.stream(self._xchg_stream):
+                self._exchange_on_current_stream(inputs, i, dev, n, dist)
+            main.wait_stream(self._xchg_stream)
+            return
+        self._exchange_on_current_stream(inputs, i, dev, n, dist)
+
+    def _exchange_on_current_stream(self, inputs, i, dev, n, dist):
         rels, dims = [], []
         for scale in range(n):
             rels.append(self._begin_fragment(scale, inputs, i, dev).tolist())
@@ -256,6 +277,8 @@ class GRUFusion(nn.Module):
                 values[:, :chv], values[:, chv:] = hx_v[:, chv:], hx_i[:, chi:]
 
             gmap.update(updated, values.detach().contiguous() if recording else values)    # update_map (:195-215)
+            if self._xchg is not None and dev.type == "cuda":
+                self._map_ready = torch.cuda.current_stream(dev).record_event()
             if self._xchg is not None and dev.type != "cuda":   # (reference path; on the GPU update() stamps the rows itself)
                 rel_t = torch.tensor(rel_l, dtype=torch.int32, device=dev)
                 self._xchg.mark_fused(scale, updated + rel_t, self._cur_fragment)

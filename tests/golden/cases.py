@@ -166,3 +166,21 @@ def panoptic_loss_case(seed=5, m=2600, n_keep=1800, q=10, dim=24, n_aux=2):
     semantic[0, xyz[:, 0], xyz[:, 1], xyz[:, 2]] = class_of[blocks]
     return {"coords_fine": coords_all[occupancy], "occupancy": occupancy, "occ_target": occ_target, "outs": outs,
             "semantic": semantic, "instance": instance}
+
+
+def mask3d_inputs_at_size(seed=23, c=48, n2=30000, n1=22000, n0=10000):
+    """cfg4-size voxel levels on the 96^3 grid for the mask-transformer decoder: every level-1 / level-0 voxel coincides with a
+    finest voxel (distance 0), so the reference's float cdist / argmin (models/mask3dformer.py) has a unique nearest voxel and
+    no tie to break by rounding noise.  -> [c0, c1, c2] int64[n,3], features f32[1,c,n] per level, mask features f32[1,c,n2]"""
+    rng = np.random.default_rng(seed)
+    c1 = rng.permutation(np.argwhere(np.ones((48, 48, 48), bool)))[:n1] * 2            # level 1: even coordinates
+    c0 = rng.permutation(np.argwhere(np.ones((24, 24, 24), bool)))[:n0] * 4            # level 0: multiples of 4
+    anchors = np.unique(np.concatenate([c1, c0]), axis=0)
+    extra = np.unique(rng.integers(0, 96, (3 * n2, 3)), axis=0)
+    taken = {tuple(v) for v in anchors}
+    extra = np.array([v for v in extra if tuple(v) not in taken])
+    extra = rng.permutation(extra)[: max(n2 - len(anchors), 0)]
+    c2 = rng.permutation(np.concatenate([anchors, extra]))
+    feats = [rng.standard_normal((1, c, len(x))).astype(np.float32) for x in (c0, c1, c2)]
+    mask_feat = rng.standard_normal((1, c, len(c2))).astype(np.float32)
+    return [c0.astype(np.int64), c1.astype(np.int64), c2.astype(np.int64)], feats, mask_feat

@@ -283,6 +283,49 @@ def gen_mask3dformer():
     _save("mask3dformer", **out)
 
 
+
+def gen_mask3dformer_at_size():
+    """the decoder in its production configuration (models/neucon_network.py:59-71: 80 queries, 48 channels, 8 heads, 6 layers)
+    on >= 20k voxels per level: what the graph-replayed / SDPA path of eprecon_amd/mask3dformer.py is tuned for.  Stored:
+    the state_dict, logits in full, the mask logits at 2,048 sampled voxels + per-query float64 sums, the panoptic labels."""
+    from models.mask3dformer import MultiScaleMaskedTransformerDecoder, panoptic_post
+
+    torch.manual_seed(9)
+    dec = MultiScaleMaskedTransformerDecoder(mask_classification=True, num_classes=20, hidden_dim=48, num_queries=80,
+                                             nheads=8, dim_feedforward=192, dec_layers=6, pre_norm=False, mask_dim=48)
+    with torch.no_grad():
+        dec.class_embed.bias[1:8] += 1.5
+        dec.class_embed.weight.mul_(3.0)
+    from cases import mask3d_inputs_at_size
+    coords, feats, mask_feat = mask3d_inputs_at_size()
+    out = {"n_per_level": np.array([len(c) for c in coords])}
+    for k, v in dec.state_dict().items():
+        out["sd__" + k] = v.numpy()
+    with torch.no_grad():
+        res = dec([torch.from_numpy(f) for f in feats], [torch.from_numpy(c)[None] for c in coords],
+                  torch.from_numpy(mask_feat), (96, 96, 96))
+        post = panoptic_post({"pred_logits": res["pred_logits"], "pred_masks": res["pred_masks"]})
+    masks = res["pred_masks"][0].numpy()
+    cols = _sample_rows(masks.shape[1], 2048, 99)
+    out["pred_logits"] = res["pred_logits"].numpy()
+    out["mask_cols"] = cols
+    out["pred_masks_sampled"] = masks[:, cols]
+    out["pred_masks_rowsum"] = masks.astype(np.float64).sum(1)
+    out["aux_last_masks_sampled"] = res["aux_outputs"][-1]["pred_masks"][0].numpy()[:, cols]
+    out["panoptic_seg"] = post["panoptic_seg"][0].numpy()
+    # margin of the per-voxel decision, so that the test can exclude voxels whose label hangs on rounding
+    prob = torch.softmax(res["pred_logits"][0], -1)
+    scores, labels = prob.max(-1)
+    keep = labels.ne(0) & (scores > 0.3)                       # models/mask3dformer.py:526
+    w = (scores[keep].view(-1, 1) * res["pred_masks"][0][keep].sigmoid())
+    out["n_kept_queries"] = np.array(int(keep.sum()))
+    top2 = torch.topk(w, min(2, w.shape[0]), dim=0).values
+    out["label_margin"] = (top2[0] - top2[1]).numpy() if w.shape[0] > 1 else np.ones(masks.shape[1], np.float32)
+    info = post["panoptic_seg"][1]
+    out["segments"] = np.array([[d["id"], int(d["isthing"]), d["category_id"]] for d in info], np.int64).reshape(-1, 3)
+    _save("mask3dformer_at_size", **out)
+
+
 def scene_fusion_inputs(seed=21, n_vox=24, n_frag=3):
     """fragments for fuse_to_global (direct substitution at the finest scale): coords, tsdf, panoptic ids"""
     rng = np.random.default_rng(seed)
@@ -562,7 +605,7 @@ def gen_criterion():
 
 
 GENERATORS = {"back_project": gen_back_project, "grid_ops": gen_grid_ops, "dense_blocks": gen_dense_blocks,
-              "gru_fusion": gen_gru_fusion, "mask3dformer": gen_mask3dformer, "scene_fusion": gen_scene_fusion,
+              "gru_fusion": gen_gru_fusion, "mask3dformer": gen_mask3dformer, "mask3dformer_at_size": gen_mask3dformer_at_size, "scene_fusion": gen_scene_fusion,
               "occ_init": gen_occ_init, "aligned_coords": gen_aligned_coords, "tsdf_fusion": gen_tsdf_fusion, "criterion": gen_criterion}
 
 if __name__ == "__main__":
