@@ -111,8 +111,28 @@ def export_ply(mesh, path):
         fh.write(frec.tobytes())
 
 
+def load_scene_npz(path):
+    """A scene file written by SaveScene -> the reference's dense arrays {origin, voxel_size, tsdf, semantic, instance}
+    (utils.py:360-366), whichever form it was written in.  The sparse form stores the scene as voxel rows
+    (coords int32[M,3] relative to `origin`, tsdf f32[M], semantic / instance int32[M], dims): the dense volumes
+    (TSDF default 1, ids default 0: models/gru_fusion.py:232-252) are rebuilt here, on the host that wants them."""
+    z = np.load(path)
+    if "coords" not in z.files:
+        return {k: z[k] for k in z.files}
+    dims, c = tuple(int(d) for d in z["dims"]), z["coords"].astype(np.int64)
+    out = {"origin": z["origin"], "voxel_size": z["voxel_size"]}
+    for key, fill, dtype in (("tsdf", 1.0, np.float32), ("semantic", 0, np.int32), ("instance", 0, np.int32)):
+        vol = np.full(dims, fill, dtype)
+        vol[c[:, 0], c[:, 1], c[:, 2]] = z[key]
+        out[key] = vol
+    return out
+
+
 class SaveScene:
-    """utils.py:190-410 (SAVE_SCENE_MESH / SAVE_INCREMENTAL paths; the Open3D incremental viewer is out of scope)"""
+    """utils.py:190-410 (SAVE_SCENE_MESH / SAVE_INCREMENTAL paths; the Open3D incremental viewer is out of scope).
+    cfg.SAVE_SCENE_NPZ (beyond the reference's keys): "sparse" (default) writes the scene volumes as voxel rows — a few MB
+    device -> host instead of three dense volumes (utils.py:345-348,380-385 copy them); "dense" writes the reference's
+    arrays.  load_scene_npz reads both."""
 
     def __init__(self, cfg):
         self.cfg = cfg
@@ -138,12 +158,46 @@ class SaveScene:
         mesh, mesh_sem, mesh_ins = tsdf_panoptic2mesh(self._voxel_size(), origin, tsdf, sem, ins)
         save_path = "{}_fusion_eval_{}".format(self.log_dir, epoch)
         os.makedirs(save_path, exist_ok=True)
-        np.savez_compressed(os.path.join(save_path, "{}.npz".format(self.scene_name)),
-                            origin=origin.cpu().numpy(), voxel_size=self._voxel_size(), tsdf=tsdf.cpu().numpy(),
-                            semantic=sem.cpu().numpy(), instance=ins.cpu().numpy())
+        sparse = (outputs.get("scene_sparse") or [None] * (batch_idx + 1))[batch_idx]
+        if sparse is not None and str(getattr(self.cfg, "SAVE_SCENE_NPZ", "sparse")) == "sparse":
+            # the scene as voxel rows: M x (3 + 3) values cross PCIe instead of 3 dense volumes
+            np.savez_compressed(os.path.join(save_path, "{}.npz".format(self.scene_name)),
+                                origin=origin.cpu().numpy(), voxel_size=self._voxel_size(), dims=np.array(sparse["dims"]),
+                                coords=sparse["coords"].cpu().numpy(), tsdf=sparse["tsdf"].cpu().numpy(),
+                                semantic=sparse["semantic"].cpu().numpy(), instance=sparse["instance"].cpu().numpy())
+        else:
+            np.savez_compressed(os.path.join(save_path, "{}.npz".format(self.scene_name)),
+                                origin=origin.cpu().numpy(), voxel_size=self._voxel_size(), tsdf=tsdf.cpu().numpy(),
+                                semantic=sem.cpu().numpy(), instance=ins.cpu().numpy())
         export_ply(mesh, os.path.join(save_path, "{}.ply".format(self.scene_name)))
         export_ply(mesh_sem, os.path.join(save_path, "mesh_semantic_{}.ply".format(self.scene_name)))
         export_ply(mesh_ins, os.path.join(save_path, "mesh_instance_{}.ply".format(self.scene_name)))
+        return save_path
+
+    def save_incremental(self, epoch_idx, batch_idx, imgs, outputs):
+        """utils.py:318-360: per key frame (self.keyframe_id, set by the caller: main.py:388) the fragment's images as PNG
+        and the scene mesh so far in three colourings.  imgs: [V,3,H,W] in 0..255; the volumes stay on the device, the
+        meshes are extracted there (csrc/marching_cubes.hip)"""
+        from PIL import Image
+        save_path = os.path.join("incremental_" + self.log_dir + "_" + str(epoch_idx), self.scene_name)
+        sub = {k: os.path.join(save_path, k) for k in ("mesh", "mesh_semantic", "mesh_instance", "mesh_image")}
+        for d in sub.values():
+            os.makedirs(d, exist_ok=True)
+        for i, img in enumerate(imgs):
+            arr = img.permute(1, 2, 0).detach().cpu().numpy().astype(np.uint8)
+            Image.fromarray(arr).save(os.path.join(sub["mesh_image"], "image_{}_{}.png".format(self.keyframe_id, i)))
+        tsdf = outputs["scene_tsdf"][batch_idx]
+        sem, ins = outputs["scene_semantic"][batch_idx], outputs["scene_instance"][batch_idx]
+        origin = outputs["origin"][batch_idx].clone()
+        if str(getattr(self.cfg, "DATASET", "scannet")) == "demo":
+            origin[2] -= 1.5
+        if bool((tsdf == 1).all()):
+            print(f"[eprecon_amd] warning: No valid partial data for scene {self.scene_name}")
+            return None
+        mesh, mesh_sem, mesh_ins = tsdf_panoptic2mesh(self._voxel_size(), origin, tsdf, sem, ins)
+        export_ply(mesh, os.path.join(sub["mesh"], "mesh_{}.ply".format(self.keyframe_id)))
+        export_ply(mesh_sem, os.path.join(sub["mesh_semantic"], "mesh_semantic_{}.ply".format(self.keyframe_id)))
+        export_ply(mesh_ins, os.path.join(sub["mesh_instance"], "mesh_instance_{}.ply".format(self.keyframe_id)))
         return save_path
 
     def __call__(self, outputs, inputs, epoch_idx):
@@ -151,5 +205,7 @@ class SaveScene:
             return
         for i, scene in enumerate(outputs["scene_name"]):
             self.scene_name = scene.replace("/", "-")
+            if getattr(self.cfg, "SAVE_INCREMENTAL", False):       # utils.py:387-388
+                self.save_incremental(epoch_idx, i, inputs["imgs"][i], outputs)
             if getattr(self.cfg, "SAVE_SCENE_MESH", True):
                 self.save_scene_eval(epoch_idx, outputs, i)

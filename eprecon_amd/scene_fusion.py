@@ -77,16 +77,23 @@ class SceneFusion:
     def save_mesh(self, outputs, scene):
         """dense scene volumes (:217-257): TSDF default 1, ids default 0, origin = min corner"""
         outputs = outputs if outputs is not None else {}
+        # (beyond the reference's keys: `scene_sparse`, the same scene as voxel rows — what save_scene.SaveScene writes
+        # to disk, so that no dense volume has to cross PCIe)
+        keys = ("origin", "scene_tsdf", "scene_name", "scene_instance", "scene_semantic", "scene_sparse")
         if "scene_name" not in outputs:
-            for k in ("origin", "scene_tsdf", "scene_name", "scene_instance", "scene_semantic"):
+            for k in keys:
                 outputs[k] = []
+        outputs.setdefault("scene_sparse", [None] * len(outputs["scene_name"]))
         if scene in outputs["scene_name"]:
             idx = outputs["scene_name"].index(scene)
-            for k in ("origin", "scene_tsdf", "scene_name", "scene_instance", "scene_semantic"):
+            for k in keys:
                 del outputs[k][idx]
         outputs["scene_name"].append(scene)
         lo = self.C.min(dim=0)[0]
         hi = self.C.max(dim=0)[0]
+        outputs["scene_sparse"].append({"coords": (self.C - lo).contiguous(), "tsdf": self.F[:, 0].contiguous(),
+                                        "instance": self.instance, "semantic": self.semantic,
+                                        "dims": tuple((hi - lo + 1).tolist())})
         outputs["origin"].append(lo.float() * self.cfg.VOXEL_SIZE)
         dims = (hi - lo + 1).tolist()
         idx = (self.C - lo).long()

@@ -108,3 +108,78 @@ def test_save_scene_writes_meshes_of_a_fused_scene(tmp_path, monkeypatch):
     assert len(mesh["vertices"]) > 5000 and mesh["faces"].max() < len(mesh["vertices"])
     # the floor of the analytic room is at z = 0: there are mesh vertices within half a voxel of it
     assert (np.abs(mesh["vertices"][:, 2]) < 0.02).sum() > 500
+
+
+def test_load_scene_npz_rebuilds_the_reference_dense_arrays(tmp_path):
+    """sparse scene file (voxel rows) -> the dense arrays of utils.py:360-366: TSDF default 1, ids default 0"""
+    from eprecon_amd.save_scene import load_scene_npz
+    rng = np.random.default_rng(0)
+    dims = (9, 7, 11)
+    cells = rng.choice(np.prod(dims), 200, replace=False)
+    c = np.stack(np.unravel_index(cells, dims), 1).astype(np.int32)
+    tsdf = rng.uniform(-1, 1, 200).astype(np.float32)
+    sem, ins = rng.integers(0, 21, 200).astype(np.int32), rng.integers(0, 50, 200).astype(np.int32)
+    p = tmp_path / "s.npz"
+    np.savez_compressed(p, origin=np.zeros(3, np.float32), voxel_size=0.04, dims=np.array(dims), coords=c, tsdf=tsdf,
+                        semantic=sem, instance=ins)
+    z = load_scene_npz(str(p))
+    ref = np.ones(dims, np.float32)
+    ref[c[:, 0], c[:, 1], c[:, 2]] = tsdf
+    assert np.array_equal(z["tsdf"], ref) and z["semantic"].sum() == sem.sum() and z["instance"].dtype == np.int32
+    assert z["semantic"][c[0, 0], c[0, 1], c[0, 2]] == sem[0] and (z["semantic"] != 0).sum() <= 200
+    dense = tmp_path / "d.npz"
+    np.savez_compressed(dense, origin=np.zeros(3), voxel_size=0.04, tsdf=ref, semantic=z["semantic"], instance=z["instance"])
+    assert np.array_equal(load_scene_npz(str(dense))["tsdf"], ref)
+
+
+@pytest.mark.gpu
+def test_scene_fusion_sparse_export_and_incremental_saving(tmp_path, monkeypatch):
+    """GRUFusion(direct_substitute).save_mesh also hands out the scene as voxel rows (`scene_sparse`); SaveScene writes the
+    .npz from them (no dense device -> host copy), load_scene_npz gives back exactly the dense volumes the reference stores
+    (models/gru_fusion.py:217-257, utils.py:345-372); SAVE_INCREMENTAL writes the per-keyframe meshes and images
+    (utils.py:318-360)"""
+    torch = pytest.importorskip("torch")
+    from types import SimpleNamespace
+    from eprecon_amd import save_scene as SS
+    from eprecon_amd.config import ModelCfg
+    from eprecon_amd.scene_fusion import SceneFusion
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(1)
+    fus = SceneFusion(ModelCfg())
+    fus.reset(torch.device("cuda"))
+    m = 5000
+    cells = rng.choice(40 * 30 * 20, m, replace=False)
+    c = np.stack(np.unravel_index(cells, (40, 30, 20)), 1).astype(np.int32) + np.array([5, -3, 2], np.int32)
+    fus.C = torch.from_numpy(c).cuda()
+    # a thin shell around the plane x = 20 (so that there is a zero crossing to mesh)
+    fus.F = torch.from_numpy(np.clip((c[:, :1] - 25 + rng.normal(0, 0.1, (m, 1))) / 3, -1, 1).astype(np.float32)).cuda()
+    fus.instance = torch.from_numpy(rng.integers(0, 40, m).astype(np.int32)).cuda()
+    fus.semantic = torch.from_numpy(rng.integers(0, 21, m).astype(np.int32)).cuda()
+    outputs = fus.save_mesh({}, "scene0007/01")
+    sp = outputs["scene_sparse"][0]
+    assert sp["dims"] == tuple(outputs["scene_tsdf"][0].shape) and sp["coords"].shape == (m, 3)
+    cfg = SimpleNamespace(LOGDIR="logs/run", DATASET="scannet", SAVE_SCENE_MESH=True, SAVE_INCREMENTAL=True,
+                          MODEL=SimpleNamespace(VOXEL_SIZE=0.04))
+    saver = SS.SaveScene(cfg)
+    saver.keyframe_id = 3                                                      # main.py:388
+    imgs = torch.from_numpy(rng.integers(0, 255, (1, 9, 3, 24, 32)).astype(np.float32)).cuda()
+    saver(outputs, {"imgs": imgs}, 2)
+    z = SS.load_scene_npz(os.path.join("results", "scene_scannet_run_fusion_eval_2", "scene0007-01.npz"))
+    assert np.array_equal(z["tsdf"], outputs["scene_tsdf"][0].cpu().numpy())
+    assert np.array_equal(z["semantic"], outputs["scene_semantic"][0].cpu().numpy())
+    assert np.array_equal(z["instance"], outputs["scene_instance"][0].cpu().numpy())
+    raw = np.load(os.path.join("results", "scene_scannet_run_fusion_eval_2", "scene0007-01.npz"))
+    assert "coords" in raw.files and raw["tsdf"].shape == (m,)                 # rows, not volumes, were written
+    inc = os.path.join("incremental_results", "scene_scannet_run_2", "scene0007-01")
+    inc = "incremental_" + os.path.join("results", "scene_scannet_run") + "_2" + os.sep + "scene0007-01"
+    assert sorted(os.listdir(inc)) == ["mesh", "mesh_image", "mesh_instance", "mesh_semantic"]
+    assert os.listdir(os.path.join(inc, "mesh")) == ["mesh_3.ply"]
+    assert len(os.listdir(os.path.join(inc, "mesh_image"))) == 9
+    from PIL import Image
+    px = np.asarray(Image.open(os.path.join(inc, "mesh_image", "image_3_0.png")))
+    assert np.array_equal(px, imgs[0, 0].permute(1, 2, 0).cpu().numpy().astype(np.uint8))
+    # dense form on request
+    cfg.SAVE_SCENE_NPZ, cfg.SAVE_INCREMENTAL = "dense", False
+    SS.SaveScene(cfg)(outputs, {}, 5)
+    raw = np.load(os.path.join("results", "scene_scannet_run_fusion_eval_5", "scene0007-01.npz"))
+    assert "coords" not in raw.files and raw["tsdf"].shape == tuple(sp["dims"])
