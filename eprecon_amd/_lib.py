@@ -110,6 +110,8 @@ SIGNATURES = {
     "eprecon_grid_rank_async": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "eprecon_conv_pack_weight_floats": (_sz, [_i, _i, _i]),
     "eprecon_conv_pack_weight_async": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "eprecon_conv_pack_weight16_floats": (_sz, [_i, _i, _i]),
+    "eprecon_conv_pack_weight16_async": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "eprecon_nchw_to_nhwc_async": (_i, [_vp, _vp, _i, _i, _i, _vp]),
 }
 
@@ -193,7 +195,7 @@ class ConvDesc(ctypes.Structure):
                 ("ln_eps", ctypes.c_float), ("ln_post_relu", ctypes.c_int),
                 ("img_h", ctypes.c_int), ("img_w", ctypes.c_int), ("img_maps", ctypes.c_int),
                 ("vox_rank", ctypes.c_void_p), ("grid_x", ctypes.c_int), ("grid_y", ctypes.c_int), ("grid_z", ctypes.c_int),
-                ("packed_weight", ctypes.c_void_p)]
+                ("packed_weight", ctypes.c_void_p), ("packed_weight16", ctypes.c_void_p)]
 
 
 _WORKSPACES = {}

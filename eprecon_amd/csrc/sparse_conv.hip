@@ -82,7 +82,8 @@ struct ConvParams {
     // the row of the voxel in a grid cell or -1; wq = the weights in MFMA operand order (pack_weights_kernel)
     const int32_t *vox_rank;
     int gx, gy, gz;
-    const float *wq;
+    const float *wq;    // ... for the 32-row tile kernel (pack_weights_kernel)
+    const float *wq16;  // ... for the 16-row tile kernel (pack_weights16_kernel)
     int debug;  // EPRECON_D3_ABLATE (timing experiments only): 1 no MFMA loop, 4 no halo row loads
 };
 
@@ -1081,11 +1082,11 @@ __device__ __forceinline__ void d3_tile_origin(int tile, int tiles_y, int tiles_
 // Returns false (block-uniform) when no cell of the tile holds a voxel.
 __device__ __forceinline__ int d3_rank(const float *sX, int cell, int P, int cin_pad) { return __float_as_int(sX[cell * P + cin_pad]); }
 
-template <int NCH, int WV>
+template <int NCH, int WV, int THREADS = 64 * WV>
 __device__ __forceinline__ bool d3_stage_halo(const ConvParams &p, int x0, int y0, int z0, float *sX, int tid, int dbg)
 {
     constexpr int cin_pad = NCH * 8, P = cin_pad + 4, C4 = cin_pad / 4;
-    constexpr int kThreads = 64 * WV, kD3Halo = d3_halo(WV);
+    constexpr int kThreads = THREADS, kD3Halo = d3_halo(WV);
     for (int e = tid; e < kD3Halo; e += kThreads) {
         const int hz = e % kD3HZ, hy = (e / kD3HZ) % kD3HY, hx = e / (kD3HZ * kD3HY);
         const int x = x0 - 1 + hx, y = y0 - 1 + hy, z = z0 - 1 + hz;
@@ -1342,13 +1343,238 @@ __global__ __launch_bounds__(256) void conv3d_tile_narrow_kernel(ConvParams p, i
     }
 }
 
-int d3_tiles(const ConvParams &p, bool narrow, int *ty = nullptr, int *tz = nullptr)
+// ---------------------------------------------------------------------------------------------
+// 16-row form of the dense-grid kernel on v_mfma_f32_16x16x4_f32, for C_out <= 32 and C_in a multiple of 16.
+// The 32-row tile kernel loses on the 94k-voxel initialisation set because its unit of work is too coarse (DESIGN.md 3b:
+// 3.1 jobs of 11.5 us per SIMD = four rounds) and because a 32-column MFMA tile is half empty for the C_out = 16 layers.
+// Here a workgroup owns 2 x 4 x 8 cells (halo 4 x 6 x 10 = 240 cells, 35 KB at C_in = 32: four workgroups per CU), a wave
+// 16 of them (one x, two y, eight z) in CT accumulator tiles of 16 x 16; a job is a quarter of the 32-row kernel's.
+//   A operand (lane l: row l & 15, k index q = l >> 4): x[cell(row)][16 kc + 4 q + s] for step s — one ds_read_b128 per chunk
+//   B operand: W[k][16 kc + 4 q + s][16 t + (l & 15)], pre-packed so that a wave fetches (k, kc, t) with one 1 KB buffer load
+//   C / D: column l & 15, rows 4 (l >> 4) + reg
+// Summation order differs from the 32x32x2 kernels (four channels per MFMA): equal within fp32 round-off, not bit for bit.
+// Own epilogue for this accumulator layout: bias, ReLU, residual (with its pending BatchNorm), row-wise LayerNorm
+// (16-lane xor-shuffles), BatchNorm summaries (fixed-order Chan merges: lane groups, then waves).
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kD16X = 2;                                     // tile x extent; y, z as the other tile kernels
+constexpr int kD16Halo = (kD16X + 2) * kD3HY * kD3HZ;        // 240
+
+// wq16[((((k * KCH + kc) * CT + t) * 4 + q) * 16 + col) * 4 + s] = W[k][16 kc + 4 q + s][16 t + col]
+__global__ void pack_weights16_kernel(const float *w, int K, int Cin, int Cout, int kch, int ct, float *wq)
 {
-    const int wv = narrow ? kD3WvNarrow : d3_wv_mfma();
+    const int total = K * kch * ct * 256;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int sidx = e & 3, col = (e >> 2) & 15, q = (e >> 6) & 3;
+        int r = e >> 8;
+        const int t = r % ct; r /= ct;
+        const int kc = r % kch, k = r / kch;
+        const int c = 16 * kc + 4 * q + sidx, co = 16 * t + col;
+        wq[e] = (c < Cin && co < Cout) ? w[((size_t)k * Cin + c) * Cout + co] : 0.0f;
+    }
+}
+
+template <int CT, int KCH>
+__global__ __launch_bounds__(256) void conv3d_tile16_kernel(ConvParams p, int tiles_y, int tiles_z, int ntiles)
+{
+    constexpr int cin_pad = KCH * 16, NCH = KCH * 2;
+    constexpr int P = cin_pad + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *sX = reinterpret_cast<float *>(smem);   // [kD16Halo][P]: channels + the cell's row in the first pad word
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, q = lane >> 4;
+    const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    if (tile >= ntiles) return;
+    int x0, y0, z0;
+    d3_tile_origin<kD16X>(tile, tiles_y, tiles_z, x0, y0, z0);
+    float *sStat = sX;  // (after the loop) [4 waves][3][16 CT] summaries
+
+    if (!d3_stage_halo<NCH, kD16X, 256>(p, x0, y0, z0, sX, tid, p.debug)) {
+        if (p.bn_partial && tid < 16 * CT && tid < p.Cout) {
+            float *dst = p.bn_partial + (size_t)tile * 3 * p.Cout + tid;
+            dst[0] = 0.0f; dst[p.Cout] = 0.0f; dst[2 * p.Cout] = 0.0f;
+        }
+        return;
+    }
+    // wave -> (x = wave / 2, y pair = wave % 2); MFMA row r -> cell (y = 2 (wave % 2) + r / 8, z = r % 8)
+    const int wx = wave >> 1, wy = 2 * (wave & 1);
+    const int cell_a = ((wx + 1) * kD3HY + wy + (l16 >> 3) + 1) * kD3HZ + (l16 & 7) + 1;   // this lane's A row
+    int orow[4];   // output rows of this lane's accumulator rows 4 q + j
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 4 * q + j;
+        orow[j] = d3_rank(sX, ((wx + 1) * kD3HY + wy + (r >> 3) + 1) * kD3HZ + (r & 7) + 1, P, cin_pad);
+    }
+    const int own = d3_rank(sX, cell_a, P, cin_pad);
+
+    f32x4 acc[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    if (__ballot(own >= 0) != 0ull && !(p.debug & 1)) {
+        const float *xa = sX + (cell_a - (kD3HY + 1) * kD3HZ - 1) * P + 4 * q;
+        constexpr unsigned kStepBytes = CT * 1024u, kOffBytes = KCH * kStepBytes;
+        const __amdgpu_buffer_rsrc_t wrsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wq), 0, (int)(27 * kOffBytes), 0x00020000);
+        const unsigned wlane = (unsigned)lane * 16u;
+        constexpr int kAheadB = (KCH * CT <= 4) ? 2 : 1;
+        float4 bq[kAheadB + 1][KCH][CT];
+        float4 aq[2][KCH];
+        auto load_b = [&](int k, float4(&dst)[KCH][CT]) {
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc)
+#pragma unroll
+                for (int t = 0; t < CT; ++t) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + (unsigned)kc * kStepBytes + (unsigned)t * 1024u,
+                                                                          (unsigned)k * kOffBytes, 0);
+                    dst[kc][t] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                }
+        };
+        auto load_a = [&](int k, float4(&dst)[KCH]) {
+            const int dx = k % 3, dy = (k / 3) % 3, dz = k / 9;
+            const float *xk = xa + ((dx * kD3HY + dy) * kD3HZ + dz) * P;
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) dst[kc] = *reinterpret_cast<const float4 *>(xk + kc * 16);
+        };
+#pragma unroll
+        for (int k = 0; k < kAheadB; ++k) load_b(k, bq[k]);
+        load_a(0, aq[0]);
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            if (k + kAheadB < 27) load_b(k + kAheadB, bq[(k + kAheadB) % (kAheadB + 1)]);
+            if (k + 1 < 27) load_a(k + 1, aq[(k + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const float4(&av)[KCH] = aq[k & 1];
+            const float4(&bk)[KCH][CT] = bq[k % (kAheadB + 1)];
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) {
+                // the CT accumulators alternate: a 16x16x4 MFMA issues every 32 cycles but returns after 40
+#pragma unroll
+                for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kc].x, bk[kc][t].x, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kc].y, bk[kc][t].y, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kc].z, bk[kc][t].z, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kc].w, bk[kc][t].w, acc[t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();  // every wave is done with the halo: the summaries' scratch overlays it
+
+    // ---- epilogue: lane holds rows orow[0..3] x columns 16 t + l16 ----
+    float v[CT][4];
+    bool colok[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int col = 16 * t + l16;
+        colok[t] = col < p.Cout;
+        const float b = (p.bias && colok[t]) ? p.bias[col] : 0.0f;
+        const float rs = (p.res_scale && colok[t]) ? p.res_scale[col] : 1.0f;
+        const float rb = (p.res_scale && colok[t]) ? p.res_shift[col] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float val = 0.0f;
+            if (colok[t] && orow[j] >= 0) {
+                val = acc[t][j] + b;
+                if (p.relu) val = fmaxf(val, 0.0f);
+                if (p.res) {
+                    float rv = p.res[(size_t)orow[j] * p.ld_res + col];
+                    if (p.res_scale) {
+                        rv = fmaf(rv, rs, rb);
+                        if (p.res_relu) rv = fmaxf(rv, 0.0f);
+                    }
+                    val += rv;
+                }
+            }
+            v[t][j] = val;
+        }
+    }
+    if (p.ln) {  // (uniform) row-wise LayerNorm over the C_out columns: 16 lanes x CT tiles hold a row
+        const float inv_c = 1.0f / (float)p.Cout;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int t = 0; t < CT; ++t) sum += v[t][j];
+#pragma unroll
+            for (int m = 8; m > 0; m >>= 1) sum += __shfl_xor(sum, m);
+            const float mean = sum * inv_c;
+            float sq = 0.0f;
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const float d = colok[t] ? v[t][j] - mean : 0.0f;
+                v[t][j] = d;
+                sq = fmaf(d, d, sq);
+            }
+#pragma unroll
+            for (int m = 8; m > 0; m >>= 1) sq += __shfl_xor(sq, m);
+            const float inv = 1.0f / sqrtf(sq * inv_c + p.ln_eps);
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const int col = 16 * t + l16;
+                float y = fmaf(v[t][j] * inv, (p.ln_gamma && colok[t]) ? p.ln_gamma[col] : 1.0f, (p.ln_beta && colok[t]) ? p.ln_beta[col] : 0.0f);
+                if (p.ln_post_relu) y = fmaxf(y, 0.0f);
+                v[t][j] = y;
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (colok[t] && orow[j] >= 0) p.out[(size_t)orow[j] * p.ld_out + 16 * t + l16] = v[t][j];
+    if (p.bn_partial) {  // (uniform) (count, mean, M2) of the stored values per column: rows in the lane, lane groups, waves
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            float n = 0.0f, sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (orow[j] >= 0) { n += 1.0f; sum += v[t][j]; }
+            float mean = n > 0.0f ? sum / n : 0.0f, m2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (orow[j] >= 0) { const float d = v[t][j] - mean; m2 = fmaf(d, d, m2); }
+#pragma unroll
+            for (int m = 16; m < 64; m <<= 1) {  // lane groups q in order: the lower group is the left operand
+                const float on = __shfl_xor(n, m), om = __shfl_xor(mean, m), oq = __shfl_xor(m2, m);
+                const bool lower = (lane & m) == 0;
+                float a_n = lower ? n : on, a_mean = lower ? mean : om, a_m2 = lower ? m2 : oq;
+                chan_merge(a_n, a_mean, a_m2, lower ? on : n, lower ? om : mean, lower ? oq : m2);
+                n = a_n; mean = a_mean; m2 = a_m2;
+            }
+            if (q == 0) {
+                float *d = sStat + (wave * 3) * 16 * CT + 16 * t + l16;
+                d[0] = n; d[16 * CT] = mean; d[2 * 16 * CT] = m2;
+            }
+        }
+        __syncthreads();
+        if (tid < 16 * CT && tid < p.Cout) {
+            float a_n = 0.0f, a_mean = 0.0f, a_m2 = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w)
+                chan_merge(a_n, a_mean, a_m2, sStat[(w * 3) * 16 * CT + tid], sStat[(w * 3 + 1) * 16 * CT + tid], sStat[(w * 3 + 2) * 16 * CT + tid]);
+            float *dst = p.bn_partial + (size_t)tile * 3 * p.Cout + tid;
+            dst[0] = a_n; dst[p.Cout] = a_mean; dst[2 * p.Cout] = a_m2;
+        }
+    }
+}
+
+enum D3Kind { kD3None = 0, kD3Narrow = 1, kD3Tile16 = 2, kD3Tile32 = 3 };
+
+int d3_tiles_kind(const ConvParams &p, int kind, int *ty = nullptr, int *tz = nullptr)
+{
+    const int wv = kind == kD3Tile16 ? kD16X : (kind == kD3Narrow ? kD3WvNarrow : d3_wv_mfma());
     const int tx = (p.gx + wv - 1) / wv, tyy = (p.gy + kD3Y - 1) / kD3Y, tzz = (p.gz + kD3Z - 1) / kD3Z;
     if (ty) *ty = tyy;
     if (tz) *tz = tzz;
     return tx * tyy * tzz;
+}
+int d3_tiles(const ConvParams &p, bool narrow, int *ty = nullptr, int *tz = nullptr)
+{
+    return d3_tiles_kind(p, narrow ? kD3Narrow : kD3Tile32, ty, tz);
 }
 size_t conv3d_tile_lds(int nch, bool narrow)
 {
@@ -1357,30 +1583,83 @@ size_t conv3d_tile_lds(int nch, bool narrow)
 }
 
 // eligibility of the dense-grid kernels (independent of the data: shapes, alignment, fusions)
-// EPRECON_CONV_DENSE3D: 0 off; 1 (default) the single-column kernel only; 2 the MFMA tile kernel as well.  Measured on the
-// 94k-voxel initialisation set (profiles/r03/conv3d_*): 32 -> 1 24 us against 82 us for the gather form; 32 -> 32 97 us
-// against 78 us — 3,185 non-empty 32-row wave jobs of 11.5 us on 1,024 SIMDs are 3.1 per SIMD, i.e. FOUR rounds (46 us
-// of MFMAs at best) where the gather form's 2,937 compacted jobs need three; see DESIGN.md 3b.
+// EPRECON_CONV_DENSE3D: 0 off; 1 the single-column kernel only; 2 (default) also the 16-row MFMA kernel; 3 also the 32-row
+// MFMA kernel.  Measured on the 94k-voxel initialisation set (rocprofv3 kernel durations, profiles/r03/conv3d_*):
+//   32 -> 1   24 us   against 82 us for the gather form            (single-column kernel)
+//   16 -> 16  24 us   against 50 us,  32 -> 16  41.5 us against 76 us,  32 -> 32  80 us against 78.5 us     (16-row kernel)
+//   32 -> 32  97 us   against 78 us  (32-row kernel: 3,185 wave jobs of 11.5 us on 1,024 SIMDs = four rounds)
+// With level 2 every 3x3x3 layer of the initialisation stack runs on a tile kernel, no hash grid / kernel map is built, and
+// the cfg2 step goes from 1.91 to 1.76 ms.
 inline int d3_level()
 {
     const char *e = getenv("EPRECON_CONV_DENSE3D");   // (read per launch: tests and probes flip it)
-    return e ? atoi(e) : 1;
+    return e ? atoi(e) : 2;
 }
 
-bool conv3d_tile_ok(const ConvParams &p, bool *narrow)
+// which dense-grid kernel takes this layer: level 1 the single-column kernel, level 2 also the 16-row MFMA kernel
+// (C_out <= 32, C_in a multiple of 16), level 3 also the 32-row MFMA kernel for the remaining shapes
+int conv3d_kind(const ConvParams &p)
 {
     const int level = d3_level();
-    *narrow = false;
-    if (level <= 0 || !p.vox_rank || p.K != 27 || p.gx <= 0 || p.gy <= 0 || p.gz <= 0) return false;
-    if (p.Cin % 4 != 0 || p.Cin > 64 || p.ld_x % 4 != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0) return false;
+    if (level <= 0 || !p.vox_rank || p.K != 27 || p.gx <= 0 || p.gy <= 0 || p.gz <= 0) return kD3None;
+    if (p.Cin % 4 != 0 || p.Cin > 64 || p.ld_x % 4 != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0) return kD3None;
     if (p.in_scale && ((reinterpret_cast<uintptr_t>(p.in_scale) & 15) != 0 || (reinterpret_cast<uintptr_t>(p.in_shift) & 15) != 0))
-        return false;
-    *narrow = p.Cout == 1 && !p.ln;
-    if (*narrow) return true;
-    if (level < 2) return false;
-    if (!p.wq || (reinterpret_cast<uintptr_t>(p.wq) & 15) != 0 || p.accumulate) return false;
-    if (p.ln && (p.Cout > 64 || p.bn_partial)) return false;
-    return true;
+        return kD3None;
+    if (p.Cout == 1 && !p.ln) return kD3Narrow;
+    if (level < 2 || p.accumulate) return kD3None;
+    const char *no16 = getenv("EPRECON_CONV_DENSE3D_NO16");   // tests / probes: the 32-row kernel for every shape
+    // (the caller packs the weights for the kernel ITS mirror of this rule picks — eprecon_amd/sparse.py DenseMap.kind —,
+    // so a missing packing means "not this kernel", never an error)
+    if (!(no16 && no16[0] == '1') && p.Cout <= 32 && p.Cin % 16 == 0 && !p.bn_scale_out && !(p.ln && p.bn_partial) && p.wq16 &&
+        (reinterpret_cast<uintptr_t>(p.wq16) & 15) == 0)
+        return kD3Tile16;
+    if (level < 3) return kD3None;
+    if (!p.wq || (reinterpret_cast<uintptr_t>(p.wq) & 15) != 0) return kD3None;
+    if (p.ln && (p.Cout > 64 || p.bn_partial)) return kD3None;
+    return kD3Tile32;
+}
+bool conv3d_tile_ok(const ConvParams &p, bool *narrow)
+{
+    const int kind = conv3d_kind(p);
+    *narrow = kind == kD3Narrow;
+    return kind != kD3None;
+}
+
+template <int CT, int KCH>
+int launch_conv3d_tile16(const ConvParams &p, hipStream_t st)
+{
+    int ty, tz;
+    const int ntiles = d3_tiles_kind(p, kD3Tile16, &ty, &tz);
+    const size_t lds = max((size_t)kD16Halo * (KCH * 16 + 4) * sizeof(float), (size_t)kWaves * 3 * 16 * CT * sizeof(float));
+    if (lds > 64 * 1024) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_tile16_kernel<CT, KCH>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (attr != hipSuccess) return EPRECON_ERR_HIP_BASE - (int)attr;
+    }
+    ConvParams q = p;
+    q.wq = p.wq16;
+    hipLaunchKernelGGL((conv3d_tile16_kernel<CT, KCH>), dim3((unsigned)ntiles), dim3(256), lds, st, q, ty, tz, ntiles);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int launch_conv3d_16(const ConvParams &p, hipStream_t st)
+{
+    const int kch = p.Cin / 16;
+    if (p.Cout <= 16) {
+        switch (kch) {
+            case 1: return launch_conv3d_tile16<1, 1>(p, st);
+            case 2: return launch_conv3d_tile16<1, 2>(p, st);
+            case 3: return launch_conv3d_tile16<1, 3>(p, st);
+            default: return launch_conv3d_tile16<1, 4>(p, st);
+        }
+    }
+    switch (kch) {
+        case 1: return launch_conv3d_tile16<2, 1>(p, st);
+        case 2: return launch_conv3d_tile16<2, 2>(p, st);
+        case 3: return launch_conv3d_tile16<2, 3>(p, st);
+        default: return launch_conv3d_tile16<2, 4>(p, st);
+    }
 }
 
 template <int NT, int NCH, int WV>
@@ -1738,12 +2017,12 @@ int conv_dispatch(ConvParams &p, int64_t n_in, hipStream_t st)
 int conv_dispatch_inner(ConvParams &p, int64_t n_in, hipStream_t st)
 {
     {
-        bool narrow;
-        if (conv3d_tile_ok(p, &narrow)) {
-            g_last_conv_kernel = narrow ? "conv3d_tile_narrow_kernel" : "conv3d_tile_kernel";
+        const int kind = conv3d_kind(p);
+        if (kind != kD3None) {
+            g_last_conv_kernel = kind == kD3Narrow ? "conv3d_tile_narrow_kernel" : kind == kD3Tile16 ? "conv3d_tile16_kernel" : "conv3d_tile_kernel";
             p.debug = getenv("EPRECON_D3_ABLATE") ? atoi(getenv("EPRECON_D3_ABLATE")) : 0;  // (read per launch: probes flip it)
-            p.bn_rows = d3_tiles(p, narrow);
-            return launch_conv3d(p, narrow, st);
+            p.bn_rows = d3_tiles_kind(p, kind);
+            return kind == kD3Tile16 ? launch_conv3d_16(p, st) : launch_conv3d(p, kind == kD3Narrow, st);
         }
         if (!p.nbr && p.K != 1) return EPRECON_ERR_ARG;  // dense-grid form requested for a shape it does not take, no map given
     }
@@ -1868,6 +2147,22 @@ extern "C" int eprecon_conv_pack_weight_async(const float *weight, int kvol, int
     return EPRECON_OK;
 }
 
+extern "C" size_t eprecon_conv_pack_weight16_floats(int kvol, int cin, int cout)
+{
+    if (kvol <= 0 || cin <= 0 || cout <= 0 || cout > 32) return 0;
+    return (size_t)kvol * ((cin + 15) / 16) * (cout <= 16 ? 1 : 2) * 256;
+}
+
+extern "C" int eprecon_conv_pack_weight16_async(const float *weight, int kvol, int cin, int cout, float *packed, void *stream)
+{
+    if (!weight || !packed || kvol <= 0 || cin <= 0 || cout <= 0 || cout > 32) return EPRECON_ERR_ARG;
+    const size_t total = eprecon_conv_pack_weight16_floats(kvol, cin, cout);
+    hipLaunchKernelGGL(pack_weights16_kernel, dim3((unsigned)min((size_t)1024, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       weight, kvol, cin, cout, (cin + 15) / 16, cout <= 16 ? 1 : 2, packed);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
 extern "C" size_t eprecon_conv_bn_partial_bytes(int64_t n_out, int cout)
 {
     return (size_t)ep::ceil_div(n_out > 0 ? n_out : 1, (int64_t)128) * 3 * (size_t)(cout > 0 ? cout : 1) * sizeof(float);
@@ -1906,6 +2201,7 @@ static void params_from_desc(ConvParams &p, const eprecon_conv_desc *d)
     p.ln_post_relu = d->ln_post_relu;
     p.img_h = d->img_h; p.img_w = d->img_w; p.img_maps = d->img_maps;
     p.vox_rank = d->vox_rank; p.gx = d->grid_x; p.gy = d->grid_y; p.gz = d->grid_z; p.wq = d->packed_weight;
+    p.wq16 = d->packed_weight16;
     p.flex_partial = 1;
 }
 
@@ -1928,8 +2224,7 @@ extern "C" int64_t eprecon_conv_desc_partial_rows(const eprecon_conv_desc *d)
     p.n_out = (int)d->n_out;
     int nt, nch;
     int64_t blocks;
-    bool narrow;
-    if (conv3d_tile_ok(p, &narrow)) return d3_tiles(p, narrow);
+    if (const int kind = conv3d_kind(p)) return d3_tiles_kind(p, kind);
     if (conv2d_tile_ok(p, &nt, &nch, &blocks)) return blocks;
     if (splitk_ok(p)) return ep::ceil_div(d->n_out, (int64_t)32);
     return ep::ceil_div(d->n_out, (int64_t)kRowsPerBlock);

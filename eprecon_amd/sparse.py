@@ -15,9 +15,10 @@ from . import _lib
 import os
 
 def _dense3d_level():
-    """EPRECON_CONV_DENSE3D: 0 off, 1 (default) the single-column (C_out == 1) kernel only, 2 the MFMA tile kernel too
-    (bit-identical to the gather form but slower on the 94k-voxel initialisation set: csrc/sparse_conv.hip, d3_level)"""
-    return int(os.environ.get("EPRECON_CONV_DENSE3D", "1"))
+    """EPRECON_CONV_DENSE3D: 0 off, 1 the single-column (C_out == 1) kernel only, 2 (default) also the 16-row MFMA tile kernel
+    (C_out <= 32, C_in % 16 == 0), 3 also the 32-row MFMA tile kernel (bit-identical to the gather form, slower on the
+    94k-voxel initialisation set); csrc/sparse_conv.hip, conv3d_kind"""
+    return int(os.environ.get("EPRECON_CONV_DENSE3D", "2"))
 
 
 def _ld(t):
@@ -105,14 +106,25 @@ class DenseMap:
         """blocking: number of voxels that were not on the grid (0 for a valid set)"""
         return int(self.rank[-1].item())
 
-    def takes(self, x, cin, cout, accumulate=False, ln=False, stats=False):
-        """mirror of the library's eligibility rule (conv3d_tile_ok, csrc/sparse_conv.hip)"""
+    def kind(self, x, cin, cout, accumulate=False, ln=False, stats=False, fused=False):
+        """mirror of the library's rule (conv3d_kind, csrc/sparse_conv.hip): 0 none (kernel map), 1 single-column kernel,
+        2 16-row MFMA kernel, 3 32-row MFMA kernel"""
         level = _dense3d_level()
         if level <= 0 or cin % 4 or cin > 64 or x.stride(0) % 4 or x.data_ptr() % 16:
-            return False
+            return 0
         if cout == 1 and not ln:
-            return True
-        return level >= 2 and not accumulate and not (ln and (cout > 64 or stats))
+            return 1
+        if level < 2 or accumulate:
+            return 0
+        if cout <= 32 and cin % 16 == 0 and not (ln and stats) and not fused \
+                and os.environ.get("EPRECON_CONV_DENSE3D_NO16", "0") != "1":
+            return 2        # (fused: the in-kernel BatchNorm finalize is not part of the 16-row kernel's epilogue)
+        if level < 3 or (ln and (cout > 64 or stats)):
+            return 0
+        return 3
+
+    def takes(self, x, cin, cout, accumulate=False, ln=False, stats=False, fused=False):
+        return self.kind(x, cin, cout, accumulate, ln, stats, fused) != 0
 
 
 def packed_weight(weight):
@@ -130,16 +142,36 @@ def packed_weight(weight):
     return hit[1]
 
 
-def _resolve_map(nbr, x, weight, desc, accumulate=False, ln=False, stats=False):
+def packed_weight16(weight):
+    """`weight` f32[27, Cin, Cout <= 32] in the operand order of the 16-row tile kernel, packed once per weight version"""
+    hit = getattr(weight, "_d3_pack16", None)
+    if hit is None or hit[0] != weight._version or hit[1].device != weight.device:
+        lib = _lib.load()
+        kvol, cin, cout = weight.shape
+        w = weight.detach().contiguous()
+        packed = torch.empty(int(lib.eprecon_conv_pack_weight16_floats(kvol, cin, cout)), dtype=torch.float32, device=weight.device)
+        _lib.check(lib.eprecon_conv_pack_weight16_async(_lib.ptr(w), kvol, cin, cout, _lib.ptr(packed), _lib.current_stream()),
+                   "eprecon_conv_pack_weight16_async")
+        hit = (weight._version, packed)
+        weight._d3_pack16 = hit
+    return hit[1]
+
+
+def _resolve_map(nbr, x, weight, desc, accumulate=False, ln=False, stats=False, fused=False):
     """nbr: None (identity), an int32[K, N] kernel map, or a DenseMap -> fills the map fields of `desc`; returns the
     objects that must stay alive until the launch is queued"""
     if isinstance(nbr, DenseMap):
         kvol, cin, cout = weight.shape
-        if kvol == 27 and nbr.takes(x, cin, cout, accumulate, ln, stats):
+        kind = nbr.kind(x, cin, cout, accumulate, ln, stats, fused) if kvol == 27 else 0
+        if kind:
             desc.vox_rank = nbr.rank.data_ptr()
             desc.grid_x, desc.grid_y, desc.grid_z = nbr.dims
             keep = [nbr.rank]
-            if cout > 1 or ln:
+            if kind == 2:
+                pw = packed_weight16(weight)
+                desc.packed_weight16 = pw.data_ptr()
+                keep.append(pw)
+            elif kind == 3:
                 pw = packed_weight(weight)
                 desc.packed_weight = pw.data_ptr()
                 keep.append(pw)
@@ -381,23 +413,26 @@ def conv_stats(x, weight, nbr=None, in_affine=None, out=None, bias=None, bn=None
     d = _lib.ConvDesc()
     d.x, d.n_in, d.ld_x = x.data_ptr(), x.shape[0], _ld(x)
     d.kvol, d.n_out = kvol, n_out
-    keep = _resolve_map(nbr, x, weight, d, stats=True)  # noqa: F841
+    fused = bn is not None and owner is not None and FUSED_FINALIZE and cout <= FUSED_FINALIZE_MAX_C and n_out > 0
+    keep = _resolve_map(nbr, x, weight, d, stats=True, fused=fused)  # noqa: F841
     d.weight, d.cin, d.cout = weight.data_ptr(), cin, cout
     d.bias = None if bias is None else bias.data_ptr()
     d.out, d.ld_out = out.data_ptr(), _ld(out)
     if in_affine is not None:
         d.in_scale, d.in_shift, d.in_relu = in_affine[0].data_ptr(), in_affine[1].data_ptr(), int(in_affine[2])
-    rows = max(int(lib.eprecon_conv_desc_partial_rows(ctypes.byref(d))), 1)
-    partial = torch.empty((rows, 3, cout), dtype=torch.float32, device=x.device)
-    d.bn_partial = partial.data_ptr()
     aff = None
-    if bn is not None and owner is not None and FUSED_FINALIZE and cout <= FUSED_FINALIZE_MAX_C and n_out > 0:
+    if fused:   # (set before the rows are asked for: the choice of kernel depends on it)
         gamma, beta, eps = bn
         a = torch.empty((2, cout), dtype=torch.float32, device=x.device)
         aff = (a[0], a[1])
-        ws = finalize_workspace(owner, rows, cout, x.device)
         d.bn_scale_out, d.bn_shift_out = a[0].data_ptr(), a[1].data_ptr()
         d.bn_gamma, d.bn_beta, d.bn_eps = _lib.ptr(gamma), _lib.ptr(beta), float(eps)
+        d.bn_ticket = 1   # placeholder: any non-null value while the rows are computed
+    rows = max(int(lib.eprecon_conv_desc_partial_rows(ctypes.byref(d))), 1)
+    partial = torch.empty((rows, 3, cout), dtype=torch.float32, device=x.device)
+    d.bn_partial = partial.data_ptr()
+    if fused:
+        ws = finalize_workspace(owner, rows, cout, x.device)
         d.bn_ticket = ws.data_ptr()
     if n_out > 0:
         _lib.check(lib.eprecon_conv_desc_async(ctypes.byref(d), _lib.current_stream()), "eprecon_conv_desc_async")

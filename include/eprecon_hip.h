@@ -268,6 +268,10 @@ typedef struct eprecon_conv_desc {
      * form (cout == 1: same sums in another order).  Other shapes fall back to nbr (EPRECON_ERR_ARG when it is NULL). */
     const int32_t *vox_rank; int grid_x; int grid_y; int grid_z;
     const float *packed_weight;
+    /* the same weights in the operand order of the 16-row tile kernel (eprecon_conv_pack_weight16_async), which takes
+     * cout <= 32 with cin a multiple of 16 (EPRECON_CONV_DENSE3D >= 2); results equal the gather form within fp32
+     * round-off (four input channels per MFMA instead of two: another summation order) */
+    const float *packed_weight16;
 } eprecon_conv_desc;
 int eprecon_conv_desc_async(const eprecon_conv_desc *desc, void *stream);
 size_t eprecon_conv_bn_finalize_workspace_bytes(int64_t partial_rows, int cout);
@@ -306,6 +310,8 @@ int eprecon_grid_rank_async(const int32_t *coords, int64_t n, int stride, int gr
 /* weight f32[kvol][cin][cout] -> the operand order of the dense-grid kernel (eprecon_conv_pack_weight_floats floats) */
 size_t eprecon_conv_pack_weight_floats(int kvol, int cin, int cout);
 int eprecon_conv_pack_weight_async(const float *weight, int kvol, int cin, int cout, float *packed, void *stream);
+size_t eprecon_conv_pack_weight16_floats(int kvol, int cin, int cout);
+int eprecon_conv_pack_weight16_async(const float *weight, int kvol, int cin, int cout, float *packed, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Normalisation epilogues  (K12)

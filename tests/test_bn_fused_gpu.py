@@ -108,7 +108,7 @@ def test_finalize_inside_the_image_tile_kernel_and_hip_graph_replay():
 def test_finalize_inside_the_dense_grid_kernels(monkeypatch):
     from eprecon_amd import sparse as SP
     from test_dense_conv3d_gpu import dev, grid_set
-    monkeypatch.setenv("EPRECON_CONV_DENSE3D", "2")
+    monkeypatch.setenv("EPRECON_CONV_DENSE3D", "3")
     rng = np.random.default_rng(5)
     for dims, fill, cin, cout in (((48, 48, 48), 0.85, 32, 1), ((20, 14, 24), 0.6, 16, 16), ((48, 48, 48), 0.85, 32, 32)):
         c = grid_set(rng, dims, 2, fill)

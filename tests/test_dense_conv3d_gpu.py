@@ -15,8 +15,10 @@ TOL = 1e-3
 
 @pytest.fixture(autouse=True)
 def all_dense_kernels(monkeypatch):
-    """by default only the single-column kernel is taken (EPRECON_CONV_DENSE3D=1); these tests cover the MFMA tile kernel too"""
-    monkeypatch.setenv("EPRECON_CONV_DENSE3D", "2")
+    """these tests cover every dense-grid kernel: level 3 with the 16-row kernel switched off -> the 32-row MFMA tile kernel for
+    every shape (bit-identical to the gather form); the 16-row kernel has its own test below"""
+    monkeypatch.setenv("EPRECON_CONV_DENSE3D", "3")
+    monkeypatch.setenv("EPRECON_CONV_DENSE3D_NO16", "1")
 
 
 def dev(a):
@@ -144,14 +146,71 @@ def test_single_column_kernel(dims, stride, fill, cin):
     assert abs(mean - yv.mean()) < 1e-5 and abs(m2 / n - yv.var()) < 1e-5 * max(1.0, yv.var())
 
 
-def test_default_level_takes_only_the_single_column_kernel(monkeypatch):
+@pytest.mark.parametrize("dims,stride,fill,cin,cout", [
+    ((48, 48, 48), 2, 0.85, 32, 32),    # the initialisation stack's layers
+    ((48, 48, 48), 2, 0.85, 32, 16),
+    ((48, 48, 48), 2, 0.85, 16, 16),
+    ((13, 9, 21), 2, 0.6, 16, 24),      # ragged grid, partial column tile
+    ((20, 12, 16), 1, 0.5, 48, 32),
+    ((16, 16, 16), 1, 0.9, 64, 8),
+])
+def test_16_row_tile_kernel(monkeypatch, dims, stride, fill, cin, cout):
+    """conv3d_tile16_kernel (v_mfma_f32_16x16x4_f32, 2x4x8-cell tiles): another summation order than the 32x32x2 kernels
+    (four input channels per MFMA) -> equal to the gather form within fp32 round-off, and to the oracle within 1e-3; every
+    epilogue it implements: bias + ReLU + residual, row-wise LayerNorm, BatchNorm summaries, pending BatchNorm on load"""
     from eprecon_amd import sparse as SP
-    monkeypatch.setenv("EPRECON_CONV_DENSE3D", "1")
+    monkeypatch.setenv("EPRECON_CONV_DENSE3D", "2")
+    monkeypatch.setenv("EPRECON_CONV_DENSE3D_NO16", "0")
+    rng, c, vs, dm = sets(dims, stride, fill, cin * 77 + cout)
+    n = len(c)
+    x = rng.standard_normal((n, cin)).astype(np.float32)
+    w = (rng.standard_normal((27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((n, cout)).astype(np.float32)
+    dx, dw, db, dres = dev(x), dev(w), dev(b), dev(res)
+    nbr = vs.kernel_map(3)
+    assert dm.kind(dx, cin, cout) == 2
+    y_map, _ = SP.sparse_conv_fused(dx, dw, nbr, db, relu=True, residual=dres)
+    y_16, _ = SP.sparse_conv_fused(dx, dw, dm, db, relu=True, residual=dres)
+    assert float((y_map - y_16).abs().max()) < 2e-5
+    ref = OS.sparse_conv(x, OS.kernel_map(c, c, 3, stride), w, b)
+    assert np.abs(y_16.cpu().numpy() - (np.maximum(ref, 0) + res)).max() < TOL
+    # BatchNorm summaries + pending BatchNorm (+ReLU) of the producer on load
+    scale, shift = dev(rng.random(cin).astype(np.float32) + 0.5), dev(rng.standard_normal(cin).astype(np.float32))
+    ya, pa = SP.conv_stats(dx, dw, nbr, in_affine=(scale, shift, True))
+    yb, pb = SP.conv_stats(dx, dw, dm, in_affine=(scale, shift, True))
+    assert float((ya - yb).abs().max()) < 2e-5 and float(pb[:, 0, 0].sum()) == n
+    g, z = torch.ones(cout, device="cuda"), torch.zeros(cout, device="cuda")
+    sa, ta = SP.bn_affine(pa, g, z, 1e-5)
+    sb, tb = SP.bn_affine(pb, g, z, 1e-5)
+    assert torch.allclose(sa, sb, rtol=1e-4, atol=1e-6) and torch.allclose(ta, tb, rtol=1e-4, atol=1e-4)
+    # row-wise LayerNorm epilogue
+    lg, lb = dev(rng.standard_normal(cout).astype(np.float32)), dev(rng.standard_normal(cout).astype(np.float32))
+    r_ = dres if cin == cout else None
+    a = SP.sparse_conv_ln(dx, dw, nbr, db, lg, lb, 1e-5, relu=True, residual=r_, post_relu=(cout == 16))
+    d = SP.sparse_conv_ln(dx, dw, dm, db, lg, lb, 1e-5, relu=True, residual=r_, post_relu=(cout == 16))
+    assert float((a - d).abs().max()) < 1e-4
+    # output as a column slice of a wider buffer
+    wide = torch.zeros((n, cout + 8), device="cuda")
+    SP.sparse_conv(dx, dw, dm, db, out=wide[:, 4:4 + cout])
+    assert float((wide[:, 4:4 + cout] - SP.sparse_conv(dx, dw, nbr, db)).abs().max()) < 2e-5 and float(wide[:, :4].abs().max()) == 0
+
+
+def test_levels_select_the_kernels(monkeypatch):
+    from eprecon_amd import sparse as SP
+    monkeypatch.delenv("EPRECON_CONV_DENSE3D_NO16", raising=False)
     rng, c, vs, dm = sets((16, 16, 16), 1, 1.0, 11)
     x = dev(rng.standard_normal((len(c), 32)).astype(np.float32))
-    assert dm.takes(x, 32, 1) and not dm.takes(x, 32, 32)
+    x40 = dev(rng.standard_normal((len(c), 40)).astype(np.float32))
+    monkeypatch.setenv("EPRECON_CONV_DENSE3D", "1")
+    assert dm.kind(x, 32, 1) == 1 and dm.kind(x, 32, 32) == 0
     w = dev((rng.standard_normal((27, 32, 32)) / 30).astype(np.float32))
     assert torch.equal(SP.sparse_conv(x, w, dm), SP.sparse_conv(x, w, vs.kernel_map(3)))   # falls back to the map
+    monkeypatch.delenv("EPRECON_CONV_DENSE3D")                                            # the default: level 2
+    assert dm.kind(x, 32, 1) == 1 and dm.kind(x, 32, 32) == 2 and dm.kind(x, 32, 16) == 2
+    assert dm.kind(x40, 40, 32) == 0 and dm.kind(x, 32, 48) == 0                          # not 16-row shapes: kernel map
+    monkeypatch.setenv("EPRECON_CONV_DENSE3D", "3")
+    assert dm.kind(x40, 40, 32) == 3 and dm.kind(x, 32, 48) == 3
 
 
 def test_sparse_set_falls_back_to_the_kernel_map():

@@ -35,7 +35,7 @@ def main():
     coords = out["init"][1].contiguous()
     n = coords.shape[0]
     vs = SP.VoxelSet(coords, 2, dims=(48, 48, 48))
-    dm, nbr = vs.conv_map(3), vs.kernel_map(3)
+    dm, nbr = SP.DenseMap(vs, (48, 48, 48)), vs.kernel_map(3)
     g = torch.Generator(device="cuda").manual_seed(0)
     x = torch.randn((n, cin), device="cuda", generator=g)
     w = torch.randn((27, cin, cout), device="cuda", generator=g) / (27 * cin) ** 0.5
