@@ -1082,10 +1082,11 @@ __device__ __forceinline__ void d3_tile_origin(int tile, int tiles_y, int tiles_
 // Returns false (block-uniform) when no cell of the tile holds a voxel.
 __device__ __forceinline__ int d3_rank(const float *sX, int cell, int P, int cin_pad) { return __float_as_int(sX[cell * P + cin_pad]); }
 
+// step 1: rows (ranks) of the halo cells -> the first pad word of each cell; false (block-uniform) for a tile without a voxel
 template <int NCH, int WV, int THREADS = 64 * WV>
-__device__ __forceinline__ bool d3_stage_halo(const ConvParams &p, int x0, int y0, int z0, float *sX, int tid, int dbg)
+__device__ __forceinline__ bool d3_stage_ranks(const ConvParams &p, int x0, int y0, int z0, float *sX, int tid)
 {
-    constexpr int cin_pad = NCH * 8, P = cin_pad + 4, C4 = cin_pad / 4;
+    constexpr int cin_pad = NCH * 8, P = cin_pad + 4;
     constexpr int kThreads = THREADS, kD3Halo = d3_halo(WV);
     for (int e = tid; e < kD3Halo; e += kThreads) {
         const int hz = e % kD3HZ, hy = (e / kD3HZ) % kD3HY, hx = e / (kD3HZ * kD3HY);
@@ -1094,10 +1095,19 @@ __device__ __forceinline__ bool d3_stage_halo(const ConvParams &p, int x0, int y
         sX[e * P + cin_pad] = __int_as_float(in ? p.vox_rank[((size_t)x * p.gy + y) * p.gz + z] : -1);
     }
     __syncthreads();
-    // this thread's output cell (the 64 WV threads cover the 32 WV cells twice)
+    // this thread's output cell (the threads cover the 32 WV cells at least once)
     const int v = tid % (32 * WV);
     const int own = d3_rank(sX, (((v >> 5) + 1) * kD3HY + ((v >> 3) & 3) + 1) * kD3HZ + (v & 7) + 1, P, cin_pad);
-    if (!__syncthreads_or(own >= 0)) return false;
+    return __syncthreads_or(own >= 0) != 0;
+}
+
+// step 2: channels [cbase, cbase + 8 NCH) of the halo rows -> sX (pitch P = 8 NCH + 4 floats), the producer's pending BatchNorm
+// (+ReLU) applied on the way in, zeros where there is no voxel or no channel.  Ends with a barrier.
+template <int NCH, int WV, int THREADS = 64 * WV>
+__device__ __forceinline__ void d3_stage_rows(const ConvParams &p, float *sX, int tid, int dbg, int cbase)
+{
+    constexpr int cin_pad = NCH * 8, P = cin_pad + 4, C4 = cin_pad / 4;
+    constexpr int kThreads = THREADS, kD3Halo = d3_halo(WV);
     constexpr int kItems = kD3Halo * C4;
     constexpr int kIter = (kItems + kThreads - 1) / kThreads;
     float4 hv[kIter];
@@ -1107,8 +1117,8 @@ __device__ __forceinline__ bool d3_stage_halo(const ConvParams &p, int x0, int y
     constexpr bool kFixedGroup = kThreads % C4 == 0;
     float4 sc0 = make_float4(1.f, 1.f, 1.f, 1.f), sh0 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (kFixedGroup && p.in_scale) {
-        sc0 = *reinterpret_cast<const float4 *>(p.in_scale + min((tid % C4) * 4, last4));
-        sh0 = *reinterpret_cast<const float4 *>(p.in_shift + min((tid % C4) * 4, last4));
+        sc0 = *reinterpret_cast<const float4 *>(p.in_scale + min(cbase + (tid % C4) * 4, last4));
+        sh0 = *reinterpret_cast<const float4 *>(p.in_shift + min(cbase + (tid % C4) * 4, last4));
     }
 #pragma unroll
     for (int it = 0; it < kIter; ++it) {  // all loads first (clamped addresses), then the fix-ups and LDS stores
@@ -1116,14 +1126,14 @@ __device__ __forceinline__ bool d3_stage_halo(const ConvParams &p, int x0, int y
         const int cell = e / C4, c4 = e - cell * C4;
         hr[it] = d3_rank(sX, cell, P, cin_pad);
         if (dbg & 4) hv[it] = make_float4(1.f, 1.f, 1.f, 1.f);
-        else hv[it] = *reinterpret_cast<const float4 *>(p.x + (size_t)max(hr[it], 0) * p.ld_x + min(c4 * 4, last4));
+        else hv[it] = *reinterpret_cast<const float4 *>(p.x + (size_t)max(hr[it], 0) * p.ld_x + min(cbase + c4 * 4, last4));
     }
 #pragma unroll
     for (int it = 0; it < kIter; ++it) {
         const int e = tid + it * kThreads;
         if (e >= kItems) break;
         const int cell = e / C4, c4 = e - cell * C4;
-        const int c = c4 * 4;
+        const int c = cbase + c4 * 4;
         float4 v4 = hv[it];
         if (p.in_scale) {
             float4 sc = sc0, sh = sh0;
@@ -1138,9 +1148,16 @@ __device__ __forceinline__ bool d3_stage_halo(const ConvParams &p, int x0, int y
             }
         }
         if (hr[it] < 0 || c >= p.Cin) v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4 *>(sX + cell * P + c) = v4;
+        *reinterpret_cast<float4 *>(sX + cell * P + c4 * 4) = v4;
     }
     __syncthreads();
+}
+
+template <int NCH, int WV, int THREADS = 64 * WV>
+__device__ __forceinline__ bool d3_stage_halo(const ConvParams &p, int x0, int y0, int z0, float *sX, int tid, int dbg)
+{
+    if (!d3_stage_ranks<NCH, WV, THREADS>(p, x0, y0, z0, sX, tid)) return false;
+    d3_stage_rows<NCH, WV, THREADS>(p, sX, tid, dbg, 0);
     return true;
 }
 
@@ -1375,12 +1392,16 @@ __global__ void pack_weights16_kernel(const float *w, int K, int Cin, int Cout, 
 }
 
 template <int CT, int KCH>
-__global__ __launch_bounds__(256) void conv3d_tile16_kernel(ConvParams p, int tiles_y, int tiles_z, int ntiles)
+__global__ __launch_bounds__(256, 7) void conv3d_tile16_kernel(ConvParams p, int tiles_y, int tiles_z, int ntiles)
 {
-    constexpr int cin_pad = KCH * 16, NCH = KCH * 2;
+    // The input channels are walked in KCH PASSES of 16: the halo tile in LDS holds 16 channels at a time (240 cells x 80 B =
+    // 19.2 KB whatever C_in is), so that seven to eight workgroups fit a CU and ALL tiles of the 94k-voxel set (1,594 non-empty,
+    // 6.2 per CU) are resident at once — with the 32-channel halo (35 KB, four per CU) the layer ran in two batches and its
+    // MFMA loop took 58 us for 36 us of MFMAs.  Accumulators carry over; one staging + barrier per pass.
+    constexpr int cin_pad = 16, NCH = 2;
     constexpr int P = cin_pad + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *sX = reinterpret_cast<float *>(smem);   // [kD16Halo][P]: channels + the cell's row in the first pad word
+    float *sX = reinterpret_cast<float *>(smem);   // [kD16Halo][P]: 16 channels + the cell's row in the first pad word
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, q = lane >> 4;
@@ -1390,7 +1411,7 @@ __global__ __launch_bounds__(256) void conv3d_tile16_kernel(ConvParams p, int ti
     d3_tile_origin<kD16X>(tile, tiles_y, tiles_z, x0, y0, z0);
     float *sStat = sX;  // (after the loop) [4 waves][3][16 CT] summaries
 
-    if (!d3_stage_halo<NCH, kD16X, 256>(p, x0, y0, z0, sX, tid, p.debug)) {
+    if (!d3_stage_ranks<NCH, kD16X, 256>(p, x0, y0, z0, sX, tid)) {
         if (p.bn_partial && tid < 16 * CT && tid < p.Cout) {
             float *dst = p.bn_partial + (size_t)tile * 3 * p.Cout + tid;
             dst[0] = 0.0f; dst[p.Cout] = 0.0f; dst[2 * p.Cout] = 0.0f;
@@ -1406,59 +1427,55 @@ __global__ __launch_bounds__(256) void conv3d_tile16_kernel(ConvParams p, int ti
         const int r = 4 * q + j;
         orow[j] = d3_rank(sX, ((wx + 1) * kD3HY + wy + (r >> 3) + 1) * kD3HZ + (r & 7) + 1, P, cin_pad);
     }
-    const int own = d3_rank(sX, cell_a, P, cin_pad);
+    const bool work = __ballot(d3_rank(sX, cell_a, P, cin_pad) >= 0) != 0ull && !(p.debug & 1);   // (wave-uniform)
 
     f32x4 acc[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    if (__ballot(own >= 0) != 0ull && !(p.debug & 1)) {
-        const float *xa = sX + (cell_a - (kD3HY + 1) * kD3HZ - 1) * P + 4 * q;
-        constexpr unsigned kStepBytes = CT * 1024u, kOffBytes = KCH * kStepBytes;
-        const __amdgpu_buffer_rsrc_t wrsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wq), 0, (int)(27 * kOffBytes), 0x00020000);
-        const unsigned wlane = (unsigned)lane * 16u;
-        constexpr int kAheadB = (KCH * CT <= 4) ? 2 : 1;
-        float4 bq[kAheadB + 1][KCH][CT];
-        float4 aq[2][KCH];
-        auto load_b = [&](int k, float4(&dst)[KCH][CT]) {
+    const float *xa = sX + (cell_a - (kD3HY + 1) * kD3HZ - 1) * P + 4 * q;
+    constexpr unsigned kStepBytes = CT * 1024u, kOffBytes = KCH * kStepBytes;
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wq), 0, (int)(27 * kOffBytes), 0x00020000);
+    const unsigned wlane = (unsigned)lane * 16u;
+    constexpr int kAheadB = 2;
+    for (int pass = 0; pass < KCH; ++pass) {
+        if (pass > 0) __syncthreads();  // every wave is done reading the previous pass's channels
+        d3_stage_rows<NCH, kD16X, 256>(p, sX, tid, p.debug, 16 * pass);
+        if (!work) continue;
+        float4 bq[kAheadB + 1][CT];
+        float4 aq[2];
+        auto load_b = [&](int k, float4(&dst)[CT]) {
 #pragma unroll
-            for (int kc = 0; kc < KCH; ++kc)
-#pragma unroll
-                for (int t = 0; t < CT; ++t) {
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + (unsigned)kc * kStepBytes + (unsigned)t * 1024u,
-                                                                          (unsigned)k * kOffBytes, 0);
-                    dst[kc][t] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-                }
+            for (int t = 0; t < CT; ++t) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + (unsigned)t * 1024u,
+                                                                      (unsigned)k * kOffBytes + (unsigned)pass * kStepBytes, 0);
+                dst[t] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            }
         };
-        auto load_a = [&](int k, float4(&dst)[KCH]) {
+        auto load_a = [&](int k) {
             const int dx = k % 3, dy = (k / 3) % 3, dz = k / 9;
-            const float *xk = xa + ((dx * kD3HY + dy) * kD3HZ + dz) * P;
-#pragma unroll
-            for (int kc = 0; kc < KCH; ++kc) dst[kc] = *reinterpret_cast<const float4 *>(xk + kc * 16);
+            return *reinterpret_cast<const float4 *>(xa + ((dx * kD3HY + dy) * kD3HZ + dz) * P);
         };
 #pragma unroll
         for (int k = 0; k < kAheadB; ++k) load_b(k, bq[k]);
-        load_a(0, aq[0]);
+        aq[0] = load_a(0);
 #pragma unroll
         for (int k = 0; k < 27; ++k) {
             if (k + kAheadB < 27) load_b(k + kAheadB, bq[(k + kAheadB) % (kAheadB + 1)]);
-            if (k + 1 < 27) load_a(k + 1, aq[(k + 1) & 1]);
+            if (k + 1 < 27) aq[(k + 1) & 1] = load_a(k + 1);
             __builtin_amdgcn_sched_barrier(0);
-            const float4(&av)[KCH] = aq[k & 1];
-            const float4(&bk)[KCH][CT] = bq[k % (kAheadB + 1)];
+            const float4 av = aq[k & 1];
+            const float4(&bk)[CT] = bq[k % (kAheadB + 1)];
+            // the CT accumulators alternate: a 16x16x4 MFMA issues every 32 cycles but returns after 40
 #pragma unroll
-            for (int kc = 0; kc < KCH; ++kc) {
-                // the CT accumulators alternate: a 16x16x4 MFMA issues every 32 cycles but returns after 40
+            for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bk[t].x, acc[t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kc].x, bk[kc][t].x, acc[t], 0, 0, 0);
+            for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bk[t].y, acc[t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kc].y, bk[kc][t].y, acc[t], 0, 0, 0);
+            for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bk[t].z, acc[t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kc].z, bk[kc][t].z, acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kc].w, bk[kc][t].w, acc[t], 0, 0, 0);
-            }
+            for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bk[t].w, acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -1630,7 +1647,7 @@ int launch_conv3d_tile16(const ConvParams &p, hipStream_t st)
 {
     int ty, tz;
     const int ntiles = d3_tiles_kind(p, kD3Tile16, &ty, &tz);
-    const size_t lds = max((size_t)kD16Halo * (KCH * 16 + 4) * sizeof(float), (size_t)kWaves * 3 * 16 * CT * sizeof(float));
+    const size_t lds = max((size_t)kD16Halo * (16 + 4) * sizeof(float), (size_t)kWaves * 3 * 16 * CT * sizeof(float));
     if (lds > 64 * 1024) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_tile16_kernel<CT, KCH>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
