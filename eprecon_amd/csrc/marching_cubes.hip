@@ -22,13 +22,16 @@
 #include <math.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "common.hpp"
 
 namespace {
 using namespace ep;
 
 int8_t g_table_host[256][16];
-int8_t *g_table_dev = nullptr;
+int8_t *g_table_by_device[64] = {nullptr};   // one upload per device, under g_table_mutex (see upload_table)
+std::mutex g_table_mutex;
 bool g_table_built = false;
 
 inline int edge_id(int axis, int b, int c) { return axis * 4 + b + 2 * c; }
@@ -253,13 +256,20 @@ __global__ __launch_bounds__(256) void mc_face_kernel(McParams p, const int8_t *
     }
 }
 
-int upload_table()
+// the case table on the CURRENT device (built / uploaded once per device; callers may be on different threads)
+int upload_table(const int8_t **table_out)
 {
+    int device = 0;
+    EP_HIP_CHECK(hipGetDevice(&device));
+    if (device < 0 || device >= 64) return EPRECON_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(g_table_mutex);
     build_table();
-    if (!g_table_dev) {
-        EP_HIP_CHECK(hipMalloc(&g_table_dev, sizeof(g_table_host)));
-        EP_HIP_CHECK(hipMemcpy(g_table_dev, g_table_host, sizeof(g_table_host), hipMemcpyHostToDevice));
+    int8_t *&dev = g_table_by_device[device];
+    if (!dev) {
+        EP_HIP_CHECK(hipMalloc(&dev, sizeof(g_table_host)));
+        EP_HIP_CHECK(hipMemcpy(dev, g_table_host, sizeof(g_table_host), hipMemcpyHostToDevice));
     }
+    *table_out = dev;
     return EPRECON_OK;
 }
 
@@ -271,6 +281,7 @@ extern "C" {
 int eprecon_marching_cubes_table(int8_t *out_host)
 {
     if (!out_host) return EPRECON_ERR_ARG;
+    std::lock_guard<std::mutex> lock(g_table_mutex);
     build_table();
     memcpy(out_host, g_table_host, sizeof(g_table_host));
     return EPRECON_OK;
@@ -290,7 +301,8 @@ int eprecon_marching_cubes_count(const float *volume, int dx, int dy, int dz, fl
     const int64_t n = (int64_t)dx * dy * dz;
     if (n > 0x7fffffff / 4) return EPRECON_ERR_UNSUPPORTED;
     if (workspace_bytes < eprecon_marching_cubes_workspace_bytes(dx, dy, dz)) return EPRECON_ERR_WORKSPACE;
-    int rc = upload_table();
+    const int8_t *table = nullptr;
+    int rc = upload_table(&table);
     if (rc != EPRECON_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     char *ws = reinterpret_cast<char *>(workspace);
@@ -300,7 +312,7 @@ int eprecon_marching_cubes_count(const float *volume, int dx, int dy, int dz, fl
     int32_t *s1 = reinterpret_cast<int32_t *>(ws + 4 * seg), *s2 = reinterpret_cast<int32_t *>(ws + 4 * seg + sseg);
     int32_t *totals = reinterpret_cast<int32_t *>(ws + 4 * seg + 2 * sseg);
     McParams p{volume, dx, dy, dz, level};
-    hipLaunchKernelGGL(mc_count_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, p, (const int8_t *)g_table_dev, nvert,
+    hipLaunchKernelGGL(mc_count_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, p, table, nvert,
                        ntri);
     EP_LAUNCH_CHECK();
     rc = ep::exclusive_scan_i32(nvert, (int)n, voff, s1, totals, st);
@@ -323,6 +335,9 @@ int eprecon_marching_cubes_emit_async(const float *volume, int dx, int dy, int d
     if (!volume || !verts || !faces || !workspace || (label_a && !vert_label_a) || (label_b && !vert_label_b))
         return EPRECON_ERR_ARG;
     const int64_t n = (int64_t)dx * dy * dz;
+    const int8_t *table = nullptr;
+    const int trc = upload_table(&table);
+    if (trc != EPRECON_OK) return trc;
     hipStream_t st = (hipStream_t)stream;
     const char *ws = reinterpret_cast<const char *>(workspace);
     const size_t seg = align_up((size_t)n * 4, 256);
@@ -331,7 +346,7 @@ int eprecon_marching_cubes_emit_async(const float *volume, int dx, int dy, int d
     const dim3 grid((unsigned)ceil_div(n, 256)), blk(256);
     hipLaunchKernelGGL(mc_vertex_kernel, grid, blk, 0, st, p, voff, verts, normals, label_a, label_b, vert_label_a, vert_label_b);
     EP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(mc_face_kernel, grid, blk, 0, st, p, (const int8_t *)g_table_dev, voff, toff, (const float *)verts, faces);
+    hipLaunchKernelGGL(mc_face_kernel, grid, blk, 0, st, p, table, voff, toff, (const float *)verts, faces);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }

@@ -9,6 +9,8 @@
 // R = floor(sqrt(best)) probe the cube c + [-R,R]^3 (only offsets with |o|^2 <= best), which
 // contains every candidate that could beat or tie the bound; (3) if nothing was found within
 // [-2q,2q]^3 fall back to a scan of the whole reference set — rare, and exact.
+#include <mutex>
+
 #include "hashgrid.hpp"
 
 namespace {
@@ -130,9 +132,16 @@ extern "C" int eprecon_nearest_voxel_async(const void *table, uint32_t capacity,
     t.keys = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(const_cast<void *>(table)) + 256);
     t.vals = reinterpret_cast<int32_t *>(t.keys + capacity);
     t.mask = capacity - 1;
-    // offsets with |o|^2 <= kShellMax, ascending |o|^2 (built once, lives for the process)
-    static int4 *shell_dev = nullptr;
+    // offsets with |o|^2 <= kShellMax, ascending |o|^2: built once PER DEVICE under a lock (the pipelined serving mode
+    // issues the panoptic branch from a worker thread: the first call may come from either thread), lives for the process
+    static std::mutex shell_mutex;
+    static int4 *shell_by_device[64] = {nullptr};
     static int n_shell = 0;
+    int device = 0;
+    EP_HIP_CHECK(hipGetDevice(&device));
+    if (device < 0 || device >= 64) return EPRECON_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(shell_mutex);
+    int4 *&shell_dev = shell_by_device[device];
     if (!shell_dev) {
         int4 host[1024];
         int cnt = 0;

@@ -56,7 +56,9 @@ class Cfg2Step:
         self.last = {}
         self.profile_dominant = False  # bench.py: time the dense 96^3 gather with the library's event pair
         self.bp_side_stream = os.environ.get("EPRECON_CFG2_BP_STREAM", "0") == "1"
-        self._bp_stream = torch.cuda.Stream(device=dev) if self.bp_side_stream else None
+        # (EPRECON_CFG2_BP_PRIO: HIP stream priority of that stream; larger = lower priority, clamped by the runtime)
+        prio = int(os.environ.get("EPRECON_CFG2_BP_PRIO", "0"))
+        self._bp_stream = torch.cuda.Stream(device=dev, priority=prio) if self.bp_side_stream else None
 
     @torch.no_grad()
     def run(self):

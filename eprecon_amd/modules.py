@@ -39,25 +39,33 @@ def recording():
 # its indice pairs each time (indice_key=None).  Here the hash grid + 27-neighbour table is built
 # once per distinct coords tensor and shared by all layers that see the same tensor.
 # ------------------------------------------------------------------------------------------------
+# The cache is keyed on the tensor OBJECT (identity + data_ptr + torch's version counter).  Writes that the HIP library
+# makes through raw pointers do not bump that counter: a caller that refills the SAME coords tensor in place (e.g. a
+# persistent serving buffer) must call clear_voxel_set_cache() (and torchsparse_utils.clear_voxelization_cache()) at the
+# fragment boundary, or hand over fresh tensors per fragment as every path in this package does.
 _SET_CACHE = []
 _SET_CACHE_MAX = 8
+_SET_CACHE_LOCK = __import__("threading").Lock()   # the pipelined serving mode calls in from a worker thread as well
 
 
 def voxel_set_for(coords, stride=1):
     key = (coords.data_ptr(), coords.shape[0], coords._version, int(stride), coords.device)
-    for k, ref, vs in _SET_CACHE:
-        if k == key and ref is coords:
-            return vs
+    with _SET_CACHE_LOCK:
+        for k, ref, vs in _SET_CACHE:
+            if k == key and ref is coords:
+                return vs
     c = coords if coords.dtype == torch.int32 else coords.to(torch.int32)
     vs = SP.VoxelSet(c.contiguous(), stride)
-    _SET_CACHE.append((key, coords, vs))
-    if len(_SET_CACHE) > _SET_CACHE_MAX:
-        _SET_CACHE.pop(0)
+    with _SET_CACHE_LOCK:
+        _SET_CACHE.append((key, coords, vs))
+        if len(_SET_CACHE) > _SET_CACHE_MAX:
+            _SET_CACHE.pop(0)
     return vs
 
 
 def clear_voxel_set_cache():
-    _SET_CACHE.clear()
+    with _SET_CACHE_LOCK:
+        _SET_CACHE.clear()
 
 
 # ------------------------------------------------------------------------------------------------

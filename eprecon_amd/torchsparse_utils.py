@@ -106,19 +106,26 @@ class _VoxEntry:
         return hit[0], hit[1]
 
 
+# Keyed on the point tensor OBJECT (identity + data_ptr + torch's version counter): a caller that refills the same tensor in
+# place through raw pointers (which does not bump the counter) must call clear_voxelization_cache() at the fragment boundary;
+# every path in this package hands over a fresh tensor per fragment.  Guarded by a lock: the pipelined serving mode calls in
+# from a worker thread while the main thread runs the next fragment.
 _VOX_CACHE = []
 _VOX_CACHE_MAX = 6
+_VOX_CACHE_LOCK = __import__("threading").Lock()
 
 
 def clear_voxelization_cache():
-    _VOX_CACHE.clear()
+    with _VOX_CACHE_LOCK:
+        _VOX_CACHE.clear()
 
 
 def _voxelize_points(pts, res):
     key = (pts.data_ptr(), pts._version, pts.shape[0], float(res))
-    for e in _VOX_CACHE:
-        if e.key == key and e.pts is pts:
-            return e
+    with _VOX_CACHE_LOCK:
+        for e in _VOX_CACHE:
+            if e.key == key and e.pts is pts:
+                return e
     lib = _lib.load()
     n = pts.shape[0]
     e = _VoxEntry()
@@ -132,9 +139,10 @@ def _voxelize_points(pts, res):
     e.lists = _segment_lists(e.inverse, e.vset.n)
     e.idx8 = e.w8 = e._order = None
     e._stale = {}
-    _VOX_CACHE.append(e)
-    if len(_VOX_CACHE) > _VOX_CACHE_MAX:
-        _VOX_CACHE.pop(0)
+    with _VOX_CACHE_LOCK:
+        _VOX_CACHE.append(e)
+        if len(_VOX_CACHE) > _VOX_CACHE_MAX:
+            _VOX_CACHE.pop(0)
     return e
 
 

@@ -171,3 +171,28 @@ def test_batched_backbone_feeds_back_projection_in_place():
         # own LDS-tiled re-layout kernel
         prepped, layout = BP._prep_feats(st)
         assert prepped.data_ptr() == st.data_ptr() and layout in (BP.LAYOUT_NHWC, BP.LAYOUT_NCHW)
+
+
+def test_non_fusion_path_with_ground_truth_targets():
+    """FUSION.FUSION_ON = False with tsdf_list / occ_list in the inputs: get_target returns 1-D targets where the
+    fusion path returns [N,1]; the reference indexes them without caring (models/neucon_network.py:117-126,454-507)"""
+    from eprecon_amd.fragment_step import seed_subsampling
+    from eprecon_amd.neucon_network import NeuConNet
+    cfg = ModelCfg()
+    cfg.FUSION.FUSION_ON = False
+    torch.manual_seed(7)
+    net = NeuConNet(cfg, panoptic_decoder=None).cuda()
+    net.train()
+    window = S.make_window(seed=0, width=320, height=240)
+    feats, feats2, inputs = S.make_model_inputs([window], feat_seed=3)
+    dev = torch.device("cuda")
+    d_feats, d_feats2, d_inputs = S.to_device(feats, dev), S.to_device(feats2, dev), S.to_device(inputs, dev)
+    with torch.no_grad():
+        for i in range(3):          # push every level's occupancy head to "mostly occupied" so that the loop reaches the end
+            net.occ_preds[i].linear3.bias.fill_(0.05)
+        net.trace = []
+        seed_subsampling(0)
+        out, loss = net(d_feats, d_feats2, d_inputs, {})
+    stages = [t["stage"] for t in net.trace]
+    assert "heads0" in stages                                   # the sparsify step ran with the 1-D targets
+    assert set(loss) >= {"tsdf_occ_loss_0"}

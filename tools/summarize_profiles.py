@@ -28,7 +28,7 @@ for d in sorted(os.listdir(src)):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if "bp_gather_mlp_kernel<256" in n or "spconv_resident_kernel<1, true, 4" in n:
+        if "bp_gather_mlp_kernel<256" in n or "spconv_resident_kernel<1, true, 4" in n or "conv3d_tile16_kernel<2, 2>" in n:
             short = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             acc[(short, r["Grid_Size"], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (n, g, c), v in sorted(acc.items()):
