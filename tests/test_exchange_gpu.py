@@ -124,3 +124,90 @@ def test_update_stamps_the_rows_it_appends_and_compaction_keeps_the_others():
     outside = ~inside(c, np.array(rel), dim)
     assert np.array_equal(out_c.cpu().numpy()[: outside.sum()], c[outside]) and np.array_equal(s[: outside.sum()], stamp[outside])
     assert np.all(s[outside.sum():] == 42) and len(s) == outside.sum() + updated.shape[0]
+
+
+def test_two_virtual_ranks_follow_the_simulated_schedule(monkeypatch):
+    """BoundaryExchange.exchange_handles at WORLD SIZE 2 on one GPU: two threads stand in for two ranks (a fake
+    `torch.distributed` shuttles their all-gathers through a mailbox), each with its own three map handles, streaming four
+    overlapping fragments per rank through exchange -> crop_union -> fuse -> update.  Every rank's maps (coordinates AND
+    features) must equal the single-process simulation of the "independent windows + exchange" schedule that the gloo test
+    checks the torch form against (tests/test_distributed_cpu.py: newest fusion wins, received voxels are not re-broadcast)."""
+    import threading
+    from eprecon_amd import distributed as D
+    from eprecon_amd.global_map import GlobalMap
+    from eprecon_amd.gru_fusion import gather_rows
+    from test_distributed_cpu import CH, DIMS, STEPS, fragment, simulate_schedule
+
+    world = 2
+    dev = torch.device(DEV)
+
+    class FakeDist:
+        def __init__(self):
+            self.barrier = threading.Barrier(world)
+            self.box = [None] * world
+            self.local = threading.local()
+
+        def get_world_size(self, group=None):
+            return world
+
+        def get_rank(self, group=None):
+            return self.local.rank
+
+        def all_gather(self, outs, t, group=None):
+            self.box[self.local.rank] = t.clone()
+            torch.cuda.synchronize()
+            self.barrier.wait()
+            for o, src in zip(outs, self.box):
+                o.copy_(src)
+            torch.cuda.synchronize()
+            self.barrier.wait()
+
+    fake = FakeDist()
+    monkeypatch.setattr(D, "dist", fake)
+    results, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            fake.local.rank = rank
+            torch.cuda.set_device(dev)
+            ex = D.BoundaryExchange(3, dev)
+            gmaps = [GlobalMap(CH[s], dev) for s in range(3)]
+            for step in range(STEPS):
+                frs = [fragment(rank, step, s) for s in range(3)]
+                ex.exchange_handles(gmaps, [fr[0].tolist() for fr in frs], DIMS)
+                for s in range(3):
+                    lo, cc, cf = frs[s]
+                    g = gmaps[s]
+                    cur_c = torch.from_numpy(np.concatenate([np.zeros((len(cc), 1), np.int32), cc - lo.astype(np.int32)], 1)).to(dev)
+                    cur_f = torch.from_numpy(cf).to(dev)
+                    updated, src_cur, src_glob, _ = g.crop_union(cur_c, cur_f, DIMS[s], 1, lo.tolist())
+                    old = g.gather(src_glob, 0, CH[s], torch.empty((updated.shape[0], CH[s]), device=dev))
+                    cur = gather_rows(cur_f, src_cur, CH[s])
+                    g.set_fragment(step * world + rank)
+                    g.update(updated, (0.5 * old + cur).contiguous())          # toy_fuse of the gloo test, on the handle
+            out = []
+            for g in gmaps:
+                c, f = g.export()
+                out.append({tuple(k): row for k, row in zip(c.cpu().numpy().tolist(), f.cpu().numpy())})
+            results[rank] = (out, ex.collectives, ex.rows_sent)
+        except Exception as exc:  # noqa: BLE001
+            errors.append((rank, repr(exc)))
+            try:
+                fake.barrier.abort()
+            except Exception:  # noqa: BLE001
+                pass
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    want = simulate_schedule()
+    for r in range(world):
+        maps, collectives, sent = results[r]
+        assert sent > 0 and 2 * STEPS <= collectives <= 3 * STEPS
+        for s in range(3):
+            assert set(maps[s]) == set(want[r][s]), (r, s, len(maps[s]), len(want[r][s]))
+            worst = max(float(np.abs(maps[s][k] - want[r][s][k]).max()) for k in maps[s])
+            assert worst < 1e-5, (r, s, worst)
