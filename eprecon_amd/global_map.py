@@ -68,6 +68,8 @@ class GlobalMap:
         Blocking (one host read for N', where the reference's torch.nonzero synchronises too)."""
         lib = _lib.load()
         n_cur = cur_feat.shape[0]
+        assert cur_feat.stride(1) == 1 or n_cur == 0
+        cur_coords = cur_coords.contiguous()     # raw pointers below: int32[N,4] rows
         cap = max(min(dim ** 3, n_cur + self.size), 1)
         dev = self.device
         updated = torch.empty((cap, 3), dtype=torch.int32, device=dev)

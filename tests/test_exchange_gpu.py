@@ -114,7 +114,7 @@ def test_update_stamps_the_rows_it_appends_and_compaction_keeps_the_others():
     g, c, f, stamp = make_map(rng, 20000, 24, 60)
     dim, rel = 24, [5, 6, 7]
     cur = np.unique(rng.integers(0, dim, (3000, 3)), axis=0).astype(np.int32)
-    cur_c = torch.from_numpy(np.concatenate([np.zeros((len(cur), 1), np.int32), cur], 1)).to(DEV)
+    cur_c = torch.from_numpy(np.ascontiguousarray(np.concatenate([np.zeros((len(cur), 1), np.int32), cur], 1))).to(DEV)
     cur_f = torch.randn((len(cur), 24), device=DEV)
     updated, _, _, _ = g.crop_union(cur_c, cur_f, dim, 1, rel)
     g.set_fragment(41)
@@ -139,7 +139,7 @@ def test_two_virtual_ranks_follow_the_simulated_schedule(monkeypatch):
     from test_distributed_cpu import CH, DIMS, STEPS, fragment, simulate_schedule
 
     world = 2
-    dev = torch.device(DEV)
+    dev = torch.device("cuda", 0)
 
     class FakeDist:
         def __init__(self):
@@ -169,7 +169,7 @@ def test_two_virtual_ranks_follow_the_simulated_schedule(monkeypatch):
     def rank_main(rank):
         try:
             fake.local.rank = rank
-            torch.cuda.set_device(dev)
+            torch.cuda.set_device(0)
             ex = D.BoundaryExchange(3, dev)
             gmaps = [GlobalMap(CH[s], dev) for s in range(3)]
             for step in range(STEPS):
@@ -178,7 +178,7 @@ def test_two_virtual_ranks_follow_the_simulated_schedule(monkeypatch):
                 for s in range(3):
                     lo, cc, cf = frs[s]
                     g = gmaps[s]
-                    cur_c = torch.from_numpy(np.concatenate([np.zeros((len(cc), 1), np.int32), cc - lo.astype(np.int32)], 1)).to(dev)
+                    cur_c = torch.from_numpy(np.ascontiguousarray(np.concatenate([np.zeros((len(cc), 1), np.int32), cc - lo.astype(np.int32)], 1))).to(dev)
                     cur_f = torch.from_numpy(cf).to(dev)
                     updated, src_cur, src_glob, _ = g.crop_union(cur_c, cur_f, DIMS[s], 1, lo.tolist())
                     old = g.gather(src_glob, 0, CH[s], torch.empty((updated.shape[0], CH[s]), device=dev))
@@ -204,9 +204,10 @@ def test_two_virtual_ranks_follow_the_simulated_schedule(monkeypatch):
         t.join(timeout=120)
     assert not errors, errors
     want = simulate_schedule()
+    assert sum(results[r][2] for r in range(world)) > 0          # (in this stream only the later fragment's rank has rows to send)
     for r in range(world):
         maps, collectives, sent = results[r]
-        assert sent > 0 and 2 * STEPS <= collectives <= 3 * STEPS
+        assert 2 * STEPS < collectives <= 3 * STEPS                # the payload all-gather ran whenever somebody had rows
         for s in range(3):
             assert set(maps[s]) == set(want[r][s]), (r, s, len(maps[s]), len(want[r][s]))
             worst = max(float(np.abs(maps[s][k] - want[r][s][k]).max()) for k in maps[s])
