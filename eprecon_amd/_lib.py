@@ -107,6 +107,7 @@ SIGNATURES = {
     "eprecon_profile_conv_arm": (_i, [_i, _i, _i, _i64]),
     "eprecon_profile_conv_ms": (_f, [_c.POINTER(_i64), _c.POINTER(_c.c_char_p)]),
     "eprecon_profile_conv_pairs": (_i64, []),
+    "eprecon_profile_mark_async": (_i, [_i, _vp]),
     "eprecon_grid_rank_async": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "eprecon_conv_pack_weight_floats": (_sz, [_i, _i, _i]),
     "eprecon_conv_pack_weight_async": (_i, [_vp, _i, _i, _i, _vp, _vp]),

@@ -82,6 +82,8 @@ def unique_coords(coords, quantum=1):
     return uniq[:m], inverse, grid
 
 
+DIRECT = os.environ.get("EPRECON_CONV_DIRECT", "1") != "0"   # (the library reads the same switch per launch)
+DIRECT_MAX_COUT = 64
 DENSE_MIN_FILL = 0.4   # a set that fills at least this share of its bounding grid takes the dense-grid convolution
 
 
@@ -143,7 +145,8 @@ def packed_weight(weight):
 
 
 def packed_weight16(weight):
-    """`weight` f32[27, Cin, Cout <= 32] in the operand order of the 16-row tile kernel, packed once per weight version"""
+    """`weight` f32[27, Cin, Cout <= 64] in the operand order of the 16x16x4 MFMA kernels (16-row tile kernel, direct gather
+    kernel), packed once per weight version"""
     hit = getattr(weight, "_d3_pack16", None)
     if hit is None or hit[0] != weight._version or hit[1].device != weight.device:
         lib = _lib.load()
@@ -179,7 +182,15 @@ def _resolve_map(nbr, x, weight, desc, accumulate=False, ln=False, stats=False, 
             return keep
         nbr = nbr.vset.kernel_map(3)
     desc.nbr = None if nbr is None else nbr.data_ptr()
-    return [nbr]
+    keep = [nbr]
+    if nbr is not None and weight.shape[0] == 27 and weight.shape[2] <= DIRECT_MAX_COUT \
+            and not accumulate and not fused and x.is_cuda and DIRECT:
+        # long lists: the direct gather kernel takes its B operands pre-packed (csrc/sparse_conv.hip, spconv_direct16_kernel);
+        # which kernel runs is the library's choice, the packing only makes the direct one possible
+        pw = packed_weight16(weight)
+        desc.packed_weight16 = pw.data_ptr()
+        keep.append(pw)
+    return keep
 
 
 class VoxelSet:
@@ -263,7 +274,7 @@ def sparse_conv(x, weight, nbr=None, bias=None, out=None, relu=False, accumulate
     weight = weight.contiguous()
     n_out = x.shape[0] if nbr is None else nbr.shape[1]
     assert x.shape[1] == cin and x.dtype == torch.float32
-    if isinstance(nbr, DenseMap):
+    if isinstance(nbr, DenseMap) or (kvol == 27 and nbr is not None and x.is_cuda):
         return sparse_conv_fused(x, weight, nbr, bias, out, relu, None, accumulate)[0]
     if nbr is not None:
         assert nbr.dtype == torch.int32 and nbr.shape[0] == kvol and nbr.is_contiguous()
@@ -289,9 +300,12 @@ def sparse_conv_fused(x, weight, nbr=None, bias=None, out=None, relu=False, resi
     weight = weight.contiguous()
     n_out = x.shape[0] if nbr is None else nbr.shape[1]
     assert x.shape[1] == cin and x.dtype == torch.float32
-    if isinstance(nbr, DenseMap):
+    if isinstance(nbr, DenseMap) or (kvol == 27 and nbr is not None and x.is_cuda):   # descriptor entry point
+        if not isinstance(nbr, DenseMap):
+            assert nbr.dtype == torch.int32 and nbr.shape[0] == kvol and nbr.is_contiguous()
         if out is None:
             out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+        assert out.shape == (n_out, cout)
         d = _lib.ConvDesc()
         d.x, d.n_in, d.ld_x = x.data_ptr(), x.shape[0], _ld(x)
         d.kvol, d.n_out = kvol, n_out

@@ -138,6 +138,8 @@ float eprecon_profile_conv_ms(int64_t *rows_out, const char **kernel_out);
 /* live (output row, kernel offset) pairs of the bracketed launch (2 * pairs * cin * cout = its algorithmic flops),
  * counted on the launch stream behind the stop event; blocks; -1 when nothing was recorded */
 int64_t eprecon_profile_conv_pairs(void);
+/* stage marker for rocprofv3 kernel traces: an empty launch of (id + 1) workgroups on `stream` (tools/trace_cfg4_layers.py) */
+int eprecon_profile_mark_async(int id, void *stream);
 
 /* NCHW -> NHWC re-layout of a stack of feature maps: in f32[maps, C, H*W] -> out f32[maps, H*W, C] */
 int eprecon_nchw_to_nhwc_async(const float *in, float *out, int maps, int channels, int hw,

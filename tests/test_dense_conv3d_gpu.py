@@ -19,6 +19,9 @@ def all_dense_kernels(monkeypatch):
     every shape (bit-identical to the gather form); the 16-row kernel has its own test below"""
     monkeypatch.setenv("EPRECON_CONV_DENSE3D", "3")
     monkeypatch.setenv("EPRECON_CONV_DENSE3D_NO16", "1")
+    # the gather form they are compared with: the 32-row 32x32x2 kernels (same summation order)
+    monkeypatch.setenv("EPRECON_CONV_DIRECT", "0")
+    monkeypatch.setenv("EPRECON_CONV_SPLITK_NARROW", "0")
 
 
 def dev(a):

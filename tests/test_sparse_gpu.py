@@ -198,3 +198,61 @@ def test_sparse_conv_ragged_channels_with_padded_pitch(cin, cout):
     got = sparse_conv(buf[:, :cin], dev(w), vs.kernel_map(3), dev(b)).cpu().numpy()
     ref = OS.sparse_conv(x, OS.kernel_map(c, c, 3, 1), w, b)
     assert np.isfinite(got).all() and np.abs(got - ref).max() < TOL
+
+
+def _last_conv_kernel(arm, fn):
+    """run fn() with the one-shot conv profiler armed: -> (result, name of the kernel family that took the launch)"""
+    import ctypes
+    from eprecon_amd import _lib
+    lib = _lib.load()
+    lib.eprecon_profile_conv_arm(*arm)
+    out = fn()
+    rows, name = ctypes.c_int64(0), ctypes.c_char_p()
+    assert lib.eprecon_profile_conv_ms(ctypes.byref(rows), ctypes.byref(name)) >= 0
+    return out, name.value.decode()
+
+
+@pytest.mark.parametrize("cin,cout", [(48, 24), (32, 32), (24, 24), (16, 16), (74, 8), (96, 48), (64, 64), (140, 16)])
+def test_direct_gather_kernel_on_a_long_list(cin, cout):
+    """the long-list form of the 3x3x3 convolution (spconv_direct16_kernel: operands straight from L2 into the 16x16x4 MFMAs,
+    no LDS staging) with every epilogue the layers use: bias + ReLU + residual, the producer's pending BatchNorm on the
+    gathered values + summaries of the output, row-wise LayerNorm"""
+    from eprecon_amd import sparse as SP
+    rng = np.random.default_rng(cin * 131 + cout)
+    c = random_coords(rng, 41003, extent=34, batch=1)
+    n = len(c)
+    x = rng.standard_normal((n, cin)).astype(np.float32)
+    w = (rng.standard_normal((27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((n, cout)).astype(np.float32)
+    vs = SP.VoxelSet(dev(c))
+    nbr_d = vs.kernel_map(3)
+    nbr = OS.kernel_map(c, c, 3, 1)
+    cp = (cin + 3) & ~3
+    buf = torch.full((n, cp), float("nan"), device="cuda")       # ragged channel counts sit on a padded pitch
+    buf[:, :cin] = dev(x)
+    dx, dw, db = buf[:, :cin], dev(w), dev(b)
+    ref = OS.sparse_conv(x, nbr, w, b)
+    (y, part), name = _last_conv_kernel((27, cin, cout, 1000), lambda: SP.sparse_conv_fused(
+        dx, dw, nbr_d, db, relu=True, residual=dev(res), bn_partial=True))
+    assert name == "spconv_direct16_kernel"
+    want = np.maximum(ref, 0) + res
+    assert np.abs(y.cpu().numpy() - want).max() < TOL
+    part = part.cpu().numpy().astype(np.float64)                     # [blocks, 3, cout]: (count, mean, M2) of the stored rows
+    assert part.shape[0] == (n + 127) // 128 and part[:, 0, 0].sum() == n
+    cnt, mean, m2 = part[:, 0], part[:, 1], part[:, 2]
+    tot_mean = (cnt * mean).sum(0) / n
+    tot_m2 = (m2 + cnt * (mean - tot_mean) ** 2).sum(0)
+    assert np.abs(tot_mean - want.mean(0)).max() < 1e-4 and np.abs(tot_m2 / n - want.var(0)).max() < 1e-3
+    # pending BatchNorm (+ ReLU) of the producer applied while gathering; missing neighbours stay zero
+    sc = rng.uniform(0.5, 1.5, cin).astype(np.float32)
+    sh = rng.standard_normal(cin).astype(np.float32)
+    y2, _ = SP.conv_stats(dx, dw, nbr_d, in_affine=(dev(sc), dev(sh), True))
+    ref2 = OS.sparse_conv(np.maximum(x * sc + sh, 0), nbr, w)
+    assert np.abs(y2.cpu().numpy() - ref2).max() < TOL
+    # LN(res + ReLU(conv)) into a channel slice of a wider buffer
+    g, be = rng.standard_normal(cout).astype(np.float32), rng.standard_normal(cout).astype(np.float32)
+    wide = torch.zeros((n, cout + 8), device="cuda")
+    out = SP.sparse_conv_ln(dx, dw, nbr_d, db, dev(g), dev(be), 1e-5, out=wide[:, 4:4 + cout], relu=True, residual=dev(res))
+    assert np.abs(out.cpu().numpy() - OS.layernorm_rows(ref, g, be, 1e-5, res, True, False)).max() < TOL
+    assert not wide[:, :4].any() and not wide[:, 4 + cout:].any()

@@ -10,15 +10,19 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eprecon_amd import sparse as SP  # noqa: E402
 
-SHAPES = [  # (rows, C_in, C_out, what)
-    (10000, 192, 96, "ConvGRU voxel s0"), (10000, 160, 80, "ConvGRU img s0"),
-    (43000, 96, 48, "ConvGRU voxel s1"), (43000, 80, 40, "ConvGRU img s1"),
-    (183000, 48, 24, "ConvGRU s2"),
-    (9000, 80, 32, "SPVCNN0 stem"), (9000, 224, 96, "SPVCNN0 up1"), (9000, 128, 96, "SPVCNN0 up2"),
-    (9000, 96, 96, "SPVCNN0 res"), (3000, 128, 128, "SPVCNN0 stage2"), (5000, 64, 64, "SPVCNN0 stage1"),
-    (40000, 140, 16, "SPVCNN1 stem (138 padded)"), (40000, 64, 48, "SPVCNN1 up2"), (40000, 48, 48, "SPVCNN1 res"),
-    (140000, 76, 8, "SPVCNN2 stem (74 padded)"), (140000, 32, 24, "SPVCNN2 up2"), (140000, 24, 24, "SPVCNN2 res"),
-    (94000, 32, 32, "init subm 32->32"),
+SHAPES = [  # (rows, C_in, C_out, what): the 3x3x3 launches of one cfg4 fragment (profiles/r03/cfg4_layers.txt)
+    (9415, 192, 96, "ConvGRU voxel s0"), (9415, 160, 80, "ConvGRU img s0"), (11880, 192, 96, "ConvGRU voxel s0 (convr)"),
+    (57444, 96, 48, "ConvGRU voxel s1"), (57444, 80, 40, "ConvGRU img s1"), (74568, 96, 48, "ConvGRU voxel s1 (convr)"),
+    (320868, 48, 24, "ConvGRU s2"),
+    (9324, 80, 32, "SPVCNN0 stem"), (9324, 128, 96, "SPVCNN0 up2"), (9324, 96, 96, "SPVCNN0 up2 res"),
+    (1532, 32, 64, "SPVCNN0 stage1"), (1532, 64, 64, "SPVCNN0 stage1 res"), (1532, 160, 96, "SPVCNN0 up1"),
+    (1532, 96, 96, "SPVCNN0 up1 res"), (204, 64, 128, "SPVCNN0 stage2"), (204, 128, 128, "SPVCNN0 stage2 res"),
+    (28864, 140, 16, "SPVCNN1 stem (138 padded)"), (28864, 64, 48, "SPVCNN1 up2"), (28864, 48, 48, "SPVCNN1 up2 res"),
+    (7561, 32, 32, "SPVCNN1 stage1 res"), (7561, 80, 48, "SPVCNN1 up1"), (7561, 48, 48, "SPVCNN1 up1 res"),
+    (1502, 64, 64, "SPVCNN1 stage2 res"),
+    (198184, 76, 8, "SPVCNN2 stem (74 padded)"), (198184, 32, 24, "SPVCNN2 up2"), (198184, 24, 24, "SPVCNN2 up2 res"),
+    (47864, 16, 16, "SPVCNN2 stage1 res"), (47864, 24, 24, "SPVCNN2 up1 res"), (10121, 32, 32, "SPVCNN2 stage2 res"),
+    (93513, 48, 48, "mask features"),
 ]
 
 
