@@ -34,59 +34,14 @@
 #include <stdlib.h>
 
 #include "common.hpp"
+#include "conv_common.hpp"
 
 namespace {
 using namespace ep;
+using namespace epconv;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct ConvParams {
-    const float *x;      // [n_in, ld_x] (+ x_col0 folded into the pointer)
-    const int32_t *nbr;  // [K][n_out] or nullptr (K must be 1: identity map)
-    const float *w;      // [K][Cin][Cout]
-    const float *bias;   // [Cout] or nullptr
-    float *out;          // [n_out, ld_out]
-    int n_out, K, Cin, Cout, ld_x, ld_out;
-    int64_t x_bytes;     // bytes addressable from x (buffer-load gathers: rows past it read as zeros)
-    int relu;            // fused ReLU epilogue
-    int accumulate;      // out += result instead of out = result
-    const float *res;    // optional [n_out, ld_res]: added after the ReLU (x + ReLU(conv(x)) blocks)
-    int ld_res;
-    float *bn_partial;   // optional [gridDim.x][3][Cout]: per-workgroup (count, mean, M2) of the stored values
-    // BatchNorm of the INPUT applied while gathering: a = [relu](x * in_scale[c] + in_shift[c]) (nullptr: a = x)
-    const float *in_scale, *in_shift;
-    int in_relu;
-    // the same for the residual operand (columns of the output)
-    const float *res_scale, *res_shift;
-    int res_relu;
-    // BatchNorm of the OUTPUT finished by the last workgroup to arrive (needs bn_partial):
-    // scale = gamma / sqrt(var + eps), shift = beta - mean * scale  -> bn_scale_out / bn_shift_out [Cout]
-    float *bn_scale_out, *bn_shift_out;
-    const float *bn_gamma, *bn_beta;
-    float bn_eps;
-    unsigned int *bn_ticket;  // workspace of the in-kernel finalize (counters zero on entry and on exit + group rows)
-    int bn_rows;              // rows of bn_partial this launch writes (set by the dispatcher)
-    // LayerNorm over the Cout channels of every output row, after bias / ReLU / residual (needs all
-    // columns in one workgroup): out = [relu]( LN(v) * ln_gamma + ln_beta )
-    int ln;
-    const float *ln_gamma, *ln_beta;
-    float ln_eps;
-    int ln_post_relu;
-    // dense 2D 'same' 3x3 convolution over [maps][img_h][img_w] pixel rows (K == 9): lets narrow layers run
-    // on conv2d_tile_kernel, which needs no kernel map
-    int img_h, img_w, img_maps;
-    // the caller sizes bn_partial with eprecon_conv_desc_partial_rows (descriptor entry point), so kernels whose
-    // workgroups do not cover 128 rows may be chosen
-    int flex_partial;
-    // dense-grid form of the 3x3x3 stride-1 convolution (conv3d_tile_kernel): vox_rank int32[gx][gy][gz] (z fastest) holds
-    // the row of the voxel in a grid cell or -1; wq = the weights in MFMA operand order (pack_weights_kernel)
-    const int32_t *vox_rank;
-    int gx, gy, gz;
-    const float *wq;    // ... for the 32-row tile kernel (pack_weights_kernel)
-    const float *wq16;  // ... for the 16-row tile kernel (pack_weights16_kernel)
-    int debug;  // EPRECON_D3_ABLATE (timing experiments only): 1 no MFMA loop, 4 no halo row loads
-    int splitk_pipe;  // split-K kernel: software-pipelined stages (EPRECON_CONV_SPLITK_PIPE=0: one stage at a time)
-};
 
 // Stage `rows` x TN weights (zero padded) from w[row0 + r][0:ncols] (row stride `stride`, rows valid
 // while row0 + r < row_end) into LDS.  Branch-free: addresses are clamped into the valid range and
@@ -133,24 +88,8 @@ __device__ __forceinline__ void stage_weights(float *dst, const float *w, int ro
 }
 
 constexpr int kRowsPerWave = 32;
-constexpr int kWaves = 4;
 constexpr int kRowsPerBlock = kRowsPerWave * kWaves;
 constexpr int kSlabC = 32;  // input channels per staged weight slab
-
-// Chan et al. merge of two (count, mean, M2) summaries; the caller fixes the order
-__device__ __forceinline__ void chan_merge(float &n_a, float &mean_a, float &m2_a, float n_b, float mean_b, float m2_b)
-{
-    if (n_b == 0.0f) return;
-    if (n_a == 0.0f) {
-        n_a = n_b; mean_a = mean_b; m2_a = m2_b;
-        return;
-    }
-    const float n = n_a + n_b;
-    const float d = mean_b - mean_a;
-    mean_a = mean_a + d * (n_b / n);
-    m2_a = m2_a + m2_b + d * d * (n_a * n_b / n);
-    n_a = n;
-}
 
 // Second half of the fused BatchNorm, inside the convolution launch (no bn_finalize launch, no host round trip).
 // Visibility between workgroups without fences (MI355X guide, "publish-large": a release fence makes the XCD's L2 write
@@ -591,7 +530,6 @@ __device__ __forceinline__ void fix_rows(const ConvParams &p, int j, int half, A
 // instruction immediates and the slab offset is the scalar offset, and a missing neighbour (j < 0) is sent past the end
 // of the buffer, where the hardware returns zeros — no 64-bit address arithmetic and no per-value select afterwards.
 // (PMC, 27-offset 32 -> 32 layer: 11 VALU instructions per MFMA with pointer gathers + fix_rows.)
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <int NCH>
 __device__ __forceinline__ void gather_rows_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned row_bytes, unsigned oob, int j, int half,
                                                 ARows &a, int cbase_bytes)
@@ -1374,7 +1312,6 @@ __global__ __launch_bounds__(256) void conv3d_tile_narrow_kernel(ConvParams p, i
 // Own epilogue for this accumulator layout: bias, ReLU, residual (with its pending BatchNorm), row-wise LayerNorm
 // (16-lane xor-shuffles), BatchNorm summaries (fixed-order Chan merges: lane groups, then waves).
 // ---------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kD16X = 2;                                     // tile x extent; y, z as the other tile kernels
 constexpr int kD16Halo = (kD16X + 2) * kD3HY * kD3HZ;        // 240
 
@@ -1453,7 +1390,7 @@ __global__ __launch_bounds__(256, 7) void conv3d_tile16_kernel(ConvParams p, int
 #pragma unroll
             for (int t = 0; t < CT; ++t) {
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + (unsigned)t * 1024u,
-                                                                      (unsigned)k * kOffBytes + (unsigned)pass * kStepBytes, 0);
+                                                                      (unsigned)((p.debug & 2) ? 0 : k) * kOffBytes + (unsigned)pass * kStepBytes, 0);
                 dst[t] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
             }
         };
@@ -1754,323 +1691,6 @@ int launch_conv3d(const ConvParams &p, bool narrow, hipStream_t st)
     int nt, ncb;
     d3_columns(p.Cout, &nt, &ncb);
     return nt == 1 ? launch_conv3d_nt<1>(p, st) : launch_conv3d_nt<2>(p, st);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Direct gather form on v_mfma_f32_16x16x4_f32 for long lists (3x3x3 kernel maps, C_out <= 64): NO operand goes through
-// LDS and there is no barrier in the loop, so the waves of a CU drift apart instead of staging, gathering and multiplying in
-// lockstep (the phases of the LDS-resident kernel add up).
-//   A operand (lane l: row l & 15, k index q = l >> 4): one 16-byte buffer gather x[nbr[k][row]][16 kc + 4 q .. + 3] per
-//     (offset, 16-channel chunk) feeds four MFMAs; a missing neighbour is sent past the end of the buffer (zeros).
-//   B operand: the weights pre-packed by pack_weights16_kernel in operand order (wq16), one coalesced 1 KB buffer load per
-//     (offset, chunk, 16-column tile), served by L1 / L2 — every wave of the launch walks the same sequence.
-//   A wave owns RT x 16 rows and all CT column tiles (RT x CT accumulators of 4 VGPRs); loads run G chunks ahead of the MFMAs
-//   (double-buffered stages of G chunks, unconditional, so the waits are `vmcnt(<loads of one stage>)`).
-// Own epilogue for the 16x16 accumulator layout (column l & 15, rows 4 (l >> 4) + reg): bias, ReLU, residual with its pending
-// BatchNorm, row-wise LayerNorm, BatchNorm summaries per 64 RT-row workgroup.  Summation order differs from the 32x32x2
-// kernels: equal within fp32 round-off, not bit for bit.
-// ---------------------------------------------------------------------------------------------
-template <int CT, int RT, int G>
-__global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p, int kch)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int ROWS = 64 * RT;
-    constexpr int NR = 4 * RT;
-    int *sNbr = reinterpret_cast<int *>(smem);                        // [K][ROWS]
-    float *sStat = reinterpret_cast<float *>(sNbr + p.K * ROWS);      // [4 waves][3][16 CT]
-    const int cpad = 16 * kch;
-    float *sAff = sStat + kWaves * 3 * 16 * CT;                       // [2][cpad]
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int l16 = lane & 15, q = lane >> 4;
-    const int row0 = (int)blockIdx.x * ROWS;
-
-    for (int e = tid; e < p.K * ROWS; e += 256) {
-        const int k = e / ROWS, r = e - k * ROWS;
-        const int row = row0 + r;
-        int j = -1;
-        if (row < p.n_out) j = p.nbr ? p.nbr[(size_t)k * p.n_out + row] : row;
-        sNbr[e] = j;
-    }
-    if (p.in_scale)
-        for (int c = tid; c < cpad; c += 256) {
-            sAff[c] = c < p.Cin ? p.in_scale[c] : 0.0f;
-            sAff[cpad + c] = c < p.Cin ? p.in_shift[c] : 0.0f;
-        }
-    __syncthreads();
-
-    f32x4 acc[RT][CT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int t = 0; t < CT; ++t) acc[rt][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
-    const unsigned row_bytes = (unsigned)p.ld_x * 4u, oob = (unsigned)p.x_bytes;
-    const int S = p.K * kch;                       // (offset, chunk) steps
-    const unsigned step_bytes = (unsigned)CT * 1024u;
-    const __amdgpu_buffer_rsrc_t wrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wq16), 0, (int)((unsigned)S * step_bytes), 0x00020000);
-    const unsigned wlane = (unsigned)lane * 16u;
-    const int *myNbr = sNbr + wave * 16 * RT + l16;
-    const unsigned cq = 16u * (unsigned)q;         // byte offset of this lane's four channels inside a chunk
-    // a last chunk of <= 8 channels (C_in = 8, 24, 40): lane group q takes channels 2 q, 2 q + 1 and the chunk is two MFMAs
-    const bool tail8 = p.Cin - 16 * (kch - 1) <= 8;
-
-    struct Stage {
-        float4 a[G][RT];
-        float4 b[G][CT];
-        unsigned live;      // bit (i * RT + rt): the neighbour of step i, row tile rt exists (only read with in_scale)
-    };
-    // steps s0 .. s0 + G - 1, clamped to the last one (a clamped step is fetched and not used)
-    auto fetch = [&](int s0, Stage &g) {
-        g.live = 0u;
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int s = min(s0 + i, S - 1);
-            const int k = s / kch, kc = s - k * kch;
-            const bool t8 = tail8 && kc == kch - 1;                         // (uniform)
-            const unsigned cbytes = 64u * (unsigned)kc + (t8 ? cq >> 1 : cq);
-            const bool cok = 16 * kc + (t8 ? 2 : 4) * q < p.Cin;
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const int j = myNbr[k * ROWS + 16 * rt];
-                const bool ok = j >= 0 && cok;
-                const unsigned off = ok ? __umul24((unsigned)j, row_bytes) + cbytes : oob;
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
-                g.a[i][rt] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-                g.live |= (ok ? 1u : 0u) << (i * RT + rt);
-            }
-#pragma unroll
-            for (int t = 0; t < CT; ++t) {
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + (unsigned)t * 1024u, (unsigned)s * step_bytes, 0);
-                g.b[i][t] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-            }
-        }
-    };
-    auto consume = [&](int s0, const Stage &g) {
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-            if (s0 + i < S) {      // (uniform)
-                float4 av[RT];
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) av[rt] = g.a[i][rt];
-                const int kc = (s0 + i) % kch;
-                const bool t8 = tail8 && kc == kch - 1;      // (uniform) .z / .w of the gathered values are not used
-                if (p.Cin & 3) {   // (uniform) ragged channel count on a padded pitch: whatever sits in the pad lanes stays out
-                    const int c = 16 * kc + (t8 ? 2 : 4) * q;
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) {
-                        if (c + 1 >= p.Cin) av[rt].y = 0.0f;
-                        if (c + 2 >= p.Cin) av[rt].z = 0.0f;
-                        if (c + 3 >= p.Cin) av[rt].w = 0.0f;
-                    }
-                }
-                if (p.in_scale) {  // (uniform) the producer's pending BatchNorm (+ ReLU) on the gathered values
-                    const int ca = 16 * kc + (t8 ? 2 : 4) * q;   // (8-byte aligned in the tail form: read as scalars)
-                    const float4 sc = make_float4(sAff[ca], sAff[ca + 1], sAff[ca + 2], sAff[ca + 3]);
-                    const float4 sh = make_float4(sAff[cpad + ca], sAff[cpad + ca + 1], sAff[cpad + ca + 2], sAff[cpad + ca + 3]);
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) {
-                        const bool ok = (g.live >> (i * RT + rt)) & 1u;
-                        float4 x = av[rt];
-                        x.x = fmaf(x.x, sc.x, sh.x); x.y = fmaf(x.y, sc.y, sh.y); x.z = fmaf(x.z, sc.z, sh.z); x.w = fmaf(x.w, sc.w, sh.w);
-                        if (p.in_relu) { x.x = fmaxf(x.x, 0.0f); x.y = fmaxf(x.y, 0.0f); x.z = fmaxf(x.z, 0.0f); x.w = fmaxf(x.w, 0.0f); }
-                        av[rt] = ok ? x : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    }
-                }
-                // independent accumulators alternate: a 16x16x4 MFMA issues every 32 cycles and returns after 40
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                    for (int t = 0; t < CT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].x, g.b[i][t].x, acc[rt][t], 0, 0, 0);
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                    for (int t = 0; t < CT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].y, g.b[i][t].y, acc[rt][t], 0, 0, 0);
-                if (!t8) {
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                        for (int t = 0; t < CT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].z, g.b[i][t].z, acc[rt][t], 0, 0, 0);
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                        for (int t = 0; t < CT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].w, g.b[i][t].w, acc[rt][t], 0, 0, 0);
-                }
-            }
-        }
-    };
-    if (!(p.debug & 1)) {
-        Stage s_a, s_b;
-        fetch(0, s_a);
-        for (int s0 = 0; s0 < S; s0 += 2 * G) {
-            fetch(s0 + G, s_b);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(s0, s_a);
-            __builtin_amdgcn_sched_barrier(0);
-            fetch(s0 + 2 * G, s_a);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(s0 + G, s_b);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-
-    // ---- epilogue: this lane holds rows orow[4 rt + j] x columns 16 t + l16 ----
-    int orow[NR];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = row0 + wave * 16 * RT + 16 * rt + 4 * q + j;
-            orow[4 * rt + j] = row < p.n_out ? row : -1;
-        }
-    float v[CT][NR];
-    bool colok[CT];
-#pragma unroll
-    for (int t = 0; t < CT; ++t) {
-        const int col = 16 * t + l16;
-        colok[t] = col < p.Cout;
-        const float b = (p.bias && colok[t]) ? p.bias[col] : 0.0f;
-        const float rs = (p.res_scale && colok[t]) ? p.res_scale[col] : 1.0f;
-        const float rb = (p.res_scale && colok[t]) ? p.res_shift[col] : 0.0f;
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            float val = 0.0f;
-            if (colok[t] && orow[r] >= 0) {
-                val = acc[r >> 2][t][r & 3] + b;
-                if (p.relu) val = fmaxf(val, 0.0f);
-                if (p.res) {
-                    float rv = p.res[(size_t)orow[r] * p.ld_res + col];
-                    if (p.res_scale) {
-                        rv = fmaf(rv, rs, rb);
-                        if (p.res_relu) rv = fmaxf(rv, 0.0f);
-                    }
-                    val += rv;
-                }
-            }
-            v[t][r] = val;
-        }
-    }
-    if (p.ln) {  // (uniform) row-wise LayerNorm over the C_out columns: 16 lanes x CT tiles hold a row
-        const float inv_c = 1.0f / (float)p.Cout;
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            float sum = 0.0f;
-#pragma unroll
-            for (int t = 0; t < CT; ++t) sum += v[t][r];
-#pragma unroll
-            for (int m = 8; m > 0; m >>= 1) sum += __shfl_xor(sum, m);
-            const float mean = sum * inv_c;
-            float sq = 0.0f;
-#pragma unroll
-            for (int t = 0; t < CT; ++t) {
-                const float d = colok[t] ? v[t][r] - mean : 0.0f;
-                v[t][r] = d;
-                sq = fmaf(d, d, sq);
-            }
-#pragma unroll
-            for (int m = 8; m > 0; m >>= 1) sq += __shfl_xor(sq, m);
-            const float inv = 1.0f / sqrtf(sq * inv_c + p.ln_eps);
-#pragma unroll
-            for (int t = 0; t < CT; ++t) {
-                const int col = 16 * t + l16;
-                float y = fmaf(v[t][r] * inv, (p.ln_gamma && colok[t]) ? p.ln_gamma[col] : 1.0f, (p.ln_beta && colok[t]) ? p.ln_beta[col] : 0.0f);
-                if (p.ln_post_relu) y = fmaxf(y, 0.0f);
-                v[t][r] = y;
-            }
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < CT; ++t)
-#pragma unroll
-        for (int r = 0; r < NR; ++r)
-            if (colok[t] && orow[r] >= 0) p.out[(size_t)orow[r] * p.ld_out + 16 * t + l16] = v[t][r];
-    if (p.bn_partial) {  // (uniform) (count, mean, M2) of the stored values per column: rows in the lane, lane groups, waves
-#pragma unroll
-        for (int t = 0; t < CT; ++t) {
-            float n = 0.0f, sum = 0.0f;
-#pragma unroll
-            for (int r = 0; r < NR; ++r)
-                if (orow[r] >= 0) { n += 1.0f; sum += v[t][r]; }
-            float mean = n > 0.0f ? sum / n : 0.0f, m2 = 0.0f;
-#pragma unroll
-            for (int r = 0; r < NR; ++r)
-                if (orow[r] >= 0) { const float d = v[t][r] - mean; m2 = fmaf(d, d, m2); }
-#pragma unroll
-            for (int m = 16; m < 64; m <<= 1) {  // lane groups q in order: the lower group is the left operand
-                const float on = __shfl_xor(n, m), om = __shfl_xor(mean, m), oq = __shfl_xor(m2, m);
-                const bool lower = (lane & m) == 0;
-                float a_n = lower ? n : on, a_mean = lower ? mean : om, a_m2 = lower ? m2 : oq;
-                chan_merge(a_n, a_mean, a_m2, lower ? on : n, lower ? om : mean, lower ? oq : m2);
-                n = a_n; mean = a_mean; m2 = a_m2;
-            }
-            if (q == 0) {
-                float *d = sStat + (wave * 3) * 16 * CT + 16 * t + l16;
-                d[0] = n; d[16 * CT] = mean; d[2 * 16 * CT] = m2;
-            }
-        }
-        __syncthreads();
-        if (tid < 16 * CT && tid < p.Cout) {
-            float a_n = 0.0f, a_mean = 0.0f, a_m2 = 0.0f;
-#pragma unroll
-            for (int w = 0; w < kWaves; ++w)
-                chan_merge(a_n, a_mean, a_m2, sStat[(w * 3) * 16 * CT + tid], sStat[(w * 3 + 1) * 16 * CT + tid], sStat[(w * 3 + 2) * 16 * CT + tid]);
-            float *dst = p.bn_partial + (size_t)blockIdx.x * 3 * p.Cout + tid;
-            dst[0] = a_n; dst[p.Cout] = a_mean; dst[2 * p.Cout] = a_m2;
-        }
-    }
-}
-
-// EPRECON_CONV_DIRECT=0: the LDS-resident kernels for every long list (read per launch: tests flip it)
-bool direct16_ok(const ConvParams &p)
-{
-    const char *e = getenv("EPRECON_CONV_DIRECT");
-    if (e && e[0] == '0') return false;
-    if (p.K != 27 || !p.wq16 || (reinterpret_cast<uintptr_t>(p.wq16) & 15) != 0) return false;
-    if (p.Cout > 64 || p.accumulate || p.bn_scale_out) return false;
-    if (p.ld_x % 4 != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0 || (p.Cin % 4 != 0 && p.ld_x < ((p.Cin + 3) & ~3))) return false;
-    if (p.x_bytes <= 0 || p.x_bytes >= 0x7fffffffll || (int64_t)p.ld_x * 4 >= (1 << 24) || p.x_bytes / ((int64_t)p.ld_x * 4) >= (1 << 24))
-        return false;
-    if (p.in_scale && ((reinterpret_cast<uintptr_t>(p.in_scale) & 15) != 0 || (reinterpret_cast<uintptr_t>(p.in_shift) & 15) != 0))
-        return false;
-    return true;
-}
-
-template <int CT, int RT, int G>
-int launch_direct16_g(const ConvParams &p, hipStream_t st)
-{
-    const int kch = (p.Cin + 15) / 16;
-    constexpr int ROWS = 64 * RT;
-    const size_t lds = (size_t)p.K * ROWS * sizeof(int) + (size_t)kWaves * 3 * 16 * CT * sizeof(float) + (size_t)2 * 16 * kch * sizeof(float);
-    hipLaunchKernelGGL((spconv_direct16_kernel<CT, RT, G>), dim3((unsigned)ceil_div(p.n_out, ROWS)), dim3(256), lds, st, p, kch);
-    EP_LAUNCH_CHECK();
-    return EPRECON_OK;
-}
-// rows per wave = 16 RT: 32, or 64 (half the weight traffic per row) — EPRECON_CONV_DIRECT_RT, read per launch
-int direct16_rt(const ConvParams &p)
-{
-    const char *e = getenv("EPRECON_CONV_DIRECT_RT");
-    const int want = e ? atoi(e) : 2;
-    return (want == 4 && p.Cout <= 32) ? 4 : 2;
-}
-template <int CT>
-int launch_direct16_ct(const ConvParams &p, hipStream_t st)
-{
-    static const int g = getenv("EPRECON_CONV_DIRECT_G") ? atoi(getenv("EPRECON_CONV_DIRECT_G")) : 2;
-    if (CT <= 2 && direct16_rt(p) == 4) return g == 1 ? launch_direct16_g<(CT <= 2 ? CT : 1), 4, 1>(p, st) : launch_direct16_g<(CT <= 2 ? CT : 1), 4, 2>(p, st);
-    if (g == 1) return launch_direct16_g<CT, 2, 1>(p, st);
-    if (g == 3) return launch_direct16_g<CT, 2, 3>(p, st);
-    return launch_direct16_g<CT, 2, 2>(p, st);
-}
-int launch_direct16(const ConvParams &p, hipStream_t st)
-{
-    switch ((p.Cout + 15) / 16) {
-        case 1: return launch_direct16_ct<1>(p, st);
-        case 2: return launch_direct16_ct<2>(p, st);
-        case 3: return launch_direct16_ct<3>(p, st);
-        default: return launch_direct16_ct<4>(p, st);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2543,7 +2163,7 @@ int conv_dispatch_inner(ConvParams &p, int64_t n_in, hipStream_t st)
     if (direct16_ok(p)) {
         g_last_conv_kernel = "spconv_direct16_kernel";
         p.debug = getenv("EPRECON_D3_ABLATE") ? atoi(getenv("EPRECON_D3_ABLATE")) : 0;
-        p.bn_rows = (int)ceil_div(p.n_out, 16 * kWaves * direct16_rt(p));
+        p.bn_rows = (int)ceil_div(p.n_out, kDirectRows);
         return launch_direct16(p, st);
     }
     const bool split = nblk < 256 && nt_full > 1 && !p.ln;
@@ -2724,7 +2344,7 @@ extern "C" int64_t eprecon_conv_desc_partial_rows(const eprecon_conv_desc *d)
     if (conv2d_tile_ok(p, &nt, &nch, &blocks)) return blocks;
     if (splitk_ok(p)) return ep::ceil_div(d->n_out, (int64_t)32);
     p.x_bytes = d->n_in > 0 ? ((d->n_in - 1) * (int64_t)p.ld_x + ((p.Cin + 3) & ~3)) * 4 : 0;
-    if (direct16_ok(p)) return ep::ceil_div(d->n_out, (int64_t)(16 * kWaves * direct16_rt(p)));
+    if (direct16_ok(p)) return ep::ceil_div(d->n_out, (int64_t)kDirectRows);
     return ep::ceil_div(d->n_out, (int64_t)kRowsPerBlock);
 }
 

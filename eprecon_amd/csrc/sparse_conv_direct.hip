@@ -1,0 +1,509 @@
+// Direct gather form of the 3x3x3 sparse convolution on v_mfma_f32_16x16x4_f32 for long lists (C_out <= 64): NO operand goes
+// through LDS and there is no barrier in the loop, so the waves of a CU drift apart instead of staging, gathering and
+// multiplying in lockstep (the phases of the LDS-resident kernel add up).
+//   A operand (lane l: row l & 15, k index q = l >> 4): one 16-byte buffer gather x[nbr[k][row]][16 kc + 4 q .. + 3] per
+//     (offset, 16-channel chunk) feeds four MFMAs; a missing neighbour is sent past the end of the buffer (zeros).
+//   B operand: the weights pre-packed by pack_weights16_kernel in operand order (wq16), one coalesced 1 KB buffer load per
+//     (offset, chunk, 16-column tile), served by L1 / L2 — every wave of the launch walks the same sequence.
+//   A wave owns 2 x 16 rows and all CT column tiles (2 x CT accumulators of 4 VGPRs); the loads of the next stage (1..3
+//   chunks) are in flight while the current one runs its MFMAs, unconditionally, so the waits are `vmcnt(<loads of a stage>)`.
+// Timing ablations (profiles/r03/conv_direct_ablate.txt): with the gathers switched off and every weight load an L1 hit the
+// first version of this kernel lost 8 % of its time — not memory but the instruction stream around the MFMAs (run-time
+// (offset, chunk) arithmetic, masks) kept the matrix pipe at ~70 %: a 16x16x4 MFMA is 32 cycles, eight issue slots.  The
+// chunk count is therefore a template parameter: offsets inside a stage are instruction immediates, one multiply + select
+// per (offset, row tile), nothing else between the MFMAs.
+// Summation order differs from the 32x32x2 kernels: equal within fp32 round-off, not bit for bit.
+#include <stdlib.h>
+
+#include "common.hpp"
+#include "conv_common.hpp"
+
+namespace epconv {
+namespace {
+using namespace ep;
+
+constexpr int kRT = 2;   // 16-row tiles per wave
+
+// Epilogue for the 16x16 accumulator layout (column l & 15, rows 4 (l >> 4) + reg): bias, ReLU, residual with its pending
+// BatchNorm, row-wise LayerNorm (16-lane xor-shuffles), BatchNorm summaries of the 128-row block (fixed-order Chan merges: rows
+// in the lane, lane groups, waves).
+template <int CT>
+__device__ __forceinline__ void direct_epilogue(const ConvParams &p, f32x4 (&acc)[kRT][CT], int row0, float *sStat)
+{
+    constexpr int RT = kRT, NR = 4 * kRT;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, q = lane >> 4;
+    int orow[NR];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = row0 + wave * 16 * RT + 16 * rt + 4 * q + j;
+            orow[4 * rt + j] = row < p.n_out ? row : -1;
+        }
+    float v[CT][NR];
+    bool colok[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int col = 16 * t + l16;
+        colok[t] = col < p.Cout;
+        const float b = (p.bias && colok[t]) ? p.bias[col] : 0.0f;
+        const float rs = (p.res_scale && colok[t]) ? p.res_scale[col] : 1.0f;
+        const float rb = (p.res_scale && colok[t]) ? p.res_shift[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float val = 0.0f;
+            if (colok[t] && orow[r] >= 0) {
+                val = acc[r >> 2][t][r & 3] + b;
+                if (p.relu) val = fmaxf(val, 0.0f);
+                if (p.res) {
+                    float rv = p.res[(size_t)orow[r] * p.ld_res + col];
+                    if (p.res_scale) {
+                        rv = fmaf(rv, rs, rb);
+                        if (p.res_relu) rv = fmaxf(rv, 0.0f);
+                    }
+                    val += rv;
+                }
+            }
+            v[t][r] = val;
+        }
+    }
+    if (p.ln) {  // (uniform) row-wise LayerNorm over the C_out columns: 16 lanes x CT tiles hold a row
+        const float inv_c = 1.0f / (float)p.Cout;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int t = 0; t < CT; ++t) sum += v[t][r];
+#pragma unroll
+            for (int m = 8; m > 0; m >>= 1) sum += __shfl_xor(sum, m);
+            const float mean = sum * inv_c;
+            float sq = 0.0f;
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const float d = colok[t] ? v[t][r] - mean : 0.0f;
+                v[t][r] = d;
+                sq = fmaf(d, d, sq);
+            }
+#pragma unroll
+            for (int m = 8; m > 0; m >>= 1) sq += __shfl_xor(sq, m);
+            const float inv = 1.0f / sqrtf(sq * inv_c + p.ln_eps);
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const int col = 16 * t + l16;
+                float y = fmaf(v[t][r] * inv, (p.ln_gamma && colok[t]) ? p.ln_gamma[col] : 1.0f, (p.ln_beta && colok[t]) ? p.ln_beta[col] : 0.0f);
+                if (p.ln_post_relu) y = fmaxf(y, 0.0f);
+                v[t][r] = y;
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (colok[t] && orow[r] >= 0) p.out[(size_t)orow[r] * p.ld_out + 16 * t + l16] = v[t][r];
+    if (p.bn_partial) {  // (uniform) (count, mean, M2) of the stored values per column: rows in the lane, lane groups, waves
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            float n = 0.0f, sum = 0.0f;
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                if (orow[r] >= 0) { n += 1.0f; sum += v[t][r]; }
+            float mean = n > 0.0f ? sum / n : 0.0f, m2 = 0.0f;
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                if (orow[r] >= 0) { const float d = v[t][r] - mean; m2 = fmaf(d, d, m2); }
+#pragma unroll
+            for (int m = 16; m < 64; m <<= 1) {  // lane groups q in order: the lower group is the left operand
+                const float on = __shfl_xor(n, m), om = __shfl_xor(mean, m), oq = __shfl_xor(m2, m);
+                const bool lower = (lane & m) == 0;
+                float a_n = lower ? n : on, a_mean = lower ? mean : om, a_m2 = lower ? m2 : oq;
+                chan_merge(a_n, a_mean, a_m2, lower ? on : n, lower ? om : mean, lower ? oq : m2);
+                n = a_n; mean = a_mean; m2 = a_m2;
+            }
+            if (q == 0) {
+                float *d = sStat + (wave * 3) * 16 * CT + 16 * t + l16;
+                d[0] = n; d[16 * CT] = mean; d[2 * 16 * CT] = m2;
+            }
+        }
+        __syncthreads();
+        if (tid < 16 * CT && tid < p.Cout) {
+            float a_n = 0.0f, a_mean = 0.0f, a_m2 = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w)
+                chan_merge(a_n, a_mean, a_m2, sStat[(w * 3) * 16 * CT + tid], sStat[(w * 3 + 1) * 16 * CT + tid], sStat[(w * 3 + 2) * 16 * CT + tid]);
+            float *dst = p.bn_partial + (size_t)blockIdx.x * 3 * p.Cout + tid;
+            dst[0] = a_n; dst[p.Cout] = a_mean; dst[2 * p.Cout] = a_m2;
+        }
+    }
+}
+
+// chunks per stage for a layer of KCH chunks: the stages of an offset are KCH / G
+constexpr int stage_chunks(int kch) { return kch % 3 == 0 ? 3 : (kch % 2 == 0 ? 2 : 1); }
+
+template <int CT, int KCH, int G = stage_chunks(KCH)>
+__global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RT = kRT, ROWS = kDirectRows;
+    constexpr int PARTS = KCH / G;
+    constexpr int cpad = 16 * KCH;
+    int *sNbr = reinterpret_cast<int *>(smem);                        // [K][ROWS]
+    float *sStat = reinterpret_cast<float *>(sNbr + p.K * ROWS);      // [4 waves][3][16 CT]
+    float *sAff = sStat + kWaves * 3 * 16 * CT;                       // [2][cpad]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, q = lane >> 4;
+    const int row0 = (int)blockIdx.x * ROWS;
+
+    for (int e = tid; e < p.K * ROWS; e += 256) {
+        const int k = e / ROWS, r = e - k * ROWS;
+        const int row = row0 + r;
+        int j = -1;
+        if (row < p.n_out) j = p.nbr ? p.nbr[(size_t)k * p.n_out + row] : row;
+        sNbr[e] = j;
+    }
+    if (p.in_scale)
+        for (int c = tid; c < cpad; c += 256) {
+            sAff[c] = c < p.Cin ? p.in_scale[c] : 0.0f;
+            sAff[cpad + c] = c < p.Cin ? p.in_shift[c] : 0.0f;
+        }
+    __syncthreads();
+
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[rt][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const unsigned row_bytes = (unsigned)p.ld_x * 4u, oob = (unsigned)p.x_bytes;
+    const int U = p.K * PARTS;                      // stages
+    constexpr unsigned kChunkBytes = (unsigned)CT * 1024u;
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wq16), 0, (int)((unsigned)p.K * KCH * kChunkBytes), 0x00020000);
+    const unsigned wlane = (unsigned)lane * 16u;
+    const int *myNbr = sNbr + wave * 16 * RT + l16;
+    // a last chunk of <= 8 channels (C_in = 8, 24, 40): lane group q takes channels 2 q, 2 q + 1 and the chunk is two MFMAs
+    const int last_c = p.Cin - 16 * (KCH - 1);      // channels of the last chunk
+    const bool tail8 = last_c <= 8;
+    const unsigned cq = 16u * (unsigned)q;
+    const unsigned cq_last = tail8 ? 8u * (unsigned)q : cq;
+    const bool last_ok = (tail8 ? 2 : 4) * q < last_c;
+
+    struct Stage {
+        float4 a[G][RT];
+        float4 b[G][CT];
+    };
+    // stage u = (offset k = u / PARTS, chunks kc0 .. kc0 + G - 1 with kc0 = (u % PARTS) * G)
+    auto fetch = [&](int u, Stage &g) {
+        const int k = PARTS == 1 ? u : u / PARTS;
+        const int part = PARTS == 1 ? 0 : u - k * PARTS;
+        const unsigned xs = 64u * (unsigned)(part * G);                 // (scalar) byte offset of the stage's first chunk
+        const unsigned ws = (unsigned)(k * KCH + part * G) * kChunkBytes;
+        const bool has_last = part == PARTS - 1;                         // (uniform) the stage holds the layer's last chunk
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int j = myNbr[k * ROWS + 16 * rt];
+            const unsigned rowsel = j >= 0 ? __umul24((unsigned)j, row_bytes) : oob;
+            const unsigned v0 = rowsel + cq;
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                unsigned off = v0 + 64u * i;
+                if (i == G - 1 && has_last) off = last_ok ? rowsel + cq_last + 64u * i : oob;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, xs, 0);
+                g.a[i][rt] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + (unsigned)t * 1024u, ws + (unsigned)i * kChunkBytes, 0);
+                g.b[i][t] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            }
+    };
+    auto consume = [&](int u, const Stage &g) {
+        const int k = PARTS == 1 ? u : u / PARTS;
+        const int part = PARTS == 1 ? 0 : u - k * PARTS;
+        const bool has_last = part == PARTS - 1;
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const bool t8 = tail8 && i == G - 1 && has_last;          // (uniform) .z / .w of the gathered values are not used
+            float4 av[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) av[rt] = g.a[i][rt];
+            if ((p.Cin & 3) && i == G - 1 && has_last) {   // (uniform) ragged channel count on a padded pitch: the pad lanes stay out
+                const int c = 16 * (KCH - 1) + (t8 ? 2 : 4) * q;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    if (c + 1 >= p.Cin) av[rt].y = 0.0f;
+                    if (c + 2 >= p.Cin) av[rt].z = 0.0f;
+                    if (c + 3 >= p.Cin) av[rt].w = 0.0f;
+                }
+            }
+            if (p.in_scale) {  // (uniform) the producer's pending BatchNorm (+ ReLU) on the gathered values
+                const int kc = part * G + i;
+                const int ca = 16 * kc + (t8 ? 2 : 4) * q;
+                const float4 sc = make_float4(sAff[ca], sAff[ca + 1], sAff[ca + 2], sAff[ca + 3]);
+                const float4 sh = make_float4(sAff[cpad + ca], sAff[cpad + ca + 1], sAff[cpad + ca + 2], sAff[cpad + ca + 3]);
+                const bool cok = (i == G - 1 && has_last) ? last_ok : true;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const bool ok = myNbr[k * ROWS + 16 * rt] >= 0 && cok;
+                    float4 x = av[rt];
+                    x.x = fmaf(x.x, sc.x, sh.x); x.y = fmaf(x.y, sc.y, sh.y); x.z = fmaf(x.z, sc.z, sh.z); x.w = fmaf(x.w, sc.w, sh.w);
+                    if (p.in_relu) { x.x = fmaxf(x.x, 0.0f); x.y = fmaxf(x.y, 0.0f); x.z = fmaxf(x.z, 0.0f); x.w = fmaxf(x.w, 0.0f); }
+                    if (p.Cin & 3) {
+                        const int c = ca;
+                        if (c + 1 >= p.Cin) x.y = 0.0f;
+                        if (c + 2 >= p.Cin) x.z = 0.0f;
+                        if (c + 3 >= p.Cin) x.w = 0.0f;
+                    }
+                    av[rt] = ok ? x : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+            }
+            // independent accumulators alternate: a 16x16x4 MFMA issues every 32 cycles and returns after 40
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < CT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].x, g.b[i][t].x, acc[rt][t], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < CT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].y, g.b[i][t].y, acc[rt][t], 0, 0, 0);
+            if (!t8) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].z, g.b[i][t].z, acc[rt][t], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].w, g.b[i][t].w, acc[rt][t], 0, 0, 0);
+            }
+        }
+    };
+    if (!(p.debug & 1)) {
+        Stage s_a, s_b;
+        fetch(0, s_a);
+        for (int u = 0; u < U; u += 2) {
+            fetch(min(u + 1, U - 1), s_b);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(u, s_a);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(min(u + 2, U - 1), s_a);
+            __builtin_amdgcn_sched_barrier(0);
+            if (u + 1 < U) consume(u + 1, s_b);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    direct_epilogue<CT>(p, acc, row0, sStat);
+}
+
+// Any chunk count (C_in > 96): the (offset, chunk) sequence is walked with run-time indices, two chunks per stage.
+template <int CT>
+__global__ __launch_bounds__(256) void spconv_direct16_generic_kernel(ConvParams p, int kch)
+{
+    constexpr int RT = kRT, G = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWS = 64 * RT;
+    constexpr int NR = 4 * RT;
+    int *sNbr = reinterpret_cast<int *>(smem);                        // [K][ROWS]
+    float *sStat = reinterpret_cast<float *>(sNbr + p.K * ROWS);      // [4 waves][3][16 CT]
+    const int cpad = 16 * kch;
+    float *sAff = sStat + kWaves * 3 * 16 * CT;                       // [2][cpad]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, q = lane >> 4;
+    const int row0 = (int)blockIdx.x * ROWS;
+
+    for (int e = tid; e < p.K * ROWS; e += 256) {
+        const int k = e / ROWS, r = e - k * ROWS;
+        const int row = row0 + r;
+        int j = -1;
+        if (row < p.n_out) j = p.nbr ? p.nbr[(size_t)k * p.n_out + row] : row;
+        sNbr[e] = j;
+    }
+    if (p.in_scale)
+        for (int c = tid; c < cpad; c += 256) {
+            sAff[c] = c < p.Cin ? p.in_scale[c] : 0.0f;
+            sAff[cpad + c] = c < p.Cin ? p.in_shift[c] : 0.0f;
+        }
+    __syncthreads();
+
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[rt][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const unsigned row_bytes = (unsigned)p.ld_x * 4u, oob = (unsigned)p.x_bytes;
+    const int S = p.K * kch;                       // (offset, chunk) steps
+    const unsigned step_bytes = (unsigned)CT * 1024u;
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wq16), 0, (int)((unsigned)S * step_bytes), 0x00020000);
+    const unsigned wlane = (unsigned)lane * 16u;
+    const int *myNbr = sNbr + wave * 16 * RT + l16;
+    const unsigned cq = 16u * (unsigned)q;         // byte offset of this lane's four channels inside a chunk
+    // a last chunk of <= 8 channels (C_in = 8, 24, 40): lane group q takes channels 2 q, 2 q + 1 and the chunk is two MFMAs
+    const bool tail8 = p.Cin - 16 * (kch - 1) <= 8;
+
+    struct Stage {
+        float4 a[G][RT];
+        float4 b[G][CT];
+        unsigned live;      // bit (i * RT + rt): the neighbour of step i, row tile rt exists (only read with in_scale)
+    };
+    // steps s0 .. s0 + G - 1, clamped to the last one (a clamped step is fetched and not used)
+    auto fetch = [&](int s0, Stage &g) {
+        g.live = 0u;
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int s = min(s0 + i, S - 1);
+            const int k = s / kch, kc = s - k * kch;
+            const bool t8 = tail8 && kc == kch - 1;                         // (uniform)
+            const unsigned cbytes = 64u * (unsigned)kc + (t8 ? cq >> 1 : cq);
+            const bool cok = 16 * kc + (t8 ? 2 : 4) * q < p.Cin;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int j = myNbr[k * ROWS + 16 * rt];
+                const bool ok = j >= 0 && cok;
+                const unsigned off = ok ? __umul24((unsigned)j, row_bytes) + cbytes : oob;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
+                g.a[i][rt] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                g.live |= (ok ? 1u : 0u) << (i * RT + rt);
+            }
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + (unsigned)t * 1024u, (unsigned)s * step_bytes, 0);
+                g.b[i][t] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            }
+        }
+    };
+    auto consume = [&](int s0, const Stage &g) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            if (s0 + i < S) {      // (uniform)
+                float4 av[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) av[rt] = g.a[i][rt];
+                const int kc = (s0 + i) % kch;
+                const bool t8 = tail8 && kc == kch - 1;      // (uniform) .z / .w of the gathered values are not used
+                if (p.Cin & 3) {   // (uniform) ragged channel count on a padded pitch: whatever sits in the pad lanes stays out
+                    const int c = 16 * kc + (t8 ? 2 : 4) * q;
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        if (c + 1 >= p.Cin) av[rt].y = 0.0f;
+                        if (c + 2 >= p.Cin) av[rt].z = 0.0f;
+                        if (c + 3 >= p.Cin) av[rt].w = 0.0f;
+                    }
+                }
+                if (p.in_scale) {  // (uniform) the producer's pending BatchNorm (+ ReLU) on the gathered values
+                    const int ca = 16 * kc + (t8 ? 2 : 4) * q;   // (8-byte aligned in the tail form: read as scalars)
+                    const float4 sc = make_float4(sAff[ca], sAff[ca + 1], sAff[ca + 2], sAff[ca + 3]);
+                    const float4 sh = make_float4(sAff[cpad + ca], sAff[cpad + ca + 1], sAff[cpad + ca + 2], sAff[cpad + ca + 3]);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const bool ok = (g.live >> (i * RT + rt)) & 1u;
+                        float4 x = av[rt];
+                        x.x = fmaf(x.x, sc.x, sh.x); x.y = fmaf(x.y, sc.y, sh.y); x.z = fmaf(x.z, sc.z, sh.z); x.w = fmaf(x.w, sc.w, sh.w);
+                        if (p.in_relu) { x.x = fmaxf(x.x, 0.0f); x.y = fmaxf(x.y, 0.0f); x.z = fmaxf(x.z, 0.0f); x.w = fmaxf(x.w, 0.0f); }
+                        av[rt] = ok ? x : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    }
+                }
+                // independent accumulators alternate: a 16x16x4 MFMA issues every 32 cycles and returns after 40
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].x, g.b[i][t].x, acc[rt][t], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].y, g.b[i][t].y, acc[rt][t], 0, 0, 0);
+                if (!t8) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int t = 0; t < CT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].z, g.b[i][t].z, acc[rt][t], 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int t = 0; t < CT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].w, g.b[i][t].w, acc[rt][t], 0, 0, 0);
+                }
+            }
+        }
+    };
+    if (!(p.debug & 1)) {
+        Stage s_a, s_b;
+        fetch(0, s_a);
+        for (int s0 = 0; s0 < S; s0 += 2 * G) {
+            fetch(s0 + G, s_b);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(s0, s_a);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(s0 + 2 * G, s_a);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(s0 + G, s_b);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    direct_epilogue<CT>(p, acc, row0, sStat);
+}
+
+template <int CT, int KCH>
+int launch_k(const ConvParams &p, hipStream_t st)
+{
+    const size_t lds = (size_t)p.K * kDirectRows * sizeof(int) + (size_t)kWaves * 3 * 16 * CT * sizeof(float) + (size_t)2 * 16 * KCH * sizeof(float);
+    // (one chunk per stage — 80 registers, six waves per SIMD instead of three — measured no faster: 266 vs 250 us on 48 -> 24)
+    hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH>), dim3((unsigned)ceil_div(p.n_out, kDirectRows)), dim3(256), lds, st, p);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+template <int CT>
+int launch_ct(const ConvParams &p, hipStream_t st)
+{
+    const int kch = (p.Cin + 15) / 16;
+    switch (kch) {
+        case 1: return launch_k<CT, 1>(p, st);
+        case 2: return launch_k<CT, 2>(p, st);
+        case 3: return launch_k<CT, 3>(p, st);
+        case 4: return launch_k<CT, 4>(p, st);
+        case 5: return launch_k<CT, 5>(p, st);
+        case 6: return launch_k<CT, 6>(p, st);
+        default: break;
+    }
+    const size_t lds = (size_t)p.K * kDirectRows * sizeof(int) + (size_t)kWaves * 3 * 16 * CT * sizeof(float) + (size_t)2 * 16 * kch * sizeof(float);
+    hipLaunchKernelGGL((spconv_direct16_generic_kernel<CT>), dim3((unsigned)ceil_div(p.n_out, kDirectRows)), dim3(256), lds, st, p, kch);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+}  // namespace
+
+// EPRECON_CONV_DIRECT=0: the LDS-resident kernels for every long list (read per launch: tests flip it)
+bool direct16_ok(const ConvParams &p)
+{
+    const char *e = getenv("EPRECON_CONV_DIRECT");
+    if (e && e[0] == '0') return false;
+    if (p.K != 27 || !p.wq16 || (reinterpret_cast<uintptr_t>(p.wq16) & 15) != 0) return false;
+    if (p.Cout > 64 || p.accumulate || p.bn_scale_out) return false;
+    if (p.ld_x % 4 != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0 || (p.Cin % 4 != 0 && p.ld_x < ((p.Cin + 3) & ~3))) return false;
+    if (p.x_bytes <= 0 || p.x_bytes >= 0x7fffffffll || (int64_t)p.ld_x * 4 >= (1 << 24) || p.x_bytes / ((int64_t)p.ld_x * 4) >= (1 << 24))
+        return false;
+    return true;
+}
+
+int launch_direct16(const ConvParams &p, hipStream_t st)
+{
+    switch ((p.Cout + 15) / 16) {
+        case 1: return launch_ct<1>(p, st);
+        case 2: return launch_ct<2>(p, st);
+        case 3: return launch_ct<3>(p, st);
+        default: return launch_ct<4>(p, st);
+    }
+}
+
+}  // namespace epconv

@@ -1,6 +1,10 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r03_shapes
+rm -rf $O; mkdir -p $O
 cd $R
-for v in "EPRECON_CFG4_PIPELINE=0" "EPRECON_CFG4_PIPELINE=0 EPRECON_CONV_DIRECT=0" "EPRECON_CFG4_PIPELINE=0 EPRECON_CONV_DIRECT=0 EPRECON_CONV_SPLITK_PIPE=0 EPRECON_CONV_SPLITK_NARROW=0 EPRECON_CONV_SPLITK_WAVES=4" "EPRECON_PIPELINE_THREAD=0" "EPRECON_PIPELINE_THREAD=0 EPRECON_CONV_DIRECT=0" "A=1" "A=2"; do
-  env $v timeout 300 python bench.py --workload cfg4 --steps 16 --warmup 4 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('cfg4 $v', round(d['ms_per_step'],2))"
-done
+run() { tag=$1; shift; env "$@" timeout 300 python tools/conv_shapes_ab.py $tag > $O/$tag.txt 2>&1; tail -1 $O/$tag.txt; }
+run lean A=1
+run g1 EPRECON_CONV_DIRECT_G1=1
+paste -d'|' <(cut -c1-62 $O/lean.txt) <(cut -c52-62 $O/g1.txt) > $O/table.txt
+grep -v "SPVCNN0\|s0" $O/table.txt

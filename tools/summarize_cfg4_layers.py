@@ -70,4 +70,4 @@ for r in trace[a + 1:b]:
         n, K, ci, co = map(int, l[:4])
         gf = 2.0 * n * K * ci * co / 1e9
         print(f"{(stack[-1] if stack else '-'):16s} {n:7d} {K:2d} {ci:4d} {co:4d}  {l[4]:30s} {' '.join(l[5:]):22s} {dur(r):7.1f} us  "
-              f"({gf / dur(r) * 1e3 / 1e3:5.1f} TF dense-equivalent)")
+              f"({gf / dur(r) * 1e3:5.1f} TF dense-equivalent)")
