@@ -2126,7 +2126,9 @@ int conv_dispatch_inner(ConvParams &p, int64_t n_in, hipStream_t st)
         }
         if (!p.nbr && p.K != 1) return EPRECON_ERR_ARG;  // dense-grid form requested for a shape it does not take, no map given
     }
-    {
+    // dense 2D 3x3 layers whose caller packed the weights for it: the direct gather kernel on the pixel map
+    const bool direct2d = p.K == 9 && direct16_ok(p);
+    if (!direct2d) {
         int nt, nch;
         int64_t blocks;
         if (conv2d_tile_ok(p, &nt, &nch, &blocks)) {
@@ -2155,7 +2157,7 @@ int conv_dispatch_inner(ConvParams &p, int64_t n_in, hipStream_t st)
     const int nt_full = (p.Cout + 31) / 32;
     if (p.ln && (nt_full > 4 || p.bn_partial || p.accumulate)) return EPRECON_ERR_UNSUPPORTED;
     p.bn_rows = (int)ceil_div(p.n_out, kRowsPerBlock);  // the gather forms: 128-row blocks (split-K: 32-row blocks)
-    if (splitk_ok(p)) {
+    if (!direct2d && splitk_ok(p)) {
         g_last_conv_kernel = "spconv_splitk_kernel";
         p.bn_rows = (int)ceil_div(p.n_out, 32);
         return vec4 ? launch_splitk_v<true>(p, st) : launch_splitk_v<false>(p, st);
@@ -2341,9 +2343,10 @@ extern "C" int64_t eprecon_conv_desc_partial_rows(const eprecon_conv_desc *d)
     int nt, nch;
     int64_t blocks;
     if (const int kind = conv3d_kind(p)) return d3_tiles_kind(p, kind);
+    p.x_bytes = d->n_in > 0 ? ((d->n_in - 1) * (int64_t)p.ld_x + ((p.Cin + 3) & ~3)) * 4 : 0;
+    if (p.K == 9 && direct16_ok(p)) return ep::ceil_div(d->n_out, (int64_t)kDirectRows);
     if (conv2d_tile_ok(p, &nt, &nch, &blocks)) return blocks;
     if (splitk_ok(p)) return ep::ceil_div(d->n_out, (int64_t)32);
-    p.x_bytes = d->n_in > 0 ? ((d->n_in - 1) * (int64_t)p.ld_x + ((p.Cin + 3) & ~3)) * 4 : 0;
     if (direct16_ok(p)) return ep::ceil_div(d->n_out, (int64_t)kDirectRows);
     return ep::ceil_div(d->n_out, (int64_t)kRowsPerBlock);
 }

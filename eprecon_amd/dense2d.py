@@ -83,6 +83,11 @@ from .sparse import FUSED_FINALIZE_MAX_C, finalize_workspace  # noqa: E402
 # branch, while the in-kernel form adds a store drain + an atomic round trip to EVERY workgroup's tail: measured 2.04 vs
 # 1.95 ms per cfg2 step (profiles/r03/bn_ticket_ab.txt).  Off here by default; EPRECON_BN_TICKET_2D=1 turns it on.
 _FUSED_FINALIZE = os.environ.get("EPRECON_BN_TICKET_2D", "0") == "1"
+# 3x3 layers on long pixel lists through the direct gather kernel (csrc/sparse_conv_direct.hip) on the pixel map instead of the
+# image-tile kernel: rocprofv3 durations on the 9 x 120 x 160 level 24->12 36.6 -> 23.4 us, 12->12 28.6 -> 17.6, 24->24 38.2 ->
+# 36.8; on 9 x 60 x 80 it is a wash (40->40 33.7 -> 28.7, 32->32 17.5 -> 18.4), hence the row threshold.
+DIRECT_2D = os.environ.get("EPRECON_CONV_DIRECT_2D", "1") == "1"
+DIRECT_2D_MIN_ROWS = int(os.environ.get("EPRECON_CONV_DIRECT_2D_MIN_ROWS", "100000"))
 MERGE_ELAN_1X1 = os.environ.get("EPRECON_ELAN_MERGE", "0") == "1"  # measured neutral on MI355X
 
 
@@ -155,6 +160,9 @@ def conv_bn_launch(w, bias, gamma, beta, eps, k, x, grid, out=None, aff=None, re
     d.in_scale, d.in_shift, d.in_relu = _dptr(x.scale), _dptr(x.shift), int(x.relu)
     if k == 3:
         d.img_h, d.img_w, d.img_maps = grid.height, grid.width, grid.maps  # narrow layers: image-tile kernel
+        if DIRECT_2D and cout <= SP.DIRECT_MAX_COUT and n >= DIRECT_2D_MIN_ROWS:
+            pw = SP.packed_weight16(w)               # long pixel lists: the direct gather kernel on the pixel map
+            d.packed_weight16 = pw.data_ptr()
     # the summaries are per workgroup: 128-row blocks (gather forms) or image tiles (tile kernel)
     partial = torch.empty((lib.eprecon_conv_desc_partial_rows(ctypes.byref(d)), 3, cout), dtype=torch.float32, device=dev)
     d.bn_partial = partial.data_ptr()

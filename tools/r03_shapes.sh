@@ -1,10 +1,11 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r03_shapes
+O=$R/gpurun_out/r03_2d
 rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
 cd $R
-run() { tag=$1; shift; env "$@" timeout 300 python tools/conv_shapes_ab.py $tag > $O/$tag.txt 2>&1; tail -1 $O/$tag.txt; }
-run lean A=1
-run g1 EPRECON_CONV_DIRECT_G1=1
-paste -d'|' <(cut -c1-62 $O/lean.txt) <(cut -c52-62 $O/g1.txt) > $O/table.txt
-grep -v "SPVCNN0\|s0" $O/table.txt
+for v in 0 1; do
+  EPRECON_CONV_DIRECT_2D=$v EPRECON_CONV_DIRECT_2D_MIN_ROWS=10000 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/t$v -o r -- python tools/conv_layers_trace.py > $O/names$v.txt 2>$O/err$v.txt
+  python tools/conv_layers_summary.py $O/t$v/r_kernel_trace.csv $O/names$v.txt > $O/sum$v.txt 2>&1
+done
+paste -d'|' <(cut -c1-120 $O/sum0.txt) <(cut -c24-120 $O/sum1.txt)
