@@ -270,9 +270,13 @@ typedef struct eprecon_conv_desc {
      * form (cout == 1: same sums in another order).  Other shapes fall back to nbr (EPRECON_ERR_ARG when it is NULL). */
     const int32_t *vox_rank; int grid_x; int grid_y; int grid_z;
     const float *packed_weight;
-    /* the same weights in the operand order of the 16-row tile kernel (eprecon_conv_pack_weight16_async), which takes
-     * cout <= 32 with cin a multiple of 16 (EPRECON_CONV_DENSE3D >= 2); results equal the gather form within fp32
-     * round-off (four input channels per MFMA instead of two: another summation order) */
+    /* the same weights in the operand order of the 16x16x4 MFMA kernels (eprecon_conv_pack_weight16_async, cout <= 64):
+     *  - with vox_rank: the 16-row tile kernel, which takes cout <= 32 with cin a multiple of 16 (EPRECON_CONV_DENSE3D >= 2);
+     *  - with nbr (kvol 27, or 9 for a pixel map): the direct gather kernel for lists the short-list rule does not take
+     *    (operands straight from L2 into the MFMAs, no LDS staging; EPRECON_CONV_DIRECT=0 switches it off).  NULL keeps the
+     *    launch on the 32x32x2 kernels.
+     * Results equal those kernels' within fp32 round-off (four input channels per MFMA instead of two: another summation
+     * order); the torchsparse / spconv layers this replaces (models/modules.py:15-72, 178-222) make no ordering promise. */
     const float *packed_weight16;
 } eprecon_conv_desc;
 int eprecon_conv_desc_async(const eprecon_conv_desc *desc, void *stream);
@@ -312,6 +316,7 @@ int eprecon_grid_rank_async(const int32_t *coords, int64_t n, int stride, int gr
 /* weight f32[kvol][cin][cout] -> the operand order of the dense-grid kernel (eprecon_conv_pack_weight_floats floats) */
 size_t eprecon_conv_pack_weight_floats(int kvol, int cin, int cout);
 int eprecon_conv_pack_weight_async(const float *weight, int kvol, int cin, int cout, float *packed, void *stream);
+/* ... -> the operand order of the 16x16x4 MFMA kernels, cout <= 64 (0 floats / EPRECON_ERR_ARG beyond) */
 size_t eprecon_conv_pack_weight16_floats(int kvol, int cin, int cout);
 int eprecon_conv_pack_weight16_async(const float *weight, int kvol, int cin, int cout, float *packed, void *stream);
 
