@@ -54,6 +54,14 @@ class Cfg2Step:
         self.init_net = Occupancy_Initialization(CH_IMG, CH_INIT_DOWN, N_VIEWS).to(dev)
         self.init_net.train()  # the reference tests in train mode (main.py:357)
         self.last = {}
+        # defer_reads: run() queues step k and returns step k - 1's outputs — the host reads of a step's counts (stage-0
+        # selection, valid voxels of the three levels) happen after the NEXT step is queued, so the GPU does not idle at the
+        # step boundary while the host starts issuing; flush() finishes the last step.  Off: run() returns its own outputs.
+        self.defer_reads = False
+        self._inflight = None
+        # the Back_Project levels are queued behind the variance volume, in front of the host's wait for its count
+        # (EPRECON_CFG2_LEVELS_FIRST=1: at the start of the step, round 2's order)
+        self.levels_inside = os.environ.get("EPRECON_CFG2_LEVELS_FIRST", "0") != "1"
         self.profile_dominant = False  # bench.py: time the dense 96^3 gather with the library's event pair
         self.bp_side_stream = os.environ.get("EPRECON_CFG2_BP_STREAM", "0") == "1"
         # (EPRECON_CFG2_BP_PRIO: HIP stream priority of that stream; larger = lower priority, clamped by the runtime)
@@ -62,35 +70,63 @@ class Cfg2Step:
 
     @torch.no_grad()
     def run(self):
-        """One pass of the cfg2 hot path.  The three dense Back_Project levels do not depend on the
-        initialisation branch, so they are queued first without a host round trip between them
-        (run_async); the host then drives the initialisation branch, whose sparse stack has to wait
-        for its valid-voxel count, while the GPU works through the queue.  Same stream: the kernels
-        still run one after the other, only the host gaps between the levels disappear."""
+        """One pass of the cfg2 hot path: initialisation branch (2D stack, variance volume, submanifold stack, stage-0
+        selection) and the three dense Back_Project levels, which do not depend on it and are queued where the branch has to
+        wait for its valid-voxel count (_issue).  Same stream: the kernels still run one after the other, only the host gaps
+        disappear."""
+        issued = self._issue()
+        if not self.defer_reads:
+            return self._finish(issued)
+        prev, self._inflight = self._inflight, issued
+        return self._finish(prev) if prev is not None else {}
+
+    def flush(self):
+        """deferred mode: read the counts of the step still in flight"""
+        if self._inflight is not None:
+            prev, self._inflight = self._inflight, None
+            return self._finish(prev)
+        return self.last
+
+    def _finish(self, issued):
+        out, pending, select = issued
+        if select is not None:
+            out["stage0_coords"], _ = select.result()
+        for name in pending:
+            out[name] = pending[name].result()
+        self.last = out
+        return out
+
+    def _issue(self):
         out = {}
         pending = {}
         main = torch.cuda.current_stream(self.device)
         side = self._bp_stream if self.bp_side_stream else main
-        if side is not main:
-            side.wait_stream(main)
-        with torch.cuda.stream(side):
-            # EPRECON_CFG2_BP_STREAM=1: the three levels on their own stream, concurrent with the initialisation branch
-            for name, lvl, interval, mv in LEVELS:
-                if self.profile_dominant and name == "bp96":
-                    _lib.load().eprecon_profile_enable(2)  # one-shot: bracket this level's gather kernel only
-                pending[name] = BP.run_async(self.coords[interval], self.origin, self.voxel_size, self.feats[lvl],
-                                             self.krcam[lvl], mv)
+
+        def queue_levels():
+            # The three dense Back_Project levels do not depend on the initialisation branch.  They are queued without a host
+            # round trip between them (run_async) at the point where the initialisation branch has to wait for its valid-voxel
+            # count: the GPU works through them while the host reads the count and starts issuing the submanifold stack.
+            if side is not main:
+                side.wait_stream(main)
+            with torch.cuda.stream(side):
+                # EPRECON_CFG2_BP_STREAM=1: the three levels on their own stream, concurrent with the initialisation branch
+                for name, lvl, interval, mv in LEVELS:
+                    if self.profile_dominant and name == "bp96":
+                        _lib.load().eprecon_profile_enable(2)  # one-shot: bracket this level's gather kernel only
+                    pending[name] = BP.run_async(self.coords[interval], self.origin, self.voxel_size, self.feats[lvl],
+                                                 self.krcam[lvl], mv)
+
+        if not self.levels_inside:
+            queue_levels()
         init = self.init_net(self.coords[2], self.origin, self.voxel_size, self.features_init,
-                             self.krcam[1], self.shape_init, 1, 2)
+                             self.krcam[1], self.shape_init, 1, 2, between=queue_levels if self.levels_inside else None)
         out["init"] = init
+        select = None
         if init is not None:
-            out["stage0_coords"], _ = GO.init_select(init[0], init[1], 1, dim=self.shape_init[0] // 2, cell=4)
-        for name in pending:
-            out[name] = pending[name].result()
+            select = GO.init_select_async(init[0], init[1], 1, dim=self.shape_init[0] // 2, cell=4)
         if side is not main:
             main.wait_stream(side)
-        self.last = out
-        return out
+        return out, pending, select
 
     def dominant_kernel_ms(self, lib):
         """elapsed ms of the last bp_gather launch (the dense 96^3 level), from the library's
@@ -111,7 +147,9 @@ class Cfg2Step:
                             "selection + Back_Project on dense 24^3/48^3/96^3 (C=80/40/24)",
                 "views": N_VIEWS, "image": "640x480", "n_vox": list(self.window["n_vox"]),
                 "stages": ["occupancy_init48", "init_select"] + [l[0] for l in LEVELS],
-                "weights": "seeded random", "fragments_per_step_per_gpu": 1}
+                "weights": "seeded random", "fragments_per_step_per_gpu": 1,
+                "host_reads": ("counts of step k read after step k + 1 is queued (flushed inside the timed region)"
+                               if self.defer_reads else "every step reads its own counts before returning")}
 
 
 WORKLOAD_SEED = 20240  # np.random state of every calibration and workload forward (the reference's sub-sampling draws from it)

@@ -24,6 +24,40 @@ def init_select(logit, coords, batch_size, dim=24, cell=4, threshold=0.3):
     return out[: host[0]], host[1:]
 
 
+class PendingSelect:
+    """init_select queued on a stream; result() waits for the counts (pinned host copy + event) and returns what
+    init_select returns"""
+
+    def __init__(self, out, pinned, event):
+        self._out, self._pinned, self._event = out, pinned, event
+
+    def result(self):
+        self._event.synchronize()
+        host = self._pinned.tolist()
+        return self._out[: host[0]], host[1:]
+
+
+def init_select_async(logit, coords, batch_size, dim=24, cell=4, threshold=0.3):
+    """init_select without the host round trip: -> PendingSelect"""
+    lib = _lib.load()
+    logit = logit.reshape(-1).contiguous()
+    coords = coords.contiguous()
+    assert coords.dtype == torch.int32 and logit.dtype == torch.float32
+    dev = coords.device
+    out = torch.empty((batch_size * dim ** 3, 4), dtype=torch.int32, device=dev)
+    counts = torch.zeros(1 + batch_size, dtype=torch.int32, device=dev)
+    ws = _lib.workspace(lib.eprecon_init_select_workspace_bytes(batch_size, dim), dev)
+    _lib.check(lib.eprecon_init_select_async(_lib.ptr(logit), _lib.ptr(coords), coords.shape[0],
+                                             float(threshold), batch_size, dim, cell, _lib.ptr(out),
+                                             _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
+               "eprecon_init_select_async")
+    pinned = torch.empty(1 + batch_size, dtype=torch.int32, pin_memory=True)
+    pinned.copy_(counts, non_blocking=True)
+    event = torch.cuda.Event()
+    event.record()
+    return PendingSelect(out, pinned, event)
+
+
 def upsample(pre_feat, pre_coords, interval):
     """models/neucon_network.py:193-214 -> (up_feat f32[8N, C], up_coords int32[8N, 4])"""
     lib = _lib.load()

@@ -151,7 +151,10 @@ class Occupancy_Initialization(nn.Module):
         y, partial, aff = self.subm4.run_stats(x, vset, bn=self.norm4)   # the logit layer finishes norm4's statistics itself
         return self.norm4.finish(y, partial, aff, out=y)
 
-    def forward(self, coords, origin, voxel_size, features_all, KRcam, shape, stage, min_view_number):
+    def forward(self, coords, origin, voxel_size, features_all, KRcam, shape, stage, min_view_number, between=None):
+        """`between` (optional, beyond the reference's signature): called once after the variance volume is queued and before
+        its valid-voxel count is read on the host — work the caller queues there keeps the GPU busy while the host waits for
+        the count and starts issuing the submanifold stack (inference on the GPU only; ignored otherwise)."""
         bs = features_all[0][0].shape[0]
         dev = features_all[0][0].device
         graphed = self.use_hip_graph and not torch.is_grad_enabled() and dev.type == "cuda"
@@ -165,8 +168,16 @@ class Occupancy_Initialization(nn.Module):
             else:
                 per_batch.append(self.feat_fusion_pre(*[torch.stack(v) for v in views]))
         fused = per_batch[0].unsqueeze(1) if bs == 1 else torch.stack(per_batch, dim=1)  # [V,B,32,H,W]
-        res = BP.view_variance(coords, origin, voxel_size, fused, KRcam, min_view_number,
-                               min_valid=INIT_MIN_VALID)
+        if between is not None and dev.type == "cuda" and not torch.is_grad_enabled():
+            pend = BP.run_async(coords, origin, voxel_size, fused, KRcam, min_view_number, BP.MODE_VARIANCE,
+                                min_valid_per_batch=INIT_MIN_VALID, want_mean=True)
+            between()
+            res = pend.result()
+            if res is not None:
+                res["var"] = res.pop("feats")
+        else:
+            res = BP.view_variance(coords, origin, voxel_size, fused, KRcam, min_view_number,
+                                   min_valid=INIT_MIN_VALID)
         if res is None:
             return None
         interval = 2 ** (2 - stage)

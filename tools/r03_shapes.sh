@@ -1,11 +1,8 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r03_2d
-rm -rf $O; mkdir -p $O
-cd /tmp && export TMPDIR=/tmp
 cd $R
-for v in 0 1; do
-  EPRECON_CONV_DIRECT_2D=$v EPRECON_CONV_DIRECT_2D_MIN_ROWS=10000 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/t$v -o r -- python tools/conv_layers_trace.py > $O/names$v.txt 2>$O/err$v.txt
-  python tools/conv_layers_summary.py $O/t$v/r_kernel_trace.csv $O/names$v.txt > $O/sum$v.txt 2>&1
+for v in "EPRECON_CFG2_LEVELS_FIRST=1" "A=1" "EPRECON_CFG2_LEVELS_FIRST=1" "A=2" "EPRECON_CFG2_DEFER=0"; do
+  env $v timeout 300 python bench.py --no-cpu-baseline --no-extra 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('cfg2 $v', round(d['ms_per_step'],4), round(d['roofline']['avg_launch_ms']*1e3,1), round(d['roofline_conv']['avg_launch_ms']*1e3,1))"
 done
-paste -d'|' <(cut -c1-120 $O/sum0.txt) <(cut -c24-120 $O/sum1.txt)
+timeout 600 python -m pytest tests/test_properties_gpu.py tests/test_occupancy_init_gpu.py tests/test_neucon_gpu.py -x -q 2>&1 | tail -2
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
