@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-3 profile collection on the GPU box: bench line, kernel stats of the default bench command, PMC passes
-# (each counter set in its own run, --kernel-trace only), cfg4 kernel stats -> gpurun_out/r03_final/
+# (each counter set in its own run, --kernel-trace only), cfg4 kernel stats, stage times, per-layer cfg4 trace, per-shape
+# convolution timings -> gpurun_out/r03_final/ (copy profiles_r03/* into profiles/r03/)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r03_final
 mkdir -p $O
@@ -20,4 +21,14 @@ python tools/summarize_cfg4.py $O/stats_cfg4 $O/profiles_r03 $O/bench_cfg4.json 
 rm -f $O/stats_cfg4/r_kernel_trace.csv
 python tools/summarize_profiles.py $O $O/profiles_r03 r03_final 35 | head -30
 python tools/profile_cfg4_stages.py 3 > $O/profiles_r03/cfg4_stage_times.txt 2>&1
+python tools/profile_cfg2_stages.py > $O/profiles_r03/cfg2_stage_times.txt 2>&1
+# per-stage / per-layer picture of a cfg4 fragment (stage markers + convolution log joined with the kernel trace)
+L=$O/layers; rm -rf $L; mkdir -p $L
+EPRECON_NO_GRAPH=1 EPRECON_CONV_LOG=$L/conv.log rocprofv3 --kernel-trace --output-format csv -d $L -o r -- python tools/trace_cfg4_layers.py $L > $L/run.log 2>&1
+python tools/summarize_cfg4_layers.py $L > $O/profiles_r03/cfg4_layers.txt 2> $L/sum.err
+rm -f $L/r_kernel_trace.csv
+# the 3x3x3 shapes of that fragment one by one: this round's kernels against round 2's selection
+python tools/conv_shapes_ab.py round3 > $L/shapes_r3.txt 2>&1
+EPRECON_CONV_DIRECT=0 EPRECON_CONV_SPLITK_PIPE=0 EPRECON_CONV_SPLITK_NARROW=0 EPRECON_CONV_SPLITK_WAVES=4 python tools/conv_shapes_ab.py round2 > $L/shapes_r2.txt 2>&1
+paste -d'|' <(cut -c1-62 $L/shapes_r2.txt) <(cut -c52-62 $L/shapes_r3.txt) | grep -v amdgpu.ids > $O/profiles_r03/conv_shapes.txt
 ls $O/profiles_r03

@@ -1,4 +1,6 @@
 #!/bin/bash
+# rocprofv3 --pmc passes over tools/conv_shapes_ab.py (the 3x3x3 shapes of a cfg4 fragment): clock, MFMA pipe busy cycles, instruction
+# mix and waits per launch of the direct gather kernel -> gpurun_out/r03_pmc/ (summary on stdout; profiles/r03/conv_direct_pmc.txt)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r03_pmc
 rm -rf $O; mkdir -p $O
