@@ -136,3 +136,35 @@ def test_tile_kernel_chain_with_ragged_tiles(cin, cmid, cout):
         act = r.run_act(act, g)
         got = D2.maps_of(D2.materialize(act), v, h, w)
     assert (got - ref).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("cin,cmid,cout", [(12, 12, 12), (24, 12, 20), (24, 24, 24), (40, 40, 40), (20, 36, 8)])
+def test_direct_gather_kernel_chain_on_the_pixel_map(monkeypatch, cin, cmid, cout):
+    """the same chain with the 3x3 layers on the direct gather kernel (spconv_direct16_kernel over the pixel map: what the
+    9 x 120 x 160 level of the fusion stack runs on): zero padding at the image borders = missing neighbours, which must stay
+    zero AFTER the producer's pending BatchNorm is applied on load; C_in = 12 / 24 / 40 end in a half chunk"""
+    from eprecon_amd import dense2d as D2
+    from eprecon_amd.modules import Conv2d_Block, Conv2d_Residual_Block
+    from test_sparse_gpu import _last_conv_kernel
+    monkeypatch.setattr(D2, "DIRECT_2D", True)
+    monkeypatch.setattr(D2, "DIRECT_2D_MIN_ROWS", 1000)
+    torch.manual_seed(cin * 100 + cout + 7)
+    dev = _dev()
+    v, h, w = 9, 50, 70
+    a = Conv2d_Block(cin, cmid, 3).to(dev).train()
+    b = Conv2d_Block(cmid, cout, 3).to(dev).train()
+    r = Conv2d_Residual_Block(cout, 3).to(dev).train()
+    for m in (a, b, r):
+        for prm in m.parameters():
+            if prm.dim() == 1:
+                prm.data.uniform_(0.5, 1.5)
+    x = torch.randn(v, cin, h, w, device=dev)
+    g = D2.PixelGrid.get(v, h, w, dev)
+    with torch.no_grad():
+        ref = r(b(a(x)))
+        act, name = _last_conv_kernel((9, cin, cmid, 1000), lambda: a.run_act(D2.Act(D2.rows_of(_cl(x))), g))
+        assert name == "spconv_direct16_kernel"
+        act = b.run_act(act, g)
+        act = r.run_act(act, g)
+        got = D2.maps_of(D2.materialize(act), v, h, w)
+    assert (got - ref).abs().max().item() < TOL
