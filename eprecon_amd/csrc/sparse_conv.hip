@@ -1997,13 +1997,18 @@ int launch_splitk_v(ConvParams &p, hipStream_t st)
     const int64_t wgs = (int64_t)grid.x * grid.y;
     const int stages = p.K * ((p.Cin + 31) / 32);
     int nw = 4;
-    const bool wide_ok = !rt2 && !p.bn_scale_out;   // (the in-kernel BatchNorm finalize is written for 256-thread workgroups)
-    if (wide_ok && max_waves >= 16 && wgs * 16 <= 4096 && stages >= 32) nw = 16;
-    else if (wide_ok && max_waves >= 8 && wgs * 8 <= 4096 && stages >= 16) nw = 8;
+    const bool wide_ok = !p.bn_scale_out;   // (the in-kernel BatchNorm finalize is written for 256-thread workgroups)
+    static const bool rt2_nw8 = !(getenv("EPRECON_CONV_SPLITK_RT2_NW8") && getenv("EPRECON_CONV_SPLITK_RT2_NW8")[0] == '0');
+    if (wide_ok && !rt2 && max_waves >= 16 && wgs * 16 <= 4096 && stages >= 32) nw = 16;
+    else if (wide_ok && max_waves >= 8 && wgs * 8 <= 4096 && stages >= 16 && (!rt2 || rt2_nw8)) nw = 8;
     const size_t w_floats = (size_t)splitk_w_floats(rt2 ? 2 : 1, nw);
     const size_t lds = w_floats * sizeof(float) + (size_t)p.K * rows * sizeof(int) +
                        (size_t)(((p.K + 3) & ~3) + ((p.K + 4) & ~3)) * sizeof(int) + (size_t)2 * ((p.Cin + 3) & ~3) * sizeof(float) + 16;
-    if (rt2)
+    // (128-row workgroups — every staged slab feeding four row tiles, half the weight traffic again — measured 157 vs 169 us on
+    // 9,415 rows 192 -> 96 with 576 bytes of spills per lane: the weight traffic is not what limits these launches; not kept)
+    if (rt2 && nw == 8)
+        hipLaunchKernelGGL((spconv_splitk_kernel<VEC4, 2, 8>), grid, dim3(512), lds, st, p);
+    else if (rt2)
         hipLaunchKernelGGL((spconv_splitk_kernel<VEC4, 2, 4>), grid, dim3(256), lds, st, p);
     else if (nw == 16) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&spconv_splitk_kernel<VEC4, 1, 16>),
