@@ -50,7 +50,7 @@ struct ConvParams {
     const float *wq;    // ... for the 32-row tile kernel (pack_weights_kernel)
     const float *wq16;  // ... for the 16-row tile kernel (pack_weights16_kernel)
     int debug;  // EPRECON_D3_ABLATE (timing experiments only): 1 no MFMA loop, 4 no halo row loads
-    int splitk_pipe;  // split-K kernel: software-pipelined stages (EPRECON_CONV_SPLITK_PIPE=0: one stage at a time)
+    int splitk_pipe;  // split-K kernel: 1 software-pipelined stages, 2 also B operands straight from the packed weights (wq); 0 neither
 };
 
 constexpr int kWaves = 4;

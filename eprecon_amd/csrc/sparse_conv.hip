@@ -1762,7 +1762,10 @@ __global__ __launch_bounds__(64 * NW) void spconv_splitk_kernel(ConvParams p)
     // NEXT stage's weight slab and neighbour values already in flight while the current one runs its 16 x RT MFMAs.  Every
     // prefetch is unconditional (addresses clamped, values masked at use) so that the waits stay `vmcnt(<loads of one stage>)`.
     const bool w_v4 = (p.Cout & 3) == 0 && ((p.Cout - col0) & 3) == 0 && (reinterpret_cast<uintptr_t>(p.w) & 15) == 0;
-    if (VEC4 && w_v4 && p.splitk_pipe) {
+    // bdirect: the caller packed the weights in MFMA operand order (pack_weights_kernel, p.wq): the B operands of a stage are
+    // four 16-byte loads straight into registers — no slab in LDS, no ds_read per MFMA pair, no wave barrier
+    const bool bdirect = p.wq != nullptr && p.splitk_pipe == 2;
+    if (VEC4 && (w_v4 || bdirect) && p.splitk_pipe) {
         if (tid == 0) {
             int n = 0;
             for (int k = 0; k < p.K; ++k)
@@ -1778,14 +1781,26 @@ __global__ __launch_bounds__(64 * NW) void spconv_splitk_kernel(ConvParams p)
             int j[RT];
             int c0;
         };
+        // packed layout (pack_weights_kernel): wq[(((((cb * K + k) * NCH8 + ch) * 2 + half) * NTP + t) * 32 + col) * 4 + s]
+        const int nch8 = (p.Cin + 7) / 8;
+        const int ntp = p.Cout <= 32 ? 1 : 2;
+        const int cbp = (int)blockIdx.y / ntp, tp = (int)blockIdx.y - cbp * ntp;
+        const float *wq_lane = p.wq ? p.wq + ((size_t)half * ntp + tp) * 128 + (size_t)r32 * 4 : nullptr;
         auto fetch = [&](int st, Stage &g) {
             const int k = sLive[st / nslab];
             g.c0 = (st % nslab) * 32;
-            const float *wk = p.w + (size_t)k * p.Cin * p.Cout + col0;
+            if (bdirect) {
+                const float *wb = wq_lane + ((size_t)(cbp * p.K + k) * nch8) * (2 * ntp * 128);
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int e = lane + it * 64, r = e >> 3, q = e & 7;
-                g.w4[it] = *reinterpret_cast<const float4 *>(wk + (size_t)min(g.c0 + r, p.Cin - 1) * p.Cout + 4 * min(q, nq - 1));
+                for (int it = 0; it < 4; ++it)   // chunk it of the slab (clamped: a chunk past C_in multiplies zeros)
+                    g.w4[it] = *reinterpret_cast<const float4 *>(wb + (size_t)min(g.c0 / 8 + it, nch8 - 1) * (2 * ntp * 128));
+            } else {
+                const float *wk = p.w + (size_t)k * p.Cin * p.Cout + col0;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int e = lane + it * 64, r = e >> 3, q = e & 7;
+                    g.w4[it] = *reinterpret_cast<const float4 *>(wk + (size_t)min(g.c0 + r, p.Cin - 1) * p.Cout + 4 * min(q, nq - 1));
+                }
             }
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
@@ -1803,10 +1818,12 @@ __global__ __launch_bounds__(64 * NW) void spconv_splitk_kernel(ConvParams p)
         for (int st = wave; st < nst; st += NW) {
             fetch(min(st + NW, nst - 1), nxt);
             const int c0 = cur.c0;
+            if (!bdirect) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int e = lane + it * 64, r = e >> 3, q = e & 7;
-                reinterpret_cast<float4 *>(myW)[e] = (c0 + r < p.Cin && q < nq) ? cur.w4[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int it = 0; it < 4; ++it) {
+                    const int e = lane + it * 64, r = e >> 3, q = e & 7;
+                    reinterpret_cast<float4 *>(myW)[e] = (c0 + r < p.Cin && q < nq) ? cur.w4[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
             float a[RT][4][4];
 #pragma unroll
@@ -1840,21 +1857,34 @@ __global__ __launch_bounds__(64 * NW) void spconv_splitk_kernel(ConvParams p)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) a[t][ch][q] = (cur.j[t] >= 0 && c + q < p.Cin) ? a[t][ch][q] : 0.0f;
                 }
-            __builtin_amdgcn_wave_barrier();
             const int nch = min(4, (p.Cin - c0 + 7) / 8);
+            if (bdirect) {
 #pragma unroll
-            for (int ch = 0; ch < 4; ++ch) {   // (unrolled with a uniform guard: register indices stay static)
-                if (ch < nch) {
-                    float bw[4];
+                for (int ch = 0; ch < 4; ++ch) {
+                    if (ch < nch) {
+                        const float bw[4] = {cur.w4[ch].x, cur.w4[ch].y, cur.w4[ch].z, cur.w4[ch].w};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) bw[q] = myW[(ch * 8 + 4 * half + q) * TN + r32];
+                        for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][ch][q], bw[q], acc[t], 0, 0, 0);
+                            for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][ch][q], bw[q], acc[t], 0, 0, 0);
+                    }
                 }
+            } else {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {   // (unrolled with a uniform guard: register indices stay static)
+                    if (ch < nch) {
+                        float bw[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) bw[q] = myW[(ch * 8 + 4 * half + q) * TN + r32];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][ch][q], bw[q], acc[t], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
             cur = nxt;
         }
     } else {
@@ -1985,7 +2015,8 @@ template <bool VEC4>
 int launch_splitk_v(ConvParams &p, hipStream_t st)
 {
     static const bool pipe_on = !(getenv("EPRECON_CONV_SPLITK_PIPE") && getenv("EPRECON_CONV_SPLITK_PIPE")[0] == '0');
-    p.splitk_pipe = pipe_on ? 1 : 0;
+    static const bool bdirect_on = !(getenv("EPRECON_CONV_SPLITK_BDIRECT") && getenv("EPRECON_CONV_SPLITK_BDIRECT")[0] == '0');
+    p.splitk_pipe = pipe_on ? ((bdirect_on && p.wq && (reinterpret_cast<uintptr_t>(p.wq) & 15) == 0) ? 2 : 1) : 0;
     static const bool rt2_on = !(getenv("EPRECON_CONV_SPLITK_RT2") && getenv("EPRECON_CONV_SPLITK_RT2")[0] == '0');
     static const int max_waves = getenv("EPRECON_CONV_SPLITK_WAVES") ? atoi(getenv("EPRECON_CONV_SPLITK_WAVES")) : 16;
     const int colb = (int)ceil_div(p.Cout, 32);

@@ -160,6 +160,9 @@ def conv_bn_launch(w, bias, gamma, beta, eps, k, x, grid, out=None, aff=None, re
     d.in_scale, d.in_shift, d.in_relu = _dptr(x.scale), _dptr(x.shift), int(x.relu)
     if k == 3:
         d.img_h, d.img_w, d.img_maps = grid.height, grid.width, grid.maps  # narrow layers: image-tile kernel
+        if SP.SPLITK_BDIRECT and n < DIRECT_2D_MIN_ROWS:
+            pq = SP.packed_weight(w)                 # short pixel lists (the 10,800-pixel level): B operands of the split-K kernel
+            d.packed_weight = pq.data_ptr()
         if DIRECT_2D and cout <= SP.DIRECT_MAX_COUT and n >= DIRECT_2D_MIN_ROWS:
             pw = SP.packed_weight16(w)               # long pixel lists: the direct gather kernel on the pixel map
             d.packed_weight16 = pw.data_ptr()

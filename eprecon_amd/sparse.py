@@ -84,6 +84,7 @@ def unique_coords(coords, quantum=1):
 
 DIRECT = os.environ.get("EPRECON_CONV_DIRECT", "1") != "0"   # (the library reads the same switch per launch)
 DIRECT_MAX_COUT = 64
+SPLITK_BDIRECT = os.environ.get("EPRECON_CONV_SPLITK_BDIRECT", "1") != "0"
 DENSE_MIN_FILL = 0.4   # a set that fills at least this share of its bounding grid takes the dense-grid convolution
 
 
@@ -189,6 +190,11 @@ def _resolve_map(nbr, x, weight, desc, accumulate=False, ln=False, stats=False, 
         # which kernel runs is the library's choice, the packing only makes the direct one possible
         pw = packed_weight16(weight)
         desc.packed_weight16 = pw.data_ptr()
+        keep.append(pw)
+    if nbr is not None and weight.shape[0] == 27 and not accumulate and x.is_cuda and SPLITK_BDIRECT:
+        # short lists: the split-K kernel reads its B operands straight from the 32x32x2 operand-order packing
+        pw = packed_weight(weight)
+        desc.packed_weight = pw.data_ptr()
         keep.append(pw)
     return keep
 
