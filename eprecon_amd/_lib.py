@@ -108,6 +108,9 @@ SIGNATURES = {
     "eprecon_profile_conv_ms": (_f, [_c.POINTER(_i64), _c.POINTER(_c.c_char_p)]),
     "eprecon_profile_conv_pairs": (_i64, []),
     "eprecon_profile_mark_async": (_i, [_i, _vp]),
+    "eprecon_sparsify_workspace_bytes": (_sz, [_i64]),
+    "eprecon_sparsify_async": (_i, [_vp, _i, _f, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                    _sz, _vp]),
     "eprecon_grid_rank_async": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "eprecon_conv_pack_weight_floats": (_sz, [_i, _i, _i]),
     "eprecon_conv_pack_weight_async": (_i, [_vp, _i, _i, _i, _vp, _vp]),

@@ -228,3 +228,150 @@ extern "C" int eprecon_upsample2x_nhwc_async(const float *in, float *out, int n,
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Sparsify for the next stage (models/neucon_network.py:454-507) as one call: occupancy = occ > thr; per batch element the
+// occupied voxels and the occupied voxels whose target is occupied (the guards' counts); the kept rows of coords / tsdf /
+// occ / feat_all compacted in row order (what torch.nonzero + four index_select + a cat produce) — three launches and ONE
+// host read instead of ~15 launches and two.  The random sub-sampling branch (:477-484) edits the occupancy on the host side
+// and then takes the reference's own sequence of torch calls (eprecon_amd/neucon_network.py).
+//   counts int32[1 + 2 * batch]: [0] kept rows, [1 + b] occupied in batch b, [1 + batch + b] occupied & target in batch b
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int kSpTile = 256;
+constexpr int kSpMaxBatch = 32;
+
+__global__ __launch_bounds__(kSpTile) void sparsify_count_kernel(const float *occ, int ld_occ, float thr, const unsigned char *tgt,
+                                                                const int4 *coords, int n, int batch, int *tile_tot, int *counts)
+{
+    const int row = blockIdx.x * kSpTile + threadIdx.x;
+    const bool keep = row < n && occ[(size_t)row * ld_occ] > thr;
+    const unsigned long long m = __ballot(keep);
+    __shared__ int sTot[kSpTile / 64];
+    __shared__ int sCnt[2 * kSpMaxBatch];
+    if (threadIdx.x < 2 * kSpMaxBatch) sCnt[threadIdx.x] = 0;
+    if ((threadIdx.x & 63) == 0) sTot[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    // per-batch counts: ballots per wave -> LDS -> ONE global atomic per workgroup and batch element (a same-address atomic
+    // per kept row serialises: 180k of them cost ~0.5 ms; integer sums do not depend on the order)
+    const int b = keep ? coords[row].x : -1;
+    const bool t = keep && (!tgt || tgt[row]);
+    for (int bb = 0; bb < batch; ++bb) {
+        const unsigned long long mb = __ballot(b == bb), mt = __ballot(b == bb && t);
+        if ((threadIdx.x & 63) == 0 && mb) {
+            atomicAdd(&sCnt[bb], __popcll(mb));
+            if (mt) atomicAdd(&sCnt[kSpMaxBatch + bb], __popcll(mt));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < batch) {
+        if (sCnt[threadIdx.x]) atomicAdd(counts + 1 + threadIdx.x, sCnt[threadIdx.x]);
+        if (sCnt[kSpMaxBatch + threadIdx.x]) atomicAdd(counts + 1 + batch + threadIdx.x, sCnt[kSpMaxBatch + threadIdx.x]);
+    }
+    if (threadIdx.x == 0) tile_tot[blockIdx.x] = sTot[0] + sTot[1] + sTot[2] + sTot[3];
+}
+
+// exclusive scan of the tile totals in place (one workgroup; <= a few thousand tiles), total -> counts[0]
+__global__ __launch_bounds__(1024) void sparsify_scan_kernel(int *tile_tot, int ntiles, int *counts)
+{
+    __shared__ int sWave[16];
+    __shared__ int sCarry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) sCarry = 0;
+    __syncthreads();
+    for (int base = 0; base < ntiles; base += 1024) {
+        const int i = base + tid;
+        const int v = i < ntiles ? tile_tot[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) sWave[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += sWave[w];
+        const int carry = sCarry;
+        if (i < ntiles) tile_tot[i] = carry + woff + incl - v;
+        __syncthreads();
+        if (tid == 1023) sCarry = carry + woff + incl;
+        __syncthreads();
+    }
+    if (tid == 0) counts[0] = sCarry;
+}
+
+// kept row r -> output row tile_off[tile] + (kept rows before it in the tile); one thread per row writes the small columns,
+// the wide feature row is copied by the row's wave cooperatively
+__global__ __launch_bounds__(kSpTile) void sparsify_compact_kernel(const float *occ, int ld_occ, float thr, const int4 *coords,
+                                                                  const float *tsdf, int ld_tsdf, const float *feat, int ld_feat,
+                                                                  int c_all, int c_feat, int n, const int *tile_off, int4 *out_coords,
+                                                                  float *out_tsdf, float *out_occ, float *out_all, float *out_feat)
+{
+    const int row = blockIdx.x * kSpTile + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float o = row < n ? occ[(size_t)row * ld_occ] : 0.0f;
+    const bool keep = row < n && o > thr;
+    const unsigned long long m = __ballot(keep);
+    __shared__ int sTot[kSpTile / 64];
+    if (lane == 0) sTot[wave] = __popcll(m);
+    __syncthreads();
+    int base = tile_off[blockIdx.x];
+    for (int w = 0; w < wave; ++w) base += sTot[w];
+    const int dst = base + __popcll(m & ((1ull << lane) - 1ull));
+    const float t = keep ? tsdf[(size_t)row * ld_tsdf] : 0.0f;
+    if (keep) {
+        out_coords[dst] = coords[row];
+        out_tsdf[dst] = t;
+        out_occ[dst] = o;
+        out_feat[(size_t)dst * (c_feat + 2) + c_feat] = t;
+        out_feat[(size_t)dst * (c_feat + 2) + c_feat + 1] = o;
+    }
+    // feature rows: the wave walks its kept rows, 64 lanes over the channels
+    unsigned long long rest = m;
+    while (rest) {
+        const int l = __ffsll((long long)rest) - 1;
+        rest &= rest - 1;
+        const int src = blockIdx.x * kSpTile + wave * 64 + l;
+        const int d = __shfl(dst, l);
+        for (int c = lane; c < c_all; c += 64) {
+            const float v = feat[(size_t)src * ld_feat + c];
+            out_all[(size_t)d * c_all + c] = v;
+            if (c < c_feat) out_feat[(size_t)d * (c_feat + 2) + c] = v;
+        }
+    }
+}
+}  // namespace
+
+extern "C" size_t eprecon_sparsify_workspace_bytes(int64_t n)
+{
+    return align_up((size_t)(ceil_div(n > 0 ? n : 1, (int64_t)kSpTile) + 1) * sizeof(int), 256);
+}
+
+extern "C" int eprecon_sparsify_async(const float *occ, int ld_occ, float threshold, const unsigned char *target,
+                                      const int32_t *coords, const float *tsdf, int ld_tsdf, const float *feat_all, int ld_feat,
+                                      int c_all, int c_feat, int64_t n, int batch, int32_t *out_coords, float *out_tsdf,
+                                      float *out_occ, float *out_all, float *out_feat, int32_t *counts, void *workspace,
+                                      size_t workspace_bytes, void *stream)
+{
+    if (n < 0 || n > 0x7fffffff || batch <= 0 || batch > kSpMaxBatch || c_all <= 0 || c_feat < 0 || c_feat > c_all || ld_occ < 1 || ld_tsdf < 1 ||
+        ld_feat < c_all || !counts || !workspace || (n > 0 && (!occ || !coords || !tsdf || !feat_all || !out_coords || !out_tsdf ||
+                                                               !out_occ || !out_all || !out_feat)))
+        return EPRECON_ERR_ARG;
+    if (workspace_bytes < eprecon_sparsify_workspace_bytes(n)) return EPRECON_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    EP_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)(1 + 2 * batch) * sizeof(int32_t), st));
+    if (n == 0) return EPRECON_OK;
+    int *tile_tot = reinterpret_cast<int *>(workspace);
+    const int ntiles = (int)ceil_div(n, (int64_t)kSpTile);
+    hipLaunchKernelGGL(sparsify_count_kernel, dim3(ntiles), dim3(kSpTile), 0, st, occ, ld_occ, threshold, target,
+                       reinterpret_cast<const int4 *>(coords), (int)n, batch, tile_tot, counts);
+    EP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sparsify_scan_kernel, dim3(1), dim3(1024), 0, st, tile_tot, ntiles, counts);
+    EP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sparsify_compact_kernel, dim3(ntiles), dim3(kSpTile), 0, st, occ, ld_occ, threshold,
+                       reinterpret_cast<const int4 *>(coords), tsdf, ld_tsdf, feat_all, ld_feat, c_all, c_feat, (int)n,
+                       (const int *)tile_tot, reinterpret_cast<int4 *>(out_coords), out_tsdf, out_occ, out_all, out_feat);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}

@@ -78,3 +78,33 @@ def upsample(pre_feat, pre_coords, interval):
                                           int(interval), _lib.ptr(up_feat), _lib.ptr(up_coords),
                                           _lib.current_stream()), "eprecon_upsample_async")
     return up_feat, up_coords
+
+
+def sparsify(occ, threshold, target, coords, tsdf, feat_all, c_feat, batch_size):
+    """models/neucon_network.py:454-507 without its random sub-sampling branch, one call + one host read:
+    occ f32[N,1], target bool[N] | None, coords int32[N,4], tsdf f32[N,1], feat_all f32[N,C] ->
+    (counts [kept, occupied per batch..., occupied & target per batch...], pre_coords, pre_tsdf [M,1], pre_occ [M,1],
+    kept_all [M,C], pre_feat [M, c_feat + 2])"""
+    lib = _lib.load()
+    n, c_all = feat_all.shape
+    dev = feat_all.device
+    assert occ.shape[0] == n and tsdf.shape[0] == n and coords.shape == (n, 4) and coords.dtype == torch.int32
+    assert coords.is_contiguous() and feat_all.stride(1) == 1
+    tgt = None
+    if target is not None:
+        tgt = target.reshape(-1).contiguous().view(torch.uint8)
+    out_coords = torch.empty((n, 4), dtype=torch.int32, device=dev)
+    out_tsdf = torch.empty((n, 1), dtype=torch.float32, device=dev)
+    out_occ = torch.empty((n, 1), dtype=torch.float32, device=dev)
+    out_all = torch.empty((n, c_all), dtype=torch.float32, device=dev)
+    out_feat = torch.empty((n, c_feat + 2), dtype=torch.float32, device=dev)
+    counts = torch.empty(1 + 2 * batch_size, dtype=torch.int32, device=dev)
+    ws = _lib.workspace(lib.eprecon_sparsify_workspace_bytes(n), dev)
+    _lib.check(lib.eprecon_sparsify_async(
+        _lib.ptr(occ), occ.stride(0), float(threshold), _lib.ptr(tgt), _lib.ptr(coords), _lib.ptr(tsdf), tsdf.stride(0),
+        _lib.ptr(feat_all), feat_all.stride(0), c_all, int(c_feat), n, batch_size, _lib.ptr(out_coords), _lib.ptr(out_tsdf),
+        _lib.ptr(out_occ), _lib.ptr(out_all), _lib.ptr(out_feat), _lib.ptr(counts), _lib.ptr(ws), ws.numel(),
+        _lib.current_stream()), "eprecon_sparsify_async")
+    host = counts.tolist()
+    m = host[0]
+    return host, out_coords[:m], out_tsdf[:m], out_occ[:m], out_all[:m], out_feat[:m]

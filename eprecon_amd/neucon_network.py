@@ -35,6 +35,10 @@ from .occupancy_initialization import Occupancy_Initialization
 from .tensor import PointTensor
 from .torchsparse_utils import aligned_camera_coords
 
+# EPRECON_FUSED_SPARSIFY=0: the reference's sequence of torch calls (threshold, index_add counts, nonzero, index_select x 4,
+# cat: ~15 launches and two host reads per level) instead of eprecon_sparsify_async (3 launches, one host read)
+_FUSED_SPARSIFY = __import__("os").environ.get("EPRECON_FUSED_SPARSIFY", "1") == "1"
+
 
 def _warn(msg):
     print(f"[eprecon_amd] warning: {msg}", file=sys.stderr)
@@ -238,6 +242,42 @@ class NeuConNet(nn.Module):
 
             # ---- sparsify for the next stage (:454-507) ----
             # (the reference's grid_mask is all ones on this path, `occupancy[grid_mask == False] = False` is a no-op)
+            # Inference on the GPU: threshold, the guards' counts and the compaction of the kept rows in ONE call and one host
+            # read (csrc/grid_ops.hip, eprecon_sparsify_async); the random sub-sampling branch and training keep the
+            # reference's sequence of torch calls below.
+            fused = None
+            if _FUSED_SPARSIFY and dev.type == "cuda" and not recording and feat_all.stride(1) == 1:
+                fused = GO.sparsify(occ, cfg.THRESHOLDS[i], occ_target,
+                                    up_coords if up_coords.dtype == torch.int32 else up_coords.to(torch.int32), tsdf, feat_all,
+                                    feat.shape[1], bs)
+                if self.training and any(cfg.TRAIN_NUM_SAMPLE[i] < nb <= cfg.TRAIN_NUM_SAMPLE[i] * EXCEED_NUM
+                                         for nb in fused[0][1:1 + bs]):
+                    fused = None          # a batch element is over its cap: np.random.choice drops rows first (below)
+            if fused is not None:
+                stats = [fused[0][1:1 + bs], fused[0][1 + bs:1 + 2 * bs]]
+                if self.trace is not None:
+                    self._record(stage=f"heads{i}", feat=feat, tsdf=tsdf, occ=occ, occupancy=occ.squeeze(1) > cfg.THRESHOLDS[i])
+                for b in range(bs):
+                    if stats[0][b] < STAGE_MIN_OCC:
+                        _warn(f"no valid points: scale {i}")
+                        return outputs, loss_dict
+                    if self.training and stats[0][b] > cfg.TRAIN_NUM_SAMPLE[i] * EXCEED_NUM:
+                        _warn(f"exceed too many points: scale {i} num_batch {stats[0][b]}")
+                        return outputs, loss_dict
+                if occ_target is not None:
+                    for b in range(bs):
+                        if stats[1][b] == 0:
+                            _warn(f"occ_target is 0: scale {i}")
+                            return outputs, loss_dict
+                _, pre_coords, pre_tsdf, pre_occ, kept_all, pre_feat = fused
+                if pre_coords.dtype != up_coords.dtype:
+                    pre_coords = pre_coords.to(up_coords.dtype)
+                panoptic_voxel_feats.append(kept_all)
+                panoptic_coords.append(pre_coords)
+                if i == cfg.N_LAYER - 1:
+                    outputs["coords"] = pre_coords
+                    outputs["tsdf"] = pre_tsdf
+                continue
             occupancy = occ.squeeze(1) > cfg.THRESHOLDS[i]
             # recorded before the guards so that an early return still leaves the logits visible;
             # `occupancy` is the same tensor object the sub-sampling below edits in place

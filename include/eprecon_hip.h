@@ -367,6 +367,20 @@ int eprecon_init_select_async(const float *logit, const int32_t *coords, int64_t
                               int batch, int dim, int cell, int32_t *out_coords, int32_t *n_out_dev,
                               void *workspace, size_t workspace_bytes, void *stream);
 /*
+ * Sparsify for the next stage (models/neucon_network.py:454-507) in one call: occupancy = occ > threshold; the kept rows of
+ * coords / tsdf / occ / feat_all compacted in row order (torch.nonzero + index_select + cat of the reference) and the counts
+ * its guards read: counts int32[1 + 2 * batch] = [kept rows, occupied per batch element ..., occupied with an occupied
+ * target per batch element ...] (target uint8[n] or NULL = all ones).  Outputs are sized for n rows:
+ * out_coords int32[n,4], out_tsdf / out_occ f32[n], out_all f32[n, c_all], out_feat f32[n, c_feat + 2] = [feat_all[:, :c_feat],
+ * tsdf, occ] (the next stage's input).  The random sub-sampling branch (:477-484) is not part of it.
+ */
+size_t eprecon_sparsify_workspace_bytes(int64_t n);
+int eprecon_sparsify_async(const float *occ, int ld_occ, float threshold, const unsigned char *target,
+                           const int32_t *coords, const float *tsdf, int ld_tsdf, const float *feat_all, int ld_feat,
+                           int c_all, int c_feat, int64_t n, int batch, int32_t *out_coords, float *out_tsdf,
+                           float *out_occ, float *out_all, float *out_feat, int32_t *counts, void *workspace,
+                           size_t workspace_bytes, void *stream);
+/*
  * NeuConNet.upsample (models/neucon_network.py:193-214): up_coords int32[8n,4], up_feat f32[8n,C];
  * children of a voxel are consecutive, in the order 0, +x, +y, +z, +xy, +xz, +yz, +xyz (x `interval`).
  * channels == 0 expands the coordinates only.
