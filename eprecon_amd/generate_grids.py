@@ -15,8 +15,21 @@ def generate_grid(n_vox, interval, device=None):
     return grid, dims
 
 
+_DENSE_CACHE = {}
+
+
 def dense_coords(n_vox, interval, batch_size, device=None):
-    """int32[B*N, 4] (b, x, y, z): what models/neucon_network.py:246-251 builds from generate_grid."""
+    """int32[B*N, 4] (b, x, y, z): what models/neucon_network.py:246-251 builds from generate_grid.  The raster of a
+    (volume, interval, batch size, device) is constant: built once (a dozen small launches) and handed out read-only."""
+    key = (tuple(int(v) for v in n_vox), int(interval), int(batch_size), str(device))
+    hit = _DENSE_CACHE.get(key)
+    if hit is None:
+        hit = _dense_coords(n_vox, interval, batch_size, device)
+        _DENSE_CACHE[key] = hit
+    return hit
+
+
+def _dense_coords(n_vox, interval, batch_size, device=None):
     grid, dims = generate_grid(n_vox, interval, device)
     xyz = grid.t().to(torch.int32)
     rows = [torch.cat([torch.full((xyz.shape[0], 1), b, dtype=torch.int32, device=xyz.device), xyz], 1)

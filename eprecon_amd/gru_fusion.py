@@ -242,6 +242,7 @@ class GRUFusion(nn.Module):
                 occ_target = tsdf_target.abs() < 1
 
             values = None if recording else torch.empty((n_u, cin), dtype=torch.float32, device=dev)
+            pts_c = None
             if recording and self._identity_fusion:
                 values = x_all
             elif recording:
@@ -283,13 +284,15 @@ class GRUFusion(nn.Module):
                 rel_t = torch.tensor(rel_l, dtype=torch.int32, device=dev)
                 self._xchg.mark_fused(scale, updated + rel_t, self._cur_fragment)
 
-            out_c.append(torch.cat([torch.full_like(updated[:, :1], i), updated * interval], dim=1))
+            # (batch element 0: the rows the aligned-camera transform was given are these coordinates already)
+            out_c.append(pts_c if (i == 0 and pts_c is not None) else
+                         torch.cat([torch.full_like(updated[:, :1], i), updated * interval], dim=1))
             out_v.append(values)
             if tsdf_target is not None:
                 out_t.append(tsdf_target)
                 out_o.append(occ_target)
         if not out_c:
             return None, None, None, None
-        coords_all = torch.cat(out_c).to(self.coords_dtype)
-        return (coords_all, torch.cat(out_v), torch.cat(out_t) if out_t else None,
-                torch.cat(out_o) if out_o else None)
+        cat1 = lambda parts: parts[0] if len(parts) == 1 else torch.cat(parts)     # (one batch element: no copy)
+        coords_all = cat1(out_c).to(self.coords_dtype)
+        return (coords_all, cat1(out_v), cat1(out_t) if out_t else None, cat1(out_o) if out_o else None)

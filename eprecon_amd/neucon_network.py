@@ -210,8 +210,11 @@ class NeuConNet(nn.Module):
                 return outputs, loss_dict
             volume, up_coords, _, _, count = project_output
             if i != 0:
-                keep = count >= min_view_number
-                feat = torch.cat([volume, up_feat if bool(keep.all()) else up_feat[keep]], dim=1)
+                if min_view_number <= 0:       # (the view count is never negative: every voxel is kept, no host read)
+                    feat = torch.cat([volume, up_feat], dim=1)
+                else:
+                    keep = count >= min_view_number
+                    feat = torch.cat([volume, up_feat if bool(keep.all()) else up_feat[keep]], dim=1)
             else:
                 feat = volume
 
