@@ -66,7 +66,9 @@ def unique_coords(coords, quantum=1):
     grid = HashGrid(n, dev)
     inverse = torch.empty(n, dtype=torch.int32, device=dev)
     uniq = torch.empty((n, 4), dtype=torch.int32, device=dev)
-    n_unique = torch.zeros(1, dtype=torch.int32, device=dev)
+    # the count lands next to the table's status word (the table's 256-byte header): ONE 8-byte host read, no torch.cat
+    header = grid.mem[:8].view(torch.int32)
+    n_unique = header[1:2]
     ws = _lib.workspace(lib.eprecon_unique_workspace_bytes(n), dev)
     _lib.check(lib.eprecon_unique_coords_async(_lib.ptr(coords), n, quantum, _lib.ptr(grid.mem),
                                                grid.capacity, _lib.ptr(inverse), _lib.ptr(uniq),
@@ -75,7 +77,7 @@ def unique_coords(coords, quantum=1):
     # one host read for the voxel count AND the table's status word (bit 0: a key out of the packable range —
     # |coordinate| >= 2^19 - 1 or batch > 14 —, bit 1: table full): such voxels would otherwise silently drop out of
     # every kernel map built on this set
-    m, status = torch.cat([n_unique, grid.mem[:4].view(torch.int32)]).tolist()
+    status, m = header.tolist()
     if status:
         raise _lib.EpreconError(f"hash grid: {'coordinate / batch index out of range' if status & 1 else 'table full'} "
                                 f"(status {status}, EPRECON_ERR_UNSUPPORTED)")
