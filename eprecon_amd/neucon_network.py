@@ -377,20 +377,26 @@ class NeuConNet(nn.Module):
         """ancestor pruning of the coarser levels, 48-channel projections, mask features, decoder (:516-581); fills
         outputs['panoptic_levels'] and outputs['panoptic_out'] on the current stream"""
         keep1, keep0 = self.prune_to_ancestors(panoptic_coords)
-        panoptic_coords[1], panoptic_voxel_feats[1] = panoptic_coords[1][keep1], panoptic_voxel_feats[1][keep1]
-        panoptic_coords[0], panoptic_voxel_feats[0] = panoptic_coords[0][keep0], panoptic_voxel_feats[0][keep0]
+        # (one nonzero per level, shared by the coordinates and the features: boolean indexing runs it once per tensor)
+        i1, i0 = torch.nonzero(keep1).squeeze(1), torch.nonzero(keep0).squeeze(1)
+        panoptic_coords[1], panoptic_voxel_feats[1] = panoptic_coords[1].index_select(0, i1), panoptic_voxel_feats[1].index_select(0, i1)
+        panoptic_coords[0], panoptic_voxel_feats[0] = panoptic_coords[0].index_select(0, i0), panoptic_voxel_feats[0].index_select(0, i0)
         for p in range(3):
             panoptic_voxel_feats[p] = self.panoptic_preds[p](panoptic_voxel_feats[p])
         outputs["panoptic_levels"] = []
         panoptic_predictions = []
         for b in range(bs):
-            rows = [torch.nonzero(panoptic_coords[p][:, 0] == b).squeeze(1) for p in range(3)]
-            c2 = panoptic_coords[2][rows[2]]
+            if bs == 1:     # every row belongs to batch element 0: no row selection (3 x nonzero + 8 gathers + 3 host reads)
+                sel = lambda t, p: t
+            else:
+                rows = [torch.nonzero(panoptic_coords[p][:, 0] == b).squeeze(1) for p in range(3)]
+                sel = lambda t, p, rows=rows: t[rows[p]]
+            c2 = sel(panoptic_coords[2], 2)
             mask_features = self.panoptic_feat_fusion.generate_mask_features(
-                panoptic_feats=panoptic_voxel_feats[2][rows[2]], coords_b=torch.zeros_like(c2[:, 0]),
+                panoptic_feats=sel(panoptic_voxel_feats[2], 2), coords_b=torch.zeros_like(c2[:, 0]),
                 coords_xyz=c2[:, 1:], batch_size=1, spitial_shape=PANOPTIC_SHAPE)
-            feats_b = [panoptic_voxel_feats[p][rows[p]].unsqueeze(0).permute(0, 2, 1) for p in range(3)]
-            coords_b = [panoptic_coords[p][rows[p]][..., 1:].unsqueeze(0) for p in range(3)]
+            feats_b = [sel(panoptic_voxel_feats[p], p).unsqueeze(0).permute(0, 2, 1) for p in range(3)]
+            coords_b = [sel(panoptic_coords[p], p)[..., 1:].unsqueeze(0) for p in range(3)]
             outputs["panoptic_levels"].append({"features": feats_b, "coords": coords_b,
                                                "mask_features": mask_features})
             if self.panoptic is not None:
