@@ -108,6 +108,7 @@ SIGNATURES = {
     "eprecon_profile_conv_ms": (_f, [_c.POINTER(_i64), _c.POINTER(_c.c_char_p)]),
     "eprecon_profile_conv_pairs": (_i64, []),
     "eprecon_profile_mark_async": (_i, [_i, _vp]),
+    "eprecon_conv_desc_workspace_bytes": (_sz, [_vp]),
     "eprecon_sparsify_workspace_bytes": (_sz, [_i64]),
     "eprecon_sparsify_async": (_i, [_vp, _i, _f, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _sz, _vp]),
@@ -199,7 +200,8 @@ class ConvDesc(ctypes.Structure):
                 ("ln_eps", ctypes.c_float), ("ln_post_relu", ctypes.c_int),
                 ("img_h", ctypes.c_int), ("img_w", ctypes.c_int), ("img_maps", ctypes.c_int),
                 ("vox_rank", ctypes.c_void_p), ("grid_x", ctypes.c_int), ("grid_y", ctypes.c_int), ("grid_z", ctypes.c_int),
-                ("packed_weight", ctypes.c_void_p), ("packed_weight16", ctypes.c_void_p)]
+                ("packed_weight", ctypes.c_void_p), ("packed_weight16", ctypes.c_void_p),
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t)]
 
 
 _WORKSPACES = {}

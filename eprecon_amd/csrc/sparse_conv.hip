@@ -2057,6 +2057,216 @@ int launch_splitk_v(ConvParams &p, hipStream_t st)
     return EPRECON_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Medium lists with wide channels (4k .. 40k rows, C_in >= 96, 64 < C_out <= 128: the coarsest level's ConvGRU and SPVCNN's
+// up-stage).  The split-K kernel above is operand-bandwidth-bound there (a 64-row x 32-column workgroup
+// fetches 384 B per input channel for 4,096 flops = 10.7 flops per byte out of L2).  Here a workgroup owns 128 rows x ALL
+// columns: each (offset, 32-channel slab) of the operand-order packed weights (p.wq) is copied ONCE into LDS (double-buffered,
+// one barrier per stage) and feeds the four waves' 32 rows x 3..4 column tiles — 27 flops per byte —, the gathers of the next
+// stage are in flight meanwhile.  128-row workgroups alone would leave most CUs idle (74 for 9,415 rows), so the 27 offsets are
+// split ACROSS workgroups (blockIdx.y): every split writes its accumulators as they sit in registers to the caller's
+// workspace, and spconv_wide_reduce_kernel adds the splits in order and runs the shared epilogue.  Deterministic; the
+// summation order differs from the other kernels' (equal within round-off).
+// ---------------------------------------------------------------------------------------------
+constexpr int kWideRows = 128;
+constexpr int kWideSlabF4 = 2 * 512;   // float4 per staged slab: 2 column blocks x [4 chunks][2 halves][2 tiles][32 columns]
+
+inline int wide_splits(int n_out)
+{
+    // workgroups wanted per launch (three fit a CU): EPRECON_CONV_WIDEK_TARGET, read per launch
+    const char *e = getenv("EPRECON_CONV_WIDEK_TARGET");
+    const int target = e ? atoi(e) : 640;   // (320: 165 us on 9,415 rows 192 -> 96 — one workgroup per CU —, 640: 123 us)
+    const int blocks = (int)ceil_div(n_out, kWideRows);
+    return max(2, min(13, (target + blocks / 2) / blocks));
+}
+
+template <int NTT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void spconv_wide_kernel(ConvParams p, int nsplit, float *partial)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, half = lane >> 5;
+    const int nch8 = (p.Cin + 7) / 8, nslab = (p.Cin + 31) / 32, cinA = (p.Cin + 3) & ~3;
+    const int split = (int)blockIdx.y;
+    const int k0 = split * p.K / nsplit, k1 = (split + 1) * p.K / nsplit, nk = k1 - k0;
+    const int kmax = (p.K + nsplit - 1) / nsplit + 1;
+    float4 *sB = reinterpret_cast<float4 *>(smem);                       // [2][kWideSlabF4]
+    int *sNbr = reinterpret_cast<int *>(sB + 2 * kWideSlabF4);           // [kmax][kWideRows]
+    float *sAff = reinterpret_cast<float *>(sNbr + kmax * kWideRows);    // [2][cinA]
+    const int row0 = (int)blockIdx.x * kWideRows;
+
+    for (int e = tid; e < nk * kWideRows; e += 256) {
+        const int kk = e / kWideRows, r = e - kk * kWideRows;
+        const int row = row0 + r;
+        sNbr[e] = row < p.n_out ? p.nbr[(size_t)(k0 + kk) * p.n_out + row] : -1;
+    }
+    if (p.in_scale)
+        for (int c = tid; c < cinA; c += 256) {
+            sAff[c] = c < p.Cin ? p.in_scale[c] : 0.0f;
+            sAff[cinA + c] = c < p.Cin ? p.in_shift[c] : 0.0f;
+        }
+
+    f32x16 acc[NTT];
+#pragma unroll
+    for (int t = 0; t < NTT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // packed layout (pack_weights_kernel, NT = 2): float4 index ((cb * K + k) * nch8 + chunk) * 128 + (half * 2 + t) * 32 + col
+    const float4 *wq4 = reinterpret_cast<const float4 *>(p.wq);
+    auto slab_src = [&](int st, int e) -> const float4 * {
+        const int kk = st / nslab, sl = st - kk * nslab;
+        const int cb = e >> 9, i = e & 511;
+        const int chunk = min(4 * sl + (i >> 7), nch8 - 1);   // (a chunk past C_in multiplies zeros)
+        return wq4 + ((size_t)(cb * p.K + k0 + kk) * nch8 + chunk) * 128 + (i & 127);
+    };
+    struct StageA {
+        float4 a[4];
+        int j, c0;
+    };
+    auto fetch_a = [&](int st, StageA &g) {
+        const int kk = st / nslab, sl = st - kk * nslab;
+        g.c0 = sl * 32;
+        g.j = sNbr[kk * kWideRows + wave * 32 + r32];
+        const float *xrow = p.x + (size_t)max(g.j, 0) * p.ld_x;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) g.a[ch] = *reinterpret_cast<const float4 *>(xrow + min(g.c0 + ch * 8 + 4 * half, cinA - 4));
+    };
+    const int nst = nk * nslab;
+    __syncthreads();   // sNbr / sAff are written
+    static_assert(kWideSlabF4 == 4 * 256, "four float4 of a slab per thread");
+    StageA cur, nxt;
+    {
+        const float4 s0 = *slab_src(0, tid), s1 = *slab_src(0, tid + 256), s2 = *slab_src(0, tid + 512), s3 = *slab_src(0, tid + 768);
+        sB[tid] = s0; sB[tid + 256] = s1; sB[tid + 512] = s2; sB[tid + 768] = s3;
+    }
+    fetch_a(0, cur);
+    for (int st = 0; st < nst; ++st) {
+        const int stn = min(st + 1, nst - 1);
+        // (named values, not an array: the array form was kept on the stack — scratch stores behind vmcnt waits in the loop)
+        const float4 b0 = *slab_src(stn, tid), b1 = *slab_src(stn, tid + 256), b2 = *slab_src(stn, tid + 512), b3 = *slab_src(stn, tid + 768);
+        fetch_a(stn, nxt);
+        __syncthreads();   // slab st is in LDS; every wave is done with slab st - 1
+        const float4 *buf = sB + (st & 1) * kWideSlabF4;
+        const int c0 = cur.c0;
+        float a[4][4];
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            a[ch][0] = cur.a[ch].x; a[ch][1] = cur.a[ch].y; a[ch][2] = cur.a[ch].z; a[ch][3] = cur.a[ch].w;
+        }
+        if (p.in_scale) {
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                const int cc = min(c0 + ch * 8 + 4 * half, cinA - 4);
+                const float4 sc4 = *reinterpret_cast<const float4 *>(sAff + cc);
+                const float4 sh4 = *reinterpret_cast<const float4 *>(sAff + cinA + cc);
+                const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float x = fmaf(a[ch][q], sc[q], sh[q]);
+                    a[ch][q] = p.in_relu ? fmaxf(x, 0.0f) : x;
+                }
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const int c = c0 + ch * 8 + 4 * half;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[ch][q] = (cur.j >= 0 && c + q < p.Cin) ? a[ch][q] : 0.0f;
+        }
+        const int nch = min(4, nch8 - c0 / 8);
+        if (!(p.debug & 1)) {
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                if (ch < nch) {   // (uniform)
+                    float4 b4[NTT];
+#pragma unroll
+                    for (int t = 0; t < NTT; ++t) b4[t] = buf[(t >> 1) * 512 + ch * 128 + (half * 2 + (t & 1)) * 32 + r32];
+#pragma unroll
+                    for (int t = 0; t < NTT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ch][0], b4[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < NTT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ch][1], b4[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < NTT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ch][2], b4[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < NTT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ch][3], b4[t].w, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        float4 *nbuf = sB + ((st + 1) & 1) * kWideSlabF4;   // read last in stage st - 1: every wave is past this stage's barrier
+        nbuf[tid] = b0; nbuf[tid + 256] = b1; nbuf[tid + 512] = b2; nbuf[tid + 768] = b3;
+        cur = nxt;
+    }
+    // accumulators as they sit in the registers: [split][row block][wave][tile][16][64 lanes]
+    float *dst = partial + ((((size_t)split * gridDim.x + blockIdx.x) * kWaves + wave) * NTT) * 1024 + lane;
+#pragma unroll
+    for (int t = 0; t < NTT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(t * 16 + r) * 64] = acc[t][r];
+}
+
+template <int NTT>
+__global__ __launch_bounds__(256) void spconv_wide_reduce_kernel(ConvParams p, int nsplit, const float *partial)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *sStat = reinterpret_cast<float *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, half = lane >> 5;
+    f32x16 acc[NTT];
+#pragma unroll
+    for (int t = 0; t < NTT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    for (int s = 0; s < nsplit; ++s) {   // fixed order
+        const float *src = partial + ((((size_t)s * gridDim.x + blockIdx.x) * kWaves + wave) * NTT) * 1024 + lane;
+#pragma unroll
+        for (int t = 0; t < NTT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] += src[(t * 16 + r) * 64];
+    }
+    conv_epilogue<NTT>(p, acc, LinearRows{(int)blockIdx.x * kWideRows + wave * 32, p.n_out}, 0, r32, half, wave, sStat,
+                       (int)blockIdx.x, 1);
+}
+
+size_t wide_workspace_bytes(const ConvParams &p)
+{
+    const int ntt = (p.Cout + 31) / 32;
+    return (size_t)wide_splits(p.n_out) * (size_t)ceil_div(p.n_out, kWideRows) * kWaves * ntt * 1024 * sizeof(float);
+}
+
+// shape / alignment rule of the kernel pair, independent of the workspace (EPRECON_CONV_WIDEK=0 switches it off; per launch)
+bool wide_shape_ok(const ConvParams &p)
+{
+    const char *e = getenv("EPRECON_CONV_WIDEK");
+    if (e && e[0] == '0') return false;
+    if (p.K != 27 || !p.nbr || !p.wq || (reinterpret_cast<uintptr_t>(p.wq) & 15) != 0) return false;
+    if (p.Cin < 96 || p.Cin % 4 != 0 || p.Cout <= 64 || p.Cout > 128) return false;
+    if (p.ld_x % 4 != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0) return false;
+    if (p.in_scale && ((reinterpret_cast<uintptr_t>(p.in_scale) & 15) != 0 || (reinterpret_cast<uintptr_t>(p.in_shift) & 15) != 0))
+        return false;
+    if (p.accumulate || p.ln || p.bn_scale_out) return false;
+    return p.n_out >= 4096 && p.n_out <= 40000;
+}
+bool wide_ok(const ConvParams &p) { return wide_shape_ok(p) && p.ws && p.ws_bytes >= wide_workspace_bytes(p); }
+
+template <int NTT>
+int launch_wide_t(const ConvParams &p, hipStream_t st)
+{
+    const int nsplit = wide_splits(p.n_out);
+    const int blocks = (int)ceil_div(p.n_out, kWideRows);
+    const int kmax = (p.K + nsplit - 1) / nsplit + 1;
+    const size_t lds = (size_t)2 * kWideSlabF4 * sizeof(float4) + (size_t)kmax * kWideRows * sizeof(int) +
+                       (size_t)2 * ((p.Cin + 3) & ~3) * sizeof(float) + 16;
+    float *partial = reinterpret_cast<float *>(p.ws);
+    hipLaunchKernelGGL((spconv_wide_kernel<NTT>), dim3((unsigned)blocks, (unsigned)nsplit), dim3(256), lds, st, p, nsplit, partial);
+    EP_LAUNCH_CHECK();
+    const size_t lds2 = (size_t)max(kWaves * 3 * 32 * NTT, 3 * 256) * sizeof(float);
+    hipLaunchKernelGGL((spconv_wide_reduce_kernel<NTT>), dim3((unsigned)blocks), dim3(256), lds2, st, p, nsplit, (const float *)partial);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+int launch_wide(const ConvParams &p, hipStream_t st) { return (p.Cout + 31) / 32 == 3 ? launch_wide_t<3>(p, st) : launch_wide_t<4>(p, st); }
+
 // short list + long (offset, slab) chain + a caller that can take 32-row BatchNorm summary blocks
 bool splitk_ok(const ConvParams &p)
 {
@@ -2195,6 +2405,11 @@ int conv_dispatch_inner(ConvParams &p, int64_t n_in, hipStream_t st)
     const int nt_full = (p.Cout + 31) / 32;
     if (p.ln && (nt_full > 4 || p.bn_partial || p.accumulate)) return EPRECON_ERR_UNSUPPORTED;
     p.bn_rows = (int)ceil_div(p.n_out, kRowsPerBlock);  // the gather forms: 128-row blocks (split-K: 32-row blocks)
+    if (wide_ok(p)) {
+        g_last_conv_kernel = "spconv_wide_kernel";
+        p.debug = getenv("EPRECON_D3_ABLATE") ? atoi(getenv("EPRECON_D3_ABLATE")) : 0;
+        return launch_wide(p, st);
+    }
     if (!direct2d && splitk_ok(p)) {
         g_last_conv_kernel = "spconv_splitk_kernel";
         p.bn_rows = (int)ceil_div(p.n_out, 32);
@@ -2358,6 +2573,7 @@ static void params_from_desc(ConvParams &p, const eprecon_conv_desc *d)
     p.img_h = d->img_h; p.img_w = d->img_w; p.img_maps = d->img_maps;
     p.vox_rank = d->vox_rank; p.gx = d->grid_x; p.gy = d->grid_y; p.gz = d->grid_z; p.wq = d->packed_weight;
     p.wq16 = d->packed_weight16;
+    p.ws = d->workspace; p.ws_bytes = d->workspace_bytes;
     p.flex_partial = 1;
 }
 
@@ -2367,6 +2583,15 @@ extern "C" int eprecon_conv_desc_async(const eprecon_conv_desc *d, void *stream)
     ConvParams p = {};
     params_from_desc(p, d);
     return conv_check_and_run(p, d->n_in, d->n_out, stream);
+}
+
+extern "C" size_t eprecon_conv_desc_workspace_bytes(const eprecon_conv_desc *d)
+{
+    if (!d || d->n_out <= 0 || d->n_out > 0x7fffffff) return 0;
+    ConvParams p = {};
+    params_from_desc(p, d);
+    p.n_out = (int)d->n_out;
+    return wide_shape_ok(p) ? wide_workspace_bytes(p) : 0;
 }
 
 // rows of bn_partial the launch described by `d` writes (= the nblk to hand to
@@ -2384,6 +2609,7 @@ extern "C" int64_t eprecon_conv_desc_partial_rows(const eprecon_conv_desc *d)
     p.x_bytes = d->n_in > 0 ? ((d->n_in - 1) * (int64_t)p.ld_x + ((p.Cin + 3) & ~3)) * 4 : 0;
     if (p.K == 9 && direct16_ok(p)) return ep::ceil_div(d->n_out, (int64_t)kDirectRows);
     if (conv2d_tile_ok(p, &nt, &nch, &blocks)) return blocks;
+    if (wide_ok(p)) return ep::ceil_div(d->n_out, (int64_t)kWideRows);
     if (splitk_ok(p)) return ep::ceil_div(d->n_out, (int64_t)32);
     if (direct16_ok(p)) return ep::ceil_div(d->n_out, (int64_t)kDirectRows);
     return ep::ceil_div(d->n_out, (int64_t)kRowsPerBlock);

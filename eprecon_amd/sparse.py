@@ -272,6 +272,17 @@ class VoxelSet:
         return self._down
 
 
+def _attach_workspace(desc, device):
+    """scratch for the kernels that reduce partial sums across workgroups (medium lists with wide channels): the library says
+    how much the described launch wants (0 for every other shape); returns the buffer to keep alive until the launch is queued"""
+    need = int(_lib.load().eprecon_conv_desc_workspace_bytes(ctypes.byref(desc)))
+    if not need:
+        return None
+    ws = _lib.workspace(need, device)
+    desc.workspace, desc.workspace_bytes = ws.data_ptr(), ws.numel()
+    return ws
+
+
 def sparse_conv(x, weight, nbr=None, bias=None, out=None, relu=False, accumulate=False):
     """out[i] (op)= bias + sum_k x[nbr[k][i]] @ weight[k].  weight f32[K, Cin, Cout] (or [Cin, Cout]
     with nbr None: a per-voxel linear layer).  x / out may be column slices of wider buffers."""
@@ -325,6 +336,7 @@ def sparse_conv_fused(x, weight, nbr=None, bias=None, out=None, relu=False, resi
         d.out, d.ld_out = out.data_ptr(), _ld(out)
         d.relu, d.accumulate = int(relu), int(accumulate)
         keep = _resolve_map(nbr, x, weight, d, accumulate=accumulate, stats=bn_partial)
+        keep.append(_attach_workspace(d, x.device))
         partial = None
         if bn_partial:
             partial = torch.empty((max(int(lib.eprecon_conv_desc_partial_rows(ctypes.byref(d))), 1), 3, cout),
@@ -450,6 +462,7 @@ def conv_stats(x, weight, nbr=None, in_affine=None, out=None, bias=None, bn=None
         d.bn_scale_out, d.bn_shift_out = a[0].data_ptr(), a[1].data_ptr()
         d.bn_gamma, d.bn_beta, d.bn_eps = _lib.ptr(gamma), _lib.ptr(beta), float(eps)
         d.bn_ticket = 1   # placeholder: any non-null value while the rows are computed
+    keep.append(_attach_workspace(d, x.device))
     rows = max(int(lib.eprecon_conv_desc_partial_rows(ctypes.byref(d))), 1)
     partial = torch.empty((rows, 3, cout), dtype=torch.float32, device=x.device)
     d.bn_partial = partial.data_ptr()

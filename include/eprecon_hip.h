@@ -278,8 +278,13 @@ typedef struct eprecon_conv_desc {
      * Results equal those kernels' within fp32 round-off (four input channels per MFMA instead of two: another summation
      * order); the torchsparse / spconv layers this replaces (models/modules.py:15-72, 178-222) make no ordering promise. */
     const float *packed_weight16;
+    /* scratch for kernels that reduce partial sums across workgroups (medium lists with wide channels, 3x3x3, with
+     * packed_weight): eprecon_conv_desc_workspace_bytes(desc) bytes (0: none needed); without it those shapes stay on the
+     * short-list kernel */
+    void *workspace; size_t workspace_bytes;
 } eprecon_conv_desc;
 int eprecon_conv_desc_async(const eprecon_conv_desc *desc, void *stream);
+size_t eprecon_conv_desc_workspace_bytes(const eprecon_conv_desc *desc);
 size_t eprecon_conv_bn_finalize_workspace_bytes(int64_t partial_rows, int cout);
 /* number of bn_partial rows the launch described by desc writes (nblk of the finalize call) */
 int64_t eprecon_conv_desc_partial_rows(const eprecon_conv_desc *desc);

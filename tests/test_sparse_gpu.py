@@ -260,11 +260,12 @@ def test_direct_gather_kernel_on_a_long_list(cin, cout):
 
 @pytest.mark.parametrize("n,cin,cout", [(204, 64, 128), (204, 128, 128), (1532, 160, 96), (1532, 64, 64), (1532, 32, 64),
                                         (7561, 32, 32), (9415, 192, 96)])
-def test_short_list_kernel(n, cin, cout):
+def test_short_list_kernel(monkeypatch, n, cin, cout):
     """SPVCNN's stride-2 / stride-4 levels and the coarse ConvGRU: the split-K kernel with 4 / 8 / 16 waves per workgroup
     (pipelined stages, narrow inputs included), with the producer's pending BatchNorm on load and the BatchNorm summaries
     of the output in 32-row blocks"""
     from eprecon_amd import sparse as SP
+    monkeypatch.setenv("EPRECON_CONV_WIDEK", "0")      # (the 9,415-row case is the cross-workgroup kernel's by default)
     rng = np.random.default_rng(n + cin + cout)
     extent = max(4, int(round((n / 0.3) ** (1 / 3))))
     c = random_coords(rng, n, extent=extent, batch=1)
@@ -286,3 +287,38 @@ def test_short_list_kernel(n, cin, cout):
     tot_mean = (cnt * mean).sum(0) / n
     tot_m2 = (m2 + cnt * (mean - tot_mean) ** 2).sum(0)
     assert np.abs(tot_mean - ref.mean(0)).max() < 1e-4 and np.abs(tot_m2 / n - ref.var(0)).max() < 1e-3
+
+
+@pytest.mark.parametrize("n,cin,cout", [(9415, 192, 96), (11880, 160, 80), (6000, 128, 128), (4200, 100, 72), (30011, 96, 96)])
+def test_medium_list_wide_kernel(n, cin, cout):
+    """medium lists with wide channels (the coarsest level's ConvGRU, SPVCNN's up-stage): 128-row workgroups over all columns,
+    weight slabs shared through LDS, the 27 offsets split across workgroups, partial sums added in order by the reduce kernel
+    which runs the shared epilogue (bias + ReLU + residual, pending BatchNorm on load, 128-row summaries)"""
+    from eprecon_amd import sparse as SP
+    rng = np.random.default_rng(n + cin + cout)
+    extent = max(4, int(round((n / 0.3) ** (1 / 3))))
+    c = random_coords(rng, n, extent=extent, batch=1)
+    n = len(c)
+    x = rng.standard_normal((n, cin)).astype(np.float32)
+    w = (rng.standard_normal((27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((n, cout)).astype(np.float32)
+    vs = SP.VoxelSet(dev(c))
+    nbr_d, nbr = vs.kernel_map(3), OS.kernel_map(c, c, 3, 1)
+    ref = OS.sparse_conv(x, nbr, w, b)
+    (y, part), name = _last_conv_kernel((27, cin, cout, 1), lambda: SP.sparse_conv_fused(
+        dev(x), dev(w), nbr_d, dev(b), relu=True, residual=dev(res), bn_partial=True))
+    assert name == "spconv_wide_kernel"
+    want = np.maximum(ref, 0) + res
+    assert np.abs(y.cpu().numpy() - want).max() < TOL
+    part = part.cpu().numpy().astype(np.float64)
+    assert part.shape[0] == (n + 127) // 128 and part[:, 0, 0].sum() == n
+    cnt, mean, m2 = part[:, 0], part[:, 1], part[:, 2]
+    tot_mean = (cnt * mean).sum(0) / n
+    tot_m2 = (m2 + cnt * (mean - tot_mean) ** 2).sum(0)
+    assert np.abs(tot_mean - want.mean(0)).max() < 1e-4 and np.abs(tot_m2 / n - want.var(0)).max() < 1e-3
+    sc = rng.uniform(0.5, 1.5, cin).astype(np.float32)
+    sh = rng.standard_normal(cin).astype(np.float32)
+    y2, _ = SP.conv_stats(dev(x), dev(w), nbr_d, in_affine=(dev(sc), dev(sh), True))
+    ref2 = OS.sparse_conv(np.maximum(x * sc + sh, 0), nbr, w)
+    assert np.abs(y2.cpu().numpy() - ref2).max() < TOL
