@@ -29,6 +29,6 @@ python tools/summarize_cfg4_layers.py $L > $O/profiles_r03/cfg4_layers.txt 2> $L
 rm -f $L/r_kernel_trace.csv
 # the 3x3x3 shapes of that fragment one by one: this round's kernels against round 2's selection
 python tools/conv_shapes_ab.py round3 > $L/shapes_r3.txt 2>&1
-EPRECON_CONV_DIRECT=0 EPRECON_CONV_SPLITK_PIPE=0 EPRECON_CONV_SPLITK_NARROW=0 EPRECON_CONV_SPLITK_WAVES=4 python tools/conv_shapes_ab.py round2 > $L/shapes_r2.txt 2>&1
+EPRECON_CONV_DIRECT=0 EPRECON_CONV_WIDEK=0 EPRECON_CONV_SPLITK_BDIRECT=0 EPRECON_CONV_SPLITK_PIPE=0 EPRECON_CONV_SPLITK_NARROW=0 EPRECON_CONV_SPLITK_WAVES=4 python tools/conv_shapes_ab.py round2 > $L/shapes_r2.txt 2>&1
 paste -d'|' <(cut -c1-62 $L/shapes_r2.txt) <(cut -c52-62 $L/shapes_r3.txt) | grep -v amdgpu.ids > $O/profiles_r03/conv_shapes.txt
 ls $O/profiles_r03
