@@ -7,7 +7,7 @@ rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cd $R
 i=0
-for c in "GRBM_GUI_ACTIVE GRBM_COUNT" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAVES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VMEM_RD"; do
+for c in "GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAVES" ; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/p$i -o r -- python tools/conv_shapes_ab.py pmc > $O/p$i.log 2>&1
   echo "pass $i rc=$?"
@@ -26,7 +26,7 @@ for d in sorted(glob.glob(O+'/p*/')):
     agg=collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows:
         n=r['Kernel_Name']
-        if 'direct16' not in n and 'tile16' not in n and 'resident' not in n: continue
+        if 'direct16' not in n and 'tile16' not in n and 'resident' not in n and 'wide' not in n and 'splitk' not in n: continue
         key=(n.split('(')[0][-45:], r['Grid_Size'])
         agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
         agg[key]['dur_us'].append(dur.get(r['Dispatch_Id'],0))
