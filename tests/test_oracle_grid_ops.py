@@ -49,3 +49,21 @@ def test_init_selection(gold):
     got = OG.init_select(logit, coords, 1)
     assert len(got) > 100
     assert np.array_equal(got[:, 1:], gold["sel_coords"]) and not got[:, 0].any()
+
+
+def test_dense_coords_is_built_once_per_shape_and_matches_generate_grid():
+    """eprecon_amd.generate_grids.dense_coords hands out one cached raster per (volume, interval, batch size, device): same
+    object on the second call, rows = [b, x, y, z] of generate_grid's x-major raster (models/neucon_network.py:246-251)"""
+    import torch
+    from eprecon_amd.generate_grids import dense_coords, generate_grid
+    a, dims = dense_coords((24, 16, 8), 4, 2, device=torch.device("cpu"))
+    b, dims_b = dense_coords((24, 16, 8), 4, 2, device=torch.device("cpu"))
+    assert a is b and dims == dims_b == (6, 4, 2)
+    grid, _ = generate_grid((24, 16, 8), 4, device=torch.device("cpu"))
+    n = grid.shape[1]
+    assert a.shape == (2 * n, 4) and a.dtype == torch.int32
+    for batch in range(2):
+        rows = a[batch * n:(batch + 1) * n]
+        assert bool((rows[:, 0] == batch).all()) and torch.equal(rows[:, 1:], grid.t().to(torch.int32))
+    other, _ = dense_coords((24, 16, 8), 2, 2, device=torch.device("cpu"))
+    assert other is not a and other.shape[0] == 2 * 12 * 8 * 4
