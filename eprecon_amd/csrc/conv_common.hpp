@@ -49,7 +49,7 @@ struct ConvParams {
     int gx, gy, gz;
     const float *wq;    // ... for the 32-row tile kernel (pack_weights_kernel)
     const float *wq16;  // ... for the 16-row tile kernel (pack_weights16_kernel)
-    int debug;  // EPRECON_D3_ABLATE (timing experiments only): 1 no MFMA loop, 4 no halo row loads
+    int debug;  // EPRECON_D3_ABLATE (timing experiments only): 1 no MFMA loop, 2 tile16: weights from the first offset, 4 no halo row loads
     int splitk_pipe;  // split-K kernel: 1 software-pipelined stages, 2 also B operands straight from the packed weights (wq); 0 neither
     void *ws;         // caller's scratch (eprecon_conv_desc.workspace): partial sums of the cross-workgroup split-K kernel
     size_t ws_bytes;

@@ -1,5 +1,7 @@
-"""Timing-only ablations of the two 16x16x4 MFMA kernels (EPRECON_D3_ABLATE bits: 1 no MFMA loop, 2 every weight load from
-the first step's address (L1 hits), 8 gathers from the row itself (coalesced), 16 gathers sent out of range (no A traffic)):
+"""Timing-only ablations of the 16x16x4 MFMA kernels and the cross-workgroup split-K kernel (EPRECON_D3_ABLATE bits the current
+kernels honour: 1 no MFMA loop (prologue + epilogue only); 2 — 16-row tile kernel only — every weight load from the first
+offset's address (L1 hits)).  The first version of the direct gather kernel also had bits 8 (gathers from the row itself) and 16
+(gathers sent out of range): those measurements are in profiles/r03/conv_direct_ablate.txt.
     python tools/conv_ablate.py"""
 import os
 import sys
@@ -35,7 +37,10 @@ def main():
     cases.append(("tile16 94k 32->32", SP.DenseMap(vs, (48, 48, 48)), coords.shape[0], 32, 32, (0, 2, 1)))
     for n, ci, co in ((320868, 48, 24), (93513, 48, 48), (198184, 24, 24), (57444, 96, 48)):
         v = SP.VoxelSet(torch.from_numpy(coords_for(n, rng)).to(dev), 1)
-        cases.append((f"direct16 {n} {ci}->{co}", v.kernel_map(3), n, ci, co, (0, 2, 8, 16, 18, 1)))
+        cases.append((f"direct16 {n} {ci}->{co}", v.kernel_map(3), n, ci, co, (0, 1)))
+    for n, ci, co in ((9415, 192, 96), (11880, 160, 80)):
+        v = SP.VoxelSet(torch.from_numpy(coords_for(n, rng)).to(dev), 1)
+        cases.append((f"wide {n} {ci}->{co}", v.kernel_map(3), n, ci, co, (0, 1)))
     with torch.no_grad():
         for name, m, n, ci, co, abls in cases:
             x = torch.randn(n, ci, device=dev)
