@@ -26,9 +26,6 @@ SIGNATURES = {
     "eprecon_back_project": (_i, [_vp, _i64, _vp, _i, _f, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "eprecon_profile_gather_kernel": (_c.c_char_p, []),
-    "eprecon_back_project_dense_workspace_bytes": (_sz, [_i64, _i]),
-    "eprecon_back_project_dense_async": (_i, [_vp, _i, _vp, _i, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
-                                             _vp, _vp, _sz, _vp]),
     "eprecon_hash_capacity": (_c.c_uint32, [_i64]),
     "eprecon_hash_table_bytes": (_sz, [_c.c_uint32]),
     "eprecon_hash_build_async": (_i, [_vp, _i64, _i, _vp, _c.c_uint32, _vp]),
@@ -44,7 +41,6 @@ SIGNATURES = {
                                              _vp, _vp]),
     "eprecon_conv_desc_async": (_i, [_vp, _vp]),
     "eprecon_conv_desc_partial_rows": (_i64, [_vp]),
-    "eprecon_conv_bn_finalize_workspace_bytes": (_sz, [_i64, _i]),
     "eprecon_affine_rows_res_async": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "eprecon_batchnorm_finalize_affine_async": (_i, [_vp, _i64, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "eprecon_affine_rows_async": (_i, [_vp, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
@@ -52,6 +48,8 @@ SIGNATURES = {
     "eprecon_batchnorm_apply_workspace_bytes": (_sz, [_i]),
     "eprecon_batchnorm_apply_partials_async": (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp, _vp, _f, _vp, _i, _i, _vp, _i,
                                                     _vp, _vp, _vp, _sz, _vp]),
+    "eprecon_batchnorm_apply_partials_res_async": (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _vp,
+                                                        _i, _vp, _sz, _vp]),
     "eprecon_batchnorm_workspace_bytes": (_sz, [_i64, _i]),
     "eprecon_batchnorm_train_async": (_i, [_vp, _i64, _i, _i, _vp, _vp, _f, _vp, _i, _i, _vp, _i, _vp, _vp,
                                            _vp, _sz, _vp]),
@@ -107,6 +105,7 @@ SIGNATURES = {
     "eprecon_profile_conv_arm": (_i, [_i, _i, _i, _i64]),
     "eprecon_profile_conv_ms": (_f, [_c.POINTER(_i64), _c.POINTER(_c.c_char_p)]),
     "eprecon_profile_conv_pairs": (_i64, []),
+    "eprecon_profile_last_conv_kernel": (_c.c_char_p, []),
     "eprecon_profile_mark_async": (_i, [_i, _vp]),
     "eprecon_conv_desc_workspace_bytes": (_sz, [_vp]),
     "eprecon_sparsify_workspace_bytes": (_sz, [_i64]),
@@ -193,9 +192,6 @@ class ConvDesc(ctypes.Structure):
                 ("in_scale", ctypes.c_void_p), ("in_shift", ctypes.c_void_p), ("in_relu", ctypes.c_int),
                 ("res_scale", ctypes.c_void_p), ("res_shift", ctypes.c_void_p), ("res_relu", ctypes.c_int),
                 ("bn_partial", ctypes.c_void_p),
-                ("bn_scale_out", ctypes.c_void_p), ("bn_shift_out", ctypes.c_void_p),
-                ("bn_gamma", ctypes.c_void_p), ("bn_beta", ctypes.c_void_p), ("bn_eps", ctypes.c_float),
-                ("bn_ticket", ctypes.c_void_p),
                 ("ln", ctypes.c_int), ("ln_gamma", ctypes.c_void_p), ("ln_beta", ctypes.c_void_p),
                 ("ln_eps", ctypes.c_float), ("ln_post_relu", ctypes.c_int),
                 ("img_h", ctypes.c_int), ("img_w", ctypes.c_int), ("img_maps", ctypes.c_int),
@@ -216,3 +212,8 @@ def workspace(nbytes, device):
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
         _WORKSPACES[key] = buf
     return buf
+
+
+def last_conv_kernel():
+    """name of the kernel family the most recent convolution launch went to (eprecon_profile_last_conv_kernel)"""
+    return load().eprecon_profile_last_conv_kernel().decode()

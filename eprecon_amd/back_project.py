@@ -16,58 +16,14 @@ import torch.nn as nn
 
 from . import _lib
 
-import os
-
 MODE_MEAN, MODE_MEAN_DEPTH, MODE_VARIANCE = 0, 1, 2
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
-# EPRECON_BP_DENSE=1 sends dense grids to the brick kernel with LDS image patches (csrc/back_project_dense.hip).
-# Bit-identical results, but MEASURED SLOWER than the list kernel on MI355X (dense 96^3, C = 24: 155-186 us vs 119 us,
-# profiles/r02/bp_brick_ab.txt): the taps cost as many LDS reads as they cost L1 reads, and LDS bank conflicts eat the
-# 2.7x bandwidth advantage.  Off by default; kept as the closed structural experiment VERDICT r01 asked for.
-DENSE_BRICKS = os.environ.get("EPRECON_BP_DENSE", "0") == "1"
-DENSE_CHANNELS = (24, 32, 40, 80)
-
-
 def mark_dense(coords, dims, interval, batch=1):
     """Tag `coords` (int32[B*Dx*Dy*Dz, 4]) as the dense x-major raster of a dims grid at spacing `interval` — what
-    generate_grids.dense_coords / ops/generate_grids.py:3-10 produce.  Operators that receive such a list may use
-    the implicit-coordinate kernels; the tag is a plain attribute and is lost by any op that makes a new tensor."""
+    generate_grids.dense_coords / ops/generate_grids.py:3-10 produce.  A plain attribute (lost by any op that makes a new
+    tensor); nothing in the library branches on it since the brick kernel of round 2 was removed."""
     coords._eprecon_dense = (tuple(int(d) for d in dims), int(interval), int(batch))
     return coords
-
-
-def _dense_hint(coords, mode, channels, want_grid):
-    hint = getattr(coords, "_eprecon_dense", None)
-    if hint is None or not DENSE_BRICKS or want_grid or mode not in (MODE_MEAN, MODE_VARIANCE):
-        return None
-    dims, interval, batch = hint
-    voxb = 8 if channels <= 32 else (4 if channels <= 64 else 2)
-    if channels not in DENSE_CHANNELS or dims[1] % 8 or dims[2] % 8 or dims[0] % voxb or (dims[0] * dims[1] * dims[2]) % 256:
-        return None
-    if coords.shape[0] != batch * dims[0] * dims[1] * dims[2]:
-        return None
-    return hint
-
-
-def _launch_dense(lib, hint, origin_f, voxel_size, feats_c, layout, krcam_f, min_view, mode, t, n_valid_dev):
-    """queue eprecon_back_project_dense_async; feats in NCHW are re-laid out first (the list entry point does the
-    same inside its workspace)"""
-    dims, interval, batch = hint
-    v, b, c, h, w = feats_c.shape
-    dev = feats_c.device
-    if layout == LAYOUT_NCHW:
-        nhwc = torch.empty((v, b, h, w, c), dtype=torch.float32, device=dev)
-        _lib.check(lib.eprecon_nchw_to_nhwc_async(_lib.ptr(feats_c), _lib.ptr(nhwc), v * b, c, h * w,
-                                                   _lib.current_stream()), "eprecon_nchw_to_nhwc_async")
-        feats_c = nhwc
-        t["_nhwc"] = nhwc
-    n = batch * dims[0] * dims[1] * dims[2]
-    ws = _lib.workspace(lib.eprecon_back_project_dense_workspace_bytes(n, batch), dev)
-    dims_h = (ctypes.c_int32 * 3)(*dims)
-    return lib.eprecon_back_project_dense_async(
-        ctypes.cast(dims_h, ctypes.c_void_p), interval, _lib.ptr(origin_f), b, float(voxel_size), _lib.ptr(feats_c),
-        _lib.ptr(krcam_f), v, c, h, w, int(min_view), mode, _lib.ptr(t["feats"]), _lib.ptr(t["mean"]), _lib.ptr(t["coords"]),
-        _lib.ptr(t["count"]), _lib.ptr(n_valid_dev), _lib.ptr(ws), ws.numel(), _lib.current_stream())
 
 
 def _prep_feats(feats):
@@ -132,18 +88,13 @@ def run_async(coords, origin, voxel_size, feats, krcam, min_view, mode=MODE_MEAN
          "grid": torch.empty((v * n * 2,), dtype=torch.float32, device=dev) if want_grid else None,
          "mask": torch.empty((v * n,), dtype=torch.uint8, device=dev) if want_grid else None}
     n_valid_dev = torch.empty((1 + b,), dtype=torch.int32, device=dev)
-    hint = _dense_hint(coords, mode, c, want_grid)
-    rc = -3
-    if hint is not None:
-        rc = _launch_dense(lib, hint, origin_f, voxel_size, feats_c, layout, krcam_f, min_view, mode, t, n_valid_dev)
-    if rc == -3:   # EPRECON_ERR_UNSUPPORTED (or no dense hint): the list kernels
-        ws_bytes = lib.eprecon_back_project_workspace_bytes(n, b, v, c, h, w, layout)
-        ws = _lib.workspace(ws_bytes, dev)
-        rc = lib.eprecon_back_project_async(
-            _lib.ptr(coords_i), n, _lib.ptr(origin_f), b, float(voxel_size), _lib.ptr(feats_c), layout,
-            _lib.ptr(krcam_f), v, c, h, w, int(min_view), mode, _lib.ptr(t["feats"]), _lib.ptr(t["mean"]),
-            _lib.ptr(t["coords"]), _lib.ptr(t["count"]), _lib.ptr(t["grid"]), _lib.ptr(t["mask"]),
-            _lib.ptr(n_valid_dev), _lib.ptr(ws), ws.numel(), _lib.current_stream())
+    ws_bytes = lib.eprecon_back_project_workspace_bytes(n, b, v, c, h, w, layout)
+    ws = _lib.workspace(ws_bytes, dev)
+    rc = lib.eprecon_back_project_async(
+        _lib.ptr(coords_i), n, _lib.ptr(origin_f), b, float(voxel_size), _lib.ptr(feats_c), layout,
+        _lib.ptr(krcam_f), v, c, h, w, int(min_view), mode, _lib.ptr(t["feats"]), _lib.ptr(t["mean"]),
+        _lib.ptr(t["coords"]), _lib.ptr(t["count"]), _lib.ptr(t["grid"]), _lib.ptr(t["mask"]),
+        _lib.ptr(n_valid_dev), _lib.ptr(ws), ws.numel(), _lib.current_stream())
     _lib.check(rc, "eprecon_back_project_async")
     pinned = torch.empty((1 + b,), dtype=torch.int32, pin_memory=True)
     pinned.copy_(n_valid_dev, non_blocking=True)
@@ -158,9 +109,6 @@ def run(coords, origin, voxel_size, feats, krcam, min_view, mode=MODE_MEAN, min_
         want_grid=False, want_mean=False):
     """Low-level entry: returns None (reference: `return None`) or a dict of device tensors
     {feats [n_valid, C(+1)], coords int32 [n_valid, 4], count f32 [N], n_valid, (grid, mask, mean)}."""
-    if _dense_hint(coords, mode, feats.shape[2], want_grid) is not None:
-        return run_async(coords, origin, voxel_size, feats, krcam, min_view, mode, min_valid_per_batch, want_grid,
-                         want_mean).result()
     lib = _lib.load()
     dev = feats.device
     if dev.type != "cuda":

@@ -29,8 +29,8 @@ namespace {
 using namespace ep;
 
 // Variants measured on MI355X (tools/ab_backproject.py, dense 96^3, C = 24, 120x160; gather kernel / whole op).
-// Only the first two are still in the build (EPRECON_BP_MLP = 0 / 1..4); the others were parity-green
-// experiments of round 1 and were removed again (git history: "back_project:" commits):
+// Only the first two are still in the build (the second is the default; the first takes C % 4 != 0); the others were
+// parity-green experiments of rounds 1 / 2 and were removed again (git history: "back_project:" commits):
 //   input-order tiles, 4-channel lanes, taps recomputed      134 us / 0.26 ms  (bp_gather_kernel)
 //   + per-pair taps in LDS, cheap projection, buffer loads   122 us            (bp_gather_mlp_kernel, default)
 //   + 2 / 3 / 4 views of loads in flight per lane            126 / 129 / 138 us (no latency to hide)
@@ -45,14 +45,6 @@ using namespace ep;
 // always touches two 64-byte L1 segments, and at one segment per clock per CU that is 89 of the 116 us: the
 // L1 access rate bounds the kernel, not latency (more loads in flight do not help), not VALU (-43 % VALU
 // bought 134 -> 122 us) and not HBM.
-int g_mlp = 1;  // views in flight per lane in the default gather (0 = the older recompute-per-lane kernel)
-void read_tuning_env()
-{
-    static bool done = false;
-    if (done) return;
-    done = true;
-    if (const char *e = getenv("EPRECON_BP_MLP")) g_mlp = atoi(e);
-}
 
 struct BpParams {
     const int32_t *coords;
@@ -842,7 +834,7 @@ size_t gather_mlp_lds_bytes(int vox, int V, int B)
 
 bool gather_mlp_supported(const BpParams &p)
 {
-    return g_mlp > 0 && p.C % 4 == 0 && p.Cs % 4 == 0 && p.V <= 32 &&
+    return p.C % 4 == 0 && p.Cs % 4 == 0 && p.V <= 32 &&
            (size_t)p.V * p.batch * p.H * p.W * p.Cs * 4 < 0x7fff0000ull &&
            gather_mlp_lds_bytes(256, p.V, p.batch) <= 64 * 1024;
 }
@@ -868,13 +860,7 @@ int launch_gather_mlp_u(const BpParams &p, int nblk, hipStream_t st)
 template <int VOX, int MODE>
 int launch_gather_mlp(const BpParams &p, int nblk, hipStream_t st)
 {
-    switch (g_mlp) {
-        case 1: return launch_gather_mlp_u<VOX, MODE, 1>(p, nblk, st);
-        case 2: return launch_gather_mlp_u<VOX, MODE, 2>(p, nblk, st);
-        case 4: return launch_gather_mlp_u<VOX, MODE, 4>(p, nblk, st);
-        case 3: return launch_gather_mlp_u<VOX, MODE, 3>(p, nblk, st);
-        default: return launch_gather_mlp_u<VOX, MODE, 1>(p, nblk, st);
-    }
+    return launch_gather_mlp_u<VOX, MODE, 1>(p, nblk, st);   // (2 / 3 / 4 views of loads in flight per lane: slower, see above)
 }
 
 }  // namespace
@@ -977,7 +963,6 @@ int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *or
     int32_t *blk_batch = reinterpret_cast<int32_t *>(ws);
     ws += ep::align_up((size_t)ep::ceil_div(n, 256) * batch * sizeof(int32_t), 256);
     const float *nhwc = feats;
-    read_tuning_env();
     int pix_stride = channels;
     if (feats_layout == EPRECON_LAYOUT_NCHW) {
         float *tmp = reinterpret_cast<float *>(ws);

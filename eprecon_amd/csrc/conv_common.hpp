@@ -24,13 +24,6 @@ struct ConvParams {
     // the same for the residual operand (columns of the output)
     const float *res_scale, *res_shift;
     int res_relu;
-    // BatchNorm of the OUTPUT finished by the last workgroup to arrive (needs bn_partial):
-    // scale = gamma / sqrt(var + eps), shift = beta - mean * scale  -> bn_scale_out / bn_shift_out [Cout]
-    float *bn_scale_out, *bn_shift_out;
-    const float *bn_gamma, *bn_beta;
-    float bn_eps;
-    unsigned int *bn_ticket;  // workspace of the in-kernel finalize (counters zero on entry and on exit + group rows)
-    int bn_rows;              // rows of bn_partial this launch writes (set by the dispatcher)
     // LayerNorm over the Cout channels of every output row, after bias / ReLU / residual (needs all
     // columns in one workgroup): out = [relu]( LN(v) * ln_gamma + ln_beta )
     int ln;
@@ -47,10 +40,10 @@ struct ConvParams {
     // the row of the voxel in a grid cell or -1; wq = the weights in MFMA operand order (pack_weights_kernel)
     const int32_t *vox_rank;
     int gx, gy, gz;
-    const float *wq;    // ... for the 32-row tile kernel (pack_weights_kernel)
-    const float *wq16;  // ... for the 16-row tile kernel (pack_weights16_kernel)
-    int debug;  // EPRECON_D3_ABLATE (timing experiments only): 1 no MFMA loop, 2 tile16: weights from the first offset, 4 no halo row loads
-    int splitk_pipe;  // split-K kernel: 1 software-pipelined stages, 2 also B operands straight from the packed weights (wq); 0 neither
+    const float *wq;    // ... in 32x32x2 operand order (pack_weights_kernel): B operands of the split-K and cross-workgroup kernels
+    const float *wq16;  // ... in 16x16x4 operand order (pack_weights16_kernel): 16-row tile kernel, direct gather kernel
+    int debug;  // always 0 in the library; timing probes build with it set: 1 no MFMA loop, 2 tile16: weights from the first offset, 4 no halo row loads
+    int splitk_pipe;  // split-K kernel: 1 software-pipelined stages, 2 also B operands straight from the packed weights (wq)
     void *ws;         // caller's scratch (eprecon_conv_desc.workspace): partial sums of the cross-workgroup split-K kernel
     size_t ws_bytes;
 };

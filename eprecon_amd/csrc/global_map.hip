@@ -385,7 +385,7 @@ __global__ void target_lookup_kernel(const float *vol, const int32_t *updated, i
     out[i] = vol[(updated[3 * i] * D + updated[3 * i + 1]) * D + updated[3 * i + 2]];
 }
 __global__ void target_append_kernel(const float *vol, const int32_t *flag, const int32_t *rank, int D, int rx, int ry,
-                                     int rz, int64_t base, int32_t *c_out, float *f_out)
+                                     int rz, int64_t base, int32_t *c_out, float *f_out, int32_t *s_out)
 {
     const int cell = blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= D * D * D || !flag[cell]) return;
@@ -394,6 +394,7 @@ __global__ void target_append_kernel(const float *vol, const int32_t *flag, cons
     c_out[3 * o + 1] = (cell / D) % D + ry;
     c_out[3 * o + 2] = cell % D + rz;
     f_out[o] = vol[cell];
+    s_out[o] = 0;  // the ground-truth twin takes no part in the boundary exchange: origin unknown, never a stale stamp
 }
 
 inline EpMap *as_map(void *h) { return reinterpret_cast<EpMap *>(h); }
@@ -745,7 +746,7 @@ int eprecon_map_target_fuse(void *handle, const float *tsdf_gt, const uint8_t *o
         EP_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(target_append_kernel, gcells, blk, 0, st, (const float *)vol, (const int32_t *)flag,
-                       (const int32_t *)rank, dim, rx, ry, rz, kept, m->coords[dst], m->feats[dst]);
+                       (const int32_t *)rank, dim, rx, ry, rz, kept, m->coords[dst], m->feats[dst], m->stamps[dst]);
     EP_LAUNCH_CHECK();
     m->cur = dst;
     m->size = kept + n_new;

@@ -145,11 +145,13 @@ __global__ __launch_bounds__(256) void bn_finalize_affine_kernel(const float *pa
     }
 }
 
+// res_scale / res_shift (optional): the residual operand carries a pending BatchNorm of its own in affine form (the 1x1 skip
+// convolution of a residual block, models/modules.py:57-65), applied on load
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float *x, int n, int C, int ld_x,
                                                        const float *mean, const float *var,
                                                        const float *gamma, const float *beta, float eps,
-                                                       const float *res, int ld_res, int relu,
-                                                       float *out, int ld_out)
+                                                       const float *res, int ld_res, const float *res_scale,
+                                                       const float *res_shift, int relu, float *out, int ld_out)
 {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= (size_t)n * C) return;
@@ -157,7 +159,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *x, int n, in
     const float inv = 1.0f / sqrtf(var[c] + eps);
     float v = (x[(size_t)r * ld_x + c] - mean[c]) * inv;
     v = v * (gamma ? gamma[c] : 1.0f) + (beta ? beta[c] : 0.0f);
-    if (res) v += res[(size_t)r * ld_res + c];
+    if (res) {
+        float rv = res[(size_t)r * ld_res + c];
+        if (res_scale) rv = fmaf(rv, res_scale[c], res_shift[c]);
+        v += rv;
+    }
     if (relu) v = fmaxf(v, 0.0f);
     out[(size_t)r * ld_out + c] = v;
 }
@@ -235,14 +241,15 @@ __global__ __launch_bounds__(256) void affine_rows_res_kernel(const float *x, in
 // SPVCNN 1.65 -> 2.15 ms per level-0 pass against the 6 us of the separate finalize launch.)
 int bn_finalize_apply(const float *x, int64_t n, int channels, int ld_x, const float *partial, int nblk,
                       const float *gamma, const float *beta, float eps, const float *residual, int ld_res,
-                      int relu, float *out, int ld_out, float *mean, float *var, hipStream_t st)
+                      int relu, float *out, int ld_out, float *mean, float *var, hipStream_t st,
+                      const float *res_scale = nullptr, const float *res_shift = nullptr)
 {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(channels), dim3(256), 0, st, partial, nblk, channels, mean, var);
     EP_LAUNCH_CHECK();
     const size_t total = (size_t)n * channels;
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div((int64_t)total, 256)), dim3(256), 0, st, x,
                        (int)n, channels, ld_x, (const float *)mean, (const float *)var, gamma, beta, eps,
-                       residual, ld_res, relu, out, ld_out);
+                       residual, ld_res, res_scale, res_shift, relu, out, ld_out);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }
@@ -313,6 +320,24 @@ int eprecon_batchnorm_apply_partials_async(const float *x, int64_t n, int channe
     float *var = var_out ? var_out : reinterpret_cast<float *>(ws);
     return bn_finalize_apply(x, n, channels, ld_x, partial, (int)nblk, gamma, beta, eps, residual, ld_res, relu,
                              out, ld_out, mean, var, (hipStream_t)stream);
+}
+
+int eprecon_batchnorm_apply_partials_res_async(const float *x, int64_t n, int channels, int ld_x, const float *partial,
+                                               int64_t nblk, const float *gamma, const float *beta, float eps,
+                                               const float *residual, int ld_res, const float *res_scale,
+                                               const float *res_shift, int relu, float *out, int ld_out, void *workspace,
+                                               size_t workspace_bytes, void *stream)
+{
+    if (!x || !out || !partial || !residual || !res_scale || !res_shift || n < 0 || nblk <= 0 || nblk > 0x7fffffff ||
+        channels <= 0 || ld_x < channels || ld_out < channels || ld_res < channels || !workspace)
+        return EPRECON_ERR_ARG;
+    if (workspace_bytes < eprecon_batchnorm_apply_workspace_bytes(channels)) return EPRECON_ERR_WORKSPACE;
+    if (n == 0) return EPRECON_OK;
+    char *ws = reinterpret_cast<char *>(workspace);
+    float *mean = reinterpret_cast<float *>(ws);
+    float *var = reinterpret_cast<float *>(ws + align_up((size_t)channels * sizeof(float), 256));
+    return bn_finalize_apply(x, n, channels, ld_x, partial, (int)nblk, gamma, beta, eps, residual, ld_res, relu, out, ld_out,
+                             mean, var, (hipStream_t)stream, res_scale, res_shift);
 }
 
 int eprecon_batchnorm_finalize_affine_async(const float *partial, int64_t nblk, int channels, const float *gamma,

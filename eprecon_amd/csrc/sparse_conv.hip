@@ -91,94 +91,6 @@ constexpr int kRowsPerWave = 32;
 constexpr int kRowsPerBlock = kRowsPerWave * kWaves;
 constexpr int kSlabC = 32;  // input channels per staged weight slab
 
-// Second half of the fused BatchNorm, inside the convolution launch (no bn_finalize launch, no host round trip).
-// Visibility between workgroups without fences (MI355X guide, "publish-large": a release fence makes the XCD's L2 write
-// back everything dirty, and the round-1 form — one ticket, __threadfence() per workgroup — ran cfg2 at 3.4 ms instead of
-// 2.3 ms): the summaries are stored WRITE-THROUGH (relaxed agent-scope atomic stores = global_store sc1), the stores are
-// drained (s_waitcnt vmcnt(0)) before the arrival is counted, and the merging workgroup reads them with sc1 loads that
-// bypass its L1.  Two levels, so that no counter sees more than 16 * (column blocks) or (rows / 16) arrivals and the last
-// arriver's serial part is short:
-//   group g = summary rows 16 g .. 16 g + 15: its last arriver merges them in row order -> group row g (write-through)
-//   the last group to finish merges the group rows in order -> (scale, shift); every counter is reset by its last arriver
-// The merge order is fixed by row / group index, not by arrival: deterministic.
-// Workspace (bn_ticket): a FIXED 16 KB region of counters ([0] top level, [1 + g] group g; zero on entry, zero again on
-// exit) followed by the group rows f32[ngroups][3][Cout]  (eprecon_conv_bn_finalize_workspace_bytes).  The counter region
-// does not depend on the launch: a layer's workspace is reused by launches of different sizes, and group rows written by
-// one launch must never land where a later, longer launch keeps its counters.
-constexpr int kBnGroupRows = 16;
-__device__ __forceinline__ void st_wt(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_l2(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-constexpr size_t kBnTicketBytes = 16384;                               // 4,096 counters
-constexpr int kBnMaxRows = (int)(kBnTicketBytes / 4 - 1) * kBnGroupRows;  // 65,520 summary rows (8.4 M voxels at 128 rows each)
-
-// every thread of the workgroup calls this after the workgroup's slice of summary row `partial_row` was stored with st_wt;
-// `ncb` workgroups (column blocks) contribute to a row.  sScratch: >= 3 * 256 floats of LDS.  Cout <= 128.
-__device__ __forceinline__ void bn_finalize_in_kernel(const ConvParams &p, float *sScratch, int partial_row, int ncb)
-{
-    __shared__ int sLast;
-    const int tid = threadIdx.x, nthr = blockDim.x;
-    const int C = p.Cout, nrows = p.bn_rows;
-    const int ngroups = (nrows + kBnGroupRows - 1) / kBnGroupRows;
-    unsigned int *tick = p.bn_ticket;
-    float *grow = reinterpret_cast<float *>(reinterpret_cast<char *>(p.bn_ticket) + kBnTicketBytes);
-    const int grp = partial_row / kBnGroupRows;
-    const int r0 = grp * kBnGroupRows, r1 = min(r0 + kBnGroupRows, nrows);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through stores have left
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned int t = __hip_atomic_fetch_add(tick + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sLast = t == (unsigned int)((r1 - r0) * ncb - 1);
-        if (sLast) __hip_atomic_store(tick + 1 + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!sLast) return;
-    for (int c = tid; c < C; c += nthr) {  // the group's rows in order; 3 * (r1 - r0) independent L2 loads per thread
-        float vn[kBnGroupRows], vm[kBnGroupRows], vq[kBnGroupRows];
-#pragma unroll
-        for (int i = 0; i < kBnGroupRows; ++i) {
-            const int r = min(r0 + i, r1 - 1);
-            const float *q = p.bn_partial + (size_t)r * 3 * C + c;
-            vn[i] = ld_l2(q); vm[i] = ld_l2(q + C); vq[i] = ld_l2(q + 2 * C);
-        }
-        float a_n = 0.0f, a_mean = 0.0f, a_m2 = 0.0f;
-#pragma unroll
-        for (int i = 0; i < kBnGroupRows; ++i)
-            if (r0 + i < r1) chan_merge(a_n, a_mean, a_m2, vn[i], vm[i], vq[i]);
-        float *g = grow + (size_t)grp * 3 * C + c;
-        st_wt(g, a_n); st_wt(g + C, a_mean); st_wt(g + 2 * C, a_m2);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned int t = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sLast = t == (unsigned int)(ngroups - 1);
-        if (sLast) __hip_atomic_store(tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!sLast) return;
-    // the last group: thread (g, c) merges group rows g, g + G, ... of column c, the G results are merged in order
-    const int G = max(1, min(nthr, 256) / C);
-    const int g = tid / C, c = tid - g * C;
-    float a_n = 0.0f, a_mean = 0.0f, a_m2 = 0.0f;
-    if (g < G) {
-        for (int b = g; b < ngroups; b += G) {
-            const float *q = grow + (size_t)b * 3 * C + c;
-            chan_merge(a_n, a_mean, a_m2, ld_l2(q), ld_l2(q + C), ld_l2(q + 2 * C));
-        }
-        sScratch[tid] = a_n; sScratch[256 + tid] = a_mean; sScratch[512 + tid] = a_m2;
-    }
-    __syncthreads();
-    if (g == 0) {
-        for (int gg = 1; gg < G; ++gg)
-            chan_merge(a_n, a_mean, a_m2, sScratch[gg * C + c], sScratch[256 + gg * C + c], sScratch[512 + gg * C + c]);
-        const float var = a_n > 0.0f ? a_m2 / a_n : 0.0f;  // biased variance
-        const float sc = (p.bn_gamma ? p.bn_gamma[c] : 1.0f) / sqrtf(var + p.bn_eps);
-        p.bn_scale_out[c] = sc;
-        p.bn_shift_out[c] = (p.bn_beta ? p.bn_beta[c] : 0.0f) - a_mean * sc;
-    }
-}
-
 // Shared epilogue.  C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31,
 // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 //   v = acc + bias; [v += out]; [v = max(v, 0)]; [v += res]; out = v
@@ -342,16 +254,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
                 chan_merge(a_n, a_mean, a_m2, sStat[(w * 3) * TN + tid], sStat[(w * 3 + 1) * TN + tid],
                            sStat[(w * 3 + 2) * TN + tid]);
             float *dst = p.bn_partial + (size_t)partial_row * 3 * p.Cout + col0 + tid;
-            if (p.bn_scale_out) {   // (uniform) read by another workgroup of this launch: write-through
-                st_wt(dst, a_n); st_wt(dst + p.Cout, a_mean); st_wt(dst + 2 * p.Cout, a_m2);
-            } else {
-                dst[0] = a_n; dst[p.Cout] = a_mean; dst[2 * p.Cout] = a_m2;
-            }
+            dst[0] = a_n; dst[p.Cout] = a_mean; dst[2 * p.Cout] = a_m2;
         }
-    }
-    if (stats && p.bn_scale_out) {
-        __syncthreads();  // the summary scratch is read; bn_finalize_in_kernel reuses it
-        bn_finalize_in_kernel(p, sStat, partial_row, ncb);
     }
 }
 
@@ -735,14 +639,13 @@ template <int NT, int NCH>
 int launch_resident_nch(const ConvParams &p, bool vec4, hipStream_t st, int nslab = 1)
 {
     // weights of `kgroup` offsets resident at a time (a multiple of the gather batch, ~24 KB -> 4 workgroups per CU)
-    static const bool pipe_env = !(getenv("EPRECON_CONV_PIPE") && getenv("EPRECON_CONV_PIPE")[0] == '0');  // default on
     // vec4: 16-byte aligned rows whose pitch covers Cin rounded up to 4; the buffer-load gathers address x with
     // 32-bit byte offsets formed by a 24-bit multiply
-    const bool pipe = pipe_env && vec4 && p.x_bytes > 0 && p.x_bytes < 0x7fffffffll && (int64_t)p.ld_x * 4 < (1 << 24) &&
+    const bool pipe = vec4 && p.x_bytes > 0 && p.x_bytes < 0x7fffffffll && (int64_t)p.ld_x * 4 < (1 << 24) &&
                       p.x_bytes / ((int64_t)p.ld_x * 4) < (1 << 24);
     const int KB = pipe ? (resident_kb(NCH) + 1) / 2 : resident_kb(NCH);  // the kernel's batch size: kgroup % KB == 0
     const size_t per_k = (size_t)NCH * 8 * 32 * NT * sizeof(float);
-    static const int group_kb = getenv("EPRECON_CONV_GROUP_KB") ? atoi(getenv("EPRECON_CONV_GROUP_KB")) : 24;
+    constexpr int group_kb = 24;   // (36 KB: -1 %, 48 KB = two workgroups per CU: +37 %)
     int kgroup = (int)max((size_t)KB, (size_t)(group_kb * 1024) / per_k / KB * KB);
     kgroup = min(kgroup, (p.K + KB - 1) / KB * KB);
     const size_t lds = max((size_t)kgroup * per_k + (size_t)p.K * kRowsPerBlock * sizeof(int) +
@@ -910,8 +813,7 @@ size_t conv2d_tile_lds(int nt, int nch) { return ((size_t)9 * nch * 8 * 32 * nt 
 // eligibility of the tile kernel; on success *blocks = workgroups per column block (= BatchNorm summary rows)
 bool conv2d_tile_ok(const ConvParams &p, int *nt_out, int *nch_out, int64_t *blocks)
 {
-    static const bool on = !(getenv("EPRECON_CONV_TILE") && getenv("EPRECON_CONV_TILE")[0] == '0');
-    if (!on || p.K != 9 || p.img_h <= 0 || p.img_w <= 0 || p.img_maps <= 0 || p.ln || p.accumulate)
+    if (p.K != 9 || p.img_h <= 0 || p.img_w <= 0 || p.img_maps <= 0 || p.ln || p.accumulate)
         return false;
     if ((int64_t)p.img_maps * p.img_h * p.img_w != p.n_out) return false;
     if (p.Cin % 4 != 0 || p.ld_x % 4 != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0) return false;
@@ -972,22 +874,6 @@ constexpr int kD3Y = 4, kD3Z = 8;
 constexpr int kD3HY = kD3Y + 2, kD3HZ = kD3Z + 2;
 constexpr int d3_halo(int wv) { return (wv + 2) * kD3HY * kD3HZ; }
 constexpr int kD3WvNarrow = 4;
-// x extent (= waves) of the MFMA kernel's tile: 2 by default, EPRECON_D3_WV=4 for A/B runs
-inline int d3_wv_mfma()
-{
-    static const int wv = (getenv("EPRECON_D3_WV") && atoi(getenv("EPRECON_D3_WV")) == 4) ? 4 : 2;
-    return wv;
-}
-
-struct RegRows {  // output rows of a lane's 16 accumulator rows, held in registers: tile row i = (r & 3) + 8 (r >> 2) + 4 half
-    const int (&row)[16];
-    int half;
-    __device__ __forceinline__ int operator()(int i) const
-    {
-        const int j = i - 4 * half;  // (the epilogues only ask for this lane's rows; i is a compile-time function of r)
-        return row[(j & 3) + 4 * (j >> 3)];
-    }
-};
 
 // Weights [K][Cin][Cout] -> MFMA operand order, zero padded, one slab per block of 32 * nt output columns:
 //   wq[(((((cb * K + k) * NCH + ch) * 2 + half) * NT + t) * 32 + col) * 4 + s] = W[k][ch*8 + 4*half + s][cb*32*NT + 32 t + col]
@@ -1100,113 +986,6 @@ __device__ __forceinline__ bool d3_stage_halo(const ConvParams &p, int x0, int y
     return true;
 }
 
-template <int NT, int NCH, int WV>
-__global__ __launch_bounds__(64 * WV) void conv3d_tile_kernel(ConvParams p, int tiles_y, int tiles_z, int ntiles)
-{
-    constexpr int cin_pad = NCH * 8;
-    constexpr int P = cin_pad + 4;  // LDS cell pitch in floats: an odd number of 16-byte units
-    constexpr int TN = 32 * NT;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *sX = reinterpret_cast<float *>(smem);             // [d3_halo(WV)][P]: cin_pad channels + the cell's row + 3 pad words
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int r32 = lane & 31, half = lane >> 5;
-    const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    if (tile >= ntiles) return;
-    const int col0 = blockIdx.y * TN;
-    int x0, y0, z0;
-    d3_tile_origin<WV>(tile, tiles_y, tiles_z, x0, y0, z0);
-
-    const int dbg = p.debug;
-    if (!d3_stage_halo<NCH, WV>(p, x0, y0, z0, sX, tid, dbg)) {
-        if (p.bn_partial && tid < TN && col0 + tid < p.Cout) {  // an empty summary row: the merges skip count 0
-            float *dst = p.bn_partial + (size_t)tile * 3 * p.Cout + col0 + tid;
-            if (p.bn_scale_out) { st_wt(dst, 0.0f); st_wt(dst + p.Cout, 0.0f); st_wt(dst + 2 * p.Cout, 0.0f); }
-            else { dst[0] = 0.0f; dst[p.Cout] = 0.0f; dst[2 * p.Cout] = 0.0f; }
-        }
-        if (p.bn_partial && p.bn_scale_out) bn_finalize_in_kernel(p, sX, tile, (int)gridDim.y);  // it still counts as an arrival
-        return;
-    }
-    const int cell0 = ((wave + 1) * kD3HY + (r32 >> 3) + 1) * kD3HZ + (r32 & 7) + 1;  // this lane's own cell in the halo
-    const int own = d3_rank(sX, cell0, P, cin_pad);
-    // rows of this lane's 16 accumulator rows (tile row i -> cell (wave, i / 8, i % 8)), read before the epilogue's
-    // scratch may overlay the halo
-    int orow[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-        orow[r] = d3_rank(sX, ((wave + 1) * kD3HY + (i >> 3) + 1) * kD3HZ + (i & 7) + 1, P, cin_pad);
-    }
-
-    f32x16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-
-    if (__ballot(own >= 0) != 0ull && !(dbg & 1)) {  // (wave-uniform) a wave without a voxel has nothing to accumulate
-        // A operands: LDS address of the halo cell at offset (-1, -1, -1) of this lane's cell; offset k adds a
-        // wave-uniform multiple of the cell pitch, the chunks are immediates of the ds_read
-        const float *xa = sX + (cell0 - (kD3HY + 1) * kD3HZ - 1) * P + 4 * half;
-        // B operands through a buffer resource over the packed weights of this column block: byte offset
-        // ((k * NCH + ch) * 2 + half) * NT * 512 + t * 512 + r32 * 16 -> the lane part is one VGPR, the offset a scalar
-        constexpr unsigned kStepBytes = 2u * NT * 512u;      // one (offset, chunk) step
-        constexpr unsigned kOffBytes = NCH * kStepBytes;     // one kernel offset
-        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(p.wq) + (size_t)blockIdx.y * 27 * (kOffBytes / 4), 0, (int)(27 * kOffBytes), 0x00020000);
-        const unsigned wlane = (unsigned)half * NT * 512u + (unsigned)r32 * 16u;
-        // Software pipeline over the 27 offsets, fully unrolled (every LDS / weight offset is an immediate): the weights of
-        // offset k + kAheadB and the A operands of offset k + 1 are requested BEFORE the MFMAs of offset k, and scheduling
-        // fences keep the compiler from sinking them (a weight fetch is an L2 round trip of ~1 us under load: with one
-        // offset of cover the loop ran at 55 % of the MFMA rate, profiles/r03/conv3d_probe.txt).
-        constexpr int kAheadB = (NCH * NT <= 8) ? 2 : 1;
-        float4 bq[kAheadB + 1][NCH][NT];
-        float4 aq[2][NCH];
-        auto load_b = [&](int k, float4(&dst)[NCH][NT]) {
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + (unsigned)ch * kStepBytes + (unsigned)t * 512u,
-                                                                          (unsigned)k * kOffBytes, 0);
-                    dst[ch][t] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-                }
-        };
-        auto load_a = [&](int k, float4(&dst)[NCH]) {
-            const int dx = k % 3, dy = (k / 3) % 3, dz = k / 9;
-            const float *xk = xa + ((dx * kD3HY + dy) * kD3HZ + dz) * P;
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) dst[ch] = *reinterpret_cast<const float4 *>(xk + ch * 8);
-        };
-#pragma unroll
-        for (int k = 0; k < kAheadB; ++k) load_b(k, bq[k]);
-        load_a(0, aq[0]);
-#pragma unroll
-        for (int k = 0; k < 27; ++k) {
-            if (k + kAheadB < 27) load_b(k + kAheadB, bq[(k + kAheadB) % (kAheadB + 1)]);
-            if (k + 1 < 27) load_a(k + 1, aq[(k + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            const float4(&av)[NCH] = aq[k & 1];
-            const float4(&bk)[NCH][NT] = bq[k % (kAheadB + 1)];
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ch].x, bk[ch][t].x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ch].y, bk[ch][t].y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ch].z, bk[ch][t].z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ch].w, bk[ch][t].w, acc[t], 0, 0, 0);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    __syncthreads();  // every wave is done with the halo (the epilogue's scratch overlays it)
-    if (p.bn_partial) {   // the shared epilogue merges kWaves wave summaries: the slots of the waves this block does not have are empty
-        for (int e = tid; e < (kWaves - WV) * 3 * TN; e += 64 * WV) sX[WV * 3 * TN + e] = 0.0f;
-    }
-    conv_epilogue<NT>(p, acc, RegRows{orow, half}, col0, r32, half, wave, sX, tile, (int)gridDim.y);
-}
-
 // C_out == 1 (the occupancy-logit layer, models/occupancy_initialization.py:171): a 32-column MFMA tile would spend 31/32
 // of its work on padding.  Same halo staging; two lanes per cell split the 16-byte channel groups, the weights of the one
 // output column come from LDS as broadcasts, plain fma chains, the BatchNorm summary of the tile by Chan merges in
@@ -1234,10 +1013,8 @@ __global__ __launch_bounds__(256) void conv3d_tile_narrow_kernel(ConvParams p, i
     if (!d3_stage_halo<NCH, WV>(p, x0, y0, z0, sX, tid, p.debug)) {  // (its barriers also publish sWn)
         if (p.bn_partial && tid == 0) {
             float *dst = p.bn_partial + (size_t)tile * 3 * p.Cout;
-            if (p.bn_scale_out) { st_wt(dst, 0.0f); st_wt(dst + p.Cout, 0.0f); st_wt(dst + 2 * p.Cout, 0.0f); }
-            else { dst[0] = 0.0f; dst[p.Cout] = 0.0f; dst[2 * p.Cout] = 0.0f; }
+            dst[0] = 0.0f; dst[p.Cout] = 0.0f; dst[2 * p.Cout] = 0.0f;
         }
-        if (p.bn_partial && p.bn_scale_out) bn_finalize_in_kernel(p, sX, tile, 1);
         return;
     }
     const int v = tid >> 1, part = tid & 1;  // cell (x = v / 32, y = (v / 8) % 4, z = v % 8), half of the channel groups
@@ -1289,12 +1066,7 @@ __global__ __launch_bounds__(256) void conv3d_tile_narrow_kernel(ConvParams p, i
             float a_n = 0.0f, a_mean = 0.0f, a_m2 = 0.0f;
             for (int w = 0; w < kWaves; ++w) chan_merge(a_n, a_mean, a_m2, sRed[w * 3], sRed[w * 3 + 1], sRed[w * 3 + 2]);
             float *dst = p.bn_partial + (size_t)tile * 3 * p.Cout;
-            if (p.bn_scale_out) { st_wt(dst, a_n); st_wt(dst + p.Cout, a_mean); st_wt(dst + 2 * p.Cout, a_m2); }
-            else { dst[0] = a_n; dst[p.Cout] = a_mean; dst[2 * p.Cout] = a_m2; }
-        }
-        if (p.bn_scale_out) {
-            __syncthreads();  // (sX is free: every thread is past its operand reads)
-            bn_finalize_in_kernel(p, sX, tile, 1);
+            dst[0] = a_n; dst[p.Cout] = a_mean; dst[2 * p.Cout] = a_m2;
         }
     }
 }
@@ -1520,42 +1292,36 @@ __global__ __launch_bounds__(256, 7) void conv3d_tile16_kernel(ConvParams p, int
     }
 }
 
-enum D3Kind { kD3None = 0, kD3Narrow = 1, kD3Tile16 = 2, kD3Tile32 = 3 };
+enum D3Kind { kD3None = 0, kD3Narrow = 1, kD3Tile16 = 2 };
 
 int d3_tiles_kind(const ConvParams &p, int kind, int *ty = nullptr, int *tz = nullptr)
 {
-    const int wv = kind == kD3Tile16 ? kD16X : (kind == kD3Narrow ? kD3WvNarrow : d3_wv_mfma());
+    const int wv = kind == kD3Tile16 ? kD16X : kD3WvNarrow;
     const int tx = (p.gx + wv - 1) / wv, tyy = (p.gy + kD3Y - 1) / kD3Y, tzz = (p.gz + kD3Z - 1) / kD3Z;
     if (ty) *ty = tyy;
     if (tz) *tz = tzz;
     return tx * tyy * tzz;
 }
-int d3_tiles(const ConvParams &p, bool narrow, int *ty = nullptr, int *tz = nullptr)
+size_t conv3d_narrow_lds(int nch)
 {
-    return d3_tiles_kind(p, narrow ? kD3Narrow : kD3Tile32, ty, tz);
-}
-size_t conv3d_tile_lds(int nch, bool narrow)
-{
-    const size_t base = ((size_t)d3_halo(narrow ? kD3WvNarrow : d3_wv_mfma()) * (nch * 8 + 4)) * sizeof(float);
-    return base + (narrow ? ((size_t)27 * nch * 8 + 16) * sizeof(float) : 0);
+    return ((size_t)d3_halo(kD3WvNarrow) * (nch * 8 + 4) + (size_t)27 * nch * 8 + 16) * sizeof(float);
 }
 
 // eligibility of the dense-grid kernels (independent of the data: shapes, alignment, fusions)
-// EPRECON_CONV_DENSE3D: 0 off; 1 the single-column kernel only; 2 (default) also the 16-row MFMA kernel; 3 also the 32-row
-// MFMA kernel.  Measured on the 94k-voxel initialisation set (rocprofv3 kernel durations, profiles/r03/conv3d_*):
+// EPRECON_CONV_DENSE3D: 0 off; 1 the single-column kernel only; 2 (default) also the 16-row MFMA kernel.
+// Measured on the 94k-voxel initialisation set (rocprofv3 kernel durations, profiles/r03/conv3d_*):
 //   32 -> 1   24 us   against 82 us for the gather form            (single-column kernel)
-//   16 -> 16  24 us   against 50 us,  32 -> 16  41.5 us against 76 us,  32 -> 32  80 us against 78.5 us     (16-row kernel)
-//   32 -> 32  97 us   against 78 us  (32-row kernel: 3,185 wave jobs of 11.5 us on 1,024 SIMDs = four rounds)
-// With level 2 every 3x3x3 layer of the initialisation stack runs on a tile kernel, no hash grid / kernel map is built, and
-// the cfg2 step goes from 1.91 to 1.76 ms.
+//   16 -> 16  24 us   against 50 us,  32 -> 16  37 us against 76 us,  32 -> 32  71 us against 78 us     (16-row kernel)
+// (a 32-row tile kernel on v_mfma_f32_32x32x2_f32 was built in round 3, bit-identical to the gather form and slower on this
+// set — 97 us against 78 us: 3,185 wave jobs of 11.5 us on 1,024 SIMDs = four rounds, DESIGN.md 3b — and removed in round 4.)
 inline int d3_level()
 {
-    const char *e = getenv("EPRECON_CONV_DENSE3D");   // (read per launch: tests and probes flip it)
+    const char *e = getenv("EPRECON_CONV_DENSE3D");   // (read per launch: tests flip it)
     return e ? atoi(e) : 2;
 }
 
 // which dense-grid kernel takes this layer: level 1 the single-column kernel, level 2 also the 16-row MFMA kernel
-// (C_out <= 32, C_in a multiple of 16), level 3 also the 32-row MFMA kernel for the remaining shapes
+// (C_out <= 32, C_in a multiple of 16); every other shape runs on the kernel map
 int conv3d_kind(const ConvParams &p)
 {
     const int level = d3_level();
@@ -1565,16 +1331,11 @@ int conv3d_kind(const ConvParams &p)
         return kD3None;
     if (p.Cout == 1 && !p.ln) return kD3Narrow;
     if (level < 2 || p.accumulate) return kD3None;
-    const char *no16 = getenv("EPRECON_CONV_DENSE3D_NO16");   // tests / probes: the 32-row kernel for every shape
     // (the caller packs the weights for the kernel ITS mirror of this rule picks — eprecon_amd/sparse.py DenseMap.kind —,
     // so a missing packing means "not this kernel", never an error)
-    if (!(no16 && no16[0] == '1') && p.Cout <= 32 && p.Cin % 16 == 0 && !p.bn_scale_out && !(p.ln && p.bn_partial) && p.wq16 &&
-        (reinterpret_cast<uintptr_t>(p.wq16) & 15) == 0)
+    if (p.Cout <= 32 && p.Cin % 16 == 0 && !(p.ln && p.bn_partial) && p.wq16 && (reinterpret_cast<uintptr_t>(p.wq16) & 15) == 0)
         return kD3Tile16;
-    if (level < 3) return kD3None;
-    if (!p.wq || (reinterpret_cast<uintptr_t>(p.wq) & 15) != 0) return kD3None;
-    if (p.ln && (p.Cout > 64 || p.bn_partial)) return kD3None;
-    return kD3Tile32;
+    return kD3None;
 }
 bool conv3d_tile_ok(const ConvParams &p, bool *narrow)
 {
@@ -1620,35 +1381,12 @@ int launch_conv3d_16(const ConvParams &p, hipStream_t st)
     }
 }
 
-template <int NT, int NCH, int WV>
-int launch_conv3d_tile_wv(const ConvParams &p, hipStream_t st)
-{
-    int ty, tz;
-    const int ntiles = d3_tiles(p, false, &ty, &tz);
-    const size_t lds = max(conv3d_tile_lds(NCH, false), (size_t)max(kWaves * 3 * 32 * NT, 3 * 256) * sizeof(float));
-    if (lds > 64 * 1024) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_tile_kernel<NT, NCH, WV>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        if (attr != hipSuccess) return EPRECON_ERR_HIP_BASE - (int)attr;
-    }
-    const dim3 grid((unsigned)ntiles, (unsigned)ceil_div(p.Cout, 32 * NT));  // == d3_columns' ncb
-    hipLaunchKernelGGL((conv3d_tile_kernel<NT, NCH, WV>), grid, dim3(64 * WV), lds, st, p, ty, tz, ntiles);
-    EP_LAUNCH_CHECK();
-    return EPRECON_OK;
-}
-
-template <int NT, int NCH>
-int launch_conv3d_tile(const ConvParams &p, hipStream_t st)
-{
-    return d3_wv_mfma() == 4 ? launch_conv3d_tile_wv<NT, NCH, 4>(p, st) : launch_conv3d_tile_wv<NT, NCH, 2>(p, st);
-}
-
 template <int NCH>
 int launch_conv3d_narrow(const ConvParams &p, hipStream_t st)
 {
     int ty, tz;
-    const int ntiles = d3_tiles(p, true, &ty, &tz);
-    const size_t lds = conv3d_tile_lds(NCH, true);
+    const int ntiles = d3_tiles_kind(p, kD3Narrow, &ty, &tz);
+    const size_t lds = conv3d_narrow_lds(NCH);
     if (lds > 64 * 1024) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_tile_narrow_kernel<NCH>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -1659,38 +1397,18 @@ int launch_conv3d_narrow(const ConvParams &p, hipStream_t st)
     return EPRECON_OK;
 }
 
-template <int NT>
-int launch_conv3d_nt(const ConvParams &p, hipStream_t st)
+int launch_conv3d_single_column(const ConvParams &p, hipStream_t st)
 {
     switch ((p.Cin + 7) / 8) {
-        case 1: return launch_conv3d_tile<NT, 1>(p, st);
-        case 2: return launch_conv3d_tile<NT, 2>(p, st);
-        case 3: return launch_conv3d_tile<NT, 3>(p, st);
-        case 4: return launch_conv3d_tile<NT, 4>(p, st);
-        case 5: return launch_conv3d_tile<NT, 5>(p, st);
-        case 6: return launch_conv3d_tile<NT, 6>(p, st);
-        case 7: return launch_conv3d_tile<NT, 7>(p, st);
-        default: return launch_conv3d_tile<NT, 8>(p, st);
+        case 1: return launch_conv3d_narrow<1>(p, st);
+        case 2: return launch_conv3d_narrow<2>(p, st);
+        case 3: return launch_conv3d_narrow<3>(p, st);
+        case 4: return launch_conv3d_narrow<4>(p, st);
+        case 5: return launch_conv3d_narrow<5>(p, st);
+        case 6: return launch_conv3d_narrow<6>(p, st);
+        case 7: return launch_conv3d_narrow<7>(p, st);
+        default: return launch_conv3d_narrow<8>(p, st);
     }
-}
-
-int launch_conv3d(const ConvParams &p, bool narrow, hipStream_t st)
-{
-    if (narrow) {
-        switch ((p.Cin + 7) / 8) {
-            case 1: return launch_conv3d_narrow<1>(p, st);
-            case 2: return launch_conv3d_narrow<2>(p, st);
-            case 3: return launch_conv3d_narrow<3>(p, st);
-            case 4: return launch_conv3d_narrow<4>(p, st);
-            case 5: return launch_conv3d_narrow<5>(p, st);
-            case 6: return launch_conv3d_narrow<6>(p, st);
-            case 7: return launch_conv3d_narrow<7>(p, st);
-            default: return launch_conv3d_narrow<8>(p, st);
-        }
-    }
-    int nt, ncb;
-    d3_columns(p.Cout, &nt, &ncb);
-    return nt == 1 ? launch_conv3d_nt<1>(p, st) : launch_conv3d_nt<2>(p, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2016,24 +1734,19 @@ __global__ __launch_bounds__(64 * NW) void spconv_splitk_kernel(ConvParams p)
 template <bool VEC4>
 int launch_splitk_v(ConvParams &p, hipStream_t st)
 {
-    static const bool pipe_on = !(getenv("EPRECON_CONV_SPLITK_PIPE") && getenv("EPRECON_CONV_SPLITK_PIPE")[0] == '0');
-    static const bool bdirect_on = !(getenv("EPRECON_CONV_SPLITK_BDIRECT") && getenv("EPRECON_CONV_SPLITK_BDIRECT")[0] == '0');
-    p.splitk_pipe = pipe_on ? ((bdirect_on && p.wq && (reinterpret_cast<uintptr_t>(p.wq) & 15) == 0) ? 2 : 1) : 0;
-    static const bool rt2_on = !(getenv("EPRECON_CONV_SPLITK_RT2") && getenv("EPRECON_CONV_SPLITK_RT2")[0] == '0');
-    static const int max_waves = getenv("EPRECON_CONV_SPLITK_WAVES") ? atoi(getenv("EPRECON_CONV_SPLITK_WAVES")) : 16;
+    // software-pipelined stages; with the caller's operand-order packing (p.wq) the B operands bypass LDS
+    p.splitk_pipe = (p.wq && (reinterpret_cast<uintptr_t>(p.wq) & 15) == 0) ? 2 : 1;
     const int colb = (int)ceil_div(p.Cout, 32);
     // (3D kernel maps only: the K = 9 layers of the 10,800-pixel maps measured slower with 64-row workgroups, 52 vs 47 us)
-    const bool rt2 = rt2_on && p.K >= 27 && ceil_div(p.n_out, 64) * colb >= 320;
+    const bool rt2 = p.K >= 27 && ceil_div(p.n_out, 64) * colb >= 320;
     const int rows = rt2 ? 64 : 32;
     const dim3 grid((unsigned)ceil_div(p.n_out, rows), (unsigned)colb);
     // waves per workgroup: four; more when four per workgroup leave SIMDs without a wave and the chain is long enough to split
     const int64_t wgs = (int64_t)grid.x * grid.y;
     const int stages = p.K * ((p.Cin + 31) / 32);
     int nw = 4;
-    const bool wide_ok = !p.bn_scale_out;   // (the in-kernel BatchNorm finalize is written for 256-thread workgroups)
-    static const bool rt2_nw8 = !(getenv("EPRECON_CONV_SPLITK_RT2_NW8") && getenv("EPRECON_CONV_SPLITK_RT2_NW8")[0] == '0');
-    if (wide_ok && !rt2 && max_waves >= 16 && wgs * 16 <= 4096 && stages >= 32) nw = 16;
-    else if (wide_ok && max_waves >= 8 && wgs * 8 <= 4096 && stages >= 16 && (!rt2 || rt2_nw8)) nw = 8;
+    if (!rt2 && wgs * 16 <= 4096 && stages >= 32) nw = 16;
+    else if (wgs * 8 <= 4096 && stages >= 16) nw = 8;
     const size_t w_floats = (size_t)splitk_w_floats(rt2 ? 2 : 1, nw);
     const size_t lds = w_floats * sizeof(float) + (size_t)p.K * rows * sizeof(int) +
                        (size_t)(((p.K + 3) & ~3) + ((p.K + 4) & ~3)) * sizeof(int) + (size_t)2 * ((p.Cin + 3) & ~3) * sizeof(float) + 16;
@@ -2073,9 +1786,8 @@ constexpr int kWideSlabF4 = 2 * 512;   // float4 per staged slab: 2 column block
 
 inline int wide_splits(int n_out)
 {
-    // workgroups wanted per launch (three fit a CU): EPRECON_CONV_WIDEK_TARGET, read per launch
-    const char *e = getenv("EPRECON_CONV_WIDEK_TARGET");
-    const int target = e ? atoi(e) : 640;   // (320: 165 us on 9,415 rows 192 -> 96 — one workgroup per CU —, 640: 123 us)
+    // workgroups wanted per launch (three fit a CU)
+    constexpr int target = 640;   // (320: 165 us on 9,415 rows 192 -> 96 — one workgroup per CU —, 640: 123 us)
     const int blocks = (int)ceil_div(n_out, kWideRows);
     return max(2, min(13, (target + blocks / 2) / blocks));
 }
@@ -2244,7 +1956,7 @@ bool wide_shape_ok(const ConvParams &p)
     if (p.ld_x % 4 != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0) return false;
     if (p.in_scale && ((reinterpret_cast<uintptr_t>(p.in_scale) & 15) != 0 || (reinterpret_cast<uintptr_t>(p.in_shift) & 15) != 0))
         return false;
-    if (p.accumulate || p.ln || p.bn_scale_out) return false;
+    if (p.accumulate || p.ln) return false;
     return p.n_out >= 4096 && p.n_out <= 40000;
 }
 bool wide_ok(const ConvParams &p) { return wide_shape_ok(p) && p.ws && p.ws_bytes >= wide_workspace_bytes(p); }
@@ -2278,10 +1990,9 @@ bool splitk_ok(const ConvParams &p)
     const int cin_pad = (p.Cin + 7) / 8 * 8;
     const int64_t wg128 = ceil_div(p.n_out, kRowsPerBlock) * nt_full;
     const int stages = p.K * ((p.Cin + 31) / 32);
-    static const int max_wg = getenv("EPRECON_CONV_SPLITK_MAXWG") ? atoi(getenv("EPRECON_CONV_SPLITK_MAXWG")) : 256;
+    constexpr int max_wg = 256, narrow_wg = 256;   // 128-row blocks x column tiles up to which the list counts as short
     // narrow inputs on very short lists (SPVCNN's stride-2 / stride-4 levels: 200..1,500 rows): the chain of a 32-row wave
     // (27 offsets x C_in / 2 MFMAs per column tile), not the weights, is what takes the time
-    const int narrow_wg = getenv("EPRECON_CONV_SPLITK_NARROW") ? atoi(getenv("EPRECON_CONV_SPLITK_NARROW")) : 256;   // (per launch: tests flip it)
     if (cin_pad <= 64) return wg128 <= narrow_wg && stages >= 8;
     return wg128 <= max_wg && stages >= 8;
 }
@@ -2326,8 +2037,6 @@ int conv_dispatch_inner(ConvParams &p, int64_t n_in, hipStream_t st);
 
 int conv_dispatch(ConvParams &p, int64_t n_in, hipStream_t st)
 {
-    // (the in-kernel BatchNorm finalize keeps one counter per 16 summary rows in a fixed region)
-    if (p.bn_scale_out && ceil_div(p.n_out, 32) > kBnMaxRows) return EPRECON_ERR_UNSUPPORTED;
     ConvProf &g = g_conv_prof;
     const bool hit = g.armed && p.K == g.K && p.Cin == g.cin && p.Cout == g.cout && p.n_out >= g.min_rows;
     // EPRECON_CONV_LOG=<file>: one line per launch (shape and the kernel that took it), in launch order, for joining with a
@@ -2367,10 +2076,8 @@ int conv_dispatch_inner(ConvParams &p, int64_t n_in, hipStream_t st)
     {
         const int kind = conv3d_kind(p);
         if (kind != kD3None) {
-            g_last_conv_kernel = kind == kD3Narrow ? "conv3d_tile_narrow_kernel" : kind == kD3Tile16 ? "conv3d_tile16_kernel" : "conv3d_tile_kernel";
-            p.debug = getenv("EPRECON_D3_ABLATE") ? atoi(getenv("EPRECON_D3_ABLATE")) : 0;  // (read per launch: probes flip it)
-            p.bn_rows = d3_tiles_kind(p, kind);
-            return kind == kD3Tile16 ? launch_conv3d_16(p, st) : launch_conv3d(p, kind == kD3Narrow, st);
+            g_last_conv_kernel = kind == kD3Narrow ? "conv3d_tile_narrow_kernel" : "conv3d_tile16_kernel";
+            return kind == kD3Tile16 ? launch_conv3d_16(p, st) : launch_conv3d_single_column(p, st);
         }
         if (!p.nbr && p.K != 1) return EPRECON_ERR_ARG;  // dense-grid form requested for a shape it does not take, no map given
     }
@@ -2381,7 +2088,6 @@ int conv_dispatch_inner(ConvParams &p, int64_t n_in, hipStream_t st)
         int64_t blocks;
         if (conv2d_tile_ok(p, &nt, &nch, &blocks)) {
             g_last_conv_kernel = "conv2d_tile_kernel";
-            p.bn_rows = (int)blocks;
             switch (nch) {
                 case 1: return launch_conv2d_tile<1>(p, st);
                 case 2: return launch_conv2d_tile<2>(p, st);
@@ -2395,45 +2101,35 @@ int conv_dispatch_inner(ConvParams &p, int64_t n_in, hipStream_t st)
     // row pitch covers the rounded-up count (the tail lanes are zeroed after the load)
     const bool vec4 = (p.ld_x % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0) &&
                       (p.Cin % 4 == 0 || p.ld_x >= ((p.Cin + 3) & ~3));
-    if (!vec4 && getenv("EPRECON_CONV_DEBUG"))
-        fprintf(stderr, "[eprecon] scalar-gather conv: n_out=%d K=%d Cin=%d Cout=%d ld_x=%d x%%16=%d\n", p.n_out, p.K, p.Cin,
-                p.Cout, p.ld_x, (int)(reinterpret_cast<uintptr_t>(p.x) & 15));
     // Output columns per workgroup: all of them (<= 128) when the row tiles alone fill the chip,
     // 32-column blocks over blockIdx.y for short lists (10,800 pixels of the 1/16 maps are 85 row
     // tiles for 256 CUs; the gathered rows are re-read from L2 by each column block).
     const int nblk = (int)ceil_div(p.n_out, kRowsPerBlock);
     const int nt_full = (p.Cout + 31) / 32;
     if (p.ln && (nt_full > 4 || p.bn_partial || p.accumulate)) return EPRECON_ERR_UNSUPPORTED;
-    p.bn_rows = (int)ceil_div(p.n_out, kRowsPerBlock);  // the gather forms: 128-row blocks (split-K: 32-row blocks)
     if (wide_ok(p)) {
         g_last_conv_kernel = "spconv_wide_kernel";
-        p.debug = getenv("EPRECON_D3_ABLATE") ? atoi(getenv("EPRECON_D3_ABLATE")) : 0;
         return launch_wide(p, st);
     }
     if (!direct2d && splitk_ok(p)) {
         g_last_conv_kernel = "spconv_splitk_kernel";
-        p.bn_rows = (int)ceil_div(p.n_out, 32);
         return vec4 ? launch_splitk_v<true>(p, st) : launch_splitk_v<false>(p, st);
     }
     if (direct16_ok(p)) {
         g_last_conv_kernel = "spconv_direct16_kernel";
-        p.debug = getenv("EPRECON_D3_ABLATE") ? atoi(getenv("EPRECON_D3_ABLATE")) : 0;
-        p.bn_rows = (int)ceil_div(p.n_out, kDirectRows);
         return launch_direct16(p, st);
     }
     const bool split = nblk < 256 && nt_full > 1 && !p.ln;
     const int cin_pad = (p.Cin + 7) / 8 * 8;
-    static const bool resident_on = !(getenv("EPRECON_CONV_RESIDENT") && getenv("EPRECON_CONV_RESIDENT")[0] == '0');
     // narrow layers: the weights of a group of offsets resident in LDS
-    if (resident_on && cin_pad <= 64 && (p.Cout <= 64 || split)) {
+    if (cin_pad <= 64 && (p.Cout <= 64 || split)) {
         g_last_conv_kernel = "spconv_resident_kernel";
         return (nt_full == 1 || split) ? launch_resident<1>(p, vec4, cin_pad, st) : launch_resident<2>(p, vec4, cin_pad, st);
     }
-    // wide inputs (C_in > 64) on the same pipelined kernel, walked in slabs of <= 64 channels (EPRECON_CONV_WIDE=0:
-    // the 32-channel slab kernel below).  Columns: 64 per workgroup when the row tiles alone fill the chip, else 32.
-    static const bool wide_on = !(getenv("EPRECON_CONV_WIDE") && getenv("EPRECON_CONV_WIDE")[0] == '0');
+    // wide inputs (C_in > 64) on the same pipelined kernel, walked in slabs of <= 64 channels.  Columns: 64 per workgroup
+    // when the row tiles alone fill the chip, else 32.
     // (3D kernel maps only: the dense 2D layers, K = 1 / 9 on 10,800..43,200 pixel rows, measured faster on the slab kernel)
-    if (resident_on && wide_on && cin_pad > 64 && vec4 && (p.K == 27 || p.K == 8) && !(p.ln && nt_full > 2)) {
+    if (cin_pad > 64 && vec4 && (p.K == 27 || p.K == 8) && !(p.ln && nt_full > 2)) {
         g_last_conv_kernel = "spconv_resident_kernel(wide)";
         const bool two = nt_full >= 2 && (p.ln || (int64_t)nblk * ((nt_full + 1) / 2) >= 256);
         return two ? launch_resident<2>(p, vec4, cin_pad, st) : launch_resident<1>(p, vec4, cin_pad, st);
@@ -2482,6 +2178,8 @@ extern "C" float eprecon_profile_conv_ms(int64_t *rows_out, const char **kernel_
     return ms;
 }
 
+extern "C" const char *eprecon_profile_last_conv_kernel(void) { return g_last_conv_kernel; }
+
 extern "C" int64_t eprecon_profile_conv_pairs(void)
 {
     ConvProf &g = g_conv_prof;
@@ -2489,13 +2187,6 @@ extern "C" int64_t eprecon_profile_conv_pairs(void)
     unsigned long long v = 0;
     if (hipMemcpy(&v, g.pairs_dev, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (int64_t)v;
-}
-
-extern "C" size_t eprecon_conv_bn_finalize_workspace_bytes(int64_t partial_rows, int cout)
-{
-    if (partial_rows <= 0 || cout <= 0) return 0;
-    const size_t ngroups = (size_t)(partial_rows + kBnGroupRows - 1) / kBnGroupRows;
-    return kBnTicketBytes + ngroups * 3 * (size_t)cout * sizeof(float);
 }
 
 extern "C" size_t eprecon_conv_pack_weight_floats(int kvol, int cin, int cout)
@@ -2548,7 +2239,6 @@ static int conv_check_and_run(ConvParams &p, int64_t n_in, int64_t n_out, void *
     if (!p.nbr && n_in != n_out) return EPRECON_ERR_ARG;
     if ((p.in_scale == nullptr) != (p.in_shift == nullptr) || (p.res_scale == nullptr) != (p.res_shift == nullptr))
         return EPRECON_ERR_ARG;
-    if (p.bn_scale_out && (!p.bn_partial || !p.bn_shift_out || !p.bn_ticket || p.Cout > 128)) return EPRECON_ERR_ARG;
     if (p.Cout > 4096 || n_out > 0x7fffffff) return EPRECON_ERR_UNSUPPORTED;
     if (n_out == 0) return EPRECON_OK;
     p.n_out = (int)n_out;
@@ -2566,8 +2256,6 @@ static void params_from_desc(ConvParams &p, const eprecon_conv_desc *d)
     p.res = d->residual; p.ld_res = d->ld_res; p.bn_partial = d->bn_partial;
     p.in_scale = d->in_scale; p.in_shift = d->in_shift; p.in_relu = d->in_relu;
     p.res_scale = d->res_scale; p.res_shift = d->res_shift; p.res_relu = d->res_relu;
-    p.bn_scale_out = d->bn_scale_out; p.bn_shift_out = d->bn_shift_out; p.bn_gamma = d->bn_gamma;
-    p.bn_beta = d->bn_beta; p.bn_eps = d->bn_eps; p.bn_ticket = d->bn_ticket;
     p.ln = d->ln; p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.ln_eps = d->ln_eps;
     p.ln_post_relu = d->ln_post_relu;
     p.img_h = d->img_h; p.img_w = d->img_w; p.img_maps = d->img_maps;

@@ -75,20 +75,10 @@ def packed_weight(conv):
     return cached[1]
 
 
-# EPRECON_BN_TICKET=0: a separate bn_finalize_affine launch per layer instead of finishing the BatchNorm inside the
-# convolution (sparse.FUSED_FINALIZE; round 1's first form of it — one counter, a release fence per workgroup — was slower
-# than the extra launch: 3.4 vs 2.3 ms per cfg2 step; the current form stores the summaries write-through, no fences)
-from .sparse import FUSED_FINALIZE_MAX_C, finalize_workspace  # noqa: E402
-# The 2D stack is replayed from a HIP graph, where a finalize node costs ~1.5 us of boundary + 7 us of kernel on a side
-# branch, while the in-kernel form adds a store drain + an atomic round trip to EVERY workgroup's tail: measured 2.04 vs
-# 1.95 ms per cfg2 step (profiles/r03/bn_ticket_ab.txt).  Off here by default; EPRECON_BN_TICKET_2D=1 turns it on.
-_FUSED_FINALIZE = os.environ.get("EPRECON_BN_TICKET_2D", "0") == "1"
 # 3x3 layers on long pixel lists through the direct gather kernel (csrc/sparse_conv_direct.hip) on the pixel map instead of the
 # image-tile kernel: rocprofv3 durations on the 9 x 120 x 160 level 24->12 36.6 -> 23.4 us, 12->12 28.6 -> 17.6, 24->24 38.2 ->
 # 36.8; on 9 x 60 x 80 it is a wash (40->40 33.7 -> 28.7, 32->32 17.5 -> 18.4), hence the row threshold.
-DIRECT_2D = os.environ.get("EPRECON_CONV_DIRECT_2D", "1") == "1"
-DIRECT_2D_MIN_ROWS = int(os.environ.get("EPRECON_CONV_DIRECT_2D_MIN_ROWS", "100000"))
-MERGE_ELAN_1X1 = os.environ.get("EPRECON_ELAN_MERGE", "0") == "1"  # measured neutral on MI355X
+DIRECT_2D_MIN_ROWS = 100000
 
 
 class Act:
@@ -112,27 +102,11 @@ def conv_bn_act(conv, bn, x, grid, out=None, aff=None, relu=True, pre_relu=False
     returns Act(raw rows, scale, shift, relu).  `out`: rows to write (may be a channel slice), `aff`: the
     (scale, shift) slices to fill (e.g. of a concat buffer's vectors)."""
     return conv_bn_launch(packed_weight(conv), conv.bias, bn.weight, bn.bias, bn.eps, conv.kernel_size[0], x, grid,
-                          out=out, aff=aff, relu=relu, pre_relu=pre_relu, residual=residual, ticket_owner=conv)
-
-
-def merged_1x1(conv_a, bn_a, conv_b, bn_b):
-    """two 1x1 conv + BatchNorm layers on the same input as one layer with concatenated output channels
-    (BatchNorm is per channel, so this is exact); cached per parameter version on conv_a"""
-    tag = tuple((t._version, t.data_ptr()) for t in (conv_a.weight, conv_b.weight, conv_a.bias, conv_b.bias,
-                                                     bn_a.weight, bn_b.weight, bn_a.bias, bn_b.bias))
-    cached = getattr(conv_a, "_eprecon_merged", None)
-    if cached is None or cached[0] != tag:
-        assert conv_a.kernel_size == (1, 1) and conv_b.kernel_size == (1, 1) and bn_a.eps == bn_b.eps
-        with torch.no_grad():
-            w = torch.cat([packed_weight(conv_a), packed_weight(conv_b)], dim=2).contiguous()
-            cat = lambda a, b: torch.cat([a.detach(), b.detach()]).contiguous()
-            cached = (tag, w, cat(conv_a.bias, conv_b.bias), cat(bn_a.weight, bn_b.weight), cat(bn_a.bias, bn_b.bias))
-        conv_a._eprecon_merged = cached
-    return cached[1:]
+                          out=out, aff=aff, relu=relu, pre_relu=pre_relu, residual=residual)
 
 
 def conv_bn_launch(w, bias, gamma, beta, eps, k, x, grid, out=None, aff=None, relu=True, pre_relu=False,
-                   residual=None, ticket_owner=None):
+                   residual=None):
     lib = _lib.load()
     kvol, cin, cout = w.shape
     rows = x.rows
@@ -145,7 +119,6 @@ def conv_bn_launch(w, bias, gamma, beta, eps, k, x, grid, out=None, aff=None, re
     if aff is None:
         a = torch.empty((2, cout), dtype=torch.float32, device=dev)
         aff = (a[0], a[1])
-    fused_finalize = _FUSED_FINALIZE and ticket_owner is not None and cout <= FUSED_FINALIZE_MAX_C
     d = _lib.ConvDesc()
     d.x, d.n_in, d.ld_x = rows.data_ptr(), n, rows.stride(0)
     d.nbr, d.kvol, d.n_out = _dptr(nbr), kvol, n
@@ -160,24 +133,19 @@ def conv_bn_launch(w, bias, gamma, beta, eps, k, x, grid, out=None, aff=None, re
     d.in_scale, d.in_shift, d.in_relu = _dptr(x.scale), _dptr(x.shift), int(x.relu)
     if k == 3:
         d.img_h, d.img_w, d.img_maps = grid.height, grid.width, grid.maps  # narrow layers: image-tile kernel
-        if SP.SPLITK_BDIRECT and n < DIRECT_2D_MIN_ROWS:
+        if n < DIRECT_2D_MIN_ROWS:
             pq = SP.packed_weight(w)                 # short pixel lists (the 10,800-pixel level): B operands of the split-K kernel
             d.packed_weight = pq.data_ptr()
-        if DIRECT_2D and cout <= SP.DIRECT_MAX_COUT and n >= DIRECT_2D_MIN_ROWS:
+        if cout <= SP.DIRECT_MAX_COUT and n >= DIRECT_2D_MIN_ROWS:
             pw = SP.packed_weight16(w)               # long pixel lists: the direct gather kernel on the pixel map
             d.packed_weight16 = pw.data_ptr()
     # the summaries are per workgroup: 128-row blocks (gather forms) or image tiles (tile kernel)
     partial = torch.empty((lib.eprecon_conv_desc_partial_rows(ctypes.byref(d)), 3, cout), dtype=torch.float32, device=dev)
     d.bn_partial = partial.data_ptr()
-    if fused_finalize:
-        d.bn_scale_out, d.bn_shift_out = aff[0].data_ptr(), aff[1].data_ptr()
-        d.bn_gamma, d.bn_beta, d.bn_eps = _dptr(gamma), _dptr(beta), float(eps)
-        d.bn_ticket = finalize_workspace(ticket_owner, partial.shape[0], cout, dev).data_ptr()
     _lib.check(lib.eprecon_conv_desc_async(ctypes.byref(d), _lib.current_stream()), "eprecon_conv_desc_async")
-    if not fused_finalize:
-        _lib.check(lib.eprecon_batchnorm_finalize_affine_async(
-            partial.data_ptr(), partial.shape[0], cout, _dptr(gamma), _dptr(beta), float(eps),
-            aff[0].data_ptr(), aff[1].data_ptr(), _lib.current_stream()), "eprecon_batchnorm_finalize_affine_async")
+    _lib.check(lib.eprecon_batchnorm_finalize_affine_async(
+        partial.data_ptr(), partial.shape[0], cout, _dptr(gamma), _dptr(beta), float(eps),
+        aff[0].data_ptr(), aff[1].data_ptr(), _lib.current_stream()), "eprecon_batchnorm_finalize_affine_async")
     return Act(out, aff[0], aff[1], relu)
 
 

@@ -60,13 +60,12 @@ class Cfg2Step:
         self.defer_reads = False
         self._inflight = None
         # the Back_Project levels are queued behind the variance volume, in front of the host's wait for its count
-        # (EPRECON_CFG2_LEVELS_FIRST=1: at the start of the step, round 2's order)
-        self.levels_inside = os.environ.get("EPRECON_CFG2_LEVELS_FIRST", "0") != "1"
+        # (levels_inside = False: at the start of the step, round 2's order: 1.67-1.70 ms against 1.60 ms)
+        self.levels_inside = True
         self.profile_dominant = False  # bench.py: time the dense 96^3 gather with the library's event pair
-        self.bp_side_stream = os.environ.get("EPRECON_CFG2_BP_STREAM", "0") == "1"
-        # (EPRECON_CFG2_BP_PRIO: HIP stream priority of that stream; larger = lower priority, clamped by the runtime)
-        prio = int(os.environ.get("EPRECON_CFG2_BP_PRIO", "0"))
-        self._bp_stream = torch.cuda.Stream(device=dev, priority=prio) if self.bp_side_stream else None
+        # (the three levels on their own stream: 1.57 ms, but the timed gather stretches to 142 us next to the 2D stack)
+        self.bp_side_stream = False
+        self._bp_stream = None
 
     @torch.no_grad()
     def run(self):
@@ -109,7 +108,7 @@ class Cfg2Step:
             if side is not main:
                 side.wait_stream(main)
             with torch.cuda.stream(side):
-                # EPRECON_CFG2_BP_STREAM=1: the three levels on their own stream, concurrent with the initialisation branch
+                # bp_side_stream: the three levels on their own stream, concurrent with the initialisation branch
                 for name, lvl, interval, mv in LEVELS:
                     if self.profile_dominant and name == "bp96":
                         _lib.load().eprecon_profile_enable(2)  # one-shot: bracket this level's gather kernel only
@@ -239,6 +238,8 @@ class Cfg4Step:
                 calibrate_occupancy_heads(self.net, self.frags)
             for p_ in self.net.parameters():
                 dist.broadcast(p_.data, 0)
+            from .sparse import clear_packed_weights
+            clear_packed_weights(self.net)     # (writes through .data do not bump the version the weight caches key on)
         else:
             calibrate_occupancy_heads(self.net, self.frags)
         # EPRECON_FORCE_EXCHANGE=1: run the boundary all-gather even at world size 1 (exercises the RCCL path on one GPU)
@@ -248,7 +249,7 @@ class Cfg4Step:
         self.pipeline = pipeline
         if pipeline:
             self.net.panoptic_stream = torch.cuda.Stream(device=self.device)
-            if os.environ.get("EPRECON_PIPELINE_THREAD", "1") == "1":
+            if pipeline != "inline":     # ("inline": the branch's launches are issued by the main thread on the side stream)
                 from concurrent.futures import ThreadPoolExecutor
                 self.net.panoptic_worker = ThreadPoolExecutor(max_workers=1, thread_name_prefix="eprecon-panoptic")
         self._pending = None
@@ -401,6 +402,8 @@ class TrainStep:
             from torch.nn.parallel import DistributedDataParallel
             for p_ in self.net.parameters():
                 dist.broadcast(p_.data, 0)
+            from .sparse import clear_packed_weights
+            clear_packed_weights(self.net)
             self.model = DistributedDataParallel(self.net, device_ids=[self.device.index], output_device=self.device.index,
                                                  broadcast_buffers=False, find_unused_parameters=True)
         self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, betas=(0.9, 0.999))

@@ -20,6 +20,9 @@ class GlobalMap:
         h = ctypes.c_void_p()
         _lib.check(lib.eprecon_map_create(self.channels, ctypes.byref(h)), "eprecon_map_create")
         self._h = h
+        # called after a stream-ordered READ of the rows has been queued (export, stamps): an owner that lets another
+        # stream rewrite the map (GRUFusion's boundary exchange) re-records the event that stream waits for
+        self.on_read = None
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -42,6 +45,8 @@ class GlobalMap:
         f = torch.empty((n, self.channels), dtype=torch.float32, device=self.device)
         _lib.check(_lib.load().eprecon_map_export_async(self._h, _lib.ptr(c), _lib.ptr(f), _lib.current_stream()),
                    "eprecon_map_export_async")
+        if self.on_read is not None:
+            self.on_read()
         return c, f
 
     @property
@@ -108,6 +113,8 @@ class GlobalMap:
         out = torch.empty(self.size, dtype=torch.int32, device=self.device)
         _lib.check(_lib.load().eprecon_map_stamps_async(self._h, _lib.ptr(out), None, 0, 0, _lib.current_stream()),
                    "eprecon_map_stamps_async")
+        if self.on_read is not None:
+            self.on_read()
         return out
 
     def set_stamps(self, stamps=None, fill=None):

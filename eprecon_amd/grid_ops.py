@@ -4,10 +4,12 @@ import torch
 from . import _lib
 
 
-def init_select(logit, coords, batch_size, dim=24, cell=4, threshold=0.3):
+def init_select(logit, coords, batch_size, dim=24, cell=4, threshold=0.3, must_be_zero=()):
     """models/neucon_network.py:264,298-318.  logit f32[N(,1)] and coords int32[N,4] of the valid
     48^3 voxels -> int32[M,4] stage-0 coordinates (raster order per batch element) and the
-    per-batch counts (one host sync, like the reference's torch.nonzero)."""
+    per-batch counts (one host sync, like the reference's torch.nonzero).
+    must_be_zero: int32 device scalars ([1]-shaped) read back in the SAME host read; a non-zero one raises (the
+    off-grid counters of the dense-grid convolution maps that produced `logit`, sparse.DenseMap)."""
     lib = _lib.load()
     logit = logit.reshape(-1).contiguous()
     coords = coords.contiguous()
@@ -20,7 +22,14 @@ def init_select(logit, coords, batch_size, dim=24, cell=4, threshold=0.3):
                                              float(threshold), batch_size, dim, cell, _lib.ptr(out),
                                              _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
                "eprecon_init_select_async")
-    host = counts.cpu().tolist()
+    if must_be_zero:
+        host = torch.cat([counts] + [t.reshape(1) for t in must_be_zero]).cpu().tolist()
+        if any(host[1 + batch_size:]):
+            raise _lib.EpreconError(f"dense-grid convolution: {host[1 + batch_size:]} voxels of the set are not on the grid "
+                                    "their VoxelSet was declared with (rows left unwritten); EPRECON_ERR_ARG")
+        host = host[:1 + batch_size]
+    else:
+        host = counts.cpu().tolist()
     return out[: host[0]], host[1:]
 
 

@@ -109,10 +109,17 @@ class GRUFusion(nn.Module):
         if self.global_volume[i] is None or self.global_volume[i].device != device:
             self.global_volume[i] = GlobalMap(self.ch_in[i], device)
             self.target_tsdf_volume[i] = GlobalMap(1, device)
+            self.global_volume[i].on_read = self._note_map_read
         self.global_volume[i].reset()
         self.target_tsdf_volume[i].reset()
         if self._xchg is not None:
             self._xchg.stamps[i] = self._xchg.new_stamps(i)
+
+    def _note_map_read(self):
+        """a read of the map rows was queued on the current stream (export / stamps): the exchange stream, which rewrites
+        rows in place, must also wait for it"""
+        if self._xchg is not None and self._xchg_stream is not None and torch.cuda.is_available():
+            self._map_ready = torch.cuda.current_stream().record_event()
 
     def _begin_fragment(self, scale, inputs, i, dev):
         """scene bookkeeping of models/gru_fusion.py:280-293 -> relative origin (LongTensor[3], host)"""
@@ -128,12 +135,21 @@ class GRUFusion(nn.Module):
 
     def _host_origins(self, inputs):
         """host copies of inputs['vol_origin'] / ['vol_origin_partial'] (f32[B,3]), fetched once per fragment
-        instead of once per scale (each .cpu() is a device synchronisation)"""
+        instead of once per scale (each .cpu() is a device synchronisation).  A caller that already holds the origins on
+        the host (the data loader builds them there: datasets/transforms.py:250-260) passes them as
+        inputs['vol_origin_host'] / ['vol_origin_partial_host'] and no device read happens at all.
+        The device read is issued on the CURRENT stream: callers that switch streams (exchange_boundaries) call this on
+        the stream the inputs were produced on first, and hit the cache afterwards."""
         vo, vp = inputs["vol_origin"], inputs["vol_origin_partial"]
         key = (vo.data_ptr(), vo._version, vp.data_ptr(), vp._version)
         hit = getattr(self, "_origin_cache", None)
         if hit is None or hit[0] != key or hit[1] is not vo or hit[2] is not vp:
-            both = torch.stack([vo.detach().float().reshape(-1, 3), vp.detach().float().reshape(-1, 3)]).cpu()
+            ho, hp = inputs.get("vol_origin_host"), inputs.get("vol_origin_partial_host")
+            if ho is not None and hp is not None:
+                both = (torch.as_tensor(ho).detach().float().reshape(-1, 3).cpu(),
+                        torch.as_tensor(hp).detach().float().reshape(-1, 3).cpu())
+            else:
+                both = torch.stack([vo.detach().float().reshape(-1, 3), vp.detach().float().reshape(-1, 3)]).cpu()
             hit = (key, vo, vp, both[0], both[1])
             self._origin_cache = hit
         return hit[3], hit[4]
@@ -157,6 +173,10 @@ class GRUFusion(nn.Module):
             if self._xchg_stream is None:
                 self._xchg_stream = torch.cuda.Stream(device=dev)
             main = torch.cuda.current_stream(dev)
+            # The origins are inputs of THIS fragment: produced / uploaded on the main stream after `_map_ready` was recorded,
+            # so the side stream is not ordered behind them.  Their host copy is therefore taken here, on the main stream
+            # (no device read at all when the caller passes the host-side origins), and the side stream only hits the cache.
+            self._host_origins(inputs)
             if self._map_ready is not None:
                 self._xchg_stream.wait_event(self._map_ready)
             else:

@@ -179,8 +179,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         self.class_embed = nn.Linear(hidden_dim, num_classes + 1)
         self.mask_embed = MLP(hidden_dim, hidden_dim * 4, mask_dim, 3)
         # the static-shape query side of every layer replayed from HIP graphs on the GPU inference path
-        _env = __import__("os").environ
-        self.use_hip_graph = _env.get("EPRECON_NO_GRAPH", "0") != "1" and _env.get("EPRECON_DECODER_GRAPH", "1") == "1"
+        self.use_hip_graph = __import__("os").environ.get("EPRECON_NO_GRAPH", "0") != "1"
         self._plan = None
         self._plan_params = None
 

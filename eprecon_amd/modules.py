@@ -129,13 +129,10 @@ class SparseSubMConv3d(nn.Module):
         nbr = vset.conv_map(3) if self.kernel == 3 else None   # dense-grid form on well-filled grids, else the kernel map
         return SP.sparse_conv(features, self.weight, nbr, self.bias, out=out, relu=relu)
 
-    def run_stats(self, features, vset, out=None, bn=None):
-        """conv + bias and the BatchNorm summaries of its output in one launch -> (y, partial[, (scale, shift) | None]);
-        bn: the TrainBatchNorm1d that follows (its statistics are then finished inside the launch)"""
+    def run_stats(self, features, vset, out=None):
+        """conv + bias and the BatchNorm summaries of its output in one launch -> (y, partial)"""
         nbr = vset.conv_map(3) if self.kernel == 3 else None
-        if bn is None:
-            return SP.sparse_conv_fused(features, self.weight, nbr, self.bias, out=out, bn_partial=True)
-        return SP.conv_stats(features, self.weight, nbr, out=out, bias=self.bias, bn=bn.bn_args(), owner=bn)
+        return SP.conv_stats(features, self.weight, nbr, out=out, bias=self.bias)
 
     def run_ln(self, features, vset, ln, out=None, relu=False, residual=None, post_relu=False):
         """conv [+ReLU] [+residual] -> LayerNorm `ln` [-> ReLU], one launch"""
@@ -254,15 +251,9 @@ class TrainBatchNorm1d(nn.BatchNorm1d):
         """second half of the BatchNorm from the producing convolution's summaries"""
         return SP.batchnorm_apply_partials(x, partial, self.weight, self.bias, self.eps, residual, relu, out)
 
-    def finish(self, x, partial, aff, residual=None, relu=False, out=None):
-        """the same when the producer may already have finished the statistics inside its launch (aff = (scale, shift)):
-        then one affine pass, else finalize + apply from the summaries"""
-        if aff is None:
-            return self.run_partials(x, partial, residual=residual, relu=relu, out=out)
-        return SP.affine_rows(x, aff[0], aff[1], residual=residual, relu=relu, out=out)
-
-    def bn_args(self):
-        return (self.weight, self.bias, self.eps)
+    def affine(self, partial):
+        """the BatchNorm in affine form (scale, shift) from the producer's summaries: consumers apply it on load"""
+        return SP.bn_affine(partial, self.weight, self.bias, self.eps)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -374,13 +365,8 @@ class ELAN(nn.Module):
         aff = torch.empty((2, 4 * d), dtype=torch.float32, device=dev)
         part = lambda a, b: D2.Act(cat[:, a:b], aff[0, a:b], aff[1, a:b], True)
         sl = lambda a, b: dict(out=cat[:, a:b], aff=(aff[0, a:b], aff[1, a:b]))
-        if D2.MERGE_ELAN_1X1:
-            # conv1 / conv2 (both 1x1 d -> d on x) as ONE d -> 2d layer writing the first two slices
-            w, b, g, be = D2.merged_1x1(self.conv1.conv, self.conv1.bn, self.conv2.conv, self.conv2.bn)
-            D2.conv_bn_launch(w, b, g, be, self.conv1.bn.eps, 1, x, grid, relu=True, **sl(0, 2 * d))
-        else:
-            self.conv1.run_act(x, grid, **sl(0, d))
-            self.conv2.run_act(x, grid, **sl(d, 2 * d))
+        self.conv1.run_act(x, grid, **sl(0, d))
+        self.conv2.run_act(x, grid, **sl(d, 2 * d))
         self.conv3.run_act(part(d, 2 * d), grid, **sl(2 * d, 2 * d + h))
         self.conv4.run_act(part(2 * d, 2 * d + h), grid, **sl(2 * d + h, 3 * d))
         self.conv5.run_act(part(2 * d + h, 3 * d), grid, **sl(3 * d, 3 * d + h))
@@ -527,17 +513,13 @@ from .torchsparse_utils import devoxelize_gate, initial_voxelize, point_to_voxel
 __all__ = ["SPVCNN", "SConv3d", "ConvGRU"]
 
 
-# BatchNorm summaries in the convolution epilogue for the SPVCNN blocks (EPRECON_SPVCNN_FUSED_BN=0: stand-alone
-# three-launch BatchNorm)
-_FUSED_BN_STATS = __import__("os").environ.get("EPRECON_SPVCNN_FUSED_BN", "1") == "1"
-
-
 def _linear_wt(lin):
     """weight of an nn.Linear as the [C_in, C_out] matrix the per-voxel GEMM takes, transposed once per weight
     version (the inference path calls every layer thousands of times with the same weights)"""
     hit = getattr(lin, "_wt_cache", None)
-    if hit is None or hit[0] != lin.weight._version or hit[1].device != lin.weight.device:
-        hit = (lin.weight._version, lin.weight.detach().t().contiguous())
+    tag = (lin.weight._version, lin.weight.data_ptr())
+    if hit is None or hit[0] != tag or hit[1].device != lin.weight.device:
+        hit = (tag, lin.weight.detach().t().contiguous())
         lin._wt_cache = hit
     return hit[1]
 
@@ -564,12 +546,9 @@ class Conv3d(nn.Module):
             return y if out is None else out.copy_(y)
         return SP.sparse_conv(feats, self.kernel, nbr, None, out=out)
 
-    def run_stats(self, feats, nbr, out=None, in_affine=None, bn=None):
-        """conv + the BatchNorm summaries of its output in one launch -> (y, partial[, (scale, shift) | None]);
-        bn: the TrainBatchNorm1d that follows (its statistics are then finished inside the launch)"""
-        if bn is None:
-            return SP.conv_stats(feats, self.kernel, nbr, in_affine=in_affine, out=out)
-        return SP.conv_stats(feats, self.kernel, nbr, in_affine=in_affine, out=out, bn=bn.bn_args(), owner=bn)
+    def run_stats(self, feats, nbr, out=None, in_affine=None):
+        """conv + the BatchNorm summaries of its output in one launch -> (y, partial)"""
+        return SP.conv_stats(feats, self.kernel, nbr, in_affine=in_affine, out=out)
 
 
 class BasicConvolutionBlock(nn.Module):
@@ -582,11 +561,8 @@ class BasicConvolutionBlock(nn.Module):
     def run(self, feats, nbr, out=None):
         if recording():
             return self.net[1].run(self.net[0].run(feats, nbr), relu=True)
-        if not _FUSED_BN_STATS:
-            y = self.net[0].run(feats, nbr, out=out)
-            return self.net[1].run(y, relu=True, out=y)
-        y, partial, aff = self.net[0].run_stats(feats, nbr, out=out, bn=self.net[1])
-        return self.net[1].finish(y, partial, aff, relu=True, out=y)
+        y, partial = self.net[0].run_stats(feats, nbr, out=out)
+        return self.net[1].run_partials(y, partial, relu=True, out=y)
 
 
 class BasicDeconvolutionBlock(nn.Module):
@@ -600,11 +576,8 @@ class BasicDeconvolutionBlock(nn.Module):
     def run(self, feats, nbr, out=None):
         if recording():
             return self.net[1].run(self.net[0].run(feats, nbr), relu=True)
-        if not _FUSED_BN_STATS:
-            y = self.net[0].run(feats, nbr, out=out)
-            return self.net[1].run(y, relu=True, out=y)
-        y, partial, aff = self.net[0].run_stats(feats, nbr, out=out, bn=self.net[1])
-        return self.net[1].finish(y, partial, aff, relu=True, out=y)
+        y, partial = self.net[0].run_stats(feats, nbr, out=out)
+        return self.net[1].run_partials(y, partial, relu=True, out=y)
 
 
 class ResidualBlock(nn.Module):
@@ -625,27 +598,17 @@ class ResidualBlock(nn.Module):
             y = self.net[3].run(y, nbr)
             skip = feats if len(self.downsample) == 0 else self.downsample[1].run(self.downsample[0].run(feats, None))
             return self.net[4].run(y, residual=skip, relu=True)
-        if not _FUSED_BN_STATS:
-            y = self.net[0].run(feats, nbr)
-            self.net[1].run(y, relu=True, out=y)
-            y2 = self.net[3].run(y, nbr)
-            if len(self.downsample) == 0:
-                skip = feats
-            else:
-                skip = self.downsample[0].run(feats, None)
-                self.downsample[1].run(skip, out=skip)
-            return self.net[4].run(y2, residual=skip, relu=True, out=out if out is not None else y2)
         # conv1's BatchNorm + ReLU stays pending and is applied by conv2 while it gathers
-        bn1 = self.net[1]
-        y, p1, a1 = self.net[0].run_stats(feats, nbr, bn=bn1)
-        scale, shift = a1 if a1 is not None else SP.bn_affine(p1, bn1.weight, bn1.bias, bn1.eps)
-        y2, p2, a2 = self.net[3].run_stats(y, nbr, in_affine=(scale, shift, True), bn=self.net[4])
+        y, p1 = self.net[0].run_stats(feats, nbr)
+        scale, shift = self.net[1].affine(p1)
+        y2, p2 = self.net[3].run_stats(y, nbr, in_affine=(scale, shift, True))
         if len(self.downsample) == 0:
-            skip = feats
-        else:
-            skip, ps, a_s = self.downsample[0].run_stats(feats, None, bn=self.downsample[1])
-            self.downsample[1].finish(skip, ps, a_s, out=skip)
-        return self.net[4].finish(y2, p2, a2, residual=skip, relu=True, out=out if out is not None else y2)
+            return self.net[4].run_partials(y2, p2, residual=feats, relu=True, out=out if out is not None else y2)
+        # the 1x1 skip convolution's BatchNorm stays pending as well: the block's tail applies both in one pass
+        skip, ps = self.downsample[0].run_stats(feats, None)
+        return SP.batchnorm_apply_partials(y2, p2, self.net[4].weight, self.net[4].bias, self.net[4].eps, residual=skip,
+                                           relu=True, out=out if out is not None else y2,
+                                           res_affine=self.downsample[1].affine(ps))
 
 
 class _PointMLP(nn.Sequential):
@@ -660,8 +623,8 @@ class _PointMLP(nn.Sequential):
         lin = self[0]
         if recording():   # (per-point GEMM on the HIP kernel: rocBLAS picks 32x32 tiles for these [N, <100] x [<100, <100] shapes)
             return self[1].run(AG.sparse_conv(feats, lin.weight.t(), None, lin.bias), relu=True)
-        y, partial, aff = SP.conv_stats(feats, _linear_wt(lin), None, bn=self[1].bn_args(), owner=self[1])
-        return self[1].finish(y, partial, aff, relu=True, out=y)
+        y, partial = SP.conv_stats(feats, _linear_wt(lin), None)
+        return self[1].run_partials(y, partial, relu=True, out=y)
 
 
 class SPVCNN(nn.Module):
@@ -726,8 +689,8 @@ class SPVCNN(nn.Module):
         cat0 = torch.empty((s1.n, cs[4] + cs[0]), dtype=torch.float32, device=dev)
         cat1 = torch.empty((s2.n, cs[3] + cs[1]), dtype=torch.float32, device=dev)
 
-        f0, p0, a0 = self.stem[0].run_stats(x0.F, s1.kernel_map(3), out=cat0[:, cs[4]:], bn=self.stem[1])
-        self.stem[1].finish(f0, p0, a0, relu=True, out=f0)
+        f0, p0 = self.stem[0].run_stats(x0.F, s1.kernel_map(3), out=cat0[:, cs[4]:])
+        self.stem[1].run_partials(f0, p0, relu=True, out=f0)
         x0 = SparseTensor(f0, s1)
         z0 = voxel_to_point(x0, z)
 

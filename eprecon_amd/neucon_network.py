@@ -35,9 +35,10 @@ from .occupancy_initialization import Occupancy_Initialization
 from .tensor import PointTensor
 from .torchsparse_utils import aligned_camera_coords
 
-# EPRECON_FUSED_SPARSIFY=0: the reference's sequence of torch calls (threshold, index_add counts, nonzero, index_select x 4,
-# cat: ~15 launches and two host reads per level) instead of eprecon_sparsify_async (3 launches, one host read)
-_FUSED_SPARSIFY = __import__("os").environ.get("EPRECON_FUSED_SPARSIFY", "1") == "1"
+# the reference's sequence of torch calls (threshold, index_add counts, nonzero, index_select x 4, cat: ~15 launches and two
+# host reads per level) stays for training and the seeded random drop; inference takes eprecon_sparsify_async (3 launches, one
+# host read).  Tests flip this module attribute to compare the two.
+_FUSED_SPARSIFY = True
 
 
 def _warn(msg):
@@ -144,8 +145,10 @@ class NeuConNet(nn.Module):
         if init_output is None or not select:
             return init_output, None, shape_init
         occ_init, coord_init, _ = init_output
+        # (the same host read checks that every voxel of the initialisation set was on the dense grid its convolutions ran on)
         selected, _ = GO.init_select(occ_init, coord_init, bs, dim=shape_init[0] // 2 ** INIT_STAGE,
-                                     cell=2 ** self.n_scales, threshold=INIT_OCC_THRESHOLD)
+                                     cell=2 ** self.n_scales, threshold=INIT_OCC_THRESHOLD,
+                                     must_be_zero=getattr(self.initialization, "dense_checks", ()))
         return init_output, selected, shape_init
 
     def forward(self, features, features_backbone2d_occ_pano, inputs, outputs, only_train_init=False,

@@ -148,8 +148,8 @@ class Occupancy_Initialization(nn.Module):
             x = conv.run_ln(x, vset, norm, relu=True, residual=x)  # LN(x + ReLU(conv(x))), one launch
         if torch.is_grad_enabled():
             return self.norm4.run(self.subm4.run(x, vset))
-        y, partial, aff = self.subm4.run_stats(x, vset, bn=self.norm4)   # the logit layer finishes norm4's statistics itself
-        return self.norm4.finish(y, partial, aff, out=y)
+        y, partial = self.subm4.run_stats(x, vset)       # the logit layer writes norm4's summaries in its epilogue
+        return self.norm4.run_partials(y, partial, out=y)
 
     def forward(self, coords, origin, voxel_size, features_all, KRcam, shape, stage, min_view_number, between=None):
         """`between` (optional, beyond the reference's signature): called once after the variance volume is queued and before
@@ -184,6 +184,7 @@ class Occupancy_Initialization(nn.Module):
         coord_valid = res["coords"]
         parts = []
         start = 0
+        self.dense_checks = []   # off-grid counters of the dense-grid maps used below (device scalars; the caller's next host read checks them)
         for b in range(bs):  # statistics of norm0 / norm4 are per batch element, as in the reference
             nb = res["n_valid_per_batch"][b]
             seg = slice(start, start + nb)
@@ -191,6 +192,8 @@ class Occupancy_Initialization(nn.Module):
             # 3x3x3 layers of the stack take the dense-grid kernel (no hash grid, no kernel map)
             vset = SP.VoxelSet(coord_valid[seg], interval, dims=shape)
             parts.append(self.sparse_stack(res["var"][seg], vset))
+            if vset._dense is not None:
+                self.dense_checks.append(vset._dense.rank[-1:])
             start += nb
         occ = parts[0] if bs == 1 else torch.cat(parts)
         out_coords = coord_valid if coords.dtype == torch.int32 else coord_valid.to(coords.dtype)

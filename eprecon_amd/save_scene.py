@@ -114,25 +114,27 @@ def export_ply(mesh, path):
 def load_scene_npz(path):
     """A scene file written by SaveScene -> the reference's dense arrays {origin, voxel_size, tsdf, semantic, instance}
     (utils.py:360-366), whichever form it was written in.  The sparse form stores the scene as voxel rows
-    (coords int32[M,3] relative to `origin`, tsdf f32[M], semantic / instance int32[M], dims): the dense volumes
+    (sparse_coords int32[M,3] relative to `origin`, sparse_tsdf f32[M], sparse_semantic / sparse_instance int32[M], dims): the dense volumes
     (TSDF default 1, ids default 0: models/gru_fusion.py:232-252) are rebuilt here, on the host that wants them."""
     z = np.load(path)
-    if "coords" not in z.files:
+    if "sparse_coords" not in z.files:
         return {k: z[k] for k in z.files}
-    dims, c = tuple(int(d) for d in z["dims"]), z["coords"].astype(np.int64)
+    dims, c = tuple(int(d) for d in z["dims"]), z["sparse_coords"].astype(np.int64)
     out = {"origin": z["origin"], "voxel_size": z["voxel_size"]}
     for key, fill, dtype in (("tsdf", 1.0, np.float32), ("semantic", 0, np.int32), ("instance", 0, np.int32)):
         vol = np.full(dims, fill, dtype)
-        vol[c[:, 0], c[:, 1], c[:, 2]] = z[key]
+        vol[c[:, 0], c[:, 1], c[:, 2]] = z["sparse_" + key]
         out[key] = vol
     return out
 
 
 class SaveScene:
     """utils.py:190-410 (SAVE_SCENE_MESH / SAVE_INCREMENTAL paths; the Open3D incremental viewer is out of scope).
-    cfg.SAVE_SCENE_NPZ (beyond the reference's keys): "sparse" (default) writes the scene volumes as voxel rows — a few MB
-    device -> host instead of three dense volumes (utils.py:345-348,380-385 copy them); "dense" writes the reference's
-    arrays.  load_scene_npz reads both."""
+    cfg.SAVE_SCENE_NPZ (beyond the reference's keys): "dense" (default) writes the reference's arrays (utils.py:360-366:
+    tsdf / semantic / instance as [X,Y,Z] volumes, what tools/generate_semantic_instance.py and the evaluation scripts
+    index); "sparse" (opt-in) writes the scene as voxel rows under DISTINCT keys (sparse_coords, sparse_tsdf, sparse_semantic,
+    sparse_instance, dims) — a few MB device -> host instead of three dense volumes, and a dense reader fails loudly on the
+    missing keys instead of misreading 1-D rows.  load_scene_npz reads both."""
 
     def __init__(self, cfg):
         self.cfg = cfg
@@ -159,12 +161,13 @@ class SaveScene:
         save_path = "{}_fusion_eval_{}".format(self.log_dir, epoch)
         os.makedirs(save_path, exist_ok=True)
         sparse = (outputs.get("scene_sparse") or [None] * (batch_idx + 1))[batch_idx]
-        if sparse is not None and str(getattr(self.cfg, "SAVE_SCENE_NPZ", "sparse")) == "sparse":
+        if sparse is not None and str(getattr(self.cfg, "SAVE_SCENE_NPZ", "dense")) == "sparse":
             # the scene as voxel rows: M x (3 + 3) values cross PCIe instead of 3 dense volumes
             np.savez_compressed(os.path.join(save_path, "{}.npz".format(self.scene_name)),
                                 origin=origin.cpu().numpy(), voxel_size=self._voxel_size(), dims=np.array(sparse["dims"]),
-                                coords=sparse["coords"].cpu().numpy(), tsdf=sparse["tsdf"].cpu().numpy(),
-                                semantic=sparse["semantic"].cpu().numpy(), instance=sparse["instance"].cpu().numpy())
+                                sparse_coords=sparse["coords"].cpu().numpy(), sparse_tsdf=sparse["tsdf"].cpu().numpy(),
+                                sparse_semantic=sparse["semantic"].cpu().numpy(),
+                                sparse_instance=sparse["instance"].cpu().numpy())
         else:
             np.savez_compressed(os.path.join(save_path, "{}.npz".format(self.scene_name)),
                                 origin=origin.cpu().numpy(), voxel_size=self._voxel_size(), tsdf=tsdf.cpu().numpy(),

@@ -16,8 +16,7 @@ import os
 
 def _dense3d_level():
     """EPRECON_CONV_DENSE3D: 0 off, 1 the single-column (C_out == 1) kernel only, 2 (default) also the 16-row MFMA tile kernel
-    (C_out <= 32, C_in % 16 == 0), 3 also the 32-row MFMA tile kernel (bit-identical to the gather form, slower on the
-    94k-voxel initialisation set); csrc/sparse_conv.hip, conv3d_kind"""
+    (C_out <= 32, C_in % 16 == 0); csrc/sparse_conv.hip, conv3d_kind"""
     return int(os.environ.get("EPRECON_CONV_DENSE3D", "2"))
 
 
@@ -84,9 +83,7 @@ def unique_coords(coords, quantum=1):
     return uniq[:m], inverse, grid
 
 
-DIRECT = os.environ.get("EPRECON_CONV_DIRECT", "1") != "0"   # (the library reads the same switch per launch)
-DIRECT_MAX_COUT = 64
-SPLITK_BDIRECT = os.environ.get("EPRECON_CONV_SPLITK_BDIRECT", "1") != "0"
+DIRECT_MAX_COUT = 64   # (operand-order packings are always handed over; which kernel runs is the library's choice)
 DENSE_MIN_FILL = 0.4   # a set that fills at least this share of its bounding grid takes the dense-grid convolution
 
 
@@ -111,9 +108,9 @@ class DenseMap:
         """blocking: number of voxels that were not on the grid (0 for a valid set)"""
         return int(self.rank[-1].item())
 
-    def kind(self, x, cin, cout, accumulate=False, ln=False, stats=False, fused=False):
+    def kind(self, x, cin, cout, accumulate=False, ln=False, stats=False):
         """mirror of the library's rule (conv3d_kind, csrc/sparse_conv.hip): 0 none (kernel map), 1 single-column kernel,
-        2 16-row MFMA kernel, 3 32-row MFMA kernel"""
+        2 16-row MFMA kernel"""
         level = _dense3d_level()
         if level <= 0 or cin % 4 or cin > 64 or x.stride(0) % 4 or x.data_ptr() % 16:
             return 0
@@ -121,28 +118,26 @@ class DenseMap:
             return 1
         if level < 2 or accumulate:
             return 0
-        if cout <= 32 and cin % 16 == 0 and not (ln and stats) and not fused \
-                and os.environ.get("EPRECON_CONV_DENSE3D_NO16", "0") != "1":
-            return 2        # (fused: the in-kernel BatchNorm finalize is not part of the 16-row kernel's epilogue)
-        if level < 3 or (ln and (cout > 64 or stats)):
-            return 0
-        return 3
+        if cout <= 32 and cin % 16 == 0 and not (ln and stats):
+            return 2
+        return 0
 
-    def takes(self, x, cin, cout, accumulate=False, ln=False, stats=False, fused=False):
-        return self.kind(x, cin, cout, accumulate, ln, stats, fused) != 0
+    def takes(self, x, cin, cout, accumulate=False, ln=False, stats=False):
+        return self.kind(x, cin, cout, accumulate, ln, stats) != 0
 
 
 def packed_weight(weight):
     """`weight` f32[27, Cin, Cout] in the operand order of the dense-grid kernel, packed once per weight version"""
     hit = getattr(weight, "_d3_pack", None)
-    if hit is None or hit[0] != weight._version or hit[1].device != weight.device:
+    tag = (weight._version, weight.data_ptr())
+    if hit is None or hit[0] != tag or hit[1].device != weight.device:
         lib = _lib.load()
         kvol, cin, cout = weight.shape
         w = weight.detach().contiguous()
         packed = torch.empty(int(lib.eprecon_conv_pack_weight_floats(kvol, cin, cout)), dtype=torch.float32, device=weight.device)
         _lib.check(lib.eprecon_conv_pack_weight_async(_lib.ptr(w), kvol, cin, cout, _lib.ptr(packed), _lib.current_stream()),
                    "eprecon_conv_pack_weight_async")
-        hit = (weight._version, packed)
+        hit = (tag, packed)
         weight._d3_pack = hit
     return hit[1]
 
@@ -151,24 +146,39 @@ def packed_weight16(weight):
     """`weight` f32[27, Cin, Cout <= 64] in the operand order of the 16x16x4 MFMA kernels (16-row tile kernel, direct gather
     kernel), packed once per weight version"""
     hit = getattr(weight, "_d3_pack16", None)
-    if hit is None or hit[0] != weight._version or hit[1].device != weight.device:
+    tag = (weight._version, weight.data_ptr())
+    if hit is None or hit[0] != tag or hit[1].device != weight.device:
         lib = _lib.load()
         kvol, cin, cout = weight.shape
         w = weight.detach().contiguous()
         packed = torch.empty(int(lib.eprecon_conv_pack_weight16_floats(kvol, cin, cout)), dtype=torch.float32, device=weight.device)
         _lib.check(lib.eprecon_conv_pack_weight16_async(_lib.ptr(w), kvol, cin, cout, _lib.ptr(packed), _lib.current_stream()),
                    "eprecon_conv_pack_weight16_async")
-        hit = (weight._version, packed)
+        hit = (tag, packed)
         weight._d3_pack16 = hit
     return hit[1]
 
 
-def _resolve_map(nbr, x, weight, desc, accumulate=False, ln=False, stats=False, fused=False):
+def clear_packed_weights(module):
+    """Drop every operand-order copy cached on the parameters / layers of `module` (packed_weight, packed_weight16,
+    dense2d.packed_weight, modules._linear_wt).  The caches are keyed on (tensor version, data_ptr): writes through `p.data`
+    (dist.broadcast(p.data, ...), EMA swaps, manual loaders) change neither — call this after them."""
+    for p_ in module.parameters():
+        for attr in ("_d3_pack", "_d3_pack16"):
+            if hasattr(p_, attr):
+                delattr(p_, attr)
+    for m in module.modules():
+        for attr in ("_wt_cache", "_eprecon_packed", "_eprecon_merged"):
+            if hasattr(m, attr):
+                delattr(m, attr)
+
+
+def _resolve_map(nbr, x, weight, desc, accumulate=False, ln=False, stats=False):
     """nbr: None (identity), an int32[K, N] kernel map, or a DenseMap -> fills the map fields of `desc`; returns the
     objects that must stay alive until the launch is queued"""
     if isinstance(nbr, DenseMap):
         kvol, cin, cout = weight.shape
-        kind = nbr.kind(x, cin, cout, accumulate, ln, stats, fused) if kvol == 27 else 0
+        kind = nbr.kind(x, cin, cout, accumulate, ln, stats) if kvol == 27 else 0
         if kind:
             desc.vox_rank = nbr.rank.data_ptr()
             desc.grid_x, desc.grid_y, desc.grid_z = nbr.dims
@@ -177,23 +187,19 @@ def _resolve_map(nbr, x, weight, desc, accumulate=False, ln=False, stats=False, 
                 pw = packed_weight16(weight)
                 desc.packed_weight16 = pw.data_ptr()
                 keep.append(pw)
-            elif kind == 3:
-                pw = packed_weight(weight)
-                desc.packed_weight = pw.data_ptr()
-                keep.append(pw)
             desc.nbr = None
             return keep
         nbr = nbr.vset.kernel_map(3)
     desc.nbr = None if nbr is None else nbr.data_ptr()
     keep = [nbr]
     if nbr is not None and weight.shape[0] == 27 and weight.shape[2] <= DIRECT_MAX_COUT \
-            and not accumulate and not fused and x.is_cuda and DIRECT:
+            and not accumulate and x.is_cuda:
         # long lists: the direct gather kernel takes its B operands pre-packed (csrc/sparse_conv.hip, spconv_direct16_kernel);
         # which kernel runs is the library's choice, the packing only makes the direct one possible
         pw = packed_weight16(weight)
         desc.packed_weight16 = pw.data_ptr()
         keep.append(pw)
-    if nbr is not None and weight.shape[0] == 27 and not accumulate and x.is_cuda and SPLITK_BDIRECT:
+    if nbr is not None and weight.shape[0] == 27 and not accumulate and x.is_cuda:
         # short lists: the split-K kernel reads its B operands straight from the 32x32x2 operand-order packing
         pw = packed_weight(weight)
         desc.packed_weight = pw.data_ptr()
@@ -394,27 +400,6 @@ def sparse_conv_ln(x, weight, nbr, bias, ln_weight, ln_bias, ln_eps, out=None, r
     return out
 
 
-# EPRECON_BN_TICKET=1: BatchNorm statistics finished INSIDE the producing convolution (csrc/sparse_conv.hip,
-# bn_finalize_in_kernel) instead of by a separate bn_finalize / bn_finalize_affine launch.  Correct (tests/test_bn_fused_gpu.py)
-# and 74 launches per fragment fewer (1,609 -> 1,536), but not faster: the store drain + atomic round trip at the tail of EVERY
-# workgroup costs what the small launches cost — cfg4 20.7 / 24.8 ms per fragment (thread / no thread) against 21.7 / 24.2 ms,
-# cfg2 +50 us through the one layer that used it (profiles/r03/bn_ticket_ab.txt).  The path is GPU-bound (25.1 ms of kernel
-# time per 24.1 ms fragment), not launch-bound.  Off by default.
-FUSED_FINALIZE = os.environ.get("EPRECON_BN_TICKET", "0") == "1"
-FUSED_FINALIZE_MAX_C = 128
-
-
-def finalize_workspace(owner, rows, cout, device):
-    """The in-kernel finalize's workspace (arrival counters zero between launches + group rows), kept on the layer that
-    owns the BatchNorm: one launch of a layer is in flight at a time, different layers may run on different streams."""
-    need = int(_lib.load().eprecon_conv_bn_finalize_workspace_bytes(int(rows), int(cout)))
-    ws = getattr(owner, "_eprecon_fin_ws", None)
-    if ws is None or ws.numel() < need or ws.device != device:
-        ws = torch.zeros(max(2 * need, 4096), dtype=torch.uint8, device=device)
-        owner._eprecon_fin_ws = ws
-    return ws
-
-
 def affine_rows(x, scale, shift, residual=None, relu=False, out=None):
     """out = [relu]( x * scale + shift [+ residual] ): a BatchNorm whose statistics its producer finished; out may be x"""
     lib = _lib.load()
@@ -428,13 +413,10 @@ def affine_rows(x, scale, shift, residual=None, relu=False, out=None):
     return out
 
 
-def conv_stats(x, weight, nbr=None, in_affine=None, out=None, bias=None, bn=None, owner=None):
+def conv_stats(x, weight, nbr=None, in_affine=None, out=None, bias=None):
     """Convolution whose epilogue also writes the per-workgroup BatchNorm summaries of its output
     (descriptor entry point: any kernel of the family may be chosen).  in_affine = (scale, shift, relu): the
-    producer's pending BatchNorm applied while gathering.  Returns (out, partial).
-    With bn = (gamma, beta, eps) and `owner` (the layer object that keeps the workspace) the BatchNorm is finished
-    inside the launch: returns (out, partial, (scale, shift)) — (scale, shift) is None when the shape is not taken
-    (C_out > 128) or EPRECON_BN_TICKET=0, and the caller finishes from `partial`."""
+    producer's pending BatchNorm applied while gathering.  Returns (out, partial)."""
     lib = _lib.load()
     if weight.dim() == 2:
         weight = weight.unsqueeze(0)
@@ -447,31 +429,19 @@ def conv_stats(x, weight, nbr=None, in_affine=None, out=None, bias=None, bn=None
     d = _lib.ConvDesc()
     d.x, d.n_in, d.ld_x = x.data_ptr(), x.shape[0], _ld(x)
     d.kvol, d.n_out = kvol, n_out
-    fused = bn is not None and owner is not None and FUSED_FINALIZE and cout <= FUSED_FINALIZE_MAX_C and n_out > 0
-    keep = _resolve_map(nbr, x, weight, d, stats=True, fused=fused)  # noqa: F841
+    keep = _resolve_map(nbr, x, weight, d, stats=True)  # noqa: F841
     d.weight, d.cin, d.cout = weight.data_ptr(), cin, cout
     d.bias = None if bias is None else bias.data_ptr()
     d.out, d.ld_out = out.data_ptr(), _ld(out)
     if in_affine is not None:
         d.in_scale, d.in_shift, d.in_relu = in_affine[0].data_ptr(), in_affine[1].data_ptr(), int(in_affine[2])
-    aff = None
-    if fused:   # (set before the rows are asked for: the choice of kernel depends on it)
-        gamma, beta, eps = bn
-        a = torch.empty((2, cout), dtype=torch.float32, device=x.device)
-        aff = (a[0], a[1])
-        d.bn_scale_out, d.bn_shift_out = a[0].data_ptr(), a[1].data_ptr()
-        d.bn_gamma, d.bn_beta, d.bn_eps = _lib.ptr(gamma), _lib.ptr(beta), float(eps)
-        d.bn_ticket = 1   # placeholder: any non-null value while the rows are computed
     keep.append(_attach_workspace(d, x.device))
     rows = max(int(lib.eprecon_conv_desc_partial_rows(ctypes.byref(d))), 1)
     partial = torch.empty((rows, 3, cout), dtype=torch.float32, device=x.device)
     d.bn_partial = partial.data_ptr()
-    if fused:
-        ws = finalize_workspace(owner, rows, cout, x.device)
-        d.bn_ticket = ws.data_ptr()
     if n_out > 0:
         _lib.check(lib.eprecon_conv_desc_async(ctypes.byref(d), _lib.current_stream()), "eprecon_conv_desc_async")
-    return (out, partial) if bn is None else (out, partial, aff)
+    return out, partial
 
 
 def bn_affine(partial, gamma, beta, eps):
@@ -485,8 +455,10 @@ def bn_affine(partial, gamma, beta, eps):
     return aff[0], aff[1]
 
 
-def batchnorm_apply_partials(x, partial, gamma=None, beta=None, eps=1e-5, residual=None, relu=False, out=None):
-    """second half of the train-mode BatchNorm from producer-side summaries (sparse_conv_fused)"""
+def batchnorm_apply_partials(x, partial, gamma=None, beta=None, eps=1e-5, residual=None, relu=False, out=None,
+                             res_affine=None):
+    """second half of the train-mode BatchNorm from producer-side summaries (conv_stats);
+    res_affine = (scale, shift): the residual carries a pending BatchNorm of its own, applied on load"""
     lib = _lib.load()
     n, c = x.shape
     assert partial.shape[1:] == (3, c) and partial.is_contiguous()
@@ -495,6 +467,12 @@ def batchnorm_apply_partials(x, partial, gamma=None, beta=None, eps=1e-5, residu
     # mean / var scratch is a per-call buffer (not the shared grow-only workspace): independent branches
     # of the 2D stack run concurrently on several streams
     ws = torch.empty((lib.eprecon_batchnorm_apply_workspace_bytes(c),), dtype=torch.uint8, device=x.device)
+    if res_affine is not None:
+        _lib.check(lib.eprecon_batchnorm_apply_partials_res_async(
+            _lib.ptr(x), n, c, _ld(x), _lib.ptr(partial), partial.shape[0], _lib.ptr(gamma), _lib.ptr(beta), float(eps),
+            _lib.ptr(residual), _ld(residual), _lib.ptr(res_affine[0]), _lib.ptr(res_affine[1]), int(relu), _lib.ptr(out),
+            _ld(out), _lib.ptr(ws), ws.numel(), _lib.current_stream()), "eprecon_batchnorm_apply_partials_res_async")
+        return out
     _lib.check(lib.eprecon_batchnorm_apply_partials_async(
         _lib.ptr(x), n, c, _ld(x), _lib.ptr(partial), partial.shape[0], _lib.ptr(gamma), _lib.ptr(beta),
         float(eps), _lib.ptr(residual), _ld(residual) if residual is not None else 0, int(relu), _lib.ptr(out),

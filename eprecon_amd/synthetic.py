@@ -256,7 +256,13 @@ def to_device(obj, device):
     if isinstance(obj, np.ndarray):
         return torch.from_numpy(np.ascontiguousarray(obj)).to(device)
     if isinstance(obj, dict):
-        return {k: to_device(v, device) for k, v in obj.items()}
+        out = {k: to_device(v, device) for k, v in obj.items()}
+        # the volume origins also stay on the host, where the data loader built them (datasets/transforms.py:250-260):
+        # GRUFusion reads them there instead of synchronising the device once per fragment
+        for k in ("vol_origin", "vol_origin_partial"):
+            if isinstance(obj.get(k), np.ndarray):
+                out[k + "_host"] = torch.from_numpy(np.ascontiguousarray(obj[k]).astype(np.float32))
+        return out
     if isinstance(obj, (list, tuple)):
         return [to_device(v, device) for v in obj]
     return obj

@@ -107,25 +107,8 @@ int eprecon_back_project(const int32_t *coords, int64_t n, const float *origin, 
  */
 int eprecon_profile_enable(int on);
 float eprecon_profile_gather_ms(void);
-/* family of the gather kernel the recorded pair brackets ("bp_gather_mlp_kernel", "bp_gather_brick_kernel", ...) */
+/* family of the gather kernel the recorded pair brackets ("bp_gather_mlp_kernel" / "bp_gather_kernel") */
 const char *eprecon_profile_gather_kernel(void);
-
-/*
- * The same operator for a DENSE grid: the voxel list is the x-major raster of dims_host[3] voxels per batch
- * element at spacing `interval` (finest-voxel units) — what ops/generate_grids.py:3-10 +
- * models/neucon_network.py:246-251 build and the occupancy initialisation always back-projects.  The coordinates
- * are implicit (out_coords is still written for the valid voxels, raster order), and workgroups own bricks of
- * voxels whose per-view image footprint is staged once in LDS (csrc/back_project_dense.hip).  feats must be
- * channels-last f32[V, B, H, W, C]; modes EPRECON_BP_MEAN and EPRECON_BP_VARIANCE; C in {24, 32, 40, 80};
- * dims multiples of 8.  EPRECON_ERR_UNSUPPORTED otherwise (callers fall back to eprecon_back_project_async).
- * Results are bit-identical to the list entry point.
- */
-size_t eprecon_back_project_dense_workspace_bytes(int64_t n, int batch);
-int eprecon_back_project_dense_async(const int32_t *dims_host, int interval, const float *origin, int batch,
-                                     float voxel_size, const float *feats_nhwc, const float *krcam, int n_views,
-                                     int channels, int height, int width, int min_view, int mode, float *out_feats,
-                                     float *out_mean, int32_t *out_coords, float *count, int32_t *n_valid_dev,
-                                     void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * The same for the gather-GEMM convolution (bench.py's `roofline_conv`): arm a one-shot — the next
@@ -138,6 +121,9 @@ float eprecon_profile_conv_ms(int64_t *rows_out, const char **kernel_out);
 /* live (output row, kernel offset) pairs of the bracketed launch (2 * pairs * cin * cout = its algorithmic flops),
  * counted on the launch stream behind the stop event; blocks; -1 when nothing was recorded */
 int64_t eprecon_profile_conv_pairs(void);
+/* name of the kernel family the most recent convolution launch of this process went to ("spconv_direct16_kernel",
+ * "spconv_splitk_kernel", "spconv_wide_kernel", "conv3d_tile16_kernel", ...): lets callers and tests assert the selection */
+const char *eprecon_profile_last_conv_kernel(void);
 /* stage marker for rocprofv3 kernel traces: an empty launch of (id + 1) workgroups on `stream` (tools/trace_cfg4_layers.py) */
 int eprecon_profile_mark_async(int id, void *stream);
 
@@ -227,16 +213,11 @@ int eprecon_sparse_conv_fused_async(const float *x, int64_t n_in, int ld_x, cons
  *   in_scale / in_shift [cin]   BatchNorm of the producer layer applied while gathering:
  *                               a = [relu]( x * in_scale[c] + in_shift[c] ), zero padding stays 0
  *   res_scale / res_shift [cout] the same for the residual operand
- *   bn_scale_out / bn_shift_out [cout]  the BatchNorm of THIS layer's output in affine form,
- *                               scale = gamma / sqrt(var + eps), shift = beta - mean * scale, finished INSIDE
- *                               the launch: summaries stored write-through, two levels of arrival counters,
- *                               the last arrivers merge in row / group order (deterministic, no fences).
- *                               bn_ticket: workspace of eprecon_conv_bn_finalize_workspace_bytes(rows, cout)
- *                               bytes (rows = eprecon_conv_desc_partial_rows) whose counters — the first
- *                               16,384 bytes, whatever the launch — are zero on entry and are left at zero;
- *                               one workspace per launch in flight.  Needs bn_partial, cout <= 128.
+ *   bn_partial                  per-workgroup (count, mean, M2) summaries of THIS layer's stored output:
+ *                               eprecon_batchnorm_finalize_affine_async turns them into (scale, shift)
  * The stored tensor is the un-normalised conv output; consumers apply (scale, shift) on load, or
- * eprecon_affine_rows_async materialises it.
+ * eprecon_affine_rows_async materialises it.  (Round 3 also finished the statistics INSIDE the launch — write-through
+ * summaries + arrival counters; parity-green and slower than the 7 us finalize launch, removed in round 4: DESIGN.md 7c.)
  */
 typedef struct eprecon_conv_desc {
     const float *x; int64_t n_in; int ld_x;
@@ -249,9 +230,6 @@ typedef struct eprecon_conv_desc {
     const float *in_scale; const float *in_shift; int in_relu;
     const float *res_scale; const float *res_shift; int res_relu;
     float *bn_partial;
-    float *bn_scale_out; float *bn_shift_out;
-    const float *bn_gamma; const float *bn_beta; float bn_eps;
-    unsigned int *bn_ticket;
     /* row-wise LayerNorm over the cout channels after bias / ReLU / residual (the spconv + LayerNorm
      * blocks of models/modules.py:447-452,473-482, models/occupancy_initialization.py:141-169):
      * out = [relu]( LN(v) * ln_gamma + ln_beta ); cout <= 128, excludes bn_partial / accumulate */
@@ -263,12 +241,13 @@ typedef struct eprecon_conv_desc {
     int img_h; int img_w; int img_maps;
     /* dense-grid form of a 3x3x3 stride-1 convolution (kvol == 27) for voxel sets that fill most of their bounding
      * grid (the submanifold stack of models/occupancy_initialization.py:131-174 on the dense 48^3 grid): vox_rank
-     * int32[grid_x*grid_y*grid_z] from eprecon_grid_rank_async maps a grid cell to its voxel's row (-1: none),
-     * packed_weight from eprecon_conv_pack_weight_async holds `weight` in MFMA operand order.  Layers the tile kernel
-     * takes (cin % 4 == 0, cin <= 64; cout == 1 needs no packed weights) run as an implicit GEMM on 4x4x8-cell tiles
-     * with the halo rows staged once in LDS: no kernel map, nbr may be NULL.  Results are bit-identical to the gather
-     * form (cout == 1: same sums in another order).  Other shapes fall back to nbr (EPRECON_ERR_ARG when it is NULL). */
+     * int32[grid_x*grid_y*grid_z] from eprecon_grid_rank_async maps a grid cell to its voxel's row (-1: none).
+     * Layers the tile kernels take (cin % 4 == 0, cin <= 64: cout == 1, or cout <= 32 with cin % 16 == 0 and
+     * packed_weight16) run as an implicit GEMM on cell tiles with the halo rows staged once in LDS: no kernel map, nbr
+     * may be NULL.  Other shapes fall back to nbr (EPRECON_ERR_ARG when it is NULL). */
     const int32_t *vox_rank; int grid_x; int grid_y; int grid_z;
+    /* `weight` in the operand order of v_mfma_f32_32x32x2_f32 (eprecon_conv_pack_weight_async): lets the short-list
+     * (split-K) and cross-workgroup (medium lists, wide channels) kernels read their B operands without LDS staging */
     const float *packed_weight;
     /* the same weights in the operand order of the 16x16x4 MFMA kernels (eprecon_conv_pack_weight16_async, cout <= 64):
      *  - with vox_rank: the 16-row tile kernel, which takes cout <= 32 with cin a multiple of 16 (EPRECON_CONV_DENSE3D >= 2);
@@ -285,11 +264,9 @@ typedef struct eprecon_conv_desc {
 } eprecon_conv_desc;
 int eprecon_conv_desc_async(const eprecon_conv_desc *desc, void *stream);
 size_t eprecon_conv_desc_workspace_bytes(const eprecon_conv_desc *desc);
-size_t eprecon_conv_bn_finalize_workspace_bytes(int64_t partial_rows, int cout);
 /* number of bn_partial rows the launch described by desc writes (nblk of the finalize call) */
 int64_t eprecon_conv_desc_partial_rows(const eprecon_conv_desc *desc);
-/* producer-side summaries partial f32[nblk][3][channels] -> the BatchNorm in affine form (the
- * separate-launch alternative to bn_ticket: no cross-workgroup synchronisation inside the convolution) */
+/* producer-side summaries partial f32[nblk][3][channels] -> the BatchNorm in affine form */
 int eprecon_batchnorm_finalize_affine_async(const float *partial, int64_t nblk, int channels, const float *gamma,
                                             const float *beta, float eps, float *scale_out, float *shift_out,
                                             void *stream);
@@ -349,6 +326,13 @@ int eprecon_batchnorm_apply_partials_async(const float *x, int64_t n, int channe
                                            int ld_res, int relu, float *out, int ld_out, float *mean_out,
                                            float *var_out, void *workspace, size_t workspace_bytes,
                                            void *stream);
+/* the same with a residual operand that carries a pending BatchNorm of its own in affine form (the 1x1 skip convolution +
+ * BatchNorm of a residual block, models/modules.py:57-65,71): residual' = residual * res_scale + res_shift on load */
+int eprecon_batchnorm_apply_partials_res_async(const float *x, int64_t n, int channels, int ld_x, const float *partial,
+                                               int64_t nblk, const float *gamma, const float *beta, float eps,
+                                               const float *residual, int ld_res, const float *res_scale,
+                                               const float *res_shift, int relu, float *out, int ld_out, void *workspace,
+                                               size_t workspace_bytes, void *stream);
 /* per row: t = x; if pre_relu t = relu(t); if residual t += residual; y = LN(t) * gamma + beta;
  * if post_relu y = relu(y).  out may alias x. */
 int eprecon_rowwise_layernorm_async(const float *x, int64_t n, int channels, int ld_x,

@@ -182,44 +182,6 @@ def test_async_queue_matches_blocking_run():
     assert pend_none.result() is None
 
 
-@pytest.mark.parametrize("name,mv", [("cfg2_l0", 0), ("cfg2_l0", 2), ("cfg2_l1", 0), ("cfg2_l1", 2), ("cfg2_l2", 2),
-                                     ("cfg1_l0", 2), ("cfg1b2_l1", 0), ("cfg1b2_l1", 2)])
-def test_dense_brick_kernel_is_bit_identical_to_the_list_kernel(gold, name, mv, monkeypatch):
-    """csrc/back_project_dense.hip (implicit coordinates, LDS image patch per brick and view) against the list kernels
-    on the same dense grids: counts, valid set, output order, coordinates and FEATURES bit for bit"""
-    from eprecon_amd import back_project as BP
-    monkeypatch.setattr(BP, "DENSE_BRICKS", True)     # off by default (slower than the list kernel, DESIGN.md 3a)
-    window, coords, origin, feats, kr = bp_inputs(gold[name + "_meta"])
-    lvl, interval, batch = (int(x) for x in gold[name + "_meta"][:3])
-    dims = [n // interval for n in window["n_vox"]]
-    ref = hip_run(coords, origin, window["voxel_size"], feats, kr, mv)
-    tagged = BP.mark_dense(_dev(coords), dims, interval, batch)
-    assert BP._dense_hint(tagged, 0, feats.shape[2], False) is not None
-    for f in (_dev(feats), _dev(feats).permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)):   # NCHW and NHWC storage
-        got = BP.run(tagged, _dev(origin), window["voxel_size"], f, _dev(kr), mv)
-        assert got["n_valid"] == ref["n_valid"] and got["n_valid_per_batch"] == ref["n_valid_per_batch"]
-        assert torch.equal(got["count"], ref["count"]) and torch.equal(got["coords"], ref["coords"])
-        assert torch.equal(got["feats"], ref["feats"])
-    from eprecon_amd import _lib
-    assert _lib.load().eprecon_profile_gather_kernel() in (b"", b"bp_gather_brick_kernel", b"bp_gather_mlp_kernel", b"bp_gather_kernel")
-
-
-@pytest.mark.parametrize("case", ["cfg1", "cfg2"])
-def test_dense_brick_variance_is_bit_identical(case, monkeypatch):
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
-    import cases
-    from eprecon_amd import back_project as BP
-    window, coords, origin, fused, kr = cases.occ_init_case(case)
-    ref = BP.view_variance(_dev(coords), _dev(origin), 0.04, _dev(fused), _dev(kr), 2)
-    monkeypatch.setattr(BP, "DENSE_BRICKS", True)
-    tagged = BP.mark_dense(_dev(coords), [n // 2 for n in window["n_vox"]], 2, 1)
-    got = BP.view_variance(tagged, _dev(origin), 0.04, _dev(fused), _dev(kr), 2)
-    for k in ("var", "mean", "coords", "count"):
-        assert torch.equal(got[k], ref[k]), k
-    assert got["n_valid"] == ref["n_valid"]
-
-
 def test_more_than_32_views_is_rejected_loudly():
     """the visible-view bitmask is 32 bits wide: 33 views must raise, not wrap"""
     from eprecon_amd import _lib

@@ -120,8 +120,8 @@ def test_load_scene_npz_rebuilds_the_reference_dense_arrays(tmp_path):
     tsdf = rng.uniform(-1, 1, 200).astype(np.float32)
     sem, ins = rng.integers(0, 21, 200).astype(np.int32), rng.integers(0, 50, 200).astype(np.int32)
     p = tmp_path / "s.npz"
-    np.savez_compressed(p, origin=np.zeros(3, np.float32), voxel_size=0.04, dims=np.array(dims), coords=c, tsdf=tsdf,
-                        semantic=sem, instance=ins)
+    np.savez_compressed(p, origin=np.zeros(3, np.float32), voxel_size=0.04, dims=np.array(dims), sparse_coords=c,
+                        sparse_tsdf=tsdf, sparse_semantic=sem, sparse_instance=ins)
     z = load_scene_npz(str(p))
     ref = np.ones(dims, np.float32)
     ref[c[:, 0], c[:, 1], c[:, 2]] = tsdf
@@ -159,7 +159,7 @@ def test_scene_fusion_sparse_export_and_incremental_saving(tmp_path, monkeypatch
     sp = outputs["scene_sparse"][0]
     assert sp["dims"] == tuple(outputs["scene_tsdf"][0].shape) and sp["coords"].shape == (m, 3)
     cfg = SimpleNamespace(LOGDIR="logs/run", DATASET="scannet", SAVE_SCENE_MESH=True, SAVE_INCREMENTAL=True,
-                          MODEL=SimpleNamespace(VOXEL_SIZE=0.04))
+                          SAVE_SCENE_NPZ="sparse", MODEL=SimpleNamespace(VOXEL_SIZE=0.04))
     saver = SS.SaveScene(cfg)
     saver.keyframe_id = 3                                                      # main.py:388
     imgs = torch.from_numpy(rng.integers(0, 255, (1, 9, 3, 24, 32)).astype(np.float32)).cuda()
@@ -169,7 +169,8 @@ def test_scene_fusion_sparse_export_and_incremental_saving(tmp_path, monkeypatch
     assert np.array_equal(z["semantic"], outputs["scene_semantic"][0].cpu().numpy())
     assert np.array_equal(z["instance"], outputs["scene_instance"][0].cpu().numpy())
     raw = np.load(os.path.join("results", "scene_scannet_run_fusion_eval_2", "scene0007-01.npz"))
-    assert "coords" in raw.files and raw["tsdf"].shape == (m,)                 # rows, not volumes, were written
+    # rows, not volumes, were written — under keys a dense reader (tools/generate_semantic_instance.py) fails loudly on
+    assert "sparse_coords" in raw.files and raw["sparse_tsdf"].shape == (m,) and "tsdf" not in raw.files
     inc = os.path.join("incremental_results", "scene_scannet_run_2", "scene0007-01")
     inc = "incremental_" + os.path.join("results", "scene_scannet_run") + "_2" + os.sep + "scene0007-01"
     assert sorted(os.listdir(inc)) == ["mesh", "mesh_image", "mesh_instance", "mesh_semantic"]
@@ -178,8 +179,9 @@ def test_scene_fusion_sparse_export_and_incremental_saving(tmp_path, monkeypatch
     from PIL import Image
     px = np.asarray(Image.open(os.path.join(inc, "mesh_image", "image_3_0.png")))
     assert np.array_equal(px, imgs[0, 0].permute(1, 2, 0).cpu().numpy().astype(np.uint8))
-    # dense form on request
-    cfg.SAVE_SCENE_NPZ, cfg.SAVE_INCREMENTAL = "dense", False
+    # the DEFAULT is the reference's dense format (utils.py:360-366): [X,Y,Z] volumes under tsdf / semantic / instance
+    del cfg.SAVE_SCENE_NPZ
+    cfg.SAVE_INCREMENTAL = False
     SS.SaveScene(cfg)(outputs, {}, 5)
     raw = np.load(os.path.join("results", "scene_scannet_run_fusion_eval_5", "scene0007-01.npz"))
-    assert "coords" not in raw.files and raw["tsdf"].shape == tuple(sp["dims"])
+    assert "sparse_coords" not in raw.files and raw["tsdf"].shape == tuple(sp["dims"]) == raw["semantic"].shape

@@ -106,7 +106,7 @@ def test_map_union_is_the_raster_ordered_set_union(seed, n_cur, n_map, dim):
 
 
 def test_documented_limits_return_error_codes():
-    """batch > 14 in a hash key, n_views > 32, unsupported dense-grid shapes: status codes, never silent truncation"""
+    """batch > 14 in a hash key, n_views > 32: status codes, never silent truncation"""
     from eprecon_amd import _lib
     from eprecon_amd import back_project as BP
     from eprecon_amd.sparse import HashGrid
@@ -120,7 +120,3 @@ def test_documented_limits_return_error_codes():
     kr = torch.zeros((33, 1, 4, 4), device="cuda")
     with pytest.raises(_lib.EpreconError):
         BP.run(coords, dev(window["vol_origin_partial"][None]), 0.04, feats, kr, 0)
-    dims = (ctypes.c_int32 * 3)(9, 8, 8)                                        # 9 is not a multiple of the brick
-    rc = lib.eprecon_back_project_dense_async(ctypes.cast(dims, ctypes.c_void_p), 1, 1, 1, 0.04, 1, 1, 9, 24, 60, 80, 0, 0,
-                                              1, None, 1, 1, 1, 1, 0, None)
-    assert rc in (-1, -3)
