@@ -177,6 +177,19 @@ def calibrate_occupancy_heads(net, features, features_occ_pano=None, inputs=None
     reset afterwards."""
     frags = features if features_occ_pano is None else [(features, features_occ_pano, inputs)]
     old_trace = net.trace
+    # the forwards below run with uncalibrated heads and trip the reference's guards by design ("no valid points", "exceed
+    # too many points"): their warnings are tagged so that a log line from a TIMED forward is attributable
+    from . import neucon_network as _NN
+    old_tag, _NN.WARN_TAG = _NN.WARN_TAG, "[calibration] "
+    try:
+        _calibrate(net, frags, keep_fraction)
+    finally:
+        _NN.WARN_TAG = old_tag
+        net.gru_fusion.scene_name = [None, None, None]
+        net.trace = old_trace
+
+
+def _calibrate(net, frags, keep_fraction):
     for i in range(net.cfg.N_LAYER):
         net.gru_fusion.scene_name = [None, None, None]
         occs = []
@@ -197,8 +210,6 @@ def calibrate_occupancy_heads(net, features, features_occ_pano=None, inputs=None
         lin = net.occ_preds[i].linear3
         lin.bias.sub_(q).div_(sigma)
         lin.weight.div_(sigma)
-    net.gru_fusion.scene_name = [None, None, None]
-    net.trace = old_trace
 
 
 class Cfg4Step:
@@ -244,21 +255,31 @@ class Cfg4Step:
             calibrate_occupancy_heads(self.net, self.frags)
         # EPRECON_FORCE_EXCHANGE=1: run the boundary all-gather even at world size 1 (exercises the RCCL path on one GPU)
         self.net.distributed_exchange = world > 1 or os.environ.get("EPRECON_FORCE_EXCHANGE", "0") == "1" or force_exchange
-        # pipeline: the panoptic branch of fragment k runs on its own stream and overlaps the front of fragment k + 1; its
-        # host-side post-processing is finished one step later (NeuConNet.panoptic_stream)
-        self.pipeline = pipeline
-        if pipeline:
-            self.net.panoptic_stream = torch.cuda.Stream(device=self.device)
-            if pipeline != "inline":     # ("inline": the branch's launches are issued by the main thread on the side stream)
-                from concurrent.futures import ThreadPoolExecutor
-                self.net.panoptic_worker = ThreadPoolExecutor(max_workers=1, thread_name_prefix="eprecon-panoptic")
         self._pending = None
+        self.pipeline = False
+        self.set_pipeline(pipeline)
         self.k = 0
         self.last = None
         self.voxels = []  # finest-level voxel count of every fragment run so far
         self.early_returns = 0
         # multi-GPU: a rank that raised would leave the others waiting in the next collective; count instead
         self.raise_on_early_return = world == 1
+
+    def set_pipeline(self, pipeline):
+        """False: every fragment is complete when run() returns (the reference's contract).  True: the panoptic branch of
+        fragment k is issued by a worker thread on its own stream and overlaps the front of fragment k + 1, its host-side
+        post-processing is finished one step later (NeuConNet.panoptic_stream / panoptic_worker: a THROUGHPUT mode that
+        changes the outputs contract — `panoptic_finish`).  "inline": the side stream without the worker thread."""
+        self.flush()
+        if self.net.panoptic_worker is not None:
+            self.net.panoptic_worker.shutdown(wait=True)
+        self.net.panoptic_stream = self.net.panoptic_worker = None
+        self.pipeline = pipeline
+        if pipeline:
+            self.net.panoptic_stream = torch.cuda.Stream(device=self.device)
+            if pipeline != "inline":
+                from concurrent.futures import ThreadPoolExecutor
+                self.net.panoptic_worker = ThreadPoolExecutor(max_workers=1, thread_name_prefix="eprecon-panoptic")
 
     @torch.no_grad()
     def run(self):

@@ -139,10 +139,46 @@ class MLP(nn.Module):
         return x
 
 
-def nearest_fine_index(coarse_xyz, fine_xyz, quantum):
+def decoder_level_inputs(coords_xyz, feats_rows, level_embed, gauss_b, spitial_shape):
+    """(src, keys) of one level as voxel rows f32[N, C]: src = feats + level_embed, keys = src + Fourier position encoding
+    (models/mask3dformer.py:346-357, models/voxel_position_encoding.py:123-152) in ONE launch (csrc/decoder.hip).
+    coords_xyz int32[N,3] (any row pitch), feats_rows f32[N, C] (row-major, any pitch)"""
+    import ctypes
+    lib = _lib.load()
+    n, c = feats_rows.shape
+    assert coords_xyz.dtype == torch.int32 and coords_xyz.stride(1) == 1 and feats_rows.stride(1) == 1
+    src = torch.empty((n, c), dtype=torch.float32, device=feats_rows.device)
+    keys = torch.empty_like(src)
+    ext = (ctypes.c_float * 3)(*[float(v) for v in spitial_shape])
+    _lib.check(lib.eprecon_decoder_keys_async(_lib.ptr(coords_xyz), coords_xyz.stride(0), _lib.ptr(feats_rows), feats_rows.stride(0),
+                                              _lib.ptr(level_embed), _lib.ptr(gauss_b), ctypes.cast(ext, ctypes.c_void_p), n, c,
+                                              _lib.ptr(src), _lib.ptr(keys), _lib.current_stream()), "eprecon_decoder_keys_async")
+    return src, keys
+
+
+def masked_attention(q, k, v, mask_logits_t, mask_rows, out, scale):
+    """out[1, H, Q, D] = the scaled-dot-product attention of nn.MultiheadAttention over the voxel rows k / v f32[N, H * D]
+    with the attention mask `sigmoid(mask_logits_t[mask_rows[n], i]) < 0.5 -> key n blocked for query i` (a query with every
+    key blocked attends to all; models/mask3dformer.py:383-397,441-443) — without the [Q, N] mask, the [H, Q, N] scores or
+    the index_select of the mask logits (csrc/decoder.hip: split-K flash attention, deterministic).
+    q f32[1, H, Q, D] contiguous; mask_logits_t f32[N_fine, Q]; mask_rows int32[N] or None (identity)."""
+    lib = _lib.load()
+    _, h, nq, d = q.shape
+    n = k.shape[0]
+    assert q.is_contiguous() and out.is_contiguous() and out.shape == q.shape and k.stride(1) == 1 and v.stride(1) == 1
+    ws = _lib.workspace(lib.eprecon_masked_attention_workspace_bytes(n, nq, h, d), q.device)
+    _lib.check(lib.eprecon_masked_attention_async(
+        _lib.ptr(q), _lib.ptr(k), k.stride(0), _lib.ptr(v), v.stride(0), n, _lib.ptr(mask_logits_t),
+        mask_logits_t.stride(0) if mask_logits_t is not None else 0, _lib.ptr(mask_rows),
+        mask_logits_t.shape[0] if mask_logits_t is not None else 0, nq, h, d, float(scale), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+        _lib.current_stream()), "eprecon_masked_attention_async")
+    return out
+
+
+def nearest_fine_index(coarse_xyz, fine_xyz, quantum, as_int32=False):
     """for every coarse voxel (multiple of `quantum`) the row of the nearest fine voxel (Euclidean on
     integer coordinates, smallest row on ties) — what argmin(cdist(fine, coarse), dim=0) returns when
-    distances are exact.  coarse int[M,3], fine int[N,3] -> int64[M]"""
+    distances are exact.  coarse int[M,3], fine int[N,3] -> int64[M] (int32 on request)"""
     lib = _lib.load()
     dev = fine_xyz.device
 
@@ -155,7 +191,7 @@ def nearest_fine_index(coarse_xyz, fine_xyz, quantum):
     _lib.check(lib.eprecon_nearest_voxel_async(_lib.ptr(grid.mem), grid.capacity, _lib.ptr(fine), fine.shape[0],
                                                _lib.ptr(coarse), coarse.shape[0], int(quantum), _lib.ptr(out),
                                                _lib.current_stream()), "eprecon_nearest_voxel_async")
-    return out.long()
+    return out if as_int32 else out.long()
 
 
 class MultiScaleMaskedTransformerDecoder(nn.Module):
@@ -180,6 +216,9 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         self.mask_embed = MLP(hidden_dim, hidden_dim * 4, mask_dim, 3)
         # the static-shape query side of every layer replayed from HIP graphs on the GPU inference path
         self.use_hip_graph = __import__("os").environ.get("EPRECON_NO_GRAPH", "0") != "1"
+        # EPRECON_DECODER_FUSED=0: the voxel side of every layer as PyTorch ops (key / value projections, SDPA over a dense
+        # [Q, N] mask) instead of the HIP kernels of csrc/decoder.hip
+        self.use_fused_voxel_side = __import__("os").environ.get("EPRECON_DECODER_FUSED", "1") == "1"
         self._plan = None
         self._plan_params = None
 
@@ -273,8 +312,54 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         attn = outputs_mask[0] if mask_indices is None else outputs_mask[0].index_select(1, mask_indices)
         return outputs_mask, (attn.sigmoid() < 0.5).detach()
 
+    def _forward_fused(self, plan, panoptic_features, panoptic_coords, mask_features, spitial_shape):
+        """GPU inference: per layer one GEMM for the mask logits (voxel-major: [N_2, Q]), the key / value projections, and the
+        masked attention as ONE split-K flash-attention pass over the level's voxels (csrc/decoder.hip) writing straight
+        into the captured query side's input; the query side is a graph replay.  pred_masks are [1, Q, N_2] VIEWS of the
+        voxel-major logit matrices (same values and shape as the reference's, other strides)."""
+        c = self.query_feat.weight.shape[1]
+        heads = self.num_heads
+        scale = 1.0 / math.sqrt(c // heads)
+        rows = lambda t: t[0].t()                                        # [1, C, N] view of voxel rows -> the rows [N, C]
+        src, keys = [], []
+        for i in range(self.num_feature_levels):
+            xyz = panoptic_coords[i][0]
+            xyz = xyz if xyz.dtype == torch.int32 else xyz.to(torch.int32)
+            f = rows(panoptic_features[i])
+            f = f if f.stride(1) == 1 else f.contiguous()
+            s_i, k_i = decoder_level_inputs(xyz, f, self.level_embed.weight[i], self.pos_enc.gauss_B, spitial_shape)
+            src.append(s_i)
+            keys.append(k_i)
+        fine = panoptic_coords[2].squeeze(0)
+        mask_rows = [nearest_fine_index(panoptic_coords[0].squeeze(0), fine, 4, as_int32=True),
+                     nearest_fine_index(panoptic_coords[1].squeeze(0), fine, 2, as_int32=True), None]
+        mf = rows(mask_features)
+        mf = mf if mf.is_contiguous() else mf.contiguous()
+        classes, masks = [plan["cls0"].clone()], []
+        me, q = plan["me0"], plan["q0"]
+        for j in range(self.num_layers):
+            lvl = j % self.num_feature_levels
+            logits_t = torch.mm(mf, me[0].t())                           # [N_2, Q]: this head's mask logits, voxel-major
+            masks.append(logits_t.t().unsqueeze(0))
+            attn = self.transformer_cross_attention_layers[j].multihead_attn
+            w, b = attn.in_proj_weight, attn.in_proj_bias
+            k = F.linear(keys[lvl], w[c:2 * c], b[c:2 * c])
+            v = F.linear(src[lvl], w[2 * c:], b[2 * c:])
+            step = plan["layers"][j]
+            masked_attention(q, k, v, logits_t, mask_rows[lvl], step["o_in"], scale)
+            step["graph"].replay()
+            classes.append(step["cls"].clone())
+            me, q = step["me"], step["q_next"]
+        masks.append(torch.mm(mf, me[0].t()).t().unsqueeze(0))
+        return {"pred_logits": classes[-1], "pred_masks": masks[-1],
+                "aux_outputs": [{"pred_logits": a, "pred_masks": b} for a, b in zip(classes[:-1], masks[:-1])]}
+
     def forward(self, panoptic_features, panoptic_coords, mask_features, spitial_shape):
         """panoptic_features 3 x [1, C, N_l]; panoptic_coords 3 x [1, N_l, 3]; mask_features [1, C, N_2]"""
+        if self.use_fused_voxel_side and mask_features.is_cuda and not torch.is_grad_enabled() and mask_features.shape[0] == 1:
+            plan = self._static_plan(mask_features.device)
+            if plan is not None and (self.query_feat.weight.shape[1] // self.num_heads) == 6 and self.num_heads % 2 == 0:
+                return self._forward_fused(plan, panoptic_features, panoptic_coords, mask_features, spitial_shape)
         pos = self.get_pos_encs(panoptic_coords, spitial_shape)
         src, sizes = [], []
         for i in range(self.num_feature_levels):

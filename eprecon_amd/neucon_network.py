@@ -41,8 +41,11 @@ from .torchsparse_utils import aligned_camera_coords
 _FUSED_SPARSIFY = True
 
 
+WARN_TAG = ""    # prefix of the guard warnings below; fragment_step.calibrate_occupancy_heads sets "[calibration] " around its forwards
+
+
 def _warn(msg):
-    print(f"[eprecon_amd] warning: {msg}", file=sys.stderr)
+    print(f"[eprecon_amd] {WARN_TAG}warning: {msg}", file=sys.stderr)
 
 
 class NeuConNet(nn.Module):

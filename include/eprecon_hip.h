@@ -585,6 +585,35 @@ int eprecon_nearest_voxel_async(const void *table, uint32_t capacity, const int3
                                 int64_t m, const int32_t *query_coords, int64_t n, int quantum,
                                 int32_t *out_index, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Voxel side of the mask-transformer decoder  (K19)
+ *
+ * Replaces  the per-level inputs of MultiScaleMaskedTransformerDecoder.forward      models/mask3dformer.py:346-357
+ *           (PositionEmbeddingCoordsSine "fourier", normalize=True                   models/voxel_position_encoding.py:123-152)
+ *           the masked cross-attention of a decoder layer                            models/mask3dformer.py:383-397
+ *           with the attention mask of forward_prediction_heads                      models/mask3dformer.py:429-445
+ *
+ * eprecon_decoder_keys_async: coords int32 rows (x, y, z) with row pitch ld_coords ints, feats f32[n, ld_feats]:
+ *   src[i, c] = feats[i, c] + level_embed[c];  keys[i, c] = src[i, c] + pos[i, c],
+ *   pos = [sin(P), cos(P)], P = (2 pi * coords / extent) @ gauss_b   (gauss_b f32[3, channels / 2], extent_host f32[3] HOST)
+ *
+ * eprecon_masked_attention_async: out f32[H, Q, D] = softmax_over_allowed_keys(scale * q k^T) v per head, q f32[H, Q, D],
+ *   k / v f32[n_keys, ld] rows whose H * D channels are the heads side by side (what nn.MultiheadAttention's in-projection
+ *   produces).  Key n is BLOCKED for query i when sigmoid(mask_logits_t[row(n), i]) < 0.5 with row(n) = mask_rows[n]
+ *   (NULL: n); mask_logits_t f32[n_mask_rows, ld_mask] is the TRANSPOSED mask-logit matrix (voxel-major).  A query whose
+ *   mask blocks every key attends to all keys (models/mask3dformer.py:388).  mask_logits_t NULL: no mask.
+ *   Shapes taken: D = 6, H even, Q * H / 2 <= 512, Q <= 255, k / v 16-byte aligned with ld % 4 == 0;
+ *   EPRECON_ERR_UNSUPPORTED otherwise (callers keep the dense PyTorch path).  Deterministic (fixed merge order).
+ * ------------------------------------------------------------------------------------------ */
+int eprecon_decoder_keys_async(const int32_t *coords, int ld_coords, const float *feats, int ld_feats, const float *level_embed,
+                               const float *gauss_b, const float *extent_host, int64_t n, int channels, float *src_out,
+                               float *keys_out, void *stream);
+size_t eprecon_masked_attention_workspace_bytes(int64_t n_keys, int n_queries, int n_heads, int head_dim);
+int eprecon_masked_attention_async(const float *q, const float *k, int ld_k, const float *v, int ld_v, int64_t n_keys,
+                                   const float *mask_logits_t, int ld_mask, const int32_t *mask_rows, int64_t n_mask_rows,
+                                   int n_queries, int n_heads, int head_dim, float scale, float *out, void *workspace,
+                                   size_t workspace_bytes, void *stream);
+
 /* x2 bilinear upsampling of channels-last maps, in f32[n,h,w,c] -> out f32[n,2h,2w,c], c % 4 == 0
  * (F.interpolate(scale_factor=2, mode="bilinear") in feat_fusion_pre,
  * models/occupancy_initialization.py:46) */

@@ -14,10 +14,20 @@ stages = json.load(open(os.path.join(src, "stages.json")))
 trace = list(csv.DictReader(open(glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True)[0])))
 trace.sort(key=lambda r: int(r["Start_Timestamp"]))
 log = [l.split() for l in open(os.path.join(src, "conv.log"))]
+# one log line per convolution CALL; the cross-workgroup split-K kernel is two launches (spconv_wide_kernel + its
+# spconv_wide_reduce_kernel): the reduce launch is folded into the call's time, not counted as a call of its own
 is_conv = lambda n: re.search(r"spconv_|conv3d_tile|conv2d_tile", n) is not None
-convs = [r for r in trace if is_conv(r["Kernel_Name"])]
-if "Dispatch_Id" in trace[0]:      # host launch order (the log's order) even when streams overlap
-    convs.sort(key=lambda r: int(r["Dispatch_Id"]))
+is_tail = lambda n: "spconv_wide_reduce_kernel" in n
+order = sorted(trace, key=lambda r: int(r["Dispatch_Id"])) if "Dispatch_Id" in trace[0] else trace   # host launch order = the log's
+convs = []
+for r in order:
+    if not is_conv(r["Kernel_Name"]):
+        continue
+    if is_tail(r["Kernel_Name"]):
+        assert convs and "spconv_wide_kernel" in convs[-1]["Kernel_Name"], "a reduce launch without its split-K launch"
+        convs[-1]["tail_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        continue
+    convs.append(r)
 assert len(convs) == len(log), (len(convs), len(log))
 for r, l in zip(convs, log):
     r["layer"] = l
@@ -69,5 +79,6 @@ for r in trace[a + 1:b]:
         l = r["layer"]
         n, K, ci, co = map(int, l[:4])
         gf = 2.0 * n * K * ci * co / 1e9
-        print(f"{(stack[-1] if stack else '-'):16s} {n:7d} {K:2d} {ci:4d} {co:4d}  {l[4]:30s} {' '.join(l[5:]):22s} {dur(r):7.1f} us  "
-              f"({gf / dur(r) * 1e3:5.1f} TF dense-equivalent)")
+        us = dur(r) + r.get("tail_ns", 0) / 1e3
+        print(f"{(stack[-1] if stack else '-'):16s} {n:7d} {K:2d} {ci:4d} {co:4d}  {l[4]:30s} {' '.join(l[5:]):22s} {us:7.1f} us  "
+              f"({gf / us * 1e3:5.1f} TF dense-equivalent)")
