@@ -251,7 +251,7 @@ class TrainBatchNorm1d(nn.BatchNorm1d):
         """second half of the BatchNorm from the producing convolution's summaries"""
         return SP.batchnorm_apply_partials(x, partial, self.weight, self.bias, self.eps, residual, relu, out)
 
-    def affine(self, partial):
+    def pending_affine(self, partial):
         """the BatchNorm in affine form (scale, shift) from the producer's summaries: consumers apply it on load"""
         return SP.bn_affine(partial, self.weight, self.bias, self.eps)
 
@@ -600,7 +600,7 @@ class ResidualBlock(nn.Module):
             return self.net[4].run(y, residual=skip, relu=True)
         # conv1's BatchNorm + ReLU stays pending and is applied by conv2 while it gathers
         y, p1 = self.net[0].run_stats(feats, nbr)
-        scale, shift = self.net[1].affine(p1)
+        scale, shift = self.net[1].pending_affine(p1)
         y2, p2 = self.net[3].run_stats(y, nbr, in_affine=(scale, shift, True))
         if len(self.downsample) == 0:
             return self.net[4].run_partials(y2, p2, residual=feats, relu=True, out=out if out is not None else y2)
@@ -608,7 +608,7 @@ class ResidualBlock(nn.Module):
         skip, ps = self.downsample[0].run_stats(feats, None)
         return SP.batchnorm_apply_partials(y2, p2, self.net[4].weight, self.net[4].bias, self.net[4].eps, residual=skip,
                                            relu=True, out=out if out is not None else y2,
-                                           res_affine=self.downsample[1].affine(ps))
+                                           res_affine=self.downsample[1].pending_affine(ps))
 
 
 class _PointMLP(nn.Sequential):
