@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void decoder_keys_kernel(const int32_t *coords
 }
 
 struct AttParams {
-    const float *q;         // [H][Q][D]
+    const float *q;         // element (h, i, d) at q[h * q_sh + i * q_sq + d]
+    int q_sh, q_sq;
     const float *k, *v;     // [N][ld]
     int ld_k, ld_v;
     const float *logits_t;  // [N_fine][ld_l] or nullptr (no mask)
@@ -86,8 +87,8 @@ __global__ __launch_bounds__(512) void masked_attention_partial_kernel(AttParams
     float qa[D], qb[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        qa[d] = p.q[((size_t)(2 * hp) * p.Q + qi) * D + d] * p.scale;
-        qb[d] = p.q[((size_t)(2 * hp + 1) * p.Q + qi) * D + d] * p.scale;
+        qa[d] = p.q[(size_t)(2 * hp) * p.q_sh + (size_t)qi * p.q_sq + d] * p.scale;
+        qb[d] = p.q[(size_t)(2 * hp + 1) * p.q_sh + (size_t)qi * p.q_sq + d] * p.scale;
     }
     // running states: [variant 0 = allowed keys, 1 = all keys][head a / b]
     float m[2][2], l[2][2], o[2][2][D];
@@ -290,12 +291,14 @@ size_t eprecon_masked_attention_workspace_bytes(int64_t n_keys, int n_queries, i
            align_up((size_t)G * n_queries * sizeof(int32_t), 256);
 }
 
-int eprecon_masked_attention_async(const float *q, const float *k, int ld_k, const float *v, int ld_v, int64_t n_keys,
+int eprecon_masked_attention_async(const float *q, int q_stride_head, int q_stride_query, const float *k, int ld_k, const float *v, int ld_v, int64_t n_keys,
                                    const float *mask_logits_t, int ld_mask, const int32_t *mask_rows, int64_t n_mask_rows,
                                    int n_queries, int n_heads, int head_dim, float scale, float *out, void *workspace,
                                    size_t workspace_bytes, void *stream)
 {
-    if (!q || !k || !v || !out || n_keys <= 0 || n_keys > 0x7fffffff || n_mask_rows < 0 || n_mask_rows > 0x7fffffff) return EPRECON_ERR_ARG;
+    if (!q || !k || !v || !out || n_keys <= 0 || n_keys > 0x7fffffff || n_mask_rows < 0 || n_mask_rows > 0x7fffffff ||
+        q_stride_head <= 0 || q_stride_query <= 0)
+        return EPRECON_ERR_ARG;
     if (!att_shape_ok(n_queries, n_heads, head_dim)) return EPRECON_ERR_UNSUPPORTED;
     const int C = n_heads * head_dim;
     if (ld_k < C || ld_v < C || ld_k % 4 || ld_v % 4 || (reinterpret_cast<uintptr_t>(k) & 15) || (reinterpret_cast<uintptr_t>(v) & 15))
@@ -304,7 +307,7 @@ int eprecon_masked_attention_async(const float *q, const float *k, int ld_k, con
     if (!workspace || workspace_bytes < eprecon_masked_attention_workspace_bytes(n_keys, n_queries, n_heads, head_dim))
         return EPRECON_ERR_WORKSPACE;
     AttParams p;
-    p.q = q; p.k = k; p.v = v; p.ld_k = ld_k; p.ld_v = ld_v;
+    p.q = q; p.q_sh = q_stride_head; p.q_sq = q_stride_query; p.k = k; p.v = v; p.ld_k = ld_k; p.ld_v = ld_v;
     p.logits_t = mask_logits_t; p.ld_l = ld_mask; p.rows = mask_rows; p.n_fine = (int)n_mask_rows;
     p.N = (int)n_keys; p.Q = n_queries; p.H = n_heads; p.scale = scale;
     const int G = att_groups(n_keys, &p.keys_per_wg);

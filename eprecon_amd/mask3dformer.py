@@ -161,14 +161,15 @@ def masked_attention(q, k, v, mask_logits_t, mask_rows, out, scale):
     with the attention mask `sigmoid(mask_logits_t[mask_rows[n], i]) < 0.5 -> key n blocked for query i` (a query with every
     key blocked attends to all; models/mask3dformer.py:383-397,441-443) — without the [Q, N] mask, the [H, Q, N] scores or
     the index_select of the mask logits (csrc/decoder.hip: split-K flash attention, deterministic).
-    q f32[1, H, Q, D] contiguous; mask_logits_t f32[N_fine, Q]; mask_rows int32[N] or None (identity)."""
+    q f32[1, H, Q, D] (any head / query strides: the head-split view of the in-projection is taken as is);
+    mask_logits_t f32[N_fine, Q]; mask_rows int32[N] or None (identity)."""
     lib = _lib.load()
     _, h, nq, d = q.shape
     n = k.shape[0]
-    assert q.is_contiguous() and out.is_contiguous() and out.shape == q.shape and k.stride(1) == 1 and v.stride(1) == 1
+    assert q.stride(3) == 1 and out.is_contiguous() and out.shape == q.shape and k.stride(1) == 1 and v.stride(1) == 1
     ws = _lib.workspace(lib.eprecon_masked_attention_workspace_bytes(n, nq, h, d), q.device)
     _lib.check(lib.eprecon_masked_attention_async(
-        _lib.ptr(q), _lib.ptr(k), k.stride(0), _lib.ptr(v), v.stride(0), n, _lib.ptr(mask_logits_t),
+        _lib.ptr(q), q.stride(1), q.stride(2), _lib.ptr(k), k.stride(0), _lib.ptr(v), v.stride(0), n, _lib.ptr(mask_logits_t),
         mask_logits_t.stride(0) if mask_logits_t is not None else 0, _lib.ptr(mask_rows),
         mask_logits_t.shape[0] if mask_logits_t is not None else 0, nq, h, d, float(scale), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
         _lib.current_stream()), "eprecon_masked_attention_async")

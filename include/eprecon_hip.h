@@ -597,7 +597,8 @@ int eprecon_nearest_voxel_async(const void *table, uint32_t capacity, const int3
  *   src[i, c] = feats[i, c] + level_embed[c];  keys[i, c] = src[i, c] + pos[i, c],
  *   pos = [sin(P), cos(P)], P = (2 pi * coords / extent) @ gauss_b   (gauss_b f32[3, channels / 2], extent_host f32[3] HOST)
  *
- * eprecon_masked_attention_async: out f32[H, Q, D] = softmax_over_allowed_keys(scale * q k^T) v per head, q f32[H, Q, D],
+ * eprecon_masked_attention_async: out f32[H, Q, D] = softmax_over_allowed_keys(scale * q k^T) v per head; q element
+ *   (h, i, d) at q[h * q_stride_head + i * q_stride_query + d] (the head-split VIEW of a [Q, H * D] in-projection is taken as is),
  *   k / v f32[n_keys, ld] rows whose H * D channels are the heads side by side (what nn.MultiheadAttention's in-projection
  *   produces).  Key n is BLOCKED for query i when sigmoid(mask_logits_t[row(n), i]) < 0.5 with row(n) = mask_rows[n]
  *   (NULL: n); mask_logits_t f32[n_mask_rows, ld_mask] is the TRANSPOSED mask-logit matrix (voxel-major).  A query whose
@@ -609,7 +610,7 @@ int eprecon_decoder_keys_async(const int32_t *coords, int ld_coords, const float
                                const float *gauss_b, const float *extent_host, int64_t n, int channels, float *src_out,
                                float *keys_out, void *stream);
 size_t eprecon_masked_attention_workspace_bytes(int64_t n_keys, int n_queries, int n_heads, int head_dim);
-int eprecon_masked_attention_async(const float *q, const float *k, int ld_k, const float *v, int ld_v, int64_t n_keys,
+int eprecon_masked_attention_async(const float *q, int q_stride_head, int q_stride_query, const float *k, int ld_k, const float *v, int ld_v, int64_t n_keys,
                                    const float *mask_logits_t, int ld_mask, const int32_t *mask_rows, int64_t n_mask_rows,
                                    int n_queries, int n_heads, int head_dim, float scale, float *out, void *workspace,
                                    size_t workspace_bytes, void *stream);

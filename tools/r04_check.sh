@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${1:-r04_a}
 mkdir -p $O
 cd $R
-python -m pytest tests -m gpu -q -x --timeout 600 ${PYTEST_ARGS} > $O/pytest.log 2>&1
+python -m pytest tests -m gpu -q --maxfail 12 --timeout 600 ${PYTEST_ARGS} > $O/pytest.log 2>&1
 tail -5 $O/pytest.log
 timeout 600 python tools/profile_cfg4_stages.py 3 > $O/cfg4_stage_times.txt 2>&1
 tail -25 $O/cfg4_stage_times.txt
