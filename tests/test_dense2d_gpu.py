@@ -146,7 +146,6 @@ def test_direct_gather_kernel_chain_on_the_pixel_map(monkeypatch, cin, cmid, cou
     from eprecon_amd import dense2d as D2
     from eprecon_amd.modules import Conv2d_Block, Conv2d_Residual_Block
     from test_sparse_gpu import _last_conv_kernel
-    monkeypatch.setattr(D2, "DIRECT_2D", True)
     monkeypatch.setattr(D2, "DIRECT_2D_MIN_ROWS", 1000)
     torch.manual_seed(cin * 100 + cout + 7)
     dev = _dev()
