@@ -17,7 +17,8 @@
 // heads 2 hp and 2 hp + 1 of query q, twice — over the allowed keys and over all keys (the fallback of an all-blocked query,
 // chosen in the reduce kernel by the exact count of allowed keys).  K / V tiles of 64 keys are staged in LDS and read as
 // broadcasts; scores are rescaled once per 8 keys.  Partial states are merged in workgroup order: deterministic.
-// HBM-bound by the contract (8 C bytes per key), exp-rate-bound in practice (2 v_exp_f32 per key, head and query).
+// HBM-bound by the contract (8 C bytes per key), VALU-bound in practice (~45 fp32 operations + 2 v_exp_f32 per key, head and
+// query).  The softmax weights use v_exp_f32 (__expf, relative error ~1e-6); the mask decision uses torch.sigmoid's expression.
 #include <math.h>
 
 #include "common.hpp"
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(512) void masked_attention_partial_kernel(AttParams
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const float m_new = fmaxf(m[var][h], mx[var][h]);
-                    const float r = expf(m[var][h] - m_new);     // (both kNegBig: exp(0) = 1 on an all-zero state)
+                    const float r = __expf(m[var][h] - m_new);   // (both kNegBig: exp(0) = 1 on an all-zero state)
                     l[var][h] *= r;
 #pragma unroll
                     for (int d = 0; d < D; ++d) o[var][h][d] *= r;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(512) void masked_attention_partial_kernel(AttParams
                     const float4 x = vr[f];
                     vv[4 * f] = x.x; vv[4 * f + 1] = x.y; vv[4 * f + 2] = x.z; vv[4 * f + 3] = x.w;
                 }
-                const float pa = expf(sa[j] - m[1][0]), pb = expf(sb[j] - m[1][1]);
+                const float pa = __expf(sa[j] - m[1][0]), pb = __expf(sb[j] - m[1][1]);
                 l[1][0] += pa; l[1][1] += pb;
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(512) void masked_attention_partial_kernel(AttParams
                     o[1][1][d] = fmaf(pb, vv[D + d], o[1][1][d]);
                 }
                 if ((alwmask >> j) & 1u) {
-                    const float ma = expf(sa[j] - m[0][0]), mb = expf(sb[j] - m[0][1]);
+                    const float ma = __expf(sa[j] - m[0][0]), mb = __expf(sb[j] - m[0][1]);
                     l[0][0] += ma; l[0][1] += mb;
 #pragma unroll
                     for (int d = 0; d < D; ++d) {
@@ -213,38 +214,57 @@ __global__ __launch_bounds__(512) void masked_attention_partial_kernel(AttParams
     if (hp == 0) p.allowed[(size_t)blockIdx.x * p.Q + qi] = n_allowed;
 }
 
-// one thread per (head, query): the workgroups' partial states merged in workgroup order; a query without an allowed key
-// takes the all-keys state (models/mask3dformer.py:388).  out[h][q][d]: what scaled_dot_product_attention returns per head.
+// one wave per (head, query): lane j merges the partial states of workgroups j, j + 64, ... in order, the 64 lane states
+// are merged by a fixed xor-butterfly (deterministic); a query without an allowed key takes the all-keys state
+// (models/mask3dformer.py:388).  out[h][q][d]: what scaled_dot_product_attention returns per head.
 template <int D>
-__global__ __launch_bounds__(256) void masked_attention_reduce_kernel(const float *partial, const int32_t *allowed, int G, int Q,
-                                                                      int H, int use_mask, float *out)
+__global__ __launch_bounds__(64) void masked_attention_reduce_kernel(const float *partial, const int32_t *allowed, int G, int Q,
+                                                                     int H, int use_mask, float *out)
 {
     constexpr int W = D + 2;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= H * Q) return;
+    const int e = blockIdx.x, lane = threadIdx.x;
     const int h = e / Q, q = e - h * Q;
     int var = 1;
     if (use_mask) {
-        int64_t cnt = 0;
-        for (int g = 0; g < G; ++g) cnt += allowed[(size_t)g * Q + q];
+        int cnt = 0;
+        for (int g = lane; g < G; g += 64) cnt += allowed[(size_t)g * Q + q] > 0 ? 1 : 0;
+#pragma unroll
+        for (int msk = 32; msk > 0; msk >>= 1) cnt += __shfl_xor(cnt, msk);
         var = cnt > 0 ? 0 : 1;
     }
-    float M = kNegBig;
-    for (int g = 0; g < G; ++g) M = fmaxf(M, partial[((((size_t)g * 2 + var) * H + h) * Q + q) * W]);
-    float L = 0.0f, O[D];
+    float M = kNegBig, L = 0.0f, O[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) O[d] = 0.0f;
-    for (int g = 0; g < G; ++g) {
-        const float *src = partial + ((((size_t)g * 2 + var) * H + h) * Q + q) * W;
-        if (src[1] == 0.0f) continue;            // an empty partial state (its max is the sentinel)
-        const float r = expf(src[0] - M);
-        L = fmaf(src[1], r, L);
-#pragma unroll
-        for (int d = 0; d < D; ++d) O[d] = fmaf(src[2 + d], r, O[d]);
+    for (int g = lane; g < G; g += 64) {
+        const float4 *src = reinterpret_cast<const float4 *>(partial + ((((size_t)g * 2 + var) * H + h) * Q + q) * W);
+        const float4 s0 = src[0], s1 = src[1];            // (m, l, o0, o1), (o2, o3, o4, o5)
+        if (s0.y == 0.0f) continue;                       // an empty partial state (its max is the sentinel)
+        const float m_new = fmaxf(M, s0.x);
+        const float ra = __expf(M - m_new), rb = __expf(s0.x - m_new);
+        L = L * ra + s0.y * rb;
+        O[0] = O[0] * ra + s0.z * rb; O[1] = O[1] * ra + s0.w * rb;
+        O[2] = O[2] * ra + s1.x * rb; O[3] = O[3] * ra + s1.y * rb;
+        O[4] = O[4] * ra + s1.z * rb; O[5] = O[5] * ra + s1.w * rb;
+        M = m_new;
     }
-    const float inv = L > 0.0f ? 1.0f / L : 0.0f;
 #pragma unroll
-    for (int d = 0; d < D; ++d) out[((size_t)h * Q + q) * D + d] = O[d] * inv;
+    for (int msk = 32; msk > 0; msk >>= 1) {
+        const float oM = __shfl_xor(M, msk), oL = __shfl_xor(L, msk);
+        float oO[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) oO[d] = __shfl_xor(O[d], msk);
+        const float m_new = fmaxf(M, oM);
+        const float ra = __expf(M - m_new), rb = __expf(oM - m_new);
+        L = L * ra + oL * rb;
+#pragma unroll
+        for (int d = 0; d < D; ++d) O[d] = O[d] * ra + oO[d] * rb;
+        M = m_new;
+    }
+    if (lane == 0) {
+        const float inv = L > 0.0f ? 1.0f / L : 0.0f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) out[((size_t)h * Q + q) * D + d] = O[d] * inv;
+    }
 }
 
 int att_groups(int64_t n_keys, int *keys_per_wg)
@@ -319,7 +339,7 @@ int eprecon_masked_attention_async(const float *q, int q_stride_head, int q_stri
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL((masked_attention_partial_kernel<6>), dim3((unsigned)G), dim3((unsigned)threads), lds, st, p);
     EP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((masked_attention_reduce_kernel<6>), dim3((unsigned)ceil_div(n_heads * n_queries, 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL((masked_attention_reduce_kernel<6>), dim3((unsigned)(n_heads * n_queries)), dim3(64), 0, st,
                        (const float *)p.partial, (const int32_t *)p.allowed, G, n_queries, n_heads, mask_logits_t ? 1 : 0, out);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
