@@ -210,7 +210,12 @@ def extra_workloads(device, lib, steps3=12, steps4=16, warm4=4):
         step.voxels.clear()
         # step.run raises if a fragment returns before the finest level.  The drop-in figure: every fragment complete
         # (panoptic_info included) when NeuConNet.forward returns, nothing carried across fragments.
+        from eprecon_amd import _lib as L
+        reads0 = L.HOST_READS
         out["cfg4_unpipelined_ms_per_fragment"] = _timed(step.run, steps4, sync)
+        # device -> host reads the host thread blocks on, counted at their call sites (eprecon_amd._lib.count_host_read):
+        # element counts the next launches are sized by, the reference's guards, the panoptic post-processing
+        out["blocking_reads_per_fragment"] = (L.HOST_READS - reads0) / steps4
         out["cfg4_ms_per_fragment"] = out["cfg4_unpipelined_ms_per_fragment"]
         out["cfg4_fragments_per_sec"] = 1e3 / out["cfg4_ms_per_fragment"]
         out["cfg4_finest_voxels_min_max"] = [min(step.voxels), max(step.voxels)]

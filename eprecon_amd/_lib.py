@@ -33,6 +33,12 @@ SIGNATURES = {
     "eprecon_hash_status": (_i, [_vp, _vp]),
     "eprecon_unique_workspace_bytes": (_sz, [_i64]),
     "eprecon_unique_coords_async": (_i, [_vp, _i64, _i, _vp, _c.c_uint32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "eprecon_unique_coords_dn_async": (_i, [_vp, _i64, _vp, _i, _vp, _c.c_uint32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "eprecon_point_quantize_dn_async": (_i, [_vp, _i64, _vp, _f, _vp, _vp, _vp]),
+    "eprecon_gru_stage_capacity": (_i64, [_vp, _i64, _i]),
+    "eprecon_gru_stage_workspace_bytes": (_sz, [_i64]),
+    "eprecon_gru_stage_begin_async": (_i, [_vp, _vp]),
+    "eprecon_gru_stage_commit_async": (_i, [_vp, _vp, _vp, _vp]),
     "eprecon_kernel_map_async": (_i, [_vp, _c.c_uint32, _vp, _i64, _i, _i, _vp, _vp]),
     "eprecon_transpose_map_async": (_i, [_vp, _i64, _vp, _i, _vp, _vp]),
     "eprecon_sparse_conv_async": (_i, [_vp, _i64, _i, _vp, _i, _i64, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
@@ -203,6 +209,28 @@ class ConvDesc(ctypes.Structure):
                 ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t)]
 
 
+class GruStageDesc(ctypes.Structure):
+    """include/eprecon_hip.h: eprecon_gru_stage_desc"""
+    _fields_ = [("map", ctypes.c_void_p), ("target_map", ctypes.c_void_p),
+                ("cur_coords", ctypes.c_void_p), ("cur_feat", ctypes.c_void_p), ("n_cur", ctypes.c_int64), ("ld_cur", ctypes.c_int),
+                ("dim", ctypes.c_int), ("interval", ctypes.c_int), ("activity_mode", ctypes.c_int),
+                ("rel", ctypes.c_int32 * 3),
+                ("tsdf_gt", ctypes.c_void_p), ("occ_gt", ctypes.c_void_p),
+                ("origin", ctypes.c_void_p), ("w2ac", ctypes.c_void_p),
+                ("voxel_size", ctypes.c_float), ("resolution", ctypes.c_float),
+                ("ch_voxel", ctypes.c_int), ("batch_index", ctypes.c_int),
+                ("capacity", ctypes.c_int64),
+                ("updated", ctypes.c_void_p), ("out_coords", ctypes.c_void_p), ("r_coords", ctypes.c_void_p),
+                ("hx_voxel", ctypes.c_void_p), ("hx_image", ctypes.c_void_p), ("tsdf_target", ctypes.c_void_p),
+                ("scaled1", ctypes.c_void_p), ("vox1", ctypes.c_void_p), ("inverse1", ctypes.c_void_p), ("uniq1", ctypes.c_void_p),
+                ("table1", ctypes.c_void_p),
+                ("scaled2", ctypes.c_void_p), ("vox2", ctypes.c_void_p), ("inverse2", ctypes.c_void_p), ("uniq2", ctypes.c_void_p),
+                ("table2", ctypes.c_void_p),
+                ("table_capacity", ctypes.c_uint32),
+                ("counts", ctypes.c_void_p),
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t)]
+
+
 _WORKSPACES = {}
 
 
@@ -215,6 +243,14 @@ def workspace(nbytes, device):
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
         _WORKSPACES[key] = buf
     return buf
+
+
+HOST_READS = 0    # blocking device -> host reads issued by the package since import (bench.py: blocking_reads_per_fragment)
+
+
+def count_host_read(n=1):
+    global HOST_READS
+    HOST_READS += n
 
 
 def last_conv_kernel():

@@ -49,6 +49,7 @@ class PendingBackProject:
         self._want_grid, self._want_mean = want_grid, want_mean
 
     def result(self):
+        _lib.count_host_read()
         self._event.synchronize()
         counts = self._pinned.tolist()
         if any(x < self._min_valid for x in counts[1:]):
@@ -134,6 +135,7 @@ def run(coords, origin, voxel_size, feats, krcam, min_view, mode=MODE_MEAN, min_
     ws_bytes = lib.eprecon_back_project_workspace_bytes(n, b, v, c, h, w, layout)
     ws = _lib.workspace(ws_bytes, dev)
 
+    _lib.count_host_read()
     rc = lib.eprecon_back_project(
         _lib.ptr(coords_i), n, _lib.ptr(origin_f), b, float(voxel_size), _lib.ptr(feats_c), layout,
         _lib.ptr(krcam_f), v, c, h, w, int(min_view), mode, int(min_valid_per_batch),

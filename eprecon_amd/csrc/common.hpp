@@ -62,6 +62,9 @@ __device__ __forceinline__ int block_exclusive_rank(bool pred, int *wave_counts,
 // device-wide exclusive scan of int32 (kernel_map.hip); scratch holds ceil(n / 2048) int32
 int exclusive_scan_i32(const int32_t *in, int n, int32_t *out, int32_t *scratch, int32_t *total_dev,
                        hipStream_t st);
+// the same with the live length on the device: min(n, *n_dev) (n_dev may be nullptr); launches are sized by n
+int exclusive_scan_i32_dn(const int32_t *in, int n, const int32_t *n_dev, int32_t *out, int32_t *scratch, int32_t *total_dev,
+                          hipStream_t st);
 
 // the gather-kernel timing hook of eprecon_profile_enable (back_project.hip), for the other gather variants
 int profile_bracket_begin(hipStream_t st);

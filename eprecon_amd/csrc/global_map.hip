@@ -33,7 +33,8 @@ struct EpMap {
     // dense FBV workspace: idx_cur, idx_glob, flag, rank (int32 [cells] each) + vol (f32 [cells])
     char *dense = nullptr;
     size_t dense_bytes = 0;
-    int64_t kept = -1;  // rows outside the FBV of the last crop (-1: no crop pending)
+    int64_t kept = -1;  // rows outside the FBV of the last crop (-1: no crop pending, -2: pending, count still on the device)
+    int pending_dim = 0;  // grid size of the pending ground-truth crop (eprecon_gru_stage_begin_async -> _commit_async)
     int rel[3] = {0, 0, 0};
     // multi-GPU boundary exchange: per row, which fragment produced its features and whether THIS rank
     // fused it: 0 unknown, +(fragment + 1) fused here, -(fragment + 1) received from another rank
@@ -397,6 +398,55 @@ __global__ void target_append_kernel(const float *vol, const int32_t *flag, cons
     s_out[o] = 0;  // the ground-truth twin takes no part in the boundary exchange: origin unknown, never a stale stamp
 }
 
+// ---- GRU-fusion stage with device-side counts (eprecon_gru_stage_begin_async) ----
+// [h | x] buffers of the two ConvGRUs of a scale in one pass: h = the map's row, x = the fragment's row (zeros where absent),
+// channels [0, chv) to the voxel cell, [chv, C) to the image cell.  The union size lives on the device.
+__global__ __launch_bounds__(256) void stage_gather_kernel(const float *map_feat, const float *cur_feat, int ld_cur,
+                                                           const int32_t *src_glob, const int32_t *src_cur, int n_cap,
+                                                           const int32_t *n_dev, int C, int chv, float *hx_v, float *hx_i)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int n = min(n_cap, *n_dev);
+    if (e >= (int64_t)n * C) return;
+    const int i = (int)(e / C), c = (int)(e - (int64_t)i * C);
+    const int jg = src_glob[i], jc = src_cur[i];
+    const float h = jg >= 0 ? map_feat[(size_t)jg * C + c] : 0.0f;
+    const float x = jc >= 0 ? cur_feat[(size_t)jc * ld_cur + c] : 0.0f;
+    const int chi = C - chv;
+    if (c < chv) {
+        hx_v[(size_t)i * 2 * chv + c] = h;
+        hx_v[(size_t)i * 2 * chv + chv + c] = x;
+    } else {
+        hx_i[(size_t)i * 2 * chi + (c - chv)] = h;
+        hx_i[(size_t)i * 2 * chi + chi + (c - chv)] = x;
+    }
+}
+// union cells -> voxel coordinates of the fragment (batch, cell * interval) and their aligned-camera coordinates
+// (models/gru_fusion.py:332-337; the arithmetic of aligned_coords_kernel, csrc/voxelize.hip: separate multiply / add, then the
+// k-ordered fma chain of the [N,4] x [4,3] product); the batch column of the points is 0 like the reference's
+__global__ void stage_points_kernel(const int32_t *updated, int n_cap, const int32_t *n_dev, int interval, int batch_index,
+                                    const float *origin, float vs, const float *w2ac, int4 *out_coords, float4 *r_coords)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= min(n_cap, *n_dev)) return;
+    const int cx = updated[3 * i] * interval, cy = updated[3 * i + 1] * interval, cz = updated[3 * i + 2] * interval;
+    out_coords[i] = make_int4(batch_index, cx, cy, cz);
+    const float X = __fadd_rn(__fmul_rn((float)cx, vs), origin[0]);
+    const float Y = __fadd_rn(__fmul_rn((float)cy, vs), origin[1]);
+    const float Z = __fadd_rn(__fmul_rn((float)cz, vs), origin[2]);
+    float r[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        r[j] = __fmaf_rn(1.0f, w2ac[4 * j + 3], __fmaf_rn(Z, w2ac[4 * j + 2], __fmaf_rn(Y, w2ac[4 * j + 1], __fmul_rn(X, w2ac[4 * j]))));
+    r_coords[i] = make_float4(r[0], r[1], r[2], 0.0f);
+}
+__global__ void target_lookup_dn_kernel(const float *vol, const int32_t *updated, int n_cap, const int32_t *n_dev, int D, float *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= min(n_cap, *n_dev)) return;
+    out[i] = vol[(updated[3 * i] * D + updated[3 * i + 1]) * D + updated[3 * i + 2]];
+}
+
 inline EpMap *as_map(void *h) { return reinterpret_cast<EpMap *>(h); }
 
 }  // namespace
@@ -664,7 +714,7 @@ int eprecon_map_update_async(void *handle, const int32_t *updated, int64_t n, co
 {
     EpMap *m = as_map(handle);
     if (!m || n < 0 || (n > 0 && (!updated || !values || ld_values < m->channels))) return EPRECON_ERR_ARG;
-    if (m->kept < 0) return EPRECON_ERR_ARG;  // no crop_union since the last update / import
+    if (m->kept < 0) return EPRECON_ERR_ARG;  // no crop since the last update / import, or its count was not committed yet
     hipStream_t st = (hipStream_t)stream;
     const int64_t new_size = m->kept + n;
     if (new_size > m->cap) {
@@ -751,6 +801,182 @@ int eprecon_map_target_fuse(void *handle, const float *tsdf_gt, const uint8_t *o
     m->cur = dst;
     m->size = kept + n_new;
     m->kept = -1;
+    return EPRECON_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * One GRU-fusion level with device-side counts (include/eprecon_hip.h: eprecon_gru_stage_desc)
+ * ------------------------------------------------------------------------------------------------------------------ */
+int64_t eprecon_gru_stage_capacity(const void *map, int64_t n_cur, int dim)
+{
+    const EpMap *m = reinterpret_cast<const EpMap *>(map);
+    if (!m || n_cur < 0 || dim <= 0) return -1;
+    const int64_t cells = (int64_t)dim * dim * dim;
+    const int64_t cap = n_cur + m->size < cells ? n_cur + m->size : cells;
+    return cap > 0 ? cap : 1;
+}
+
+size_t eprecon_gru_stage_workspace_bytes(int64_t capacity)
+{
+    const int64_t cap = capacity > 0 ? capacity : 1;
+    return 2 * align_up((size_t)cap * sizeof(int32_t), 256) + eprecon_unique_workspace_bytes(cap);
+}
+
+int eprecon_gru_stage_begin_async(const eprecon_gru_stage_desc *d, void *stream)
+{
+    if (!d || !d->map || d->n_cur < 0 || d->dim <= 0 || d->dim > 512 || d->interval <= 0 || d->capacity <= 0 || !d->updated ||
+        !d->out_coords || !d->r_coords || !d->hx_voxel || !d->hx_image || !d->counts || !d->origin || !d->w2ac || !d->workspace ||
+        !(d->resolution > 0.0f) || !d->scaled1 || !d->vox1 || !d->inverse1 || !d->uniq1 || !d->table1 || !d->scaled2 || !d->vox2 ||
+        !d->inverse2 || !d->uniq2 || !d->table2)
+        return EPRECON_ERR_ARG;
+    EpMap *m = as_map(d->map);
+    EpMap *tm = as_map(d->target_map);
+    const int C = m->channels;
+    if (d->ch_voxel <= 0 || d->ch_voxel >= C || (d->n_cur > 0 && (!d->cur_coords || !d->cur_feat || d->ld_cur < C))) return EPRECON_ERR_ARG;
+    if (d->capacity < eprecon_gru_stage_capacity(d->map, d->n_cur, d->dim)) return EPRECON_ERR_ARG;
+    if (d->workspace_bytes < eprecon_gru_stage_workspace_bytes(d->capacity)) return EPRECON_ERR_WORKSPACE;
+    if (tm && (tm->channels != 1 || !d->tsdf_gt || !d->occ_gt || !d->tsdf_target)) return EPRECON_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int dim = d->dim, cells = dim * dim * dim;
+    const int cap = (int)d->capacity;
+    int rc = ensure_dense(m, dim);
+    if (rc == EPRECON_OK) rc = ensure_flags(m, m->size, cells);
+    if (rc != EPRECON_OK) return rc;
+    char *ws = reinterpret_cast<char *>(d->workspace);
+    const size_t iseg = align_up((size_t)cap * sizeof(int32_t), 256);
+    int32_t *src_cur = reinterpret_cast<int32_t *>(ws);
+    int32_t *src_glob = reinterpret_cast<int32_t *>(ws + iseg);
+    void *uws = ws + 2 * iseg;
+    const size_t uws_bytes = d->workspace_bytes - 2 * iseg;
+    int32_t *cnt = d->counts;
+    EP_HIP_CHECK(hipMemsetAsync(cnt, 0, 8 * sizeof(int32_t), st));
+
+    // --- crop + union (the kernels of eprecon_map_crop_union, without its host read) ---
+    const size_t seg = align_up((size_t)cells * 4, 256);
+    CropParams p;
+    p.cur_coords = d->cur_coords; p.cur_feat = d->cur_feat; p.n_cur = (int)d->n_cur; p.ld_cur = d->ld_cur;
+    p.glob_coords = m->coords[m->cur]; p.glob_feat = m->feats[m->cur]; p.n_glob = (int)m->size;
+    p.C = C; p.D = dim; p.interval = d->interval; p.mode = d->activity_mode;
+    for (int a = 0; a < 3; ++a) p.rel[a] = m->rel[a] = d->rel[a];
+    p.idx_cur = reinterpret_cast<int32_t *>(m->dense);
+    p.idx_glob = reinterpret_cast<int32_t *>(m->dense + seg);
+    p.flag = reinterpret_cast<int32_t *>(m->dense + 2 * seg);
+    int32_t *rank = reinterpret_cast<int32_t *>(m->dense + 3 * seg);
+    p.keep = m->keep;
+    EP_HIP_CHECK(hipMemsetAsync(p.idx_cur, 0xFF, 2 * seg, st));
+    EP_HIP_CHECK(hipMemsetAsync(p.flag, 0, seg, st));
+    const int64_t rows = d->n_cur + m->size;
+    if (rows > 0) {
+        hipLaunchKernelGGL(map_crop_scatter_kernel, dim3((unsigned)ceil_div(rows, 32)), dim3(256), 0, st, p);
+        EP_LAUNCH_CHECK();
+    }
+    rc = ep::exclusive_scan_i32(p.flag, cells, rank, m->scan_scratch, cnt + 0, st);
+    if (rc != EPRECON_OK) return rc;
+    rc = ep::exclusive_scan_i32(m->keep, (int)m->size, m->keep_rank, m->scan_scratch + m->scratch_cap / 2, cnt + 1, st);
+    if (rc != EPRECON_OK) return rc;
+    hipLaunchKernelGGL(map_emit_kernel, dim3((unsigned)ceil_div(cells, 256)), dim3(256), 0, st, (const int32_t *)p.flag,
+                       (const int32_t *)rank, (const int32_t *)p.idx_cur, (const int32_t *)p.idx_glob, dim, d->updated, src_cur, src_glob);
+    EP_LAUNCH_CHECK();
+    m->kept = -2;   // a crop is pending; eprecon_gru_stage_commit supplies the count the host read
+    const int32_t *n_u = cnt + 0;
+
+    // --- [h | x] rows of the two cells ---
+    hipLaunchKernelGGL(stage_gather_kernel, dim3((unsigned)ceil_div((int64_t)cap * C, 256)), dim3(256), 0, st,
+                       (const float *)m->feats[m->cur], d->cur_feat, d->ld_cur, (const int32_t *)src_glob, (const int32_t *)src_cur, cap,
+                       n_u, C, d->ch_voxel, d->hx_voxel, d->hx_image);
+    EP_LAUNCH_CHECK();
+
+    // --- ground-truth twin: dense volume <- map rows inside the FBV <- the fragment's ground truth; targets at the union ---
+    if (tm) {
+        rc = ensure_dense(tm, dim);
+        if (rc == EPRECON_OK) rc = ensure_flags(tm, tm->size, cells);
+        if (rc != EPRECON_OK) return rc;
+        int32_t *tflag = reinterpret_cast<int32_t *>(tm->dense + 2 * seg);
+        int32_t *trank = reinterpret_cast<int32_t *>(tm->dense + 3 * seg);
+        float *vol = reinterpret_cast<float *>(tm->dense + 4 * seg);
+        for (int a = 0; a < 3; ++a) tm->rel[a] = d->rel[a];
+        const dim3 blk(256), gcells((unsigned)ceil_div(cells, 256));
+        hipLaunchKernelGGL(fill_f32_kernel, gcells, blk, 0, st, vol, cells, 1.0f);
+        EP_LAUNCH_CHECK();
+        if (tm->size > 0) {
+            hipLaunchKernelGGL(target_scatter_kernel, dim3((unsigned)ceil_div(tm->size, 256)), blk, 0, st,
+                               (const int32_t *)tm->coords[tm->cur], (const float *)tm->feats[tm->cur], (int)tm->size, dim, d->rel[0],
+                               d->rel[1], d->rel[2], vol, tm->keep);
+            EP_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(target_merge_kernel, gcells, blk, 0, st, d->tsdf_gt, d->occ_gt, cells, vol, tflag);
+        EP_LAUNCH_CHECK();
+        hipLaunchKernelGGL(target_lookup_dn_kernel, dim3((unsigned)ceil_div(cap, 256)), blk, 0, st, (const float *)vol,
+                           (const int32_t *)d->updated, cap, n_u, dim, d->tsdf_target);
+        EP_LAUNCH_CHECK();
+        rc = ep::exclusive_scan_i32(tflag, cells, trank, tm->scan_scratch, cnt + 4, st);
+        if (rc != EPRECON_OK) return rc;
+        rc = ep::exclusive_scan_i32(tm->keep, (int)tm->size, tm->keep_rank, tm->scan_scratch + tm->scratch_cap / 2, cnt + 5, st);
+        if (rc != EPRECON_OK) return rc;
+        tm->kept = -2;
+        tm->pending_dim = dim;
+    }
+
+    // --- the fragment's points and the two voxelisations the six SConv3d of the scale share ---
+    hipLaunchKernelGGL(stage_points_kernel, dim3((unsigned)ceil_div(cap, 256)), dim3(256), 0, st, (const int32_t *)d->updated, cap, n_u,
+                       d->interval, d->batch_index, d->origin, d->voxel_size, d->w2ac, reinterpret_cast<int4 *>(d->out_coords),
+                       reinterpret_cast<float4 *>(d->r_coords));
+    EP_LAUNCH_CHECK();
+    rc = eprecon_point_quantize_dn_async(d->r_coords, cap, n_u, d->resolution, d->scaled1, d->vox1, stream);
+    if (rc != EPRECON_OK) return rc;
+    rc = eprecon_unique_coords_dn_async(d->vox1, cap, n_u, 1, d->table1, d->table_capacity, d->inverse1, d->uniq1, cnt + 2, uws,
+                                        uws_bytes, stream);
+    if (rc != EPRECON_OK) return rc;
+    rc = eprecon_point_quantize_dn_async(d->scaled1, cap, n_u, d->resolution, d->scaled2, d->vox2, stream);
+    if (rc != EPRECON_OK) return rc;
+    rc = eprecon_unique_coords_dn_async(d->vox2, cap, n_u, 1, d->table2, d->table_capacity, d->inverse2, d->uniq2, cnt + 3, uws,
+                                        uws_bytes, stream);
+    if (rc != EPRECON_OK) return rc;
+    // the status words of the two tables next to the counts: one host read for everything
+    EP_HIP_CHECK(hipMemcpyAsync(cnt + 6, d->table1, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    EP_HIP_CHECK(hipMemcpyAsync(cnt + 7, d->table2, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    return EPRECON_OK;
+}
+
+int eprecon_gru_stage_commit_async(void *map, void *target_map, const int32_t *counts_host, void *stream)
+{
+    EpMap *m = as_map(map);
+    EpMap *tm = as_map(target_map);
+    if (!m || !counts_host || m->kept != -2) return EPRECON_ERR_ARG;
+    if (counts_host[1] < 0 || counts_host[1] > m->size) return EPRECON_ERR_ARG;
+    m->kept = counts_host[1];
+    if (!tm) return EPRECON_OK;
+    if (tm->kept != -2) return EPRECON_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n_new = counts_host[4], kept = tm->size > 0 ? counts_host[5] : 0;
+    // (the dims of the pending crop are those of the dense workspace the begin call filled)
+    if (n_new < 0 || kept < 0 || kept > tm->size) return EPRECON_ERR_ARG;
+    if (kept + n_new > tm->cap) {
+        EP_HIP_CHECK(hipStreamSynchronize(st));
+        int rc = ensure_rows(tm, kept + n_new);
+        if (rc != EPRECON_OK) return rc;
+    }
+    const int dim = tm->pending_dim, cells = dim * dim * dim;
+    const size_t seg = align_up((size_t)cells * 4, 256);
+    int32_t *tflag = reinterpret_cast<int32_t *>(tm->dense + 2 * seg);
+    int32_t *trank = reinterpret_cast<int32_t *>(tm->dense + 3 * seg);
+    float *vol = reinterpret_cast<float *>(tm->dense + 4 * seg);
+    const dim3 blk(256), gcells((unsigned)ceil_div(cells, 256));
+    const int src = tm->cur, dst = 1 - tm->cur;
+    if (tm->size > 0) {
+        hipLaunchKernelGGL(map_compact_kernel, dim3((unsigned)ceil_div(tm->size * 4, 256)), blk, 0, st,
+                           (const int32_t *)tm->keep, (const int32_t *)tm->keep_rank, (int)tm->size,
+                           (const int32_t *)tm->coords[src], (const float *)tm->feats[src], (const int32_t *)tm->stamps[src], 1,
+                           tm->coords[dst], tm->feats[dst], tm->stamps[dst]);
+        EP_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(target_append_kernel, gcells, blk, 0, st, (const float *)vol, (const int32_t *)tflag,
+                       (const int32_t *)trank, dim, tm->rel[0], tm->rel[1], tm->rel[2], kept, tm->coords[dst], tm->feats[dst],
+                       tm->stamps[dst]);
+    EP_LAUNCH_CHECK();
+    tm->cur = dst;
+    tm->size = kept + n_new;
+    tm->kept = -1;
     return EPRECON_OK;
 }
 

@@ -24,9 +24,11 @@ constexpr int kScanBlock = 256;
 constexpr int kScanItems = 8;                       // per thread
 constexpr int kScanTile = kScanBlock * kScanItems;  // 2048 per block
 
-__global__ __launch_bounds__(kScanBlock) void scan_tile_sums(const int32_t *in, int n, int32_t *sums)
+// (n_dev, optional: the live length is min(n, *n_dev) — the launch is sized by the capacity n, the count lives on the device)
+__global__ __launch_bounds__(kScanBlock) void scan_tile_sums(const int32_t *in, int n, int32_t *sums, const int32_t *n_dev)
 {
     __shared__ int sWave[kScanBlock / kWave];
+    if (n_dev) n = min(n, *n_dev);
     const int base = blockIdx.x * kScanTile;
     int s = 0;
     for (int k = 0; k < kScanItems; ++k) {
@@ -76,9 +78,10 @@ __global__ __launch_bounds__(1024) void scan_sums_inplace(int32_t *sums, int nbl
 
 // out[i] = exclusive prefix of in[0..i); each block rescans its 2048-element tile in LDS
 __global__ __launch_bounds__(kScanBlock) void scan_apply(const int32_t *in, int n, const int32_t *sums,
-                                                         int32_t *out)
+                                                         int32_t *out, const int32_t *n_dev)
 {
     __shared__ int sWave[kScanBlock / kWave];
+    if (n_dev) n = min(n, *n_dev);
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
     const int base = blockIdx.x * kScanTile + tid * kScanItems;  // blocked arrangement
     int v[kScanItems];
@@ -108,9 +111,11 @@ __global__ __launch_bounds__(kScanBlock) void scan_apply(const int32_t *in, int 
 // short inputs: the whole scan in ONE workgroup (1024 threads x 8 items per round, carry between rounds): one launch
 // instead of three for the many scans over a few thousand elements of the voxelisation / union bookkeeping
 constexpr int kSmallScanMax = 32768;
-__global__ __launch_bounds__(1024) void scan_small_kernel(const int32_t *in, int n, int32_t *out, int32_t *total)
+__global__ __launch_bounds__(1024) void scan_small_kernel(const int32_t *in, int n, int32_t *out, int32_t *total,
+                                                          const int32_t *n_dev)
 {
     __shared__ int sWave[1024 / kWave];
+    if (n_dev) n = min(n, *n_dev);
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
     int carry = 0;
     for (int base = 0; base < n; base += 1024 * kScanItems) {
@@ -152,28 +157,32 @@ __global__ __launch_bounds__(1024) void scan_small_kernel(const int32_t *in, int
 }  // namespace
 
 namespace ep {
-// scratch: ceil(n / 2048) int32.  `total_dev` (optional) receives the grand total.
-int exclusive_scan_i32(const int32_t *in, int n, int32_t *out, int32_t *scratch, int32_t *total_dev,
-                       hipStream_t st)
+// scratch: ceil(n / 2048) int32.  `total_dev` (optional) receives the grand total.  n_dev (optional, device): the live
+// length is min(n, *n_dev); launches are sized by n.
+int exclusive_scan_i32_dn(const int32_t *in, int n, const int32_t *n_dev, int32_t *out, int32_t *scratch, int32_t *total_dev,
+                          hipStream_t st)
 {
     if (n <= 0) {
         if (total_dev) EP_HIP_CHECK(hipMemsetAsync(total_dev, 0, sizeof(int32_t), st));
         return EPRECON_OK;
     }
-    static const bool small_on = !(getenv("EPRECON_SCAN_SMALL") && getenv("EPRECON_SCAN_SMALL")[0] == '0');
-    if (small_on && n <= kSmallScanMax) {
-        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in, n, out, total_dev);
+    if (n <= kSmallScanMax) {
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in, n, out, total_dev, n_dev);
         EP_LAUNCH_CHECK();
         return EPRECON_OK;
     }
     const int nblk = (int)ceil_div(n, kScanTile);
-    hipLaunchKernelGGL(scan_tile_sums, dim3(nblk), dim3(kScanBlock), 0, st, in, n, scratch);
+    hipLaunchKernelGGL(scan_tile_sums, dim3(nblk), dim3(kScanBlock), 0, st, in, n, scratch, n_dev);
     EP_LAUNCH_CHECK();
     hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(1024), 0, st, scratch, nblk, total_dev);
     EP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scan_apply, dim3(nblk), dim3(kScanBlock), 0, st, in, n, scratch, out);
+    hipLaunchKernelGGL(scan_apply, dim3(nblk), dim3(kScanBlock), 0, st, in, n, scratch, out, n_dev);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
+}
+int exclusive_scan_i32(const int32_t *in, int n, int32_t *out, int32_t *scratch, int32_t *total_dev, hipStream_t st)
+{
+    return exclusive_scan_i32_dn(in, n, nullptr, out, scratch, total_dev, st);
 }
 }  // namespace ep
 
@@ -192,9 +201,10 @@ __global__ void hash_clear_kernel(unsigned long long *keys, int32_t *vals, uint3
 }
 
 // coords int32[n,4] (b,x,y,z); key = floor(c / q) * q per spatial coordinate (q >= 1)
-__global__ void hash_insert_kernel(HashTable t, const int4 *coords, int n, int q, int32_t *status)
+__global__ void hash_insert_kernel(HashTable t, const int4 *coords, int n, int q, int32_t *status, const int32_t *n_dev)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n = min(n, *n_dev);
     if (i >= n) return;
     int4 c = coords[i];
     if (q > 1) {
@@ -224,9 +234,10 @@ __global__ void hash_query_kernel(HashTable t, const int4 *queries, int m, int q
 
 // first[i] = 1 when row i is the first occurrence of its (quantised) key
 __global__ void first_flag_kernel(HashTable t, const int4 *coords, int n, int q, int32_t *first,
-                                  int32_t *owner)
+                                  int32_t *owner, const int32_t *n_dev)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n = min(n, *n_dev);
     if (i >= n) return;
     int4 c = coords[i];
     if (q > 1) {
@@ -243,9 +254,10 @@ __global__ void first_flag_kernel(HashTable t, const int4 *coords, int n, int q,
 // the table values are rewritten from "first row" to "unique id" so later lookups return ids.
 __global__ void unique_finalize_kernel(HashTable t, const int4 *coords, int n, int q,
                                        const int32_t *owner, const int32_t *rank, int32_t *inverse,
-                                       int4 *unique_coords)
+                                       int4 *unique_coords, const int32_t *n_dev)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n = min(n, *n_dev);
     if (i >= n) return;
     const int o = owner[i];
     if (o < 0) {
@@ -360,8 +372,8 @@ extern "C" {
 uint32_t eprecon_hash_capacity(int64_t n) { return ep::hash_capacity_for(n); }
 size_t eprecon_hash_table_bytes(uint32_t capacity) { return 256 + (size_t)capacity * 12; }
 
-int eprecon_hash_build_async(const int32_t *coords, int64_t n, int quantum, void *table,
-                             uint32_t capacity, void *stream)
+static int hash_build_impl(const int32_t *coords, int64_t n, const int32_t *n_dev, int quantum, void *table, uint32_t capacity,
+                           void *stream)
 {
     if (!table || !is_pow2(capacity) || n < 0 || quantum < 1 || (uint64_t)capacity < (uint64_t)n + 1 ||
         (n > 0 && !coords))
@@ -373,10 +385,16 @@ int eprecon_hash_build_async(const int32_t *coords, int64_t n, int quantum, void
     EP_LAUNCH_CHECK();
     if (n > 0) {
         hipLaunchKernelGGL(hash_insert_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, t,
-                           reinterpret_cast<const int4 *>(coords), (int)n, quantum, table_status(table));
+                           reinterpret_cast<const int4 *>(coords), (int)n, quantum, table_status(table), n_dev);
         EP_LAUNCH_CHECK();
     }
     return EPRECON_OK;
+}
+
+int eprecon_hash_build_async(const int32_t *coords, int64_t n, int quantum, void *table,
+                             uint32_t capacity, void *stream)
+{
+    return hash_build_impl(coords, n, nullptr, quantum, table, capacity, stream);
 }
 
 int eprecon_hash_query_async(const void *table, uint32_t capacity, const int32_t *queries, int64_t m,
@@ -406,15 +424,14 @@ size_t eprecon_unique_workspace_bytes(int64_t n)
     return align_up((size_t)(n > 0 ? n : 1) * 4, 256) * 3 + align_up((size_t)ceil_div(n > 0 ? n : 1, 2048) * 4, 256) + 256;
 }
 
-int eprecon_unique_coords_async(const int32_t *coords, int64_t n, int quantum, void *table,
-                                uint32_t capacity, int32_t *inverse, int32_t *unique_coords,
-                                int32_t *n_unique_dev, void *workspace, size_t workspace_bytes,
-                                void *stream)
+static int unique_coords_impl(const int32_t *coords, int64_t n, const int32_t *n_dev, int quantum, void *table,
+                              uint32_t capacity, int32_t *inverse, int32_t *unique_coords, int32_t *n_unique_dev,
+                              void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!n_unique_dev || !workspace || workspace_bytes < eprecon_unique_workspace_bytes(n))
         return n_unique_dev && workspace ? EPRECON_ERR_WORKSPACE : EPRECON_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    int rc = eprecon_hash_build_async(coords, n, quantum, table, capacity, stream);
+    int rc = hash_build_impl(coords, n, n_dev, quantum, table, capacity, stream);
     if (rc != EPRECON_OK) return rc;
     if (n == 0) {
         EP_HIP_CHECK(hipMemsetAsync(n_unique_dev, 0, sizeof(int32_t), st));
@@ -430,17 +447,35 @@ int eprecon_unique_coords_async(const int32_t *coords, int64_t n, int quantum, v
     HashTable t = make_table(table, capacity);
     const dim3 grid((unsigned)ceil_div(n, 256)), block(256);
     const int4 *c4 = reinterpret_cast<const int4 *>(coords);
-    hipLaunchKernelGGL(first_flag_kernel, grid, block, 0, st, t, c4, (int)n, quantum, first, owner);
+    hipLaunchKernelGGL(first_flag_kernel, grid, block, 0, st, t, c4, (int)n, quantum, first, owner, n_dev);
     EP_LAUNCH_CHECK();
-    rc = ep::exclusive_scan_i32(first, (int)n, rank, scratch, n_unique_dev, st);
+    rc = ep::exclusive_scan_i32_dn(first, (int)n, n_dev, rank, scratch, n_unique_dev, st);
     if (rc != EPRECON_OK) return rc;
     hipLaunchKernelGGL(unique_finalize_kernel, grid, block, 0, st, t, c4, (int)n, quantum, owner, rank,
-                       inverse, reinterpret_cast<int4 *>(unique_coords));
+                       inverse, reinterpret_cast<int4 *>(unique_coords), n_dev);
     EP_LAUNCH_CHECK();
     hipLaunchKernelGGL(table_vals_to_ids_kernel, dim3((capacity + 255) / 256), block, 0, st, t, capacity,
                        rank);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
+}
+
+int eprecon_unique_coords_async(const int32_t *coords, int64_t n, int quantum, void *table,
+                                uint32_t capacity, int32_t *inverse, int32_t *unique_coords,
+                                int32_t *n_unique_dev, void *workspace, size_t workspace_bytes,
+                                void *stream)
+{
+    return unique_coords_impl(coords, n, nullptr, quantum, table, capacity, inverse, unique_coords, n_unique_dev, workspace,
+                              workspace_bytes, stream);
+}
+
+int eprecon_unique_coords_dn_async(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, int quantum, void *table,
+                                   uint32_t capacity, int32_t *inverse, int32_t *unique_coords, int32_t *n_unique_dev,
+                                   void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!n_dev) return EPRECON_ERR_ARG;
+    return unique_coords_impl(coords, n_cap, n_dev, quantum, table, capacity, inverse, unique_coords, n_unique_dev, workspace,
+                              workspace_bytes, stream);
 }
 
 int eprecon_kernel_map_async(const void *table, uint32_t capacity, const int32_t *coords, int64_t n,

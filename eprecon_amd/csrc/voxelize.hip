@@ -38,9 +38,11 @@ __global__ void aligned_coords_kernel(const int4 *coords, int n, const float *or
 }
 
 // pts f32[N,4] (x,y,z,b) -> scaled f32[N,4] (x/res, y/res, z/res, b) and int32[N,4] (b, floor ...)
-__global__ void point_quantize_kernel(const float4 *pts, int n, float res, float4 *scaled, int4 *vox)
+// (n_dev, optional: the live count is min(n, *n_dev); the launch is sized by n)
+__global__ void point_quantize_kernel(const float4 *pts, int n, float res, float4 *scaled, int4 *vox, const int32_t *n_dev)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n = min(n, *n_dev);
     if (i >= n) return;
     const float4 p = pts[i];
     const float x = __fdiv_rn(p.x, res), y = __fdiv_rn(p.y, res), z = __fdiv_rn(p.z, res);
@@ -334,7 +336,20 @@ int eprecon_point_quantize_async(const float *points_xyzb, int64_t n, float reso
     if (n == 0) return EPRECON_OK;
     hipLaunchKernelGGL(point_quantize_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
                        (hipStream_t)stream, reinterpret_cast<const float4 *>(points_xyzb), (int)n, resolution,
-                       reinterpret_cast<float4 *>(scaled_xyzb), reinterpret_cast<int4 *>(voxel_bxyz));
+                       reinterpret_cast<float4 *>(scaled_xyzb), reinterpret_cast<int4 *>(voxel_bxyz), (const int32_t *)nullptr);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_point_quantize_dn_async(const float *points_xyzb, int64_t n_cap, const int32_t *n_dev, float resolution,
+                                    float *scaled_xyzb, int32_t *voxel_bxyz, void *stream)
+{
+    if (n_cap < 0 || !n_dev || !(resolution > 0.0f) || (n_cap > 0 && (!points_xyzb || !scaled_xyzb || !voxel_bxyz)))
+        return EPRECON_ERR_ARG;
+    if (n_cap == 0) return EPRECON_OK;
+    hipLaunchKernelGGL(point_quantize_kernel, dim3((unsigned)ceil_div(n_cap, 256)), dim3(256), 0,
+                       (hipStream_t)stream, reinterpret_cast<const float4 *>(points_xyzb), (int)n_cap, resolution,
+                       reinterpret_cast<float4 *>(scaled_xyzb), reinterpret_cast<int4 *>(voxel_bxyz), n_dev);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }

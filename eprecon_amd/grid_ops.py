@@ -22,6 +22,7 @@ def init_select(logit, coords, batch_size, dim=24, cell=4, threshold=0.3, must_b
                                              float(threshold), batch_size, dim, cell, _lib.ptr(out),
                                              _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
                "eprecon_init_select_async")
+    _lib.count_host_read()
     if must_be_zero:
         host = torch.cat([counts] + [t.reshape(1) for t in must_be_zero]).cpu().tolist()
         if any(host[1 + batch_size:]):
@@ -41,6 +42,7 @@ class PendingSelect:
         self._out, self._pinned, self._event = out, pinned, event
 
     def result(self):
+        _lib.count_host_read()
         self._event.synchronize()
         host = self._pinned.tolist()
         return self._out[: host[0]], host[1:]
@@ -114,6 +116,7 @@ def sparsify(occ, threshold, target, coords, tsdf, feat_all, c_feat, batch_size)
         _lib.ptr(feat_all), feat_all.stride(0), c_all, int(c_feat), n, batch_size, _lib.ptr(out_coords), _lib.ptr(out_tsdf),
         _lib.ptr(out_occ), _lib.ptr(out_all), _lib.ptr(out_feat), _lib.ptr(counts), _lib.ptr(ws), ws.numel(),
         _lib.current_stream()), "eprecon_sparsify_async")
+    _lib.count_host_read()
     host = counts.tolist()
     m = host[0]
     return host, out_coords[:m], out_tsdf[:m], out_occ[:m], out_all[:m], out_feat[:m]

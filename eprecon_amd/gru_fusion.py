@@ -21,7 +21,8 @@ from . import _lib
 from .global_map import GlobalMap
 from .modules import ConvGRU
 from .tensor import PointTensor
-from .torchsparse_utils import aligned_camera_coords, prepare_convgru_voxelizations
+from .torchsparse_utils import (aligned_camera_coords, convgru_resolution, prepare_convgru_voxelizations,
+                                register_voxelization)
 
 
 def fbv_union(cur_coords, cur_feat, glob_coords, glob_feat, dim, interval, rel, mode=0):
@@ -97,6 +98,9 @@ class GRUFusion(nn.Module):
                                                 vres=cfg.VOXEL_SIZE * 2 ** (self.n_scales - i)))
         self._identity_fusion = False  # tests: skip the ConvGRUs (pins the bookkeeping alone)
         self.two_streams = __import__("os").environ.get("EPRECON_GRU_STREAMS", "1") == "1"
+        # EPRECON_GRU_STAGE=0: the level's bookkeeping as separate calls with a host read each (crop_union, target_fuse, the
+        # two unique-voxel counts) instead of ONE queued stage call + one read (GlobalMap.stage_begin)
+        self.stage_call = __import__("os").environ.get("EPRECON_GRU_STAGE", "1") == "1"
         self._side = None
         self._xchg = None              # multi-GPU: distributed.BoundaryExchange (stamps of the map voxels)
         self._n_exchanged = self._cur_fragment = 0
@@ -149,6 +153,7 @@ class GRUFusion(nn.Module):
                 both = (torch.as_tensor(ho).detach().float().reshape(-1, 3).cpu(),
                         torch.as_tensor(hp).detach().float().reshape(-1, 3).cpu())
             else:
+                _lib.count_host_read()
                 both = torch.stack([vo.detach().float().reshape(-1, 3), vp.detach().float().reshape(-1, 3)]).cpu()
             hit = (key, vo, vp, both[0], both[1])
             self._origin_cache = hit
@@ -206,6 +211,52 @@ class GRUFusion(nn.Module):
             if c.shape[0] != maps[scale][0].shape[0] or f is not maps[scale][1]:
                 self.global_volume[scale].set(c, f)
 
+    def _fuse_staged(self, scale, i, cur_c, cur_f, dim, interval, rel_l, origin, inputs, dev):
+        """one batch element of one level on the stage call (inference on the GPU): -> (coords, fused values, tsdf_target,
+        occ_target).  One host read for the whole bookkeeping; the ConvGRUs find their voxelisations in the cache."""
+        cfg = self.cfg
+        gmap = self.global_volume[scale]
+        chv, cin = self.ch_voxel[scale], self.ch_in[scale]
+        chi = cin - chv
+        gv, gi = self.fusion_nets_voxel[scale], self.fusion_nets_img[scale]
+        res = convgru_resolution(gv.convz.pres, gv.convz.vres)
+        tmap = tsdf_gt = occ_gt = None
+        if "occ_list" in inputs:
+            lvl = cfg.N_LAYER - scale - 1
+            tmap, tsdf_gt, occ_gt = self.target_tsdf_volume[scale], inputs["tsdf_list"][lvl][i], inputs["occ_list"][lvl][i]
+        st = gmap.stage_begin(tmap, cur_c, cur_f, dim, interval, rel_l, tsdf_gt, occ_gt, origin,
+                              inputs["world_to_aligned_camera"][i], cfg.VOXEL_SIZE, res, chv, batch_index=i).read()
+        n_u = st.n
+        r_coords = st.r_coords
+        e1 = register_voxelization(r_coords, res, st.scaled1, st.vox1, st.inverse1, st.uniq1, st.grid1)
+        register_voxelization(e1.scaled, res, st.scaled2, st.vox2, st.inverse2, st.uniq2, st.grid2)
+        values = torch.empty((n_u, cin), dtype=torch.float32, device=dev)
+        hx_v, hx_i = st.hx_v, st.hx_i
+        if self._identity_fusion:          # tests: the bookkeeping alone (the fragment's rows pass through)
+            values[:, :chv], values[:, chv:] = hx_v[:, chv:], hx_i[:, chi:]
+        else:
+            prepare_convgru_voxelizations(r_coords, gv.convz.pres, gv.convz.vres)   # kernel maps, point lists, corner tables
+        if self._identity_fusion:
+            pass
+        elif self.two_streams:
+            main = torch.cuda.current_stream(dev)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                gi(PointTensor(hx_i[:, :chi], r_coords), PointTensor(hx_i[:, chi:], r_coords), out=values[:, chv:])
+            gv(PointTensor(hx_v[:, :chv], r_coords), PointTensor(hx_v[:, chv:], r_coords), out=values[:, :chv])
+            main.wait_stream(self._side)
+        else:
+            gv(PointTensor(hx_v[:, :chv], r_coords), PointTensor(hx_v[:, chv:], r_coords), out=values[:, :chv])
+            gi(PointTensor(hx_i[:, :chi], r_coords), PointTensor(hx_i[:, chi:], r_coords), out=values[:, chv:])
+        gmap.update(st.updated, values)                                          # update_map (:195-215)
+        if self._xchg is not None:
+            self._map_ready = torch.cuda.current_stream(dev).record_event()
+        tsdf_target = st.tsdf_target
+        occ_target = tsdf_target.abs() < 1 if tsdf_target is not None else None
+        return st.out_coords, values, tsdf_target, occ_target
+
     def forward(self, coords, values_in, inputs, scale=2, outputs=None, save_mesh=False, panoptic_infos=None):
         """coords int[N,4] (b,x,y,z) finest units, values_in f32[N,C] ->
         (coords[N',4] raster order per batch element, fused f32[N',C], tsdf_target f32[N',1] | None,
@@ -234,6 +285,12 @@ class GRUFusion(nn.Module):
             cur_c, cur_f = coords[lo:hi], values_in[lo:hi]
             gmap = self.global_volume[scale]
             rel_l = rel.tolist()
+            if self.stage_call and dev.type == "cuda" and not torch.is_grad_enabled() and cur_f.stride(1) == 1:
+                res = self._fuse_staged(scale, i, cur_c, cur_f, dim, interval, rel_l, origin, inputs, dev)
+                for part, lst in zip(res, (out_c, out_v, out_t, out_o)):
+                    if part is not None:
+                        lst.append(part)
+                continue
             updated, src_cur, src_glob, _ = gmap.crop_union(cur_c, cur_f, dim, interval, rel_l)
             n_u, cin = updated.shape[0], self.ch_in[scale]
             chi = cin - chv

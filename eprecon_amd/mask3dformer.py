@@ -428,6 +428,7 @@ def panoptic_inference(mask_cls, mask_pred, object_mask_threshold=0.3, thing_id=
     scores, labels = F.softmax(mask_cls, dim=-1).max(-1)
     prob = mask_pred.sigmoid()
     keep = labels.ne(0) & (scores > object_mask_threshold)
+    _lib.count_host_read(3)           # (boolean indexing sizes its result on the host; then the two .cpu() below)
     cur_scores, cur_classes, cur_masks = scores[keep], labels[keep], prob[keep]
     n = cur_masks.shape[-1]
     seg = torch.zeros(n, dtype=torch.int32, device=prob.device)

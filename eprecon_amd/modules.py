@@ -681,7 +681,7 @@ class SPVCNN(nn.Module):
             return self._forward_recording(z)
         cs = self.cs
         dev = z.F.device
-        x0 = initial_voxelize(z, self.pres, self.vres)
+        x0 = initial_voxelize(z, self.pres, self.vres, levels=3)   # strides 1, 2, 4 numbered together: one host read
         s1 = x0.vset
         s2, down12, up21 = s1.downsample()
         s4, down24, up42 = s2.downsample()

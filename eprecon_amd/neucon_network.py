@@ -20,6 +20,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import _lib
 from . import grid_ops as GO
 from . import sparse as SP
 from .back_project import Back_Project
@@ -384,6 +385,7 @@ class NeuConNet(nn.Module):
         outputs['panoptic_levels'] and outputs['panoptic_out'] on the current stream"""
         keep1, keep0 = self.prune_to_ancestors(panoptic_coords)
         # (one nonzero per level, shared by the coordinates and the features: boolean indexing runs it once per tensor)
+        _lib.count_host_read(2)           # (torch.nonzero synchronises to size its result)
         i1, i0 = torch.nonzero(keep1).squeeze(1), torch.nonzero(keep0).squeeze(1)
         panoptic_coords[1], panoptic_voxel_feats[1] = panoptic_coords[1].index_select(0, i1), panoptic_voxel_feats[1].index_select(0, i1)
         panoptic_coords[0], panoptic_voxel_feats[0] = panoptic_coords[0].index_select(0, i0), panoptic_voxel_feats[0].index_select(0, i0)

@@ -34,6 +34,11 @@ class HashGrid:
         self.mem = torch.empty(int(lib.eprecon_hash_table_bytes(self.capacity)), dtype=torch.uint8,
                                device=device)
 
+    @property
+    def header(self):
+        """int32[2] view of the table's header: (status word, count of unique keys written by the unique calls)"""
+        return self.mem[:8].view(torch.int32)
+
     def build(self, coords, quantum=1):
         lib = _lib.load()
         _lib.check(lib.eprecon_hash_build_async(_lib.ptr(coords), coords.shape[0], quantum,
@@ -56,30 +61,46 @@ class HashGrid:
                           "eprecon_hash_status")
 
 
-def unique_coords(coords, quantum=1):
-    """-> (unique int32[M,4] in first-occurrence order, inverse int32[N], HashGrid mapping key -> id).
-    One host sync to learn M (the reference's torch.unique syncs as well)."""
+def check_hash_status(status):
+    """status word of a hash table (bit 0: a key out of the packable range — |coordinate| >= 2^19 - 1 or batch > 14 —, bit 1:
+    table full): such voxels would otherwise silently drop out of every kernel map built on the set"""
+    if status:
+        raise _lib.EpreconError(f"hash grid: {'coordinate / batch index out of range' if status & 1 else 'table full'} "
+                                f"(status {status}, EPRECON_ERR_UNSUPPORTED)")
+
+
+def unique_coords_queued(coords, quantum=1, n_dev=None):
+    """Queue the unique (quantised) voxel numbering of `coords` WITHOUT reading the count back:
+    -> (unique int32[N,4] whose first M rows are written, inverse int32[N], HashGrid).  M and the table's status word land in
+    grid.header (device); n_dev (a device int32 element): only the first min(N, *n_dev) rows of `coords` are live."""
     lib = _lib.load()
     coords = coords.contiguous()
     n, dev = coords.shape[0], coords.device
     grid = HashGrid(n, dev)
     inverse = torch.empty(n, dtype=torch.int32, device=dev)
     uniq = torch.empty((n, 4), dtype=torch.int32, device=dev)
-    # the count lands next to the table's status word (the table's 256-byte header): ONE 8-byte host read, no torch.cat
-    header = grid.mem[:8].view(torch.int32)
-    n_unique = header[1:2]
+    n_unique = grid.header[1:2]
     ws = _lib.workspace(lib.eprecon_unique_workspace_bytes(n), dev)
-    _lib.check(lib.eprecon_unique_coords_async(_lib.ptr(coords), n, quantum, _lib.ptr(grid.mem),
-                                               grid.capacity, _lib.ptr(inverse), _lib.ptr(uniq),
-                                               _lib.ptr(n_unique), _lib.ptr(ws), ws.numel(),
-                                               _lib.current_stream()), "eprecon_unique_coords_async")
-    # one host read for the voxel count AND the table's status word (bit 0: a key out of the packable range —
-    # |coordinate| >= 2^19 - 1 or batch > 14 —, bit 1: table full): such voxels would otherwise silently drop out of
-    # every kernel map built on this set
-    status, m = header.tolist()
-    if status:
-        raise _lib.EpreconError(f"hash grid: {'coordinate / batch index out of range' if status & 1 else 'table full'} "
-                                f"(status {status}, EPRECON_ERR_UNSUPPORTED)")
+    if n_dev is None:
+        _lib.check(lib.eprecon_unique_coords_async(_lib.ptr(coords), n, quantum, _lib.ptr(grid.mem), grid.capacity,
+                                                   _lib.ptr(inverse), _lib.ptr(uniq), _lib.ptr(n_unique), _lib.ptr(ws), ws.numel(),
+                                                   _lib.current_stream()), "eprecon_unique_coords_async")
+    else:
+        _lib.check(lib.eprecon_unique_coords_dn_async(_lib.ptr(coords), n, _lib.ptr(n_dev), quantum, _lib.ptr(grid.mem),
+                                                      grid.capacity, _lib.ptr(inverse), _lib.ptr(uniq), _lib.ptr(n_unique),
+                                                      _lib.ptr(ws), ws.numel(), _lib.current_stream()),
+                   "eprecon_unique_coords_dn_async")
+    return uniq, inverse, grid
+
+
+def unique_coords(coords, quantum=1):
+    """-> (unique int32[M,4] in first-occurrence order, inverse int32[N], HashGrid mapping key -> id).
+    One host sync to learn M (the reference's torch.unique syncs as well)."""
+    uniq, inverse, grid = unique_coords_queued(coords, quantum)
+    # the count lands next to the table's status word (the table's 256-byte header): ONE 8-byte host read, no torch.cat
+    _lib.count_host_read()
+    status, m = grid.header.tolist()
+    check_hash_status(status)
     return uniq[:m], inverse, grid
 
 
@@ -157,6 +178,32 @@ def packed_weight16(weight):
         hit = (tag, packed)
         weight._d3_pack16 = hit
     return hit[1]
+
+
+def voxel_hierarchy(vox, levels=3):
+    """The voxel sets of a point cloud at tensor strides 1, 2, 4, ... with ONE host read for all their sizes: the unique
+    numbering of `vox` int32[N,4] and of each coarser stride is queued back to back (the coarser calls take the finer
+    count from the device, eprecon_unique_coords_dn_async), then the `levels` counts and status words are read together.
+    -> (VoxelSet at stride 1 with its downsample chain attached, inverse int32[N])"""
+    n = vox.shape[0]
+    grids, uniqs, invs = [], [], []
+    src, n_dev = vox, None
+    for lvl in range(levels):
+        u, inv, g = unique_coords_queued(src, quantum=2 ** lvl, n_dev=n_dev)
+        grids.append(g); uniqs.append(u); invs.append(inv)
+        src, n_dev = u, g.header[1:2]
+    _lib.count_host_read()
+    host = torch.cat([g.header for g in grids]).tolist()
+    sizes = []
+    for lvl in range(levels):
+        check_hash_status(host[2 * lvl])
+        sizes.append(host[2 * lvl + 1])
+    base = VoxelSet(uniqs[0][:sizes[0]], 1, grid=grids[0])
+    cur = base
+    for lvl in range(1, levels):
+        coarse, _, _ = cur.downsample(pre=(uniqs[lvl][:sizes[lvl]], invs[lvl][:sizes[lvl - 1]], grids[lvl]))
+        cur = coarse
+    return base, invs[0]
 
 
 def clear_packed_weights(module):
@@ -257,12 +304,14 @@ class VoxelSet:
             self._k3 = nbr
         return self._k3
 
-    def downsample(self):
-        """k2s2 strided set: -> (coarse VoxelSet, down_map int32[8, M], up_map int32[8, N])"""
+    def downsample(self, pre=None):
+        """k2s2 strided set: -> (coarse VoxelSet, down_map int32[8, M], up_map int32[8, N]).
+        pre = (unique int32[M,4], parent int32[N], HashGrid): the strided set numbered by an earlier queued call
+        (voxel_hierarchy: the counts of all strides read back at once)"""
         if self._down is None:
             lib = _lib.load()
             q = 2 * self.stride
-            uniq, parent, cgrid = unique_coords(self.coords, quantum=q)
+            uniq, parent, cgrid = pre if pre is not None else unique_coords(self.coords, quantum=q)
             coarse = VoxelSet(uniq, q, grid=cgrid)
             m = coarse.n
             down = torch.empty((8, m), dtype=torch.int32, device=self.coords.device)

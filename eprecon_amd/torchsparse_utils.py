@@ -120,22 +120,15 @@ def clear_voxelization_cache():
         _VOX_CACHE.clear()
 
 
-def _voxelize_points(pts, res):
-    key = (pts.data_ptr(), pts._version, pts.shape[0], float(res))
+def _cached_entry(key, pts):
     with _VOX_CACHE_LOCK:
         for e in _VOX_CACHE:
             if e.key == key and e.pts is pts:
                 return e
-    lib = _lib.load()
-    n = pts.shape[0]
-    e = _VoxEntry()
-    e.key, e.pts = key, pts
-    e.scaled = torch.empty_like(pts)
-    e.vox = torch.empty((n, 4), dtype=torch.int32, device=pts.device)
-    _lib.check(lib.eprecon_point_quantize_async(_lib.ptr(pts), n, float(res), _lib.ptr(e.scaled), _lib.ptr(e.vox),
-                                                _lib.current_stream()), "eprecon_point_quantize_async")
-    uniq, e.inverse, grid = SP.unique_coords(e.vox, 1)
-    e.vset = SP.VoxelSet(uniq, 1, grid=grid)
+    return None
+
+
+def _publish_entry(e):
     e.lists = _segment_lists(e.inverse, e.vset.n)
     e.idx8 = e.w8 = e._order = None
     e._stale = {}
@@ -144,6 +137,40 @@ def _voxelize_points(pts, res):
         if len(_VOX_CACHE) > _VOX_CACHE_MAX:
             _VOX_CACHE.pop(0)
     return e
+
+
+def _voxelize_points(pts, res, levels=1):
+    """levels > 1 (SPVCNN): the strided voxel sets of the U-Net's down stages are numbered in the same pass and ALL sizes are
+    read back at once (sparse.voxel_hierarchy) — one host read per SPVCNN pass instead of three"""
+    key = (pts.data_ptr(), pts._version, pts.shape[0], float(res))
+    e = _cached_entry(key, pts)
+    if e is not None:
+        return e
+    lib = _lib.load()
+    n = pts.shape[0]
+    e = _VoxEntry()
+    e.key, e.pts = key, pts
+    e.scaled = torch.empty_like(pts)
+    e.vox = torch.empty((n, 4), dtype=torch.int32, device=pts.device)
+    _lib.check(lib.eprecon_point_quantize_async(_lib.ptr(pts), n, float(res), _lib.ptr(e.scaled), _lib.ptr(e.vox),
+                                                _lib.current_stream()), "eprecon_point_quantize_async")
+    if levels > 1 and pts.is_cuda:
+        e.vset, e.inverse = SP.voxel_hierarchy(e.vox, levels)
+    else:
+        uniq, e.inverse, grid = SP.unique_coords(e.vox, 1)
+        e.vset = SP.VoxelSet(uniq, 1, grid=grid)
+    return _publish_entry(e)
+
+
+def register_voxelization(pts, res, scaled, vox, inverse, uniq, grid):
+    """An entry whose quantisation and voxel numbering were computed elsewhere with device-side counts (GRU-fusion stage,
+    eprecon_gru_stage_begin_async) and already sliced to their sizes: published under the points tensor `pts` so that the
+    SConv3d that voxelise these points find it (initial_voxelize)"""
+    e = _VoxEntry()
+    e.key, e.pts = (pts.data_ptr(), pts._version, pts.shape[0], float(res)), pts
+    e.scaled, e.vox, e.inverse = scaled, vox, inverse
+    e.vset = SP.VoxelSet(uniq, 1, grid=grid)
+    return _publish_entry(e)
 
 
 def _entry_corner_tables(e):
@@ -162,12 +189,16 @@ def _entry_corner_tables(e):
     return e.idx8, e.w8
 
 
+def convgru_resolution(init_res, after_res):
+    return float(after_res) / float(init_res) if init_res != 1 else float(after_res)
+
+
 def prepare_convgru_voxelizations(coords, init_res, after_res):
     """Everything the six SConv3d of the two ConvGRUs of a scale share, built up front on the current stream: the
     voxelisation of `coords` (convz / convq) and of the once-scaled coordinates (convr), their kernel maps and corner
     tables (stale ones in LITERAL_CONVR mode).  Afterwards the two cells only READ these entries and can run on two
-    streams."""
-    res = float(after_res) / float(init_res) if init_res != 1 else float(after_res)
+    streams.  (Entries registered by the GRU-fusion stage call are found in the cache: no quantise / unique / host read.)"""
+    res = convgru_resolution(init_res, after_res)
     pts = coords if coords.is_contiguous() else coords.contiguous()
     e1 = _voxelize_points(pts, res)
     e1.vset.kernel_map(3)
@@ -181,7 +212,7 @@ def prepare_convgru_voxelizations(coords, init_res, after_res):
     return e1, e2
 
 
-def initial_voxelize(z, init_res, after_res):
+def initial_voxelize(z, init_res, after_res, levels=1):
     """ops/torchsparse_utils.py:15-35: floor(z.C * init_res / after_res) -> unique voxels
     (first-occurrence order) -> scatter-mean of z.F.  Overwrites z.C with the scaled coordinates.
 
@@ -193,7 +224,7 @@ def initial_voxelize(z, init_res, after_res):
     pts = z.C if z.C.is_contiguous() else z.C.contiguous()
     res = float(after_res) / float(init_res) if init_res != 1 else float(after_res)
     prev = getattr(z, "_vox_entry", None)
-    e = _voxelize_points(pts, res)
+    e = _voxelize_points(pts, res, levels)
     feat = _segment_mean(z.F, e.lists, e.vset.n, idx=e.inverse)
     z.C, z.vox = e.scaled, e.vox
     if prev is not None and LITERAL_CONVR and 1 in z.idx_query:

@@ -166,6 +166,15 @@ int eprecon_unique_coords_async(const int32_t *coords, int64_t n, int quantum, v
                                 int32_t *n_unique_dev, void *workspace, size_t workspace_bytes,
                                 void *stream);
 
+/* The same with the row count ON THE DEVICE ("outputs written into caller-allocated buffers sized by the static
+ * caps, with the actual count returned through a device counter"): the live count is min(n_cap, *n_dev), buffers, the
+ * table and the workspace are sized for n_cap, launches cover n_cap rows.  Lets a chain of data-dependent steps (quantise ->
+ * unique -> unique of the coarser stride ...) be queued without a host round trip between them; the caller reads all
+ * counts back once. */
+int eprecon_unique_coords_dn_async(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, int quantum, void *table,
+                                   uint32_t capacity, int32_t *inverse, int32_t *unique_coords, int32_t *n_unique_dev,
+                                   void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Kernel maps and sparse convolution  (K5, K10, K11, K13)
  *
@@ -392,6 +401,9 @@ int eprecon_aligned_coords_async(const int32_t *coords, int64_t n, const float *
 /* scaled = (x/res, y/res, z/res, b) (IEEE division); voxel = (b, floor x', floor y', floor z') */
 int eprecon_point_quantize_async(const float *points_xyzb, int64_t n, float resolution, float *scaled_xyzb,
                                  int32_t *voxel_bxyz, void *stream);
+/* ... with the point count on the device (see eprecon_unique_coords_dn_async) */
+int eprecon_point_quantize_dn_async(const float *points_xyzb, int64_t n_cap, const int32_t *n_dev, float resolution,
+                                    float *scaled_xyzb, int32_t *voxel_bxyz, void *stream);
 /* CSR lists of the points of each voxel: idx int32[n] in [-1, m) -> offsets int32[m+1],
  * order int32[n] (points of voxel v = order[offsets[v] : offsets[v+1]], ascending point index) */
 size_t eprecon_segment_workspace_bytes(int64_t n, int64_t m);
@@ -505,6 +517,53 @@ int eprecon_map_update_async(void *handle, const int32_t *updated, int64_t n, co
 int eprecon_map_target_fuse(void *handle, const float *tsdf_gt, const uint8_t *occ_gt, int dim,
                             const int32_t *relative_origin_host, const int32_t *updated, int64_t n, float *tsdf_target_out,
                             void *stream);
+/*
+ * One GRU-fusion level as ONE stream-ordered call with device-side counts  (models/gru_fusion.py:259-345 up to the ConvGRUs:
+ * convert2dense + the gathers :321-326, the ground-truth twin :99-113, the fragment's points and their aligned-camera
+ * coordinates :328-337, and the coordinate side of the two voxelisations the six SConv3d of the two ConvGRUs share,
+ * ops/torchsparse_utils.py:15-35).  Replaces eprecon_map_crop_union (blocking) + 4 gathers + eprecon_map_target_fuse (blocking) +
+ * eprecon_aligned_coords_async + 2 x (eprecon_point_quantize_async, eprecon_unique_coords_async + a host read each): nothing
+ * here waits for the device.  Every output has `capacity` rows (eprecon_gru_stage_capacity: min(dim^3, n_cur + map rows));
+ * counts int32[8] (device) = [0] union voxels n_u, [1] map rows outside the FBV, [2] / [3] unique voxels of the first / second
+ * voxelisation, [4] ground-truth cells appended, [5] ground-truth rows kept, [6] / [7] status words of table1 / table2.
+ * The caller reads counts back ONCE, hands them to eprecon_gru_stage_commit_async (which finishes the ground-truth twin's
+ * update and arms eprecon_map_update_async) and slices its buffers; kernel maps / point lists / corner tables are then built
+ * on the exact sizes.  The second voxelisation is that of the ALREADY SCALED points (models/modules.py:216-217 with the
+ * in-place z.C of ops/torchsparse_utils.py:33).
+ */
+typedef struct eprecon_gru_stage_desc {
+    void *map;                    /* feature map of this scale (C channels) */
+    void *target_map;             /* ground-truth twin (1 channel) or NULL */
+    const int32_t *cur_coords;    /* int32[n_cur,4] (b,x,y,z), finest units, ONE batch element */
+    const float *cur_feat;        /* f32[n_cur, ld_cur] */
+    int64_t n_cur; int ld_cur;
+    int dim; int interval; int activity_mode;
+    int32_t rel[3];               /* relative origin of the fragment volume in the scene grid of this scale */
+    const float *tsdf_gt; const uint8_t *occ_gt;   /* [dim^3] ground truth of the fragment, with target_map */
+    const float *origin;          /* f32[3] (device): vol_origin_partial of this batch element */
+    const float *w2ac;            /* f32[16] (device): world_to_aligned_camera of this batch element */
+    float voxel_size;             /* finest voxel size */
+    float resolution;             /* what the SConv3d divide the point coordinates by (vres / pres) */
+    int ch_voxel;                 /* channels [0, ch_voxel) feed the voxel ConvGRU, [ch_voxel, C) the image ConvGRU */
+    int batch_index;              /* batch column of out_coords */
+    int64_t capacity;
+    int32_t *updated;             /* int32[cap,3] union cells, raster order */
+    int32_t *out_coords;          /* int32[cap,4] (batch_index, cell * interval) */
+    float *r_coords;              /* f32[cap,4] aligned-camera (x,y,z,0) */
+    float *hx_voxel;              /* f32[cap, 2 ch_voxel]      [h | x]: the map's row, the fragment's row (zeros where absent) */
+    float *hx_image;              /* f32[cap, 2 (C - ch_voxel)] */
+    float *tsdf_target;           /* f32[cap] ground-truth TSDF at the union cells, with target_map */
+    float *scaled1; int32_t *vox1; int32_t *inverse1; int32_t *uniq1; void *table1;   /* f32[cap,4], int32[cap,4], [cap], [cap,4] */
+    float *scaled2; int32_t *vox2; int32_t *inverse2; int32_t *uniq2; void *table2;
+    uint32_t table_capacity;      /* eprecon_hash_capacity(capacity) */
+    int32_t *counts;              /* int32[8] (device) */
+    void *workspace; size_t workspace_bytes;   /* eprecon_gru_stage_workspace_bytes(capacity) */
+} eprecon_gru_stage_desc;
+int64_t eprecon_gru_stage_capacity(const void *map, int64_t n_cur, int dim);
+size_t eprecon_gru_stage_workspace_bytes(int64_t capacity);
+int eprecon_gru_stage_begin_async(const eprecon_gru_stage_desc *desc, void *stream);
+/* counts_host int32[8]: the host copy of desc->counts */
+int eprecon_gru_stage_commit_async(void *map, void *target_map, const int32_t *counts_host, void *stream);
 /*
  * Multi-GPU boundary exchange on the handle (the schedule of eprecon_amd/distributed.py, which emulates the
  * sequential map updates of models/gru_fusion.py:195-215,275 across ranks).  Every row carries a stamp: 0 unknown,

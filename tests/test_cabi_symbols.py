@@ -67,21 +67,23 @@ def test_operators_refuse_cpu_tensors():
         Back_Project(24)(coords, torch.zeros(1, 3), 0.04, feats, torch.eye(4).expand(9, 1, 4, 4), 0)
 
 
-def test_conv_desc_layout_matches_header(tmp_path):
-    """the ctypes mirror of eprecon_conv_desc has the size and field offsets the C compiler gives the header's
-    struct (a drift here would silently corrupt every fused convolution launch)"""
+@pytest.mark.parametrize("c_name,py_name", [("eprecon_conv_desc", "ConvDesc"), ("eprecon_gru_stage_desc", "GruStageDesc")])
+def test_struct_layouts_match_header(tmp_path, c_name, py_name):
+    """the ctypes mirrors of the descriptor structs have the size and field offsets the C compiler gives the header's
+    structs (a drift here would silently corrupt every launch that goes through them)"""
     import ctypes
     import subprocess
     from eprecon_amd import _lib
-    fields = [f[0] for f in _lib.ConvDesc._fields_]
+    mirror = getattr(_lib, py_name)
+    fields = [f[0] for f in mirror._fields_]
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "eprecon_hip.h"', 'int main(void) {',
-           '  printf("%zu\\n", sizeof(eprecon_conv_desc));']
-    src += [f'  printf("%zu\\n", offsetof(eprecon_conv_desc, {name}));' for name in fields]
+           f'  printf("%zu\\n", sizeof({c_name}));']
+    src += [f'  printf("%zu\\n", offsetof({c_name}, {name}));' for name in fields]
     src += ['  return 0;', '}']
     c_file = tmp_path / "layout.c"
     c_file.write_text("\n".join(src))
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c_file), "-o", str(exe)])
     out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    assert out[0] == ctypes.sizeof(_lib.ConvDesc)
-    assert out[1:] == [getattr(_lib.ConvDesc, name).offset for name in fields]
+    assert out[0] == ctypes.sizeof(mirror)
+    assert out[1:] == [getattr(mirror, name).offset for name in fields]

@@ -93,3 +93,34 @@ def test_fusion_with_convgru_matches_oracle(scale):
         assert np.array_equal(tsdf_t.cpu().numpy(), r["tsdf_target"])
         assert np.array_equal(occ_t.cpu().numpy(), r["occ_target"])
         assert np.array_equal(fus.global_volume[scale].C.cpu().numpy(), st.C)
+
+
+@pytest.mark.parametrize("scale", [1, 2])
+def test_stage_call_equals_the_separate_calls(scale):
+    """the level's bookkeeping queued as ONE call with device-side counts (eprecon_gru_stage_begin_async + one host read)
+    against the separate blocking calls (crop_union, gathers, target_fuse, aligned coordinates, two voxelisations): every
+    output and both maps bit for bit over the fragment sequence, with one host read per level instead of four"""
+    from eprecon_amd import _lib
+    from eprecon_amd.gru_fusion import GRUFusion
+    cfg = ModelCfg(N_VOX=[24, 24, 24])
+    frags, origin, interval, d, c = sequence(scale)
+    outs, reads = [], []
+    for staged in (True, False):
+        torch.manual_seed(scale + 10)
+        fus = GRUFusion(cfg, ch_in=[6, 4, 3], ch_voxel=[4, 3, 2]).cuda()
+        fus.stage_call = staged
+        seq = []
+        before = _lib.HOST_READS
+        for fr in frags:
+            inputs, _ = make_inputs(fr, origin, gt_lists(scale, fr))
+            with torch.no_grad():
+                res = fus(dev(fr["coords"]), dev(fr["values"]), inputs, scale)
+            seq.append([t.cpu().numpy() for t in res] + [fus.global_volume[scale].C.cpu().numpy(), fus.global_volume[scale].F.cpu().numpy(),
+                                                        fus.target_tsdf_volume[scale].C.cpu().numpy(),
+                                                        fus.target_tsdf_volume[scale].F.cpu().numpy()])
+        reads.append(_lib.HOST_READS - before)
+        outs.append(seq)
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and np.array_equal(x, y)
+    assert reads[0] == len(frags)      # one counted read per fragment and level on the stage call
