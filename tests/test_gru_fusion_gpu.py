@@ -123,4 +123,6 @@ def test_stage_call_equals_the_separate_calls(scale):
     for a, b in zip(*outs):
         for x, y in zip(a, b):
             assert x.shape == y.shape and np.array_equal(x, y)
-    assert reads[0] == len(frags)      # one counted read per fragment and level on the stage call
+    # counted blocking reads per fragment and level: the origins (these inputs carry no host copy) + ONE for the stage call,
+    # against origins + crop_union + target_fuse + the two unique-voxel counts
+    assert reads == [2 * len(frags), 5 * len(frags)]

@@ -1,0 +1,11 @@
+#!/bin/bash
+# kernel statistics of the cfg4 bench (launches / kernel time per fragment) -> gpurun_out/$1/
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/${1:-r04_stats}
+mkdir -p $O/profiles
+cd /tmp && export TMPDIR=/tmp
+EPRECON_CFG4_PIPELINE=0 python $R/bench.py --workload cfg4 --steps 24 --warmup 8 > $O/bench_cfg4.json 2> $O/bench_cfg4.err
+EPRECON_CFG4_PIPELINE=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg4 -o r -- python $R/bench.py --workload cfg4 --steps 12 --warmup 4 > $O/stats_cfg4.log 2>&1
+cd $R
+python tools/summarize_cfg4.py $O/stats_cfg4 $O/profiles $O/bench_cfg4.json | head -70
+rm -f $O/stats_cfg4/r_kernel_trace.csv
