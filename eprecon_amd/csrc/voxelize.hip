@@ -174,14 +174,18 @@ __global__ __launch_bounds__(256) void devoxelize_kernel(const float *feat, int 
 //   mode 1  out = sigmoid(v)                         update gate z
 //   mode 2  out = sigmoid(v) * h                     r * h, written straight into the [r*h, x] concat buffer
 //   mode 3  out = (1 - zg) * h + zg * tanh(v)        new hidden state
+// tail (optional): tail_dst[i, 0:tail_c] = tail_src[i, 0:tail_c] in the same launch — the x half of the [r*h, x] buffer the
+// reference builds with torch.cat (models/modules.py:218), so that no separate copy of the [h, x] buffer is needed
 __global__ __launch_bounds__(256) void devoxelize_gate_kernel(const float *feat, int ld_f, const int32_t *idx,
                                                               const float *wts, int n, int C, const float *skip,
                                                               int ld_s, int mode, const float *h, int ld_h,
-                                                              const float *zg, int ld_z, float *out, int ld_o)
+                                                              const float *zg, int ld_z, float *out, int ld_o,
+                                                              const float *tail_src, int ld_ts, float *tail_dst, int ld_td, int tail_c)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= (int64_t)n * C) return;
     const int i = (int)(e / C), c = (int)(e - (int64_t)i * C);
+    for (int t = c; t < tail_c; t += C) tail_dst[(size_t)i * ld_td + t] = tail_src[(size_t)i * ld_ts + t];
     float s = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -243,11 +247,14 @@ __device__ __forceinline__ float gate1(float v, int mode, float h, float z)
 __global__ __launch_bounds__(256) void devoxelize_gate4_kernel(const float *feat, int ld_f, const int32_t *idx,
                                                                const float *wts, int n, int C4, const float *skip, int ld_s,
                                                                int mode, const float *h, int ld_h, const float *zg, int ld_z,
-                                                               float *out, int ld_o)
+                                                               float *out, int ld_o, const float *tail_src, int ld_ts,
+                                                               float *tail_dst, int ld_td, int tail_c4)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= (int64_t)n * C4) return;
     const int i = (int)(e / C4), c = 4 * (int)(e - (int64_t)i * C4);
+    for (int t = c / 4; t < tail_c4; t += C4)
+        *reinterpret_cast<float4 *>(tail_dst + (size_t)i * ld_td + 4 * t) = *reinterpret_cast<const float4 *>(tail_src + (size_t)i * ld_ts + 4 * t);
     const float4 s = devox4(feat, ld_f, idx, wts, i, c);
     const float4 k = *reinterpret_cast<const float4 *>(skip + (size_t)i * ld_s + c);
     float4 hv = make_float4(0.f, 0.f, 0.f, 0.f), zv = hv;
@@ -467,26 +474,46 @@ int eprecon_remap_index_async(const int32_t *idx, int64_t n, const int32_t *rank
 }
 
 
+static int devoxelize_gate_impl(const float *voxel_feat, int ld_feat, const int32_t *idx8, const float *weight8,
+                                int64_t n, int channels, const float *skip, int ld_skip, int mode, const float *h,
+                                int ld_h, const float *zgate, int ld_z, float *out, int ld_out, const float *tail_src,
+                                int ld_tail_src, float *tail_dst, int ld_tail_dst, int tail_channels, void *stream)
+{
+    if (n < 0 || channels <= 0 || mode < 1 || mode > 3 || tail_channels < 0) return EPRECON_ERR_ARG;
+    if (n == 0) return EPRECON_OK;
+    if (!voxel_feat || !idx8 || !weight8 || !skip || !out || (mode >= 2 && !h) || (mode == 3 && !zgate))
+        return EPRECON_ERR_ARG;
+    if (tail_channels > 0 && (!tail_src || !tail_dst || ld_tail_src < tail_channels || ld_tail_dst < tail_channels)) return EPRECON_ERR_ARG;
+    const bool v4 = (channels & 3) == 0 && vec4_ok(voxel_feat, ld_feat) && vec4_ok(out, ld_out) && vec4_ok(skip, ld_skip) &&
+                    vec4_ok(idx8, 4) && vec4_ok(weight8, 4) && (mode < 2 || vec4_ok(h, ld_h)) && (mode < 3 || vec4_ok(zgate, ld_z)) &&
+                    (tail_channels == 0 || ((tail_channels & 3) == 0 && vec4_ok(tail_src, ld_tail_src) && vec4_ok(tail_dst, ld_tail_dst)));
+    if (v4)
+        hipLaunchKernelGGL(devoxelize_gate4_kernel, dim3((unsigned)ceil_div(n * (channels / 4), 256)), dim3(256), 0,
+                           (hipStream_t)stream, voxel_feat, ld_feat, idx8, weight8, (int)n, channels / 4, skip, ld_skip, mode,
+                           h, ld_h, zgate, ld_z, out, ld_out, tail_src, ld_tail_src, tail_dst, ld_tail_dst, tail_channels / 4);
+    else
+        hipLaunchKernelGGL(devoxelize_gate_kernel, dim3((unsigned)ceil_div(n * channels, 256)), dim3(256), 0,
+                           (hipStream_t)stream, voxel_feat, ld_feat, idx8, weight8, (int)n, channels, skip, ld_skip, mode,
+                           h, ld_h, zgate, ld_z, out, ld_out, tail_src, ld_tail_src, tail_dst, ld_tail_dst, tail_channels);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
 int eprecon_devoxelize_gate_async(const float *voxel_feat, int ld_feat, const int32_t *idx8, const float *weight8,
                                   int64_t n, int channels, const float *skip, int ld_skip, int mode, const float *h,
                                   int ld_h, const float *zgate, int ld_z, float *out, int ld_out, void *stream)
 {
-    if (n < 0 || channels <= 0 || mode < 1 || mode > 3) return EPRECON_ERR_ARG;
-    if (n == 0) return EPRECON_OK;
-    if (!voxel_feat || !idx8 || !weight8 || !skip || !out || (mode >= 2 && !h) || (mode == 3 && !zgate))
-        return EPRECON_ERR_ARG;
-    const bool v4 = (channels & 3) == 0 && vec4_ok(voxel_feat, ld_feat) && vec4_ok(out, ld_out) && vec4_ok(skip, ld_skip) &&
-                    vec4_ok(idx8, 4) && vec4_ok(weight8, 4) && (mode < 2 || vec4_ok(h, ld_h)) && (mode < 3 || vec4_ok(zgate, ld_z));
-    if (v4)
-        hipLaunchKernelGGL(devoxelize_gate4_kernel, dim3((unsigned)ceil_div(n * (channels / 4), 256)), dim3(256), 0,
-                           (hipStream_t)stream, voxel_feat, ld_feat, idx8, weight8, (int)n, channels / 4, skip, ld_skip, mode,
-                           h, ld_h, zgate, ld_z, out, ld_out);
-    else
-        hipLaunchKernelGGL(devoxelize_gate_kernel, dim3((unsigned)ceil_div(n * channels, 256)), dim3(256), 0,
-                           (hipStream_t)stream, voxel_feat, ld_feat, idx8, weight8, (int)n, channels, skip, ld_skip, mode,
-                           h, ld_h, zgate, ld_z, out, ld_out);
-    EP_LAUNCH_CHECK();
-    return EPRECON_OK;
+    return devoxelize_gate_impl(voxel_feat, ld_feat, idx8, weight8, n, channels, skip, ld_skip, mode, h, ld_h, zgate, ld_z, out,
+                                ld_out, nullptr, 0, nullptr, 0, 0, stream);
+}
+
+int eprecon_devoxelize_gate_tail_async(const float *voxel_feat, int ld_feat, const int32_t *idx8, const float *weight8,
+                                       int64_t n, int channels, const float *skip, int ld_skip, int mode, const float *h,
+                                       int ld_h, const float *zgate, int ld_z, float *out, int ld_out, const float *tail_src,
+                                       int ld_tail_src, float *tail_dst, int ld_tail_dst, int tail_channels, void *stream)
+{
+    return devoxelize_gate_impl(voxel_feat, ld_feat, idx8, weight8, n, channels, skip, ld_skip, mode, h, ld_h, zgate, ld_z, out,
+                                ld_out, tail_src, ld_tail_src, tail_dst, ld_tail_dst, tail_channels, stream);
 }
 
 }  // extern "C"

@@ -351,7 +351,9 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             step["graph"].replay()
             classes.append(step["cls"].clone())
             me, q = step["me"], step["q_next"]
-        masks.append(torch.mm(mf, me[0].t()).t().unsqueeze(0))
+        # the final head's masks in the reference's own layout ([1, Q, N_2] contiguous): panoptic_post reduces over them
+        # row-wise, which crawls on the transposed view (8 ms against 0.2 ms at 56k voxels)
+        masks.append(torch.mm(me[0], mf.t()).unsqueeze(0))
         return {"pred_logits": classes[-1], "pred_masks": masks[-1],
                 "aux_outputs": [{"pred_logits": a, "pred_masks": b} for a, b in zip(classes[:-1], masks[:-1])]}
 

@@ -736,13 +736,15 @@ class SConv3d(nn.Module):
             skip = SP.sparse_conv(z.F, _linear_wt(lin), None, lin.bias)
         return voxel_to_point(y, z, out=skip, accumulate=True)
 
-    def run_gate(self, z, mode, h=None, zgate=None, out=None):
-        """forward(z).F followed by the ConvGRU gate arithmetic of `mode` (torchsparse_utils.devoxelize_gate)"""
+    def run_gate(self, z, mode, h=None, zgate=None, out=None, skip=None, tail=None):
+        """forward(z).F followed by the ConvGRU gate arithmetic of `mode` (torchsparse_utils.devoxelize_gate).
+        skip: the point-wise Linear of this layer when the caller already computed it (ConvGRU: one GEMM for two gates)"""
         x = initial_voxelize(z, self.pres, self.vres)
         y = SparseTensor(self.net.run(x.F, x.vset.kernel_map(3)), x.vset)
-        lin = self.point_transforms[0]
-        skip = SP.sparse_conv(z.F, _linear_wt(lin), None, lin.bias)
-        return devoxelize_gate(y, z, skip, mode, h=h, zgate=zgate, out=out)
+        if skip is None:
+            lin = self.point_transforms[0]
+            skip = SP.sparse_conv(z.F, _linear_wt(lin), None, lin.bias)
+        return devoxelize_gate(y, z, skip, mode, h=h, zgate=zgate, out=out, tail=tail)
 
 
 class ConvGRU(nn.Module):
@@ -785,9 +787,23 @@ class ConvGRU(nn.Module):
             hx_f = torch.cat([hf, xf], dim=1)
             hf = hx_f[:, :c]
         hx = PointTensor(hx_f, h.C)
-        z = self.convz.run_gate(hx, 1)
-        rhx = hx_f.clone()
-        self.convr.run_gate(hx, 2, h=hf, out=rhx[:, :c])
+        # the point-wise Linear skips of convz and convr read the same [h, x] rows: ONE GEMM [N, c_in] x [c_in, 2 c]
+        w_zr, b_zr = self._merged_skip()
+        skip_zr = SP.sparse_conv(hx_f, w_zr, None, b_zr)
+        z = self.convz.run_gate(hx, 1, skip=skip_zr[:, :c])
+        # [r * h | x]: r * h written by convr's gate kernel, which copies the x half alongside (no clone of [h, x])
+        rhx = torch.empty_like(hx_f)
+        self.convr.run_gate(hx, 2, h=hf, out=rhx[:, :c], skip=skip_zr[:, c:], tail=(hx_f[:, c:], rhx[:, c:]))
         x.F = rhx
         h.F = self.convq.run_gate(x, 3, h=hf, zgate=z, out=out)
         return h.F
+
+    def _merged_skip(self):
+        lz, lr = self.convz.point_transforms[0], self.convr.point_transforms[0]
+        tag = tuple((t._version, t.data_ptr()) for t in (lz.weight, lr.weight, lz.bias, lr.bias))
+        hit = getattr(self, "_wt_cache", None)
+        if hit is None or hit[0] != tag:
+            with torch.no_grad():
+                hit = (tag, torch.cat([lz.weight.t(), lr.weight.t()], dim=1).contiguous(), torch.cat([lz.bias, lr.bias]).contiguous())
+            self._wt_cache = hit
+        return hit[1], hit[2]

@@ -298,18 +298,21 @@ def voxel_to_point(x, z, nearest=False, out=None, accumulate=False):
     return new
 
 
-def devoxelize_gate(x, z, skip, mode, h=None, zgate=None, out=None):
+def devoxelize_gate(x, z, skip, mode, h=None, zgate=None, out=None, tail=None):
     """voxel_to_point(x, z).F + skip followed by the ConvGRU gate arithmetic, one launch
-    (eprecon_devoxelize_gate_async; mode 1 sigmoid, 2 sigmoid * h, 3 (1 - zgate) * h + zgate * tanh)"""
+    (eprecon_devoxelize_gate_async; mode 1 sigmoid, 2 sigmoid * h, 3 (1 - zgate) * h + zgate * tanh).
+    tail = (src, dst): row-wise copy dst[:] = src[:] of two [n, t] column slices in the same launch"""
     lib = _lib.load()
     s = x.s
     n, c = z.C.shape[0], x.F.shape[1]
     _corner_tables(x.vset, s, z)
     if out is None:
         out = torch.empty((n, c), dtype=torch.float32, device=x.F.device)
-    _lib.check(lib.eprecon_devoxelize_gate_async(
+    t_src, t_dst = tail if tail is not None else (None, None)
+    _lib.check(lib.eprecon_devoxelize_gate_tail_async(
         _lib.ptr(x.F), x.F.stride(0), _lib.ptr(z.idx_query[s]), _lib.ptr(z.weights[s]), n, c, _lib.ptr(skip),
         skip.stride(0), int(mode), _lib.ptr(h), h.stride(0) if h is not None else 0, _lib.ptr(zgate),
-        zgate.stride(0) if zgate is not None else 0, _lib.ptr(out), out.stride(0), _lib.current_stream()),
-        "eprecon_devoxelize_gate_async")
+        zgate.stride(0) if zgate is not None else 0, _lib.ptr(out), out.stride(0), _lib.ptr(t_src),
+        t_src.stride(0) if t_src is not None else 0, _lib.ptr(t_dst), t_dst.stride(0) if t_dst is not None else 0,
+        t_src.shape[1] if t_src is not None else 0, _lib.current_stream()), "eprecon_devoxelize_gate_tail_async")
     return out

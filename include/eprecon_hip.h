@@ -448,6 +448,13 @@ int eprecon_devoxelize_gate_async(const float *voxel_feat, int ld_feat, const in
                                   int64_t n, int channels, const float *skip, int ld_skip, int mode, const float *h,
                                   int ld_h, const float *zgate, int ld_z, float *out, int ld_out, void *stream);
 
+/* ... and, in the same launch, tail_dst[i, 0:tail_channels] = tail_src[i, 0:tail_channels]: with mode 2 writing r * h into the
+ * first half of the [r*h, x] buffer (models/modules.py:218) the x half is copied alongside, so the buffer needs no clone of [h, x] */
+int eprecon_devoxelize_gate_tail_async(const float *voxel_feat, int ld_feat, const int32_t *idx8, const float *weight8,
+                                       int64_t n, int channels, const float *skip, int ld_skip, int mode, const float *h,
+                                       int ld_h, const float *zgate, int ld_z, float *out, int ld_out, const float *tail_src,
+                                       int ld_tail_src, float *tail_dst, int ld_tail_dst, int tail_channels, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * GRU-fusion union  (K15)
  *
