@@ -109,6 +109,7 @@ SIGNATURES = {
     "eprecon_nearest_voxel_async": (_i, [_vp, _c.c_uint32, _vp, _i64, _vp, _i64, _i, _vp, _vp]),
     "eprecon_upsample2x_nhwc_async": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "eprecon_decoder_keys_async": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
+    "eprecon_decoder_query_side_async": (_i, [_vp, _vp]),
     "eprecon_masked_attention_workspace_bytes": (_sz, [_i64, _i, _i, _i]),
     "eprecon_masked_attention_async": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i64, _vp, _i, _vp, _i64, _i, _i, _i, _f, _vp, _vp, _sz, _vp]),
     "eprecon_profile_enable": (_i, [_i]),
@@ -231,6 +232,16 @@ class GruStageDesc(ctypes.Structure):
                 ("table_capacity", ctypes.c_uint32),
                 ("counts", ctypes.c_void_p),
                 ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t)]
+
+
+class DecoderLayerDesc(ctypes.Structure):
+    """include/eprecon_hip.h: eprecon_decoder_layer_desc"""
+    _PTRS_A = ["o_attn", "state_in", "query_pos", "cross_out_wt", "cross_out_b", "cross_ln_g", "cross_ln_b", "self_in_wt", "self_in_b",
+               "self_out_wt", "self_out_b", "self_ln_g", "self_ln_b", "ffn1_wt", "ffn1_b", "ffn2_wt", "ffn2_b", "ffn_ln_g", "ffn_ln_b",
+               "dec_ln_g", "dec_ln_b", "cls_wt", "cls_b", "m1_wt", "m1_b", "m2_wt", "m2_b", "m3_wt", "m3_b", "next_q_wt", "next_q_b"]
+    _PTRS_B = ["state_out", "cls_out", "mask_embed_out", "next_q_out", "workspace"]
+    _fields_ = ([(n, ctypes.c_int) for n in ("n_queries", "channels", "n_heads", "ffn_dim", "n_class_logits", "mask_hidden")]
+                + [(n, ctypes.c_void_p) for n in _PTRS_A] + [("ln_eps", ctypes.c_float)] + [(n, ctypes.c_void_p) for n in _PTRS_B])
 
 
 _WORKSPACES = {}

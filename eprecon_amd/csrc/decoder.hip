@@ -267,6 +267,223 @@ __global__ __launch_bounds__(64) void masked_attention_reduce_kernel(const float
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Query side of a decoder layer (static shape [Q, C]): everything between two cross-attentions — out-projection + residual +
+// LayerNorm of the cross-attention, self-attention over the Q queries, FFN, the prediction head's class / mask embeddings and
+// the next layer's projected queries (models/mask3dformer.py:399-445 with the post-norm blocks of :33-196).  ~25 PyTorch
+// launches per layer (7 GEMMs of [80, 48] x [48, 48..192], LayerNorms, an 80 x 80 attention, ...) become TWO: every step but
+// the self-attention is row-wise, so a workgroup owns kQsRows query rows and walks the layer as vector-matrix products — the
+// row in LDS, the weights pre-transposed to [in][out] so that thread n reads column n coalesced (they stay in L2: 350 KB per
+// layer, read by every workgroup); the self-attention needs every row's keys / values and is the one grid-wide dependency:
+//   query_side_a:  u = o W_o + b; t1 = LN(x + u); [Qs | Ks] = (t1 + pos) W_qk + b; Vs = t1 W_v + b      -> workspace
+//   query_side_b:  A = softmax(Qs Ks^T / sqrt(d)) Vs per head; t2 = LN(t1 + A W_o' + b); t3 = LN(t2 + FFN(t2));
+//                  dec = LN_dec(t3); class logits, mask embedding MLP, next layer's q = (t3 + pos) W_q' + b
+// Sums run in a fixed order (k ascending inside a part, parts in order): deterministic; equal to the PyTorch modules within
+// fp32 round-off.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kQsRows = 2;        // query rows per workgroup
+constexpr int kQsThreads = 192;   // >= the widest layer (ffn_dim, mask_hidden)
+constexpr int kQsMaxC = 64;       // channels (one wave holds a row for the LayerNorms)
+
+// y[r][n] = [relu]( bias[n] + sum_k x[r][k] * wt[k][n] ) for the workgroup's rows; x / y in LDS (row pitch ldx / ldy), wt [K][N]
+// (row pitch ldw) in global memory.  The threads split into parts = blockDim / N groups of N; part p takes a contiguous range of k.
+__device__ __forceinline__ void qs_gemv(const float *__restrict__ wt, int ldw, const float *__restrict__ bias, const float *sx, int ldx,
+                                        float *sy, int ldy, int K, int N, bool relu, float *sPart)
+{
+    const int tid = threadIdx.x;
+    const int parts = max(1, min((int)blockDim.x / N, K));
+    const int part = tid / N, n = tid - part * N;
+    const int kchunk = (K + parts - 1) / parts;
+    float acc[kQsRows];
+#pragma unroll
+    for (int r = 0; r < kQsRows; ++r) acc[r] = 0.0f;
+    if (part < parts) {
+        const int k0 = part * kchunk, k1 = min(K, k0 + kchunk);
+        for (int k = k0; k < k1; ++k) {
+            const float w = wt[(size_t)k * ldw + n];
+#pragma unroll
+            for (int r = 0; r < kQsRows; ++r) acc[r] = fmaf(sx[r * ldx + k], w, acc[r]);
+        }
+        if (parts > 1) {
+#pragma unroll
+            for (int r = 0; r < kQsRows; ++r) sPart[(r * parts + part) * N + n] = acc[r];
+        }
+    }
+    if (parts > 1) __syncthreads();
+    if (part == 0) {
+        const float b = bias ? bias[n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < kQsRows; ++r) {
+            float v = acc[r];
+            for (int p = 1; p < parts; ++p) v += sPart[(r * parts + p) * N + n];
+            v += b;
+            sy[r * ldy + n] = relu ? fmaxf(v, 0.0f) : v;
+        }
+    }
+    __syncthreads();
+}
+
+// sy[r][:] = LayerNorm(sa[r][:] (+ sb[r][:])) * g + b over C <= 64 channels: wave r owns row r
+__device__ __forceinline__ void qs_layernorm(const float *sa, const float *sb, int ld, float *sy, int ldy, int C, const float *g,
+                                             const float *b, float eps)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave < kQsRows) {
+        float v = 0.0f;
+        if (lane < C) v = sa[wave * ld + lane] + (sb ? sb[wave * ld + lane] : 0.0f);
+        float s = v;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+        const float mean = s / (float)C;
+        const float d = lane < C ? v - mean : 0.0f;
+        float q = d * d;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) q += __shfl_xor(q, m);
+        const float inv = 1.0f / sqrtf(q / (float)C + eps);
+        if (lane < C) sy[wave * ldy + lane] = d * inv * g[lane] + b[lane];
+    }
+    __syncthreads();
+}
+
+struct QsParams {
+    int Q, C, H, FF, K1, MH;
+    const float *o_attn, *state_in, *query_pos;
+    const float *cross_out_wt, *cross_out_b, *cross_ln_g, *cross_ln_b;
+    const float *self_in_wt, *self_in_b, *self_out_wt, *self_out_b, *self_ln_g, *self_ln_b;
+    const float *ffn1_wt, *ffn1_b, *ffn2_wt, *ffn2_b, *ffn_ln_g, *ffn_ln_b;
+    const float *dec_ln_g, *dec_ln_b, *cls_wt, *cls_b, *m1_wt, *m1_b, *m2_wt, *m2_b, *m3_wt, *m3_b;
+    const float *next_q_wt, *next_q_b;
+    float eps;
+    float *state_out, *cls_out, *me_out, *next_q_out;
+    float *ws;   // [4][Q][C]: t1, Qs, Ks, Vs
+};
+
+__global__ __launch_bounds__(kQsThreads) void query_side_a_kernel(QsParams p)
+{
+    __shared__ float sX[kQsRows * kQsMaxC], sO[kQsRows * kQsMaxC], sU[kQsRows * kQsMaxC], sT[kQsRows * kQsMaxC];
+    __shared__ float sY[kQsRows * 3 * kQsMaxC], sPart[kQsThreads * kQsRows];
+    const int tid = threadIdx.x, C = p.C, D = C / p.H;
+    const int q0 = blockIdx.x * kQsRows;
+    for (int e = tid; e < kQsRows * C; e += kQsThreads) {
+        const int r = e / C, c = e - r * C;
+        const int q = min(q0 + r, p.Q - 1);
+        sX[r * kQsMaxC + c] = p.state_in[(size_t)q * C + c];
+        sO[r * kQsMaxC + c] = p.o_attn[((size_t)(c / D) * p.Q + q) * D + (c % D)];   // [H][Q][D] -> row q, heads side by side
+    }
+    __syncthreads();
+    qs_gemv(p.cross_out_wt, C, p.cross_out_b, sO, kQsMaxC, sU, kQsMaxC, C, C, false, sPart);
+    qs_layernorm(sX, sU, kQsMaxC, sT, kQsMaxC, C, p.cross_ln_g, p.cross_ln_b, p.eps);
+    for (int e = tid; e < kQsRows * C; e += kQsThreads) {
+        const int r = e / C, c = e - r * C;
+        sX[r * kQsMaxC + c] = sT[r * kQsMaxC + c] + p.query_pos[(size_t)min(q0 + r, p.Q - 1) * C + c];
+    }
+    __syncthreads();
+    // the packed in-projection [C][3C]: columns [0, 2C) = q | k (from t1 + pos), columns [2C, 3C) = v (from t1)
+    qs_gemv(p.self_in_wt, 3 * C, p.self_in_b, sX, kQsMaxC, sY, 3 * kQsMaxC, C, 2 * C, false, sPart);
+    qs_gemv(p.self_in_wt + 2 * C, 3 * C, p.self_in_b + 2 * C, sT, kQsMaxC, sY + 2 * C, 3 * kQsMaxC, C, C, false, sPart);
+    for (int e = tid; e < kQsRows * C; e += kQsThreads) {
+        const int r = e / C, c = e - r * C;
+        const int q = q0 + r;
+        if (q >= p.Q) continue;
+        p.ws[((size_t)0 * p.Q + q) * C + c] = sT[r * kQsMaxC + c];
+        p.ws[((size_t)1 * p.Q + q) * C + c] = sY[r * 3 * kQsMaxC + c];
+        p.ws[((size_t)2 * p.Q + q) * C + c] = sY[r * 3 * kQsMaxC + C + c];
+        p.ws[((size_t)3 * p.Q + q) * C + c] = sY[r * 3 * kQsMaxC + 2 * C + c];
+    }
+}
+
+constexpr int kQsMaxQ = 128;      // queries (the self-attention's key axis, held in LDS per head)
+constexpr int kQsMaxW = 256;      // widest hidden layer
+__global__ __launch_bounds__(kQsThreads) void query_side_b_kernel(QsParams p)
+{
+    __shared__ float sT1[kQsRows * kQsMaxC], sA[kQsRows * kQsMaxC], sU[kQsRows * kQsMaxC], sT2[kQsRows * kQsMaxC];
+    __shared__ float sT3[kQsRows * kQsMaxC], sDec[kQsRows * kQsMaxC], sQ[kQsRows * kQsMaxC];
+    __shared__ float sH1[kQsRows * kQsMaxW], sH2[kQsRows * kQsMaxW], sPart[kQsThreads * kQsRows];
+    __shared__ float sS[kQsRows * 8 * kQsMaxQ];     // scores / probabilities [row][head][key]  (H <= 8)
+    const int tid = threadIdx.x, C = p.C, H = p.H, D = C / H, Q = p.Q;
+    const int q0 = blockIdx.x * kQsRows;
+    const float *t1 = p.ws, *Qs = p.ws + (size_t)Q * C, *Ks = p.ws + (size_t)2 * Q * C, *Vs = p.ws + (size_t)3 * Q * C;
+    for (int e = tid; e < kQsRows * C; e += kQsThreads) {
+        const int r = e / C, c = e - r * C;
+        const int q = min(q0 + r, Q - 1);
+        sT1[r * kQsMaxC + c] = t1[(size_t)q * C + c];
+        sQ[r * kQsMaxC + c] = Qs[(size_t)q * C + c];
+    }
+    __syncthreads();
+    // ---- self-attention of the workgroup's rows over all Q keys ----
+    const float scale = 1.0f / sqrtf((float)D);
+    for (int e = tid; e < kQsRows * H * Q; e += kQsThreads) {
+        const int r = e / (H * Q), h = (e / Q) % H, j = e % Q;
+        float sdot = 0.0f;
+        for (int d = 0; d < D; ++d) sdot = fmaf(sQ[r * kQsMaxC + h * D + d] * scale, Ks[(size_t)j * C + h * D + d], sdot);
+        sS[(r * H + h) * kQsMaxQ + j] = sdot;
+    }
+    __syncthreads();
+    {   // softmax over the keys: one wave per (row, head) pair in turn
+        const int wave = tid >> 6, lane = tid & 63, nw = kQsThreads / 64;
+        for (int rh = wave; rh < kQsRows * H; rh += nw) {
+            float *row = sS + rh * kQsMaxQ;
+            float mx = -3.0e38f;
+            for (int j = lane; j < Q; j += 64) mx = fmaxf(mx, row[j]);
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+            float sum = 0.0f;
+            for (int j = lane; j < Q; j += 64) {
+                const float e_ = expf(row[j] - mx);
+                row[j] = e_;
+                sum += e_;
+            }
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m);
+            const float inv = 1.0f / sum;
+            for (int j = lane; j < Q; j += 64) row[j] *= inv;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < kQsRows * C; e += kQsThreads) {
+        const int r = e / C, c = e - r * C, h = c / D;
+        const float *pr = sS + (r * H + h) * kQsMaxQ;
+        float a = 0.0f;
+        for (int j = 0; j < Q; ++j) a = fmaf(pr[j], Vs[(size_t)j * C + c], a);
+        sA[r * kQsMaxC + c] = a;
+    }
+    __syncthreads();
+    qs_gemv(p.self_out_wt, C, p.self_out_b, sA, kQsMaxC, sU, kQsMaxC, C, C, false, sPart);
+    qs_layernorm(sT1, sU, kQsMaxC, sT2, kQsMaxC, C, p.self_ln_g, p.self_ln_b, p.eps);
+    // ---- FFN ----
+    qs_gemv(p.ffn1_wt, p.FF, p.ffn1_b, sT2, kQsMaxC, sH1, kQsMaxW, C, p.FF, true, sPart);
+    qs_gemv(p.ffn2_wt, C, p.ffn2_b, sH1, kQsMaxW, sU, kQsMaxC, p.FF, C, false, sPart);
+    qs_layernorm(sT2, sU, kQsMaxC, sT3, kQsMaxC, C, p.ffn_ln_g, p.ffn_ln_b, p.eps);
+    // ---- prediction head + the next layer's queries ----
+    qs_layernorm(sT3, nullptr, kQsMaxC, sDec, kQsMaxC, C, p.dec_ln_g, p.dec_ln_b, p.eps);
+    qs_gemv(p.cls_wt, p.K1, p.cls_b, sDec, kQsMaxC, sU, kQsMaxC, C, p.K1, false, sPart);
+    for (int e = tid; e < kQsRows * p.K1; e += kQsThreads) {
+        const int r = e / p.K1, c = e - r * p.K1;
+        if (q0 + r < Q) p.cls_out[(size_t)(q0 + r) * p.K1 + c] = sU[r * kQsMaxC + c];
+    }
+    __syncthreads();
+    qs_gemv(p.m1_wt, p.MH, p.m1_b, sDec, kQsMaxC, sH1, kQsMaxW, C, p.MH, true, sPart);
+    qs_gemv(p.m2_wt, p.MH, p.m2_b, sH1, kQsMaxW, sH2, kQsMaxW, p.MH, p.MH, true, sPart);
+    qs_gemv(p.m3_wt, C, p.m3_b, sH2, kQsMaxW, sU, kQsMaxC, p.MH, C, false, sPart);
+    for (int e = tid; e < kQsRows * C; e += kQsThreads) {
+        const int r = e / C, c = e - r * C;
+        const int q = q0 + r;
+        if (q < Q) {
+            p.me_out[(size_t)q * C + c] = sU[r * kQsMaxC + c];
+            p.state_out[(size_t)q * C + c] = sT3[r * kQsMaxC + c];
+        }
+        sA[r * kQsMaxC + c] = sT3[r * kQsMaxC + c] + p.query_pos[(size_t)min(q, Q - 1) * C + c];
+    }
+    __syncthreads();
+    if (p.next_q_wt) {
+        qs_gemv(p.next_q_wt, C, p.next_q_b, sA, kQsMaxC, sU, kQsMaxC, C, C, false, sPart);
+        for (int e = tid; e < kQsRows * C; e += kQsThreads) {
+            const int r = e / C, c = e - r * C;
+            if (q0 + r < Q) p.next_q_out[(size_t)(q0 + r) * C + c] = sU[r * kQsMaxC + c];
+        }
+    }
+}
+
 int att_groups(int64_t n_keys, int *keys_per_wg)
 {
     // ~3 workgroups per CU; ranges are whole LDS tiles
@@ -341,6 +558,40 @@ int eprecon_masked_attention_async(const float *q, int q_stride_head, int q_stri
     EP_LAUNCH_CHECK();
     hipLaunchKernelGGL((masked_attention_reduce_kernel<6>), dim3((unsigned)(n_heads * n_queries)), dim3(64), 0, st,
                        (const float *)p.partial, (const int32_t *)p.allowed, G, n_queries, n_heads, mask_logits_t ? 1 : 0, out);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_decoder_query_side_async(const eprecon_decoder_layer_desc *d, void *stream)
+{
+    if (!d || !d->o_attn || !d->state_in || !d->query_pos || !d->workspace || !d->state_out || !d->cls_out || !d->mask_embed_out ||
+        !d->cross_out_wt || !d->cross_out_b || !d->cross_ln_g || !d->cross_ln_b || !d->self_in_wt || !d->self_in_b || !d->self_out_wt ||
+        !d->self_out_b || !d->self_ln_g || !d->self_ln_b || !d->ffn1_wt || !d->ffn1_b || !d->ffn2_wt || !d->ffn2_b || !d->ffn_ln_g ||
+        !d->ffn_ln_b || !d->dec_ln_g || !d->dec_ln_b || !d->cls_wt || !d->cls_b || !d->m1_wt || !d->m1_b || !d->m2_wt || !d->m2_b ||
+        !d->m3_wt || !d->m3_b || (d->next_q_wt && (!d->next_q_b || !d->next_q_out)))
+        return EPRECON_ERR_ARG;
+    const int Q = d->n_queries, C = d->channels, H = d->n_heads;
+    if (Q <= 0 || Q > kQsMaxQ || C <= 0 || C > kQsMaxC || H <= 0 || H > 8 || C % H || d->ffn_dim <= 0 || d->ffn_dim > kQsThreads ||
+        d->mask_hidden <= 0 || d->mask_hidden > kQsThreads || d->n_class_logits <= 0 || d->n_class_logits > kQsMaxC || 3 * C > kQsThreads)
+        return EPRECON_ERR_UNSUPPORTED;
+    QsParams p;
+    p.Q = Q; p.C = C; p.H = H; p.FF = d->ffn_dim; p.K1 = d->n_class_logits; p.MH = d->mask_hidden;
+    p.o_attn = d->o_attn; p.state_in = d->state_in; p.query_pos = d->query_pos;
+    p.cross_out_wt = d->cross_out_wt; p.cross_out_b = d->cross_out_b; p.cross_ln_g = d->cross_ln_g; p.cross_ln_b = d->cross_ln_b;
+    p.self_in_wt = d->self_in_wt; p.self_in_b = d->self_in_b; p.self_out_wt = d->self_out_wt; p.self_out_b = d->self_out_b;
+    p.self_ln_g = d->self_ln_g; p.self_ln_b = d->self_ln_b;
+    p.ffn1_wt = d->ffn1_wt; p.ffn1_b = d->ffn1_b; p.ffn2_wt = d->ffn2_wt; p.ffn2_b = d->ffn2_b; p.ffn_ln_g = d->ffn_ln_g; p.ffn_ln_b = d->ffn_ln_b;
+    p.dec_ln_g = d->dec_ln_g; p.dec_ln_b = d->dec_ln_b; p.cls_wt = d->cls_wt; p.cls_b = d->cls_b;
+    p.m1_wt = d->m1_wt; p.m1_b = d->m1_b; p.m2_wt = d->m2_wt; p.m2_b = d->m2_b; p.m3_wt = d->m3_wt; p.m3_b = d->m3_b;
+    p.next_q_wt = d->next_q_wt; p.next_q_b = d->next_q_b;
+    p.eps = d->ln_eps;
+    p.state_out = d->state_out; p.cls_out = d->cls_out; p.me_out = d->mask_embed_out; p.next_q_out = d->next_q_out;
+    p.ws = d->workspace;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)ceil_div(Q, kQsRows);
+    hipLaunchKernelGGL(query_side_a_kernel, dim3(grid), dim3(kQsThreads), 0, st, p);
+    EP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(query_side_b_kernel, dim3(grid), dim3(kQsThreads), 0, st, p);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }

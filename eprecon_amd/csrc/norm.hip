@@ -241,7 +241,6 @@ __global__ __launch_bounds__(256) void affine_rows_res_kernel(const float *x, in
 // applies the statistics to its slice of rows.  (Round 3's first version gave ONE wave per channel the whole row list: a 10 us
 // serial chain of Chan merges per workgroup, slower than the separate 5 us finalize launch; here the chain is nblk / G long.)
 constexpr int kFusedMaxBlocks = 512;
-constexpr int kFusedMaxWgs = 256;
 __global__ __launch_bounds__(256) void bn_apply_fused_kernel(const float *x, int n, int C, int ld_x, const float *partial, int nblk,
                                                              const float *gamma, const float *beta, float eps, const float *res,
                                                              int ld_res, const float *res_scale, const float *res_shift, int relu,
@@ -288,9 +287,12 @@ int bn_finalize_apply(const float *x, int64_t n, int channels, int ld_x, const f
                       int relu, float *out, int ld_out, float *mean, float *var, hipStream_t st,
                       const float *res_scale = nullptr, const float *res_shift = nullptr, bool stats_wanted = false)
 {
-    if (nblk <= kFusedMaxBlocks && channels <= 256 && !stats_wanted) {   // (the caller's mean / var outputs need the finalize launch)
-        // short lists: statistics finished by every workgroup of the ONE launch (256 workgroups at most)
-        const int rows_per_wg = (int)max((int64_t)ceil_div(n, (int64_t)kFusedMaxWgs), (int64_t)max(1, 2048 / channels));
+    // short lists: statistics finished by every workgroup of the ONE launch.  ~16 elements per thread; taken only while the
+    // redundant reads of the summaries (every workgroup reads all nblk rows) stay below ~16 MB of L2 traffic — beyond that the
+    // separate 5 us finalize launch is cheaper (measured: with 256 fat workgroups SPVCNN lost 0.2 ms per level)
+    const int64_t wgs = ceil_div(n * channels, (int64_t)4096);
+    if (nblk <= kFusedMaxBlocks && channels <= 256 && !stats_wanted && (int64_t)nblk * channels * 12 * wgs <= (16ll << 20)) {
+        const int rows_per_wg = (int)ceil_div(n, wgs);
         hipLaunchKernelGGL(bn_apply_fused_kernel, dim3((unsigned)ceil_div(n, (int64_t)rows_per_wg)), dim3(256), 0, st, x, (int)n, channels,
                            ld_x, partial, nblk, gamma, beta, eps, residual, ld_res, res_scale, res_shift, relu, out, ld_out, rows_per_wg);
         EP_LAUNCH_CHECK();

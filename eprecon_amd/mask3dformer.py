@@ -217,8 +217,8 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         self.mask_embed = MLP(hidden_dim, hidden_dim * 4, mask_dim, 3)
         # the static-shape query side of every layer replayed from HIP graphs on the GPU inference path
         self.use_hip_graph = __import__("os").environ.get("EPRECON_NO_GRAPH", "0") != "1"
-        # EPRECON_DECODER_FUSED=0: the voxel side of every layer as PyTorch ops (key / value projections, SDPA over a dense
-        # [Q, N] mask) instead of the HIP kernels of csrc/decoder.hip
+        # EPRECON_DECODER_FUSED=0: the decoder on PyTorch ops (key / value projections, SDPA over a dense [Q, N] mask, the query
+        # side replayed from HIP graphs) instead of the HIP kernels of csrc/decoder.hip
         self.use_fused_voxel_side = __import__("os").environ.get("EPRECON_DECODER_FUSED", "1") == "1"
         self._plan = None
         self._plan_params = None
@@ -313,14 +313,92 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         attn = outputs_mask[0] if mask_indices is None else outputs_mask[0].index_select(1, mask_indices)
         return outputs_mask, (attn.sigmoid() < 0.5).detach()
 
-    def _forward_fused(self, plan, panoptic_features, panoptic_coords, mask_features, spitial_shape):
-        """GPU inference: per layer one GEMM for the mask logits (voxel-major: [N_2, Q]), the key / value projections, and the
-        masked attention as ONE split-K flash-attention pass over the level's voxels (csrc/decoder.hip) writing straight
-        into the captured query side's input; the query side is a graph replay.  pred_masks are [1, Q, N_2] VIEWS of the
-        voxel-major logit matrices (same values and shape as the reference's, other strides)."""
+    def _query_side_pack(self, device):
+        """Everything the HIP query side needs, built once per parameter version: every weight matrix transposed to [in][out]
+        (contiguous), the prediction head of the UNTOUCHED queries (static: models/mask3dformer.py:376-381 runs it before the
+        first layer) and the first layer's projected queries."""
+        params = self._plan_params
+        if params is None:
+            params = self._plan_params = list(self.parameters())
+        key = (device, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        pack = getattr(self, "_qs_pack", None)
+        if pack is not None and pack["key"] == key:
+            return pack
+        t = lambda w: w.detach().t().contiguous()
+        v = lambda x: x.detach().contiguous()
+        layers = []
+        for j in range(self.num_layers):
+            ca = self.transformer_cross_attention_layers[j]
+            sa = self.transformer_self_attention_layers[j]
+            ff = self.transformer_ffn_layers[j]
+            c = ca.multihead_attn.embed_dim
+            w = {"cross_out_wt": t(ca.multihead_attn.out_proj.weight), "cross_out_b": v(ca.multihead_attn.out_proj.bias),
+                 "cross_ln_g": v(ca.norm.weight), "cross_ln_b": v(ca.norm.bias),
+                 "self_in_wt": t(sa.self_attn.in_proj_weight), "self_in_b": v(sa.self_attn.in_proj_bias),
+                 "self_out_wt": t(sa.self_attn.out_proj.weight), "self_out_b": v(sa.self_attn.out_proj.bias),
+                 "self_ln_g": v(sa.norm.weight), "self_ln_b": v(sa.norm.bias),
+                 "ffn1_wt": t(ff.linear1.weight), "ffn1_b": v(ff.linear1.bias), "ffn2_wt": t(ff.linear2.weight), "ffn2_b": v(ff.linear2.bias),
+                 "ffn_ln_g": v(ff.norm.weight), "ffn_ln_b": v(ff.norm.bias),
+                 "dec_ln_g": v(self.decoder_norm.weight), "dec_ln_b": v(self.decoder_norm.bias),
+                 "cls_wt": t(self.class_embed.weight), "cls_b": v(self.class_embed.bias)}
+            for i, lin in enumerate(self.mask_embed.layers):
+                w[f"m{i + 1}_wt"], w[f"m{i + 1}_b"] = t(lin.weight), v(lin.bias)
+            if j + 1 < self.num_layers:
+                nxt = self.transformer_cross_attention_layers[j + 1].multihead_attn
+                w["next_q_wt"], w["next_q_b"] = t(nxt.in_proj_weight[:c]), v(nxt.in_proj_bias[:c])
+            layers.append(w)
+        state0 = self.query_feat.weight.detach().unsqueeze(1)
+        qe = self.query_embed.weight.detach().unsqueeze(1)
+        with torch.no_grad():
+            cls0, me0 = self._head_static(state0)
+            q0 = self._project_q(0, state0, qe)
+        ok = (len(self.mask_embed.layers) == 3 and self.decoder_norm.eps == 1e-5 and
+              all(l.norm.eps == 1e-5 for l in self.transformer_ffn_layers))
+        pack = {"key": key, "layers": layers, "cls0": cls0.contiguous(), "me0": me0.contiguous(), "q0": q0, "ok": ok,
+                "state0": self.query_feat.weight.detach().contiguous(), "qpos": self.query_embed.weight.detach().contiguous(),
+                "ffn_dim": self.transformer_ffn_layers[0].linear1.out_features, "n_cls": self.class_embed.out_features,
+                "mask_hidden": self.mask_embed.layers[0].out_features}
+        self._qs_pack = pack
+        return pack
+
+    def _query_side_hip(self, pack, j, o_attn, state, outs, cls_out, ws):
+        """one layer's query side on csrc/decoder.hip (two launches): -> (state, class logits [1, Q, K+1], mask embedding
+        [1, Q, C], next layer's head-split queries | None)"""
+        import ctypes
+        lib = _lib.load()
+        w = pack["layers"][j]
+        q_n, c = state.shape
+        d = _lib.DecoderLayerDesc()
+        d.n_queries, d.channels, d.n_heads = q_n, c, self.num_heads
+        d.ffn_dim, d.n_class_logits, d.mask_hidden = pack["ffn_dim"], pack["n_cls"], pack["mask_hidden"]
+        d.o_attn, d.state_in, d.query_pos = o_attn.data_ptr(), state.data_ptr(), pack["qpos"].data_ptr()
+        for name, tensor in w.items():
+            setattr(d, name, tensor.data_ptr())
+        d.ln_eps = 1e-5
+        d.state_out, d.mask_embed_out, d.cls_out = outs[0].data_ptr(), outs[1].data_ptr(), cls_out.data_ptr()
+        last = "next_q_wt" not in w
+        d.next_q_out = None if last else outs[2].data_ptr()
+        d.workspace = ws.data_ptr()
+        _lib.check(lib.eprecon_decoder_query_side_async(ctypes.byref(d), _lib.current_stream()), "eprecon_decoder_query_side_async")
+        h = self.num_heads
+        q_next = None if last else outs[2].view(q_n, h, c // h).transpose(0, 1).unsqueeze(0)
+        return outs[0], cls_out.unsqueeze(0), outs[1].unsqueeze(0), q_next
+
+    def _forward_fused(self, panoptic_features, panoptic_coords, mask_features, spitial_shape):
+        """GPU inference, every step on csrc/decoder.hip + three GEMMs per layer: the mask logits (voxel-major: [N_2, Q]), the
+        key / value projections, the masked attention as ONE split-K flash-attention pass over the level's voxels, and the
+        query side (static shape) as two launches.  pred_masks of the auxiliary heads are [1, Q, N_2] VIEWS of the voxel-major
+        logit matrices (same values and shape as the reference's, other strides); the final head's are contiguous."""
+        pack = self._query_side_pack(mask_features.device)
         c = self.query_feat.weight.shape[1]
         heads = self.num_heads
+        n_q = self.num_queries
+        dev = mask_features.device
         scale = 1.0 / math.sqrt(c // heads)
+        outs = torch.empty((self.num_layers, 3, n_q, c), dtype=torch.float32, device=dev)
+        cls_all = torch.empty((self.num_layers, n_q, pack["n_cls"]), dtype=torch.float32, device=dev)
+        ws = torch.empty((4, n_q, c), dtype=torch.float32, device=dev)
+        o_attn = torch.empty((1, heads, n_q, c // heads), dtype=torch.float32, device=dev)
         rows = lambda t: t[0].t()                                        # [1, C, N] view of voxel rows -> the rows [N, C]
         src, keys = [], []
         for i in range(self.num_feature_levels):
@@ -336,8 +414,8 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
                      nearest_fine_index(panoptic_coords[1].squeeze(0), fine, 2, as_int32=True), None]
         mf = rows(mask_features)
         mf = mf if mf.is_contiguous() else mf.contiguous()
-        classes, masks = [plan["cls0"].clone()], []
-        me, q = plan["me0"], plan["q0"]
+        classes, masks = [pack["cls0"].clone()], []
+        me, q, state = pack["me0"], pack["q0"], pack["state0"]
         for j in range(self.num_layers):
             lvl = j % self.num_feature_levels
             logits_t = torch.mm(mf, me[0].t())                           # [N_2, Q]: this head's mask logits, voxel-major
@@ -346,11 +424,9 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             w, b = attn.in_proj_weight, attn.in_proj_bias
             k = F.linear(keys[lvl], w[c:2 * c], b[c:2 * c])
             v = F.linear(src[lvl], w[2 * c:], b[2 * c:])
-            step = plan["layers"][j]
-            masked_attention(q, k, v, logits_t, mask_rows[lvl], step["o_in"], scale)
-            step["graph"].replay()
-            classes.append(step["cls"].clone())
-            me, q = step["me"], step["q_next"]
+            masked_attention(q, k, v, logits_t, mask_rows[lvl], o_attn, scale)
+            state, cls, me, q = self._query_side_hip(pack, j, o_attn, state, outs[j], cls_all[j], ws)
+            classes.append(cls)
         # the final head's masks in the reference's own layout ([1, Q, N_2] contiguous): panoptic_post reduces over them
         # row-wise, which crawls on the transposed view (8 ms against 0.2 ms at 56k voxels)
         masks.append(torch.mm(me[0], mf.t()).unsqueeze(0))
@@ -360,9 +436,11 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
     def forward(self, panoptic_features, panoptic_coords, mask_features, spitial_shape):
         """panoptic_features 3 x [1, C, N_l]; panoptic_coords 3 x [1, N_l, 3]; mask_features [1, C, N_2]"""
         if self.use_fused_voxel_side and mask_features.is_cuda and not torch.is_grad_enabled() and mask_features.shape[0] == 1:
-            plan = self._static_plan(mask_features.device)
-            if plan is not None and (self.query_feat.weight.shape[1] // self.num_heads) == 6 and self.num_heads % 2 == 0:
-                return self._forward_fused(plan, panoptic_features, panoptic_coords, mask_features, spitial_shape)
+            c = self.query_feat.weight.shape[1]
+            ffn = self.transformer_ffn_layers[0].linear1.out_features
+            if (c // self.num_heads == 6 and self.num_heads % 2 == 0 and self.num_heads <= 8 and c <= 64 and self.num_queries <= 128
+                    and ffn <= 192 and self.mask_embed.layers[0].out_features <= 192 and self._query_side_pack(mask_features.device)["ok"]):
+                return self._forward_fused(panoptic_features, panoptic_coords, mask_features, spitial_shape)
         pos = self.get_pos_encs(panoptic_coords, spitial_shape)
         src, sizes = [], []
         for i in range(self.num_feature_levels):

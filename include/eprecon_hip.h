@@ -681,6 +681,36 @@ int eprecon_masked_attention_async(const float *q, int q_stride_head, int q_stri
                                    int n_queries, int n_heads, int head_dim, float scale, float *out, void *workspace,
                                    size_t workspace_bytes, void *stream);
 
+/*
+ * Query side of a decoder layer (static shape [Q, C]): out-projection + residual + LayerNorm of the cross-attention whose
+ * per-head output is o_attn (eprecon_masked_attention_async), self-attention over the queries, FFN (post-norm blocks,
+ * models/mask3dformer.py:33-196,399-427), the prediction head's class logits and mask embedding (:429-436) and the NEXT layer's
+ * in-projected queries — two launches instead of ~25.  Every weight matrix is given TRANSPOSED, f32[in][out] row-major
+ * (nn.Linear stores [out][in]); self_in_wt is nn.MultiheadAttention.in_proj_weight transposed: f32[C][3C] with the q | k | v
+ * columns side by side.  workspace: 4 * Q * C floats.  Shapes taken: Q <= 128, C <= 64 with C % H == 0, H <= 8,
+ * ffn_dim / mask_hidden <= 192, n_class_logits <= 64 (EPRECON_ERR_UNSUPPORTED otherwise).
+ */
+typedef struct eprecon_decoder_layer_desc {
+    int n_queries; int channels; int n_heads; int ffn_dim; int n_class_logits; int mask_hidden;
+    const float *o_attn;        /* f32[H][Q][C/H] */
+    const float *state_in;      /* f32[Q][C] queries entering the layer */
+    const float *query_pos;     /* f32[Q][C] */
+    const float *cross_out_wt; const float *cross_out_b; const float *cross_ln_g; const float *cross_ln_b;
+    const float *self_in_wt; const float *self_in_b; const float *self_out_wt; const float *self_out_b;
+    const float *self_ln_g; const float *self_ln_b;
+    const float *ffn1_wt; const float *ffn1_b; const float *ffn2_wt; const float *ffn2_b; const float *ffn_ln_g; const float *ffn_ln_b;
+    const float *dec_ln_g; const float *dec_ln_b; const float *cls_wt; const float *cls_b;
+    const float *m1_wt; const float *m1_b; const float *m2_wt; const float *m2_b; const float *m3_wt; const float *m3_b;
+    const float *next_q_wt; const float *next_q_b;     /* the next layer's cross-attention q in-projection, or NULL */
+    float ln_eps;
+    float *state_out;           /* f32[Q][C] */
+    float *cls_out;             /* f32[Q][n_class_logits] */
+    float *mask_embed_out;      /* f32[Q][C] */
+    float *next_q_out;          /* f32[Q][C] or NULL */
+    float *workspace;
+} eprecon_decoder_layer_desc;
+int eprecon_decoder_query_side_async(const eprecon_decoder_layer_desc *desc, void *stream);
+
 /* x2 bilinear upsampling of channels-last maps, in f32[n,h,w,c] -> out f32[n,2h,2w,c], c % 4 == 0
  * (F.interpolate(scale_factor=2, mode="bilinear") in feat_fusion_pre,
  * models/occupancy_initialization.py:46) */

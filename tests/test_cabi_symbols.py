@@ -67,7 +67,8 @@ def test_operators_refuse_cpu_tensors():
         Back_Project(24)(coords, torch.zeros(1, 3), 0.04, feats, torch.eye(4).expand(9, 1, 4, 4), 0)
 
 
-@pytest.mark.parametrize("c_name,py_name", [("eprecon_conv_desc", "ConvDesc"), ("eprecon_gru_stage_desc", "GruStageDesc")])
+@pytest.mark.parametrize("c_name,py_name", [("eprecon_conv_desc", "ConvDesc"), ("eprecon_gru_stage_desc", "GruStageDesc"),
+                                            ("eprecon_decoder_layer_desc", "DecoderLayerDesc")])
 def test_struct_layouts_match_header(tmp_path, c_name, py_name):
     """the ctypes mirrors of the descriptor structs have the size and field offsets the C compiler gives the header's
     structs (a drift here would silently corrupt every launch that goes through them)"""

@@ -207,3 +207,34 @@ def test_fused_voxel_side_equals_the_dense_path_at_cfg4_size(golden_dir):
     assert float((fused["pred_masks"] - dense["pred_masks"]).abs().max()) < 1e-3
     for a, b in zip(fused["aux_outputs"], dense["aux_outputs"]):
         assert float((a["pred_logits"] - b["pred_logits"]).abs().max()) < 5e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("j", [0, 5])
+def test_query_side_kernels_match_the_torch_modules(j):
+    """csrc/decoder.hip query_side_a / _b against the PyTorch modules they replace (cross-attention out-projection + LN,
+    nn.MultiheadAttention self-attention, FFN, decoder_norm + class / mask embeddings, next layer's projected queries)"""
+    from eprecon_amd.mask3dformer import MultiScaleMaskedTransformerDecoder
+    torch.manual_seed(11 + j)
+    dec = MultiScaleMaskedTransformerDecoder(mask_classification=True, num_classes=20, hidden_dim=48, num_queries=80,
+                                             nheads=8, dim_feedforward=192, dec_layers=6, pre_norm=False, mask_dim=48).cuda()
+    for prm in dec.parameters():                      # biases / LayerNorm parameters away from their 0 / 1 defaults
+        if prm.dim() == 1:
+            prm.data.normal_(0.3, 0.5)
+    o_attn = torch.randn((1, 8, 80, 6), device="cuda")
+    state = torch.randn((80, 48), device="cuda")
+    qe = dec.query_embed.weight.unsqueeze(1)
+    with torch.no_grad():
+        ref_state, ref_cls, ref_me, ref_q = dec._query_side(j, o_attn, state.unsqueeze(1), qe)
+        pack = dec._query_side_pack(state.device)
+        outs = torch.full((3, 80, 48), float("nan"), device="cuda")
+        cls_out = torch.full((80, 21), float("nan"), device="cuda")
+        ws = torch.empty((4, 80, 48), device="cuda")
+        got_state, got_cls, got_me, got_q = dec._query_side_hip(pack, j, o_attn, state, outs, cls_out, ws)
+    assert float((got_state - ref_state[:, 0]).abs().max()) < 2e-5
+    assert float((got_cls - ref_cls).abs().max()) < 5e-5
+    assert float((got_me - ref_me).abs().max()) < 5e-5
+    if j == 5:
+        assert ref_q is None and got_q is None
+    else:
+        assert got_q.shape == ref_q.shape and float((got_q - ref_q).abs().max()) < 5e-5
