@@ -236,68 +236,15 @@ __global__ __launch_bounds__(256) void affine_rows_res_kernel(const float *x, in
     out[(size_t)r * ld_out + c] = v;
 }
 
-// One-launch form for short summary lists: every workgroup merges the <= kFusedMaxBlocks summary rows itself — thread (g, c)
-// rows g, g + G, ... of column c with G = 256 / C row groups working side by side, the G results in order through LDS — and
-// applies the statistics to its slice of rows.  (Round 3's first version gave ONE wave per channel the whole row list: a 10 us
-// serial chain of Chan merges per workgroup, slower than the separate 5 us finalize launch; here the chain is nblk / G long.)
-constexpr int kFusedMaxBlocks = 512;
-__global__ __launch_bounds__(256) void bn_apply_fused_kernel(const float *x, int n, int C, int ld_x, const float *partial, int nblk,
-                                                             const float *gamma, const float *beta, float eps, const float *res,
-                                                             int ld_res, const float *res_scale, const float *res_shift, int relu,
-                                                             float *out, int ld_out, int rows_per_wg)
-{
-    __shared__ float sN[256], sMean[256], sM2[256];
-    const int tid = threadIdx.x;
-    const int G = 256 / C;
-    const int g = tid / C, c = tid - g * C;
-    float a_n = 0.0f, a_mean = 0.0f, a_m2 = 0.0f;
-    if (g < G) {
-        for (int b = g; b < nblk; b += G) {
-            const float *p = partial + (size_t)b * 3 * C;
-            chan_merge(a_n, a_mean, a_m2, p[c], p[C + c], p[2 * C + c]);
-        }
-        sN[tid] = a_n; sMean[tid] = a_mean; sM2[tid] = a_m2;
-    }
-    __syncthreads();
-    if (tid < C) {   // (g == 0) the G group results in order
-        for (int gg = 1; gg < G; ++gg) chan_merge(a_n, a_mean, a_m2, sN[gg * C + tid], sMean[gg * C + tid], sM2[gg * C + tid]);
-        const float var = a_n > 0.0f ? a_m2 / a_n : 0.0f;   // biased variance
-        sN[tid] = a_mean;
-        sMean[tid] = 1.0f / sqrtf(var + eps);
-    }
-    __syncthreads();
-    const int r0 = blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, n);
-    const int total = (r1 - r0) * C;
-    for (int e = tid; e < total; e += 256) {
-        const int r = r0 + e / C, cc = e % C;
-        float v = (x[(size_t)r * ld_x + cc] - sN[cc]) * sMean[cc];
-        v = v * (gamma ? gamma[cc] : 1.0f) + (beta ? beta[cc] : 0.0f);
-        if (res) {
-            float rv = res[(size_t)r * ld_res + cc];
-            if (res_scale) rv = fmaf(rv, res_scale[cc], res_shift[cc]);
-            v += rv;
-        }
-        if (relu) v = fmaxf(v, 0.0f);
-        out[(size_t)r * ld_out + cc] = v;
-    }
-}
-
+// (One-launch forms for short summary lists — every workgroup finishing the statistics itself before applying them — were
+// measured twice and removed: round 3 with one wave per channel (a 10 us serial chain of Chan merges per workgroup), round 4
+// with 256 / C row groups merging side by side and the launch limited to ~16 MB of redundant summary reads: SPVCNN still lost
+// 0.1-0.18 ms per level against the separate 5 us finalize launch, gpurun r04_c / r04_d.)
 int bn_finalize_apply(const float *x, int64_t n, int channels, int ld_x, const float *partial, int nblk,
                       const float *gamma, const float *beta, float eps, const float *residual, int ld_res,
                       int relu, float *out, int ld_out, float *mean, float *var, hipStream_t st,
-                      const float *res_scale = nullptr, const float *res_shift = nullptr, bool stats_wanted = false)
+                      const float *res_scale = nullptr, const float *res_shift = nullptr)
 {
-    // short lists: statistics finished by every workgroup of the ONE launch.  ~16 elements per thread; taken only while the
-    // redundant reads of the summaries (every workgroup reads all nblk rows) stay below ~16 MB of L2 traffic — beyond that the
-    // separate 5 us finalize launch is cheaper (measured: with 256 fat workgroups SPVCNN lost 0.2 ms per level)
-    const int64_t wgs = ceil_div(n * channels, (int64_t)4096);
-    if (nblk <= kFusedMaxBlocks && channels <= 256 && !stats_wanted && (int64_t)nblk * channels * 12 * wgs <= (16ll << 20)) {
-        const int rows_per_wg = (int)ceil_div(n, wgs);
-        hipLaunchKernelGGL(bn_apply_fused_kernel, dim3((unsigned)ceil_div(n, (int64_t)rows_per_wg)), dim3(256), 0, st, x, (int)n, channels,
-                           ld_x, partial, nblk, gamma, beta, eps, residual, ld_res, res_scale, res_shift, relu, out, ld_out, rows_per_wg);
-        EP_LAUNCH_CHECK();
-        return EPRECON_OK;
-    }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(channels), dim3(256), 0, st, partial, nblk, channels, mean, var);
     EP_LAUNCH_CHECK();
     const size_t total = (size_t)n * channels;
@@ -345,7 +292,7 @@ int eprecon_batchnorm_train_async(const float *x, int64_t n, int channels, int l
     hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(256), 0, st, x, (int)n, channels, ld_x, partial);
     EP_LAUNCH_CHECK();
     return bn_finalize_apply(x, n, channels, ld_x, partial, nblk, gamma, beta, eps, residual, ld_res, relu, out,
-                             ld_out, mean, var, st, nullptr, nullptr, mean_out || var_out);
+                             ld_out, mean, var, st);
 }
 
 size_t eprecon_batchnorm_apply_workspace_bytes(int channels)
@@ -373,7 +320,7 @@ int eprecon_batchnorm_apply_partials_async(const float *x, int64_t n, int channe
     ws += align_up((size_t)channels * sizeof(float), 256);
     float *var = var_out ? var_out : reinterpret_cast<float *>(ws);
     return bn_finalize_apply(x, n, channels, ld_x, partial, (int)nblk, gamma, beta, eps, residual, ld_res, relu,
-                             out, ld_out, mean, var, (hipStream_t)stream, nullptr, nullptr, mean_out || var_out);
+                             out, ld_out, mean, var, (hipStream_t)stream);
 }
 
 int eprecon_batchnorm_apply_partials_res_async(const float *x, int64_t n, int channels, int ld_x, const float *partial,

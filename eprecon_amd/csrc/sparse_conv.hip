@@ -1826,8 +1826,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 
     // packed layout (pack_weights_kernel, NT = 2): float4 index ((cb * K + k) * nch8 + chunk) * 128 + (half * 2 + t) * 32 + col
     const float4 *wq4 = reinterpret_cast<const float4 *>(p.wq);
+    // Offsets none of the workgroup's 128 rows has a neighbour at are skipped (no slab staged, no gathers, no MFMAs): ConvGRU's
+    // second gate convolution runs on a voxel set without a single adjacent pair (the already scaled coordinates divided by
+    // the resolution again, models/modules.py:216-217) — 26 of its 27 offsets are dead for every row.
+    __shared__ int sLiveK[32];
+    __syncthreads();   // sNbr / sAff are written
+    int nlive = 0;
+    for (int kk = 0; kk < nk; ++kk) {
+        const int any = __syncthreads_or(tid < kWideRows && sNbr[kk * kWideRows + tid] >= 0);
+        if (any) {
+            if (tid == 0) sLiveK[nlive] = kk;
+            ++nlive;
+        }
+    }
+    __syncthreads();
     auto slab_src = [&](int st, int e) -> const float4 * {
-        const int kk = st / nslab, sl = st - kk * nslab;
+        const int kl = st / nslab, sl = st - kl * nslab;
+        const int kk = sLiveK[kl];
         const int cb = e >> 9, i = e & 511;
         const int chunk = min(4 * sl + (i >> 7), nch8 - 1);   // (a chunk past C_in multiplies zeros)
         return wq4 + ((size_t)(cb * p.K + k0 + kk) * nch8 + chunk) * 128 + (i & 127);
@@ -1837,22 +1852,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         int j, c0;
     };
     auto fetch_a = [&](int st, StageA &g) {
-        const int kk = st / nslab, sl = st - kk * nslab;
+        const int kl = st / nslab, sl = st - kl * nslab;
+        const int kk = sLiveK[kl];
         g.c0 = sl * 32;
         g.j = sNbr[kk * kWideRows + wave * 32 + r32];
         const float *xrow = p.x + (size_t)max(g.j, 0) * p.ld_x;
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) g.a[ch] = *reinterpret_cast<const float4 *>(xrow + min(g.c0 + ch * 8 + 4 * half, cinA - 4));
     };
-    const int nst = nk * nslab;
-    __syncthreads();   // sNbr / sAff are written
+    const int nst = nlive * nslab;
     static_assert(kWideSlabF4 == 4 * 256, "four float4 of a slab per thread");
     StageA cur, nxt;
-    {
+    if (nst > 0) {
         const float4 s0 = *slab_src(0, tid), s1 = *slab_src(0, tid + 256), s2 = *slab_src(0, tid + 512), s3 = *slab_src(0, tid + 768);
         sB[tid] = s0; sB[tid + 256] = s1; sB[tid + 512] = s2; sB[tid + 768] = s3;
+        fetch_a(0, cur);
     }
-    fetch_a(0, cur);
     for (int st = 0; st < nst; ++st) {
         const int stn = min(st + 1, nst - 1);
         // (named values, not an array: the array form was kept on the stack — scratch stores behind vmcnt waits in the loop)

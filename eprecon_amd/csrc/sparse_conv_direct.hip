@@ -139,6 +139,22 @@ __device__ __forceinline__ void direct_epilogue(const ConvParams &p, f32x4 (&acc
     }
 }
 
+// The offsets at which at least one of a wave's 32 rows (lane l16 looks at rows l16 and 16 + l16 of the wave: `nbr_lane` points
+// at its first row's column of the staged neighbour table, pitch `rows` per offset) has a neighbour -> live[0 .. n) in
+// ascending order, written by lane 0; returns n (wave-uniform).  K <= 32.  The caller publishes the list with a barrier.
+__device__ __forceinline__ int live_offsets(const int *nbr_lane, int K, int rows, unsigned char *live, int lane)
+{
+    int n = 0;
+    for (int k = 0; k < K; ++k) {
+        const bool any = nbr_lane[k * rows] >= 0 || nbr_lane[k * rows + 16] >= 0;
+        if (__ballot(any) != 0ull) {
+            if (lane == 0) live[n] = (unsigned char)k;
+            ++n;
+        }
+    }
+    return n;
+}
+
 // chunks per stage for a layer of KCH chunks: the stages of an offset are KCH / G
 constexpr int stage_chunks(int kch) { return kch % 3 == 0 ? 3 : (kch % 2 == 0 ? 2 : 1); }
 
@@ -152,6 +168,7 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
     int *sNbr = reinterpret_cast<int *>(smem);                        // [K][ROWS]
     float *sStat = reinterpret_cast<float *>(sNbr + p.K * ROWS);      // [4 waves][3][16 CT]
     float *sAff = sStat + kWaves * 3 * 16 * CT;                       // [2][cpad]
+    unsigned char *sLive = reinterpret_cast<unsigned char *>(sAff + 2 * cpad);   // [4 waves][32] live offsets of a wave\'s 32 rows
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, q = lane >> 4;
@@ -170,6 +187,13 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
             sAff[cpad + c] = c < p.Cin ? p.in_shift[c] : 0.0f;
         }
     __syncthreads();
+    // Offsets none of the wave's 32 rows has a neighbour at are skipped altogether (no gathers, no weight loads, no MFMAs):
+    // an output-stationary kernel otherwise multiplies zeros for every missing neighbour.  On the surface-shaped sets of a
+    // fragment 12-25 % of the (32-row, offset) groups are dead; on the second voxelisation of ConvGRU's convr — already
+    // scaled coordinates divided by the resolution again, models/modules.py:216-217: no two voxels are adjacent — 26 of the
+    // 27 offsets are (profiles/r04/conv_tile_liveness.txt).
+    const int n_live = live_offsets(sNbr + wave * 16 * RT + l16, p.K, ROWS, sLive + wave * 32, lane);
+    __syncthreads();
 
     f32x4 acc[RT][CT];
 #pragma unroll
@@ -179,7 +203,8 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
     const unsigned row_bytes = (unsigned)p.ld_x * 4u, oob = (unsigned)p.x_bytes;
-    const int U = p.K * PARTS;                      // stages
+    const int U = n_live * PARTS;                   // stages: (live offset, part)
+    const unsigned char *myLive = sLive + wave * 32;
     constexpr unsigned kChunkBytes = (unsigned)CT * 1024u;
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wq16), 0, (int)((unsigned)p.K * KCH * kChunkBytes), 0x00020000);
@@ -198,8 +223,9 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
     };
     // stage u = (offset k = u / PARTS, chunks kc0 .. kc0 + G - 1 with kc0 = (u % PARTS) * G)
     auto fetch = [&](int u, Stage &g) {
-        const int k = PARTS == 1 ? u : u / PARTS;
-        const int part = PARTS == 1 ? 0 : u - k * PARTS;
+        const int kl = PARTS == 1 ? u : u / PARTS;
+        const int part = PARTS == 1 ? 0 : u - kl * PARTS;
+        const int k = __builtin_amdgcn_readfirstlane((int)myLive[kl]);   // (wave-uniform: the weight offset below is a scalar)
         const unsigned xs = 64u * (unsigned)(part * G);                 // (scalar) byte offset of the stage's first chunk
         const unsigned ws = (unsigned)(k * KCH + part * G) * kChunkBytes;
         const bool has_last = part == PARTS - 1;                         // (uniform) the stage holds the layer's last chunk
@@ -225,8 +251,9 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
             }
     };
     auto consume = [&](int u, const Stage &g) {
-        const int k = PARTS == 1 ? u : u / PARTS;
-        const int part = PARTS == 1 ? 0 : u - k * PARTS;
+        const int kl = PARTS == 1 ? u : u / PARTS;
+        const int part = PARTS == 1 ? 0 : u - kl * PARTS;
+        const int k = __builtin_amdgcn_readfirstlane((int)myLive[kl]);
         const bool has_last = part == PARTS - 1;
 #pragma unroll
         for (int i = 0; i < G; ++i) {
@@ -285,7 +312,7 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
             }
         }
     };
-    if (!(p.debug & 1)) {
+    if (!(p.debug & 1) && U > 0) {
         Stage s_a, s_b;
         fetch(0, s_a);
         for (int u = 0; u < U; u += 2) {
@@ -314,6 +341,7 @@ __global__ __launch_bounds__(256) void spconv_direct16_generic_kernel(ConvParams
     float *sStat = reinterpret_cast<float *>(sNbr + p.K * ROWS);      // [4 waves][3][16 CT]
     const int cpad = 16 * kch;
     float *sAff = sStat + kWaves * 3 * 16 * CT;                       // [2][cpad]
+    unsigned char *sLive = reinterpret_cast<unsigned char *>(sAff + 2 * cpad);   // [4 waves][32]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, q = lane >> 4;
@@ -332,6 +360,9 @@ __global__ __launch_bounds__(256) void spconv_direct16_generic_kernel(ConvParams
             sAff[cpad + c] = c < p.Cin ? p.in_shift[c] : 0.0f;
         }
     __syncthreads();
+    const int n_live = live_offsets(sNbr + wave * 16 * RT + l16, p.K, ROWS, sLive + wave * 32, lane);   // (see the template kernel)
+    __syncthreads();
+    const unsigned char *myLive = sLive + wave * 32;
 
     f32x4 acc[RT][CT];
 #pragma unroll
@@ -341,10 +372,10 @@ __global__ __launch_bounds__(256) void spconv_direct16_generic_kernel(ConvParams
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
     const unsigned row_bytes = (unsigned)p.ld_x * 4u, oob = (unsigned)p.x_bytes;
-    const int S = p.K * kch;                       // (offset, chunk) steps
+    const int S = n_live * kch;                    // (live offset, chunk) steps
     const unsigned step_bytes = (unsigned)CT * 1024u;
     const __amdgpu_buffer_rsrc_t wrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wq16), 0, (int)((unsigned)S * step_bytes), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wq16), 0, (int)((unsigned)p.K * kch * step_bytes), 0x00020000);
     const unsigned wlane = (unsigned)lane * 16u;
     const int *myNbr = sNbr + wave * 16 * RT + l16;
     const unsigned cq = 16u * (unsigned)q;         // byte offset of this lane's four channels inside a chunk
@@ -362,7 +393,8 @@ __global__ __launch_bounds__(256) void spconv_direct16_generic_kernel(ConvParams
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int s = min(s0 + i, S - 1);
-            const int k = s / kch, kc = s - k * kch;
+            const int kl = s / kch, kc = s - kl * kch;
+            const int k = __builtin_amdgcn_readfirstlane((int)myLive[kl]);
             const bool t8 = tail8 && kc == kch - 1;                         // (uniform)
             const unsigned cbytes = 64u * (unsigned)kc + (t8 ? cq >> 1 : cq);
             const bool cok = 16 * kc + (t8 ? 2 : 4) * q < p.Cin;
@@ -377,7 +409,7 @@ __global__ __launch_bounds__(256) void spconv_direct16_generic_kernel(ConvParams
             }
 #pragma unroll
             for (int t = 0; t < CT; ++t) {
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + (unsigned)t * 1024u, (unsigned)s * step_bytes, 0);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + (unsigned)t * 1024u, (unsigned)(k * kch + kc) * step_bytes, 0);
                 g.b[i][t] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
             }
         }
@@ -435,7 +467,7 @@ __global__ __launch_bounds__(256) void spconv_direct16_generic_kernel(ConvParams
             }
         }
     };
-    if (!(p.debug & 1)) {
+    if (!(p.debug & 1) && S > 0) {
         Stage s_a, s_b;
         fetch(0, s_a);
         for (int s0 = 0; s0 < S; s0 += 2 * G) {
@@ -455,7 +487,7 @@ __global__ __launch_bounds__(256) void spconv_direct16_generic_kernel(ConvParams
 template <int CT, int KCH>
 int launch_k(const ConvParams &p, hipStream_t st)
 {
-    const size_t lds = (size_t)p.K * kDirectRows * sizeof(int) + (size_t)kWaves * 3 * 16 * CT * sizeof(float) + (size_t)2 * 16 * KCH * sizeof(float);
+    const size_t lds = (size_t)p.K * kDirectRows * sizeof(int) + (size_t)kWaves * 3 * 16 * CT * sizeof(float) + (size_t)2 * 16 * KCH * sizeof(float) + kWaves * 32;
     // (one chunk per stage — 80 registers, six waves per SIMD instead of three — measured no faster: 266 vs 250 us on 48 -> 24)
     hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH>), dim3((unsigned)ceil_div(p.n_out, kDirectRows)), dim3(256), lds, st, p);
     EP_LAUNCH_CHECK();
@@ -475,7 +507,7 @@ int launch_ct(const ConvParams &p, hipStream_t st)
         case 6: return launch_k<CT, 6>(p, st);
         default: break;
     }
-    const size_t lds = (size_t)p.K * kDirectRows * sizeof(int) + (size_t)kWaves * 3 * 16 * CT * sizeof(float) + (size_t)2 * 16 * kch * sizeof(float);
+    const size_t lds = (size_t)p.K * kDirectRows * sizeof(int) + (size_t)kWaves * 3 * 16 * CT * sizeof(float) + (size_t)2 * 16 * kch * sizeof(float) + kWaves * 32;
     hipLaunchKernelGGL((spconv_direct16_generic_kernel<CT>), dim3((unsigned)ceil_div(p.n_out, kDirectRows)), dim3(256), lds, st, p, kch);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;

@@ -322,3 +322,33 @@ def test_medium_list_wide_kernel(n, cin, cout):
     y2, _ = SP.conv_stats(dev(x), dev(w), nbr_d, in_affine=(dev(sc), dev(sh), True))
     ref2 = OS.sparse_conv(np.maximum(x * sc + sh, 0), nbr, w)
     assert np.abs(y2.cpu().numpy() - ref2).max() < TOL
+
+
+@pytest.mark.parametrize("n,cin,cout,kernel", [(41003, 48, 24, "spconv_direct16_kernel"), (30011, 140, 16, "spconv_direct16_kernel"),
+                                               (9415, 192, 96, "spconv_wide_kernel"), (12000, 96, 48, "spconv_direct16_kernel")])
+def test_dead_offsets_are_skipped_not_multiplied(n, cin, cout, kernel):
+    """voxel sets whose kernel maps are mostly / entirely -1: (a) no two voxels adjacent — ConvGRU's second gate convolution
+    runs on such a set (already scaled coordinates divided by the resolution again, models/modules.py:216-217): only the centre
+    offset is live and the kernels skip the other 26 —, (b) thin sheets two voxels thick, where whole 32-row groups miss the
+    out-of-plane offsets.  Same results as the oracle that sums over the live pairs only."""
+    from eprecon_amd import sparse as SP
+    rng = np.random.default_rng(n + cin)
+    side = int(np.ceil(n ** (1 / 3))) + 1
+    g = np.stack(np.meshgrid(np.arange(side), np.arange(side), np.arange(side), indexing="ij"), -1).reshape(-1, 3)
+    iso = g[rng.permutation(len(g))[:n]] * 3                        # spacing 3: no neighbours at all
+    sheet = np.stack(np.meshgrid(np.arange(2), np.arange(120), np.arange(max(n // 240, 2)), indexing="ij"), -1).reshape(-1, 3)
+    for xyz in (iso, sheet[:n]):
+        c = np.concatenate([np.zeros((len(xyz), 1), np.int64), xyz], 1).astype(np.int32)
+        x = rng.standard_normal((len(c), cin)).astype(np.float32)
+        w = (rng.standard_normal((27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        vs = SP.VoxelSet(dev(c))
+        nbr = OS.kernel_map(c, c, 3, 1)
+        (y, part), name = _last_conv_kernel((27, cin, cout, 1), lambda: SP.sparse_conv_fused(dev(x), dev(w), vs.kernel_map(3), dev(b),
+                                                                                             bn_partial=True))
+        if xyz is iso:
+            assert (nbr >= 0).sum() == len(c)                       # the centre offset only
+        assert name == kernel
+        ref = OS.sparse_conv(x, nbr, w, b)
+        assert np.abs(y.cpu().numpy() - ref).max() < TOL
+        assert float(part[:, 0, 0].sum()) == len(c)
