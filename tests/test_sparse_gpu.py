@@ -324,8 +324,8 @@ def test_medium_list_wide_kernel(n, cin, cout):
     assert np.abs(y2.cpu().numpy() - ref2).max() < TOL
 
 
-@pytest.mark.parametrize("n,cin,cout,kernel", [(41003, 48, 24, "spconv_direct16_kernel"), (30011, 140, 16, "spconv_direct16_kernel"),
-                                               (9415, 192, 96, "spconv_wide_kernel"), (12000, 96, 48, "spconv_direct16_kernel")])
+@pytest.mark.parametrize("n,cin,cout,kernel", [(41003, 48, 24, "spconv_direct16_kernel"), (50021, 140, 16, "spconv_direct16_kernel"),
+                                               (9415, 192, 96, "spconv_wide_kernel"), (12000, 96, 48, "spconv_splitk_kernel")])
 def test_dead_offsets_are_skipped_not_multiplied(n, cin, cout, kernel):
     """voxel sets whose kernel maps are mostly / entirely -1: (a) no two voxels adjacent — ConvGRU's second gate convolution
     runs on such a set (already scaled coordinates divided by the resolution again, models/modules.py:216-217): only the centre

@@ -11,4 +11,4 @@ timeout 600 python tools/profile_cfg4_stages.py 3 > $O/cfg4_stage_times.txt 2>&1
 tail -24 $O/cfg4_stage_times.txt
 EPRECON_CFG4_PIPELINE=0 timeout 600 python bench.py --workload cfg4 --steps 16 --warmup 8 > $O/bench_cfg4_unpipelined.json 2> $O/bench_cfg4_unpipelined.err
 tail -1 $O/bench_cfg4_unpipelined.json | cut -c1-200
-python tools/conv_tile_liveness.py > $O/conv_tile_liveness.txt 2>&1; tail -12 $O/conv_tile_liveness.txt
+
