@@ -23,7 +23,8 @@ def tocuda(obj, device):
     if isinstance(obj, torch.Tensor):
         return obj.to(device)
     if isinstance(obj, dict):
-        return {k: tocuda(v, device) for k, v in obj.items()}
+        # (keys ending in _host are the caller's host-side copies — the volume origins GRUFusion reads on the host — and stay there)
+        return {k: (v if isinstance(k, str) and k.endswith("_host") else tocuda(v, device)) for k, v in obj.items()}
     if isinstance(obj, (list, tuple)) and obj and not isinstance(obj[0], str):
         return [tocuda(v, device) for v in obj]
     return obj
@@ -55,7 +56,12 @@ class NeuralRecon(nn.Module):
 
     def forward(self, inputs, save_mesh=False, training=True):
         dev = self.pixel_mean.device
+        # the data loader builds the volume origins on the host (datasets/transforms.py:250-260): GRUFusion's scene
+        # bookkeeping reads them there instead of synchronising the device once per fragment
+        host = {k + "_host": inputs[k] for k in ("vol_origin", "vol_origin_partial")
+                if torch.is_tensor(inputs.get(k)) and not inputs[k].is_cuda and k + "_host" not in inputs}
         inputs = tocuda(inputs, dev)
+        inputs.update(host)
         outputs = {}
         imgs = torch.unbind(inputs["imgs"], 1)
         if torch.is_grad_enabled() or not self.batch_views:
