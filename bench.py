@@ -67,14 +67,15 @@ def parse():
 
 
 def cpu_baseline(step, seconds):
-    """The same step on the host cores with the CPU oracle (`kind` = "port": oracle/c/*.c is a
-    C + OpenMP port of the reference's back-projection, oracle/*.py numpy ports of the sparse
-    layers; the 2D fusion convolutions run as the same PyTorch modules on CPU threads).
-    Bounded sample: whole steps are repeated until about `seconds` of wall time are spent."""
+    """The same step on the host cores (`kind` = "port"): oracle/c/*.c, a C + OpenMP port of the reference's back-projection;
+    the spconv layers as PyTorch-CPU gather -> matmul -> index_add_ per kernel offset (oracle/torch_cpu.py: the shape the
+    reference's own CPU path would take); the 2D fusion convolutions as the same PyTorch modules on the CPU threads; the stage-0
+    selection in numpy.  Protocol (SURVEY.md 8d with one warm-up step instead of three: a step takes about a second): whole
+    steps until `seconds` are spent and at least 5 are done (10 at most); the MEDIAN step is reported, with its per-stage split."""
     import torch
     from oracle import back_project as O
     from oracle import grid_ops as OG
-    from oracle import occupancy_init as OI
+    from oracle import torch_cpu as TC
     from eprecon_amd import synthetic as S
     from eprecon_amd.fragment_step import LEVELS
 
@@ -88,10 +89,10 @@ def cpu_baseline(step, seconds):
     net = Occupancy_Initialization(CH_IMG, CH_INIT_DOWN, N_VIEWS)   # same weights, on the host
     net.load_state_dict({k: v.detach().cpu() for k, v in step.init_net.state_dict().items()})
     net.train()
-    sd = {k: v.numpy() for k, v in net.state_dict().items()}
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
     f_init = [[t.cpu() for t in view] for view in step.features_init]
-    # one thread budget for all three CPU engines (OpenMP oracle, torch, numpy BLAS): more than
-    # ~64 threads only adds fork/join overhead on these sizes
+    # one thread budget for all CPU engines (OpenMP oracle, torch, numpy BLAS): more than ~64 threads only adds fork / join
+    # overhead on these sizes
     threads = min(64, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     O.set_threads(threads)
@@ -99,29 +100,41 @@ def cpu_baseline(step, seconds):
     blas_limit = threadpool_limits(limits=threads)
 
     def one_step():
+        t = [time.perf_counter()]
+        lap = lambda: t.append(time.perf_counter())
         with torch.no_grad():
-            fused = net.feat_fusion_pre(torch.stack([f[2][0] for f in f_init]),
-                                        torch.stack([f[1][0] for f in f_init]),
+            fused = net.feat_fusion_pre(torch.stack([f[2][0] for f in f_init]), torch.stack([f[1][0] for f in f_init]),
                                         torch.stack([f[0][0] for f in f_init])).unsqueeze(1).numpy()
-        r = O.back_project(coords[2], origin, w["voxel_size"], fused, kr[1], 2, O.MODE_VARIANCE)
-        logit = OI.sparse_stack(sd, r["feats"], r["coords"], 2)
+            lap()
+            r = O.back_project(coords[2], origin, w["voxel_size"], fused, kr[1], 2, O.MODE_VARIANCE)
+            lap()
+            pairs = TC.kernel_map_pairs(r["coords"], 2)
+            lap()
+            logit = TC.sparse_stack(sd, torch.from_numpy(r["feats"]), pairs).numpy()
+            lap()
         OG.init_select(logit, r["coords"], 1)
+        lap()
         for _, lvl, interval, mv in LEVELS:
             O.back_project(coords[interval], origin, w["voxel_size"], feats[lvl], kr[lvl], mv)
+            lap()
+        names = ["fusion2d_torch_cpu", "variance_back_project_c_omp", "kernel_map_numpy", "sparse_stack_torch_cpu", "init_select_numpy",
+                 "bp24_c_omp", "bp48_c_omp", "bp96_c_omp"]
+        return t[-1] - t[0], {n: (b_ - a_) * 1e3 for n, a_, b_ in zip(names, t[:-1], t[1:])}
 
     one_step()
-    n, t0 = 0, time.perf_counter()
-    while n < 1 or time.perf_counter() - t0 < seconds:
-        one_step()
-        n += 1
+    runs, t0 = [], time.perf_counter()
+    while len(runs) < 5 or (len(runs) < 10 and time.perf_counter() - t0 < seconds):
+        runs.append(one_step())
     dt = time.perf_counter() - t0
     blas_limit.restore_original_limits()
-    return {"value": n / dt, "unit": "fragments/s", "cores": threads, "kind": "port",
-            "sample": f"{n} whole steps of the same workload (same window, seed {step.seed}) in {dt:.1f} s",
-            "ms_per_step": dt / n * 1e3,
-            "protocol": "1 warm-up step, then whole steps repeated for a bounded wall time (mean); C + OpenMP "
-                        "back-projection, numpy sparse layers, PyTorch-CPU 2D convolutions; not the 3-warm-up / "
-                        "median-of-10 PyTorch-CPU protocol of SURVEY.md 8d (one step takes seconds)"}
+    runs.sort(key=lambda r: r[0])
+    med, stages = runs[len(runs) // 2]
+    return {"value": 1.0 / med, "unit": "fragments/s", "cores": threads, "kind": "port",
+            "sample": f"{len(runs)} whole steps of the same workload (same window, seed {step.seed}) in {dt:.1f} s, median step",
+            "ms_per_step": med * 1e3, "stages_ms": {k: round(v, 1) for k, v in stages.items()},
+            "protocol": "1 warm-up step, then 5-10 whole steps, median (SURVEY.md 8d's protocol with one warm-up instead of "
+                        "three); C + OpenMP back-projection, PyTorch-CPU sparse layers (gather / matmul / index_add_ per "
+                        "offset) and 2D convolutions, numpy kernel map and stage-0 selection"}
 
 
 def _conv_roofline_record(lib, ms, rows, name, kvol, cin, cout, what):

@@ -50,6 +50,8 @@ class NeuralRecon(nn.Module):
         self.init_overlap_count = 0
         self.loss_weights = list(getattr(cfg, "LW", LOSS_WEIGHTS))
         self.batch_views = True   # False: always the reference's per-view backbone loop
+        self.two_backbone_streams = True
+        self._side = None
 
     def normalizer(self, x):
         return (x - self.pixel_mean.type_as(x)) / self.pixel_std.type_as(x)
@@ -72,8 +74,23 @@ class NeuralRecon(nn.Module):
             # inference: the 9 views as ONE channels-last batch per backbone (per-view BatchNorm statistics, so the
             # values are those of the loop above); the maps feed the back-projection without a re-layout
             norm = [self.normalizer(img) for img in imgs]
-            features_backbone2d = self.backbone2d.forward_views(norm)
-            features_occ_pano = self.backbone_occ_pano.forward_views(norm)
+            if dev.type == "cuda" and self.two_backbone_streams:
+                # the two backbones are independent networks on the same images: the second one is queued on its own
+                # stream (their late, low-resolution layers leave most of the chip idle on their own)
+                main = torch.cuda.current_stream(dev)
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=dev)
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    features_occ_pano = self.backbone_occ_pano.forward_views(norm)
+                features_backbone2d = self.backbone2d.forward_views(norm)
+                main.wait_stream(self._side)
+                for view in features_occ_pano:      # allocated on the side stream, consumed on the main stream
+                    for t in view:
+                        t.record_stream(main)
+            else:
+                features_backbone2d = self.backbone2d.forward_views(norm)
+                features_occ_pano = self.backbone_occ_pano.forward_views(norm)
         outputs, loss_dict = self.neucon_net(features_backbone2d, features_occ_pano, inputs, outputs,
                                              only_train_init=self.only_train_init, only_train_occ=self.only_train_occ,
                                              init_overlap_count=self.init_overlap_count)

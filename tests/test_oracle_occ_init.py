@@ -87,3 +87,29 @@ def test_feat_fusion_pre_matches_reference(gold):
     ref = gold["fusion_pre_out"]
     assert y.shape == ref.shape
     assert np.abs(y - ref).max() < 1e-4, np.abs(y - ref).max()
+
+
+def test_torch_cpu_sparse_stack_equals_the_numpy_oracle():
+    """oracle/torch_cpu.py (what bench.py's cpu_baseline times for the spconv layers: gather -> matmul -> index_add_ per
+    offset on the torch CPU threads) against the numpy restatement of the same wiring (oracle/occupancy_init.py)"""
+    import torch
+    from eprecon_amd.config import CH_IMG, CH_INIT_DOWN, N_VIEWS
+    from eprecon_amd.occupancy_initialization import Occupancy_Initialization
+    from oracle import occupancy_init as OI
+    from oracle import torch_cpu as TC
+    torch.manual_seed(5)
+    net = Occupancy_Initialization(CH_IMG, CH_INIT_DOWN, N_VIEWS).train()
+    for prm in net.parameters():
+        if prm.dim() == 1:
+            prm.data.normal_(0.5, 0.3)
+    sd_t = {k: v.detach() for k, v in net.state_dict().items()}
+    sd_n = {k: v.numpy() for k, v in sd_t.items()}
+    rng = np.random.default_rng(3)
+    g = np.stack(np.meshgrid(np.arange(14), np.arange(12), np.arange(10), indexing="ij"), -1).reshape(-1, 3) * 2
+    g = g[rng.random(len(g)) < 0.8]
+    coords = np.concatenate([np.zeros((len(g), 1), np.int64), g], 1).astype(np.int32)
+    var = rng.standard_normal((len(coords), 32)).astype(np.float32)
+    ref = OI.sparse_stack(sd_n, var, coords, 2)
+    with torch.no_grad():
+        got = TC.sparse_stack(sd_t, torch.from_numpy(var), TC.kernel_map_pairs(coords, 2)).numpy()
+    assert got.shape == ref.shape and np.abs(got - ref).max() < 2e-4
