@@ -314,7 +314,15 @@ def bench_cfg5(device, rank, world, dist, steps=8, warmup=4):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t[0].item())
     xch = step.net.gru_fusion._xchg
+    # what every rank put on the wire (rows and bytes of its packed boundary payloads, per fragment): makes a scaling curve
+    # interpretable — a rank that waits in the payload all-gather waits for the LARGEST of these
+    mine = torch.tensor([float(xch.rows_sent), float(xch.bytes_sent)] if xch is not None else [0.0, 0.0], dtype=torch.float64, device=device)
+    per_rank = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(per_rank, mine)
+    n_frag = steps + warmup
     return {"cfg5_fragments_per_sec": world * steps / elapsed, "cfg5_ms_per_step": elapsed / steps * 1e3,
+            "cfg5_exchange_rows_per_fragment_by_rank": [round(float(v[0]) / n_frag, 1) for v in per_rank],
+            "cfg5_exchange_bytes_per_fragment_by_rank": [round(float(v[1]) / n_frag, 1) for v in per_rank],
             "cfg5_steps": steps, "cfg5_early_returns_max_over_ranks": int(t[1].item()),
             "cfg5_collectives_per_fragment": (xch.collectives / (steps + warmup)) if xch is not None else 0,
             "cfg5_workload": f"{world} ranks x 1 fragment per step of one scene (fragments dealt round-robin), whole "

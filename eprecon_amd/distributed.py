@@ -132,6 +132,7 @@ class BoundaryExchange:
         self.stamps = [self.new_stamps(s) for s in range(n_scales)]
         self.collectives = 0        # issued so far (tests / bench reporting)
         self.rows_sent = 0          # payload rows this rank contributed so far
+        self.bytes_sent = 0         # ... and their size in the packed payload (4 + C floats per row)
 
     def new_stamps(self, scale):
         return _Stamps(self.device, max(self.extent >> (self.n_scales - 1 - scale), 32))
@@ -165,6 +166,7 @@ class BoundaryExchange:
             g.pack_boundary(payload[off:], n)
             off += n * widths[s]
         self.rows_sent += sum(all_counts[rank])
+        self.bytes_sent += 4 * sizes[rank]
         bufs = [torch.empty_like(payload) for _ in range(world)]
         dist.all_gather(bufs, payload, group=self.group)                               # collective 3
         self.collectives += 1

@@ -1,11 +1,13 @@
-"""CPU, world_size 2, gloo: the boundary-voxel exchange of the multi-GPU schedule (N > 1 path).
+"""CPU, world sizes 2 and 4, gloo: the boundary-voxel exchange of the multi-GPU schedule (N > 1 path).
 
 1. stateless one-scale form: after the exchange each rank's map restricted to its FBV equals the un-sharded
    union of all maps restricted to that FBV (lower rank wins duplicates); voxels outside are untouched.
 2. the stateful protocol GRUFusion uses (distributed.BoundaryExchange, three scales packed into three collectives
    per fragment): two ranks stream overlapping fragments of one scene through exchange -> local fusion ->
    stamp; each rank's maps (coordinates AND features) must equal a single-process simulation of the same
-   "independent windows + exchange" schedule: newest fusion result wins, received voxels are not re-broadcast."""
+   "independent windows + exchange" schedule: newest fusion result wins, received voxels are not re-broadcast.
+3. world size 4 with UNEVEN per-rank voxel counts (occupancy 10 % ... 40 %) and a rank whose fragments lie far from everybody
+   else's: it sends nothing and receives nothing, yet takes part in every collective (the schedule must not desynchronise)."""
 import os
 import socket
 
@@ -31,13 +33,20 @@ CH = [5, 3, 2]
 STEPS = 4
 
 
-def fragment(rank, step, scale):
-    """(fbv origin int[3], current voxels int32[n,3] scene grid, features f32[n,C]) of fragment step*2+rank"""
-    f = step * 2 + rank
-    rng = np.random.default_rng(1000 * scale + f)
+def fragment(rank, step, scale, world=2):
+    """(fbv origin int[3], current voxels int32[n,3] scene grid, features f32[n,C]) of fragment step*world+rank.
+    world 4: the ranks' fragments differ in size (occupancy 10 / 20 / 30 / 40 %) and the last rank works far away from the others"""
+    f = step * world + rank
+    rng = np.random.default_rng(1000 * scale + f + 7919 * (world - 2))
     d = DIMS[scale]
     lo = np.array([f * d // 3, (f % 2) * (d // 4), 0])         # consecutive fragments overlap by ~2/3
-    occ = rng.random((d, d, d)) < 0.3
+    fill = 0.3
+    if world == 4:
+        lo[0] = f * d // 6                                     # ~5/6: a rank's last fragment reaches into two neighbours' volumes
+        fill = 0.1 * (rank + 1)
+        if rank == 3:
+            lo = lo + np.array([0, 40 * d, 0])                 # no overlap with any other rank's volume, ever
+    occ = rng.random((d, d, d)) < fill
     xyz = np.argwhere(occ) + lo
     return lo, xyz.astype(np.int32), rng.standard_normal((len(xyz), CH[scale])).astype(np.float32)
 
@@ -55,33 +64,40 @@ def toy_fuse(map_c, map_f, lo, d, cur_c, cur_f):
     return (np.concatenate([map_c[~inside], upd]), np.concatenate([map_f[~inside], fused.astype(np.float32)]), upd)
 
 
-def simulate_schedule():
-    """single-process oracle of the 2-rank schedule -> per rank, per scale {coord: feature}"""
-    maps = [[(np.zeros((0, 3), np.int32), np.zeros((0, CH[s]), np.float32)) for s in range(3)] for _ in range(2)]
-    stamps = [[{} for _ in range(3)] for _ in range(2)]           # coord -> (stamp, local)
+def simulate_schedule(world=2):
+    """single-process oracle of the `world`-rank schedule -> (per rank, per scale {coord: feature}, rows sent per rank)"""
+    maps = [[(np.zeros((0, 3), np.int32), np.zeros((0, CH[s]), np.float32)) for s in range(3)] for _ in range(world)]
+    stamps = [[{} for _ in range(3)] for _ in range(world)]           # coord -> (stamp, local)
+    rows_sent = [0] * world
+    inside = lambda k, lo, d: all(lo[a] <= k[a] < lo[a] + d for a in range(3))
     for step in range(STEPS):
-        frs = [[fragment(r, step, s) for s in range(3)] for r in range(2)]
-        sent = [[None] * 3 for _ in range(2)]
-        for r in range(2):                                         # what each rank sends (pre-exchange state)
-            for s in range(3):
+        frs = [[fragment(r, step, s, world) for s in range(3)] for r in range(world)]
+        sent = [[None] * 3 for _ in range(world)]
+        for r in range(world):                                     # what each rank sends (pre-exchange state): its own
+            for s in range(3):                                     # fusion results inside ANY other rank's volume
                 c, f = maps[r][s]
-                lo_o = frs[1 - r][s][0]
                 out = []
                 for k, row in zip(c.tolist(), f):
                     st = stamps[r][s].get(tuple(k), (-1, False))
-                    if st[1] and all(lo_o[a] <= k[a] < lo_o[a] + DIMS[s] for a in range(3)):
+                    if st[1] and any(inside(k, frs[o][s][0], DIMS[s]) for o in range(world) if o != r):
                         out.append((tuple(k), st[0], row))
                 sent[r][s] = out
-        for r in range(2):                                         # receive: newer wins, absent appended
-            for s in range(3):
+                rows_sent[r] += len(out)
+        for r in range(world):                                     # receive: newest copy per voxel, newer than local wins,
+            for s in range(3):                                     # absent voxels are appended
                 c, f = maps[r][s]
                 lo = frs[r][s][0]
+                best = {}
+                for o in range(world):
+                    if o == r:
+                        continue
+                    for k, st, row in sent[o][s]:
+                        if inside(k, lo, DIMS[s]) and (k not in best or st > best[k][0]):
+                            best[k] = (st, row)
                 index = {tuple(k): i for i, k in enumerate(c.tolist())}
                 f = f.copy()
                 add_c, add_f = [], []
-                for k, st, row in sent[1 - r][s]:
-                    if not all(lo[a] <= k[a] < lo[a] + DIMS[s] for a in range(3)):
-                        continue
+                for k, (st, row) in best.items():
                     if k in index:
                         if st > stamps[r][s].get(k, (-1, False))[0]:
                             f[index[k]] = row
@@ -94,14 +110,14 @@ def simulate_schedule():
                     c = np.concatenate([c, np.array(add_c, np.int32)])
                     f = np.concatenate([f, np.stack(add_f)])
                 maps[r][s] = (c, f)
-        for r in range(2):                                         # local fusion + stamping
+        for r in range(world):                                     # local fusion + stamping
             for s in range(3):
                 lo, cc, cf = frs[r][s]
                 c, f, upd = toy_fuse(*maps[r][s], lo, DIMS[s], cc, cf)
                 maps[r][s] = (c, f)
                 for k in upd.tolist():
-                    stamps[r][s][tuple(k)] = (step * 2 + r, True)
-    return [[{tuple(k): row for k, row in zip(c.tolist(), f)} for c, f in maps[r]] for r in range(2)]
+                    stamps[r][s][tuple(k)] = (step * world + r, True)
+    return [[{tuple(k): row for k, row in zip(c.tolist(), f)} for c, f in maps[r]] for r in range(world)], rows_sent
 
 
 def _worker(rank, world, port, q):
@@ -116,7 +132,7 @@ def _worker(rank, world, port, q):
     ex = D.BoundaryExchange(3, torch.device("cpu"))
     maps = [(torch.zeros((0, 3), dtype=torch.int32), torch.zeros((0, CH[s]))) for s in range(3)]
     for step in range(STEPS):
-        frs = [fragment(rank, step, s) for s in range(3)]
+        frs = [fragment(rank, step, s, world) for s in range(3)]
         maps = ex.exchange(maps, [fr[0].tolist() for fr in frs], DIMS)
         for s in range(3):
             lo_s, cc, cf = frs[s]
@@ -129,24 +145,33 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.fixture(scope="module")
-def world2():
+def _run_world(world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
-    for _ in range(2):
-        item = q.get(timeout=180)
+    for _ in range(world):
+        item = q.get(timeout=240)
         res[item[0]] = item[1:]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     return res
+
+
+@pytest.fixture(scope="module")
+def world2():
+    return _run_world(2)
+
+
+@pytest.fixture(scope="module")
+def world4():
+    return _run_world(4)
 
 
 def test_boundary_exchange_world2(world2):
@@ -168,7 +193,7 @@ def test_boundary_exchange_world2(world2):
 
 def test_fragment_streams_match_the_schedule_oracle(world2):
     """coordinates and FEATURES of every rank's maps after 4 steps of exchange -> fuse -> stamp"""
-    expect = simulate_schedule()
+    expect, _ = simulate_schedule()
     refreshed = 0
     for r in range(2):
         maps, collectives = world2[r][3], world2[r][4]
@@ -192,3 +217,38 @@ def simulate_no_exchange():
         lo, cc, cf = fragment(0, step, 2)
         c, f, _ = toy_fuse(c, f, lo, DIMS[2], cc, cf)
     return {tuple(k): row for k, row in zip(c.tolist(), f)}
+
+
+def test_four_ranks_uneven_counts_and_a_silent_rank(world4):
+    """world size 4: per-rank voxel counts differ by 4x, rank 3 never overlaps anybody (it sends nothing and receives
+    nothing) and still issues the same three collectives per fragment as the others; every rank's maps equal the
+    single-process simulation of the schedule"""
+    expect, rows_sent = simulate_schedule(4)
+    assert rows_sent[3] == 0 and min(rows_sent[:3]) > 0 and len(set(rows_sent[:3])) == 3     # a silent rank, uneven senders
+    sizes = []
+    for r in range(4):
+        maps, collectives = world4[r][3], world4[r][4]
+        assert collectives == 3 * STEPS
+        for s in range(3):
+            got = {tuple(k): row for k, row in zip(maps[s][0].tolist(), maps[s][1])}
+            assert len(got) == len(maps[s][0]) and set(got) == set(expect[r][s])
+            for k, row in got.items():
+                assert np.array_equal(row, expect[r][s][k]), (r, s, k)
+        sizes.append(sum(len(m[0]) for m in maps))
+    assert sizes[0] < sizes[2]                                         # (the uneven fill really shows in the maps)
+    # the silent rank's maps are exactly what it would have fused alone
+    alone = simulate_alone(3, 4)
+    for s in range(3):
+        got = {tuple(k): row for k, row in zip(world4[3][3][s][0].tolist(), world4[3][3][s][1])}
+        assert set(got) == set(alone[s]) and all(np.array_equal(got[k], alone[s][k]) for k in got)
+
+
+def simulate_alone(rank, world):
+    out = []
+    for s in range(3):
+        c, f = np.zeros((0, 3), np.int32), np.zeros((0, CH[s]), np.float32)
+        for step in range(STEPS):
+            lo, cc, cf = fragment(rank, step, s, world)
+            c, f, _ = toy_fuse(c, f, lo, DIMS[s], cc, cf)
+        out.append({tuple(k): row for k, row in zip(c.tolist(), f)})
+    return out

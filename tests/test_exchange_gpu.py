@@ -126,8 +126,11 @@ def test_update_stamps_the_rows_it_appends_and_compaction_keeps_the_others():
     assert np.all(s[outside.sum():] == 42) and len(s) == outside.sum() + updated.shape[0]
 
 
-def test_two_virtual_ranks_follow_the_simulated_schedule(monkeypatch):
-    """BoundaryExchange.exchange_handles at WORLD SIZE 2 on one GPU: two threads stand in for two ranks (a fake
+@pytest.mark.parametrize("world", [2, 4])
+def test_virtual_ranks_follow_the_simulated_schedule(monkeypatch, world):
+    """BoundaryExchange.exchange_handles at WORLD SIZE 2 and 4 on one GPU (4: uneven per-rank voxel counts and a rank that never
+    overlaps anybody — it sends and receives nothing but takes every collective, and the all-counts-zero skip of the payload
+    all-gather is taken by all ranks or none): threads stand in for the ranks (a fake
     `torch.distributed` shuttles their all-gathers through a mailbox), each with its own three map handles, streaming four
     overlapping fragments per rank through exchange -> crop_union -> fuse -> update.  Every rank's maps (coordinates AND
     features) must equal the single-process simulation of the "independent windows + exchange" schedule that the gloo test
@@ -138,7 +141,6 @@ def test_two_virtual_ranks_follow_the_simulated_schedule(monkeypatch):
     from eprecon_amd.gru_fusion import gather_rows
     from test_distributed_cpu import CH, DIMS, STEPS, fragment, simulate_schedule
 
-    world = 2
     dev = torch.device("cuda", 0)
 
     class FakeDist:
@@ -173,7 +175,7 @@ def test_two_virtual_ranks_follow_the_simulated_schedule(monkeypatch):
             ex = D.BoundaryExchange(3, dev)
             gmaps = [GlobalMap(CH[s], dev) for s in range(3)]
             for step in range(STEPS):
-                frs = [fragment(rank, step, s) for s in range(3)]
+                frs = [fragment(rank, step, s, world) for s in range(3)]
                 ex.exchange_handles(gmaps, [fr[0].tolist() for fr in frs], DIMS)
                 for s in range(3):
                     lo, cc, cf = frs[s]
@@ -203,8 +205,12 @@ def test_two_virtual_ranks_follow_the_simulated_schedule(monkeypatch):
     for t in threads:
         t.join(timeout=120)
     assert not errors, errors
-    want = simulate_schedule()
-    assert sum(results[r][2] for r in range(world)) > 0          # (in this stream only the later fragment's rank has rows to send)
+    want, rows_sent = simulate_schedule(world)
+    assert sum(results[r][2] for r in range(world)) > 0          # (world 2: only the later fragment's rank has rows to send)
+    assert [results[r][2] for r in range(world)] == rows_sent    # every rank sent exactly the rows the schedule says
+    if world == 4:
+        assert rows_sent[3] == 0 and len(set(rows_sent)) == 4    # a silent rank, three uneven senders
+    assert len({results[r][1] for r in range(world)}) == 1       # the same number of collectives on every rank
     for r in range(world):
         maps, collectives, sent = results[r]
         assert 2 * STEPS < collectives <= 3 * STEPS                # the payload all-gather ran whenever somebody had rows
