@@ -520,8 +520,11 @@ bool direct16_ok(const ConvParams &p)
 {
     const char *e = getenv("EPRECON_CONV_DIRECT");
     if (e && e[0] == '0') return false;
-    // 3x3x3 kernel maps, and the 3x3 pixel maps of the dense 2D stack (the caller packs the weights only where it wants them)
-    if ((p.K != 27 && p.K != 9) || !p.nbr || !p.wq16 || (reinterpret_cast<uintptr_t>(p.wq16) & 15) != 0) return false;
+    // 3x3x3 kernel maps, the 3x3 pixel maps of the dense 2D stack, and point-wise layers on long lists (K = 1, identity map: a
+    // streaming [N, C_in] x [C_in, C_out] product) — the caller packs the weights only where it wants this kernel
+    const bool pointwise = p.K == 1 && !p.nbr;
+    if (!pointwise && ((p.K != 27 && p.K != 9) || !p.nbr)) return false;
+    if (!p.wq16 || (reinterpret_cast<uintptr_t>(p.wq16) & 15) != 0) return false;
     if (p.Cout > 64 || p.accumulate) return false;
     if (p.ld_x % 4 != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0 || (p.Cin % 4 != 0 && p.ld_x < ((p.Cin + 3) & ~3))) return false;
     if (p.x_bytes <= 0 || p.x_bytes >= 0x7fffffffll || (int64_t)p.ld_x * 4 >= (1 << 24) || p.x_bytes / ((int64_t)p.ld_x * 4) >= (1 << 24))

@@ -163,11 +163,13 @@ def packed_weight(weight):
     return hit[1]
 
 
-def packed_weight16(weight):
-    """`weight` f32[27, Cin, Cout <= 64] in the operand order of the 16x16x4 MFMA kernels (16-row tile kernel, direct gather
-    kernel), packed once per weight version"""
-    hit = getattr(weight, "_d3_pack16", None)
-    tag = (weight._version, weight.data_ptr())
+def packed_weight16(weight, owner=None):
+    """`weight` f32[K, Cin, Cout <= 64] in the operand order of the 16x16x4 MFMA kernels (16-row tile kernel, direct gather
+    kernel), packed once per weight version.  owner: the tensor OBJECT the packing is cached on when `weight` is a transient
+    view of it (a [Cin, Cout] matrix unsqueezed to K = 1)"""
+    owner = weight if owner is None else owner
+    hit = getattr(owner, "_d3_pack16", None)
+    tag = (owner._version, owner.data_ptr(), tuple(weight.shape))
     if hit is None or hit[0] != tag or hit[1].device != weight.device:
         lib = _lib.load()
         kvol, cin, cout = weight.shape
@@ -176,7 +178,7 @@ def packed_weight16(weight):
         _lib.check(lib.eprecon_conv_pack_weight16_async(_lib.ptr(w), kvol, cin, cout, _lib.ptr(packed), _lib.current_stream()),
                    "eprecon_conv_pack_weight16_async")
         hit = (tag, packed)
-        weight._d3_pack16 = hit
+        owner._d3_pack16 = hit
     return hit[1]
 
 
@@ -220,9 +222,14 @@ def clear_packed_weights(module):
                 delattr(m, attr)
 
 
-def _resolve_map(nbr, x, weight, desc, accumulate=False, ln=False, stats=False):
+# point-wise layers (K = 1) on lists at least this long take the direct kernel too (a streaming [N, C_in] x [C_in, C_out <= 64]
+# product: csrc/sparse_conv_direct.hip); shorter lists are launch-bound on any kernel
+K1_DIRECT_MIN_ROWS = int(os.environ.get("EPRECON_CONV_K1_DIRECT_MIN_ROWS", "20000"))
+
+
+def _resolve_map(nbr, x, weight, desc, accumulate=False, ln=False, stats=False, owner=None):
     """nbr: None (identity), an int32[K, N] kernel map, or a DenseMap -> fills the map fields of `desc`; returns the
-    objects that must stay alive until the launch is queued"""
+    objects that must stay alive until the launch is queued.  owner: the caller's weight object (packings are cached on it)"""
     if isinstance(nbr, DenseMap):
         kvol, cin, cout = weight.shape
         kind = nbr.kind(x, cin, cout, accumulate, ln, stats) if kvol == 27 else 0
@@ -239,6 +246,11 @@ def _resolve_map(nbr, x, weight, desc, accumulate=False, ln=False, stats=False):
         nbr = nbr.vset.kernel_map(3)
     desc.nbr = None if nbr is None else nbr.data_ptr()
     keep = [nbr]
+    if nbr is None and weight.shape[0] == 1 and weight.shape[2] <= DIRECT_MAX_COUT and not accumulate and x.is_cuda \
+            and x.shape[0] >= K1_DIRECT_MIN_ROWS:
+        pw = packed_weight16(weight, owner)
+        desc.packed_weight16 = pw.data_ptr()
+        keep.append(pw)
     if nbr is not None and weight.shape[0] == 27 and weight.shape[2] <= DIRECT_MAX_COUT \
             and not accumulate and x.is_cuda:
         # long lists: the direct gather kernel takes its B operands pre-packed (csrc/sparse_conv.hip, spconv_direct16_kernel);
@@ -342,14 +354,16 @@ def sparse_conv(x, weight, nbr=None, bias=None, out=None, relu=False, accumulate
     """out[i] (op)= bias + sum_k x[nbr[k][i]] @ weight[k].  weight f32[K, Cin, Cout] (or [Cin, Cout]
     with nbr None: a per-voxel linear layer).  x / out may be column slices of wider buffers."""
     lib = _lib.load()
+    w_owner = weight
     if weight.dim() == 2:
         weight = weight.unsqueeze(0)
     kvol, cin, cout = weight.shape
     weight = weight.contiguous()
     n_out = x.shape[0] if nbr is None else nbr.shape[1]
     assert x.shape[1] == cin and x.dtype == torch.float32
-    if isinstance(nbr, DenseMap) or (kvol == 27 and nbr is not None and x.is_cuda):
-        return sparse_conv_fused(x, weight, nbr, bias, out, relu, None, accumulate)[0]
+    if isinstance(nbr, DenseMap) or (kvol == 27 and nbr is not None and x.is_cuda) or \
+            (kvol == 1 and nbr is None and x.is_cuda and cout <= DIRECT_MAX_COUT and not accumulate and n_out >= K1_DIRECT_MIN_ROWS):
+        return sparse_conv_fused(x, w_owner, nbr, bias, out, relu, None, accumulate)[0]
     if nbr is not None:
         assert nbr.dtype == torch.int32 and nbr.shape[0] == kvol and nbr.is_contiguous()
     if out is None:
@@ -368,14 +382,16 @@ def sparse_conv_fused(x, weight, nbr=None, bias=None, out=None, relu=False, resi
     bn_partial, the per-workgroup BatchNorm summaries f32[ceil(n/128), 3, cout] of the stored values.
     Returns (out, partial or None)."""
     lib = _lib.load()
+    w_owner = weight
     if weight.dim() == 2:
         weight = weight.unsqueeze(0)
     kvol, cin, cout = weight.shape
     weight = weight.contiguous()
     n_out = x.shape[0] if nbr is None else nbr.shape[1]
     assert x.shape[1] == cin and x.dtype == torch.float32
-    if isinstance(nbr, DenseMap) or (kvol == 27 and nbr is not None and x.is_cuda):   # descriptor entry point
-        if not isinstance(nbr, DenseMap):
+    k1_direct = kvol == 1 and nbr is None and x.is_cuda and cout <= DIRECT_MAX_COUT and not accumulate and n_out >= K1_DIRECT_MIN_ROWS
+    if isinstance(nbr, DenseMap) or (kvol == 27 and nbr is not None and x.is_cuda) or k1_direct:   # descriptor entry point
+        if nbr is not None and not isinstance(nbr, DenseMap):
             assert nbr.dtype == torch.int32 and nbr.shape[0] == kvol and nbr.is_contiguous()
         if out is None:
             out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
@@ -390,7 +406,7 @@ def sparse_conv_fused(x, weight, nbr=None, bias=None, out=None, relu=False, resi
             d.residual, d.ld_res = residual.data_ptr(), _ld(residual)
         d.out, d.ld_out = out.data_ptr(), _ld(out)
         d.relu, d.accumulate = int(relu), int(accumulate)
-        keep = _resolve_map(nbr, x, weight, d, accumulate=accumulate, stats=bn_partial)
+        keep = _resolve_map(nbr, x, weight, d, accumulate=accumulate, stats=bn_partial, owner=w_owner)
         keep.append(_attach_workspace(d, x.device))
         partial = None
         if bn_partial:
@@ -422,6 +438,7 @@ def sparse_conv_ln(x, weight, nbr, bias, ln_weight, ln_bias, ln_eps, out=None, r
     """conv + bias [+ReLU] [+residual] -> row-wise LayerNorm [-> ReLU] in ONE launch (descriptor entry point):
     the spconv + LayerNorm blocks of the reference without a second pass over the tensor."""
     lib = _lib.load()
+    w_owner = weight
     if weight.dim() == 2:
         weight = weight.unsqueeze(0)
     kvol, cin, cout = weight.shape
@@ -433,7 +450,7 @@ def sparse_conv_ln(x, weight, nbr, bias, ln_weight, ln_bias, ln_eps, out=None, r
     d = _lib.ConvDesc()
     d.x, d.n_in, d.ld_x = x.data_ptr(), x.shape[0], _ld(x)
     d.kvol, d.n_out = kvol, n_out
-    keep = _resolve_map(nbr, x, weight, d, ln=True)  # noqa: F841  (alive until the launch is queued)
+    keep = _resolve_map(nbr, x, weight, d, ln=True, owner=w_owner)  # noqa: F841  (alive until the launch is queued)
     d.weight, d.cin, d.cout = weight.data_ptr(), cin, cout
     d.bias = None if bias is None else bias.data_ptr()
     if residual is not None:
@@ -467,6 +484,7 @@ def conv_stats(x, weight, nbr=None, in_affine=None, out=None, bias=None):
     (descriptor entry point: any kernel of the family may be chosen).  in_affine = (scale, shift, relu): the
     producer's pending BatchNorm applied while gathering.  Returns (out, partial)."""
     lib = _lib.load()
+    w_owner = weight
     if weight.dim() == 2:
         weight = weight.unsqueeze(0)
     kvol, cin, cout = weight.shape
@@ -478,7 +496,7 @@ def conv_stats(x, weight, nbr=None, in_affine=None, out=None, bias=None):
     d = _lib.ConvDesc()
     d.x, d.n_in, d.ld_x = x.data_ptr(), x.shape[0], _ld(x)
     d.kvol, d.n_out = kvol, n_out
-    keep = _resolve_map(nbr, x, weight, d, stats=True)  # noqa: F841
+    keep = _resolve_map(nbr, x, weight, d, stats=True, owner=w_owner)  # noqa: F841
     d.weight, d.cin, d.cout = weight.data_ptr(), cin, cout
     d.bias = None if bias is None else bias.data_ptr()
     d.out, d.ld_out = out.data_ptr(), _ld(out)

@@ -352,3 +352,45 @@ def test_dead_offsets_are_skipped_not_multiplied(n, cin, cout, kernel):
         ref = OS.sparse_conv(x, nbr, w, b)
         assert np.abs(y.cpu().numpy() - ref).max() < TOL
         assert float(part[:, 0, 0].sum()) == len(c)
+
+
+@pytest.mark.parametrize("cin,cout", [(48, 48), (48, 24), (8, 32), (74, 8), (32, 24), (192, 64)])
+def test_pointwise_layers_on_long_lists_take_the_direct_kernel(monkeypatch, cin, cout):
+    """K = 1 (a per-voxel Linear: SConv3d's skip, SPVCNN's 1x1 convolutions and point MLPs, the fused heads) on a long list:
+    the direct kernel as a streaming [N, C_in] x [C_in, C_out] product, with the epilogues those layers use, against the
+    oracle and against the kernels short lists stay on"""
+    from eprecon_amd import sparse as SP
+    monkeypatch.setattr(SP, "K1_DIRECT_MIN_ROWS", 1000)
+    rng = np.random.default_rng(cin * 7 + cout)
+    n = 50021
+    x = rng.standard_normal((n, cin)).astype(np.float32)
+    w = (rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((n, cout)).astype(np.float32)
+    cp = (cin + 3) & ~3
+    buf = torch.full((n, cp + 4), float("nan"), device="cuda")        # a column slice of a wider buffer, ragged channel counts padded
+    buf[:, :cin] = dev(x)
+    dx, dw, db = buf[:, :cin], dev(w), dev(b)
+    ref = x @ w + b
+    (y, part), name = _last_conv_kernel((1, cin, cout, 1), lambda: SP.sparse_conv_fused(dx, dw, None, db, relu=True, residual=dev(res),
+                                                                                        bn_partial=True))
+    assert name == "spconv_direct16_kernel"
+    want = np.maximum(ref, 0) + res
+    assert np.abs(y.cpu().numpy() - want).max() < TOL
+    part = part.cpu().numpy().astype(np.float64)
+    assert part.shape[0] == (n + 127) // 128 and part[:, 0, 0].sum() == n
+    tot_mean = (part[:, 0] * part[:, 1]).sum(0) / n
+    assert np.abs(tot_mean - want.mean(0)).max() < 1e-4
+    # plain call (bias only) through sparse_conv, the producer's pending BatchNorm on load, LayerNorm epilogue
+    assert np.abs(SP.sparse_conv(dx, dw, None, db).cpu().numpy() - ref).max() < TOL
+    sc, sh = rng.uniform(0.5, 1.5, cin).astype(np.float32), rng.standard_normal(cin).astype(np.float32)
+    y2, _ = SP.conv_stats(dx, dw, None, in_affine=(dev(sc), dev(sh), True))
+    assert np.abs(y2.cpu().numpy() - np.maximum(x * sc + sh, 0) @ w).max() < TOL
+    g, be = rng.standard_normal(cout).astype(np.float32), rng.standard_normal(cout).astype(np.float32)
+    yl = SP.sparse_conv_ln(dx, dw, None, db, dev(g), dev(be), 1e-5, post_relu=True)
+    assert np.abs(yl.cpu().numpy() - OS.layernorm_rows(ref, g, be, 1e-5, None, False, True)).max() < TOL
+    # the short-list kernels give the same values
+    monkeypatch.setattr(SP, "K1_DIRECT_MIN_ROWS", 10 ** 9)
+    y_old, name_old = _last_conv_kernel((1, cin, cout, 1), lambda: SP.sparse_conv(dx, dw, None, db))
+    assert name_old != "spconv_direct16_kernel"
+    assert np.abs(y_old.cpu().numpy() - ref).max() < TOL

@@ -65,7 +65,7 @@ for k, (n, t) in per_stage.items():
 print("\n# top kernels per stage (launches, ms per fragment)")
 for k in per_stage:
     print(f"[{k}]")
-    for kn, (n, t) in sorted(kernels[k].items(), key=lambda kv: -kv[1][1])[:12]:
+    for kn, (n, t) in sorted(kernels[k].items(), key=lambda kv: -kv[1][1])[:40]:
         print(f"    {n / nf:6.1f} {t / nf / 1e3:7.3f}  {kn}")
 print("\n# convolution launches of the last fragment: stage | rows K Cin Cout | kernel | us")
 a, b = frags[-1]
