@@ -141,10 +141,14 @@ def _conv_roofline_record(lib, ms, rows, name, kvol, cin, cout, what):
     """one armed launch of the gather-GEMM family -> the roofline record; live kernel-map pairs are counted by the
     library on the launch stream right behind the timed launch (eprecon_profile_conv_pairs)"""
     pairs = int(lib.eprecon_profile_conv_pairs())
+    issued = int(lib.eprecon_profile_conv_executed_pairs())      # (the direct kernel skips dead offsets per 32 rows)
+    if issued <= 0:
+        issued = rows * kvol
     t = float(np.mean(ms))
     flops = 2.0 * pairs * cin * cout
     return {"bound": "mfma", "kernel": f"{name.decode()} ({what}, {rows} voxels)", "flops": flops,
-            "executed_flops": 2.0 * rows * kvol * cin * cout, "live_pairs": pairs, "avg_launch_ms": t,
+            "executed_flops": 2.0 * issued * cin * cout, "executed_over_live": issued / max(pairs, 1),
+            "output_stationary_flops": 2.0 * rows * kvol * cin * cout, "live_pairs": pairs, "avg_launch_ms": t,
             "achieved": flops / (t * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
             "frac": flops / (t * 1e-3) / 1e12 / F32_MFMA_PEAK_TF}
 

@@ -117,6 +117,7 @@ SIGNATURES = {
     "eprecon_profile_conv_arm": (_i, [_i, _i, _i, _i64]),
     "eprecon_profile_conv_ms": (_f, [_c.POINTER(_i64), _c.POINTER(_c.c_char_p)]),
     "eprecon_profile_conv_pairs": (_i64, []),
+    "eprecon_profile_conv_executed_pairs": (_i64, []),
     "eprecon_profile_last_conv_kernel": (_c.c_char_p, []),
     "eprecon_profile_mark_async": (_i, [_i, _vp]),
     "eprecon_conv_desc_workspace_bytes": (_sz, [_vp]),

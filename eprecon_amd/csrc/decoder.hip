@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64) void masked_attention_reduce_kernel(const float
 // fp32 round-off.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kQsRows = 2;        // query rows per workgroup
-constexpr int kQsThreads = 192;   // >= the widest layer (ffn_dim, mask_hidden)
+constexpr int kQsThreads = 384;   // >= the widest layer (ffn_dim, mask_hidden); the narrow layers split their sum over 384 / N parts
 constexpr int kQsMaxC = 64;       // channels (one wave holds a row for the LayerNorms)
 
 // y[r][n] = [relu]( bias[n] + sum_k x[r][k] * wt[k][n] ) for the workgroup's rows; x / y in LDS (row pitch ldx / ldy), wt [K][N]
@@ -299,10 +299,19 @@ __device__ __forceinline__ void qs_gemv(const float *__restrict__ wt, int ldw, c
     for (int r = 0; r < kQsRows; ++r) acc[r] = 0.0f;
     if (part < parts) {
         const int k0 = part * kchunk, k1 = min(K, k0 + kchunk);
-        for (int k = k0; k < k1; ++k) {
-            const float w = wt[(size_t)k * ldw + n];
+        // eight weights in flight per thread (the chain of L2 latencies, not the arithmetic, is what a layer costs); the sum
+        // itself runs k-ascending as before
+        constexpr int U = 8;
+        for (int k = k0; k < k1; k += U) {
+            float w[U];
 #pragma unroll
-            for (int r = 0; r < kQsRows; ++r) acc[r] = fmaf(sx[r * ldx + k], w, acc[r]);
+            for (int i = 0; i < U; ++i) w[i] = k + i < k1 ? wt[(size_t)(k + i) * ldw + n] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < U; ++i)
+                if (k + i < k1) {
+#pragma unroll
+                    for (int r = 0; r < kQsRows; ++r) acc[r] = fmaf(sx[r * ldx + k + i], w[i], acc[r]);
+                }
         }
         if (parts > 1) {
 #pragma unroll
@@ -400,6 +409,7 @@ __global__ __launch_bounds__(kQsThreads) void query_side_b_kernel(QsParams p)
     __shared__ float sT3[kQsRows * kQsMaxC], sDec[kQsRows * kQsMaxC], sQ[kQsRows * kQsMaxC];
     __shared__ float sH1[kQsRows * kQsMaxW], sH2[kQsRows * kQsMaxW], sPart[kQsThreads * kQsRows];
     __shared__ float sS[kQsRows * 8 * kQsMaxQ];     // scores / probabilities [row][head][key]  (H <= 8)
+    __shared__ float sKV[kQsMaxQ * kQsMaxC];        // every query's self-attention keys, then values ([Q][C], 20 KB at 80 x 48)
     const int tid = threadIdx.x, C = p.C, H = p.H, D = C / H, Q = p.Q;
     const int q0 = blockIdx.x * kQsRows;
     const float *t1 = p.ws, *Qs = p.ws + (size_t)Q * C, *Ks = p.ws + (size_t)2 * Q * C, *Vs = p.ws + (size_t)3 * Q * C;
@@ -409,16 +419,18 @@ __global__ __launch_bounds__(kQsThreads) void query_side_b_kernel(QsParams p)
         sT1[r * kQsMaxC + c] = t1[(size_t)q * C + c];
         sQ[r * kQsMaxC + c] = Qs[(size_t)q * C + c];
     }
+    for (int e = tid; e < Q * C; e += kQsThreads) sKV[e] = Ks[e];
     __syncthreads();
     // ---- self-attention of the workgroup's rows over all Q keys ----
     const float scale = 1.0f / sqrtf((float)D);
     for (int e = tid; e < kQsRows * H * Q; e += kQsThreads) {
         const int r = e / (H * Q), h = (e / Q) % H, j = e % Q;
         float sdot = 0.0f;
-        for (int d = 0; d < D; ++d) sdot = fmaf(sQ[r * kQsMaxC + h * D + d] * scale, Ks[(size_t)j * C + h * D + d], sdot);
+        for (int d = 0; d < D; ++d) sdot = fmaf(sQ[r * kQsMaxC + h * D + d] * scale, sKV[j * C + h * D + d], sdot);
         sS[(r * H + h) * kQsMaxQ + j] = sdot;
     }
     __syncthreads();
+    for (int e = tid; e < Q * C; e += kQsThreads) sKV[e] = Vs[e];   // (published by the barrier behind the softmax)
     {   // softmax over the keys: one wave per (row, head) pair in turn
         const int wave = tid >> 6, lane = tid & 63, nw = kQsThreads / 64;
         for (int rh = wave; rh < kQsRows * H; rh += nw) {
@@ -444,7 +456,7 @@ __global__ __launch_bounds__(kQsThreads) void query_side_b_kernel(QsParams p)
         const int r = e / C, c = e - r * C, h = c / D;
         const float *pr = sS + (r * H + h) * kQsMaxQ;
         float a = 0.0f;
-        for (int j = 0; j < Q; ++j) a = fmaf(pr[j], Vs[(size_t)j * C + c], a);
+        for (int j = 0; j < Q; ++j) a = fmaf(pr[j], sKV[j * C + c], a);
         sA[r * kQsMaxC + c] = a;
     }
     __syncthreads();

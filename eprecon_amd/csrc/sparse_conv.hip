@@ -32,6 +32,7 @@
 // narrow or short layers are bound by their dependent chain (staging round trips), see DESIGN.md 3b.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.hpp"
 #include "conv_common.hpp"
@@ -2020,7 +2021,7 @@ struct ConvProf {
     int64_t min_rows = 0, rows = 0;
     const char *kernel = "";
     hipEvent_t start = nullptr, stop = nullptr;
-    unsigned long long *pairs_dev = nullptr;  // live (output row, offset) pairs of the bracketed launch
+    unsigned long long *pairs_dev = nullptr;  // [0] live (output row, offset) pairs of the bracketed launch, [1] the pairs it issues MFMAs for
 } g_conv_prof;
 
 // live pairs of a launch = what its algorithmic flop count rests on; counted on the launch stream BEHIND the stop event
@@ -2042,6 +2043,21 @@ __global__ void count_grid_pairs_kernel(const int32_t *rank, int gx, int gy, int
             const int xx = x + k % 3 - 1, yy = y + (k / 3) % 3 - 1, zz = z + k / 9 - 1;
             if (xx >= 0 && xx < gx && yy >= 0 && yy < gy && zz >= 0 && zz < gz) c += rank[(xx * gy + yy) * gz + zz] >= 0;
         }
+    }
+    for (int m = 32; m > 0; m >>= 1) c += __shfl_xor(c, m);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+// rows of the (32-row group, offset) pairs with at least one neighbour: what the direct kernel issues MFMAs for
+__global__ void count_map_groups_kernel(const int32_t *nbr, int n, int K, unsigned long long *out)
+{
+    const int groups = (n + 31) / 32;
+    unsigned long long c = 0;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < K * groups; e += gridDim.x * blockDim.x) {
+        const int k = e / groups, g = e - k * groups;
+        const int rows = min(32, n - 32 * g);
+        bool any = false;
+        for (int i = 0; i < rows; ++i) any |= nbr[(size_t)k * n + 32 * g + i] >= 0;
+        if (any) c += rows;
     }
     for (int m = 32; m > 0; m >>= 1) c += __shfl_xor(c, m);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
@@ -2073,12 +2089,14 @@ int conv_dispatch(ConvParams &p, int64_t n_in, hipStream_t st)
     g.rows = p.n_out;
     g.kernel = g_last_conv_kernel;
     if (g.pairs_dev) {
-        EP_HIP_CHECK(hipMemsetAsync(g.pairs_dev, 0, sizeof(unsigned long long), st));
+        EP_HIP_CHECK(hipMemsetAsync(g.pairs_dev, 0, 2 * sizeof(unsigned long long), st));
         bool narrow;
         if (conv3d_tile_ok(p, &narrow))
             hipLaunchKernelGGL(count_grid_pairs_kernel, dim3(256), dim3(256), 0, st, p.vox_rank, p.gx, p.gy, p.gz, g.pairs_dev);
         else if (p.nbr)
             hipLaunchKernelGGL(count_map_pairs_kernel, dim3(256), dim3(256), 0, st, p.nbr, (size_t)p.K * p.n_out, g.pairs_dev);
+        if (p.nbr && !strcmp(g.kernel, "spconv_direct16_kernel"))
+            hipLaunchKernelGGL(count_map_groups_kernel, dim3(256), dim3(256), 0, st, p.nbr, p.n_out, p.K, g.pairs_dev + 1);
         else  // identity map
             EP_HIP_CHECK(hipMemcpyAsync(g.pairs_dev, &g.rows, sizeof(unsigned long long), hipMemcpyHostToDevice, st));
         EP_LAUNCH_CHECK();
@@ -2174,7 +2192,7 @@ extern "C" int eprecon_profile_conv_arm(int kvol, int cin, int cout, int64_t min
     if (!g.start) {
         EP_HIP_CHECK(hipEventCreate(&g.start));
         EP_HIP_CHECK(hipEventCreate(&g.stop));
-        EP_HIP_CHECK(hipMalloc(&g.pairs_dev, sizeof(unsigned long long)));
+        EP_HIP_CHECK(hipMalloc(&g.pairs_dev, 2 * sizeof(unsigned long long)));
     }
     g.K = kvol; g.cin = cin; g.cout = cout; g.min_rows = min_rows;
     g.armed = true;
@@ -2202,6 +2220,15 @@ extern "C" int64_t eprecon_profile_conv_pairs(void)
     unsigned long long v = 0;
     if (hipMemcpy(&v, g.pairs_dev, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (int64_t)v;
+}
+
+extern "C" int64_t eprecon_profile_conv_executed_pairs(void)
+{
+    ConvProf &g = g_conv_prof;
+    if (!g.recorded || !g.pairs_dev || hipEventSynchronize(g.stop) != hipSuccess) return -1;
+    unsigned long long v = 0;
+    if (hipMemcpy(&v, g.pairs_dev + 1, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int64_t)v;   // 0: the kernel that took the launch walks every offset of every row
 }
 
 extern "C" size_t eprecon_conv_pack_weight_floats(int kvol, int cin, int cout)

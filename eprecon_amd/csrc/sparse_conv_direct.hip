@@ -139,21 +139,52 @@ __device__ __forceinline__ void direct_epilogue(const ConvParams &p, f32x4 (&acc
     }
 }
 
-// The offsets at which at least one of a wave's 32 rows (lane l16 looks at rows l16 and 16 + l16 of the wave: `nbr_lane` points
-// at its first row's column of the staged neighbour table, pitch `rows` per offset) has a neighbour -> live[0 .. n) in
-// ascending order, written by lane 0; returns n (wave-uniform).  K <= 32.  The caller publishes the list with a barrier.
-__device__ __forceinline__ int live_offsets(const int *nbr_lane, int K, int rows, unsigned char *live, int lane)
+// The workgroup's slice of the kernel map -> LDS ([K][128 rows]), and for every wave the offsets at which at least one of its
+// 32 rows has a neighbour, as a bit mask (wave-uniform: it lives in scalar registers, and the walk below — lowest set bit,
+// clear it — is scalar arithmetic).  All loads of a thread are issued before the first is used (K <= 27: at most 14 per
+// thread).  Load pass `it` of wave w covers offset 2 it + w / 2, rows 64 (w % 2) .. + 63: the two halves of its ballot are
+// the flags of consumer waves 2 (w % 2) and 2 (w % 2) + 1, left in sFlag[offset][consumer wave].  Ends with the barrier that
+// publishes the table (and whatever the caller staged before the call).
+constexpr int kMapLoads = 14;
+__device__ __forceinline__ unsigned stage_map(const ConvParams &p, int row0, int *sNbr, int *sFlag, int tid)
 {
-    int n = 0;
-    for (int k = 0; k < K; ++k) {
-        const bool any = nbr_lane[k * rows] >= 0 || nbr_lane[k * rows + 16] >= 0;
-        if (__ballot(any) != 0ull) {
-            if (lane == 0) live[n] = (unsigned char)k;
-            ++n;
-        }
+    static_assert(kDirectRows == 128 && kRT == 2 && kWaves == 4, "the pass -> (offset, row half) arithmetic below");
+    const int total = p.K * kDirectRows;
+    const int lane = tid & 63, wave = tid >> 6;
+    int jv[kMapLoads];
+#pragma unroll
+    for (int it = 0; it < kMapLoads; ++it) {
+        const int e = tid + it * 256;
+        const int k = e >> 7, row = row0 + (e & 127);
+        int j = -1;
+        if (e < total && row < p.n_out) j = p.nbr ? p.nbr[(size_t)k * p.n_out + row] : row;
+        jv[it] = j;
     }
-    return n;
+#pragma unroll
+    for (int it = 0; it < kMapLoads; ++it) {
+        const int e = tid + it * 256;
+        if (e < total) sNbr[e] = jv[it];
+        const unsigned long long b = __ballot(jv[it] >= 0);
+        const int k = 2 * it + (wave >> 1);
+        if (lane < 2 && k < p.K) sFlag[k * kWaves + 2 * (wave & 1) + lane] = (lane ? (unsigned)(b >> 32) : (unsigned)b) != 0u;
+    }
+    __syncthreads();
+    const bool mine = lane < p.K && sFlag[lane * kWaves + wave] != 0;
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(mine));
 }
+
+// Position in the (live offset, part) sequence of a wave: `k` the current offset, `rest` the live offsets after it.
+// next() stays on the last position once the sequence is exhausted (a stage fetched past the end is not consumed).
+struct LiveCursor {
+    unsigned rest;
+    int k, part;
+    __device__ __forceinline__ explicit LiveCursor(unsigned mask) : rest(mask & (mask - 1u)), k(__builtin_ctz(mask)), part(0) {}
+    __device__ __forceinline__ void next(int parts)
+    {
+        if (part + 1 < parts) ++part;
+        else if (rest) { k = __builtin_ctz(rest); rest &= rest - 1u; part = 0; }
+    }
+};
 
 // chunks per stage for a layer of KCH chunks: the stages of an offset are KCH / G
 constexpr int stage_chunks(int kch) { return kch % 3 == 0 ? 3 : (kch % 2 == 0 ? 2 : 1); }
@@ -168,32 +199,23 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
     int *sNbr = reinterpret_cast<int *>(smem);                        // [K][ROWS]
     float *sStat = reinterpret_cast<float *>(sNbr + p.K * ROWS);      // [4 waves][3][16 CT]
     float *sAff = sStat + kWaves * 3 * 16 * CT;                       // [2][cpad]
-    unsigned char *sLive = reinterpret_cast<unsigned char *>(sAff + 2 * cpad);   // [4 waves][32] live offsets of a wave\'s 32 rows
+    int *sFlag = reinterpret_cast<int *>(sAff + 2 * cpad);            // [K][4 waves] the wave has a neighbour at the offset
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, q = lane >> 4;
     const int row0 = (int)blockIdx.x * ROWS;
 
-    for (int e = tid; e < p.K * ROWS; e += 256) {
-        const int k = e / ROWS, r = e - k * ROWS;
-        const int row = row0 + r;
-        int j = -1;
-        if (row < p.n_out) j = p.nbr ? p.nbr[(size_t)k * p.n_out + row] : row;
-        sNbr[e] = j;
-    }
     if (p.in_scale)
         for (int c = tid; c < cpad; c += 256) {
             sAff[c] = c < p.Cin ? p.in_scale[c] : 0.0f;
             sAff[cpad + c] = c < p.Cin ? p.in_shift[c] : 0.0f;
         }
-    __syncthreads();
     // Offsets none of the wave's 32 rows has a neighbour at are skipped altogether (no gathers, no weight loads, no MFMAs):
     // an output-stationary kernel otherwise multiplies zeros for every missing neighbour.  On the surface-shaped sets of a
     // fragment 12-25 % of the (32-row, offset) groups are dead; on the second voxelisation of ConvGRU's convr — already
     // scaled coordinates divided by the resolution again, models/modules.py:216-217: no two voxels are adjacent — 26 of the
     // 27 offsets are (profiles/r04/conv_tile_liveness.txt).
-    const int n_live = live_offsets(sNbr + wave * 16 * RT + l16, p.K, ROWS, sLive + wave * 32, lane);
-    __syncthreads();
+    const unsigned live = stage_map(p, row0, sNbr, sFlag, tid);
 
     f32x4 acc[RT][CT];
 #pragma unroll
@@ -203,8 +225,7 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
     const unsigned row_bytes = (unsigned)p.ld_x * 4u, oob = (unsigned)p.x_bytes;
-    const int U = n_live * PARTS;                   // stages: (live offset, part)
-    const unsigned char *myLive = sLive + wave * 32;
+    const int U = __builtin_popcount(live) * PARTS;   // stages: (live offset, part)
     constexpr unsigned kChunkBytes = (unsigned)CT * 1024u;
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wq16), 0, (int)((unsigned)p.K * KCH * kChunkBytes), 0x00020000);
@@ -222,10 +243,8 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
         float4 b[G][CT];
     };
     // stage u = (offset k = u / PARTS, chunks kc0 .. kc0 + G - 1 with kc0 = (u % PARTS) * G)
-    auto fetch = [&](int u, Stage &g) {
-        const int kl = PARTS == 1 ? u : u / PARTS;
-        const int part = PARTS == 1 ? 0 : u - kl * PARTS;
-        const int k = __builtin_amdgcn_readfirstlane((int)myLive[kl]);   // (wave-uniform: the weight offset below is a scalar)
+    auto fetch = [&](const LiveCursor &c, Stage &g) {
+        const int k = c.k, part = c.part;                                // (wave-uniform: the weight offset below is a scalar)
         const unsigned xs = 64u * (unsigned)(part * G);                 // (scalar) byte offset of the stage's first chunk
         const unsigned ws = (unsigned)(k * KCH + part * G) * kChunkBytes;
         const bool has_last = part == PARTS - 1;                         // (uniform) the stage holds the layer's last chunk
@@ -250,10 +269,8 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
                 g.b[i][t] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
             }
     };
-    auto consume = [&](int u, const Stage &g) {
-        const int kl = PARTS == 1 ? u : u / PARTS;
-        const int part = PARTS == 1 ? 0 : u - kl * PARTS;
-        const int k = __builtin_amdgcn_readfirstlane((int)myLive[kl]);
+    auto consume = [&](const LiveCursor &c, const Stage &g) {
+        const int k = c.k, part = c.part;
         const bool has_last = part == PARTS - 1;
 #pragma unroll
         for (int i = 0; i < G; ++i) {
@@ -314,15 +331,20 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
     };
     if (!(p.debug & 1) && U > 0) {
         Stage s_a, s_b;
-        fetch(0, s_a);
+        LiveCursor cf(live), cc(live);     // the fetches run one to two stages ahead of the MFMAs
+        fetch(cf, s_a);
         for (int u = 0; u < U; u += 2) {
-            fetch(min(u + 1, U - 1), s_b);
+            cf.next(PARTS);
+            fetch(cf, s_b);
             __builtin_amdgcn_sched_barrier(0);
-            consume(u, s_a);
+            consume(cc, s_a);
+            cc.next(PARTS);
             __builtin_amdgcn_sched_barrier(0);
-            fetch(min(u + 2, U - 1), s_a);
+            cf.next(PARTS);
+            fetch(cf, s_a);
             __builtin_amdgcn_sched_barrier(0);
-            if (u + 1 < U) consume(u + 1, s_b);
+            if (u + 1 < U) consume(cc, s_b);
+            cc.next(PARTS);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -341,28 +363,19 @@ __global__ __launch_bounds__(256) void spconv_direct16_generic_kernel(ConvParams
     float *sStat = reinterpret_cast<float *>(sNbr + p.K * ROWS);      // [4 waves][3][16 CT]
     const int cpad = 16 * kch;
     float *sAff = sStat + kWaves * 3 * 16 * CT;                       // [2][cpad]
-    unsigned char *sLive = reinterpret_cast<unsigned char *>(sAff + 2 * cpad);   // [4 waves][32]
+    int *sFlag = reinterpret_cast<int *>(sAff + 2 * cpad);            // [K][4 waves] the wave has a neighbour at the offset
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, q = lane >> 4;
     const int row0 = (int)blockIdx.x * ROWS;
 
-    for (int e = tid; e < p.K * ROWS; e += 256) {
-        const int k = e / ROWS, r = e - k * ROWS;
-        const int row = row0 + r;
-        int j = -1;
-        if (row < p.n_out) j = p.nbr ? p.nbr[(size_t)k * p.n_out + row] : row;
-        sNbr[e] = j;
-    }
     if (p.in_scale)
         for (int c = tid; c < cpad; c += 256) {
             sAff[c] = c < p.Cin ? p.in_scale[c] : 0.0f;
             sAff[cpad + c] = c < p.Cin ? p.in_shift[c] : 0.0f;
         }
-    __syncthreads();
-    const int n_live = live_offsets(sNbr + wave * 16 * RT + l16, p.K, ROWS, sLive + wave * 32, lane);   // (see the template kernel)
-    __syncthreads();
-    const unsigned char *myLive = sLive + wave * 32;
+    // (live offsets of the wave's 32 rows: see the template kernel)
+    const unsigned live = stage_map(p, row0, sNbr, sFlag, tid);
 
     f32x4 acc[RT][CT];
 #pragma unroll
@@ -372,7 +385,7 @@ __global__ __launch_bounds__(256) void spconv_direct16_generic_kernel(ConvParams
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
     const unsigned row_bytes = (unsigned)p.ld_x * 4u, oob = (unsigned)p.x_bytes;
-    const int S = n_live * kch;                    // (live offset, chunk) steps
+    const int S = __builtin_popcount(live) * kch;  // (live offset, chunk) steps
     const unsigned step_bytes = (unsigned)CT * 1024u;
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wq16), 0, (int)((unsigned)p.K * kch * step_bytes), 0x00020000);
@@ -387,14 +400,13 @@ __global__ __launch_bounds__(256) void spconv_direct16_generic_kernel(ConvParams
         float4 b[G][CT];
         unsigned live;      // bit (i * RT + rt): the neighbour of step i, row tile rt exists (only read with in_scale)
     };
-    // steps s0 .. s0 + G - 1, clamped to the last one (a clamped step is fetched and not used)
-    auto fetch = [&](int s0, Stage &g) {
+    // the G steps at the cursor, which moves on (and stays on the last step: a step fetched past the end is not used)
+    auto fetch = [&](LiveCursor &c, Stage &g) {
         g.live = 0u;
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            const int s = min(s0 + i, S - 1);
-            const int kl = s / kch, kc = s - kl * kch;
-            const int k = __builtin_amdgcn_readfirstlane((int)myLive[kl]);
+            const int k = c.k, kc = c.part;
+            c.next(kch);
             const bool t8 = tail8 && kc == kch - 1;                         // (uniform)
             const unsigned cbytes = 64u * (unsigned)kc + (t8 ? cq >> 1 : cq);
             const bool cok = 16 * kc + (t8 ? 2 : 4) * q < p.Cin;
@@ -469,13 +481,14 @@ __global__ __launch_bounds__(256) void spconv_direct16_generic_kernel(ConvParams
     };
     if (!(p.debug & 1) && S > 0) {
         Stage s_a, s_b;
-        fetch(0, s_a);
+        LiveCursor cf(live);
+        fetch(cf, s_a);
         for (int s0 = 0; s0 < S; s0 += 2 * G) {
-            fetch(s0 + G, s_b);
+            fetch(cf, s_b);
             __builtin_amdgcn_sched_barrier(0);
             consume(s0, s_a);
             __builtin_amdgcn_sched_barrier(0);
-            fetch(s0 + 2 * G, s_a);
+            fetch(cf, s_a);
             __builtin_amdgcn_sched_barrier(0);
             consume(s0 + G, s_b);
             __builtin_amdgcn_sched_barrier(0);
@@ -487,7 +500,7 @@ __global__ __launch_bounds__(256) void spconv_direct16_generic_kernel(ConvParams
 template <int CT, int KCH>
 int launch_k(const ConvParams &p, hipStream_t st)
 {
-    const size_t lds = (size_t)p.K * kDirectRows * sizeof(int) + (size_t)kWaves * 3 * 16 * CT * sizeof(float) + (size_t)2 * 16 * KCH * sizeof(float) + kWaves * 32;
+    const size_t lds = (size_t)p.K * kDirectRows * sizeof(int) + (size_t)kWaves * 3 * 16 * CT * sizeof(float) + (size_t)2 * 16 * KCH * sizeof(float) + (size_t)p.K * kWaves * sizeof(int);
     // (one chunk per stage — 80 registers, six waves per SIMD instead of three — measured no faster: 266 vs 250 us on 48 -> 24)
     hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH>), dim3((unsigned)ceil_div(p.n_out, kDirectRows)), dim3(256), lds, st, p);
     EP_LAUNCH_CHECK();
@@ -507,7 +520,7 @@ int launch_ct(const ConvParams &p, hipStream_t st)
         case 6: return launch_k<CT, 6>(p, st);
         default: break;
     }
-    const size_t lds = (size_t)p.K * kDirectRows * sizeof(int) + (size_t)kWaves * 3 * 16 * CT * sizeof(float) + (size_t)2 * 16 * kch * sizeof(float) + kWaves * 32;
+    const size_t lds = (size_t)p.K * kDirectRows * sizeof(int) + (size_t)kWaves * 3 * 16 * CT * sizeof(float) + (size_t)2 * 16 * kch * sizeof(float) + (size_t)p.K * kWaves * sizeof(int);
     hipLaunchKernelGGL((spconv_direct16_generic_kernel<CT>), dim3((unsigned)ceil_div(p.n_out, kDirectRows)), dim3(256), lds, st, p, kch);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;

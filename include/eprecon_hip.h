@@ -121,6 +121,10 @@ float eprecon_profile_conv_ms(int64_t *rows_out, const char **kernel_out);
 /* live (output row, kernel offset) pairs of the bracketed launch (2 * pairs * cin * cout = its algorithmic flops),
  * counted on the launch stream behind the stop event; blocks; -1 when nothing was recorded */
 int64_t eprecon_profile_conv_pairs(void);
+/* the (row, offset) pairs that launch issued MFMAs for: the direct kernel skips an offset for the 32 rows of a wave when none
+ * of them has a neighbour there, so this is 32 x the live (32-row group, offset) pairs; 0 for the kernels that walk every offset
+ * of every row (executed = kvol * rows) */
+int64_t eprecon_profile_conv_executed_pairs(void);
 /* name of the kernel family the most recent convolution launch of this process went to ("spconv_direct16_kernel",
  * "spconv_splitk_kernel", "spconv_wide_kernel", "conv3d_tile16_kernel", ...): lets callers and tests assert the selection */
 const char *eprecon_profile_last_conv_kernel(void);
