@@ -117,6 +117,8 @@ SIGNATURES = {
     "eprecon_profile_conv_arm": (_i, [_i, _i, _i, _i64]),
     "eprecon_profile_conv_ms": (_f, [_c.POINTER(_i64), _c.POINTER(_c.c_char_p)]),
     "eprecon_profile_conv_pairs": (_i64, []),
+    "eprecon_mlp4x_supported": (_i, [_i, _i]),
+    "eprecon_mlp4x_async": (_i, [_vp, _vp]),
     "eprecon_profile_conv_executed_pairs": (_i64, []),
     "eprecon_profile_last_conv_kernel": (_c.c_char_p, []),
     "eprecon_profile_mark_async": (_i, [_i, _vp]),
@@ -243,6 +245,19 @@ class DecoderLayerDesc(ctypes.Structure):
     _PTRS_B = ["state_out", "cls_out", "mask_embed_out", "next_q_out", "workspace"]
     _fields_ = ([(n, ctypes.c_int) for n in ("n_queries", "channels", "n_heads", "ffn_dim", "n_class_logits", "mask_hidden")]
                 + [(n, ctypes.c_void_p) for n in _PTRS_A] + [("ln_eps", ctypes.c_float)] + [(n, ctypes.c_void_p) for n in _PTRS_B])
+
+
+class Mlp4xHead(ctypes.Structure):
+    """include/eprecon_hip.h: eprecon_mlp4x_head"""
+    _fields_ = ([(n, ctypes.c_void_p) for n in ("w1", "b1", "g1", "be1", "w2", "b2", "g2", "be2", "w3", "b3", "y")]
+                + [("ld_y", ctypes.c_int64)])
+
+
+class Mlp4xDesc(ctypes.Structure):
+    """include/eprecon_hip.h: eprecon_mlp4x_desc"""
+    _fields_ = [("x", ctypes.c_void_p), ("ld_x", ctypes.c_int64), ("n", ctypes.c_int64), ("channels", ctypes.c_int),
+                ("out_channels", ctypes.c_int), ("heads", ctypes.c_int), ("residual", ctypes.c_int), ("eps1", ctypes.c_float),
+                ("eps2", ctypes.c_float), ("head", Mlp4xHead * 2)]
 
 
 _WORKSPACES = {}

@@ -414,11 +414,24 @@ def _ln_rows(norm, y, residual=None, pre_relu=False, post_relu=False):
     return F.relu(t) if post_relu else t
 
 
-# measured per fragment (tools/profile_cfg4_stages.py): heads of the finest level (371k rows) 0.55 -> 0.39 ms fused, but the
-# coarser levels (12k / 57k rows, 384 / 192-wide intermediates stay on hipBLASLt + row-wise LN) 0.32 -> 0.41 and 0.39 -> 0.41:
-# fused only on long lists
+# EPRECON_FUSED_HEADS=0: the heads as separate Linear / LayerNorm launches (the PyTorch modules) instead of csrc/heads.hip
 _FUSED_HEADS = __import__("os").environ.get("EPRECON_FUSED_HEADS", "1") == "1"
-_FUSED_HEADS_MIN_ROWS = 150000
+
+
+def fused_heads_ok(mod, x):
+    """inference on the GPU: the whole Linear4xTrans as one launch (eprecon_mlp4x_async)"""
+    return (_FUSED_HEADS and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
+            and x.stride(1) == 1 and SP.mlp4x_supported(mod.linear1.in_features, mod.linear3.out_features))
+
+
+def linear4x_pair(mod_a, mod_b, x):
+    """(mod_a(x), mod_b(x)) for two heads of equal shape on the same rows (tsdf_preds / occ_preds,
+    models/neucon_network.py:437-438): one launch on the GPU inference path"""
+    if fused_heads_ok(mod_a, x) and mod_a.linear3.out_features == mod_b.linear3.out_features \
+            and mod_a.linear1.in_features == mod_b.linear1.in_features:
+        ya, yb = SP.mlp4x([mod_a, mod_b], x)
+        return ya, yb
+    return mod_a(x), mod_b(x)
 
 
 class Linear4xTrans(nn.Module):
@@ -445,21 +458,8 @@ class Linear4xTrans(nn.Module):
             lin = lambda layer, t: AG.sparse_conv(t, layer.weight.t(), None, layer.bias)
         else:
             lin = lambda layer, t: layer(t)
-        if _FUSED_HEADS and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 \
-                and x.shape[0] >= _FUSED_HEADS_MIN_ROWS:
-            # inference on the GPU: Linear + LayerNorm + ReLU as ONE launch (per-voxel GEMM with the row-wise LayerNorm in
-            # its epilogue) wherever a row of the output fits a workgroup (<= 128 columns): the 4C-wide intermediate of a
-            # 371k-voxel level is written once instead of written, re-read and re-written
-            def lin_ln(layer, norm, t):
-                if layer.out_features <= 128:
-                    return SP.sparse_conv_ln(t, _linear_wt(layer), None, layer.bias, norm.weight, norm.bias, norm.eps,
-                                             post_relu=True)
-                return _ln_rows(norm, layer(t), post_relu=True)
-            xc = x if x.stride(1) == 1 else x.contiguous()
-            h = lin_ln(self.linear1, self.norm1, xc)
-            h = lin_ln(self.linear2, self.norm2, h)
-            y = self.linear3(h)
-            return y + h if self.use_residual else y
+        if fused_heads_ok(self, x):
+            return SP.mlp4x([self], x)[0]
         h = _ln_rows(self.norm1, lin(self.linear1, x), post_relu=True)
         h = _ln_rows(self.norm2, lin(self.linear2, h), post_relu=True)
         y = lin(self.linear3, h)

@@ -31,7 +31,7 @@ from .config import (CH_IMG, CH_INIT_DOWN, CH_VOXEL, EXCEED_NUM, INIT_MIN_VIEW, 
 from .generate_grids import dense_coords
 from .gru_fusion import GRUFusion
 from .mask3dformer import MultiScaleMaskedTransformerDecoder, panoptic_post
-from .modules import Linear4xTrans, Panoptic_Feat_Fusion, SPVCNN
+from .modules import Linear4xTrans, Panoptic_Feat_Fusion, SPVCNN, linear4x_pair
 from .occupancy_initialization import Occupancy_Initialization
 from .tensor import PointTensor
 from .torchsparse_utils import aligned_camera_coords
@@ -243,8 +243,7 @@ class NeuConNet(nn.Module):
                 feat = feat_all[:, :voxel_dim]
                 self._record(stage=f"gru{i}", coords_in=fuse_in[0], feat_in=fuse_in[1], coords=up_coords,
                              feat_all=feat_all, tsdf_target=tsdf_target)
-            tsdf = self.tsdf_preds[i](feat)
-            occ = self.occ_preds[i](feat)
+            tsdf, occ = linear4x_pair(self.tsdf_preds[i], self.occ_preds[i], feat)
             if recording and tsdf_target is not None:   # :441-449 (grid_mask is all ones with FUSION.FULL)
                 loss_dict[f"tsdf_occ_loss_{i}"] = compute_loss(tsdf, occ, tsdf_target, occ_target, pos_weight=cfg.POS_WEIGHT)
             else:

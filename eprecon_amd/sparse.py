@@ -574,3 +574,77 @@ def rowwise_layernorm(x, gamma=None, beta=None, eps=1e-5, residual=None, pre_rel
         _lib.ptr(gamma), _lib.ptr(beta), float(eps), int(pre_relu), int(post_relu), _lib.ptr(out),
         _ld(out), _lib.current_stream()), "eprecon_rowwise_layernorm_async")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# the per-voxel heads (Linear4xTrans) as one launch: csrc/heads.hip
+# ------------------------------------------------------------------------------------------------
+def _pack_mlp_weight(wt):
+    """Wt f32[K][M] (in x out) -> f32[ceil(M/16)][ceil(K/16)][64][4] in the operand order of eprecon_mlp4x_async:
+    block (t, c), lane 16 q + m, component i = Wt[16 c + 4 q + i][16 t + m]"""
+    k, m = wt.shape
+    kc, mt = (k + 15) // 16, (m + 15) // 16
+    w = torch.zeros((16 * kc, 16 * mt), dtype=torch.float32, device=wt.device)
+    w[:k, :m] = wt
+    return w.view(kc, 4, 4, mt, 16).permute(3, 0, 1, 4, 2).contiguous().view(-1)
+
+
+def _pad16(v, n=None):
+    n = v.shape[0] if n is None else n
+    out = torch.zeros(((n + 15) // 16 * 16,), dtype=torch.float32, device=v.device)
+    out[:v.shape[0]] = v
+    return out
+
+
+def mlp4x_supported(channels, out_channels):
+    return bool(_lib.load().eprecon_mlp4x_supported(int(channels), int(out_channels)))
+
+
+def pack_mlp4x(mod):
+    """the parameters of a Linear4xTrans in the kernel's operand order, ONE flat buffer (cached on the module per weight
+    version; clear_packed_weights drops it) -> dict name -> tensor view"""
+    params = (mod.linear1.weight, mod.linear1.bias, mod.norm1.weight, mod.norm1.bias, mod.linear2.weight, mod.linear2.bias,
+              mod.norm2.weight, mod.norm2.bias, mod.linear3.weight, mod.linear3.bias)
+    tag = tuple((p_._version, p_.data_ptr()) for p_ in params)
+    hit = getattr(mod, "_eprecon_packed", None)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    with torch.no_grad():
+        parts = {"w1": _pack_mlp_weight(mod.linear1.weight.t()), "b1": _pad16(mod.linear1.bias), "g1": _pad16(mod.norm1.weight),
+                 "be1": _pad16(mod.norm1.bias), "w2": _pack_mlp_weight(mod.linear2.weight.t()), "b2": _pad16(mod.linear2.bias),
+                 "g2": _pad16(mod.norm2.weight), "be2": _pad16(mod.norm2.bias), "w3": _pack_mlp_weight(mod.linear3.weight.t()),
+                 "b3": _pad16(mod.linear3.bias)}
+        flat = torch.cat([v for v in parts.values()])        # (every part is a multiple of 16 floats: 16-byte aligned views)
+        views, off = {}, 0
+        for name, v in parts.items():
+            views[name] = flat[off:off + v.numel()]
+            off += v.numel()
+    mod._eprecon_packed = (tag, views)
+    return views
+
+
+def mlp4x(mods, x, outs=None):
+    """y_h = Linear4xTrans_h(x) for the 1 or 2 modules `mods` of equal shape (TSDF and occupancy heads share their input rows):
+    one launch.  x f32[n, >= C] (row pitch free), -> list of f32[n, C_out]"""
+    lib = _lib.load()
+    m0 = mods[0]
+    c, cout = m0.linear1.in_features, m0.linear3.out_features
+    n = x.shape[0]
+    assert x.dtype == torch.float32 and x.stride(1) == 1 and x.shape[1] >= c and 1 <= len(mods) <= 2
+    d = _lib.Mlp4xDesc()
+    d.x, d.ld_x, d.n = x.data_ptr(), x.stride(0), n
+    d.channels, d.out_channels, d.heads, d.residual = c, cout, len(mods), int(m0.use_residual)
+    d.eps1, d.eps2 = float(m0.norm1.eps), float(m0.norm2.eps)
+    if outs is None:
+        outs = [torch.empty((n, cout), dtype=torch.float32, device=x.device) for _ in mods]
+    keep = []
+    for h, (mod, y) in enumerate(zip(mods, outs)):
+        assert mod.linear1.in_features == c and mod.linear3.out_features == cout
+        pk = pack_mlp4x(mod)
+        keep.append(pk)
+        hd = d.head[h]
+        for name in ("w1", "b1", "g1", "be1", "w2", "b2", "g2", "be2", "w3", "b3"):
+            setattr(hd, name, pk[name].data_ptr())
+        hd.y, hd.ld_y = y.data_ptr(), y.stride(0)
+    _lib.check(lib.eprecon_mlp4x_async(ctypes.byref(d), _lib.current_stream()), "eprecon_mlp4x_async")
+    return outs

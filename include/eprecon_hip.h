@@ -715,6 +715,34 @@ typedef struct eprecon_decoder_layer_desc {
 } eprecon_decoder_layer_desc;
 int eprecon_decoder_query_side_async(const eprecon_decoder_layer_desc *desc, void *stream);
 
+/*
+ * The per-voxel heads as one launch  (models/modules.py:273-311 Linear4xTrans: Linear(C, 4C) - LayerNorm - ReLU -
+ * Linear(4C, C) - LayerNorm - ReLU - Linear(C, C_out), + the second hidden layer as a skip when C == C_out; callers
+ * models/neucon_network.py:437-438 tsdf_preds / occ_preds — `heads` = 2: both run on the same rows — and :546-548
+ * panoptic_preds).  A wave owns 16 voxels; the chain stays in its registers (csrc/heads.hip).
+ *   x f32[n][ld_x]: the first `channels` columns of a row are the input.  y of head h: f32[n][ld_y], out_channels columns.
+ *   Weights are handed over PACKED for the kernel's operand order (eprecon_amd/sparse.py pack_mlp4x; all 16-byte aligned):
+ *     layer with weight Wt f32[K][M] (in x out)  ->  f32[ceil(M/16)][ceil(K/16)][64][4],
+ *     block (t, c), lane l = 16 q + m, component i  =  Wt[16 c + 4 q + i][16 t + m]   (0 outside the matrix);
+ *     bias / LayerNorm weight / LayerNorm bias vectors padded with zeros to a multiple of 16.
+ * Shapes taken (eprecon_mlp4x_supported): channels 24 / 48 / 96 with out_channels <= 16, channels 48 / 88 / 176 with
+ * out_channels 33..48; EPRECON_ERR_ARG otherwise (the caller keeps those on separate launches).
+ */
+typedef struct eprecon_mlp4x_head {
+    const float *w1; const float *b1; const float *g1; const float *be1;   /* Linear(C, 4C), LayerNorm(4C) */
+    const float *w2; const float *b2; const float *g2; const float *be2;   /* Linear(4C, C), LayerNorm(C) */
+    const float *w3; const float *b3;                                      /* Linear(C, C_out) */
+    float *y; int64_t ld_y;
+} eprecon_mlp4x_head;
+typedef struct eprecon_mlp4x_desc {
+    const float *x; int64_t ld_x; int64_t n;
+    int channels; int out_channels; int heads; int residual;
+    float eps1; float eps2;
+    eprecon_mlp4x_head head[2];
+} eprecon_mlp4x_desc;
+int eprecon_mlp4x_supported(int channels, int out_channels);
+int eprecon_mlp4x_async(const eprecon_mlp4x_desc *desc, void *stream);
+
 /* x2 bilinear upsampling of channels-last maps, in f32[n,h,w,c] -> out f32[n,2h,2w,c], c % 4 == 0
  * (F.interpolate(scale_factor=2, mode="bilinear") in feat_fusion_pre,
  * models/occupancy_initialization.py:46) */
