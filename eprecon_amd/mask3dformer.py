@@ -347,6 +347,17 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
                 nxt = self.transformer_cross_attention_layers[j + 1].multihead_attn
                 w["next_q_wt"], w["next_q_b"] = t(nxt.in_proj_weight[:c]), v(nxt.in_proj_bias[:c])
             layers.append(w)
+        # key / value in-projections of the layers that attend to the same level, side by side: [C][n_layers_of_level * C]
+        kv_levels = []
+        for lvl in range(self.num_feature_levels):
+            js = [j for j in range(self.num_layers) if j % self.num_feature_levels == lvl]
+            mh = [self.transformer_cross_attention_layers[j].multihead_attn for j in js]
+            c = mh[0].embed_dim
+            kv_levels.append({"layers": js,
+                              "wk": torch.cat([t(m.in_proj_weight[c:2 * c]) for m in mh], 1).contiguous(),
+                              "bk": torch.cat([v(m.in_proj_bias[c:2 * c]) for m in mh]).contiguous(),
+                              "wv": torch.cat([t(m.in_proj_weight[2 * c:]) for m in mh], 1).contiguous(),
+                              "bv": torch.cat([v(m.in_proj_bias[2 * c:]) for m in mh]).contiguous()})
         state0 = self.query_feat.weight.detach().unsqueeze(1)
         qe = self.query_embed.weight.detach().unsqueeze(1)
         with torch.no_grad():
@@ -354,7 +365,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             q0 = self._project_q(0, state0, qe)
         ok = (len(self.mask_embed.layers) == 3 and self.decoder_norm.eps == 1e-5 and
               all(l.norm.eps == 1e-5 for l in self.transformer_ffn_layers))
-        pack = {"key": key, "layers": layers, "cls0": cls0.contiguous(), "me0": me0.contiguous(), "q0": q0, "ok": ok,
+        pack = {"key": key, "layers": layers, "kv_levels": kv_levels, "cls0": cls0.contiguous(), "me0": me0.contiguous(), "q0": q0, "ok": ok,
                 "state0": self.query_feat.weight.detach().contiguous(), "qpos": self.query_embed.weight.detach().contiguous(),
                 "ffn_dim": self.transformer_ffn_layers[0].linear1.out_features, "n_cls": self.class_embed.out_features,
                 "mask_hidden": self.mask_embed.layers[0].out_features}
@@ -400,15 +411,20 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         ws = torch.empty((4, n_q, c), dtype=torch.float32, device=dev)
         o_attn = torch.empty((1, heads, n_q, c // heads), dtype=torch.float32, device=dev)
         rows = lambda t: t[0].t()                                        # [1, C, N] view of voxel rows -> the rows [N, C]
-        src, keys = [], []
+        # per level: the projected keys / values of EVERY layer that attends to it in two products (columns [a C, (a + 1) C) =
+        # the a-th of those layers): 6 launches for the 6 layers' 12 projections
+        k_of, v_of = [None] * self.num_layers, [None] * self.num_layers
         for i in range(self.num_feature_levels):
             xyz = panoptic_coords[i][0]
             xyz = xyz if xyz.dtype == torch.int32 else xyz.to(torch.int32)
             f = rows(panoptic_features[i])
             f = f if f.stride(1) == 1 else f.contiguous()
             s_i, k_i = decoder_level_inputs(xyz, f, self.level_embed.weight[i], self.pos_enc.gauss_B, spitial_shape)
-            src.append(s_i)
-            keys.append(k_i)
+            kv = pack["kv_levels"][i]
+            k_all = SP.sparse_conv(k_i, kv["wk"], None, kv["bk"])
+            v_all = SP.sparse_conv(s_i, kv["wv"], None, kv["bv"])
+            for a, j in enumerate(kv["layers"]):
+                k_of[j], v_of[j] = k_all[:, a * c:(a + 1) * c], v_all[:, a * c:(a + 1) * c]
         fine = panoptic_coords[2].squeeze(0)
         mask_rows = [nearest_fine_index(panoptic_coords[0].squeeze(0), fine, 4, as_int32=True),
                      nearest_fine_index(panoptic_coords[1].squeeze(0), fine, 2, as_int32=True), None]
@@ -420,11 +436,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             lvl = j % self.num_feature_levels
             logits_t = torch.mm(mf, me[0].t())                           # [N_2, Q]: this head's mask logits, voxel-major
             masks.append(logits_t.t().unsqueeze(0))
-            attn = self.transformer_cross_attention_layers[j].multihead_attn
-            w, b = attn.in_proj_weight, attn.in_proj_bias
-            k = F.linear(keys[lvl], w[c:2 * c], b[c:2 * c])
-            v = F.linear(src[lvl], w[2 * c:], b[2 * c:])
-            masked_attention(q, k, v, logits_t, mask_rows[lvl], o_attn, scale)
+            masked_attention(q, k_of[j], v_of[j], logits_t, mask_rows[lvl], o_attn, scale)
             state, cls, me, q = self._query_side_hip(pack, j, o_attn, state, outs[j], cls_all[j], ws)
             classes.append(cls)
         # the final head's masks in the reference's own layout ([1, Q, N_2] contiguous): panoptic_post reduces over them
