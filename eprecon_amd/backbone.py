@@ -1,15 +1,24 @@
 """2D image feature extractor — mirror of models/backbone.py:22-77 (MnasMulti): MNASNet-1.0 trunk up
 to stride 16 + FPN head -> [f4 (24ch, 1/4), f8 (40ch, 1/8), f16 (80ch, 1/16)].
 
-This is the feeder of the 3D path and stays PyTorch-ROCm (MIOpen), as BASELINE.json prescribes.
+This is the feeder of the 3D path.  The point-wise and dense 3 x 3 convolutions stay PyTorch-ROCm (hipBLASLt / MIOpen), as
+BASELINE.json prescribes; on the batched GPU inference path (forward_views) the depthwise convolutions and the per-view
+train-mode BatchNorms run on csrc/backbone2d.hip (MIOpen serves fp32 channels-last depthwise layers with its naive
+reference kernel: 1.85 of the 4.4 ms of a pass).  EPRECON_BACKBONE_HIP=0: everything on PyTorch ops.
 torchvision (and its pretrained download) is not available in this environment, so the MNASNet
 trunk is defined here with the layer layout and parameter names of torchvision's `MNASNet.layers`
 ([0..7] stem, [8] 16->24 k3 s2 e3 x3, [9] 24->40 k5 s2 e3 x3, [10] 40->80 k5 s2 e6 x3), which
 keeps reference checkpoints loadable; weights are random-initialised.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import _lib
+
+BACKBONE_HIP = os.environ.get("EPRECON_BACKBONE_HIP", "1") == "1"
 
 
 def _round_to_multiple_of(val, divisor, round_up_bias=0.9):
@@ -90,9 +99,12 @@ class MnasMulti(nn.Module):
         (no NCHW -> NHWC re-layout, no copy)."""
         v, b = len(imgs), imgs[0].shape[0]
         x = torch.cat(list(imgs), 0).contiguous(memory_format=torch.channels_last)
-        c0 = self._run(self.conv0, x, v)
-        c1 = self._run(self.conv1, c0, v)
-        c2 = self._run(self.conv2, c1, v)
+        run = self._run
+        if BACKBONE_HIP and x.is_cuda and not torch.is_grad_enabled() and x.dtype == torch.float32:
+            run = self._run_hip
+        c0 = run(self.conv0, x, v)
+        c1 = run(self.conv1, c0, v)
+        c2 = run(self.conv2, c1, v)
         levels = self._head(c0, c1, c2)
         return [[lvl[i * b:(i + 1) * b] for lvl in levels] for i in range(v)]
 
@@ -107,6 +119,129 @@ class MnasMulti(nn.Module):
                 x = self._run(m, x, v)
             return x
         return mod(x)
+
+
+    # ---- the same on csrc/backbone2d.hip: depthwise convolutions + per-view BatchNorm ----
+    def _run_hip(self, mod, x, v, residual=None):
+        """a Sequential walked with one module of look-ahead: a BatchNorm (+ ReLU) in front of a depthwise convolution
+        stays PENDING and is applied by that convolution on load; any other BatchNorm (+ ReLU) is statistics + one apply
+        pass, which also adds the block's skip (`residual`, at the last BatchNorm of an inverted-residual block)"""
+        if isinstance(mod, _InvertedResidual):
+            return self._run_hip(mod.layers, x, v, residual=x if mod.apply_residual else None)
+        if not isinstance(mod, nn.Sequential):
+            return mod(x)
+        mods = list(mod)
+        i, pending = 0, None
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.BatchNorm2d):
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                nxt = mods[i + 1 + int(relu)] if i + 1 + int(relu) < len(mods) else None
+                aff = bn_views_stats(m, x, v)
+                if _is_depthwise(nxt) and _hip_ok(x):
+                    pending = (aff, relu)
+                else:
+                    last = i + 1 + int(relu) >= len(mods)
+                    x = bn_views_apply(x, aff, v, relu, residual if last else None)
+                    if last:
+                        residual = None
+                i += 1 + int(relu)
+            elif _is_depthwise(m) and _hip_ok(x):
+                x = dwconv_nhwc(m, x, v, pending)
+                pending = None
+                i += 1
+            elif isinstance(m, (nn.Sequential, _InvertedResidual)):
+                x = self._run_hip(m, x, v)
+                i += 1
+            else:
+                assert pending is None
+                x = m(x)
+                i += 1
+        assert pending is None
+        return x if residual is None else x + residual
+
+
+def _is_depthwise(m):
+    return (isinstance(m, nn.Conv2d) and m.groups == m.in_channels == m.out_channels and m.groups > 1 and m.bias is None
+            and m.kernel_size in ((3, 3), (5, 5)) and m.stride in ((1, 1), (2, 2)) and m.padding == (m.kernel_size[0] // 2,) * 2
+            and m.dilation == (1, 1) and m.in_channels % 4 == 0)
+
+
+def _hip_ok(x):
+    return x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and x.shape[1] <= 480 \
+        and x.is_contiguous(memory_format=torch.channels_last)
+
+
+_COUNTERS = {}
+
+
+def _bn_counters(device):
+    """the statistics kernel's per-view tickets: zero between launches (the last workgroup of a view resets its ticket)"""
+    key = (device.type, device.index, _lib.current_stream())
+    buf = _COUNTERS.get(key)
+    if buf is None:
+        buf = _COUNTERS[key] = torch.zeros(256, dtype=torch.int32, device=device)
+    return buf
+
+
+def bn_views_stats(bn, x, v):
+    """train-mode BatchNorm2d of a channels-last [V*B, C, H, W] batch with separate statistics per view, as
+    (scale, shift) f32[V, 2, C] (eprecon_bn2d_views_stats_async); PyTorch ops when the map is not taken by the kernel"""
+    n, c, h, w = x.shape
+    rows = (n // v) * h * w
+    if not _hip_ok(x) or v > 256:
+        x5 = x.reshape(v, n // v, c, h * w).transpose(1, 2).reshape(v, c, -1)
+        var, mean = torch.var_mean(x5, dim=2, unbiased=False)
+        sc = bn.weight / torch.sqrt(var + bn.eps)
+        return torch.stack([sc, bn.bias - mean * sc], 1).contiguous()
+    lib = _lib.load()
+    aff = torch.empty((v, 2, c), dtype=torch.float32, device=x.device)
+    ws = _lib.workspace(lib.eprecon_bn2d_views_workspace_bytes(v, rows, c), x.device)
+    _lib.check(lib.eprecon_bn2d_views_stats_async(_lib.ptr(x), v, rows, c, _lib.ptr(bn.weight), _lib.ptr(bn.bias), float(bn.eps),
+                                                  _lib.ptr(aff), _lib.ptr(_bn_counters(x.device)), _lib.ptr(ws), ws.numel(),
+                                                  _lib.current_stream()), "eprecon_bn2d_views_stats_async")
+    return aff
+
+
+def bn_views_apply(x, aff, v, relu, residual=None):
+    """[relu](x * scale + shift) [+ residual] per view, in place on a channels-last map"""
+    n, c, h, w = x.shape
+    if not _hip_ok(x) or (residual is not None and not _hip_ok(residual)):
+        b = n // v
+        sc = aff[:, 0].repeat_interleave(b, 0)[:, :, None, None]
+        sh = aff[:, 1].repeat_interleave(b, 0)[:, :, None, None]
+        y = x * sc + sh
+        y = F.relu(y) if relu else y
+        return y if residual is None else y + residual
+    _lib.check(_lib.load().eprecon_bn2d_views_apply_async(_lib.ptr(x), v, (n // v) * h * w, c, _lib.ptr(aff), int(relu),
+                                                          _lib.ptr(residual), _lib.ptr(x), _lib.current_stream()),
+               "eprecon_bn2d_views_apply_async")
+    return x
+
+
+def _dw_taps(conv):
+    """[C, 1, k, k] -> tap-major [k*k, C], cached per weight version"""
+    w = conv.weight
+    tag = (w._version, w.data_ptr())
+    hit = getattr(conv, "_eprecon_packed", None)
+    if hit is None or hit[0] != tag:
+        hit = (tag, w.detach().reshape(w.shape[0], -1).t().contiguous())
+        conv._eprecon_packed = hit
+    return hit[1]
+
+
+def dwconv_nhwc(conv, x, v, pending=None):
+    """depthwise conv of a channels-last map on eprecon_dwconv2d_nhwc_async; pending = ((scale, shift) f32[V,2,C], relu):
+    the producer's BatchNorm (+ ReLU), applied on load"""
+    n, c, h, w = x.shape
+    k, s = conv.kernel_size[0], conv.stride[0]
+    ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+    out = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    aff, relu = pending if pending is not None else (None, False)
+    _lib.check(_lib.load().eprecon_dwconv2d_nhwc_async(_lib.ptr(x), n, h, w, c, _lib.ptr(_dw_taps(conv)), k, s, _lib.ptr(aff),
+                                                       max(n // v, 1), int(relu), _lib.ptr(out), _lib.current_stream()),
+               "eprecon_dwconv2d_nhwc_async")
+    return out
 
 
 def _bn_per_view(bn, x, v):
