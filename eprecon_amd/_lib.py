@@ -118,9 +118,9 @@ SIGNATURES = {
     "eprecon_profile_conv_ms": (_f, [_c.POINTER(_i64), _c.POINTER(_c.c_char_p)]),
     "eprecon_profile_conv_pairs": (_i64, []),
     "eprecon_mlp4x_supported": (_i, [_i, _i]),
-    "eprecon_bn2d_views_chunks": (_i, [_i64]),
+    "eprecon_bn2d_views_chunks": (_i, [_i64, _i]),
     "eprecon_bn2d_views_workspace_bytes": (_sz, [_i, _i64, _i]),
-    "eprecon_bn2d_views_stats_async": (_i, [_vp, _i, _i64, _i, _vp, _vp, _f, _vp, _vp, _vp, _sz, _vp]),
+    "eprecon_bn2d_views_stats_async": (_i, [_vp, _i, _i64, _i, _vp, _vp, _f, _vp, _vp, _sz, _vp]),
     "eprecon_bn2d_views_apply_async": (_i, [_vp, _i, _i64, _i, _vp, _i, _vp, _vp, _vp]),
     "eprecon_dwconv2d_nhwc_async": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "eprecon_mlp4x_async": (_i, [_vp, _vp]),

@@ -172,18 +172,6 @@ def _hip_ok(x):
         and x.is_contiguous(memory_format=torch.channels_last)
 
 
-_COUNTERS = {}
-
-
-def _bn_counters(device):
-    """the statistics kernel's per-view tickets: zero between launches (the last workgroup of a view resets its ticket)"""
-    key = (device.type, device.index, _lib.current_stream())
-    buf = _COUNTERS.get(key)
-    if buf is None:
-        buf = _COUNTERS[key] = torch.zeros(256, dtype=torch.int32, device=device)
-    return buf
-
-
 def bn_views_stats(bn, x, v):
     """train-mode BatchNorm2d of a channels-last [V*B, C, H, W] batch with separate statistics per view, as
     (scale, shift) f32[V, 2, C] (eprecon_bn2d_views_stats_async); PyTorch ops when the map is not taken by the kernel"""
@@ -198,7 +186,7 @@ def bn_views_stats(bn, x, v):
     aff = torch.empty((v, 2, c), dtype=torch.float32, device=x.device)
     ws = _lib.workspace(lib.eprecon_bn2d_views_workspace_bytes(v, rows, c), x.device)
     _lib.check(lib.eprecon_bn2d_views_stats_async(_lib.ptr(x), v, rows, c, _lib.ptr(bn.weight), _lib.ptr(bn.bias), float(bn.eps),
-                                                  _lib.ptr(aff), _lib.ptr(_bn_counters(x.device)), _lib.ptr(ws), ws.numel(),
+                                                  _lib.ptr(aff), _lib.ptr(ws), ws.numel(),
                                                   _lib.current_stream()), "eprecon_bn2d_views_stats_async")
     return aff
 

@@ -4,11 +4,9 @@
 // naive reference kernel (1.85 of the 4.4 ms of a 9-view pass, profiles/r04/backbone_kernels.txt) and PyTorch's instance-norm
 // route costs four launches per BatchNorm; the point-wise (1 x 1) layers are plain GEMMs and stay on hipBLASLt.
 //
-//   bn_views_stats_kernel   per (view, channel) mean / biased variance -> the BatchNorm as (scale, shift) per view.  A view's rows
-//                           are cut into `chunks` ranges (one workgroup each: shifted sums -> (n, mean, M2)); the LAST
-//                           workgroup of a view to finish merges the chunk summaries in chunk order (Chan) and writes
-//                           scale = g / sqrt(var + eps), shift = b - mean * scale.  Deterministic: the merge order is fixed,
-//                           the ticket only decides WHO merges.
+//   bn_views_stats_kernel   a view's rows are cut into `chunks` ranges, one workgroup each: shifted sums -> (n, mean, M2) per channel
+//   bn_views_finalize_kernel  the range summaries of a view merged in range order (Chan) -> the BatchNorm as
+//                           scale = g / sqrt(var + eps), shift = b - mean * scale per (view, channel).  Deterministic.
 //   bn_views_apply_kernel   y = [relu](x * scale + shift) [+ residual]   (in place or not)
 //   dwconv_nhwc_kernel      out[n, oy, ox, c] = sum_taps w[tap][c] * f(x[n, oy S + dy - P, ox S + dx - P, c]) with zero padding;
 //                           f = the PENDING BatchNorm + ReLU of the producer (scale / shift of the pixel's view) when given: the
@@ -24,7 +22,6 @@ struct BnViewsParams {
     const float *x;
     int rows_per_view, C, chunks;
     float *partial;          // [V][chunks][3][C]
-    int *counters;           // [V], zero between launches
     const float *gamma, *beta;
     float eps;
     float *affine;           // [V][2][C]
@@ -33,7 +30,6 @@ struct BnViewsParams {
 __global__ __launch_bounds__(256) void bn_views_stats_kernel(BnViewsParams p)
 {
     __shared__ float sS[1024], sQ[1024];
-    __shared__ int sLast;
     const int tid = threadIdx.x, view = blockIdx.y, chunk = blockIdx.x;
     const int C = p.C, C4 = C >> 2, R = 256 / C4;
     const int c4 = tid % C4, r = tid / C4;
@@ -43,7 +39,20 @@ __global__ __launch_bounds__(256) void bn_views_stats_kernel(BnViewsParams p)
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s, pv = s;
     if (r < R && r0 < r1) {
         pv = *reinterpret_cast<const float4 *>(base + (size_t)r0 * C + 4 * c4);     // pivot: the sums run on x - pivot
-        for (int row = r0 + r; row < r1; row += R) {
+        // four rows in flight per thread (independent loads, one accumulator pair: the adds are cheap, the latency is not)
+        int row = r0 + r;
+        for (; row + 3 * R < r1; row += 4 * R) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(base + (size_t)(row + u * R) * C + 4 * c4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float dx = v[u].x - pv.x, dy = v[u].y - pv.y, dz = v[u].z - pv.z, dw = v[u].w - pv.w;
+                s.x += dx; s.y += dy; s.z += dz; s.w += dw;
+                q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
+            }
+        }
+        for (; row < r1; row += R) {
             const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)row * C + 4 * c4);
             const float dx = v.x - pv.x, dy = v.y - pv.y, dz = v.z - pv.z, dw = v.w - pv.w;
             s.x += dx; s.y += dy; s.z += dz; s.w += dw;
@@ -66,30 +75,41 @@ __global__ __launch_bounds__(256) void bn_views_stats_kernel(BnViewsParams p)
         dst[C + c] = pivot + dm;
         dst[2 * C + c] = fmaxf(tq - ts * dm, 0.0f);
     }
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) sLast = atomicAdd(p.counters + view, 1) == p.chunks - 1;
-    __syncthreads();
-    if (!sLast) return;
-    __threadfence();
+}
+
+// (scale, shift) of a view from its range summaries: Chan's pairwise update in range order.  A second launch, not a "last
+// workgroup merges" epilogue of the first: that needs a device-scope fence in every workgroup, and on a part whose eight XCDs
+// have private L2s each such fence writes the L2 back — measured 40-50 us per BatchNorm against ~10 for the two launches.
+__global__ __launch_bounds__(64) void bn_views_finalize_kernel(BnViewsParams p)
+{
+    const int tid = blockIdx.y * 64 + threadIdx.x, view = blockIdx.x, C = p.C;
     const float *src = p.partial + (size_t)view * p.chunks * 3 * C;
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += 64 * (int)gridDim.y) {
         float n = 0.0f, mean = 0.0f, m2 = 0.0f;
-        for (int k = 0; k < p.chunks; ++k) {          // Chan's pairwise update, chunk order
-            const float nb = src[(size_t)k * 3 * C + c];
-            if (nb <= 0.0f) continue;
-            const float mb = src[(size_t)k * 3 * C + C + c], qb = src[(size_t)k * 3 * C + 2 * C + c];
-            const float nn = n + nb, d = mb - mean;
-            mean += d * (nb / nn);
-            m2 += qb + d * d * (n * nb / nn);
-            n = nn;
+        for (int k0 = 0; k0 < p.chunks; k0 += 16) {   // 48 loads in flight, then Chan's pairwise update in chunk order
+            float nb[16], mb[16], qb[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const bool ok = k0 + u < p.chunks;
+                const float *e = src + (size_t)(ok ? k0 + u : 0) * 3 * C + c;
+                nb[u] = ok ? e[0] : 0.0f;
+                mb[u] = e[C];
+                qb[u] = e[2 * C];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (nb[u] <= 0.0f) continue;
+                const float nn = n + nb[u], d = mb[u] - mean;
+                mean += d * (nb[u] / nn);
+                m2 += qb[u] + d * d * (n * nb[u] / nn);
+                n = nn;
+            }
         }
         const float var = n > 0.0f ? m2 / n : 0.0f;
         const float sc = (p.gamma ? p.gamma[c] : 1.0f) / sqrtf(var + p.eps);
         p.affine[(size_t)view * 2 * C + c] = sc;
         p.affine[(size_t)view * 2 * C + C + c] = (p.beta ? p.beta[c] : 0.0f) - mean * sc;
     }
-    if (tid == 0) p.counters[view] = 0;
 }
 
 __global__ __launch_bounds__(256) void bn_views_apply_kernel(const float *x, const float *affine, const float *residual, float *out,
@@ -119,18 +139,22 @@ struct DwParams {
     int N, H, W, C, Ho, Wo, imgs_per_view, relu;
 };
 
-template <int K, int S>
+// PX output pixels of a row per thread: the K + (PX - 1) S input columns of a tap row are loaded (and BatchNorm'ed) once and
+// shared by the PX outputs — 10 loads per output instead of 25 for the 5 x 5 stride-1 layers.  Every output still sums its taps in
+// (dy, dx) order.
+template <int K, int S, int PX>
 __global__ __launch_bounds__(256) void dwconv_nhwc_kernel(DwParams p)
 {
-    constexpr int P = K / 2;
+    constexpr int P = K / 2, COLS = K + (PX - 1) * S;
     const int C4 = p.C >> 2;
-    const long long total = (long long)p.N * p.Ho * p.Wo * C4;
+    const int wg = (p.Wo + PX - 1) / PX;
+    const long long total = (long long)p.N * p.Ho * wg * C4;
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     const int c4 = (int)(e % C4);
     long long pix = e / C4;
-    const int ox = (int)(pix % p.Wo);
-    pix /= p.Wo;
+    const int ox0 = (int)(pix % wg) * PX;
+    pix /= wg;
     const int oy = (int)(pix % p.Ho);
     const int n = (int)(pix / p.Ho);
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -141,25 +165,49 @@ __global__ __launch_bounds__(256) void dwconv_nhwc_kernel(DwParams p)
     }
     const float *img = p.x + (size_t)n * p.H * p.W * p.C + 4 * c4;
     const float *wq = p.w + 4 * c4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc[PX];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int dy = 0; dy < K; ++dy) {
         const int iy = oy * S + dy - P;
         if (iy < 0 || iy >= p.H) continue;
+        float4 v[COLS];
+#pragma unroll
+        for (int cx = 0; cx < COLS; ++cx) {
+            const int ix = ox0 * S + cx - P;
+            v[cx] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ix >= 0 && ix < p.W) {
+                float4 t = *reinterpret_cast<const float4 *>(img + ((size_t)iy * p.W + ix) * p.C);
+                if (p.affine) {
+                    t.x = t.x * sc.x + sh.x; t.y = t.y * sc.y + sh.y; t.z = t.z * sc.z + sh.z; t.w = t.w * sc.w + sh.w;
+                    if (p.relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+                }
+                v[cx] = t;
+            }
+        }
 #pragma unroll
         for (int dx = 0; dx < K; ++dx) {
-            const int ix = ox * S + dx - P;
-            if (ix < 0 || ix >= p.W) continue;
-            float4 v = *reinterpret_cast<const float4 *>(img + ((size_t)iy * p.W + ix) * p.C);
-            if (p.affine) {
-                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            }
             const float4 w = *reinterpret_cast<const float4 *>(wq + (size_t)(dy * K + dx) * p.C);
-            acc.x = fmaf(v.x, w.x, acc.x); acc.y = fmaf(v.y, w.y, acc.y); acc.z = fmaf(v.z, w.z, acc.z); acc.w = fmaf(v.w, w.w, acc.w);
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                const float4 t = v[j * S + dx];
+                acc[j].x = fmaf(t.x, w.x, acc[j].x); acc[j].y = fmaf(t.y, w.y, acc[j].y);
+                acc[j].z = fmaf(t.z, w.z, acc[j].z); acc[j].w = fmaf(t.w, w.w, acc[j].w);
+            }
         }
     }
-    reinterpret_cast<float4 *>(p.out)[e] = acc;
+    float *orow = p.out + (((size_t)n * p.Ho + oy) * p.Wo) * p.C + 4 * c4;
+#pragma unroll
+    for (int j = 0; j < PX; ++j)
+        if (ox0 + j < p.Wo) *reinterpret_cast<float4 *>(orow + (size_t)(ox0 + j) * p.C) = acc[j];
+}
+
+template <int K, int S, int PX>
+void launch_dw(const DwParams &p, hipStream_t st)
+{
+    const long long total = (long long)p.N * p.Ho * ((p.Wo + PX - 1) / PX) * (p.C / 4);
+    hipLaunchKernelGGL((dwconv_nhwc_kernel<K, S, PX>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, p);
 }
 
 bool aligned16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -168,26 +216,36 @@ bool aligned16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 
 
 extern "C" {
 
-int eprecon_bn2d_views_chunks(int64_t rows_per_view) { return rows_per_view >= 16384 ? 32 : (rows_per_view >= 2048 ? 16 : 4); }
+// A workgroup has 256 / (channels / 4) row lanes; a range is ~16 rows per lane (a thread's loop is a chain of load latencies,
+// four in flight), at most 128 ranges per view (the last workgroup of a view merges them).
+int eprecon_bn2d_views_chunks(int64_t rows_per_view, int channels)
+{
+    if (channels < 4) return 1;
+    const int64_t lanes = 256 / (channels / 4) > 0 ? 256 / (channels / 4) : 1;
+    const int64_t c = (rows_per_view + lanes * 16 - 1) / (lanes * 16);
+    return (int)(c < 1 ? 1 : (c > 128 ? 128 : c));
+}
 
 size_t eprecon_bn2d_views_workspace_bytes(int views, int64_t rows_per_view, int channels)
 {
     if (views <= 0 || channels <= 0) return 0;
-    return (size_t)views * eprecon_bn2d_views_chunks(rows_per_view) * 3 * channels * sizeof(float);
+    return (size_t)views * eprecon_bn2d_views_chunks(rows_per_view, channels) * 3 * channels * sizeof(float);
 }
 
 int eprecon_bn2d_views_stats_async(const float *x, int views, int64_t rows_per_view, int channels, const float *gamma,
-                                   const float *beta, float eps, float *affine_out, int32_t *counters, void *workspace,
+                                   const float *beta, float eps, float *affine_out, void *workspace,
                                    size_t workspace_bytes, void *stream)
 {
     if (views < 0 || rows_per_view < 0 || channels <= 0 || channels % 4 || channels > 480 || rows_per_view > 0x7fffffff) return EPRECON_ERR_ARG;
     if (views == 0) return EPRECON_OK;
-    if (!x || !affine_out || !counters || !workspace || !aligned16(x) || !aligned16(affine_out)) return EPRECON_ERR_ARG;
+    if (!x || !affine_out || !workspace || !aligned16(x) || !aligned16(affine_out)) return EPRECON_ERR_ARG;
     if (workspace_bytes < eprecon_bn2d_views_workspace_bytes(views, rows_per_view, channels)) return EPRECON_ERR_WORKSPACE;
     BnViewsParams p;
-    p.x = x; p.rows_per_view = (int)rows_per_view; p.C = channels; p.chunks = eprecon_bn2d_views_chunks(rows_per_view);
-    p.partial = (float *)workspace; p.counters = counters; p.gamma = gamma; p.beta = beta; p.eps = eps; p.affine = affine_out;
+    p.x = x; p.rows_per_view = (int)rows_per_view; p.C = channels; p.chunks = eprecon_bn2d_views_chunks(rows_per_view, channels);
+    p.partial = (float *)workspace; p.gamma = gamma; p.beta = beta; p.eps = eps; p.affine = affine_out;
     hipLaunchKernelGGL(bn_views_stats_kernel, dim3((unsigned)p.chunks, (unsigned)views), dim3(256), 0, (hipStream_t)stream, p);
+    EP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_views_finalize_kernel, dim3((unsigned)views, (unsigned)ceil_div(channels, 64)), dim3(64), 0, (hipStream_t)stream, p);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }
@@ -222,12 +280,12 @@ int eprecon_dwconv2d_nhwc_async(const float *x, int n, int height, int width, in
     p.imgs_per_view = imgs_per_view; p.relu = relu;
     const long long total = (long long)n * p.Ho * p.Wo * (channels / 4);
     if (total > 0x7fffffffll * 256) return EPRECON_ERR_UNSUPPORTED;
-    const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (ksize == 3 && stride == 1) hipLaunchKernelGGL((dwconv_nhwc_kernel<3, 1>), grid, block, 0, st, p);
-    else if (ksize == 3) hipLaunchKernelGGL((dwconv_nhwc_kernel<3, 2>), grid, block, 0, st, p);
-    else if (stride == 1) hipLaunchKernelGGL((dwconv_nhwc_kernel<5, 1>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((dwconv_nhwc_kernel<5, 2>), grid, block, 0, st, p);
+    // (a padded input value enters an output's sum as fmaf(0, w, acc) = acc: the (dy, dx) order of a sum does not depend on PX)
+    if (ksize == 3 && stride == 1) launch_dw<3, 1, 4>(p, st);
+    else if (ksize == 3) launch_dw<3, 2, 2>(p, st);
+    else if (stride == 1) launch_dw<5, 1, 4>(p, st);
+    else launch_dw<5, 2, 2>(p, st);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }

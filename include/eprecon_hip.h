@@ -753,18 +753,18 @@ int eprecon_mlp4x_async(const eprecon_mlp4x_desc *desc, void *stream);
  *
  * eprecon_bn2d_views_stats_async: rows [views][rows_per_view][channels] (a view's images x pixels) -> affine_out
  *   f32[views][2][channels] = (scale, shift) of the train-mode BatchNorm of each view (biased variance, eps inside the root):
- *   y = x * scale + shift.  counters: int32[views], zero on entry and on completion (a persistent zero-initialised buffer);
- *   workspace: eprecon_bn2d_views_workspace_bytes.  Deterministic.  channels <= 480.
+ *   y = x * scale + shift.  workspace: eprecon_bn2d_views_workspace_bytes.  Two launches (range summaries, merge in range
+ *   order): deterministic.  channels <= 480.
  * eprecon_bn2d_views_apply_async: out = [relu](x * scale + shift) [+ residual]; out may be x.
  * eprecon_dwconv2d_nhwc_async: depthwise ksize x ksize (3 or 5), stride 1 or 2, zero padding ksize / 2, no bias;
  *   weight_taps f32[ksize * ksize][channels] (tap-major: torch's [C,1,k,k] weight transposed).  affine (optional,
  *   f32[views][2][channels]): the producer's pending BatchNorm (+ ReLU when relu != 0) applied to every loaded input value
  *   (padding stays zero); image i belongs to view i / imgs_per_view.  out f32[n][ho][wo][channels].
  * ------------------------------------------------------------------------------------------ */
-int eprecon_bn2d_views_chunks(int64_t rows_per_view);
+int eprecon_bn2d_views_chunks(int64_t rows_per_view, int channels);
 size_t eprecon_bn2d_views_workspace_bytes(int views, int64_t rows_per_view, int channels);
 int eprecon_bn2d_views_stats_async(const float *x, int views, int64_t rows_per_view, int channels, const float *gamma,
-                                   const float *beta, float eps, float *affine_out, int32_t *counters, void *workspace,
+                                   const float *beta, float eps, float *affine_out, void *workspace,
                                    size_t workspace_bytes, void *stream);
 int eprecon_bn2d_views_apply_async(const float *x, int views, int64_t rows_per_view, int channels, const float *affine, int relu,
                                    const float *residual, float *out, void *stream);
