@@ -279,6 +279,29 @@ def workspace(nbytes, device):
     return buf
 
 
+# Device-side values whose check rides on a LATER blocking read instead of costing one of their own: (int32 device element,
+# expected value, message).  The next read site that drains the list (grid_ops.sparsify) raises EpreconError on a mismatch.
+_DEFERRED = []
+
+
+def defer_check(dev_value, expected, what):
+    _DEFERRED.append((dev_value, int(expected), what))
+    if len(_DEFERRED) > 16:        # (a path that never reaches a draining read: keep the newest only)
+        del _DEFERRED[0]
+
+
+def take_deferred():
+    out = list(_DEFERRED)
+    _DEFERRED.clear()
+    return out
+
+
+def verify_deferred(items, host_values):
+    for (_, expected, what), got in zip(items, host_values):
+        if int(got) != expected:
+            raise EpreconError(f"{what}: expected {expected}, the device reports {int(got)} (EPRECON_ERR_ARG)")
+
+
 HOST_READS = 0    # blocking device -> host reads issued by the package since import (bench.py: blocking_reads_per_fragment)
 
 

@@ -135,6 +135,23 @@ def run(coords, origin, voxel_size, feats, krcam, min_view, mode=MODE_MEAN, min_
     ws_bytes = lib.eprecon_back_project_workspace_bytes(n, b, v, c, h, w, layout)
     ws = _lib.workspace(ws_bytes, dev)
 
+    if min_view <= 0 and b == 1 and n >= max(int(min_valid_per_batch), 1):
+        # every voxel is valid (the view count is never negative; the one batch element owns all rows): nothing to wait for.
+        # The count is still produced on the device and checked with the level's next blocking read (a batch index out of
+        # range is the one way a row can drop out).
+        _lib.check(lib.eprecon_back_project_async(
+            _lib.ptr(coords_i), n, _lib.ptr(origin_f), b, float(voxel_size), _lib.ptr(feats_c), layout,
+            _lib.ptr(krcam_f), v, c, h, w, int(min_view), mode, _lib.ptr(out_feats), _lib.ptr(out_mean), _lib.ptr(out_coords),
+            _lib.ptr(count), _lib.ptr(out_grid), _lib.ptr(out_mask), _lib.ptr(n_valid_dev), _lib.ptr(ws), ws.numel(),
+            _lib.current_stream()), "eprecon_back_project_async")
+        _lib.defer_check(n_valid_dev[0:1], n, "back-projection with min_view <= 0: rows with a batch index out of range")
+        res = {"feats": out_feats, "coords": out_coords, "count": count, "n_valid": n, "n_valid_per_batch": [n]}
+        if want_grid:
+            res["grid"] = out_grid.view(v, n, 2)
+            res["mask"] = out_mask.view(v, n).bool()
+        if want_mean:
+            res["mean"] = out_mean
+        return res
     _lib.count_host_read()
     rc = lib.eprecon_back_project(
         _lib.ptr(coords_i), n, _lib.ptr(origin_f), b, float(voxel_size), _lib.ptr(feats_c), layout,

@@ -90,9 +90,20 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *partial, 
     __shared__ float sN[256], sMean[256], sM2[256];
     const int c = blockIdx.x, tid = threadIdx.x;
     float a_n = 0.0f, a_mean = 0.0f, a_m2 = 0.0f;
-    for (int b = tid; b < nblk; b += 256) {
-        const float *p = partial + (size_t)b * 3 * C;
-        chan_merge(a_n, a_mean, a_m2, p[c], p[C + c], p[2 * C + c]);
+    // (the summaries of four rows are loaded before the first is merged: the chain of load latencies, not the arithmetic, is
+    // what this kernel costs; the merge order — rows t, t + 256, ... — is unchanged)
+    for (int b = tid; b < nblk; b += 4 * 256) {
+        float vn[4], vm[4], vq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int bb = b + u * 256;
+            const float *p = partial + (size_t)(bb < nblk ? bb : b) * 3 * C;
+            vn[u] = bb < nblk ? p[c] : 0.0f;
+            vm[u] = p[C + c];
+            vq[u] = p[2 * C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) chan_merge(a_n, a_mean, a_m2, vn[u], vm[u], vq[u]);
     }
     sN[tid] = a_n; sMean[tid] = a_mean; sM2[tid] = a_m2;
     __syncthreads();
@@ -120,9 +131,20 @@ __global__ __launch_bounds__(256) void bn_finalize_affine_kernel(const float *pa
     __shared__ float sN[4], sMean[4], sM2[4];
     const int c = blockIdx.x, tid = threadIdx.x;
     float a_n = 0.0f, a_mean = 0.0f, a_m2 = 0.0f;
-    for (int b = tid; b < nblk; b += 256) {
-        const float *p = partial + (size_t)b * 3 * C;
-        chan_merge(a_n, a_mean, a_m2, p[c], p[C + c], p[2 * C + c]);
+    // (the summaries of four rows are loaded before the first is merged: the chain of load latencies, not the arithmetic, is
+    // what this kernel costs; the merge order — rows t, t + 256, ... — is unchanged)
+    for (int b = tid; b < nblk; b += 4 * 256) {
+        float vn[4], vm[4], vq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int bb = b + u * 256;
+            const float *p = partial + (size_t)(bb < nblk ? bb : b) * 3 * C;
+            vn[u] = bb < nblk ? p[c] : 0.0f;
+            vm[u] = p[C + c];
+            vq[u] = p[2 * C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) chan_merge(a_n, a_mean, a_m2, vn[u], vm[u], vq[u]);
     }
     const int lane = tid & 63;
 #pragma unroll

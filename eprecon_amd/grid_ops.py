@@ -117,6 +117,12 @@ def sparsify(occ, threshold, target, coords, tsdf, feat_all, c_feat, batch_size)
         _lib.ptr(out_occ), _lib.ptr(out_all), _lib.ptr(out_feat), _lib.ptr(counts), _lib.ptr(ws), ws.numel(),
         _lib.current_stream()), "eprecon_sparsify_async")
     _lib.count_host_read()
-    host = counts.tolist()
+    pending = _lib.take_deferred()            # checks that ride on this read (back-projection without a read of its own)
+    if pending:
+        host = torch.cat([counts] + [t.reshape(1) for t, _, _ in pending]).tolist()
+        _lib.verify_deferred(pending, host[counts.numel():])
+        host = host[:counts.numel()]
+    else:
+        host = counts.tolist()
     m = host[0]
     return host, out_coords[:m], out_tsdf[:m], out_occ[:m], out_all[:m], out_feat[:m]

@@ -520,22 +520,26 @@ def panoptic_inference(mask_cls, mask_pred, object_mask_threshold=0.3, thing_id=
     scores, labels = F.softmax(mask_cls, dim=-1).max(-1)
     prob = mask_pred.sigmoid()
     keep = labels.ne(0) & (scores > object_mask_threshold)
-    _lib.count_host_read(3)           # (boolean indexing sizes its result on the host; then the two .cpu() below)
-    cur_scores, cur_classes, cur_masks = scores[keep], labels[keep], prob[keep]
-    n = cur_masks.shape[-1]
+    n = prob.shape[-1]
     seg = torch.zeros(n, dtype=torch.int32, device=prob.device)
     info = []
-    if cur_masks.shape[0] == 0:
+    # The reference compacts the kept queries first (boolean indexing: a host read) and reads two more tensors back; here
+    # the dropped queries stay in place with a score below every kept one, and the per-query counts, the keep flags and the
+    # classes come back in ONE read.  Kept queries keep their relative order, so the ids come out the same.
+    q = prob.shape[0]
+    weighted = torch.where(keep.view(-1, 1), scores.view(-1, 1) * prob, prob.new_full((), -1.0))
+    owner = weighted.argmax(0)
+    confident = (prob >= 0.5) & keep.view(-1, 1)
+    onehot = (owner.unsqueeze(0) == torch.arange(q, device=owner.device).unsqueeze(1)) & keep.view(-1, 1)
+    _lib.count_host_read()
+    host = torch.stack([onehot.sum(1), confident.sum(1), (onehot & confident).sum(1), keep.long(), labels.long()]).cpu()
+    stats, kept, classes = host[:3], host[3].tolist(), host[4].tolist()
+    if not any(kept):
         return [seg, info]
-    owner = (cur_scores.view(-1, 1) * cur_masks).argmax(0)
-    confident = cur_masks >= 0.5
-    # all per-query counts in three reductions (the reference syncs three times per query)
-    q = cur_masks.shape[0]
-    onehot = owner.unsqueeze(0) == torch.arange(q, device=owner.device).unsqueeze(1)
-    stats = torch.stack([onehot.sum(1), confident.sum(1), (onehot & confident).sum(1)]).cpu()
-    classes = cur_classes.cpu().tolist()
     seg_id, stuff_ids = 0, {}
     for k in range(q):
+        if not kept[k]:
+            continue
         mask_area, original_area, joint = (int(v) for v in stats[:, k])
         if mask_area > 0 and original_area > 0 and joint > 0:
             if mask_area / original_area < overlap_threshold:

@@ -384,8 +384,12 @@ class NeuConNet(nn.Module):
         outputs['panoptic_levels'] and outputs['panoptic_out'] on the current stream"""
         keep1, keep0 = self.prune_to_ancestors(panoptic_coords)
         # (one nonzero per level, shared by the coordinates and the features: boolean indexing runs it once per tensor)
-        _lib.count_host_read(2)           # (torch.nonzero synchronises to size its result)
-        i1, i0 = torch.nonzero(keep1).squeeze(1), torch.nonzero(keep0).squeeze(1)
+        # both counts in ONE read, then the row lists with their sizes given (torch.nonzero sizes its result on the host: two
+        # reads)
+        _lib.count_host_read()
+        n1, n0 = torch.stack([keep1.sum(), keep0.sum()]).tolist()
+        i1 = torch.nonzero_static(keep1, size=n1).squeeze(1)
+        i0 = torch.nonzero_static(keep0, size=n0).squeeze(1)
         panoptic_coords[1], panoptic_voxel_feats[1] = panoptic_coords[1].index_select(0, i1), panoptic_voxel_feats[1].index_select(0, i1)
         panoptic_coords[0], panoptic_voxel_feats[0] = panoptic_coords[0].index_select(0, i0), panoptic_voxel_feats[0].index_select(0, i0)
         for p in range(3):
