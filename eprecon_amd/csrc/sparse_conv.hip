@@ -2093,11 +2093,11 @@ int conv_dispatch(ConvParams &p, int64_t n_in, hipStream_t st)
         bool narrow;
         if (conv3d_tile_ok(p, &narrow))
             hipLaunchKernelGGL(count_grid_pairs_kernel, dim3(256), dim3(256), 0, st, p.vox_rank, p.gx, p.gy, p.gz, g.pairs_dev);
-        else if (p.nbr)
+        else if (p.nbr) {
             hipLaunchKernelGGL(count_map_pairs_kernel, dim3(256), dim3(256), 0, st, p.nbr, (size_t)p.K * p.n_out, g.pairs_dev);
-        if (p.nbr && !strcmp(g.kernel, "spconv_direct16_kernel"))
-            hipLaunchKernelGGL(count_map_groups_kernel, dim3(256), dim3(256), 0, st, p.nbr, p.n_out, p.K, g.pairs_dev + 1);
-        else  // identity map
+            if (!strcmp(g.kernel, "spconv_direct16_kernel"))
+                hipLaunchKernelGGL(count_map_groups_kernel, dim3(256), dim3(256), 0, st, p.nbr, p.n_out, p.K, g.pairs_dev + 1);
+        } else  // identity map
             EP_HIP_CHECK(hipMemcpyAsync(g.pairs_dev, &g.rows, sizeof(unsigned long long), hipMemcpyHostToDevice, st));
         EP_LAUNCH_CHECK();
     }

@@ -52,6 +52,9 @@ d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in sel]
 print(f"rocprofv3 kernel trace: {len(d)} launches of {sel[0]['Kernel_Name'][:60]} with grid {sel[0]['Grid_Size_X']}: avg {sum(d) / len(d):.1f} us, min {min(d):.1f}, max {max(d):.1f}")
 PY
 rm -rf $O/conv_instance/*/*kernel_trace.csv $O/conv_instance/*kernel_trace.csv
+# 5b. the 2D feeder alone (kernel list), and where the HOST time of a cfg4 fragment goes
+bash tools/r04_backbone.sh r04_final/bb > $P/backbone_kernels.txt 2>/dev/null
+python tools/profile_cfg4_host.py 8 2>/dev/null > $P/cfg4_host_profile.txt
 # 6. dead offsets in the kernel maps of a fragment; the 3x3x3 shapes of a fragment one by one
 python tools/conv_tile_liveness.py 2>/dev/null > $P/conv_tile_liveness.txt
 python tools/conv_shapes_ab.py round4 2>/dev/null > $P/conv_shapes.txt
