@@ -1998,8 +1998,8 @@ int launch_wide(const ConvParams &p, hipStream_t st) { return (p.Cout + 31) / 32
 // short list + long (offset, slab) chain + a caller that can take 32-row BatchNorm summary blocks
 bool splitk_ok(const ConvParams &p)
 {
-    static const bool on = !(getenv("EPRECON_CONV_SPLITK") && getenv("EPRECON_CONV_SPLITK")[0] == '0');
-    if (!on || p.accumulate) return false;
+    const char *e = getenv("EPRECON_CONV_SPLITK");   // (per launch, like the other selection switches)
+    if ((e && e[0] == '0') || p.accumulate) return false;
     if (p.bn_partial && !p.flex_partial) return false;
     const int nt_full = (p.Cout + 31) / 32;
     if (p.ln && nt_full > 1) return false;

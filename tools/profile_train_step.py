@@ -8,7 +8,7 @@ import torch
 from eprecon_amd.fragment_step import TrainStep
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-s = TrainStep(seed=0)
+s = TrainStep(seed=0, lr=1e-6)      # (lr: see bench.py, extra_workloads.train)
 for _ in range(3):
     s.run()
 torch.cuda.synchronize()
