@@ -24,7 +24,7 @@ def run_scene(step):
         o = step.run()
         info = o.get("panoptic_info")
         out.append({"coords": o["coords"].clone(), "tsdf": o["tsdf"].clone(),
-                    "segments": None if info is None else len(info[0][1])})
+                    "segments": None if info is None else len(info[0]["panoptic_seg"][1])})
     torch.cuda.synchronize()
     return out
 
@@ -145,11 +145,22 @@ def test_pipelined_modes(scene, default_run):
 
 
 def test_exchange_forced_at_one_rank(scene, default_run, monkeypatch):
-    """EPRECON_FORCE_EXCHANGE=1 (+ EPRECON_XCHG_STREAM=0): the boundary exchange path with nobody to exchange with"""
-    monkeypatch.setattr(scene.net, "distributed_exchange", True)
-    assert_same_scene(default_run, run_scene(scene), exact=True)
-    monkeypatch.setenv("EPRECON_XCHG_STREAM", "0")
-    assert_same_scene(default_run, run_scene(scene), exact=True)
+    """EPRECON_FORCE_EXCHANGE=1 (+ EPRECON_XCHG_STREAM=0): the boundary exchange path (selection kernels on the map handles,
+    RCCL collectives in a single-rank group, stamps) with nobody to exchange with — on its own stream and on the main one"""
+    import socket
+    import torch.distributed as dist
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        monkeypatch.setattr(scene.net, "distributed_exchange", True)
+        assert_same_scene(default_run, run_scene(scene), exact=True)
+        monkeypatch.setenv("EPRECON_XCHG_STREAM", "0")
+        assert_same_scene(default_run, run_scene(scene), exact=True)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
 
 
 # EPRECON_CFG2_DEFER: tests/test_cfg2_step_gpu.py (deferred reads and level order do not change the outputs).
@@ -166,5 +177,5 @@ def test_bench_line_through_a_single_rank_process_group():
                LOCAL_RANK="0")
     out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1",
                                    "--no-cpu-baseline", "--no-extra"], env=env, cwd=root, stderr=subprocess.DEVNULL)
-    line = json.loads(out.decode().strip().splitlines()[-1])
+    line = json.loads([l for l in out.decode().splitlines() if l.startswith("{")][-1])   # (RCCL prints its banner at exit)
     assert line["metric"] == "fragments_per_sec" and line["n_gpus"] == 1 and line["value"] > 0 and "roofline" in line
