@@ -69,6 +69,8 @@ SIGNATURES = {
     "eprecon_segment_lists_async": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "eprecon_segment_mean_async": (_i, [_vp, _i, _vp, _vp, _i64, _i, _vp, _i, _vp]),
     "eprecon_sphash_async": (_i, [_vp, _i64, _vp, _vp]),
+    "eprecon_sphash_order_workspace_bytes": (_sz, [_i64]),
+    "eprecon_sphash_order_async": (_i, [_vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "eprecon_remap_index_async": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _vp]),
     "eprecon_trilinear_map_async": (_i, [_vp, _c.c_uint32, _vp, _i64, _i, _vp, _vp, _vp]),
     "eprecon_devoxelize_async": (_i, [_vp, _i, _vp, _vp, _i64, _i, _vp, _i, _i, _vp]),

@@ -12,8 +12,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libeprecon_hip.so")
+# --offload-compress: the gfx950 code objects are stored zstd-compressed in the fat binary (7.6 -> 2.x MB; rocPRIM's radix sort
+# alone is 2.3 MB uncompressed) and unpacked by the HIP runtime at load
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+         "-fno-fast-math", "-Wall", "-Wno-unused-function", "--offload-compress"]
 
 
 def sources():
@@ -46,7 +48,7 @@ def build(force=False, verbose=False):
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1) or 1) as pool:
         list(pool.map(subprocess.check_call, jobs))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
+    cmd = [hipcc, "--offload-arch=gfx950", "--offload-compress", "-shared", "-fPIC"] + objs + ["-o", OUT]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

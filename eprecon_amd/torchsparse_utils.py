@@ -79,12 +79,12 @@ class _VoxEntry:
         if self._order is None:
             lib = _lib.load()
             c = self.vset.coords
-            h = torch.empty(c.shape[0], dtype=torch.int64, device=c.device)
-            _lib.check(lib.eprecon_sphash_async(_lib.ptr(c), c.shape[0], _lib.ptr(h), _lib.current_stream()),
-                       "eprecon_sphash_async")
-            perm = torch.sort(h, stable=True)[1].to(torch.int32)
-            rank = torch.empty_like(perm)
-            rank[perm.long()] = torch.arange(perm.shape[0], dtype=torch.int32, device=c.device)
+            n = c.shape[0]
+            perm = torch.empty(n, dtype=torch.int32, device=c.device)
+            rank = torch.empty(n, dtype=torch.int32, device=c.device)
+            ws = _lib.workspace(lib.eprecon_sphash_order_workspace_bytes(n), c.device)
+            _lib.check(lib.eprecon_sphash_order_async(_lib.ptr(c), n, _lib.ptr(perm), _lib.ptr(rank), _lib.ptr(ws), ws.numel(),
+                                                      _lib.current_stream()), "eprecon_sphash_order_async")
             self._order = (perm, rank)
         return self._order
 

@@ -428,6 +428,12 @@ int eprecon_segment_mean_async(const float *feat, int ld_feat, const int32_t *of
  * a rank >= m_new, an out-of-bounds read in the reference, becomes -1).
  */
 int eprecon_sphash_async(const int32_t *coords, int64_t n, int64_t *out_hash, void *stream);
+/* the whole order in one call (csrc/hash_order.hip): perm_out[k] = row of the voxel with the k-th smallest hash (hashes of
+ * distinct voxels are distinct in practice; equal hashes keep their row order), rank_out = the inverse permutation.
+ * workspace: eprecon_sphash_order_workspace_bytes(n). */
+size_t eprecon_sphash_order_workspace_bytes(int64_t n);
+int eprecon_sphash_order_async(const int32_t *coords, int64_t n, int32_t *perm_out, int32_t *rank_out, void *workspace,
+                               size_t workspace_bytes, void *stream);
 int eprecon_remap_index_async(const int32_t *idx, int64_t n, const int32_t *rank_old, const int32_t *perm_new,
                               int64_t m_new, int32_t *out, void *stream);
 /* 8-corner indices int32[n,8] and renormalised trilinear weights f32[n,8] of points (in voxel

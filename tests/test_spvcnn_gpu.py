@@ -110,6 +110,15 @@ def test_sphash_order_matches_oracle():
     _lib.check(lib.eprecon_sphash_async(_lib.ptr(ct), len(c), _lib.ptr(h), _lib.current_stream()), "sphash")
     ref = PV.sphash(c)
     assert np.array_equal(h.cpu().numpy(), ref) and (ref >= 0).all() and len(np.unique(ref)) == len(ref)
+    # the whole order in one call (hash + rocPRIM radix sort + inverse permutation) == argsort of the oracle's hashes
+    perm = torch.empty(len(c), dtype=torch.int32, device="cuda")
+    rank = torch.empty(len(c), dtype=torch.int32, device="cuda")
+    ws = torch.empty(lib.eprecon_sphash_order_workspace_bytes(len(c)), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.eprecon_sphash_order_async(_lib.ptr(ct), len(c), _lib.ptr(perm), _lib.ptr(rank), _lib.ptr(ws), ws.numel(),
+                                              _lib.current_stream()), "sphash_order")
+    order = np.argsort(ref, kind="stable")
+    assert np.array_equal(perm.cpu().numpy(), order)
+    assert np.array_equal(rank.cpu().numpy()[order], np.arange(len(c)))
 
 
 @pytest.mark.parametrize("literal", [True, False])
