@@ -1936,24 +1936,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 template <int NTT>
 __global__ __launch_bounds__(256) void spconv_wide_reduce_kernel(ConvParams p, int nsplit, const float *partial)
 {
+    // one 32-column tile per workgroup (blockIdx.y): 3-4 x the workgroups of a one-dimensional grid, which had 74 of them on
+    // 256 CUs for the 9,415-row level; the BatchNorm summaries are per column, so nothing couples the tiles
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *sStat = reinterpret_cast<float *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, half = lane >> 5;
-    f32x16 acc[NTT];
+    const int t = blockIdx.y;
+    f32x16 acc[1];
 #pragma unroll
-    for (int t = 0; t < NTT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
     for (int s = 0; s < nsplit; ++s) {   // fixed order
         const float *src = partial + ((((size_t)s * gridDim.x + blockIdx.x) * kWaves + wave) * NTT) * 1024 + lane;
 #pragma unroll
-        for (int t = 0; t < NTT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] += src[(t * 16 + r) * 64];
+        for (int r = 0; r < 16; ++r) acc[0][r] += src[(t * 16 + r) * 64];
     }
-    conv_epilogue<NTT>(p, acc, LinearRows{(int)blockIdx.x * kWideRows + wave * 32, p.n_out}, 0, r32, half, wave, sStat,
-                       (int)blockIdx.x, 1);
+    conv_epilogue<1>(p, acc, LinearRows{(int)blockIdx.x * kWideRows + wave * 32, p.n_out}, 32 * t, r32, half, wave, sStat,
+                     (int)blockIdx.x, (int)gridDim.y);
 }
 
 size_t wide_workspace_bytes(const ConvParams &p)
@@ -1989,7 +1988,7 @@ int launch_wide_t(const ConvParams &p, hipStream_t st)
     hipLaunchKernelGGL((spconv_wide_kernel<NTT>), dim3((unsigned)blocks, (unsigned)nsplit), dim3(256), lds, st, p, nsplit, partial);
     EP_LAUNCH_CHECK();
     const size_t lds2 = (size_t)max(kWaves * 3 * 32 * NTT, 3 * 256) * sizeof(float);
-    hipLaunchKernelGGL((spconv_wide_reduce_kernel<NTT>), dim3((unsigned)blocks), dim3(256), lds2, st, p, nsplit, (const float *)partial);
+    hipLaunchKernelGGL((spconv_wide_reduce_kernel<NTT>), dim3((unsigned)blocks, (unsigned)NTT), dim3(256), lds2, st, p, nsplit, (const float *)partial);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }
