@@ -120,6 +120,8 @@ SIGNATURES = {
     "eprecon_profile_conv_ms": (_f, [_c.POINTER(_i64), _c.POINTER(_c.c_char_p)]),
     "eprecon_profile_conv_pairs": (_i64, []),
     "eprecon_mlp4x_supported": (_i, [_i, _i]),
+    "eprecon_gru_stage_finish_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "eprecon_gru_stage_finish_async": (_i, [_vp, _vp]),
     "eprecon_bn2d_views_chunks": (_i, [_i64, _i]),
     "eprecon_bn2d_views_workspace_bytes": (_sz, [_i, _i64, _i]),
     "eprecon_bn2d_views_stats_async": (_i, [_vp, _i, _i64, _i, _vp, _vp, _f, _vp, _vp, _sz, _vp]),
@@ -252,6 +254,17 @@ class DecoderLayerDesc(ctypes.Structure):
     _PTRS_B = ["state_out", "cls_out", "mask_embed_out", "next_q_out", "workspace"]
     _fields_ = ([(n, ctypes.c_int) for n in ("n_queries", "channels", "n_heads", "ffn_dim", "n_class_logits", "mask_hidden")]
                 + [(n, ctypes.c_void_p) for n in _PTRS_A] + [("ln_eps", ctypes.c_float)] + [(n, ctypes.c_void_p) for n in _PTRS_B])
+
+
+class GruFinishDesc(ctypes.Structure):
+    """include/eprecon_hip.h: eprecon_gru_finish_desc"""
+    _fields_ = ([(n, ctypes.c_int64) for n in ("n", "m1", "m2")]
+                + [(n, ctypes.c_void_p) for n in ("inverse1", "inverse2", "uniq1", "uniq2", "table1", "table2")]
+                + [("table_capacity", ctypes.c_uint32)] + [(n, ctypes.c_void_p) for n in ("scaled1", "scaled2")]
+                + [("literal", ctypes.c_int)]
+                + [(n, ctypes.c_void_p) for n in ("offsets1", "order1", "offsets2", "order2", "nbr1", "nbr2", "idx8_1", "weight8_1",
+                                                  "idx8_2", "weight8_2", "perm1", "rank1", "perm2", "rank2", "workspace")]
+                + [("workspace_bytes", ctypes.c_size_t)])
 
 
 class Mlp4xHead(ctypes.Structure):

@@ -22,7 +22,7 @@ from .global_map import GlobalMap
 from .modules import ConvGRU
 from .tensor import PointTensor
 from .torchsparse_utils import (aligned_camera_coords, convgru_resolution, prepare_convgru_voxelizations,
-                                register_voxelization)
+                                register_voxelization, register_voxelization_pair)
 
 
 def fbv_union(cur_coords, cur_feat, glob_coords, glob_feat, dim, interval, rel, mode=0):
@@ -228,8 +228,14 @@ class GRUFusion(nn.Module):
                               inputs["world_to_aligned_camera"][i], cfg.VOXEL_SIZE, res, chv, batch_index=i).read()
         n_u = st.n
         r_coords = st.r_coords
-        e1 = register_voxelization(r_coords, res, st.scaled1, st.vox1, st.inverse1, st.uniq1, st.grid1)
-        register_voxelization(e1.scaled, res, st.scaled2, st.vox2, st.inverse2, st.uniq2, st.grid2)
+        if self._identity_fusion:      # tests: the bookkeeping alone
+            e1 = register_voxelization(r_coords, res, st.scaled1, st.vox1, st.inverse1, st.uniq1, st.grid1)
+            register_voxelization(e1.scaled, res, st.scaled2, st.vox2, st.inverse2, st.uniq2, st.grid2)
+        else:
+            # point lists, kernel maps, corner tables (and the reference's hash order / stale indices) of both voxelisations:
+            # one library call; prepare_convgru_voxelizations below then finds everything in place
+            register_voxelization_pair(r_coords, res, (st.scaled1, st.vox1, st.inverse1, st.uniq1, st.grid1),
+                                       (st.scaled2, st.vox2, st.inverse2, st.uniq2, st.grid2))
         values = torch.empty((n_u, cin), dtype=torch.float32, device=dev)
         hx_v, hx_i = st.hx_v, st.hx_i
         if self._identity_fusion:          # tests: the bookkeeping alone (the fragment's rows pass through)

@@ -1,5 +1,6 @@
 """Point <-> voxel glue of the point-voxel U-Net — mirror of ops/torchsparse_utils.py:15-105 on
 libeprecon_hip.so (csrc/voxelize.hip, csrc/kernel_map.hip)."""
+import ctypes
 import os
 
 import torch
@@ -171,6 +172,63 @@ def register_voxelization(pts, res, scaled, vox, inverse, uniq, grid):
     e.scaled, e.vox, e.inverse = scaled, vox, inverse
     e.vset = SP.VoxelSet(uniq, 1, grid=grid)
     return _publish_entry(e)
+
+
+def register_voxelization_pair(pts, res, first, second):
+    """The two voxelisations the six SConv3d of a level's ConvGRUs share (of `pts` and of the once-scaled points), whose
+    coordinate side came out of the GRU-fusion stage call: first / second = (scaled, vox, inverse, uniq, grid), already
+    sliced to their sizes.  Everything else the cells need — CSR point lists, 3x3x3 kernel maps, corner tables, and in
+    LITERAL_CONVR mode the reference's hash order + stale indices — is queued by ONE library call
+    (eprecon_gru_stage_finish_async) and the two cache entries are published complete: the SConv3d layers only read."""
+    lib = _lib.load()
+    dev = pts.device
+    n = pts.shape[0]
+    (sc1, vox1, inv1, uq1, g1), (sc2, vox2, inv2, uq2, g2) = first, second
+    m1, m2 = uq1.shape[0], uq2.shape[0]
+    i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
+    d = _lib.GruFinishDesc()
+    d.n, d.m1, d.m2 = n, m1, m2
+    d.inverse1, d.inverse2, d.uniq1, d.uniq2 = inv1.data_ptr(), inv2.data_ptr(), uq1.data_ptr(), uq2.data_ptr()
+    d.table1, d.table2, d.table_capacity = g1.mem.data_ptr(), g2.mem.data_ptr(), g1.capacity
+    assert g1.capacity == g2.capacity
+    d.scaled1, d.scaled2, d.literal = sc1.data_ptr(), sc2.data_ptr(), int(LITERAL_CONVR)
+    off1, ord1, off2, ord2 = i32(m1 + 1), i32(max(n, 1)), i32(m2 + 1), i32(max(n, 1))
+    nbr1, nbr2 = i32(27, m1), i32(27, m2)
+    idx1, w1, idx2 = i32(n, 8), torch.empty((n, 8), dtype=torch.float32, device=dev), i32(n, 8)
+    d.offsets1, d.order1, d.offsets2, d.order2 = off1.data_ptr(), ord1.data_ptr(), off2.data_ptr(), ord2.data_ptr()
+    d.nbr1, d.nbr2, d.idx8_1, d.weight8_1, d.idx8_2 = nbr1.data_ptr(), nbr2.data_ptr(), idx1.data_ptr(), w1.data_ptr(), idx2.data_ptr()
+    w2 = order = None
+    if LITERAL_CONVR:
+        order = i32(2, m1), i32(2, m2)
+        d.perm1, d.rank1, d.perm2, d.rank2 = order[0][0].data_ptr(), order[0][1].data_ptr(), order[1][0].data_ptr(), order[1][1].data_ptr()
+    else:
+        w2 = torch.empty((n, 8), dtype=torch.float32, device=dev)
+        d.weight8_2 = w2.data_ptr()
+    ws = _lib.workspace(lib.eprecon_gru_stage_finish_workspace_bytes(n, m1, m2), dev)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    _lib.check(lib.eprecon_gru_stage_finish_async(ctypes.byref(d), _lib.current_stream()), "eprecon_gru_stage_finish_async")
+    entries = []
+    for src, scaled, vox, inv, uq, grid, lists, nbr in ((pts, sc1, vox1, inv1, uq1, g1, (off1, ord1), nbr1),
+                                                         (sc1, sc2, vox2, inv2, uq2, g2, (off2, ord2), nbr2)):
+        e = _VoxEntry()
+        e.key, e.pts = (src.data_ptr(), src._version, src.shape[0], float(res)), src
+        e.scaled, e.vox, e.inverse, e.lists = scaled, vox, inv, lists
+        e.vset = SP.VoxelSet(uq, 1, grid=grid)
+        e.vset._k3 = nbr
+        e.idx8 = e.w8 = e._order = None
+        e._stale = {}
+        entries.append(e)
+    e1, e2 = entries
+    e1.idx8, e1.w8 = idx1, w1
+    if LITERAL_CONVR:
+        e1._order, e2._order = (order[0][0], order[0][1]), (order[1][0], order[1][1])
+        e2._stale[id(e1)] = (idx2, w1, e1)
+    else:
+        e2.idx8, e2.w8 = idx2, w2
+    with _VOX_CACHE_LOCK:
+        _VOX_CACHE.extend(entries)
+        del _VOX_CACHE[:max(0, len(_VOX_CACHE) - _VOX_CACHE_MAX)]
+    return e1, e2
 
 
 def _entry_corner_tables(e):

@@ -777,6 +777,32 @@ int eprecon_bn2d_views_apply_async(const float *x, int views, int64_t rows_per_v
 int eprecon_dwconv2d_nhwc_async(const float *x, int n, int height, int width, int channels, const float *weight_taps, int ksize,
                                 int stride, const float *affine, int imgs_per_view, int relu, float *out, void *stream);
 
+/*
+ * The rest of a GRU-fusion level's geometry after its host read (sizes known), in one call (csrc/gru_stage_finish.hip): for the
+ * two voxelisations shared by the six SConv3d of the level's ConvGRUs — CSR point lists (offsets int32[m+1], order int32[n]),
+ * 3x3x3 kernel maps int32[27][m], the first voxelisation's trilinear corner tables (idx8 int32[n][8], weight8 f32[n][8]) and
+ *   literal != 0 (the reference's convr, models/modules.py:216-217): the hash order of both sets (perm / rank int32[m]) and
+ *                idx8_2 = the FIRST tables' indices carried to the second set in hash order (eprecon_remap_index_async);
+ *   literal == 0: the second voxelisation's own corner tables (idx8_2, weight8_2 from scaled2).
+ * Replaces the same sequence of single calls (eprecon_segment_lists_async, eprecon_kernel_map_async,
+ * eprecon_trilinear_map_async, eprecon_sphash_order_async, eprecon_remap_index_async): bit-identical outputs.
+ */
+typedef struct eprecon_gru_finish_desc {
+    int64_t n; int64_t m1; int64_t m2;
+    const int32_t *inverse1; const int32_t *inverse2;      /* int32[n]: point -> voxel */
+    const int32_t *uniq1; const int32_t *uniq2;            /* int32[m][4] */
+    const void *table1; const void *table2; uint32_t table_capacity;
+    const float *scaled1; const float *scaled2;            /* f32[n][4] points in voxel units (scaled2: literal == 0 only) */
+    int literal;
+    int32_t *offsets1; int32_t *order1; int32_t *offsets2; int32_t *order2;
+    int32_t *nbr1; int32_t *nbr2;
+    int32_t *idx8_1; float *weight8_1; int32_t *idx8_2; float *weight8_2;
+    int32_t *perm1; int32_t *rank1; int32_t *perm2; int32_t *rank2;   /* literal != 0 only */
+    void *workspace; size_t workspace_bytes;
+} eprecon_gru_finish_desc;
+size_t eprecon_gru_stage_finish_workspace_bytes(int64_t n, int64_t m1, int64_t m2);
+int eprecon_gru_stage_finish_async(const eprecon_gru_finish_desc *desc, void *stream);
+
 /* x2 bilinear upsampling of channels-last maps, in f32[n,h,w,c] -> out f32[n,2h,2w,c], c % 4 == 0
  * (F.interpolate(scale_factor=2, mode="bilinear") in feat_fusion_pre,
  * models/occupancy_initialization.py:46) */

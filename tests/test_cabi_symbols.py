@@ -43,10 +43,31 @@ def test_build_identity(lib):
 
 def test_only_gfx950_code_objects():
     """the fat binary must carry gfx950 code only (no multi-arch / compatibility builds)"""
+    import struct
+    import subprocess
+    import tempfile
     from eprecon_amd import _lib
     data = open(_lib.LIB_PATH, "rb").read()
     archs = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-f]+)", data))
+    # the code objects are stored compressed (--offload-compress: "CCOB" bundles, one per translation unit): each is handed to
+    # clang-offload-bundler, which lists the targets it holds
+    bundler = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
+    n_bundles = 0
+    for m in re.finditer(b"CCOB", data):
+        o = m.start()
+        ver, method = struct.unpack_from("<HH", data, o + 4)
+        if ver not in (2, 3) or method > 1:
+            continue                                  # (the four bytes somewhere else in the file)
+        total = struct.unpack_from("<Q", data, o + 8)[0] if ver >= 3 else struct.unpack_from("<I", data, o + 8)[0]
+        with tempfile.NamedTemporaryFile(suffix=".bin") as f:
+            f.write(data[o:o + total])
+            f.flush()
+            out = subprocess.run([bundler, "--list", "--type=o", f"--input={f.name}"], capture_output=True, text=True)
+        if out.returncode == 0:
+            n_bundles += 1
+            archs.update(t.rsplit("--", 1)[1].encode() for t in out.stdout.split() if "amdgcn" in t)
     assert archs == {b"gfx950"}, archs
+    assert n_bundles == 0 or n_bundles >= 10          # compressed build: every translation unit was inspected
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
@@ -69,7 +90,8 @@ def test_operators_refuse_cpu_tensors():
 
 @pytest.mark.parametrize("c_name,py_name", [("eprecon_conv_desc", "ConvDesc"), ("eprecon_gru_stage_desc", "GruStageDesc"),
                                             ("eprecon_decoder_layer_desc", "DecoderLayerDesc"),
-                                            ("eprecon_mlp4x_head", "Mlp4xHead"), ("eprecon_mlp4x_desc", "Mlp4xDesc")])
+                                            ("eprecon_mlp4x_head", "Mlp4xHead"), ("eprecon_mlp4x_desc", "Mlp4xDesc"),
+                                            ("eprecon_gru_finish_desc", "GruFinishDesc")])
 def test_struct_layouts_match_header(tmp_path, c_name, py_name):
     """the ctypes mirrors of the descriptor structs have the size and field offsets the C compiler gives the header's
     structs (a drift here would silently corrupt every launch that goes through them)"""
