@@ -112,6 +112,8 @@ SIGNATURES = {
     "eprecon_upsample2x_nhwc_async": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "eprecon_decoder_keys_async": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "eprecon_decoder_query_side_async": (_i, [_vp, _vp]),
+    "eprecon_panoptic_stats_async": (_i, [_vp, _i64, _vp, _vp, _i, _i64, _vp, _vp, _vp, _vp]),
+    "eprecon_panoptic_assign_async": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "eprecon_masked_attention_workspace_bytes": (_sz, [_i64, _i, _i, _i]),
     "eprecon_masked_attention_async": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i64, _vp, _i, _vp, _i64, _i, _i, _i, _f, _vp, _vp, _sz, _vp]),
     "eprecon_profile_enable": (_i, [_i]),

@@ -609,3 +609,86 @@ int eprecon_decoder_query_side_async(const eprecon_decoder_layer_desc *d, void *
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// panoptic_inference on the voxel side (models/mask3dformer.py:515-581): per voxel the kept query with the largest
+// score * sigmoid(mask logit) (first one on ties) owns it; per query the number of owned voxels, of voxels with
+// sigmoid >= 0.5, and of both.  ONE pass over the [Q, N] logits (coalesced along the voxels) instead of ~15 [Q, N] tensor
+// ops, integer atomics only (LDS histogram per workgroup, then one global add per query): deterministic.  The host then
+// decides per query (area ratio, stuff classes merged) and a second launch writes the segment ids.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kPanMaxQ = 256;
+
+__global__ __launch_bounds__(256) void panoptic_stats_kernel(const float *logits, long long ld, const float *scores, const int *keep,
+                                                             int Q, int N, int *owner, unsigned char *conf, int *counts)
+{
+    __shared__ int sCnt[3 * kPanMaxQ];
+    __shared__ float sScore[kPanMaxQ];
+    __shared__ int sKeep[kPanMaxQ];
+    for (int i = threadIdx.x; i < 3 * Q; i += 256) sCnt[i] = 0;
+    for (int i = threadIdx.x; i < Q; i += 256) { sScore[i] = scores[i]; sKeep[i] = keep[i]; }
+    __syncthreads();
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v < N) {
+        float best = -1.0f;
+        int bq = -1, bconf = 0;
+        for (int q = 0; q < Q; ++q) {
+            if (!sKeep[q]) continue;                     // (uniform)
+            const float x = logits[(size_t)q * ld + v];
+            const float p = 1.0f / (1.0f + expf(-x));    // torch.sigmoid in fp32
+            const float w = sScore[q] * p;
+            const int c = p >= 0.5f;
+            if (c) atomicAdd(&sCnt[Q + q], 1);
+            if (w > best) { best = w; bq = q; bconf = c; }
+        }
+        owner[v] = bq;
+        conf[v] = (unsigned char)bconf;
+        if (bq >= 0) {
+            atomicAdd(&sCnt[bq], 1);
+            if (bconf) atomicAdd(&sCnt[2 * Q + bq], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * Q; i += 256)
+        if (sCnt[i]) atomicAdd(counts + i, sCnt[i]);
+}
+
+__global__ void panoptic_assign_kernel(const int *owner, const unsigned char *conf, const int *idmap, int N, int *seg)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    const int q = owner[v];
+    seg[v] = (q >= 0 && conf[v]) ? idmap[q] : 0;
+}
+}  // namespace
+
+extern "C" {
+
+int eprecon_panoptic_stats_async(const float *mask_logits, int64_t ld, const float *scores, const int32_t *keep, int n_queries,
+                                 int64_t n, int32_t *owner_out, uint8_t *confident_out, int32_t *counts_out, void *stream)
+{
+    if (n < 0 || n > 0x7fffffff || n_queries <= 0 || n_queries > kPanMaxQ || ld < n || !scores || !keep || !counts_out) return EPRECON_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    EP_HIP_CHECK(hipMemsetAsync(counts_out, 0, (size_t)3 * n_queries * sizeof(int32_t), st));
+    if (n == 0) return EPRECON_OK;
+    if (!mask_logits || !owner_out || !confident_out) return EPRECON_ERR_ARG;
+    hipLaunchKernelGGL(panoptic_stats_kernel, dim3((unsigned)ceil_div(n, (int64_t)256)), dim3(256), 0, st, mask_logits, (long long)ld, scores,
+                       keep, n_queries, (int)n, owner_out, confident_out, counts_out);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_panoptic_assign_async(const int32_t *owner, const uint8_t *confident, const int32_t *idmap, int64_t n, int32_t *seg_out,
+                                  void *stream)
+{
+    if (n < 0 || n > 0x7fffffff) return EPRECON_ERR_ARG;
+    if (n == 0) return EPRECON_OK;
+    if (!owner || !confident || !idmap || !seg_out) return EPRECON_ERR_ARG;
+    hipLaunchKernelGGL(panoptic_assign_kernel, dim3((unsigned)ceil_div(n, (int64_t)256)), dim3(256), 0, (hipStream_t)stream, owner, confident,
+                       idmap, (int)n, seg_out);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+}  // extern "C"

@@ -518,24 +518,42 @@ THING_IDS = tuple(range(3, 21))  # classes 1 (wall) and 2 (floor) are stuff
 def panoptic_inference(mask_cls, mask_pred, object_mask_threshold=0.3, thing_id=THING_IDS, overlap_threshold=0.5):
     """mask_cls f32[Q, K+1], mask_pred f32[Q, N] (logits) -> [panoptic_seg int32[N], segments_info]"""
     scores, labels = F.softmax(mask_cls, dim=-1).max(-1)
-    prob = mask_pred.sigmoid()
     keep = labels.ne(0) & (scores > object_mask_threshold)
-    n = prob.shape[-1]
-    seg = torch.zeros(n, dtype=torch.int32, device=prob.device)
+    q, n = mask_pred.shape
+    dev = mask_pred.device
+    seg = torch.zeros(n, dtype=torch.int32, device=dev)
     info = []
-    # The reference compacts the kept queries first (boolean indexing: a host read) and reads two more tensors back; here
-    # the dropped queries stay in place with a score below every kept one, and the per-query counts, the keep flags and the
-    # classes come back in ONE read.  Kept queries keep their relative order, so the ids come out the same.
-    q = prob.shape[0]
-    weighted = torch.where(keep.view(-1, 1), scores.view(-1, 1) * prob, prob.new_full((), -1.0))
-    owner = weighted.argmax(0)
-    confident = (prob >= 0.5) & keep.view(-1, 1)
-    onehot = (owner.unsqueeze(0) == torch.arange(q, device=owner.device).unsqueeze(1)) & keep.view(-1, 1)
-    _lib.count_host_read()
-    host = torch.stack([onehot.sum(1), confident.sum(1), (onehot & confident).sum(1), keep.long(), labels.long()]).cpu()
+    hip = mask_pred.is_cuda and not torch.is_grad_enabled() and mask_pred.dtype == torch.float32 and mask_pred.stride(1) == 1 \
+        and q <= 256
+    if hip:
+        # one pass over the [Q, N] logits (csrc/decoder.hip, panoptic_stats_kernel): owner of every voxel, its confidence, the
+        # three per-query counts; ONE host read (counts + keep flags + classes); ids written by a second launch below
+        lib = _lib.load()
+        owner = torch.empty(n, dtype=torch.int32, device=dev)
+        conf = torch.empty(n, dtype=torch.uint8, device=dev)
+        meta = torch.empty((5, q), dtype=torch.int32, device=dev)
+        meta[3], meta[4] = keep, labels
+        sc = scores.contiguous()
+        _lib.check(lib.eprecon_panoptic_stats_async(_lib.ptr(mask_pred), mask_pred.stride(0), _lib.ptr(sc), _lib.ptr(meta[3]), q, n,
+                                                    _lib.ptr(owner), _lib.ptr(conf), _lib.ptr(meta), _lib.current_stream()),
+                   "eprecon_panoptic_stats_async")
+        _lib.count_host_read()
+        host = meta.cpu()
+    else:
+        # The reference compacts the kept queries first (boolean indexing: a host read) and reads two more tensors back; here
+        # the dropped queries stay in place with a score below every kept one, and the per-query counts, the keep flags and
+        # the classes come back in ONE read.  Kept queries keep their relative order, so the ids come out the same.
+        prob = mask_pred.sigmoid()
+        weighted = torch.where(keep.view(-1, 1), scores.view(-1, 1) * prob, prob.new_full((), -1.0))
+        owner = weighted.argmax(0)
+        confident = (prob >= 0.5) & keep.view(-1, 1)
+        onehot = (owner.unsqueeze(0) == torch.arange(q, device=owner.device).unsqueeze(1)) & keep.view(-1, 1)
+        _lib.count_host_read()
+        host = torch.stack([onehot.sum(1), confident.sum(1), (onehot & confident).sum(1), keep.long(), labels.long()]).cpu()
     stats, kept, classes = host[:3], host[3].tolist(), host[4].tolist()
     if not any(kept):
         return [seg, info]
+    idmap = [0] * q
     seg_id, stuff_ids = 0, {}
     for k in range(q):
         if not kept[k]:
@@ -546,15 +564,23 @@ def panoptic_inference(mask_cls, mask_pred, object_mask_threshold=0.3, thing_id=
                 continue
             cls = int(classes[k])
             isthing = cls in thing_id
-            region = onehot[k] & confident[k]
+            region = None if hip else onehot[k] & confident[k]
             if not isthing:
                 if cls in stuff_ids:
-                    seg[region] = stuff_ids[cls]
+                    idmap[k] = stuff_ids[cls]
+                    if not hip:
+                        seg[region] = stuff_ids[cls]
                     continue
                 stuff_ids[cls] = seg_id + 1
             seg_id += 1
-            seg[region] = seg_id
+            idmap[k] = seg_id
+            if not hip:
+                seg[region] = seg_id
             info.append({"id": seg_id, "isthing": bool(isthing), "category_id": cls})
+    if hip and any(idmap):
+        ids = torch.tensor(idmap, dtype=torch.int32).to(dev, non_blocking=True)
+        _lib.check(_lib.load().eprecon_panoptic_assign_async(_lib.ptr(owner), _lib.ptr(conf), _lib.ptr(ids), n, _lib.ptr(seg),
+                                                             _lib.current_stream()), "eprecon_panoptic_assign_async")
     return [seg, info]
 
 

@@ -722,6 +722,20 @@ typedef struct eprecon_decoder_layer_desc {
 int eprecon_decoder_query_side_async(const eprecon_decoder_layer_desc *desc, void *stream);
 
 /*
+ * panoptic_inference on the voxel side (models/mask3dformer.py:515-581 after the per-query softmax / keep decision):
+ *   mask_logits f32[Q][ld] (the final head's pred_masks of one batch element), scores f32[Q], keep int32[Q] (label != 0 and
+ *   score > threshold) -> owner_out int32[n]: the kept query with the largest score * sigmoid(logit) (first on ties, -1 when
+ *   no query is kept), confident_out u8[n]: sigmoid(logit of the owner) >= 0.5, counts_out int32[3][Q]: voxels owned,
+ *   voxels with sigmoid >= 0.5, both (zeroed by the call).  Integer atomics only: deterministic.
+ * eprecon_panoptic_assign_async: seg[v] = idmap[owner[v]] where the owner is confident, else 0 (idmap int32[Q]: the segment id
+ *   the host gave the query, 0 for rejected ones).
+ */
+int eprecon_panoptic_stats_async(const float *mask_logits, int64_t ld, const float *scores, const int32_t *keep, int n_queries,
+                                 int64_t n, int32_t *owner_out, uint8_t *confident_out, int32_t *counts_out, void *stream);
+int eprecon_panoptic_assign_async(const int32_t *owner, const uint8_t *confident, const int32_t *idmap, int64_t n, int32_t *seg_out,
+                                  void *stream);
+
+/*
  * The per-voxel heads as one launch  (models/modules.py:273-311 Linear4xTrans: Linear(C, 4C) - LayerNorm - ReLU -
  * Linear(4C, C) - LayerNorm - ReLU - Linear(C, C_out), + the second hidden layer as a skip when C == C_out; callers
  * models/neucon_network.py:437-438 tsdf_preds / occ_preds — `heads` = 2: both run on the same rows — and :546-548

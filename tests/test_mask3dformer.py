@@ -53,6 +53,36 @@ def test_panoptic_inference_stuff_merging_and_overlap_rule():
 
 
 @pytest.mark.gpu
+def test_panoptic_post_on_the_device_matches_reference_and_the_tensor_path(gold):
+    """the two-launch HIP form (owner / confidence / per-query counts in one pass, ids in a second) == the reference's
+    golden segmentation, and == the tensor-op path on a larger random case with ties, dropped queries and merged stuff"""
+    from eprecon_amd.mask3dformer import panoptic_inference, panoptic_post
+    res = panoptic_post({"pred_logits": torch.from_numpy(gold["pred_logits"]).cuda(),
+                         "pred_masks": torch.from_numpy(gold["pred_masks"]).cuda()})
+    seg, info = res["panoptic_seg"]
+    assert seg.dtype == torch.int32 and np.array_equal(seg.cpu().numpy(), gold["panoptic_seg"])
+    got = np.array([[d["id"], int(d["isthing"]), d["category_id"]] for d in info], np.int64).reshape(-1, 3)
+    assert np.array_equal(got, gold["segments"])
+    torch.manual_seed(5)
+    q, n = 80, 50021
+    cls = torch.randn(q, 21)
+    m = torch.randn(q, n) - 6.0
+    for k in range(q):                # every query owns a block of voxels (plus noise elsewhere) and has a clear class
+        m[k, 600 * k:600 * (k + 1)] += 9.0
+        cls[k, [0, 1, 2, 5, 9, 17][k % 6]] += 6.0      # "no object" for every sixth, two stuff classes (merged), things
+    m[7] = m[3]                       # exact ties between two queries' logits
+    cls[7] = cls[3]
+    m[:, -100:] = -20.0               # voxels nobody is confident about
+    with torch.no_grad():
+        seg_d, info_d = panoptic_inference(cls.cuda(), m.cuda())
+        strided = m.t().contiguous().cuda().t()       # same values, voxel-major storage: the tensor-op path on the same device
+        assert strided.stride(1) != 1
+        seg_h, info_h = panoptic_inference(cls.cuda(), strided)
+    assert info_d == info_h and len(info_h) > 3, (info_d, info_h)
+    assert torch.equal(seg_d, seg_h), int((seg_d != seg_h).sum())
+
+
+@pytest.mark.gpu
 def test_decoder_matches_reference_golden(gold):
     from eprecon_amd.mask3dformer import MultiScaleMaskedTransformerDecoder
     dec = MultiScaleMaskedTransformerDecoder(mask_classification=True, num_classes=20, hidden_dim=16, num_queries=12,
