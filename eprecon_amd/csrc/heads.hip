@@ -135,10 +135,159 @@ __global__ __launch_bounds__(256) void mlp4x_kernel(MlpParams p)
     }
 }
 
+// Short lists (a few thousand voxels: 147 workgroups of the form above at the coarsest level, every wave streaming the whole
+// 300 KB of weights behind a chain of L2 latencies): the FOUR waves of a workgroup share 16 voxels.  Wave w takes a quarter of
+// the hidden (4C) features through the first product and LayerNorm (its statistics exchanged through LDS), multiplies its
+// quarter of the second product's inputs — a K-split, the four partial results summed in wave order through LDS — and the
+// tail (second LayerNorm, last product) is replicated, wave t storing output tile t.  4 x the workgroups, a quarter of the
+// weight stream per wave.
+template <int KC, int T1, int T3>
+__global__ __launch_bounds__(256) void mlp4x_split_kernel(MlpParams p)
+{
+    constexpr int T2 = KC, TW = (T1 + 3) / 4;
+    __shared__ float sRed[2][4][16];
+    __shared__ float sPart[4][T2][256];
+    const int head = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l16 = lane & 15, q = lane >> 4;
+    const int v0 = (int)blockIdx.x * 16;
+    const int vox = min(v0 + l16, p.n - 1);
+    const float *xr = p.x + (size_t)vox * p.ldx;
+    f32x4 xb[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const int ch = 16 * c + 4 * q;
+        xb[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (ch < p.C) {
+            if (p.vec4) xb[c] = ld4(xr + ch);
+            else xb[c] = f32x4{xr[ch], xr[ch + 1], xr[ch + 2], xr[ch + 3]};
+        }
+    }
+    const int t0 = wave * T1 / 4, t1 = (wave + 1) * T1 / 4;     // this wave's hidden tiles (uniform)
+    // ---- first product on the wave's tiles ----
+    f32x4 h1[TW];
+    {
+        const float *w = p.w1[head] + lane * 4;
+#pragma unroll
+        for (int j = 0; j < TW; ++j) h1[j] = t0 + j < t1 ? ld4(p.b1[head] + 16 * (t0 + j) + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            f32x4 a[TW];
+#pragma unroll
+            for (int j = 0; j < TW; ++j) a[j] = ld4(w + (size_t)((t0 + min(j, t1 - t0 - 1)) * KC + c) * 256);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TW; ++j)
+                    if (t0 + j < t1) h1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][i], xb[c][i], h1[j], 0, 0, 0);
+        }
+    }
+    // ---- LayerNorm over all 4C features: partial sums per wave, totals through LDS (wave order) ----
+    const float cnt = (float)(4 * p.C);
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < TW; ++j)
+        if (t0 + j < t1) s += h1[j][0] + h1[j][1] + h1[j][2] + h1[j][3];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (q == 0) sRed[0][wave][l16] = s;
+    __syncthreads();
+    const float mean = (sRed[0][0][l16] + sRed[0][1][l16] + sRed[0][2][l16] + sRed[0][3][l16]) / cnt;
+    float v = 0.0f;
+#pragma unroll
+    for (int j = 0; j < TW; ++j)
+        if (t0 + j < t1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d = h1[j][i] - mean;
+                v = fmaf(d, d, v);
+            }
+        }
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (q == 0) sRed[1][wave][l16] = v;
+    __syncthreads();
+    const float inv = 1.0f / sqrtf((sRed[1][0][l16] + sRed[1][1][l16] + sRed[1][2][l16] + sRed[1][3][l16]) / cnt + p.eps1);
+#pragma unroll
+    for (int j = 0; j < TW; ++j)
+        if (t0 + j < t1) {
+            const f32x4 gg = ld4(p.g1[head] + 16 * (t0 + j) + 4 * q), bb = ld4(p.be1[head] + 16 * (t0 + j) + 4 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h1[j][i] = fmaxf((h1[j][i] - mean) * inv * gg[i] + bb[i], 0.0f);
+        }
+    // ---- second product: this wave's share of the inputs, partial results to LDS ----
+    {
+        f32x4 part[T2];
+#pragma unroll
+        for (int t = 0; t < T2; ++t) part[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *w = p.w2[head] + lane * 4;
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+            if (t0 + j < t1) {
+                f32x4 a[T2];
+#pragma unroll
+                for (int t = 0; t < T2; ++t) a[t] = ld4(w + (size_t)(t * T1 + t0 + j) * 256);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < T2; ++t) part[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][i], h1[j][i], part[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T2; ++t) *reinterpret_cast<f32x4 *>(&sPart[wave][t][lane * 4]) = part[t];
+    }
+    __syncthreads();
+    f32x4 h2[T2];
+#pragma unroll
+    for (int t = 0; t < T2; ++t) {
+        h2[t] = ld4(p.b2[head] + 16 * t + 4 * q);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const f32x4 o = *reinterpret_cast<const f32x4 *>(&sPart[w][t][lane * 4]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h2[t][i] += o[i];
+        }
+    }
+    layernorm_relu<T2>(h2, q, p.C, p.eps2, p.g2[head], p.be2[head]);
+    // ---- last product: output tile `wave` ----
+    if (wave >= T3) return;                       // (wave-uniform: the MFMAs below need every lane of the wave)
+    f32x4 o = ld4(p.b3[head] + 16 * wave + 4 * q);
+    {
+        const float *w = p.w3[head] + lane * 4;
+#pragma unroll
+        for (int c = 0; c < T2; ++c) {
+            const f32x4 a = ld4(w + (size_t)(wave * T2 + c) * 256);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], h2[c][i], o, 0, 0, 0);
+        }
+    }
+    if (v0 + l16 >= p.n) return;
+    float *yr = p.y[head] + (size_t)(v0 + l16) * p.ldy[head];
+    const int f = 16 * wave + 4 * q;
+    if constexpr (T3 == T2) {
+        if (p.residual) {
+            // (h2 tile `wave` of this lane: a compile-time index is needed for the register array)
+#pragma unroll
+            for (int t = 0; t < T2; ++t)
+                if (t == wave) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] += h2[t][i];
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (f + i < p.Cout) yr[f + i] = o[i];
+}
+
 template <int KC, int T1, int T3>
 int launch(const MlpParams &p, int heads, hipStream_t st)
 {
-    hipLaunchKernelGGL((mlp4x_kernel<KC, T1, T3>), dim3((unsigned)ceil_div(p.n, (int64_t)64), (unsigned)heads), dim3(256), 0, st, p);
+    // the four-waves-per-16-voxels form while the one-wave form would leave most CUs without a second workgroup
+    if (p.n <= 40000)
+        hipLaunchKernelGGL((mlp4x_split_kernel<KC, T1, T3>), dim3((unsigned)ceil_div(p.n, (int64_t)16), (unsigned)heads), dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((mlp4x_kernel<KC, T1, T3>), dim3((unsigned)ceil_div(p.n, (int64_t)64), (unsigned)heads), dim3(256), 0, st, p);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }

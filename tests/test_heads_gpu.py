@@ -27,7 +27,7 @@ def _module(cin, cout, seed):
 
 
 @pytest.mark.parametrize("cin,cout", [(24, 1), (48, 1), (96, 1), (48, 48), (88, 48), (176, 48)])
-@pytest.mark.parametrize("n,extra", [(1, 0), (63, 3), (1000, 81), (20011, 1)])
+@pytest.mark.parametrize("n,extra", [(1, 0), (63, 3), (1000, 81), (20011, 1), (50001, 0)])   # (<= 40,000 rows: four waves per 16 voxels)
 def test_one_launch_equals_the_modules(cin, cout, n, extra):
     from eprecon_amd import sparse as SP
     m = _module(cin, cout, 1)
