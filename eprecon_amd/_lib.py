@@ -122,6 +122,8 @@ SIGNATURES = {
     "eprecon_profile_conv_ms": (_f, [_c.POINTER(_i64), _c.POINTER(_c.c_char_p)]),
     "eprecon_profile_conv_pairs": (_i64, []),
     "eprecon_mlp4x_supported": (_i, [_i, _i]),
+    "eprecon_spvcnn_geometry_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "eprecon_spvcnn_geometry_async": (_i, [_vp, _vp]),
     "eprecon_gru_stage_finish_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "eprecon_gru_stage_finish_async": (_i, [_vp, _vp]),
     "eprecon_bn2d_views_chunks": (_i, [_i64, _i]),
@@ -266,6 +268,17 @@ class GruFinishDesc(ctypes.Structure):
                 + [("literal", ctypes.c_int)]
                 + [(n, ctypes.c_void_p) for n in ("offsets1", "order1", "offsets2", "order2", "nbr1", "nbr2", "idx8_1", "weight8_1",
                                                   "idx8_2", "weight8_2", "perm1", "rank1", "perm2", "rank2", "workspace")]
+                + [("workspace_bytes", ctypes.c_size_t)])
+
+
+class SpvcnnGeometryDesc(ctypes.Structure):
+    """include/eprecon_hip.h: eprecon_spvcnn_geometry_desc"""
+    _fields_ = ([(n, ctypes.c_int64) for n in ("n", "n1", "n2", "n4")]
+                + [(n, ctypes.c_void_p) for n in ("scaled", "vox", "inverse1", "coords1", "coords2", "coords4", "parent2", "parent4",
+                                                  "table1", "table2", "table4")]
+                + [(n, ctypes.c_uint32) for n in ("capacity1", "capacity2", "capacity4")]
+                + [(n, ctypes.c_void_p) for n in ("offsets1", "order1", "idx4", "offsets4", "order4", "down12", "up21", "down24", "up42",
+                                                  "k1", "k2", "k4", "idx8_1", "weight8_1", "idx8_4", "weight8_4", "workspace")]
                 + [("workspace_bytes", ctypes.c_size_t)])
 
 

@@ -1,0 +1,47 @@
+// The geometry of one SPVCNN pass (models/modules.py:75-175 with ops/torchsparse_utils.py:15-105) in ONE call, after the pass's
+// host read has given the sizes of the three strided voxel sets: the point -> voxel CSR lists of strides 1 and 4, the two
+// k2s2 maps and their transposes, the three 3x3x3 kernel maps, the trilinear corner tables of strides 1 and 4.  Nothing new is
+// computed here: the call issues what the Python modules used to issue one by one (14 calls per pass).
+#include "common.hpp"
+
+extern "C" {
+
+size_t eprecon_spvcnn_geometry_workspace_bytes(int64_t n, int64_t n1, int64_t n4)
+{
+    const size_t a = eprecon_segment_workspace_bytes(n, n1), b = eprecon_segment_workspace_bytes(n, n4);
+    return a > b ? a : b;
+}
+
+int eprecon_spvcnn_geometry_async(const eprecon_spvcnn_geometry_desc *d, void *stream)
+{
+    if (!d || d->n < 0 || d->n1 < 0 || d->n2 < 0 || d->n4 < 0) return EPRECON_ERR_ARG;
+    if (d->n == 0 || d->n1 == 0) return EPRECON_OK;
+    if (d->workspace_bytes < eprecon_spvcnn_geometry_workspace_bytes(d->n, d->n1, d->n4)) return EPRECON_ERR_WORKSPACE;
+#define EP_STEP(call)                \
+    do {                             \
+        const int rc_ = (call);      \
+        if (rc_ != EPRECON_OK) return rc_; \
+    } while (0)
+    EP_STEP(eprecon_segment_lists_async(d->inverse1, d->n, d->n1, d->offsets1, d->order1, d->workspace, d->workspace_bytes, stream));
+    if (d->n2 > 0) {
+        EP_STEP(eprecon_kernel_map_async(d->table1, d->capacity1, d->coords2, d->n2, 2, 1, d->down12, stream));
+        EP_STEP(eprecon_transpose_map_async(d->coords1, d->n1, d->parent2, 1, d->up21, stream));
+    }
+    if (d->n4 > 0) {
+        EP_STEP(eprecon_kernel_map_async(d->table2, d->capacity2, d->coords4, d->n4, 2, 2, d->down24, stream));
+        EP_STEP(eprecon_transpose_map_async(d->coords2, d->n2, d->parent4, 2, d->up42, stream));
+    }
+    EP_STEP(eprecon_kernel_map_async(d->table1, d->capacity1, d->coords1, d->n1, 3, 1, d->k1, stream));
+    if (d->n2 > 0) EP_STEP(eprecon_kernel_map_async(d->table2, d->capacity2, d->coords2, d->n2, 3, 2, d->k2, stream));
+    if (d->n4 > 0) EP_STEP(eprecon_kernel_map_async(d->table4, d->capacity4, d->coords4, d->n4, 3, 4, d->k4, stream));
+    EP_STEP(eprecon_trilinear_map_async(d->table1, d->capacity1, d->scaled, d->n, 1, d->idx8_1, d->weight8_1, stream));
+    if (d->n4 > 0) {
+        EP_STEP(eprecon_hash_query_async(d->table4, d->capacity4, d->vox, d->n, 4, d->idx4, stream));
+        EP_STEP(eprecon_segment_lists_async(d->idx4, d->n, d->n4, d->offsets4, d->order4, d->workspace, d->workspace_bytes, stream));
+        EP_STEP(eprecon_trilinear_map_async(d->table4, d->capacity4, d->scaled, d->n, 4, d->idx8_4, d->weight8_4, stream));
+    }
+#undef EP_STEP
+    return EPRECON_OK;
+}
+
+}  // extern "C"

@@ -182,11 +182,14 @@ def packed_weight16(weight, owner=None):
     return hit[1]
 
 
-def voxel_hierarchy(vox, levels=3):
+def voxel_hierarchy(vox, levels=3, points=None):
     """The voxel sets of a point cloud at tensor strides 1, 2, 4, ... with ONE host read for all their sizes: the unique
     numbering of `vox` int32[N,4] and of each coarser stride is queued back to back (the coarser calls take the finer
     count from the device, eprecon_unique_coords_dn_async), then the `levels` counts and status words are read together.
-    -> (VoxelSet at stride 1 with its downsample chain attached, inverse int32[N])"""
+    -> (VoxelSet at stride 1 with its downsample chain attached, inverse int32[N]).
+    points = scaled f32[N,4] (levels == 3, SPVCNN): everything else a pass needs from the coordinates — CSR point lists and
+    trilinear corner tables of strides 1 and 4, the strided maps, the three kernel maps — is queued by ONE library call
+    behind the read (eprecon_spvcnn_geometry_async) -> (VoxelSet, inverse, tables)."""
     n = vox.shape[0]
     grids, uniqs, invs = [], [], []
     src, n_dev = vox, None
@@ -200,12 +203,44 @@ def voxel_hierarchy(vox, levels=3):
     for lvl in range(levels):
         check_hash_status(host[2 * lvl])
         sizes.append(host[2 * lvl + 1])
+    if points is not None and levels == 3 and n > 0 and sizes[0] > 0:
+        return _hierarchy_with_geometry(vox, points, grids, uniqs, invs, sizes)
     base = VoxelSet(uniqs[0][:sizes[0]], 1, grid=grids[0])
     cur = base
     for lvl in range(1, levels):
         coarse, _, _ = cur.downsample(pre=(uniqs[lvl][:sizes[lvl]], invs[lvl][:sizes[lvl - 1]], grids[lvl]))
         cur = coarse
-    return base, invs[0]
+    return (base, invs[0]) if points is None else (base, invs[0], None)
+
+
+def _hierarchy_with_geometry(vox, points, grids, uniqs, invs, sizes):
+    lib = _lib.load()
+    dev = vox.device
+    n = vox.shape[0]
+    n1, n2, n4 = sizes
+    c1, c2, c4 = uniqs[0][:n1], uniqs[1][:n2], uniqs[2][:n4]
+    i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
+    t = {"offsets1": i32(n1 + 1), "order1": i32(n), "idx4": i32(n), "offsets4": i32(n4 + 1), "order4": i32(n),
+         "down12": i32(8, n2), "up21": i32(8, n1), "down24": i32(8, n4), "up42": i32(8, n2),
+         "k1": i32(27, n1), "k2": i32(27, n2), "k4": i32(27, n4), "idx8_1": i32(n, 8), "idx8_4": i32(n, 8),
+         "weight8_1": torch.empty((n, 8), dtype=torch.float32, device=dev),
+         "weight8_4": torch.empty((n, 8), dtype=torch.float32, device=dev)}
+    d = _lib.SpvcnnGeometryDesc()
+    d.n, d.n1, d.n2, d.n4 = n, n1, n2, n4
+    d.scaled, d.vox, d.inverse1 = points.data_ptr(), vox.data_ptr(), invs[0].data_ptr()
+    d.coords1, d.coords2, d.coords4 = c1.data_ptr(), c2.data_ptr(), c4.data_ptr()
+    d.parent2, d.parent4 = invs[1].data_ptr(), invs[2].data_ptr()
+    d.table1, d.table2, d.table4 = (g.mem.data_ptr() for g in grids)
+    d.capacity1, d.capacity2, d.capacity4 = (g.capacity for g in grids)
+    for name, buf in t.items():
+        setattr(d, name, buf.data_ptr())
+    ws = _lib.workspace(lib.eprecon_spvcnn_geometry_workspace_bytes(n, n1, n4), dev)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    _lib.check(lib.eprecon_spvcnn_geometry_async(ctypes.byref(d), _lib.current_stream()), "eprecon_spvcnn_geometry_async")
+    s1, s2, s4 = VoxelSet(c1, 1, grid=grids[0]), VoxelSet(c2, 2, grid=grids[1]), VoxelSet(c4, 4, grid=grids[2])
+    s1._k3, s2._k3, s4._k3 = t["k1"], t["k2"], t["k4"]
+    s1._down, s2._down = (s2, t["down12"], t["up21"]), (s4, t["down24"], t["up42"])
+    return s1, invs[0], t
 
 
 def clear_packed_weights(module):

@@ -72,7 +72,7 @@ class _VoxEntry:
     (scaled points, voxel set + hash grid + kernel map, point -> voxel lists, trilinear corners / weights).
     The six SConv3d of the two ConvGRUs of a scale voxelise the same points: convz and convq of both GRUs
     share one entry, both convr the entry built on the already-scaled coordinates."""
-    __slots__ = ("key", "pts", "scaled", "vox", "vset", "inverse", "lists", "idx8", "w8", "_order", "_stale")
+    __slots__ = ("key", "pts", "scaled", "vox", "vset", "inverse", "lists", "idx8", "w8", "_order", "_stale", "stride4")
 
     def sphash_order(self):
         """(perm, rank): perm[k] = id of the voxel with the k-th smallest torchsparse hash, rank = its inverse —
@@ -131,7 +131,7 @@ def _cached_entry(key, pts):
 
 def _publish_entry(e):
     e.lists = _segment_lists(e.inverse, e.vset.n)
-    e.idx8 = e.w8 = e._order = None
+    e.idx8 = e.w8 = e._order = e.stride4 = None
     e._stale = {}
     with _VOX_CACHE_LOCK:
         _VOX_CACHE.append(e)
@@ -156,7 +156,16 @@ def _voxelize_points(pts, res, levels=1):
     _lib.check(lib.eprecon_point_quantize_async(_lib.ptr(pts), n, float(res), _lib.ptr(e.scaled), _lib.ptr(e.vox),
                                                 _lib.current_stream()), "eprecon_point_quantize_async")
     if levels > 1 and pts.is_cuda:
-        e.vset, e.inverse = SP.voxel_hierarchy(e.vox, levels)
+        e.vset, e.inverse, tables = SP.voxel_hierarchy(e.vox, levels, points=e.scaled)
+        if tables is not None:
+            # the pass's whole geometry came out of one library call: publish the entry complete
+            e.lists = (tables["offsets1"], tables["order1"])
+            e.idx8, e.w8, e._order, e._stale = tables["idx8_1"], tables["weight8_1"], None, {}
+            e.stride4 = (tables["idx4"], (tables["offsets4"], tables["order4"]), tables["idx8_4"], tables["weight8_4"])
+            with _VOX_CACHE_LOCK:
+                _VOX_CACHE.append(e)
+                del _VOX_CACHE[:max(0, len(_VOX_CACHE) - _VOX_CACHE_MAX)]
+            return e
     else:
         uniq, e.inverse, grid = SP.unique_coords(e.vox, 1)
         e.vset = SP.VoxelSet(uniq, 1, grid=grid)
@@ -296,6 +305,11 @@ def initial_voxelize(z, init_res, after_res, levels=1):
     z.additional_features["lists"].clear()
     z.additional_features["idx_query"][1] = e.inverse
     z.additional_features["lists"][1] = e.lists
+    s4 = getattr(e, "stride4", None)
+    if s4 is not None and not (prev is not None and LITERAL_CONVR):
+        # (SPVCNN: the stride-4 transfers of the pass were tabulated with the rest of its geometry)
+        z.additional_features["idx_query"][4], z.additional_features["lists"][4] = s4[0], s4[1]
+        z.idx_query[4], z.weights[4] = s4[2], s4[3]
     z._vox_entry = e
     return SparseTensor(feat, e.vset)
 

@@ -817,6 +817,30 @@ typedef struct eprecon_gru_finish_desc {
 size_t eprecon_gru_stage_finish_workspace_bytes(int64_t n, int64_t m1, int64_t m2);
 int eprecon_gru_stage_finish_async(const eprecon_gru_finish_desc *desc, void *stream);
 
+/*
+ * The geometry of one SPVCNN pass after its host read (the sizes n1, n2, n4 of the voxel sets at tensor strides 1, 2, 4, numbered
+ * by three queued eprecon_unique_coords(_dn)_async calls), in one call (csrc/spvcnn_geometry.hip): CSR point lists of strides 1
+ * and 4 (offsets int32[m+1], order int32[n]; idx4 int32[n] = the stride-4 voxel of every point), the k2s2 maps down12 int32[8][n2],
+ * down24 int32[8][n4] and their transposes up21 int32[8][n1], up42 int32[8][n2], the 3x3x3 kernel maps k1 / k2 / k4
+ * int32[27][n1 / n2 / n4], trilinear corner tables of strides 1 and 4 (int32[n][8], f32[n][8]).  parent2 int32[n1] / parent4
+ * int32[n2]: the inverse index of the stride-2 / stride-4 numbering.  Replaces the same sequence of single calls: bit-identical.
+ */
+typedef struct eprecon_spvcnn_geometry_desc {
+    int64_t n; int64_t n1; int64_t n2; int64_t n4;
+    const float *scaled; const int32_t *vox; const int32_t *inverse1;     /* points: f32[n][4], int32[n][4], int32[n] */
+    const int32_t *coords1; const int32_t *coords2; const int32_t *coords4;
+    const int32_t *parent2; const int32_t *parent4;
+    const void *table1; const void *table2; const void *table4;
+    uint32_t capacity1; uint32_t capacity2; uint32_t capacity4;
+    int32_t *offsets1; int32_t *order1; int32_t *idx4; int32_t *offsets4; int32_t *order4;
+    int32_t *down12; int32_t *up21; int32_t *down24; int32_t *up42;
+    int32_t *k1; int32_t *k2; int32_t *k4;
+    int32_t *idx8_1; float *weight8_1; int32_t *idx8_4; float *weight8_4;
+    void *workspace; size_t workspace_bytes;
+} eprecon_spvcnn_geometry_desc;
+size_t eprecon_spvcnn_geometry_workspace_bytes(int64_t n, int64_t n1, int64_t n4);
+int eprecon_spvcnn_geometry_async(const eprecon_spvcnn_geometry_desc *desc, void *stream);
+
 /* x2 bilinear upsampling of channels-last maps, in f32[n,h,w,c] -> out f32[n,2h,2w,c], c % 4 == 0
  * (F.interpolate(scale_factor=2, mode="bilinear") in feat_fusion_pre,
  * models/occupancy_initialization.py:46) */
