@@ -13,27 +13,18 @@ from eprecon_amd import _lib  # noqa: E402
 from eprecon_amd import sparse as SP  # noqa: E402
 from eprecon_amd.fragment_step import Cfg4Step  # noqa: E402
 
-MAPS = []
-_orig = SP.VoxelSet.kernel_map
-
-
-def recording_kernel_map(self, ksize=3):
-    fresh = self._k3 is None
-    nbr = _orig(self, ksize)
-    if fresh and self.stride == 1 and nbr.shape[1] > 200000:
-        MAPS.append(nbr)
-    return nbr
+from eprecon_amd import torchsparse_utils as TU  # noqa: E402
 
 
 def main():
     step = Cfg4Step(seed=0, device=torch.device("cuda"))
     for _ in range(2 * step.n_fragments - 1):
         step.run()
-    SP.VoxelSet.kernel_map = recording_kernel_map
     step.run()                                  # the last fragment of the scene: the largest map state
-    SP.VoxelSet.kernel_map = _orig
     torch.cuda.synchronize()
-    cands = [(float((m >= 0).float().mean()), m) for m in MAPS]
+    # the kernel maps of the fragment's voxelisations are in the cache the SConv3d layers read (the finest level's last)
+    maps = [e.vset._k3 for e in TU._VOX_CACHE if e.vset._k3 is not None and e.vset._k3.shape[1] > 200000]
+    cands = [(float((m >= 0).float().mean()), m) for m in maps]
     cands = [c for c in cands if c[0] > 0.2]    # (the second ConvGRU voxelisation has no adjacent voxels: 1 / 27 live)
     live_frac, nbr = max(cands, key=lambda c: c[1].shape[1])
     n = nbr.shape[1]

@@ -12,8 +12,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eprecon_amd import sparse as SP  # noqa: E402
 from eprecon_amd.fragment_step import Cfg4Step  # noqa: E402
 
+from eprecon_amd import torchsparse_utils as TU  # noqa: E402
+
 MAPS = []
 _orig = SP.VoxelSet.kernel_map
+_orig_hier = SP._hierarchy_with_geometry
+_orig_pair = TU.register_voxelization_pair
 
 
 def recording_kernel_map(self, ksize=3):
@@ -24,11 +28,29 @@ def recording_kernel_map(self, ksize=3):
     return nbr
 
 
+# (the maps of an SPVCNN pass and of a level's two ConvGRU voxelisations are built inside one library call each: pick them up
+# where the call hands them over)
+def recording_hierarchy(*a, **k):
+    s1, inv, t = _orig_hier(*a, **k)
+    s2 = s1._down[0]
+    MAPS.extend([(1, s1._k3), (2, s2._k3), (4, s2._down[0]._k3)])
+    return s1, inv, t
+
+
+def recording_pair(*a, **k):
+    e1, e2 = _orig_pair(*a, **k)
+    MAPS.extend([(1, e1.vset._k3), (1, e2.vset._k3)])
+    return e1, e2
+
+
 def main():
     step = Cfg4Step(seed=0, device=torch.device("cuda"))
     for _ in range(2 * step.n_fragments):
         step.run()
     SP.VoxelSet.kernel_map = recording_kernel_map
+    SP._hierarchy_with_geometry = recording_hierarchy
+    import eprecon_amd.gru_fusion as GF
+    GF.register_voxelization_pair = recording_pair
     for _ in range(step.n_fragments):
         step.run()
     torch.cuda.synchronize()
