@@ -1,4 +1,4 @@
-"""gpurun_out/<dir> (tools/collect_profiles.sh) -> the committed summaries under profiles/<round>/"""
+"""gpurun_out/<dir> (tools/collect_profiles_r04.sh) -> the committed summaries under profiles/<round>/"""
 import collections, csv, json, os, sys
 
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
