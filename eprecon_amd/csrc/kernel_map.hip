@@ -18,7 +18,7 @@ namespace {
 using namespace ep;
 
 // -------------------------------------------------------------------------------------------
-// device-wide exclusive scan of int32 (n up to 2^31), three launches, deterministic
+// device-wide exclusive scan of int32 (n up to 2^31), one to three launches, deterministic
 // -------------------------------------------------------------------------------------------
 constexpr int kScanBlock = 256;
 constexpr int kScanItems = 8;                       // per thread
@@ -76,13 +76,38 @@ __global__ __launch_bounds__(1024) void scan_sums_inplace(int32_t *sums, int nbl
     if (tid == 0 && total) *total = carry;
 }
 
-// out[i] = exclusive prefix of in[0..i); each block rescans its 2048-element tile in LDS
+// out[i] = exclusive prefix of in[0..i); each block rescans its 2048-element tile in LDS.
+// RAW: `sums` holds the tile totals as scan_tile_sums left them and every workgroup adds up the totals in front of its own
+// tile itself (a few hundred values: cheaper than the third launch that used to scan them); the last workgroup also
+// publishes the grand total.
+template <bool RAW>
 __global__ __launch_bounds__(kScanBlock) void scan_apply(const int32_t *in, int n, const int32_t *sums,
-                                                         int32_t *out, const int32_t *n_dev)
+                                                         int32_t *out, const int32_t *n_dev, int32_t *total)
 {
     __shared__ int sWave[kScanBlock / kWave];
+    __shared__ int sBase;
     if (n_dev) n = min(n, *n_dev);
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+    int tile_base;
+    if (RAW) {
+        int acc = 0;
+        for (int j = tid; j < (int)blockIdx.x; j += kScanBlock) acc += sums[j];
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+        if (lane == 0) sWave[wid] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < kScanBlock / kWave; ++w) t += sWave[w];
+            sBase = t;
+            if (total && blockIdx.x == gridDim.x - 1) *total = t + sums[blockIdx.x];
+        }
+        __syncthreads();
+        tile_base = sBase;
+        __syncthreads();      // (sWave is reused below)
+    } else {
+        tile_base = sums[blockIdx.x];
+    }
     const int base = blockIdx.x * kScanTile + tid * kScanItems;  // blocked arrangement
     int v[kScanItems];
     int s = 0;
@@ -99,7 +124,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_apply(const int32_t *in, int 
     }
     if (lane == kWave - 1) sWave[wid] = x;
     __syncthreads();
-    int off = sums[blockIdx.x] + x - s;
+    int off = tile_base + x - s;
     for (int w = 0; w < wid; ++w) off += sWave[w];
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
@@ -174,9 +199,14 @@ int exclusive_scan_i32_dn(const int32_t *in, int n, const int32_t *n_dev, int32_
     const int nblk = (int)ceil_div(n, kScanTile);
     hipLaunchKernelGGL(scan_tile_sums, dim3(nblk), dim3(kScanBlock), 0, st, in, n, scratch, n_dev);
     EP_LAUNCH_CHECK();
+    if (nblk <= 4096) {       // (8.4 M elements: two launches; the tile totals are summed by the consumers)
+        hipLaunchKernelGGL(scan_apply<true>, dim3(nblk), dim3(kScanBlock), 0, st, in, n, scratch, out, n_dev, total_dev);
+        EP_LAUNCH_CHECK();
+        return EPRECON_OK;
+    }
     hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(1024), 0, st, scratch, nblk, total_dev);
     EP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scan_apply, dim3(nblk), dim3(kScanBlock), 0, st, in, n, scratch, out, n_dev);
+    hipLaunchKernelGGL(scan_apply<false>, dim3(nblk), dim3(kScanBlock), 0, st, in, n, scratch, out, n_dev, (int32_t *)nullptr);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }
