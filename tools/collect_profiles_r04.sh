@@ -55,6 +55,12 @@ rm -rf $O/conv_instance/*/*kernel_trace.csv $O/conv_instance/*kernel_trace.csv
 # 5b. the 2D feeder alone (kernel list), and where the HOST time of a cfg4 fragment goes
 bash tools/r04_backbone.sh r04_final/bb > $P/backbone_kernels.txt 2>/dev/null
 python tools/profile_cfg4_host.py 8 2>/dev/null > $P/cfg4_host_profile.txt
+# 5c. how much of a fragment's wall time the GPU is busy (union of the kernel intervals of all streams between two markers)
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d $O/busy -o r -- python $R/tools/gpu_busy_cfg4.py > /dev/null 2>&1
+cd $R
+python tools/gpu_busy_cfg4.py --summarize $(find $O/busy -name "*kernel_trace.csv" | head -1) > $P/cfg4_gpu_busy.txt
+rm -f $(find $O/busy -name "*kernel_trace.csv")
 # 6. dead offsets in the kernel maps of a fragment; the 3x3x3 shapes of a fragment one by one
 python tools/conv_tile_liveness.py 2>/dev/null > $P/conv_tile_liveness.txt
 python tools/conv_shapes_ab.py round4 2>/dev/null > $P/conv_shapes.txt
