@@ -282,11 +282,14 @@ __global__ void first_flag_kernel(HashTable t, const int4 *coords, int n, int q,
 
 // inverse[i] = unique id of row i; unique_coords[uid] = quantised coords of the first occurrence;
 // the table values are rewritten from "first row" to "unique id" so later lookups return ids.
+// (the launch also covers the table: thread s < cap rewrites slot s — table_vals_to_ids_kernel's job; the two halves touch
+// disjoint data, so one launch serves both)
 __global__ void unique_finalize_kernel(HashTable t, const int4 *coords, int n, int q,
                                        const int32_t *owner, const int32_t *rank, int32_t *inverse,
-                                       int4 *unique_coords, const int32_t *n_dev)
+                                       int4 *unique_coords, const int32_t *n_dev, uint32_t cap)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((uint32_t)i < cap && t.keys[i] != kEmptyKey) t.vals[i] = rank[t.vals[i]];
     if (n_dev) n = min(n, *n_dev);
     if (i >= n) return;
     const int o = owner[i];
@@ -305,12 +308,6 @@ __global__ void unique_finalize_kernel(HashTable t, const int4 *coords, int n, i
         }
         unique_coords[uid] = c;
     }
-}
-
-__global__ void table_vals_to_ids_kernel(HashTable t, uint32_t cap, const int32_t *rank)
-{
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < cap && t.keys[s] != kEmptyKey) t.vals[s] = rank[t.vals[s]];
 }
 
 // nbr[k][i] = row of the voxel at coords[i] + offset_k * stride (or -1).
@@ -481,11 +478,9 @@ static int unique_coords_impl(const int32_t *coords, int64_t n, const int32_t *n
     EP_LAUNCH_CHECK();
     rc = ep::exclusive_scan_i32_dn(first, (int)n, n_dev, rank, scratch, n_unique_dev, st);
     if (rc != EPRECON_OK) return rc;
-    hipLaunchKernelGGL(unique_finalize_kernel, grid, block, 0, st, t, c4, (int)n, quantum, owner, rank,
-                       inverse, reinterpret_cast<int4 *>(unique_coords), n_dev);
-    EP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(table_vals_to_ids_kernel, dim3((capacity + 255) / 256), block, 0, st, t, capacity,
-                       rank);
+    const int64_t span = n > (int64_t)capacity ? n : (int64_t)capacity;
+    hipLaunchKernelGGL(unique_finalize_kernel, dim3((unsigned)ceil_div(span, 256)), block, 0, st, t, c4, (int)n, quantum, owner, rank,
+                       inverse, reinterpret_cast<int4 *>(unique_coords), n_dev, capacity);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }
