@@ -80,6 +80,10 @@ SIGNATURES = {
     "eprecon_devoxelize_backward_async": (_i, [_vp, _i, _vp, _vp, _i64, _i, _i64, _vp, _i, _vp]),
     "eprecon_gather_rows_scaled_async": (_i, [_vp, _i, _vp, _vp, _i64, _i, _vp, _i, _vp]),
     "eprecon_back_project_backward_async": (_i, [_vp, _i64, _vp, _i, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "eprecon_back_project_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "eprecon_back_project_backward_det_async": (_i, [_vp, _i64, _vp, _i, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _sz,
+                                                     _vp]),
+    "eprecon_devoxelize_backward_csr_async": (_i, [_vp, _i, _vp, _vp, _vp, _i64, _i, _vp, _i, _vp]),
     "eprecon_devoxelize_gate_async": (_i, [_vp, _i, _vp, _vp, _i64, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "eprecon_devoxelize_gate_tail_async": (_i, [_vp, _i, _vp, _vp, _i64, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i,
                                                 _i, _vp]),

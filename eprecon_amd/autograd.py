@@ -91,6 +91,28 @@ def sparse_conv(x, weight, nbr=None, bias=None):
     return _SparseConv.apply(x, weight, bias, nbr)
 
 
+_CORNER_LISTS = []     # [(idx8 tensor, n_voxels, offsets, order)], newest last
+
+
+def corner_lists(idx8, m):
+    """CSR lists voxel -> (point, corner) entries of a corner table idx8 int32[n, 8] (eprecon_segment_lists_async over the
+    flattened table; missing corners skipped), cached on the table's identity"""
+    for t, mm, offsets, order in _CORNER_LISTS:
+        if t is idx8 and mm == m:
+            return offsets, order
+    lib = _lib.load()
+    flat = idx8.reshape(-1)
+    n8, dev = flat.shape[0], idx8.device
+    offsets = torch.empty(m + 1, dtype=torch.int32, device=dev)
+    order = torch.empty(max(n8, 1), dtype=torch.int32, device=dev)
+    ws = _lib.workspace(lib.eprecon_segment_workspace_bytes(n8, m), dev)
+    _lib.check(lib.eprecon_segment_lists_async(_lib.ptr(flat), n8, m, _lib.ptr(offsets), _lib.ptr(order), _lib.ptr(ws), ws.numel(),
+                                               _lib.current_stream()), "eprecon_segment_lists_async")
+    _CORNER_LISTS.append((idx8, m, offsets, order))
+    del _CORNER_LISTS[:max(0, len(_CORNER_LISTS) - 24)]
+    return offsets, order
+
+
 class _Devoxelize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, idx8, w8):
@@ -109,9 +131,12 @@ class _Devoxelize(torch.autograd.Function):
         dout = dout.contiguous()
         n, c = dout.shape
         dfeat = torch.empty((ctx.m, c), dtype=torch.float32, device=dout.device)
-        _lib.check(lib.eprecon_devoxelize_backward_async(_lib.ptr(dout), dout.stride(0), _lib.ptr(ctx.idx8), _lib.ptr(ctx.w8), n, c,
-                                                         ctx.m, _lib.ptr(dfeat), dfeat.stride(0), _lib.current_stream()),
-                   "eprecon_devoxelize_backward_async")
+        # run-to-run bit-identical: no float atomics — the entries that reach a voxel are summed in the order of a CSR list that
+        # depends on the corner table only (built once per table, shared by the layers that devoxelise with it)
+        offsets, order = corner_lists(ctx.idx8, ctx.m)
+        _lib.check(lib.eprecon_devoxelize_backward_csr_async(_lib.ptr(dout), dout.stride(0), _lib.ptr(ctx.w8), _lib.ptr(offsets),
+                                                             _lib.ptr(order), ctx.m, c, _lib.ptr(dfeat), dfeat.stride(0),
+                                                             _lib.current_stream()), "eprecon_devoxelize_backward_csr_async")
         return dfeat, None, None
 
 
@@ -177,10 +202,12 @@ class _BackProjectGrad(torch.autograd.Function):
         dfeats = torch.empty((v, b, h, w, c), dtype=torch.float32, device=dev)
         origin_f = origin.to(device=dev, dtype=torch.float32).reshape(-1, 3).contiguous()
         krcam_f = krcam.to(device=dev, dtype=torch.float32).contiguous()
-        _lib.check(lib.eprecon_back_project_backward_async(
+        # (the deterministic form: 64-bit fixed-point accumulation with integer atomics, converted at the end)
+        ws = _lib.workspace(lib.eprecon_back_project_backward_workspace_bytes(b, v, c, h, w), dev)
+        _lib.check(lib.eprecon_back_project_backward_det_async(
             _lib.ptr(coords_valid), coords_valid.shape[0], _lib.ptr(origin_f), b, voxel_size, _lib.ptr(nhwc), _lib.ptr(krcam_f), v, c,
-            h, w, mode, _lib.ptr(dout), dout.stride(0), _lib.ptr(dmean), _lib.ptr(dfeats), _lib.current_stream()),
-            "eprecon_back_project_backward_async")
+            h, w, mode, _lib.ptr(dout), dout.stride(0), _lib.ptr(dmean), _lib.ptr(dfeats), _lib.ptr(ws), ws.numel(),
+            _lib.current_stream()), "eprecon_back_project_backward_det_async")
         return dfeats.permute(0, 1, 4, 2, 3), None, None, None, None, None, None, None
 
 

@@ -734,7 +734,20 @@ struct BpBwdParams {
     const float *dout; int ld_dout;
     const float *dmean;                    // VARIANCE only, may be null
     float *dfeats;                         // [V*B][H*W][C], zeroed by the caller
+    unsigned long long *dfix;              // the same elements as 64-bit fixed point (deterministic form), or null
 };
+
+constexpr double kFixScale = 1099511627776.0;   // 2^40
+__device__ __forceinline__ unsigned long long to_fixed(float v)
+{
+    const double x = fmin(fmax((double)v * kFixScale, -9.0e18), 9.0e18);
+    return (unsigned long long)__double2ll_rn(x);           // two's complement: an unsigned add is a signed add
+}
+__global__ void fixed_to_float_kernel(const unsigned long long *acc, long long n, float *out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)((double)(long long)acc[i] * (1.0 / kFixScale));
+}
 
 __global__ __launch_bounds__(256) void bp_backward_kernel(BpBwdParams p)
 {
@@ -783,11 +796,20 @@ __global__ __launch_bounds__(256) void bp_backward_kernel(BpBwdParams p)
         } else {
             gv = g * inv;
         }
-        float *d = p.dfeats + mo;
-        if (t.w00 != 0.0f) unsafeAtomicAdd(d + t.o00, t.w00 * gv);
-        if (t.w10 != 0.0f) unsafeAtomicAdd(d + t.o10, t.w10 * gv);
-        if (t.w01 != 0.0f) unsafeAtomicAdd(d + t.o01, t.w01 * gv);
-        if (t.w11 != 0.0f) unsafeAtomicAdd(d + t.o11, t.w11 * gv);
+        if (p.dfix) {
+            // order-independent accumulation: 64-bit fixed point (2^-40 resolution, |sum| < 8.4e6), integer atomics
+            unsigned long long *d = p.dfix + mo;
+            if (t.w00 != 0.0f) atomicAdd(d + t.o00, to_fixed(t.w00 * gv));
+            if (t.w10 != 0.0f) atomicAdd(d + t.o10, to_fixed(t.w10 * gv));
+            if (t.w01 != 0.0f) atomicAdd(d + t.o01, to_fixed(t.w01 * gv));
+            if (t.w11 != 0.0f) atomicAdd(d + t.o11, to_fixed(t.w11 * gv));
+        } else {
+            float *d = p.dfeats + mo;
+            if (t.w00 != 0.0f) unsafeAtomicAdd(d + t.o00, t.w00 * gv);
+            if (t.w10 != 0.0f) unsafeAtomicAdd(d + t.o10, t.w10 * gv);
+            if (t.w01 != 0.0f) unsafeAtomicAdd(d + t.o01, t.w01 * gv);
+            if (t.w11 != 0.0f) unsafeAtomicAdd(d + t.o11, t.w11 * gv);
+        }
     }
 }
 
@@ -1062,25 +1084,58 @@ int eprecon_back_project(const int32_t *coords, int64_t n, const float *origin, 
     return EPRECON_OK;
 }
 
-int eprecon_back_project_backward_async(const int32_t *coords_valid, int64_t n_valid, const float *origin, int batch,
-                                        float voxel_size, const float *feats_nhwc, const float *krcam, int n_views,
-                                        int channels, int height, int width, int mode, const float *dout, int ld_dout,
-                                        const float *dmean, float *dfeats_nhwc, void *stream)
+static int bp_backward_impl(const int32_t *coords_valid, int64_t n_valid, const float *origin, int batch, float voxel_size,
+                            const float *feats_nhwc, const float *krcam, int n_views, int channels, int height, int width, int mode,
+                            const float *dout, int ld_dout, const float *dmean, float *dfeats_nhwc, void *workspace,
+                            size_t workspace_bytes, void *stream)
 {
     if (n_valid < 0 || batch < 1 || n_views < 1 || channels < 1 || !dfeats_nhwc || !krcam || !origin) return EPRECON_ERR_ARG;
     if (mode == EPRECON_BP_VARIANCE && !feats_nhwc) return EPRECON_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    EP_HIP_CHECK(hipMemsetAsync(dfeats_nhwc, 0, (size_t)n_views * batch * height * width * channels * sizeof(float), st));
+    const size_t elems = (size_t)n_views * batch * height * width * channels;
+    if (workspace && workspace_bytes < elems * sizeof(unsigned long long)) return EPRECON_ERR_WORKSPACE;
+    if (workspace) EP_HIP_CHECK(hipMemsetAsync(workspace, 0, elems * sizeof(unsigned long long), st));
+    if (!workspace || n_valid == 0) EP_HIP_CHECK(hipMemsetAsync(dfeats_nhwc, 0, elems * sizeof(float), st));
     if (n_valid == 0) return EPRECON_OK;
     if (!coords_valid || !dout) return EPRECON_ERR_ARG;
     BpBwdParams p;
     p.coords = coords_valid; p.n = n_valid; p.origin = origin; p.batch = batch; p.voxel_size = voxel_size;
     p.feats_nhwc = feats_nhwc; p.krcam = krcam; p.V = n_views; p.C = channels; p.H = height; p.W = width; p.mode = mode;
-    p.dout = dout; p.ld_dout = ld_dout; p.dmean = dmean; p.dfeats = dfeats_nhwc;
+    p.dout = dout; p.ld_dout = ld_dout; p.dmean = dmean; p.dfeats = dfeats_nhwc; p.dfix = (unsigned long long *)workspace;
     const size_t lds = (((size_t)n_views * batch * 12 + 3) & ~(size_t)3) * sizeof(float);
     hipLaunchKernelGGL(bp_backward_kernel, dim3((unsigned)ceil_div(n_valid * channels, 256)), dim3(256), lds, st, p);
     EP_LAUNCH_CHECK();
+    if (workspace) {
+        hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)ceil_div((int64_t)elems, 256)), dim3(256), 0, st,
+                           (const unsigned long long *)workspace, (long long)elems, dfeats_nhwc);
+        EP_LAUNCH_CHECK();
+    }
     return EPRECON_OK;
+}
+
+int eprecon_back_project_backward_async(const int32_t *coords_valid, int64_t n_valid, const float *origin, int batch,
+                                        float voxel_size, const float *feats_nhwc, const float *krcam, int n_views,
+                                        int channels, int height, int width, int mode, const float *dout, int ld_dout,
+                                        const float *dmean, float *dfeats_nhwc, void *stream)
+{
+    return bp_backward_impl(coords_valid, n_valid, origin, batch, voxel_size, feats_nhwc, krcam, n_views, channels, height, width, mode,
+                            dout, ld_dout, dmean, dfeats_nhwc, nullptr, 0, stream);
+}
+
+size_t eprecon_back_project_backward_workspace_bytes(int batch, int n_views, int channels, int height, int width)
+{
+    return (size_t)n_views * batch * height * width * channels * sizeof(unsigned long long);
+}
+
+int eprecon_back_project_backward_det_async(const int32_t *coords_valid, int64_t n_valid, const float *origin, int batch,
+                                            float voxel_size, const float *feats_nhwc, const float *krcam, int n_views,
+                                            int channels, int height, int width, int mode, const float *dout, int ld_dout,
+                                            const float *dmean, float *dfeats_nhwc, void *workspace, size_t workspace_bytes,
+                                            void *stream)
+{
+    if (!workspace) return EPRECON_ERR_ARG;
+    return bp_backward_impl(coords_valid, n_valid, origin, batch, voxel_size, feats_nhwc, krcam, n_views, channels, height, width, mode,
+                            dout, ld_dout, dmean, dfeats_nhwc, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

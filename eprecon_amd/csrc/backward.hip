@@ -231,6 +231,24 @@ __global__ __launch_bounds__(256) void devoxelize_bwd_kernel(const float *dout, 
     }
 }
 
+// The same without atomics: the (point, corner) entries that reach a voxel come as a CSR list (eprecon_segment_lists_async over
+// the flattened idx8: ascending entry index inside a voxel), one thread per (voxel, channel) adds its entries up in list order.
+// Deterministic; the list depends on the corner table only and is shared by every layer that devoxelises with it.
+__global__ __launch_bounds__(256) void devoxelize_bwd_csr_kernel(const float *dout, int ld_o, const float *w8, const int32_t *offsets,
+                                                                 const int32_t *order, int64_t m, int channels, float *dfeat, int ld_f)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= m * channels) return;
+    const int64_t v = e / channels;
+    const int c = (int)(e - v * channels);
+    float acc = 0.0f;
+    for (int k = offsets[v]; k < offsets[v + 1]; ++k) {
+        const int ent = order[k];
+        acc = fmaf(w8[ent], dout[(int64_t)(ent >> 3) * ld_o + c], acc);
+    }
+    dfeat[v * ld_f + c] = acc;
+}
+
 __global__ __launch_bounds__(256) void gather_rows_scaled_kernel(const float *src, int ld_s, const int32_t *idx,
                                                                  const float *scale, int64_t n, int channels, float *dst,
                                                                  int ld_d)
@@ -338,6 +356,19 @@ int eprecon_devoxelize_backward_async(const float *dout, int ld_out, const int32
                            ld_out, idx8, weight8, n, channels, dvoxel_feat, ld_feat);
         EP_LAUNCH_CHECK();
     }
+    return EPRECON_OK;
+}
+
+int eprecon_devoxelize_backward_csr_async(const float *dout, int ld_out, const float *weight8, const int32_t *offsets,
+                                          const int32_t *order, int64_t n_voxels, int channels, float *dvoxel_feat, int ld_feat,
+                                          void *stream)
+{
+    if (channels < 0 || n_voxels < 0) return EPRECON_ERR_ARG;
+    if (n_voxels == 0 || channels == 0) return EPRECON_OK;
+    if (!dout || !weight8 || !offsets || !order || !dvoxel_feat || n_voxels * channels > 0x7fffffffll * 256) return EPRECON_ERR_ARG;
+    hipLaunchKernelGGL(devoxelize_bwd_csr_kernel, dim3((unsigned)ep::ceil_div(n_voxels * channels, 256)), dim3(256), 0,
+                       (hipStream_t)stream, dout, ld_out, weight8, offsets, order, n_voxels, channels, dvoxel_feat, ld_feat);
+    EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }
 

@@ -869,6 +869,13 @@ int eprecon_sparse_conv_wgrad_async(const float *x, int ld_x, const float *dy, i
 int eprecon_invert_map_async(const int32_t *nbr, int kvol, int64_t n_out, int64_t n_in, int32_t *inv, void *stream);
 int eprecon_devoxelize_backward_async(const float *dout, int ld_out, const int32_t *idx8, const float *weight8, int64_t n,
                                       int channels, int64_t n_voxels, float *dvoxel_feat, int ld_feat, void *stream);
+/* the same without float atomics (run-to-run bit-identical): offsets int32[n_voxels + 1] / order int32[<= 8 n] = the CSR lists
+ * of eprecon_segment_lists_async over the flattened idx8 (entry e = 8 p + corner; entries of missing corners are skipped);
+ * dvoxel_feat[v] = sum over the voxel's entries in list order of weight8[e] * dout[e / 8].  The lists depend on the corner
+ * table only: build once, reuse for every layer that devoxelises with it. */
+int eprecon_devoxelize_backward_csr_async(const float *dout, int ld_out, const float *weight8, const int32_t *offsets,
+                                          const int32_t *order, int64_t n_voxels, int channels, float *dvoxel_feat, int ld_feat,
+                                          void *stream);
 int eprecon_gather_rows_scaled_async(const float *src, int ld_src, const int32_t *idx, const float *scale, int64_t n,
                                      int channels, float *dst, int ld_dst, void *stream);
 /* back-projection: d feats[view][b][y][x][c] (channels-last, zeroed here) from d out f32[n_valid, ld_dout] (and, mode
@@ -879,6 +886,14 @@ int eprecon_back_project_backward_async(const int32_t *coords_valid, int64_t n_v
                                         float voxel_size, const float *feats_nhwc, const float *krcam, int n_views,
                                         int channels, int height, int width, int mode, const float *dout, int ld_dout,
                                         const float *dmean, float *dfeats_nhwc, void *stream);
+/* the same, run-to-run bit-identical: contributions are accumulated as 64-bit fixed point (2^-40 resolution, |sum| < 8.4e6) with
+ * integer atomics — order-independent — in `workspace` (eprecon_back_project_backward_workspace_bytes) and converted at the end */
+size_t eprecon_back_project_backward_workspace_bytes(int batch, int n_views, int channels, int height, int width);
+int eprecon_back_project_backward_det_async(const int32_t *coords_valid, int64_t n_valid, const float *origin, int batch,
+                                            float voxel_size, const float *feats_nhwc, const float *krcam, int n_views,
+                                            int channels, int height, int width, int mode, const float *dout, int ld_dout,
+                                            const float *dmean, float *dfeats_nhwc, void *workspace, size_t workspace_bytes,
+                                            void *stream);
 
 #ifdef __cplusplus
 }

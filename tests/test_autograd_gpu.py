@@ -133,6 +133,23 @@ def test_devoxelize_and_segment_mean_gradients():
     close(a.grad, r.grad)
 
 
+def test_devoxelize_gradient_is_bit_identical_run_to_run():
+    """no float atomics: the (point, corner) entries of a voxel are summed in CSR-list order"""
+    from eprecon_amd import autograd as AG
+    z, x = point_case(50000, 24, seed=7)
+    idx8, w8 = z.idx_query[1], z.weights[1]
+    m = x.F.shape[0]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    vf = torch.randn(m, 24, device="cuda", generator=g)
+    dout = torch.randn(50000, 24, device="cuda", generator=g)
+    grads = []
+    for _ in range(3):
+        a = vf.clone().requires_grad_()
+        AG.devoxelize(a, idx8, w8).backward(dout)
+        grads.append(a.grad.clone())
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+
+
 def _grid_sample_reference(feats, grid, mask, mode):
     """feats [V,B=1,C,H,W], grid [V,N,2], mask bool[V,N] -> the reference's masked mean / variance"""
     v = feats.shape[0]

@@ -61,6 +61,33 @@ def test_optimisation_steps_reduce_the_loss(step):
     assert np.isfinite(last) and last < first, (first, last)
 
 
+def test_two_identical_steps_give_identical_gradients():
+    """the backward of the HIP operators is run-to-run bit-identical (weight gradients reduced in chunk order, devoxelise
+    through CSR lists, back-projection through 64-bit fixed-point integer atomics); PyTorch's own scatter ops (index_put with
+    accumulate in the criterion / panoptic tail) are asked for their deterministic forms"""
+    from eprecon_amd.fragment_step import TrainStep
+    prev = torch.are_deterministic_algorithms_enabled()
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    try:
+        s = TrainStep(seed=0, lr=2e-6)
+        grads = []
+        for _ in range(2):
+            s.optimizer.zero_grad(set_to_none=True)
+            _, losses = s.loss()
+            losses["total_loss"].backward()
+            grads.append({n: p.grad.clone() for n, p in s.net.named_parameters() if p.grad is not None})
+            grads[-1]["__features__"] = s.f2[0][0].grad.clone()
+            for views in (s.f1, s.f2):
+                for levels in views:
+                    for t in levels:
+                        t.grad = None
+    finally:
+        torch.use_deterministic_algorithms(prev)
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 100
+    different = [n for n in grads[0] if not torch.equal(grads[0][n], grads[1][n])]
+    assert not different, different[:10]
+
+
 def test_only_train_init_loss(step):
     step.net.gru_fusion.scene_name = [None, None, None]
     outputs, losses = step.net(step.f1, step.f2, step.inputs, {}, only_train_init=True)
