@@ -261,7 +261,10 @@ __global__ __launch_bounds__(256) void affine_rows_res_kernel(const float *x, in
 // (One-launch forms for short summary lists — every workgroup finishing the statistics itself before applying them — were
 // measured twice and removed: round 3 with one wave per channel (a 10 us serial chain of Chan merges per workgroup), round 4
 // with 256 / C row groups merging side by side and the launch limited to ~16 MB of redundant summary reads: SPVCNN still lost
-// 0.1-0.18 ms per level against the separate 5 us finalize launch, gpurun r04_c / r04_d.)
+// 0.1-0.18 ms per level against the separate 5 us finalize launch, gpurun r04_c / r04_d.  A third form — workgroups of
+// 64 channels x 256 rows, the list merged once per workgroup by four row lanes with eight summary rows in flight — lost as well:
+// SPVCNN of the coarsest level 1.42 -> 1.68 ms.  The merge is a chain of dependent divisions; 74 workgroups repeating it in
+// front of their rows is slower than one 5 us launch doing it once.)
 int bn_finalize_apply(const float *x, int64_t n, int channels, int ld_x, const float *partial, int nblk,
                       const float *gamma, const float *beta, float eps, const float *residual, int ld_res,
                       int relu, float *out, int ld_out, float *mean, float *var, hipStream_t st,
