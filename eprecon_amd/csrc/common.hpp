@@ -66,6 +66,15 @@ int exclusive_scan_i32(const int32_t *in, int n, int32_t *out, int32_t *scratch,
 int exclusive_scan_i32_dn(const int32_t *in, int n, const int32_t *n_dev, int32_t *out, int32_t *scratch, int32_t *total_dev,
                           hipStream_t st);
 
+// A side stream of the library's own per caller stream, for entry points that issue two independent chains of small launches
+// (csrc/gru_stage_finish.hip): record ev_fork on the caller's stream and let `side` wait for it, issue the second chain on
+// `side`, record ev_join there and let the caller's stream wait for it.
+struct Fork {
+    hipStream_t main = nullptr, side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+};
+int fork_for(hipStream_t main, Fork &out);
+
 // the gather-kernel timing hook of eprecon_profile_enable (back_project.hip), for the other gather variants
 int profile_bracket_begin(hipStream_t st);
 int profile_bracket_end(hipStream_t st, const char *kernel);

@@ -6,40 +6,53 @@
 
 extern "C" {
 
-size_t eprecon_spvcnn_geometry_workspace_bytes(int64_t n, int64_t n1, int64_t n4)
+static size_t geometry_half_bytes(int64_t n, int64_t n1, int64_t n4)
 {
     const size_t a = eprecon_segment_workspace_bytes(n, n1), b = eprecon_segment_workspace_bytes(n, n4);
-    return a > b ? a : b;
+    return ep::align_up(a > b ? a : b, 256);
 }
+
+size_t eprecon_spvcnn_geometry_workspace_bytes(int64_t n, int64_t n1, int64_t n4) { return 2 * geometry_half_bytes(n, n1, n4); }
 
 int eprecon_spvcnn_geometry_async(const eprecon_spvcnn_geometry_desc *d, void *stream)
 {
     if (!d || d->n < 0 || d->n1 < 0 || d->n2 < 0 || d->n4 < 0) return EPRECON_ERR_ARG;
     if (d->n == 0 || d->n1 == 0) return EPRECON_OK;
     if (d->workspace_bytes < eprecon_spvcnn_geometry_workspace_bytes(d->n, d->n1, d->n4)) return EPRECON_ERR_WORKSPACE;
+    const size_t half = geometry_half_bytes(d->n, d->n1, d->n4);
+    void *ws_a = d->workspace, *ws_b = (char *)d->workspace + half;
+    hipStream_t main = (hipStream_t)stream;
+    ep::Fork f;
+    int rc = ep::fork_for(main, f);
+    if (rc != EPRECON_OK) return rc;
+    void *side = (void *)f.side;
 #define EP_STEP(call)                \
     do {                             \
         const int rc_ = (call);      \
         if (rc_ != EPRECON_OK) return rc_; \
     } while (0)
-    EP_STEP(eprecon_segment_lists_async(d->inverse1, d->n, d->n1, d->offsets1, d->order1, d->workspace, d->workspace_bytes, stream));
+    // two independent chains of small launches side by side (see ep::Fork): the strided sets on the library's side stream ...
+    EP_HIP_CHECK(hipEventRecord(f.ev_fork, main));
+    EP_HIP_CHECK(hipStreamWaitEvent(f.side, f.ev_fork, 0));
     if (d->n2 > 0) {
-        EP_STEP(eprecon_kernel_map_async(d->table1, d->capacity1, d->coords2, d->n2, 2, 1, d->down12, stream));
-        EP_STEP(eprecon_transpose_map_async(d->coords1, d->n1, d->parent2, 1, d->up21, stream));
+        EP_STEP(eprecon_kernel_map_async(d->table1, d->capacity1, d->coords2, d->n2, 2, 1, d->down12, side));
+        EP_STEP(eprecon_transpose_map_async(d->coords1, d->n1, d->parent2, 1, d->up21, side));
+        EP_STEP(eprecon_kernel_map_async(d->table2, d->capacity2, d->coords2, d->n2, 3, 2, d->k2, side));
     }
     if (d->n4 > 0) {
-        EP_STEP(eprecon_kernel_map_async(d->table2, d->capacity2, d->coords4, d->n4, 2, 2, d->down24, stream));
-        EP_STEP(eprecon_transpose_map_async(d->coords2, d->n2, d->parent4, 2, d->up42, stream));
+        EP_STEP(eprecon_kernel_map_async(d->table2, d->capacity2, d->coords4, d->n4, 2, 2, d->down24, side));
+        EP_STEP(eprecon_transpose_map_async(d->coords2, d->n2, d->parent4, 2, d->up42, side));
+        EP_STEP(eprecon_kernel_map_async(d->table4, d->capacity4, d->coords4, d->n4, 3, 4, d->k4, side));
+        EP_STEP(eprecon_hash_query_async(d->table4, d->capacity4, d->vox, d->n, 4, d->idx4, side));
+        EP_STEP(eprecon_segment_lists_async(d->idx4, d->n, d->n4, d->offsets4, d->order4, ws_b, half, side));
+        EP_STEP(eprecon_trilinear_map_async(d->table4, d->capacity4, d->scaled, d->n, 4, d->idx8_4, d->weight8_4, side));
     }
+    EP_HIP_CHECK(hipEventRecord(f.ev_join, f.side));
+    // ... the stride-1 set on the caller's
+    EP_STEP(eprecon_segment_lists_async(d->inverse1, d->n, d->n1, d->offsets1, d->order1, ws_a, half, stream));
     EP_STEP(eprecon_kernel_map_async(d->table1, d->capacity1, d->coords1, d->n1, 3, 1, d->k1, stream));
-    if (d->n2 > 0) EP_STEP(eprecon_kernel_map_async(d->table2, d->capacity2, d->coords2, d->n2, 3, 2, d->k2, stream));
-    if (d->n4 > 0) EP_STEP(eprecon_kernel_map_async(d->table4, d->capacity4, d->coords4, d->n4, 3, 4, d->k4, stream));
     EP_STEP(eprecon_trilinear_map_async(d->table1, d->capacity1, d->scaled, d->n, 1, d->idx8_1, d->weight8_1, stream));
-    if (d->n4 > 0) {
-        EP_STEP(eprecon_hash_query_async(d->table4, d->capacity4, d->vox, d->n, 4, d->idx4, stream));
-        EP_STEP(eprecon_segment_lists_async(d->idx4, d->n, d->n4, d->offsets4, d->order4, d->workspace, d->workspace_bytes, stream));
-        EP_STEP(eprecon_trilinear_map_async(d->table4, d->capacity4, d->scaled, d->n, 4, d->idx8_4, d->weight8_4, stream));
-    }
+    EP_HIP_CHECK(hipStreamWaitEvent(main, f.ev_join, 0));
 #undef EP_STEP
     return EPRECON_OK;
 }
