@@ -133,7 +133,7 @@ def test_convgru_with_fresh_indices_runs(scene, monkeypatch):
 
 
 def test_pipelined_modes(scene, default_run):
-    """EPRECON_CFG4_PIPELINE=1 with and without the worker thread (EPRECON_PIPELINE_THREAD=0): a throughput mode, same fragments"""
+    """EPRECON_CFG4_PIPELINE=1 (bench.py): the pipelined serving mode, with and without the worker thread — same fragments"""
     try:
         for mode in (True, "inline"):
             scene.set_pipeline(mode)
