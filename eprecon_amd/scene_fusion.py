@@ -126,10 +126,15 @@ class SceneFusion:
             origin = inputs["vol_origin_partial"][i]
             rel = ((origin.detach().float().cpu() - self.global_origin) / voxel_size).long()
             rel_t = rel.to(device=dev, dtype=torch.int32)
-            rows = torch.nonzero(coords[:, 0] == i).squeeze(1)
-            if rows.numel() == 0:
-                continue
-            lo, hi = int(rows[0]), int(rows[-1]) + 1
+            if len(inputs["fragment"]) == 1:
+                lo, hi = 0, coords.shape[0]        # every row belongs to the one batch element: no row search, no host read
+                if hi == 0:
+                    continue
+            else:
+                rows = torch.nonzero(coords[:, 0] == i).squeeze(1)
+                if rows.numel() == 0:
+                    continue
+                lo, hi = int(rows[0]), int(rows[-1]) + 1
             cur_c, cur_f = coords[lo:hi].contiguous(), values_in[lo:hi].contiguous()
             updated, src_cur, src_glob, gvalid = fbv_union(cur_c, cur_f, self.C, self.F, dim, interval, rel.tolist(), mode=1)
             values = gather_rows(cur_f, src_cur, 1, fill=1.0)
@@ -138,10 +143,11 @@ class SceneFusion:
             seg_ids = gather_rows(seg_src, src_cur, 1, fill=0.0).squeeze(1).to(torch.int32)
             seg[0] = seg_ids
             new_inst, new_sem = self._panoptic_fusion(gvalid, rel_t, seg_ids, seg[1], updated)
-            self.F = torch.cat([self.F[~gvalid], values])
-            self.C = torch.cat([self.C[~gvalid], updated + rel_t])
-            self.instance = torch.cat([self.instance[~gvalid], new_inst])
-            self.semantic = torch.cat([self.semantic[~gvalid], new_sem])
+            outside = torch.nonzero(~gvalid).squeeze(1)     # ONE row search for the four state tensors (boolean indexing: one each)
+            self.F = torch.cat([self.F.index_select(0, outside), values])
+            self.C = torch.cat([self.C.index_select(0, outside), updated + rel_t])
+            self.instance = torch.cat([self.instance.index_select(0, outside), new_inst])
+            self.semantic = torch.cat([self.semantic.index_select(0, outside), new_sem])
             if save_mesh:
                 outputs = self.save_mesh(outputs, self.scene_name)
         return outputs
