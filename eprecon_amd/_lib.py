@@ -299,6 +299,25 @@ class Mlp4xDesc(ctypes.Structure):
                 ("eps2", ctypes.c_float), ("head", Mlp4xHead * 2)]
 
 
+# Side streams are shared by role across every model object of the process: HIP multiplexes streams onto a few hardware
+# queues (four by default), and a process that builds several networks, each creating its own side streams, piles up
+# fifteen of them.
+SIDE_PAIR, SIDE_BRANCH_A, SIDE_BRANCH_B, SIDE_PANOPTIC, SIDE_EXCHANGE, SIDE_SETUP = range(6)
+_SIDE_STREAMS = {}
+
+
+def side_stream(device, role):
+    """the process-wide side stream of `role` on `device`: SIDE_PAIR the second of two twin networks (ConvGRU cells, 2D
+    backbones), SIDE_BRANCH_A / _B the outer levels of the 2D fusion stack, SIDE_PANOPTIC the pipelined panoptic branch,
+    SIDE_EXCHANGE the boundary exchange, SIDE_SETUP one-off warm-up / graph-capture work"""
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (index, role)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=torch.device("cuda", index))
+    return st
+
+
 _WORKSPACES = {}
 
 

@@ -276,7 +276,7 @@ class Cfg4Step:
         self.net.panoptic_stream = self.net.panoptic_worker = None
         self.pipeline = pipeline
         if pipeline:
-            self.net.panoptic_stream = torch.cuda.Stream(device=self.device)
+            self.net.panoptic_stream = _lib.side_stream(self.device, _lib.SIDE_PANOPTIC)
             if pipeline != "inline":
                 from concurrent.futures import ThreadPoolExecutor
                 self.net.panoptic_worker = ThreadPoolExecutor(max_workers=1, thread_name_prefix="eprecon-panoptic")

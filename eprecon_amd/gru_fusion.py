@@ -176,7 +176,7 @@ class GRUFusion(nn.Module):
             # ahead of the GPU — and end the run-ahead at the start of every fragment.  On its own stream it waits only for
             # the event behind the last map update; the main stream joins it afterwards (the merges change the maps).
             if self._xchg_stream is None:
-                self._xchg_stream = torch.cuda.Stream(device=dev)
+                self._xchg_stream = _lib.side_stream(dev, _lib.SIDE_EXCHANGE)
             main = torch.cuda.current_stream(dev)
             # The origins are inputs of THIS fragment: produced / uploaded on the main stream after `_map_ready` was recorded,
             # so the side stream is not ordered behind them.  Their host copy is therefore taken here, on the main stream
@@ -247,7 +247,7 @@ class GRUFusion(nn.Module):
         elif self.two_streams:
             main = torch.cuda.current_stream(dev)
             if self._side is None:
-                self._side = torch.cuda.Stream(device=dev)
+                self._side = _lib.side_stream(dev, _lib.SIDE_PAIR)
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
                 gi(PointTensor(hx_i[:, :chi], r_coords), PointTensor(hx_i[:, chi:], r_coords), out=values[:, chv:])
@@ -348,7 +348,7 @@ class GRUFusion(nn.Module):
                     prepare_convgru_voxelizations(r_coords, gv.convz.pres, gv.convz.vres)
                     main = torch.cuda.current_stream(dev)
                     if self._side is None:
-                        self._side = torch.cuda.Stream(device=dev)
+                        self._side = _lib.side_stream(dev, _lib.SIDE_PAIR)
                     self._side.wait_stream(main)
                     with torch.cuda.stream(self._side):
                         gi(PointTensor(hx_i[:, :chi], r_coords), PointTensor(hx_i[:, chi:], r_coords), out=values[:, chv:])

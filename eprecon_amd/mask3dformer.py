@@ -288,7 +288,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         attn0 = self.transformer_cross_attention_layers[0].multihead_attn
         h, c = attn0.num_heads, attn0.embed_dim
         state = self.query_feat.weight.unsqueeze(1)
-        side = torch.cuda.Stream(device=device)
+        side = _lib.side_stream(device, _lib.SIDE_SETUP)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
             cls0, me0 = self._head_static(state)

@@ -9,6 +9,7 @@ way main.py:430-436 calls it.  With autograd enabled loss_dict carries the train
 import torch
 import torch.nn as nn
 
+from . import _lib
 from .backbone import MnasMulti
 from .gru_fusion import GRUFusion
 from .neucon_network import NeuConNet
@@ -79,7 +80,7 @@ class NeuralRecon(nn.Module):
                 # stream (their late, low-resolution layers leave most of the chip idle on their own)
                 main = torch.cuda.current_stream(dev)
                 if self._side is None:
-                    self._side = torch.cuda.Stream(device=dev)
+                    self._side = _lib.side_stream(dev, _lib.SIDE_PAIR)
                 self._side.wait_stream(main)
                 with torch.cuda.stream(self._side):
                     features_occ_pano = self.backbone_occ_pano.forward_views(norm)

@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
 from . import back_project as BP
 from . import dense2d as D2
 from . import sparse as SP
@@ -95,7 +96,7 @@ class Occupancy_Initialization(nn.Module):
         # join at the concat (under HIP-graph capture this becomes three parallel branches).
         main = torch.cuda.current_stream()
         if self._side_streams is None:
-            self._side_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            self._side_streams = (_lib.side_stream(dev, _lib.SIDE_BRANCH_A), _lib.side_stream(dev, _lib.SIDE_BRANCH_B))
         s1, s4 = self._side_streams
         s1.wait_stream(main)
         s4.wait_stream(main)
@@ -122,7 +123,7 @@ class Occupancy_Initialization(nn.Module):
         entry = self._graphs.get(key)
         if entry is None:
             static_in = [torch.stack(v) for v in views]
-            side = torch.cuda.Stream()
+            side = _lib.side_stream(static_in[0].device, _lib.SIDE_SETUP)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(3):  # first-use work (kernel maps, packed weights) happens outside the capture
