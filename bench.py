@@ -218,8 +218,14 @@ def extra_workloads(device, lib, steps3=12, steps4=16, warm4=4):
 
     def leg(name, fn):
         try:
+            # Every leg starts with the previous leg's networks really gone.  They sit in reference cycles, and until the
+            # collector runs their HIP-graph executables (three parallel branches each) and streams stay alive: the
+            # multi-stream parts of the NEXT leg then measured 23-27 ms per e2e fragment instead of 18.5-19.6 (four boxes;
+            # bisected down to this line).
+            import gc
             sync()
-            torch.cuda.empty_cache()     # every leg starts from an empty caching allocator
+            gc.collect()
+            torch.cuda.empty_cache()
             fn()
         except Exception as exc:  # noqa: BLE001
             out[f"{name}_error"] = f"{type(exc).__name__}: {exc}"
@@ -294,13 +300,8 @@ def extra_workloads(device, lib, steps3=12, steps4=16, warm4=4):
         out["train_finest_voxels_min_max"] = [min(step.voxels), max(step.voxels)] if step.voxels else None
         out["train_workload"] = step.describe()["workload"] + " (lr 1e-6, see bench.py)"
 
-    # e2e first: behind the cfg3 / cfg4 / pipelined legs of the same process it measured 23-27 ms per fragment on four boxes
-    # where it measures 19.0-19.6 ms on its own, in front of them, or behind any single one of them (tools/profile_e2e.py and
-    # bisections of this function).  Not tracked down (not the caching allocator, not the number of side streams — both
-    # tried); the multi-stream pipelined figure of the cfg4 leg is the one that pays when it runs second (13 -> 16 ms),
-    # the unpipelined contract figure does not move.
-    leg("e2e", e2e)
     leg("cfg34", cfg34)
+    leg("e2e", e2e)
     leg("train", train)
     prof = newest_profile("cfg4_kernel_stats.json")
     if prof:
