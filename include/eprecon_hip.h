@@ -800,6 +800,9 @@ int eprecon_dwconv2d_nhwc_async(const float *x, int n, int height, int width, in
  *   literal == 0: the second voxelisation's own corner tables (idx8_2, weight8_2 from scaled2).
  * Replaces the same sequence of single calls (eprecon_segment_lists_async, eprecon_kernel_map_async,
  * eprecon_trilinear_map_async, eprecon_sphash_order_async, eprecon_remap_index_async): bit-identical outputs.
+ * The second voxelisation's chain is issued on a side stream the library owns (one per caller stream, forked from and joined to
+ * `stream` with events inside the call): on return everything is ordered on `stream` as usual.  Like every call that forks, it
+ * must not be issued while `stream` is being captured into a HIP graph.  (eprecon_spvcnn_geometry_async does the same.)
  */
 typedef struct eprecon_gru_finish_desc {
     int64_t n; int64_t m1; int64_t m2;
