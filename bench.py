@@ -432,7 +432,8 @@ def main():
     if args.workload == "train":
         from eprecon_amd.fragment_step import TrainStep
         # data parallel: one fragment per rank and step, gradients all-reduced by DDP over RCCL
-        return bench_cfg4(args, TrainStep(seed=0, device=torch.device("cuda", local_rank), rank=rank, world=world),
+        # (lr 1e-6: see extra_workloads.train — at the reference's 1e-4 the synthetic fragment leaves its sparsity regime after a step)
+        return bench_cfg4(args, TrainStep(seed=0, device=torch.device("cuda", local_rank), rank=rank, world=world, lr=1e-6),
                           world, rank, dist, use_dist)
     if args.workload == "cfg4":
         from eprecon_amd.fragment_step import Cfg4Step
