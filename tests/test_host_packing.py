@@ -73,3 +73,25 @@ def test_sizing_functions_of_the_library():
     assert lib.eprecon_sphash_order_workspace_bytes(400000) > lib.eprecon_sphash_order_workspace_bytes(1000) > 0
     assert lib.eprecon_gru_stage_finish_workspace_bytes(1000, 900, 1000) >= lib.eprecon_sphash_order_workspace_bytes(1000)
     assert lib.eprecon_spvcnn_geometry_workspace_bytes(1000, 900, 100) > 0
+
+
+def test_backbone_walker_on_the_pytorch_fallbacks():
+    """MnasMulti._run_hip (one module of look-ahead: pending BatchNorm in front of a depthwise layer, the block's skip added by
+    the last BatchNorm's apply pass) walks the trunk correctly: on CPU tensors every HIP piece falls back to its PyTorch
+    expression, and the result must equal the plain per-view route"""
+    import eprecon_amd.backbone as BB
+    torch.manual_seed(0)
+    net = BB.MnasMulti(1.0).train()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.7, 1.3)
+                m.bias.uniform_(-0.2, 0.2)
+        x = torch.randn(4, 3, 32, 48).contiguous(memory_format=torch.channels_last)     # two views of two images
+        v = 2
+        for stage in (net.conv0, net.conv1):
+            a = net._run(stage, x, v)
+            b = net._run_hip(stage, x, v)
+            assert a.shape == b.shape
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-4), float((a - b).abs().max())
+            x = a
