@@ -68,22 +68,32 @@ int eprecon_gru_stage_finish_async(const eprecon_gru_finish_desc *d, void *strea
         const int rc_ = (call);            \
         if (rc_ != EPRECON_OK) return rc_; \
     } while (0)
-    // ---- second voxelisation: side stream ----
+    // Each chain is a lambda so that a failing step cannot skip the join: whatever was issued on the side stream is
+    // ordered before the caller's later work either way, and the first error is what the call returns.
+    auto second = [&]() -> int {  // ---- second voxelisation: side stream ----
+        EP_STEP(eprecon_segment_lists_async(d->inverse2, d->n, d->m2, d->offsets2, d->order2, ws_b, half, side));
+        if (d->m2 > 0) EP_STEP(eprecon_kernel_map_async(d->table2, d->table_capacity, d->uniq2, d->m2, 3, 1, d->nbr2, side));
+        if (d->literal)
+            EP_STEP(eprecon_sphash_order_async(d->uniq2, d->m2, d->perm2, d->rank2, ws_b, half, side));
+        else
+            EP_STEP(eprecon_trilinear_map_async(d->table2, d->table_capacity, d->scaled2, d->n, 1, d->idx8_2, d->weight8_2, side));
+        return EPRECON_OK;
+    };
+    auto first = [&]() -> int {  // ---- first voxelisation: the caller's stream ----
+        EP_STEP(eprecon_segment_lists_async(d->inverse1, d->n, d->m1, d->offsets1, d->order1, ws_a, half, stream));
+        if (d->m1 > 0) EP_STEP(eprecon_kernel_map_async(d->table1, d->table_capacity, d->uniq1, d->m1, 3, 1, d->nbr1, stream));
+        EP_STEP(eprecon_trilinear_map_async(d->table1, d->table_capacity, d->scaled1, d->n, 1, d->idx8_1, d->weight8_1, stream));
+        if (d->literal) EP_STEP(eprecon_sphash_order_async(d->uniq1, d->m1, d->perm1, d->rank1, ws_a, half, stream));
+        return EPRECON_OK;
+    };
     EP_HIP_CHECK(hipEventRecord(f.ev_fork, main));
     EP_HIP_CHECK(hipStreamWaitEvent(f.side, f.ev_fork, 0));
-    EP_STEP(eprecon_segment_lists_async(d->inverse2, d->n, d->m2, d->offsets2, d->order2, ws_b, half, side));
-    if (d->m2 > 0) EP_STEP(eprecon_kernel_map_async(d->table2, d->table_capacity, d->uniq2, d->m2, 3, 1, d->nbr2, side));
-    if (d->literal)
-        EP_STEP(eprecon_sphash_order_async(d->uniq2, d->m2, d->perm2, d->rank2, ws_b, half, side));
-    else
-        EP_STEP(eprecon_trilinear_map_async(d->table2, d->table_capacity, d->scaled2, d->n, 1, d->idx8_2, d->weight8_2, side));
+    const int rc_second = second();
     EP_HIP_CHECK(hipEventRecord(f.ev_join, f.side));
-    // ---- first voxelisation: the caller's stream ----
-    EP_STEP(eprecon_segment_lists_async(d->inverse1, d->n, d->m1, d->offsets1, d->order1, ws_a, half, stream));
-    if (d->m1 > 0) EP_STEP(eprecon_kernel_map_async(d->table1, d->table_capacity, d->uniq1, d->m1, 3, 1, d->nbr1, stream));
-    EP_STEP(eprecon_trilinear_map_async(d->table1, d->table_capacity, d->scaled1, d->n, 1, d->idx8_1, d->weight8_1, stream));
-    if (d->literal) EP_STEP(eprecon_sphash_order_async(d->uniq1, d->m1, d->perm1, d->rank1, ws_a, half, stream));
+    const int rc_first = first();
     EP_HIP_CHECK(hipStreamWaitEvent(main, f.ev_join, 0));
+    if (rc_second != EPRECON_OK) return rc_second;
+    if (rc_first != EPRECON_OK) return rc_first;
     if (d->literal) EP_STEP(eprecon_remap_index_async(d->idx8_1, d->n * 8, d->rank1, d->perm2, d->m2, d->idx8_2, stream));
 #undef EP_STEP
     return EPRECON_OK;

@@ -26,33 +26,43 @@ int eprecon_spvcnn_geometry_async(const eprecon_spvcnn_geometry_desc *d, void *s
     int rc = ep::fork_for(main, f);
     if (rc != EPRECON_OK) return rc;
     void *side = (void *)f.side;
-#define EP_STEP(call)                \
-    do {                             \
-        const int rc_ = (call);      \
+#define EP_STEP(call)                      \
+    do {                                   \
+        const int rc_ = (call);            \
         if (rc_ != EPRECON_OK) return rc_; \
     } while (0)
-    // two independent chains of small launches side by side (see ep::Fork): the strided sets on the library's side stream ...
+    // two independent chains of small launches side by side (see ep::Fork); each is a lambda so that a failing step cannot
+    // skip the join, and the first error is what the call returns
+    auto strided = [&]() -> int {  // the strided sets: the library's side stream
+        if (d->n2 > 0) {
+            EP_STEP(eprecon_kernel_map_async(d->table1, d->capacity1, d->coords2, d->n2, 2, 1, d->down12, side));
+            EP_STEP(eprecon_transpose_map_async(d->coords1, d->n1, d->parent2, 1, d->up21, side));
+            EP_STEP(eprecon_kernel_map_async(d->table2, d->capacity2, d->coords2, d->n2, 3, 2, d->k2, side));
+        }
+        if (d->n4 > 0) {
+            EP_STEP(eprecon_kernel_map_async(d->table2, d->capacity2, d->coords4, d->n4, 2, 2, d->down24, side));
+            EP_STEP(eprecon_transpose_map_async(d->coords2, d->n2, d->parent4, 2, d->up42, side));
+            EP_STEP(eprecon_kernel_map_async(d->table4, d->capacity4, d->coords4, d->n4, 3, 4, d->k4, side));
+            EP_STEP(eprecon_hash_query_async(d->table4, d->capacity4, d->vox, d->n, 4, d->idx4, side));
+            EP_STEP(eprecon_segment_lists_async(d->idx4, d->n, d->n4, d->offsets4, d->order4, ws_b, half, side));
+            EP_STEP(eprecon_trilinear_map_async(d->table4, d->capacity4, d->scaled, d->n, 4, d->idx8_4, d->weight8_4, side));
+        }
+        return EPRECON_OK;
+    };
+    auto unit = [&]() -> int {  // the stride-1 set: the caller's stream
+        EP_STEP(eprecon_segment_lists_async(d->inverse1, d->n, d->n1, d->offsets1, d->order1, ws_a, half, stream));
+        EP_STEP(eprecon_kernel_map_async(d->table1, d->capacity1, d->coords1, d->n1, 3, 1, d->k1, stream));
+        EP_STEP(eprecon_trilinear_map_async(d->table1, d->capacity1, d->scaled, d->n, 1, d->idx8_1, d->weight8_1, stream));
+        return EPRECON_OK;
+    };
     EP_HIP_CHECK(hipEventRecord(f.ev_fork, main));
     EP_HIP_CHECK(hipStreamWaitEvent(f.side, f.ev_fork, 0));
-    if (d->n2 > 0) {
-        EP_STEP(eprecon_kernel_map_async(d->table1, d->capacity1, d->coords2, d->n2, 2, 1, d->down12, side));
-        EP_STEP(eprecon_transpose_map_async(d->coords1, d->n1, d->parent2, 1, d->up21, side));
-        EP_STEP(eprecon_kernel_map_async(d->table2, d->capacity2, d->coords2, d->n2, 3, 2, d->k2, side));
-    }
-    if (d->n4 > 0) {
-        EP_STEP(eprecon_kernel_map_async(d->table2, d->capacity2, d->coords4, d->n4, 2, 2, d->down24, side));
-        EP_STEP(eprecon_transpose_map_async(d->coords2, d->n2, d->parent4, 2, d->up42, side));
-        EP_STEP(eprecon_kernel_map_async(d->table4, d->capacity4, d->coords4, d->n4, 3, 4, d->k4, side));
-        EP_STEP(eprecon_hash_query_async(d->table4, d->capacity4, d->vox, d->n, 4, d->idx4, side));
-        EP_STEP(eprecon_segment_lists_async(d->idx4, d->n, d->n4, d->offsets4, d->order4, ws_b, half, side));
-        EP_STEP(eprecon_trilinear_map_async(d->table4, d->capacity4, d->scaled, d->n, 4, d->idx8_4, d->weight8_4, side));
-    }
+    const int rc_strided = strided();
     EP_HIP_CHECK(hipEventRecord(f.ev_join, f.side));
-    // ... the stride-1 set on the caller's
-    EP_STEP(eprecon_segment_lists_async(d->inverse1, d->n, d->n1, d->offsets1, d->order1, ws_a, half, stream));
-    EP_STEP(eprecon_kernel_map_async(d->table1, d->capacity1, d->coords1, d->n1, 3, 1, d->k1, stream));
-    EP_STEP(eprecon_trilinear_map_async(d->table1, d->capacity1, d->scaled, d->n, 1, d->idx8_1, d->weight8_1, stream));
+    const int rc_unit = unit();
     EP_HIP_CHECK(hipStreamWaitEvent(main, f.ev_join, 0));
+    if (rc_strided != EPRECON_OK) return rc_strided;
+    if (rc_unit != EPRECON_OK) return rc_unit;
 #undef EP_STEP
     return EPRECON_OK;
 }
