@@ -64,4 +64,7 @@ rm -f $(find $O/busy -name "*kernel_trace.csv")
 # 6. dead offsets in the kernel maps of a fragment; the 3x3x3 shapes of a fragment one by one
 python tools/conv_tile_liveness.py 2>/dev/null > $P/conv_tile_liveness.txt
 python tools/conv_shapes_ab.py round4 2>/dev/null > $P/conv_shapes.txt
+
+# static: registers / LDS / scratch / waves per SIMD of every kernel, from the code objects' metadata (no GPU)
+python tools/kernel_resources.py > $P/kernel_resources.txt
 ls -la $P
