@@ -1,0 +1,55 @@
+"""bench.py's record arithmetic and the committed evidence it quotes (CPU): the convolution roofline record from armed
+launches, the figure of the cfg4-leading instance alone recomputed from the committed rocprofv3 rows, the defaults of the
+driver's command line."""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_conv_record_from_armed_launches():
+    samples = [{"ms": 0.25, "rows": 1000, "pairs": 15000, "issued": 20000, "name": b"spconv_direct16_kernel"},
+               {"ms": 0.35, "rows": 1000, "pairs": 15000, "issued": 20000, "name": b"spconv_direct16_kernel"}]
+    r = bench._conv_roofline_record(samples, 27, 48, 24, "what")
+    assert r["launches_timed"] == 2 and r["avg_launch_ms"] == pytest.approx(0.30)
+    assert r["flops"] == 2.0 * 15000 * 48 * 24
+    assert r["executed_flops"] == 2.0 * 20000 * 48 * 24
+    assert r["executed_over_live"] == pytest.approx(20000 / 15000)
+    assert r["output_stationary_flops"] == 2.0 * 1000 * 27 * 48 * 24
+    assert r["achieved"] == pytest.approx(r["flops"] / 0.30e-3 / 1e12)
+    assert r["frac"] == pytest.approx(r["achieved"] / bench.F32_MFMA_PEAK_TF)
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and "1000 voxels" in r["kernel"]
+
+
+def test_conv_record_without_an_executed_count_falls_back_to_every_offset():
+    r = bench._conv_roofline_record([{"ms": 1.0, "rows": 10, "pairs": 100, "issued": 0, "name": b"k"}], 27, 8, 8, "w")
+    assert r["executed_flops"] == 2.0 * 10 * 27 * 8 * 8
+
+
+def test_instance_alone_recomputes_from_the_committed_rows():
+    """`roofline_conv_cfg4.alone` is parsed from profiles/rNN/conv_cfg4_instance.txt: the fraction the file states must follow
+    from its own rocprofv3 average and live-pair count (the round-3 figure could not be recomputed from profiles/)"""
+    path = bench.newest_profile("conv_cfg4_instance.txt")
+    assert path and int(re.search(r"profiles/r(\d+)/", path).group(1)) >= 4
+    text = open(path).read()
+    rows, pairs = map(int, re.search(r"rows (\d+) .* live pairs (\d+)", text).groups())
+    launches, avg_us = re.search(r"rocprofv3 kernel trace: (\d+) launches .* avg ([0-9.]+) us", text).groups()
+    stated = float(re.search(r"= ([0-9.]+) of the fp32-MFMA peak", text).group(1))
+    hip_us = float(re.search(r"([0-9.]+) us per launch \(HIP events", text).group(1))
+    flops = 2.0 * pairs * 48 * 24
+    assert int(launches) >= 10 and rows > 100000
+    assert flops / (hip_us * 1e-6) / 1e12 / bench.F32_MFMA_PEAK_TF == pytest.approx(stated, abs=2e-3)
+    assert abs(float(avg_us) - hip_us) / hip_us < 0.03       # rocprofv3's average agrees with the HIP-event time
+    assert pairs <= 27 * rows
+
+
+def test_driver_defaults(monkeypatch):
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert (a.gpus, a.workload) == (1, "cfg2") and a.steps >= 10 and a.warmup >= 1
+    assert bench.HBM_PEAK_GBS == 8000.0 and 150 < bench.F32_MFMA_PEAK_TF < 160
