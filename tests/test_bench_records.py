@@ -53,3 +53,28 @@ def test_driver_defaults(monkeypatch):
     a = bench.parse()
     assert (a.gpus, a.workload) == (1, "cfg2") and a.steps >= 10 and a.warmup >= 1
     assert bench.HBM_PEAK_GBS == 8000.0 and 150 < bench.F32_MFMA_PEAK_TF < 160
+
+
+def test_headline_roofline_recomputes_from_the_committed_profiles():
+    """the bench line's `roofline` against profiles/rNN: algorithmic bytes / the rocprofv3 average of the same kernel, and the
+    PMC traffic from the raw counters with the guide's gfx950 correction (FETCH_SIZE x2, KiB)"""
+    import json
+    line = json.load(open(bench.newest_profile("bench_cfg2_r04_final.json")))
+    roof = line["roofline"]
+    assert line["metric"] and line["n_gpus"] == 1 and line["dtype"] == "f32" and line["vs_baseline"] is None
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"]) and roof["peak"] == bench.HBM_PEAK_GBS
+    assert roof["achieved"] == pytest.approx(roof["algorithmic_bytes"] / (roof["avg_launch_ms"] * 1e-3) / 1e9)
+    # 16 N + 4 V C H W + n_valid (4 C + 16) at N = 96^3, V = 9, C = 24, 120 x 160, every voxel valid (DESIGN 3a)
+    n = 96 ** 3
+    assert roof["algorithmic_bytes"] == 16 * n + 4 * 9 * 24 * 120 * 160 + n * (4 * 24 + 16)
+    summary = open(bench.newest_profile("bench_cfg2_r04_final_rocprof_summary.txt")).read()
+    avg_us = float(re.search(r"bp_gather_mlp_kernel<256, 0, 6, 1>.*?\| \d+ \| [0-9.]+ \| [0-9.]+ \| ([0-9.]+) \|", summary).group(1))
+    assert abs(avg_us - roof["avg_launch_ms"] * 1e3) / avg_us < 0.05     # HIP events in bench.py vs rocprofv3's average
+    pmc = json.load(open(bench.newest_profile("pmc_traffic_bp_gather.json")))
+    fetch = float(re.search(r"bp_gather_mlp_kernel<256, 0, 6, 1> \| grid \d+ \| FETCH_SIZE \| ([0-9.]+)", summary).group(1))
+    assert pmc["fetch_size_kib_raw"] == pytest.approx(fetch, rel=1e-4)
+    assert pmc["traffic_bytes"] == pytest.approx(2 * pmc["fetch_size_kib_raw"] * 1024 + pmc["write_size_kib"] * 1024)
+    assert os.path.exists(os.path.join(ROOT, pmc["source"]))
+    assert roof["traffic"] == pytest.approx(pmc["traffic_bytes"], rel=0.02)
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
