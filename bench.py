@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+A bare `python bench.py --gpus N` (no WORLD_SIZE in the environment) spawns the N ranks itself — one process per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT set per child — the launch model of the
+reference's main.py:67-76 (`torch.multiprocessing.spawn`-style, one rank per device).
+
 One "step" = one pass of the hot path over ONE synthetic 9-view 640x480 fragment window whose
 inputs (feature pyramids, projection matrices, voxel lists) are already resident in HBM:
 the stages listed in `Cfg2Step` (eprecon_amd.fragment_step).  With N ranks every rank processes its
@@ -330,6 +334,21 @@ def extra_workloads(device, lib, steps3=12, steps4=16, warm4=4):
     return out
 
 
+def fragment_summary(extra):
+    """The figure of merit north_star names — the WHOLE coarse-to-fine fragment (BASELINE configs[3]: 4 sequential fragments,
+    persistent GRU map, panoptic head) — at the top level of the line, next to the cfg2 headline the metric is quoted on:
+    ms per fragment, launches and blocking host reads per fragment, the leading convolution's fraction of the fp32-MFMA peak
+    (alone on the device), and the whole drop-in boundary NeuralRecon.forward."""
+    conv = extra.get("roofline_conv_cfg4") or {}
+    return {"cfg4_ms_per_fragment": extra.get("cfg4_ms_per_fragment"),
+            "cfg4_fragments_per_sec": extra.get("cfg4_fragments_per_sec"),
+            "cfg4_launches_per_fragment": extra.get("launches_per_fragment"),
+            "cfg4_blocking_reads_per_fragment": extra.get("blocking_reads_per_fragment"),
+            "cfg4_roofline_conv_alone_frac": (conv.get("alone") or {}).get("frac"),
+            "cfg4_roofline_conv_in_situ_frac": conv.get("frac"),
+            "e2e_ms_per_fragment": extra.get("e2e_ms_per_fragment")}
+
+
 def bench_cfg5(device, rank, world, dist, steps=8, warmup=4):
     """whole NeuConNet.forward per fragment with the boundary exchange on; fragments/s over all ranks"""
     import torch
@@ -404,8 +423,28 @@ def bench_cfg4(args, step, world, rank, dist, use_dist=False):
         dist.destroy_process_group()
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes of this one (same command line,
+    the rendezvous variables torch.distributed.run would set) and wait for them.  Rank 0's JSON line goes to this process's
+    stdout unchanged; the exit code is the first non-zero one of the children."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    children = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [c.wait() for c in children]
+    return next((c for c in codes if c), 0)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))
     import torch
     import torch.distributed as dist
 
@@ -415,7 +454,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        raise SystemExit(f"bench.py needs a GPU (the HIP path has no CPU fallback) [rank {rank} of {world}]")
     torch.cuda.set_device(local_rank)
     # EPRECON_BENCH_FORCE_DIST=1 exercises the RCCL path (init, barrier, MAX all-reduce) at world size 1
     use_dist = world > 1 or os.environ.get("EPRECON_BENCH_FORCE_DIST", "0") == "1"
@@ -522,6 +561,7 @@ def main():
                     out["extra"] = {"error": f"{type(exc).__name__}: {exc}"}
                 if cfg5 is not None:
                     out["extra"].update(cfg5)
+                out.update(fragment_summary(out["extra"]))
         elif cfg5 is not None:
             out["extra"] = cfg5
         if world == 1 and not args.no_cpu_baseline:

@@ -1,7 +1,9 @@
 """Regenerates tests/golden/free_run.npz: ONE fragment through the FREE-RUNNING CPU oracle (oracle/free_run.py) at cfg1
-image size (9 views of 320x240, 96^3 fragment volume, empty scene map), SURVEY.md section 4 bullet 3.
+image size (9 views of 320x240, 96^3 fragment volume, empty scene map), SURVEY.md section 4 bullet 3 — and, with
+`--size 640`, tests/golden/free_run_640.npz: the same at BASELINE's full image size (9 views of 640x480, cfg3), so that the
+error accumulation across the stages of models/neucon_network.py:230-624 is pinned at the size the metric is quoted on.
 
-    python tests/golden/make_free_run.py          (CPU only, ~2 min; does not touch /root/reference)
+    python tests/golden/make_free_run.py [--size 640]     (CPU only, a few minutes; does not touch /root/reference)
 
 This fixture pins the HIP path against the oracle END TO END (no teacher forcing): tests/test_free_run_gpu.py loads the
 calibrated occupancy heads stored here into a NeuConNet built from the same torch seed and compares its free-running
@@ -25,22 +27,24 @@ from eprecon_amd.config import ModelCfg  # noqa: E402
 from oracle import free_run as FR  # noqa: E402
 
 SEED, WINDOW, FEAT_SEED = 7, dict(seed=0, width=320, height=240), 3
+WINDOWS = {320: WINDOW, 640: dict(seed=0, width=640, height=480)}
+FILES = {320: "free_run.npz", 640: "free_run_640.npz"}
 KEEP = (0.45, 0.35, 0.25)
 
 
-def build():
+def build(size=320):
     """network and inputs exactly as tests/test_free_run_gpu.py rebuilds them"""
     from eprecon_amd.neucon_network import NeuConNet
     torch.manual_seed(SEED)
     net = NeuConNet(ModelCfg())
     net.train()
-    window = S.make_window(**WINDOW)
+    window = S.make_window(**WINDOWS[size])
     feats, feats2, inputs = S.make_model_inputs([window], feat_seed=FEAT_SEED)
     return net, feats, feats2, inputs
 
 
-def main():
-    net, feats, feats2, inputs = build()
+def main(size=320):
+    net, feats, feats2, inputs = build(size)
     sd = {k: v.detach().numpy().copy() for k, v in net.state_dict().items()}
     init = net.initialization
     with torch.no_grad():   # the dense 2D fusion stack: the same PyTorch modules on the CPU (pinned to the reference's, dense_blocks.npz)
@@ -62,10 +66,14 @@ def main():
         out[f"s{i}_counts"] = np.array([st["n_in"], st["n_fused"], st["n_occ"]])
         print(f"stage {i}: in {st['n_in']} fused {st['n_fused']} occupied {st['n_occ']}  "
               f"|logit| < 1e-3: {(np.abs(st['occ']) < 1e-3).sum()}  min |logit| {np.abs(st['occ']).min():.2e}")
-    path = os.path.join(HERE, "free_run.npz")
+    out["size"] = np.array(size)
+    path = os.path.join(HERE, FILES[size])
     np.savez_compressed(path, **out)
     print(f"free_run: {os.path.getsize(path) / 1024:.0f} KiB, finest voxels {len(rec['coords'])}")
 
 
 if __name__ == "__main__":
-    main()
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=320, choices=sorted(WINDOWS))
+    main(ap.parse_args().size)

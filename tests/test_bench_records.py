@@ -78,3 +78,30 @@ def test_headline_roofline_recomputes_from_the_committed_profiles():
     assert roof["traffic"] == pytest.approx(pmc["traffic_bytes"], rel=0.02)
     cpu = line["cpu_baseline"]
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
+
+
+def test_bare_multi_gpu_command_spawns_one_rank_per_gpu():
+    """`python bench.py --gpus 2` without a launcher (no WORLD_SIZE): the parent spawns the two ranks itself (main.py:67-76 of the
+    reference launches one process per device the same way); on a box without a GPU every rank reaches the "needs a GPU" exit,
+    and the parent returns their non-zero code instead of refusing the command line"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""       # (also on a GPU box: this test is about the launch)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    for rank in (0, 1):
+        assert f"needs a GPU (the HIP path has no CPU fallback) [rank {rank} of 2]" in r.stderr, r.stderr
+    assert "launch with torch.distributed.run" not in r.stderr
+
+
+def test_whole_fragment_figures_are_first_class():
+    """the cfg4 figures (ms per fragment, launches, blocking reads, the leading convolution alone) sit at the top level of the line"""
+    extra = {"cfg4_ms_per_fragment": 12.5, "cfg4_fragments_per_sec": 80.0, "launches_per_fragment": 800.0,
+             "blocking_reads_per_fragment": 8.0, "e2e_ms_per_fragment": 18.0,
+             "roofline_conv_cfg4": {"frac": 0.2, "alone": {"frac": 0.33}}}
+    s = bench.fragment_summary(extra)
+    assert s == {"cfg4_ms_per_fragment": 12.5, "cfg4_fragments_per_sec": 80.0, "cfg4_launches_per_fragment": 800.0,
+                 "cfg4_blocking_reads_per_fragment": 8.0, "cfg4_roofline_conv_alone_frac": 0.33,
+                 "cfg4_roofline_conv_in_situ_frac": 0.2, "e2e_ms_per_fragment": 18.0}
+    assert bench.fragment_summary({"cfg34_error": "x"})["cfg4_ms_per_fragment"] is None
