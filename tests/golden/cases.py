@@ -184,3 +184,23 @@ def mask3d_inputs_at_size(seed=23, c=48, n2=30000, n1=22000, n0=10000):
     feats = [rng.standard_normal((1, c, len(x))).astype(np.float32) for x in (c0, c1, c2)]
     mask_feat = rng.standard_normal((1, c, len(c2))).astype(np.float32)
     return [c0.astype(np.int64), c1.astype(np.int64), c2.astype(np.int64)], feats, mask_feat
+
+
+def sparse_layer_inputs(seed=31, n=6000, cin=20, extent=3.0):
+    """seeded inputs of the sparse-layer pin (also rebuilt by tests/test_sparse_layers_pin.py): a surface-like point cloud in
+    metres (two slabs + noise, rotated: the aligned-camera frame of models/neucon_network.py:387-398 is not axis-aligned),
+    point features, and the [h | x] rows of a ConvGRU"""
+    rng = np.random.default_rng(seed)
+    u = rng.uniform(0, extent, (n, 2)).astype(np.float32)
+    z = np.where(rng.random(n) < 0.5, 0.6 + 0.2 * np.sin(2 * u[:, 0]), 1.7 + 0.1 * u[:, 1]).astype(np.float32)
+    p = np.concatenate([u, z[:, None]], 1) + rng.normal(0, 0.01, (n, 3)).astype(np.float32)
+    a = 0.3
+    rot = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+    pts = np.concatenate([p @ rot.T, np.zeros((n, 1), np.float32)], 1).astype(np.float32)      # (x, y, z, batch) like r_coords
+    feats = rng.standard_normal((n, cin)).astype(np.float32)
+    h = rng.standard_normal((n, 12)).astype(np.float32) * 0.5
+    x = rng.standard_normal((n, 12)).astype(np.float32) * 0.5
+    grid = np.unique(rng.integers(0, 24, (4000, 3)), axis=0).astype(np.int32)
+    grid = np.concatenate([np.zeros((len(grid), 1), np.int32), grid], 1)                          # (b, x, y, z) like spconv's indices
+    sub_f = rng.standard_normal((len(grid), 16)).astype(np.float32)
+    return {"pts": pts, "feats": feats, "h": h, "x": x, "sub_coords": grid, "sub_feats": sub_f}

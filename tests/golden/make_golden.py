@@ -604,9 +604,90 @@ def gen_criterion():
     _save("criterion", **out)
 
 
+
+def gen_sparse_layers():
+    """THE PIN THE BUILD COULD NOT PRODUCE: per-layer activations of the reference's own torchsparse / spconv
+    layers — SPVCNN (models/modules.py:75-175 with ops/torchsparse_utils.py:15-105), ConvGRU / SConv3d (:178-222),
+    SparseSubMConv3d (:249-271) — with seeded weights on seeded inputs.  Runs only where `torchsparse` and `spconv` import
+    (they need their CUDA extensions; neither is installed nor installable in the build container): otherwise it says so and
+    writes nothing, and tests/test_sparse_layers_pin.py skips with the same message.  Where it runs it needs a CUDA device
+    (`.cuda()` is NOT patched away for this generator: the two libraries have no CPU kernels for these ops)."""
+    if not ref_shim.have_real("torchsparse", "torchsparse.nn", "torchsparse.nn.functional", "spconv", "spconv.pytorch"):
+        print("sparse_layers: skipped — torchsparse / spconv are not importable here (parity of the sparse layers stays unpinned)")
+        return False
+    if not torch.cuda.is_available():
+        print("sparse_layers: skipped — torchsparse / spconv import, but their kernels need a CUDA device")
+        return False
+    dev = torch.device("cuda")
+    import models.modules as M
+    from torchsparse.tensor import PointTensor
+    from cases import sparse_layer_inputs
+    inp = sparse_layer_inputs()
+    out = {"seed": np.array(31)}
+    t = lambda a: torch.from_numpy(a).to(dev)
+
+    def record(module, prefix):
+        """forward hooks on every leaf-ish submodule: features (and coordinates where the output carries them)"""
+        recs, hooks = {}, []
+
+        def hook(name):
+            def fn(mod, args, res):
+                f = getattr(res, "F", res)
+                if torch.is_tensor(f):
+                    recs[f"{prefix}/{name}/F"] = f.detach().cpu().numpy()
+                    c = getattr(res, "C", None)
+                    if torch.is_tensor(c):
+                        recs[f"{prefix}/{name}/C"] = c.detach().cpu().numpy()
+            return fn
+        for name, mod in module.named_modules():
+            if name and len(list(mod.children())) == 0:
+                hooks.append(mod.register_forward_hook(hook(name)))
+        return recs, hooks
+
+    # --- SPVCNN at the finest level's shape (cr = 1/4 -> channels 8, 16, 32, 24, 24; vres = VOXEL_SIZE) ---
+    torch.manual_seed(5)
+    net = M.SPVCNN(num_classes=1, in_channels=inp["feats"].shape[1], pres=1, cr=0.25, vres=0.04, dropout=False).to(dev).train()
+    out.update({f"spvcnn/sd/{k}": v.detach().cpu().numpy() for k, v in net.state_dict().items() if "num_batches" not in k})
+    recs, hooks = record(net, "spvcnn")
+    with torch.no_grad():
+        y = net(PointTensor(t(inp["feats"]), t(inp["pts"])))
+    for h_ in hooks:
+        h_.remove()
+    out.update(recs)
+    out["spvcnn/out"] = y.detach().cpu().numpy()
+
+    # --- ConvGRU (both cells of a level share this shape: hidden 12, input 12) ---
+    torch.manual_seed(6)
+    gru = M.ConvGRU(hidden_dim=12, input_dim=12, pres=1, vres=0.04).to(dev).train()
+    out.update({f"convgru/sd/{k}": v.detach().cpu().numpy() for k, v in gru.state_dict().items()})
+    recs, hooks = record(gru, "convgru")
+    with torch.no_grad():
+        hn = gru(PointTensor(t(inp["h"]), t(inp["pts"])), PointTensor(t(inp["x"]), t(inp["pts"])))
+    for h_ in hooks:
+        h_.remove()
+    out.update(recs)
+    out["convgru/out"] = hn.detach().cpu().numpy()
+
+    # --- SparseSubMConv3d 3x3x3 and 1x1x1 (spconv weight layout travels with the fixture) ---
+    torch.manual_seed(7)
+    for k in (3, 1):
+        conv = M.SparseSubMConv3d(16, 8, k).to(dev)
+        with torch.no_grad():
+            conv.sparsesubmconv3d.bias.uniform_(-0.1, 0.1)
+            yk = conv(t(inp["sub_feats"]), t(inp["sub_coords"]), [24, 24, 24], 1)
+        out[f"subm{k}/weight"] = conv.sparsesubmconv3d.weight.detach().cpu().numpy()
+        out[f"subm{k}/bias"] = conv.sparsesubmconv3d.bias.detach().cpu().numpy()
+        out[f"subm{k}/out"] = yk.detach().cpu().numpy()
+    import torchsparse, spconv  # noqa: E401
+    out["torchsparse_version"] = np.array(getattr(torchsparse, "__version__", "?"))
+    out["spconv_version"] = np.array(getattr(spconv, "__version__", "?"))
+    _save("sparse_layers", **out)
+    return True
+
 GENERATORS = {"back_project": gen_back_project, "grid_ops": gen_grid_ops, "dense_blocks": gen_dense_blocks,
               "gru_fusion": gen_gru_fusion, "mask3dformer": gen_mask3dformer, "mask3dformer_at_size": gen_mask3dformer_at_size, "scene_fusion": gen_scene_fusion,
-              "occ_init": gen_occ_init, "aligned_coords": gen_aligned_coords, "tsdf_fusion": gen_tsdf_fusion, "criterion": gen_criterion}
+              "occ_init": gen_occ_init, "aligned_coords": gen_aligned_coords, "tsdf_fusion": gen_tsdf_fusion, "criterion": gen_criterion,
+              "sparse_layers": gen_sparse_layers}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GENERATORS)

@@ -25,12 +25,20 @@ def install():
 
     torch.Tensor.cuda = lambda self, *a, **k: self
     torch.nn.Module.cuda = lambda self, *a, **k: self
+    import importlib
     for name in ["spconv", "spconv.pytorch", "torchsparse", "torchsparse.nn",
                  "torchsparse.nn.functional", "torchsparse.nn.utils", "torchsparse.tensor",
                  "torchsparse.utils", "torchvision", "torchvision.utils", "trimesh", "skimage",
                  "skimage.measure", "loguru", "cv2", "pyrender", "pyvista", "transforms3d",
                  "numba", "yacs", "yacs.config", "tensorboardX", "memory_profiler"]:
         if name not in sys.modules:
+            # the real module when it is installed (an environment that has torchsparse / spconv can then generate the
+            # sparse-layer pin: make_golden.py gen_sparse_layers); a stand-in otherwise
+            try:
+                importlib.import_module(name)
+                continue
+            except Exception:  # noqa: BLE001  (ImportError, or a CUDA extension that fails to load)
+                pass
             m = MagicMock()
             m.__all__ = []
             sys.modules[name] = m
@@ -41,3 +49,8 @@ def install():
         pkg.__path__ = [os.path.join(REF, "models")]
         sys.modules["models"] = pkg
     return torch
+
+
+def have_real(*names):
+    """True when every module in `names` is the real package, not the MagicMock stand-in install() leaves when it is absent"""
+    return all(name in sys.modules and not isinstance(sys.modules[name], MagicMock) for name in names)
