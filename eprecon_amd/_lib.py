@@ -10,7 +10,8 @@ import os
 import torch  # noqa: F401  (must be loaded before the HIP library, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libeprecon_hip.so")
+# EPRECON_LIB_PATH: an A/B twin of the library built by `python -m eprecon_amd.build --plain` (timing tools only)
+LIB_PATH = os.environ.get("EPRECON_LIB_PATH") or os.path.join(_HERE, "libeprecon_hip.so")
 
 _c = ctypes
 _vp, _i, _i64, _f, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
@@ -333,26 +334,82 @@ def workspace(nbytes, device):
 
 
 # Device-side values whose check rides on a LATER blocking read instead of costing one of their own: (int32 device element,
-# expected value, message).  The next read site that drains the list (grid_ops.sparsify) raises EpreconError on a mismatch.
+# expected value, message, stream the producing launch was queued on).  EVERY blocking count read of the package goes through
+# read_counts(), which takes the entries queued on ITS stream along in the same transfer and raises EpreconError on a
+# mismatch (entries of another stream — the pipelined panoptic worker — are left for that stream's reads: a read on stream A
+# does not wait for stream B).  Guarded by a lock: the worker thread reads too.
 _DEFERRED = []
+_DEFERRED_LOCK = __import__("threading").Lock()
+_DEFERRED_MAX = 64
 
 
 def defer_check(dev_value, expected, what):
-    _DEFERRED.append((dev_value, int(expected), what))
-    if len(_DEFERRED) > 16:        # (a path that never reaches a draining read: keep the newest only)
-        del _DEFERRED[0]
+    item = (dev_value, int(expected), what, current_stream())
+    with _DEFERRED_LOCK:
+        _DEFERRED.append(item)
+        if len(_DEFERRED) > _DEFERRED_MAX:   # (a path that never reaches a read: keep the newest only)
+            del _DEFERRED[0]
 
 
-def take_deferred():
-    out = list(_DEFERRED)
-    _DEFERRED.clear()
+def take_deferred(stream="current"):
+    """the pending checks queued on `stream` (default: the current one; None: all of them), removed from the list"""
+    st = current_stream() if stream == "current" else stream
+    with _DEFERRED_LOCK:
+        out = [it for it in _DEFERRED if stream is None or it[3] == st]
+        _DEFERRED[:] = [it for it in _DEFERRED if not (stream is None or it[3] == st)]
     return out
 
 
 def verify_deferred(items, host_values):
-    for (_, expected, what), got in zip(items, host_values):
+    for (_, expected, what, *_rest), got in zip(items, host_values):
         if int(got) != expected:
             raise EpreconError(f"{what}: expected {expected}, the device reports {int(got)} (EPRECON_ERR_ARG)")
+
+
+def read_counts(counts):
+    """THE blocking device -> host read of the package: `counts` (an int32 device tensor) as a flat Python list.  The pending
+    deferred checks of the current stream ride along in the same transfer and are verified before the counts are returned."""
+    count_host_read()
+    pending = take_deferred()
+    flat = counts.reshape(-1)
+    if pending:
+        host = torch.cat([flat] + [t.reshape(1).to(flat.dtype) for t, *_ in pending]).tolist()
+        verify_deferred(pending, host[flat.numel():])
+        return host[:flat.numel()]
+    return flat.tolist()
+
+
+class PinnedRead:
+    """read_counts() without blocking now: the counts AND the deferred checks pending on the current stream at this point are
+    copied to pinned host memory behind everything queued so far; result() waits for that copy only (an event), verifies the
+    checks and returns the counts.  Work queued after the constructor is not waited for."""
+
+    def __init__(self, counts):
+        self._pending = take_deferred()
+        flat = counts.reshape(-1)
+        self._n = flat.numel()
+        src = flat if not self._pending else torch.cat([flat] + [t.reshape(1).to(flat.dtype) for t, *_ in self._pending])
+        self._pinned = torch.empty(src.numel(), dtype=src.dtype, pin_memory=True)
+        self._pinned.copy_(src, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record()
+
+    def result(self):
+        count_host_read()
+        self._event.synchronize()
+        host = self._pinned.tolist()
+        if self._pending:
+            verify_deferred(self._pending, host[self._n:])
+            self._pending = []
+        return host[:self._n]
+
+
+def drain_deferred():
+    """blocking: verify whatever is pending on the current stream (end of a step that finished without a count read)"""
+    pending = take_deferred()
+    if pending:
+        count_host_read()
+        verify_deferred(pending, torch.cat([t.reshape(1).to(torch.int32) for t, *_ in pending]).tolist())
 
 
 HOST_READS = 0    # blocking device -> host reads issued by the package since import (bench.py: blocking_reads_per_fragment)

@@ -91,15 +91,13 @@ def sparse_conv(x, weight, nbr=None, bias=None):
     return _SparseConv.apply(x, weight, bias, nbr)
 
 
-_CORNER_LISTS = []     # [(idx8 tensor, n_voxels, offsets, order)], newest last
-
-
 def corner_lists(idx8, m):
     """CSR lists voxel -> (point, corner) entries of a corner table idx8 int32[n, 8] (eprecon_segment_lists_async over the
-    flattened table; missing corners skipped), cached on the table's identity"""
-    for t, mm, offsets, order in _CORNER_LISTS:
-        if t is idx8 and mm == m:
-            return offsets, order
+    flattened table; missing corners skipped), cached ON the table tensor (`idx8._csr`): the lists die with the table
+    instead of pinning up to 24 tables + lists in a process-global list across training iterations"""
+    hit = getattr(idx8, "_csr", None)
+    if hit is not None and hit[0] == m:
+        return hit[1], hit[2]
     lib = _lib.load()
     flat = idx8.reshape(-1)
     n8, dev = flat.shape[0], idx8.device
@@ -108,8 +106,7 @@ def corner_lists(idx8, m):
     ws = _lib.workspace(lib.eprecon_segment_workspace_bytes(n8, m), dev)
     _lib.check(lib.eprecon_segment_lists_async(_lib.ptr(flat), n8, m, _lib.ptr(offsets), _lib.ptr(order), _lib.ptr(ws), ws.numel(),
                                                _lib.current_stream()), "eprecon_segment_lists_async")
-    _CORNER_LISTS.append((idx8, m, offsets, order))
-    del _CORNER_LISTS[:max(0, len(_CORNER_LISTS) - 24)]
+    idx8._csr = (m, offsets, order)
     return offsets, order
 
 

@@ -43,15 +43,13 @@ class PendingBackProject:
     (pinned host copy + event) and returns what `run()` returns.  Lets independent levels be issued
     back to back without a host round trip between them."""
 
-    def __init__(self, tensors, n, v, c, batch, min_valid_per_batch, n_valid_pinned, event, want_grid, want_mean):
+    def __init__(self, tensors, n, v, c, batch, min_valid_per_batch, read, want_grid, want_mean):
         self._t, self._n, self._v, self._c, self._batch = tensors, n, v, c, batch
-        self._min_valid, self._pinned, self._event = min_valid_per_batch, n_valid_pinned, event
+        self._min_valid, self._read = min_valid_per_batch, read
         self._want_grid, self._want_mean = want_grid, want_mean
 
     def result(self):
-        _lib.count_host_read()
-        self._event.synchronize()
-        counts = self._pinned.tolist()
+        counts = self._read.result()     # (deferred checks pending at queue time rode along: _lib.PinnedRead)
         if any(x < self._min_valid for x in counts[1:]):
             return None  # reference: `return None`
         nv, t, v = counts[0], self._t, self._v
@@ -97,13 +95,10 @@ def run_async(coords, origin, voxel_size, feats, krcam, min_view, mode=MODE_MEAN
         _lib.ptr(t["coords"]), _lib.ptr(t["count"]), _lib.ptr(t["grid"]), _lib.ptr(t["mask"]),
         _lib.ptr(n_valid_dev), _lib.ptr(ws), ws.numel(), _lib.current_stream())
     _lib.check(rc, "eprecon_back_project_async")
-    pinned = torch.empty((1 + b,), dtype=torch.int32, pin_memory=True)
-    pinned.copy_(n_valid_dev, non_blocking=True)
-    event = torch.cuda.Event()
-    event.record()
+    read = _lib.PinnedRead(n_valid_dev)
     # inputs stay referenced until result(): the kernels may still be reading them
     t["_keep"] = (coords_i, origin_f, krcam_f, feats_c, n_valid_dev)
-    return PendingBackProject(t, n, v, c, b, int(min_valid_per_batch), pinned, event, want_grid, want_mean)
+    return PendingBackProject(t, n, v, c, b, int(min_valid_per_batch), read, want_grid, want_mean)
 
 
 def run(coords, origin, voxel_size, feats, krcam, min_view, mode=MODE_MEAN, min_valid_per_batch=1,
@@ -159,6 +154,7 @@ def run(coords, origin, voxel_size, feats, krcam, min_view, mode=MODE_MEAN, min_
         _lib.ptr(out_feats), _lib.ptr(out_mean), _lib.ptr(out_coords), _lib.ptr(count),
         _lib.ptr(out_grid), _lib.ptr(out_mask), _lib.ptr(n_valid_dev),
         ctypes.cast(n_valid_host, ctypes.c_void_p), _lib.ptr(ws), ws.numel(), _lib.current_stream())
+    _lib.drain_deferred()          # (the library copied the counts itself: pending checks are verified here, when there are any)
     if not _lib.check(rc, "eprecon_back_project"):
         return None
     nv = int(n_valid_host[0])

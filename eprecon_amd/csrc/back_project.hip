@@ -743,10 +743,18 @@ __device__ __forceinline__ unsigned long long to_fixed(float v)
     const double x = fmin(fmax((double)v * kFixScale, -9.0e18), 9.0e18);
     return (unsigned long long)__double2ll_rn(x);           // two's complement: an unsigned add is a signed add
 }
+// A non-finite contribution (a diverging training run) must stay visible: the clamp above would turn NaN / Inf into a finite
+// +-8.2e6.  Such a contribution is not added; the element of the fp32 output (zeroed by the caller) is marked NaN instead — a
+// plain store of one value, so still independent of the order — and the conversion below leaves marked elements alone.
+__device__ __forceinline__ void fixed_add(unsigned long long *acc, float *mark, float v)
+{
+    if (__builtin_isfinite(v)) atomicAdd(acc, to_fixed(v));
+    else *mark = __builtin_nanf("");
+}
 __global__ void fixed_to_float_kernel(const unsigned long long *acc, long long n, float *out)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (float)((double)(long long)acc[i] * (1.0 / kFixScale));
+    if (i < n && !__builtin_isnan(out[i])) out[i] = (float)((double)(long long)acc[i] * (1.0 / kFixScale));
 }
 
 __global__ __launch_bounds__(256) void bp_backward_kernel(BpBwdParams p)
@@ -799,10 +807,11 @@ __global__ __launch_bounds__(256) void bp_backward_kernel(BpBwdParams p)
         if (p.dfix) {
             // order-independent accumulation: 64-bit fixed point (2^-40 resolution, |sum| < 8.4e6), integer atomics
             unsigned long long *d = p.dfix + mo;
-            if (t.w00 != 0.0f) atomicAdd(d + t.o00, to_fixed(t.w00 * gv));
-            if (t.w10 != 0.0f) atomicAdd(d + t.o10, to_fixed(t.w10 * gv));
-            if (t.w01 != 0.0f) atomicAdd(d + t.o01, to_fixed(t.w01 * gv));
-            if (t.w11 != 0.0f) atomicAdd(d + t.o11, to_fixed(t.w11 * gv));
+            float *m = p.dfeats + mo;
+            if (t.w00 != 0.0f) fixed_add(d + t.o00, m + t.o00, t.w00 * gv);
+            if (t.w10 != 0.0f) fixed_add(d + t.o10, m + t.o10, t.w10 * gv);
+            if (t.w01 != 0.0f) fixed_add(d + t.o01, m + t.o01, t.w01 * gv);
+            if (t.w11 != 0.0f) fixed_add(d + t.o11, m + t.o11, t.w11 * gv);
         } else {
             float *d = p.dfeats + mo;
             if (t.w00 != 0.0f) unsafeAtomicAdd(d + t.o00, t.w00 * gv);
@@ -1095,7 +1104,8 @@ static int bp_backward_impl(const int32_t *coords_valid, int64_t n_valid, const 
     const size_t elems = (size_t)n_views * batch * height * width * channels;
     if (workspace && workspace_bytes < elems * sizeof(unsigned long long)) return EPRECON_ERR_WORKSPACE;
     if (workspace) EP_HIP_CHECK(hipMemsetAsync(workspace, 0, elems * sizeof(unsigned long long), st));
-    if (!workspace || n_valid == 0) EP_HIP_CHECK(hipMemsetAsync(dfeats_nhwc, 0, elems * sizeof(float), st));
+    // (the fp32 output is zeroed in the fixed-point form too: it carries the NaN marks of non-finite contributions, fixed_add)
+    EP_HIP_CHECK(hipMemsetAsync(dfeats_nhwc, 0, elems * sizeof(float), st));
     if (n_valid == 0) return EPRECON_OK;
     if (!coords_valid || !dout) return EPRECON_ERR_ARG;
     BpBwdParams p;

@@ -20,8 +20,7 @@ class GruStage:
     def read(self):
         from . import sparse as SP
         lib = _lib.load()
-        _lib.count_host_read()
-        host = self.counts.tolist()
+        host = _lib.read_counts(self.counts)
         n_u, kept, m1, m2 = host[:4]
         SP.check_hash_status(host[6])
         SP.check_hash_status(host[7])

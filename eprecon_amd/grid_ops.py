@@ -22,15 +22,14 @@ def init_select(logit, coords, batch_size, dim=24, cell=4, threshold=0.3, must_b
                                              float(threshold), batch_size, dim, cell, _lib.ptr(out),
                                              _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
                "eprecon_init_select_async")
-    _lib.count_host_read()
     if must_be_zero:
-        host = torch.cat([counts] + [t.reshape(1) for t in must_be_zero]).cpu().tolist()
+        host = _lib.read_counts(torch.cat([counts] + [t.reshape(1) for t in must_be_zero]))
         if any(host[1 + batch_size:]):
             raise _lib.EpreconError(f"dense-grid convolution: {host[1 + batch_size:]} voxels of the set are not on the grid "
                                     "their VoxelSet was declared with (rows left unwritten); EPRECON_ERR_ARG")
         host = host[:1 + batch_size]
     else:
-        host = counts.cpu().tolist()
+        host = _lib.read_counts(counts)     # (the off-grid counters of dense-grid maps ride along: sparse.DenseMap defers them)
     return out[: host[0]], host[1:]
 
 
@@ -38,13 +37,11 @@ class PendingSelect:
     """init_select queued on a stream; result() waits for the counts (pinned host copy + event) and returns what
     init_select returns"""
 
-    def __init__(self, out, pinned, event):
-        self._out, self._pinned, self._event = out, pinned, event
+    def __init__(self, out, read):
+        self._out, self._read = out, read
 
     def result(self):
-        _lib.count_host_read()
-        self._event.synchronize()
-        host = self._pinned.tolist()
+        host = self._read.result()       # (the deferred checks pending when the selection was queued rode along: _lib.PinnedRead)
         return self._out[: host[0]], host[1:]
 
 
@@ -62,11 +59,7 @@ def init_select_async(logit, coords, batch_size, dim=24, cell=4, threshold=0.3):
                                              float(threshold), batch_size, dim, cell, _lib.ptr(out),
                                              _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
                "eprecon_init_select_async")
-    pinned = torch.empty(1 + batch_size, dtype=torch.int32, pin_memory=True)
-    pinned.copy_(counts, non_blocking=True)
-    event = torch.cuda.Event()
-    event.record()
-    return PendingSelect(out, pinned, event)
+    return PendingSelect(out, _lib.PinnedRead(counts))
 
 
 def upsample(pre_feat, pre_coords, interval):
@@ -116,13 +109,6 @@ def sparsify(occ, threshold, target, coords, tsdf, feat_all, c_feat, batch_size)
         _lib.ptr(feat_all), feat_all.stride(0), c_all, int(c_feat), n, batch_size, _lib.ptr(out_coords), _lib.ptr(out_tsdf),
         _lib.ptr(out_occ), _lib.ptr(out_all), _lib.ptr(out_feat), _lib.ptr(counts), _lib.ptr(ws), ws.numel(),
         _lib.current_stream()), "eprecon_sparsify_async")
-    _lib.count_host_read()
-    pending = _lib.take_deferred()            # checks that ride on this read (back-projection without a read of its own)
-    if pending:
-        host = torch.cat([counts] + [t.reshape(1) for t, _, _ in pending]).tolist()
-        _lib.verify_deferred(pending, host[counts.numel():])
-        host = host[:counts.numel()]
-    else:
-        host = counts.tolist()
+    host = _lib.read_counts(counts)     # (deferred checks ride on this read: back-projection without a read of its own)
     m = host[0]
     return host, out_coords[:m], out_tsdf[:m], out_occ[:m], out_all[:m], out_feat[:m]

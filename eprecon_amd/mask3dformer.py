@@ -363,8 +363,11 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         with torch.no_grad():
             cls0, me0 = self._head_static(state0)
             q0 = self._project_q(0, state0, qe)
+        # the kernel evaluates every LayerNorm of the query side with ONE eps (1e-5): all four kinds must carry it
         ok = (len(self.mask_embed.layers) == 3 and self.decoder_norm.eps == 1e-5 and
-              all(l.norm.eps == 1e-5 for l in self.transformer_ffn_layers))
+              all(l.norm.eps == 1e-5 for l in self.transformer_ffn_layers) and
+              all(l.norm.eps == 1e-5 for l in self.transformer_cross_attention_layers) and
+              all(l.norm.eps == 1e-5 for l in self.transformer_self_attention_layers))
         pack = {"key": key, "layers": layers, "kv_levels": kv_levels, "cls0": cls0.contiguous(), "me0": me0.contiguous(), "q0": q0, "ok": ok,
                 "state0": self.query_feat.weight.detach().contiguous(), "qpos": self.query_embed.weight.detach().contiguous(),
                 "ffn_dim": self.transformer_ffn_layers[0].linear1.out_features, "n_cls": self.class_embed.out_features,

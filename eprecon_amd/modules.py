@@ -420,8 +420,11 @@ _FUSED_HEADS = __import__("os").environ.get("EPRECON_FUSED_HEADS", "1") == "1"
 
 def fused_heads_ok(mod, x):
     """inference on the GPU: the whole Linear4xTrans as one launch (eprecon_mlp4x_async)"""
+    # (x.shape[1] == in_features: the kernel reads the first C columns of a wider row, where the PyTorch modules — and the
+    # reference — raise on the shape mismatch; a wider input takes the module path and raises there)
     return (_FUSED_HEADS and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
-            and x.stride(1) == 1 and SP.mlp4x_supported(mod.linear1.in_features, mod.linear3.out_features))
+            and x.stride(1) == 1 and x.shape[1] == mod.linear1.in_features
+            and SP.mlp4x_supported(mod.linear1.in_features, mod.linear3.out_features))
 
 
 def linear4x_pair(mod_a, mod_b, x):

@@ -377,6 +377,8 @@ class NeuConNet(nn.Module):
                 return outputs
             outputs["panoptic_finish"] = finish
         self._record(stage="panoptic", coords=panoptic_coords, feats=panoptic_voxel_feats)
+        if recording:
+            _lib.drain_deferred()   # training has no fused sparsify read: the back-projections' deferred row-count checks are verified here
         return outputs, loss_dict
 
     def _panoptic_branch(self, panoptic_coords, panoptic_voxel_feats, bs, outputs):

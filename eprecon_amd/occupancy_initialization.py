@@ -185,7 +185,7 @@ class Occupancy_Initialization(nn.Module):
         coord_valid = res["coords"]
         parts = []
         start = 0
-        self.dense_checks = []   # off-grid counters of the dense-grid maps used below (device scalars; the caller's next host read checks them)
+        self.dense_checks = []   # (kept for callers that passed it on: a DenseMap defers its own off-grid check now, sparse.DenseMap)
         for b in range(bs):  # statistics of norm0 / norm4 are per batch element, as in the reference
             nb = res["n_valid_per_batch"][b]
             seg = slice(start, start + nb)
@@ -193,8 +193,6 @@ class Occupancy_Initialization(nn.Module):
             # 3x3x3 layers of the stack take the dense-grid kernel (no hash grid, no kernel map)
             vset = SP.VoxelSet(coord_valid[seg], interval, dims=shape)
             parts.append(self.sparse_stack(res["var"][seg], vset))
-            if vset._dense is not None:
-                self.dense_checks.append(vset._dense.rank[-1:])
             start += nb
         occ = parts[0] if bs == 1 else torch.cat(parts)
         out_coords = coord_valid if coords.dtype == torch.int32 else coord_valid.to(coords.dtype)

@@ -117,13 +117,20 @@ def load_scene_npz(path):
     (sparse_coords int32[M,3] relative to `origin`, sparse_tsdf f32[M], sparse_semantic / sparse_instance int32[M], dims): the dense volumes
     (TSDF default 1, ids default 0: models/gru_fusion.py:232-252) are rebuilt here, on the host that wants them."""
     z = np.load(path)
+    prefix = "sparse_"
     if "sparse_coords" not in z.files:
-        return {k: z[k] for k in z.files}
-    dims, c = tuple(int(d) for d in z["dims"]), z["sparse_coords"].astype(np.int64)
+        # files of the earlier sparse layout (round 3: rows under the DENSE key names coords / tsdf / semantic / instance + dims)
+        # are recognised by their 1-D tsdf next to `coords` and `dims` and rebuilt like the current ones, instead of coming
+        # back as 1-D rows under the names a dense reader indexes as volumes
+        if "coords" in z.files and "dims" in z.files and "tsdf" in z.files and z["tsdf"].ndim == 1:
+            prefix = ""
+        else:
+            return {k: z[k] for k in z.files}
+    dims, c = tuple(int(d) for d in z["dims"]), z[prefix + "coords"].astype(np.int64)
     out = {"origin": z["origin"], "voxel_size": z["voxel_size"]}
     for key, fill, dtype in (("tsdf", 1.0, np.float32), ("semantic", 0, np.int32), ("instance", 0, np.int32)):
         vol = np.full(dims, fill, dtype)
-        vol[c[:, 0], c[:, 1], c[:, 2]] = z["sparse_" + key]
+        vol[c[:, 0], c[:, 1], c[:, 2]] = z[prefix + key]
         out[key] = vol
     return out
 

@@ -98,8 +98,7 @@ def unique_coords(coords, quantum=1):
     One host sync to learn M (the reference's torch.unique syncs as well)."""
     uniq, inverse, grid = unique_coords_queued(coords, quantum)
     # the count lands next to the table's status word (the table's 256-byte header): ONE 8-byte host read, no torch.cat
-    _lib.count_host_read()
-    status, m = grid.header.tolist()
+    status, m = _lib.read_counts(grid.header)
     check_hash_status(status)
     return uniq[:m], inverse, grid
 
@@ -120,6 +119,10 @@ class DenseMap:
         self.rank = torch.empty(gx * gy * gz + 1, dtype=torch.int32, device=vset.coords.device)
         _lib.check(lib.eprecon_grid_rank_async(_lib.ptr(vset.coords), vset.n, vset.stride, gx, gy, gz, _lib.ptr(self.rank),
                                                _lib.current_stream()), "eprecon_grid_rank_async")
+        # rank[-1] counts the voxels that were NOT on the declared grid (their output rows would stay unwritten): checked with
+        # the next blocking count read on this stream (_lib.read_counts), at no read of its own
+        _lib.defer_check(self.rank[-1:], 0, "dense-grid convolution: voxels of the set are not on the grid their VoxelSet was "
+                                            "declared with (rows left unwritten)")
 
     @property
     def shape(self):          # (K, N) like the kernel-map tensor it stands in for
@@ -197,8 +200,7 @@ def voxel_hierarchy(vox, levels=3, points=None):
         u, inv, g = unique_coords_queued(src, quantum=2 ** lvl, n_dev=n_dev)
         grids.append(g); uniqs.append(u); invs.append(inv)
         src, n_dev = u, g.header[1:2]
-    _lib.count_host_read()
-    host = torch.cat([g.header for g in grids]).tolist()
+    host = _lib.read_counts(torch.cat([g.header for g in grids]))
     sizes = []
     for lvl in range(levels):
         check_hash_status(host[2 * lvl])

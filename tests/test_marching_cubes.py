@@ -130,6 +130,12 @@ def test_load_scene_npz_rebuilds_the_reference_dense_arrays(tmp_path):
     dense = tmp_path / "d.npz"
     np.savez_compressed(dense, origin=np.zeros(3), voxel_size=0.04, tsdf=ref, semantic=z["semantic"], instance=z["instance"])
     assert np.array_equal(load_scene_npz(str(dense))["tsdf"], ref)
+    # a file of the EARLIER sparse layout (rows under the dense key names + dims) is rebuilt too, not handed back as 1-D rows
+    legacy = tmp_path / "l.npz"
+    np.savez_compressed(legacy, origin=np.zeros(3, np.float32), voxel_size=0.04, dims=np.array(dims), coords=c, tsdf=tsdf,
+                        semantic=sem, instance=ins)
+    zl = load_scene_npz(str(legacy))
+    assert np.array_equal(zl["tsdf"], ref) and np.array_equal(zl["semantic"], z["semantic"]) and np.array_equal(zl["instance"], z["instance"])
 
 
 @pytest.mark.gpu
