@@ -1,6 +1,9 @@
 """Microbenchmark of the gather-GEMM convolution on the layer shapes of cfg4 (3x3x3, stride 1): kernel time per
 launch from HIP events around 20 back-to-back launches.  Run under different EPRECON_CONV_* switches to A/B.
-    python tools/conv_shapes_ab.py [tag]"""
+    python tools/conv_shapes_ab.py [tag]
+EPRECON_AB_IN_AFFINE=1: every launch applies a pending BatchNorm + ReLU to its input while gathering (the second convolution of
+a ResidualBlock, models/modules.py:46-72): the path the per-file `-fno-honor-nans` of eprecon_amd/build.py is about.
+EPRECON_LIB_PATH=eprecon_amd/libeprecon_hip_plain.so: the twin built without the per-file flags (python -m eprecon_amd.build --plain)."""
 import os
 import sys
 
@@ -37,7 +40,7 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "default"
     rng = np.random.default_rng(0)
     dev = torch.device("cuda")
-    print(f"# {tag}: " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("EPRECON_CONV")))
+    print(f"# {tag}: " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith(("EPRECON_CONV", "EPRECON_AB", "EPRECON_LIB"))))
     total = 0.0
     with torch.no_grad():
         for n, ci, co, what in SHAPES:
@@ -47,12 +50,15 @@ def main():
             x = torch.randn(n, ci, device=dev)
             w = torch.randn(27, ci, co, device=dev) * 0.05
             out = torch.empty(n, co, device=dev)
+            aff = None
+            if os.environ.get("EPRECON_AB_IN_AFFINE", "0") == "1":
+                aff = (torch.rand(ci, device=dev) + 0.5, torch.randn(ci, device=dev) * 0.1, True)
             for _ in range(3):
-                SP.conv_stats(x, w, nbr, out=out)
+                SP.conv_stats(x, w, nbr, out=out, in_affine=aff)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(20):
-                SP.conv_stats(x, w, nbr, out=out)
+                SP.conv_stats(x, w, nbr, out=out, in_affine=aff)
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / 20 * 1e3
