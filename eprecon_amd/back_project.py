@@ -49,7 +49,10 @@ class PendingBackProject:
         self._want_grid, self._want_mean = want_grid, want_mean
 
     def result(self):
-        counts = self._read.result()     # (deferred checks pending at queue time rode along: _lib.PinnedRead)
+        return self.result_from(self._read.result())     # (deferred checks pending at queue time rode along: _lib.PinnedRead)
+
+    def result_from(self, counts):
+        """counts: the 1 + B values of `n_valid_dev` as read by the caller (hold_read: together with other counts)"""
         if any(x < self._min_valid for x in counts[1:]):
             return None  # reference: `return None`
         nv, t, v = counts[0], self._t, self._v
@@ -64,8 +67,11 @@ class PendingBackProject:
 
 
 def run_async(coords, origin, voxel_size, feats, krcam, min_view, mode=MODE_MEAN, min_valid_per_batch=1,
-              want_grid=False, want_mean=False):
-    """Queue the back-projection on the current stream and return a PendingBackProject."""
+              want_grid=False, want_mean=False, hold_read=False):
+    """Queue the back-projection on the current stream and return a PendingBackProject.
+    hold_read: no host copy of the counts is queued — the caller reads `.n_valid_dev` itself, together with whatever else it
+    queued on the device count `.n_valid_dev[0:1]` of the compacted rows `.coords_all` (torchsparse_utils.SpvcnnPrefetch), and
+    hands the values to result_from()."""
     lib = _lib.load()
     dev = feats.device
     if dev.type != "cuda":
@@ -95,10 +101,12 @@ def run_async(coords, origin, voxel_size, feats, krcam, min_view, mode=MODE_MEAN
         _lib.ptr(t["coords"]), _lib.ptr(t["count"]), _lib.ptr(t["grid"]), _lib.ptr(t["mask"]),
         _lib.ptr(n_valid_dev), _lib.ptr(ws), ws.numel(), _lib.current_stream())
     _lib.check(rc, "eprecon_back_project_async")
-    read = _lib.PinnedRead(n_valid_dev)
+    read = None if hold_read else _lib.PinnedRead(n_valid_dev)
     # inputs stay referenced until result(): the kernels may still be reading them
     t["_keep"] = (coords_i, origin_f, krcam_f, feats_c, n_valid_dev)
-    return PendingBackProject(t, n, v, c, b, int(min_valid_per_batch), read, want_grid, want_mean)
+    pend = PendingBackProject(t, n, v, c, b, int(min_valid_per_batch), read, want_grid, want_mean)
+    pend.n_valid_dev, pend.coords_all = n_valid_dev, t["coords"]
+    return pend
 
 
 def run(coords, origin, voxel_size, feats, krcam, min_view, mode=MODE_MEAN, min_valid_per_batch=1,
@@ -201,6 +209,22 @@ class Back_Project(nn.Module):
             return None
         out_coords = res["coords"] if coords.dtype == torch.int32 else res["coords"].to(coords.dtype)
         return [res["feats"], out_coords, res.get("grid"), res.get("mask"), res["count"]]
+
+
+def forward_behind(module, coords, origin, voxel_size, feats, KRcam, min_view_number, behind):
+    """Back_Project.forward with more work queued on the DEVICE count of its valid rows in front of the one host read:
+    behind(valid_coords int32[N,4] (first n_valid rows live), n_valid_dev int32[1]) -> (extra int32 device tensor,
+    finish(n_valid, host_extra)).  -> (what forward returns, finish(...)'s result | None).  Inference only."""
+    pend = run_async(coords, origin, voxel_size, feats, KRcam, min_view_number, MODE_MEAN, want_grid=module.return_projection,
+                     hold_read=True)
+    extra, finish = behind(pend.coords_all, pend.n_valid_dev[0:1])
+    nb = pend.n_valid_dev.numel()
+    host = _lib.read_counts(torch.cat([pend.n_valid_dev, extra.reshape(-1)]))
+    res = pend.result_from(host[:nb])
+    if res is None:
+        return None, None
+    out_coords = res["coords"] if coords.dtype == torch.int32 else res["coords"].to(coords.dtype)
+    return [res["feats"], out_coords, res.get("grid"), res.get("mask"), res["count"]], finish(res["n_valid"], host[nb:])
 
 
 def view_variance(coords, origin, voxel_size, feats_fused, KRcam, min_view_number, min_valid=1000):

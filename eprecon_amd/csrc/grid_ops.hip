@@ -161,13 +161,16 @@ int eprecon_init_select_async(const float *logit, const int32_t *coords, int64_t
 int eprecon_upsample_async(const float *feat, int ld_feat, const int32_t *coords, int64_t n, int channels,
                            int interval, float *up_feat, int32_t *up_coords, void *stream)
 {
-    if (n < 0 || channels < 0 || interval <= 0 || (n > 0 && (!coords || !up_coords))) return EPRECON_ERR_ARG;
+    // (up_coords null with channels > 0: the children were written by an earlier call, eprecon_spvcnn_points_dn_async)
+    if (n < 0 || channels < 0 || interval <= 0 || (n > 0 && (!coords || (!up_coords && channels == 0)))) return EPRECON_ERR_ARG;
     if (n == 0) return EPRECON_OK;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(upsample_coords_kernel, dim3((unsigned)ceil_div(n * 8, 256)), dim3(256), 0, st,
-                       reinterpret_cast<const int4 *>(coords), (int)n, interval,
-                       reinterpret_cast<int4 *>(up_coords));
-    EP_LAUNCH_CHECK();
+    if (up_coords) {
+        hipLaunchKernelGGL(upsample_coords_kernel, dim3((unsigned)ceil_div(n * 8, 256)), dim3(256), 0, st,
+                           reinterpret_cast<const int4 *>(coords), (int)n, interval,
+                           reinterpret_cast<int4 *>(up_coords));
+        EP_LAUNCH_CHECK();
+    }
     if (channels > 0) {
         if (!feat || !up_feat || ld_feat < channels) return EPRECON_ERR_ARG;
         const size_t total = (size_t)n * 8 * channels;

@@ -424,6 +424,13 @@ int eprecon_hash_build_async(const int32_t *coords, int64_t n, int quantum, void
     return hash_build_impl(coords, n, nullptr, quantum, table, capacity, stream);
 }
 
+int eprecon_hash_build_dn_async(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, int quantum, void *table,
+                                uint32_t capacity, void *stream)
+{
+    if (!n_dev) return EPRECON_ERR_ARG;
+    return hash_build_impl(coords, n_cap, n_dev, quantum, table, capacity, stream);
+}
+
 int eprecon_hash_query_async(const void *table, uint32_t capacity, const int32_t *queries, int64_t m,
                              int quantum, int32_t *out_index, void *stream)
 {

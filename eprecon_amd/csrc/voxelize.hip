@@ -50,6 +50,48 @@ __global__ void point_quantize_kernel(const float4 *pts, int n, float res, float
     vox[i] = make_int4((int)p.w, (int)floorf(x), (int)floorf(y), (int)floorf(z));
 }
 
+// The coordinate side of an SPVCNN pass from a voxel list whose LENGTH is still on the device (the rows a compaction has just
+// written: sparsify's kept rows, a back-projection's valid rows): [8 children per row, models/neucon_network.py:193-214 ->]
+// aligned-camera points (:387-398) -> scaled points and voxel indices (ops/torchsparse_utils.py:15-19) in ONE launch sized by
+// the capacity; thread 0 leaves the live point count (8 x rows or rows) for the dn numbering calls that follow.  The arithmetic
+// is that of upsample_coords_kernel (grid_ops.hip), aligned_coords_kernel and point_quantize_kernel, statement by statement.
+__global__ void spvcnn_points_dn_kernel(const int4 *src, int cap_src, const int32_t *n_src_dev, int children, int interval,
+                                        const float *origin, float vs, const float *w2ac, int batch, float res, int4 *up,
+                                        float4 *r_out, float4 *scaled, int4 *vox, int32_t *n_pts_dev)
+{
+    const int n_src = min(cap_src, max(*n_src_dev, 0));
+    const int n_pts = children ? n_src * 8 : n_src;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e == 0) n_pts_dev[0] = n_pts;
+    if (e >= n_pts) return;
+    int4 c;
+    if (children) {
+        const int i = e >> 3, k = e & 7;
+        const int dx = (0xB2 >> k) & 1, dy = (0xD4 >> k) & 1, dz = (0xE8 >> k) & 1;   // child order 0, x, y, z, xy, xz, yz, xyz
+        c = src[i];
+        c.y += dx * interval;
+        c.z += dy * interval;
+        c.w += dz * interval;
+        up[e] = c;
+    } else {
+        c = src[e];
+    }
+    const int b = min(max(c.x, 0), batch - 1);
+    const float X = __fadd_rn(__fmul_rn((float)c.y, vs), origin[3 * b + 0]);
+    const float Y = __fadd_rn(__fmul_rn((float)c.z, vs), origin[3 * b + 1]);
+    const float Z = __fadd_rn(__fmul_rn((float)c.w, vs), origin[3 * b + 2]);
+    const float *M = w2ac + 16 * b;
+    float r[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        r[j] = __fmaf_rn(1.0f, M[4 * j + 3], __fmaf_rn(Z, M[4 * j + 2], __fmaf_rn(Y, M[4 * j + 1], __fmul_rn(X, M[4 * j]))));
+    const float pw = (float)c.x;
+    r_out[e] = make_float4(r[0], r[1], r[2], pw);
+    const float x = __fdiv_rn(r[0], res), y = __fdiv_rn(r[1], res), z = __fdiv_rn(r[2], res);
+    scaled[e] = make_float4(x, y, z, pw);
+    vox[e] = make_int4((int)pw, (int)floorf(x), (int)floorf(y), (int)floorf(z));
+}
+
 // ---- CSR point lists per voxel ----
 __global__ void seg_count_kernel(const int32_t *idx, int n, int32_t *counts)
 {
@@ -357,6 +399,25 @@ int eprecon_point_quantize_dn_async(const float *points_xyzb, int64_t n_cap, con
     hipLaunchKernelGGL(point_quantize_kernel, dim3((unsigned)ceil_div(n_cap, 256)), dim3(256), 0,
                        (hipStream_t)stream, reinterpret_cast<const float4 *>(points_xyzb), (int)n_cap, resolution,
                        reinterpret_cast<float4 *>(scaled_xyzb), reinterpret_cast<int4 *>(voxel_bxyz), n_dev);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_spvcnn_points_dn_async(const int32_t *src_coords, int64_t cap_src, const int32_t *n_src_dev, int children,
+                                   int interval, const float *origin, int batch, float voxel_size,
+                                   const float *world_to_aligned_camera, float resolution, int32_t *up_coords, float *r_coords,
+                                   float *scaled_xyzb, int32_t *voxel_bxyz, int32_t *n_points_dev, void *stream)
+{
+    if (cap_src < 0 || !n_src_dev || batch <= 0 || !origin || !world_to_aligned_camera || !(resolution > 0.0f) || !n_points_dev ||
+        (children && (interval <= 0 || !up_coords)) || (cap_src > 0 && (!src_coords || !r_coords || !scaled_xyzb || !voxel_bxyz)))
+        return EPRECON_ERR_ARG;
+    const int64_t cap_pts = children ? cap_src * 8 : cap_src;
+    if (cap_pts > 0x7fffffff) return EPRECON_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(spvcnn_points_dn_kernel, dim3((unsigned)ceil_div(cap_pts > 0 ? cap_pts : 1, 256)), dim3(256), 0,
+                       (hipStream_t)stream, reinterpret_cast<const int4 *>(src_coords), (int)cap_src, n_src_dev, children ? 1 : 0,
+                       interval, origin, voxel_size, world_to_aligned_camera, batch, resolution, reinterpret_cast<int4 *>(up_coords),
+                       reinterpret_cast<float4 *>(r_coords), reinterpret_cast<float4 *>(scaled_xyzb),
+                       reinterpret_cast<int4 *>(voxel_bxyz), n_points_dev);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }

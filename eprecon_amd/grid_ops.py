@@ -62,8 +62,9 @@ def init_select_async(logit, coords, batch_size, dim=24, cell=4, threshold=0.3):
     return PendingSelect(out, _lib.PinnedRead(counts))
 
 
-def upsample(pre_feat, pre_coords, interval):
-    """models/neucon_network.py:193-214 -> (up_feat f32[8N, C], up_coords int32[8N, 4])"""
+def upsample(pre_feat, pre_coords, interval, up_coords=None):
+    """models/neucon_network.py:193-214 -> (up_feat f32[8N, C], up_coords int32[8N, 4]).
+    up_coords: the children when an earlier call already wrote them (torchsparse_utils.SpvcnnPrefetch): features only"""
     lib = _lib.load()
     n = pre_coords.shape[0]
     coords = pre_coords if pre_coords.dtype == torch.int32 else pre_coords.to(torch.int32)
@@ -77,6 +78,12 @@ def upsample(pre_feat, pre_coords, interval):
                                               _lib.current_stream()), "eprecon_upsample_async")
         return feat.repeat_interleave(8, dim=0), up_coords
     up_feat = torch.empty((8 * n, c), dtype=torch.float32, device=feat.device)
+    if up_coords is not None:
+        assert up_coords.shape == (8 * n, 4) and up_coords.dtype == torch.int32
+        _lib.check(lib.eprecon_upsample_async(_lib.ptr(feat), feat.stride(0), _lib.ptr(coords), n, c,
+                                              int(interval), _lib.ptr(up_feat), None,
+                                              _lib.current_stream()), "eprecon_upsample_async")
+        return up_feat, up_coords
     up_coords = torch.empty((8 * n, 4), dtype=torch.int32, device=feat.device)
     _lib.check(lib.eprecon_upsample_async(_lib.ptr(feat), feat.stride(0), _lib.ptr(coords), n, c,
                                           int(interval), _lib.ptr(up_feat), _lib.ptr(up_coords),
@@ -84,11 +91,15 @@ def upsample(pre_feat, pre_coords, interval):
     return up_feat, up_coords
 
 
-def sparsify(occ, threshold, target, coords, tsdf, feat_all, c_feat, batch_size):
+def sparsify(occ, threshold, target, coords, tsdf, feat_all, c_feat, batch_size, behind=None):
     """models/neucon_network.py:454-507 without its random sub-sampling branch, one call + one host read:
     occ f32[N,1], target bool[N] | None, coords int32[N,4], tsdf f32[N,1], feat_all f32[N,C] ->
     (counts [kept, occupied per batch..., occupied & target per batch...], pre_coords, pre_tsdf [M,1], pre_occ [M,1],
-    kept_all [M,C], pre_feat [M, c_feat + 2])"""
+    kept_all [M,C], pre_feat [M, c_feat + 2])
+    behind (optional): callable(kept_coords int32[N,4] (first M rows live), n_kept_dev int32[1]) -> (extra int32 device tensor,
+    finish(m, host_extra)): work queued on the DEVICE count of kept rows in front of the read (the next level's coordinate
+    side, torchsparse_utils.SpvcnnPrefetch; the panoptic pruning), whose own counts ride on this read; the call then
+    returns a 7-tuple whose last element is finish(...)'s result"""
     lib = _lib.load()
     n, c_all = feat_all.shape
     dev = feat_all.device
@@ -109,6 +120,12 @@ def sparsify(occ, threshold, target, coords, tsdf, feat_all, c_feat, batch_size)
         _lib.ptr(feat_all), feat_all.stride(0), c_all, int(c_feat), n, batch_size, _lib.ptr(out_coords), _lib.ptr(out_tsdf),
         _lib.ptr(out_occ), _lib.ptr(out_all), _lib.ptr(out_feat), _lib.ptr(counts), _lib.ptr(ws), ws.numel(),
         _lib.current_stream()), "eprecon_sparsify_async")
+    if behind is not None:
+        extra, finish = behind(out_coords, counts[0:1])
+        host = _lib.read_counts(torch.cat([counts, extra.reshape(-1)]))
+        m = host[0]
+        return (host[:counts.numel()], out_coords[:m], out_tsdf[:m], out_occ[:m], out_all[:m], out_feat[:m],
+                finish(m, host[counts.numel():]))
     host = _lib.read_counts(counts)     # (deferred checks ride on this read: back-projection without a read of its own)
     m = host[0]
     return host, out_coords[:m], out_tsdf[:m], out_occ[:m], out_all[:m], out_feat[:m]

@@ -34,12 +34,16 @@ from .mask3dformer import MultiScaleMaskedTransformerDecoder, panoptic_post
 from .modules import Linear4xTrans, Panoptic_Feat_Fusion, SPVCNN, linear4x_pair
 from .occupancy_initialization import Occupancy_Initialization
 from .tensor import PointTensor
-from .torchsparse_utils import aligned_camera_coords
+from .torchsparse_utils import SpvcnnPrefetch, aligned_camera_coords
 
 # the reference's sequence of torch calls (threshold, index_add counts, nonzero, index_select x 4, cat: ~15 launches and two
 # host reads per level) stays for training and the seeded random drop; inference takes eprecon_sparsify_async (3 launches, one
 # host read).  Tests flip this module attribute to compare the two.
 _FUSED_SPARSIFY = True
+# EPRECON_PREFETCH=0: every SPVCNN pass reads the sizes of its voxel sets itself and the panoptic pruning reads its own counts
+# (round 4: 14 blocking reads per fragment) instead of queueing that work on the DEVICE count of the rows a compaction has just
+# written and letting its counts ride on the compaction's read (torchsparse_utils.SpvcnnPrefetch: 10 reads).  Same results.
+_PREFETCH = __import__("os").environ.get("EPRECON_PREFETCH", "1") == "1"
 
 
 WARN_TAG = ""    # prefix of the guard warnings below; fragment_step.calibrate_occupancy_heads sets "[calibration] " around its forwards
@@ -155,6 +159,31 @@ class NeuConNet(nn.Module):
                                      must_be_zero=getattr(self.initialization, "dense_checks", ()))
         return init_output, selected, shape_init
 
+    def _spvcnn_behind(self, level, inputs, children):
+        """the hook (grid_ops.sparsify / back_project.forward_behind) that queues the coordinate side of SPVCNN pass `level`
+        on the device count of the rows just compacted; finish -> (up_coords | None, r_coords)"""
+        cfg, net = self.cfg, self.sp_convs[level]
+        interval = 2 ** (self.n_scales - level)
+        res = float(net.vres) / float(net.pres) if net.pres != 1 else float(net.vres)     # initial_voxelize's resolution
+
+        def behind(coords, n_dev):
+            pf = SpvcnnPrefetch(coords, n_dev, children, interval, inputs["vol_origin_partial"], cfg.VOXEL_SIZE,
+                                inputs["world_to_aligned_camera"], res)
+            return pf.headers(), (lambda m, host: pf.finish(8 * m if children else m, host))
+        return behind
+
+    @staticmethod
+    def _prune_behind(coords1, coords0):
+        """the ancestor pruning of levels 1 and 0 (prune_to_ancestors) queued on the device count of the finest level's kept
+        rows; finish -> (keep1, keep0, n1, n0)"""
+        def behind(fine, n_dev):
+            dev = fine.device
+            keep1 = SP.HashGrid(fine.shape[0], dev).build(fine, quantum=2, n_dev=n_dev).query(coords1.contiguous()) >= 0
+            keep0 = SP.HashGrid(fine.shape[0], dev).build(fine, quantum=4, n_dev=n_dev).query(coords0.contiguous()) >= 0
+            sums = torch.stack([keep1.sum(), keep0.sum()]).to(torch.int32)
+            return sums, (lambda m, host: (keep1, keep0, int(host[0]), int(host[1])))
+        return behind
+
     def forward(self, features, features_backbone2d_occ_pano, inputs, outputs, only_train_init=False,
                 only_train_occ=False, init_overlap_count=0):
         cfg = self.cfg
@@ -197,20 +226,35 @@ class NeuConNet(nn.Module):
         pre_feat = pre_coords = None
         panoptic_voxel_feats, panoptic_coords = [], []
         occ_target = occupancy = None
+        # inference on the GPU: the coordinate side of every SPVCNN pass (and the panoptic pruning) is queued on the device
+        # count of the rows the previous compaction wrote, and its sizes ride on that compaction's host read
+        prefetch = _PREFETCH and dev.type == "cuda" and not recording and _FUSED_SPARSIFY
+        ahead = pruned = None        # (up_coords, r_coords) of the level about to run; (keep1, keep0, n1, n0)
         for i in range(cfg.N_LAYER):
             interval = 2 ** (self.n_scales - i)
             scale = self.n_scales - i
+            ready, ahead = ahead, None
             if i == 0:
                 up_coords = coord_init_selected.contiguous()
                 min_view_number = 2
                 up_feat = None
             else:
-                up_feat, up_coords = self.upsample(pre_feat, pre_coords, interval)
+                if ready is not None and ready[0] is not None and ready[0].shape[0] == 8 * pre_coords.shape[0]:
+                    up_feat, up_coords = GO.upsample(pre_feat, pre_coords, interval, up_coords=ready[0])
+                else:
+                    ready = None
+                    up_feat, up_coords = self.upsample(pre_feat, pre_coords, interval)
                 min_view_number = 0
             feats = stack_views([f[scale] for f in features_backbone2d_occ_pano])   # no copy for batched backbones
             KRcam = inputs["proj_matrices"][:, :, scale].permute(1, 0, 2, 3).contiguous()
-            project_output = self.back_projection[i](up_coords, inputs["vol_origin_partial"], cfg.VOXEL_SIZE,
-                                                     feats, KRcam, min_view_number)
+            if i == 0 and prefetch and up_coords.dtype == torch.int32:
+                from . import back_project as BP
+                project_output, ready = BP.forward_behind(self.back_projection[0], up_coords, inputs["vol_origin_partial"],
+                                                          cfg.VOXEL_SIZE, feats, KRcam, min_view_number,
+                                                          self._spvcnn_behind(0, inputs, children=False))
+            else:
+                project_output = self.back_projection[i](up_coords, inputs["vol_origin_partial"], cfg.VOXEL_SIZE,
+                                                         feats, KRcam, min_view_number)
             if project_output is None:
                 loss_dict[f"tsdf_occ_loss_{i}"] = zero
                 _warn(f"no valid points in back_projection: scale {i}")
@@ -225,8 +269,11 @@ class NeuConNet(nn.Module):
             else:
                 feat = volume
 
-            r_coords = aligned_camera_coords(up_coords, inputs["vol_origin_partial"], cfg.VOXEL_SIZE,
-                                             inputs["world_to_aligned_camera"])
+            if ready is not None and ready[1].shape[0] == up_coords.shape[0]:
+                r_coords = ready[1]        # (queued ahead with the voxelisation the SPVCNN pass below finds in the cache)
+            else:
+                r_coords = aligned_camera_coords(up_coords, inputs["vol_origin_partial"], cfg.VOXEL_SIZE,
+                                                 inputs["world_to_aligned_camera"])
             sp_in = feat
             feat = self.sp_convs[i](PointTensor(feat.contiguous(), r_coords))
             feat_all = torch.cat([feat, volume], dim=-1)
@@ -256,12 +303,23 @@ class NeuConNet(nn.Module):
             # reference's sequence of torch calls below.
             fused = None
             if _FUSED_SPARSIFY and dev.type == "cuda" and not recording and feat_all.stride(1) == 1:
+                behind = None
+                if prefetch and i + 1 < cfg.N_LAYER:
+                    behind = self._spvcnn_behind(i + 1, inputs, children=True)
+                elif prefetch and i + 1 == cfg.N_LAYER and len(panoptic_coords) == 2 and bs == 1 \
+                        and all(c.dtype == torch.int32 for c in panoptic_coords):
+                    behind = self._prune_behind(panoptic_coords[1], panoptic_coords[0])
                 fused = GO.sparsify(occ, cfg.THRESHOLDS[i], occ_target,
                                     up_coords if up_coords.dtype == torch.int32 else up_coords.to(torch.int32), tsdf, feat_all,
-                                    feat.shape[1], bs)
+                                    feat.shape[1], bs, behind=behind)
                 if self.training and any(cfg.TRAIN_NUM_SAMPLE[i] < nb <= cfg.TRAIN_NUM_SAMPLE[i] * EXCEED_NUM
                                          for nb in fused[0][1:1 + bs]):
                     fused = None          # a batch element is over its cap: np.random.choice drops rows first (below)
+                elif behind is not None:
+                    if i + 1 < cfg.N_LAYER:
+                        ahead = fused[6]
+                    else:
+                        pruned = fused[6]
             if fused is not None:
                 stats = [fused[0][1:1 + bs], fused[0][1 + bs:1 + 2 * bs]]
                 if self.trace is not None:
@@ -278,7 +336,7 @@ class NeuConNet(nn.Module):
                         if stats[1][b] == 0:
                             _warn(f"occ_target is 0: scale {i}")
                             return outputs, loss_dict
-                _, pre_coords, pre_tsdf, pre_occ, kept_all, pre_feat = fused
+                _, pre_coords, pre_tsdf, pre_occ, kept_all, pre_feat = fused[:6]
                 if pre_coords.dtype != up_coords.dtype:
                     pre_coords = pre_coords.to(up_coords.dtype)
                 panoptic_voxel_feats.append(kept_all)
@@ -338,7 +396,7 @@ class NeuConNet(nn.Module):
         # ---- C. panoptic segmentation (:516-587) ---------------------------------------------------
         side = self.panoptic_stream if (not recording and dev.type == "cuda" and self.panoptic is not None) else None
         if side is None:
-            self._panoptic_branch(panoptic_coords, panoptic_voxel_feats, bs, outputs)
+            self._panoptic_branch(panoptic_coords, panoptic_voxel_feats, bs, outputs, pruned)
             if self.panoptic is not None:
                 outputs["panoptic_info"] = [panoptic_post(o) for o in outputs["panoptic_out"]]  # :583-587
                 if recording and "rgb_list" in inputs and occ_target is not None:
@@ -351,12 +409,12 @@ class NeuConNet(nn.Module):
             # deferred: outputs["panoptic_finish"]() waits for the branch, fills outputs["panoptic_info"] and returns outputs.
             main = torch.cuda.current_stream(dev)
             side.wait_stream(main)
-            for t in list(panoptic_voxel_feats) + list(panoptic_coords):
+            for t in list(panoptic_voxel_feats) + list(panoptic_coords) + (list(pruned[:2]) if pruned is not None else []):
                 t.record_stream(side)       # allocated on the main stream, read on the side stream after this call returns
-            def branch(outputs=outputs, coords=panoptic_coords, feats=panoptic_voxel_feats, side=side):
+            def branch(outputs=outputs, coords=panoptic_coords, feats=panoptic_voxel_feats, side=side, pruned=pruned):
                 # (grad mode and the current stream are thread-local: both are set here)
                 with torch.no_grad(), torch.cuda.stream(side):
-                    self._panoptic_branch(coords, feats, bs, outputs)
+                    self._panoptic_branch(coords, feats, bs, outputs, pruned)
                     if self.panoptic_worker is not None:
                         # the host-synchronising post-processing too: it is the worker that waits for the decoder
                         outputs["panoptic_info"] = [panoptic_post(o) for o in outputs["panoptic_out"]]
@@ -381,15 +439,19 @@ class NeuConNet(nn.Module):
             _lib.drain_deferred()   # training has no fused sparsify read: the back-projections' deferred row-count checks are verified here
         return outputs, loss_dict
 
-    def _panoptic_branch(self, panoptic_coords, panoptic_voxel_feats, bs, outputs):
+    def _panoptic_branch(self, panoptic_coords, panoptic_voxel_feats, bs, outputs, pruned=None):
         """ancestor pruning of the coarser levels, 48-channel projections, mask features, decoder (:516-581); fills
-        outputs['panoptic_levels'] and outputs['panoptic_out'] on the current stream"""
-        keep1, keep0 = self.prune_to_ancestors(panoptic_coords)
-        # (one nonzero per level, shared by the coordinates and the features: boolean indexing runs it once per tensor)
-        # both counts in ONE read, then the row lists with their sizes given (torch.nonzero sizes its result on the host: two
-        # reads)
-        _lib.count_host_read()
-        n1, n0 = torch.stack([keep1.sum(), keep0.sum()]).tolist()
+        outputs['panoptic_levels'] and outputs['panoptic_out'] on the current stream.  pruned = (keep1, keep0, n1, n0): the
+        pruning was queued ahead and its counts came with the finest level's sparsify read (_prune_behind)"""
+        if pruned is not None:
+            keep1, keep0, n1, n0 = pruned
+        else:
+            keep1, keep0 = self.prune_to_ancestors(panoptic_coords)
+            # (one nonzero per level, shared by the coordinates and the features: boolean indexing runs it once per tensor)
+            # both counts in ONE read, then the row lists with their sizes given (torch.nonzero sizes its result on the host:
+            # two reads)
+            _lib.count_host_read()
+            n1, n0 = torch.stack([keep1.sum(), keep0.sum()]).tolist()
         i1 = torch.nonzero_static(keep1, size=n1).squeeze(1)
         i0 = torch.nonzero_static(keep0, size=n0).squeeze(1)
         panoptic_coords[1], panoptic_voxel_feats[1] = panoptic_coords[1].index_select(0, i1), panoptic_voxel_feats[1].index_select(0, i1)

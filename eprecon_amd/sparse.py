@@ -39,8 +39,14 @@ class HashGrid:
         """int32[2] view of the table's header: (status word, count of unique keys written by the unique calls)"""
         return self.mem[:8].view(torch.int32)
 
-    def build(self, coords, quantum=1):
+    def build(self, coords, quantum=1, n_dev=None):
+        """n_dev (a device int32 element): only the first min(N, *n_dev) rows of `coords` are live"""
         lib = _lib.load()
+        if n_dev is not None:
+            _lib.check(lib.eprecon_hash_build_dn_async(_lib.ptr(coords), coords.shape[0], _lib.ptr(n_dev), quantum,
+                                                       _lib.ptr(self.mem), self.capacity, _lib.current_stream()),
+                       "eprecon_hash_build_dn_async")
+            return self
         _lib.check(lib.eprecon_hash_build_async(_lib.ptr(coords), coords.shape[0], quantum,
                                                 _lib.ptr(self.mem), self.capacity,
                                                 _lib.current_stream()), "eprecon_hash_build_async")

@@ -11,7 +11,7 @@ from . import sparse as SP
 from .tensor import PointTensor, SparseTensor
 
 __all__ = ["initial_voxelize", "point_to_voxel", "voxel_to_point", "aligned_camera_coords", "devoxelize_gate",
-           "clear_voxelization_cache"]
+           "clear_voxelization_cache", "SpvcnnPrefetch"]
 
 
 def aligned_camera_coords(coords, origin, voxel_size, world_to_aligned_camera):
@@ -170,6 +170,74 @@ def _voxelize_points(pts, res, levels=1):
         uniq, e.inverse, grid = SP.unique_coords(e.vox, 1)
         e.vset = SP.VoxelSet(uniq, 1, grid=grid)
     return _publish_entry(e)
+
+
+class SpvcnnPrefetch:
+    """The coordinate side of the NEXT SPVCNN pass, queued while the length of its input list is still on the device.
+
+    The voxels an SPVCNN pass runs on are the rows a compaction has just written — the occupied rows sparsify keeps
+    (models/neucon_network.py:454-507, expanded to their 8 children :193-214) or the valid rows of the stage-0 back-projection —
+    and the host learns their number from that compaction's count read.  The pass then needs a SECOND read: the sizes of its
+    three strided voxel sets.  Here the chain [children ->] aligned-camera points -> scaled points / voxel indices -> unique
+    numbering at strides 1, 2, 4 is queued on the device count (eprecon_spvcnn_points_dn_async, eprecon_unique_coords_dn_async)
+    BEFORE the compaction's read; `headers()` are appended to that read and `finish()` slices the buffers and publishes the
+    voxelisation under the points tensor it returns, where SPVCNN.forward's initial_voxelize finds it: one blocking read per
+    level less, bit-identical results (the same kernels' arithmetic on the same rows)."""
+
+    def __init__(self, src_coords, n_src_dev, children, interval, origin, voxel_size, world_to_aligned_camera, res):
+        lib = _lib.load()
+        dev = src_coords.device
+        assert src_coords.dtype == torch.int32 and src_coords.is_contiguous()
+        cap_src = src_coords.shape[0]
+        cap = cap_src * 8 if children else cap_src
+        origin = origin.float().reshape(-1, 3).contiguous()
+        w2ac = world_to_aligned_camera.float().reshape(-1, 4, 4).contiguous()
+        self.res = float(res)
+        self.up = torch.empty((cap, 4), dtype=torch.int32, device=dev) if children else None
+        self.r = torch.empty((cap, 4), dtype=torch.float32, device=dev)
+        self.scaled = torch.empty((cap, 4), dtype=torch.float32, device=dev)
+        self.vox = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+        self.n_pts = torch.empty(1, dtype=torch.int32, device=dev)
+        _lib.check(lib.eprecon_spvcnn_points_dn_async(
+            _lib.ptr(src_coords), cap_src, _lib.ptr(n_src_dev), int(bool(children)), int(interval), _lib.ptr(origin), origin.shape[0],
+            float(voxel_size), _lib.ptr(w2ac), self.res, _lib.ptr(self.up), _lib.ptr(self.r), _lib.ptr(self.scaled),
+            _lib.ptr(self.vox), _lib.ptr(self.n_pts), _lib.current_stream()), "eprecon_spvcnn_points_dn_async")
+        self.grids, self.uniqs, self.invs = [], [], []
+        src, n_dev = self.vox, self.n_pts
+        for lvl in range(3):
+            u, inv, g = SP.unique_coords_queued(src, quantum=2 ** lvl, n_dev=n_dev)
+            self.grids.append(g); self.uniqs.append(u); self.invs.append(inv)
+            src, n_dev = u, g.header[1:2]
+        self._keep = (src_coords, n_src_dev, origin, w2ac)
+
+    def headers(self):
+        """int32[6]: (status word, unique count) of the three tables, to be read with the compaction's own counts"""
+        return torch.cat([g.header for g in self.grids])
+
+    def finish(self, n_pts, host):
+        """n_pts: live points (8 x kept rows, or the valid rows), host: the six header values -> (up_coords | None, r_coords):
+        the rows of the new level and their aligned-camera points; the voxelisation (three strided sets + the pass's geometry)
+        is published under `r_coords`"""
+        sizes = []
+        for lvl in range(3):
+            SP.check_hash_status(host[2 * lvl])
+            sizes.append(host[2 * lvl + 1])
+        r = self.r[:n_pts]
+        up = self.up[:n_pts] if self.up is not None else None
+        if n_pts == 0 or sizes[0] == 0:
+            return up, r
+        e = _VoxEntry()
+        e.key, e.pts = (r.data_ptr(), r._version, r.shape[0], self.res), r
+        e.scaled, e.vox = self.scaled[:n_pts], self.vox[:n_pts]
+        invs = [self.invs[0][:n_pts], self.invs[1], self.invs[2]]
+        e.vset, e.inverse, tables = SP._hierarchy_with_geometry(e.vox, e.scaled, self.grids, self.uniqs, invs, sizes)
+        e.lists = (tables["offsets1"], tables["order1"])
+        e.idx8, e.w8, e._order, e._stale = tables["idx8_1"], tables["weight8_1"], None, {}
+        e.stride4 = (tables["idx4"], (tables["offsets4"], tables["order4"]), tables["idx8_4"], tables["weight8_4"])
+        with _VOX_CACHE_LOCK:
+            _VOX_CACHE.append(e)
+            del _VOX_CACHE[:max(0, len(_VOX_CACHE) - _VOX_CACHE_MAX)]
+        return up, r
 
 
 def register_voxelization(pts, res, scaled, vox, inverse, uniq, grid):

@@ -152,6 +152,9 @@ size_t eprecon_hash_table_bytes(uint32_t capacity);
 /* value of a key = smallest input row that carries it */
 int eprecon_hash_build_async(const int32_t *coords, int64_t n, int quantum, void *table,
                              uint32_t capacity, void *stream);
+/* ... with the row count on the device: only the first min(n_cap, *n_dev) rows are inserted (the table is sized by n_cap) */
+int eprecon_hash_build_dn_async(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, int quantum, void *table,
+                                uint32_t capacity, void *stream);
 /* out_index[i] = value stored for queries[i] (int32[m,4] bxyz), or -1 */
 int eprecon_hash_query_async(const void *table, uint32_t capacity, const int32_t *queries, int64_t m,
                              int quantum, int32_t *out_index, void *stream);
@@ -385,7 +388,7 @@ int eprecon_sparsify_async(const float *occ, int ld_occ, float threshold, const 
 /*
  * NeuConNet.upsample (models/neucon_network.py:193-214): up_coords int32[8n,4], up_feat f32[8n,C];
  * children of a voxel are consecutive, in the order 0, +x, +y, +z, +xy, +xz, +yz, +xyz (x `interval`).
- * channels == 0 expands the coordinates only.
+ * channels == 0 expands the coordinates only; up_coords NULL (channels > 0) expands the features only.
  */
 int eprecon_upsample_async(const float *feat, int ld_feat, const int32_t *coords, int64_t n, int channels,
                            int interval, float *up_feat, int32_t *up_coords, void *stream);
@@ -405,6 +408,20 @@ int eprecon_aligned_coords_async(const int32_t *coords, int64_t n, const float *
 /* scaled = (x/res, y/res, z/res, b) (IEEE division); voxel = (b, floor x', floor y', floor z') */
 int eprecon_point_quantize_async(const float *points_xyzb, int64_t n, float resolution, float *scaled_xyzb,
                                  int32_t *voxel_bxyz, void *stream);
+/*
+ * The coordinate side of the NEXT SPVCNN pass, queued BEFORE the host has read how many rows a compaction kept
+ * (models/neucon_network.py:454-507 keeps the occupied rows, :193-214 expands them to 8 children, :387-398 maps them to the
+ * aligned camera frame, ops/torchsparse_utils.py:15-19 scales and floors them): src_coords int32[cap_src,4] with the live row
+ * count in *n_src_dev; children != 0: every row -> its 8 children (interval of the new level) in up_coords int32[8 cap_src,4];
+ * r_coords / scaled_xyzb f32[cap_pts,4], voxel_bxyz int32[cap_pts,4], *n_points_dev = live points.  One launch sized by the
+ * capacity; the unique-voxel numbering (eprecon_unique_coords_dn_async) then runs on *n_points_dev, and the level's size read
+ * rides on the read of the compaction's own counts (one blocking read instead of two).  Same arithmetic as
+ * eprecon_upsample_async + eprecon_aligned_coords_async + eprecon_point_quantize_async.
+ */
+int eprecon_spvcnn_points_dn_async(const int32_t *src_coords, int64_t cap_src, const int32_t *n_src_dev, int children,
+                                   int interval, const float *origin, int batch, float voxel_size,
+                                   const float *world_to_aligned_camera, float resolution, int32_t *up_coords, float *r_coords,
+                                   float *scaled_xyzb, int32_t *voxel_bxyz, int32_t *n_points_dev, void *stream);
 /* ... with the point count on the device (see eprecon_unique_coords_dn_async) */
 int eprecon_point_quantize_dn_async(const float *points_xyzb, int64_t n_cap, const int32_t *n_dev, float resolution,
                                     float *scaled_xyzb, int32_t *voxel_bxyz, void *stream);

@@ -15,3 +15,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _no_deferred_checks_leak_between_tests():
+    """the device-side checks that ride on the next blocking read (eprecon_amd._lib.defer_check) are per process: a test that
+    provokes one on purpose, or never reaches a read, must not hand it to the next test"""
+    yield
+    try:
+        from eprecon_amd import _lib
+        _lib.take_deferred(None)
+    except Exception:  # noqa: BLE001  (library absent: nothing to clear)
+        pass

@@ -54,7 +54,14 @@ def test_rank_volume_matches_definition():
 def test_rank_volume_counts_voxels_off_the_grid():
     from eprecon_amd.sparse import DenseMap, VoxelSet
     c = np.array([[0, 0, 0, 0], [0, 2, 2, 2], [0, 3, 2, 2], [0, 40, 0, 0], [0, -2, 0, 0]], np.int32)  # odd, outside, negative
+    from eprecon_amd import _lib
+    _lib.take_deferred(None)
     assert DenseMap(VoxelSet(dev(c), 2), (8, 8, 8)).off_grid() == 3
+    # production: nobody calls off_grid() — the map deferred its own check, and the NEXT blocking count read on the stream raises
+    # instead of leaving three output rows of every convolution on the set unwritten
+    with pytest.raises(_lib.EpreconError, match="not on the grid"):
+        _lib.read_counts(torch.zeros(1, dtype=torch.int32, device="cuda"))
+    assert _lib.take_deferred(None) == []
 
 
 def test_pending_batchnorm_on_load_and_column_slices():

@@ -91,6 +91,24 @@ def test_gru_stage_call_off(scene, default_run, monkeypatch):
     assert_same_scene(default_run, run_scene(scene), exact=True)
 
 
+def test_prefetch_off(scene, default_run, monkeypatch):
+    """EPRECON_PREFETCH=0: every SPVCNN pass reads its own voxel-set sizes and the panoptic pruning its own counts (14 blocking
+    reads per fragment) instead of riding on the previous compaction's read (10): bit-identical fragments, four reads apart"""
+    import eprecon_amd.neucon_network as NN
+    from eprecon_amd import _lib
+    r0 = _lib.HOST_READS
+    on = run_scene(scene)
+    r1 = _lib.HOST_READS
+    monkeypatch.setattr(NN, "_PREFETCH", False)
+    off = run_scene(scene)
+    r2 = _lib.HOST_READS
+    assert_same_scene(default_run, on, exact=True)
+    assert_same_scene(default_run, off, exact=True)
+    n = scene.n_fragments
+    # three SPVCNN size reads + the pruning's read per fragment (a level that falls back to the seeded random drop keeps its own)
+    assert 3 * n <= (r2 - r1) - (r1 - r0) <= 4 * n, ((r1 - r0) / n, (r2 - r1) / n)
+
+
 def test_gru_one_stream(scene, default_run, monkeypatch):
     """EPRECON_GRU_STREAMS=0: the two ConvGRUs of a level on one stream"""
     monkeypatch.setattr(scene.net.gru_fusion, "two_streams", False)
