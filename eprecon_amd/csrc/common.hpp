@@ -66,6 +66,25 @@ int exclusive_scan_i32(const int32_t *in, int n, int32_t *out, int32_t *scratch,
 int exclusive_scan_i32_dn(const int32_t *in, int n, const int32_t *n_dev, int32_t *out, int32_t *scratch, int32_t *total_dev,
                           hipStream_t st);
 
+// Several device regions filled with a 32-bit pattern each in ONE launch (instead of a hipMemsetAsync / clear kernel per
+// region): the prologues of the stage calls clear a handful of index volumes, counters and hash tables of a few MB each, and
+// every launch they do not need is ~5 us of a fragment's chain.  Regions: 16-byte aligned, sizes multiples of 16 bytes.
+struct FillRegion {
+    void *p;
+    size_t bytes;
+    uint32_t value;
+};
+constexpr int kMaxFillRegions = 12;
+int multi_fill(const FillRegion *regions, int count, hipStream_t st);
+// the three regions that reset an open-addressing table (header, keys = empty, values = int max): kernel_map.hip
+int table_clear_regions(void *table, uint32_t capacity, FillRegion *out3);
+
+// eprecon_unique_coords_dn_async for callers inside the library: table_cleared = the caller reset the table itself (multi_fill);
+// status_copy (optional device int32): receives the table's status word from the call's last launch
+int unique_coords_dn(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, int quantum, void *table, uint32_t capacity,
+                     int32_t *inverse, int32_t *unique_coords, int32_t *n_unique_dev, void *workspace, size_t workspace_bytes,
+                     bool table_cleared, int32_t *status_copy, void *stream);
+
 // A side stream of the library's own per caller stream, for entry points that issue two independent chains of small launches
 // (csrc/gru_stage_finish.hip): record ev_fork on the caller's stream and let `side` wait for it, issue the second chain on
 // `side`, record ev_join there and let the caller's stream wait for it.

@@ -440,6 +440,31 @@ __global__ void stage_points_kernel(const int32_t *updated, int n_cap, const int
         r[j] = __fmaf_rn(1.0f, w2ac[4 * j + 3], __fmaf_rn(Z, w2ac[4 * j + 2], __fmaf_rn(Y, w2ac[4 * j + 1], __fmul_rn(X, w2ac[4 * j]))));
     r_coords[i] = make_float4(r[0], r[1], r[2], 0.0f);
 }
+// ... and, in the same launch, the two voxelisations' coordinate side (point_quantize_kernel twice, csrc/voxelize.hip: IEEE division
+// by the resolution, floor; the second one on the ALREADY-SCALED points — ConvGRU's convr, models/modules.py:216-217)
+__global__ void stage_points_quantize_kernel(const int32_t *updated, int n_cap, const int32_t *n_dev, int interval, int batch_index,
+                                             const float *origin, float vs, const float *w2ac, float res, int4 *out_coords,
+                                             float4 *r_coords, float4 *scaled1, int4 *vox1, float4 *scaled2, int4 *vox2)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= min(n_cap, *n_dev)) return;
+    const int cx = updated[3 * i] * interval, cy = updated[3 * i + 1] * interval, cz = updated[3 * i + 2] * interval;
+    out_coords[i] = make_int4(batch_index, cx, cy, cz);
+    const float X = __fadd_rn(__fmul_rn((float)cx, vs), origin[0]);
+    const float Y = __fadd_rn(__fmul_rn((float)cy, vs), origin[1]);
+    const float Z = __fadd_rn(__fmul_rn((float)cz, vs), origin[2]);
+    float r[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        r[j] = __fmaf_rn(1.0f, w2ac[4 * j + 3], __fmaf_rn(Z, w2ac[4 * j + 2], __fmaf_rn(Y, w2ac[4 * j + 1], __fmul_rn(X, w2ac[4 * j]))));
+    r_coords[i] = make_float4(r[0], r[1], r[2], 0.0f);
+    const float x1 = __fdiv_rn(r[0], res), y1 = __fdiv_rn(r[1], res), z1 = __fdiv_rn(r[2], res);
+    scaled1[i] = make_float4(x1, y1, z1, 0.0f);
+    vox1[i] = make_int4(0, (int)floorf(x1), (int)floorf(y1), (int)floorf(z1));
+    const float x2 = __fdiv_rn(x1, res), y2 = __fdiv_rn(y1, res), z2 = __fdiv_rn(z1, res);
+    scaled2[i] = make_float4(x2, y2, z2, 0.0f);
+    vox2[i] = make_int4(0, (int)floorf(x2), (int)floorf(y2), (int)floorf(z2));
+}
 __global__ void target_lookup_dn_kernel(const float *vol, const int32_t *updated, int n_cap, const int32_t *n_dev, int D, float *out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -849,10 +874,35 @@ int eprecon_gru_stage_begin_async(const eprecon_gru_stage_desc *d, void *stream)
     void *uws = ws + 2 * iseg;
     const size_t uws_bytes = d->workspace_bytes - 2 * iseg;
     int32_t *cnt = d->counts;
-    EP_HIP_CHECK(hipMemsetAsync(cnt, 0, 8 * sizeof(int32_t), st));
+    const size_t seg = align_up((size_t)cells * 4, 256);
+    if ((reinterpret_cast<uintptr_t>(cnt) & 15) != 0) return EPRECON_ERR_ARG;
+
+    // --- everything the call has to reset, in ONE launch (was: three memsets, a fill kernel and two table clears): the
+    //     counters, the two index volumes (-1) and the flag volume (0) of the crop, the ground-truth twin's dense volume (1.0)
+    //     and the two hash tables of the shared voxelisations ---
+    {
+        ep::FillRegion reg[ep::kMaxFillRegions];
+        int nr = 0;
+        reg[nr++] = ep::FillRegion{cnt, 8 * sizeof(int32_t), 0u};
+        reg[nr++] = ep::FillRegion{m->dense, 2 * seg, 0xFFFFFFFFu};
+        reg[nr++] = ep::FillRegion{m->dense + 2 * seg, seg, 0u};
+        if (tm) {
+            rc = ensure_dense(tm, dim);
+            if (rc == EPRECON_OK) rc = ensure_flags(tm, tm->size, cells);
+            if (rc != EPRECON_OK) return rc;
+            reg[nr++] = ep::FillRegion{tm->dense + 4 * seg, seg, 0x3f800000u};   // 1.0f (the whole 256-byte-aligned segment)
+        }
+        rc = ep::table_clear_regions(d->table1, d->table_capacity, reg + nr);
+        if (rc != EPRECON_OK) return rc;
+        nr += 3;
+        rc = ep::table_clear_regions(d->table2, d->table_capacity, reg + nr);
+        if (rc != EPRECON_OK) return rc;
+        nr += 3;
+        rc = ep::multi_fill(reg, nr, st);
+        if (rc != EPRECON_OK) return rc;
+    }
 
     // --- crop + union (the kernels of eprecon_map_crop_union, without its host read) ---
-    const size_t seg = align_up((size_t)cells * 4, 256);
     CropParams p;
     p.cur_coords = d->cur_coords; p.cur_feat = d->cur_feat; p.n_cur = (int)d->n_cur; p.ld_cur = d->ld_cur;
     p.glob_coords = m->coords[m->cur]; p.glob_feat = m->feats[m->cur]; p.n_glob = (int)m->size;
@@ -863,8 +913,6 @@ int eprecon_gru_stage_begin_async(const eprecon_gru_stage_desc *d, void *stream)
     p.flag = reinterpret_cast<int32_t *>(m->dense + 2 * seg);
     int32_t *rank = reinterpret_cast<int32_t *>(m->dense + 3 * seg);
     p.keep = m->keep;
-    EP_HIP_CHECK(hipMemsetAsync(p.idx_cur, 0xFF, 2 * seg, st));
-    EP_HIP_CHECK(hipMemsetAsync(p.flag, 0, seg, st));
     const int64_t rows = d->n_cur + m->size;
     if (rows > 0) {
         hipLaunchKernelGGL(map_crop_scatter_kernel, dim3((unsigned)ceil_div(rows, 32)), dim3(256), 0, st, p);
@@ -888,16 +936,11 @@ int eprecon_gru_stage_begin_async(const eprecon_gru_stage_desc *d, void *stream)
 
     // --- ground-truth twin: dense volume <- map rows inside the FBV <- the fragment's ground truth; targets at the union ---
     if (tm) {
-        rc = ensure_dense(tm, dim);
-        if (rc == EPRECON_OK) rc = ensure_flags(tm, tm->size, cells);
-        if (rc != EPRECON_OK) return rc;
         int32_t *tflag = reinterpret_cast<int32_t *>(tm->dense + 2 * seg);
         int32_t *trank = reinterpret_cast<int32_t *>(tm->dense + 3 * seg);
-        float *vol = reinterpret_cast<float *>(tm->dense + 4 * seg);
+        float *vol = reinterpret_cast<float *>(tm->dense + 4 * seg);     // (filled with 1.0 by the call's first launch)
         for (int a = 0; a < 3; ++a) tm->rel[a] = d->rel[a];
         const dim3 blk(256), gcells((unsigned)ceil_div(cells, 256));
-        hipLaunchKernelGGL(fill_f32_kernel, gcells, blk, 0, st, vol, cells, 1.0f);
-        EP_LAUNCH_CHECK();
         if (tm->size > 0) {
             hipLaunchKernelGGL(target_scatter_kernel, dim3((unsigned)ceil_div(tm->size, 256)), blk, 0, st,
                                (const int32_t *)tm->coords[tm->cur], (const float *)tm->feats[tm->cur], (int)tm->size, dim, d->rel[0],
@@ -918,23 +961,20 @@ int eprecon_gru_stage_begin_async(const eprecon_gru_stage_desc *d, void *stream)
     }
 
     // --- the fragment's points and the two voxelisations the six SConv3d of the scale share ---
-    hipLaunchKernelGGL(stage_points_kernel, dim3((unsigned)ceil_div(cap, 256)), dim3(256), 0, st, (const int32_t *)d->updated, cap, n_u,
-                       d->interval, d->batch_index, d->origin, d->voxel_size, d->w2ac, reinterpret_cast<int4 *>(d->out_coords),
-                       reinterpret_cast<float4 *>(d->r_coords));
+    // (one launch for the points and both quantisations; the tables were reset by the call's first launch; each numbering's
+    // last launch leaves its table's status word next to the counts: one host read for everything)
+    hipLaunchKernelGGL(stage_points_quantize_kernel, dim3((unsigned)ceil_div(cap, 256)), dim3(256), 0, st, (const int32_t *)d->updated,
+                       cap, n_u, d->interval, d->batch_index, d->origin, d->voxel_size, d->w2ac, d->resolution,
+                       reinterpret_cast<int4 *>(d->out_coords), reinterpret_cast<float4 *>(d->r_coords),
+                       reinterpret_cast<float4 *>(d->scaled1), reinterpret_cast<int4 *>(d->vox1),
+                       reinterpret_cast<float4 *>(d->scaled2), reinterpret_cast<int4 *>(d->vox2));
     EP_LAUNCH_CHECK();
-    rc = eprecon_point_quantize_dn_async(d->r_coords, cap, n_u, d->resolution, d->scaled1, d->vox1, stream);
+    rc = ep::unique_coords_dn(d->vox1, cap, n_u, 1, d->table1, d->table_capacity, d->inverse1, d->uniq1, cnt + 2, uws, uws_bytes,
+                              true, cnt + 6, stream);
     if (rc != EPRECON_OK) return rc;
-    rc = eprecon_unique_coords_dn_async(d->vox1, cap, n_u, 1, d->table1, d->table_capacity, d->inverse1, d->uniq1, cnt + 2, uws,
-                                        uws_bytes, stream);
+    rc = ep::unique_coords_dn(d->vox2, cap, n_u, 1, d->table2, d->table_capacity, d->inverse2, d->uniq2, cnt + 3, uws, uws_bytes,
+                              true, cnt + 7, stream);
     if (rc != EPRECON_OK) return rc;
-    rc = eprecon_point_quantize_dn_async(d->scaled1, cap, n_u, d->resolution, d->scaled2, d->vox2, stream);
-    if (rc != EPRECON_OK) return rc;
-    rc = eprecon_unique_coords_dn_async(d->vox2, cap, n_u, 1, d->table2, d->table_capacity, d->inverse2, d->uniq2, cnt + 3, uws,
-                                        uws_bytes, stream);
-    if (rc != EPRECON_OK) return rc;
-    // the status words of the two tables next to the counts: one host read for everything
-    EP_HIP_CHECK(hipMemcpyAsync(cnt + 6, d->table1, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-    EP_HIP_CHECK(hipMemcpyAsync(cnt + 7, d->table2, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     return EPRECON_OK;
 }
 

@@ -286,9 +286,11 @@ __global__ void first_flag_kernel(HashTable t, const int4 *coords, int n, int q,
 // disjoint data, so one launch serves both)
 __global__ void unique_finalize_kernel(HashTable t, const int4 *coords, int n, int q,
                                        const int32_t *owner, const int32_t *rank, int32_t *inverse,
-                                       int4 *unique_coords, const int32_t *n_dev, uint32_t cap)
+                                       int4 *unique_coords, const int32_t *n_dev, uint32_t cap, const int32_t *status,
+                                       int32_t *status_copy)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && status_copy) *status_copy = *status;   // (the inserts finished a launch ago: the word is final)
     if ((uint32_t)i < cap && t.keys[i] != kEmptyKey) t.vals[i] = rank[t.vals[i]];
     if (n_dev) n = min(n, *n_dev);
     if (i >= n) return;
@@ -394,22 +396,81 @@ __global__ __launch_bounds__(256) void pixel_map_kernel(int maps, int h, int w, 
 
 }  // namespace
 
+namespace ep {
+namespace {
+struct FillParams {
+    uint4 *p[kMaxFillRegions];
+    unsigned long long end[kMaxFillRegions];   // exclusive prefix end, in 16-byte words
+    uint32_t value[kMaxFillRegions];
+    int count;
+};
+__global__ __launch_bounds__(256) void multi_fill_kernel(FillParams f)
+{
+    const unsigned long long e = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long begin = 0;
+#pragma unroll 1
+    for (int r = 0; r < f.count; ++r) {
+        if (e < f.end[r]) {
+            const uint32_t v = f.value[r];
+            f.p[r][e - begin] = make_uint4(v, v, v, v);
+            return;
+        }
+        begin = f.end[r];
+    }
+}
+}  // namespace
+
+int multi_fill(const FillRegion *regions, int count, hipStream_t st)
+{
+    if (count < 0 || count > kMaxFillRegions) return EPRECON_ERR_ARG;
+    FillParams f;
+    f.count = 0;
+    unsigned long long total = 0;
+    for (int r = 0; r < count; ++r) {
+        if (regions[r].bytes == 0) continue;
+        if (!regions[r].p || (reinterpret_cast<uintptr_t>(regions[r].p) & 15) || (regions[r].bytes & 15)) return EPRECON_ERR_ARG;
+        total += regions[r].bytes / 16;
+        f.p[f.count] = reinterpret_cast<uint4 *>(regions[r].p);
+        f.end[f.count] = total;
+        f.value[f.count] = regions[r].value;
+        ++f.count;
+    }
+    if (total == 0) return EPRECON_OK;
+    hipLaunchKernelGGL(multi_fill_kernel, dim3((unsigned)ceil_div((int64_t)total, 256)), dim3(256), 0, st, f);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int table_clear_regions(void *table, uint32_t capacity, FillRegion *out3)
+{
+    if (!table || !is_pow2(capacity)) return EPRECON_ERR_ARG;
+    HashTable t = make_table(table, capacity);
+    out3[0] = FillRegion{table, 16, 0u};                                          // status word (and the unique count next to it)
+    out3[1] = FillRegion{t.keys, (size_t)capacity * 8, 0xFFFFFFFFu};              // kEmptyKey
+    out3[2] = FillRegion{t.vals, (size_t)capacity * 4, 0x7fffffffu};
+    return EPRECON_OK;
+}
+}  // namespace ep
+
 extern "C" {
+
 
 uint32_t eprecon_hash_capacity(int64_t n) { return ep::hash_capacity_for(n); }
 size_t eprecon_hash_table_bytes(uint32_t capacity) { return 256 + (size_t)capacity * 12; }
 
 static int hash_build_impl(const int32_t *coords, int64_t n, const int32_t *n_dev, int quantum, void *table, uint32_t capacity,
-                           void *stream)
+                           void *stream, bool cleared = false)
 {
     if (!table || !is_pow2(capacity) || n < 0 || quantum < 1 || (uint64_t)capacity < (uint64_t)n + 1 ||
         (n > 0 && !coords))
         return EPRECON_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     HashTable t = make_table(table, capacity);
-    hipLaunchKernelGGL(hash_clear_kernel, dim3((capacity + 255) / 256), dim3(256), 0, st, t.keys, t.vals,
-                       capacity, table_status(table));
-    EP_LAUNCH_CHECK();
+    if (!cleared) {   // (cleared: the caller reset the table with its other regions, ep::multi_fill + ep::table_clear_regions)
+        hipLaunchKernelGGL(hash_clear_kernel, dim3((capacity + 255) / 256), dim3(256), 0, st, t.keys, t.vals,
+                           capacity, table_status(table));
+        EP_LAUNCH_CHECK();
+    }
     if (n > 0) {
         hipLaunchKernelGGL(hash_insert_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, t,
                            reinterpret_cast<const int4 *>(coords), (int)n, quantum, table_status(table), n_dev);
@@ -460,15 +521,17 @@ size_t eprecon_unique_workspace_bytes(int64_t n)
 
 static int unique_coords_impl(const int32_t *coords, int64_t n, const int32_t *n_dev, int quantum, void *table,
                               uint32_t capacity, int32_t *inverse, int32_t *unique_coords, int32_t *n_unique_dev,
-                              void *workspace, size_t workspace_bytes, void *stream)
+                              void *workspace, size_t workspace_bytes, void *stream, bool cleared = false,
+                              int32_t *status_copy = nullptr)
 {
     if (!n_unique_dev || !workspace || workspace_bytes < eprecon_unique_workspace_bytes(n))
         return n_unique_dev && workspace ? EPRECON_ERR_WORKSPACE : EPRECON_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    int rc = hash_build_impl(coords, n, n_dev, quantum, table, capacity, stream);
+    int rc = hash_build_impl(coords, n, n_dev, quantum, table, capacity, stream, cleared);
     if (rc != EPRECON_OK) return rc;
     if (n == 0) {
         EP_HIP_CHECK(hipMemsetAsync(n_unique_dev, 0, sizeof(int32_t), st));
+        if (status_copy) EP_HIP_CHECK(hipMemsetAsync(status_copy, 0, sizeof(int32_t), st));
         return EPRECON_OK;
     }
     if (!inverse || !unique_coords) return EPRECON_ERR_ARG;
@@ -487,10 +550,26 @@ static int unique_coords_impl(const int32_t *coords, int64_t n, const int32_t *n
     if (rc != EPRECON_OK) return rc;
     const int64_t span = n > (int64_t)capacity ? n : (int64_t)capacity;
     hipLaunchKernelGGL(unique_finalize_kernel, dim3((unsigned)ceil_div(span, 256)), block, 0, st, t, c4, (int)n, quantum, owner, rank,
-                       inverse, reinterpret_cast<int4 *>(unique_coords), n_dev, capacity);
+                       inverse, reinterpret_cast<int4 *>(unique_coords), n_dev, capacity, (const int32_t *)table_status(table),
+                       status_copy);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }
+
+}  // extern "C"
+
+namespace ep {
+int unique_coords_dn(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, int quantum, void *table, uint32_t capacity,
+                     int32_t *inverse, int32_t *unique_coords, int32_t *n_unique_dev, void *workspace, size_t workspace_bytes,
+                     bool table_cleared, int32_t *status_copy, void *stream)
+{
+    if (!n_dev) return EPRECON_ERR_ARG;
+    return unique_coords_impl(coords, n_cap, n_dev, quantum, table, capacity, inverse, unique_coords, n_unique_dev, workspace,
+                              workspace_bytes, stream, table_cleared, status_copy);
+}
+}  // namespace ep
+
+extern "C" {
 
 int eprecon_unique_coords_async(const int32_t *coords, int64_t n, int quantum, void *table,
                                 uint32_t capacity, int32_t *inverse, int32_t *unique_coords,
@@ -508,6 +587,30 @@ int eprecon_unique_coords_dn_async(const int32_t *coords, int64_t n_cap, const i
     if (!n_dev) return EPRECON_ERR_ARG;
     return unique_coords_impl(coords, n_cap, n_dev, quantum, table, capacity, inverse, unique_coords, n_unique_dev, workspace,
                               workspace_bytes, stream);
+}
+
+int eprecon_unique_hierarchy_dn_async(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, int levels, void *const *tables,
+                                      const uint32_t *capacities, int32_t *const *inverse, int32_t *const *unique_coords,
+                                      void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (levels < 1 || levels > 3 || !tables || !capacities || !inverse || !unique_coords || n_cap < 0) return EPRECON_ERR_ARG;
+    ep::FillRegion reg[9];
+    for (int l = 0; l < levels; ++l) {
+        const int rc = ep::table_clear_regions(tables[l], capacities[l], reg + 3 * l);
+        if (rc != EPRECON_OK) return rc;
+    }
+    int rc = ep::multi_fill(reg, 3 * levels, (hipStream_t)stream);     // ONE launch resets the tables of all strides
+    if (rc != EPRECON_OK) return rc;
+    const int32_t *src = coords, *live = n_dev;
+    for (int l = 0; l < levels; ++l) {
+        int32_t *count = reinterpret_cast<int32_t *>(tables[l]) + 1;       // next to the table's status word: one 8-byte read per stride
+        rc = unique_coords_impl(src, n_cap, live, 1 << l, tables[l], capacities[l], inverse[l], unique_coords[l], count, workspace,
+                                workspace_bytes, stream, true, nullptr);
+        if (rc != EPRECON_OK) return rc;
+        src = unique_coords[l];
+        live = count;
+    }
+    return EPRECON_OK;
 }
 
 int eprecon_kernel_map_async(const void *table, uint32_t capacity, const int32_t *coords, int64_t n,

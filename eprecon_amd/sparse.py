@@ -99,6 +99,27 @@ def unique_coords_queued(coords, quantum=1, n_dev=None):
     return uniq, inverse, grid
 
 
+def unique_hierarchy_queued(coords, levels=3, n_dev=None):
+    """unique_coords_queued for the strides 1, 2, 4, ... of one point cloud in ONE library call (the tables of all strides are
+    reset by one launch; level l numbers the unique rows of level l - 1 at quantum 2^l, its count taken from the device):
+    -> (uniqs, inverses, grids), each a list over the levels; the counts / status words sit in grids[l].header"""
+    lib = _lib.load()
+    coords = coords.contiguous()
+    n, dev = coords.shape[0], coords.device
+    grids = [HashGrid(n, dev) for _ in range(levels)]
+    invs = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(levels)]
+    uniqs = [torch.empty((n, 4), dtype=torch.int32, device=dev) for _ in range(levels)]
+    ws = _lib.workspace(lib.eprecon_unique_workspace_bytes(n), dev)
+    vp = ctypes.c_void_p * levels
+    tables = vp(*[g.mem.data_ptr() for g in grids])
+    caps = (ctypes.c_uint32 * levels)(*[g.capacity for g in grids])
+    inv_p, uniq_p = vp(*[t.data_ptr() for t in invs]), vp(*[t.data_ptr() for t in uniqs])
+    _lib.check(lib.eprecon_unique_hierarchy_dn_async(_lib.ptr(coords), n, _lib.ptr(n_dev), levels, tables, caps, inv_p, uniq_p,
+                                                     _lib.ptr(ws), ws.numel(), _lib.current_stream()),
+               "eprecon_unique_hierarchy_dn_async")
+    return uniqs, invs, grids
+
+
 def unique_coords(coords, quantum=1):
     """-> (unique int32[M,4] in first-occurrence order, inverse int32[N], HashGrid mapping key -> id).
     One host sync to learn M (the reference's torch.unique syncs as well)."""
@@ -200,12 +221,7 @@ def voxel_hierarchy(vox, levels=3, points=None):
     trilinear corner tables of strides 1 and 4, the strided maps, the three kernel maps — is queued by ONE library call
     behind the read (eprecon_spvcnn_geometry_async) -> (VoxelSet, inverse, tables)."""
     n = vox.shape[0]
-    grids, uniqs, invs = [], [], []
-    src, n_dev = vox, None
-    for lvl in range(levels):
-        u, inv, g = unique_coords_queued(src, quantum=2 ** lvl, n_dev=n_dev)
-        grids.append(g); uniqs.append(u); invs.append(inv)
-        src, n_dev = u, g.header[1:2]
+    uniqs, invs, grids = unique_hierarchy_queued(vox, levels)
     host = _lib.read_counts(torch.cat([g.header for g in grids]))
     sizes = []
     for lvl in range(levels):

@@ -202,12 +202,7 @@ class SpvcnnPrefetch:
             _lib.ptr(src_coords), cap_src, _lib.ptr(n_src_dev), int(bool(children)), int(interval), _lib.ptr(origin), origin.shape[0],
             float(voxel_size), _lib.ptr(w2ac), self.res, _lib.ptr(self.up), _lib.ptr(self.r), _lib.ptr(self.scaled),
             _lib.ptr(self.vox), _lib.ptr(self.n_pts), _lib.current_stream()), "eprecon_spvcnn_points_dn_async")
-        self.grids, self.uniqs, self.invs = [], [], []
-        src, n_dev = self.vox, self.n_pts
-        for lvl in range(3):
-            u, inv, g = SP.unique_coords_queued(src, quantum=2 ** lvl, n_dev=n_dev)
-            self.grids.append(g); self.uniqs.append(u); self.invs.append(inv)
-            src, n_dev = u, g.header[1:2]
+        self.uniqs, self.invs, self.grids = SP.unique_hierarchy_queued(self.vox, 3, n_dev=self.n_pts)
         self._keep = (src_coords, n_src_dev, origin, w2ac)
 
     def headers(self):
