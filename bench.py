@@ -393,6 +393,8 @@ def bench_cfg4(args, step, world, rank, dist, use_dist=False):
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    from eprecon_amd import _lib as L
+    reads0 = L.HOST_READS
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step.run()
@@ -418,6 +420,7 @@ def bench_cfg4(args, step, world, rank, dist, use_dist=False):
                           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": step.describe(),
                           "last_fragment_voxels": n_out,
+                          "blocking_reads_per_fragment": (L.HOST_READS - reads0) / args.steps,
                           "finest_voxels_min_max": [min(step.voxels), max(step.voxels)]}), flush=True)
     if use_dist:
         dist.destroy_process_group()
