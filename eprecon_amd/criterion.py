@@ -65,11 +65,12 @@ def dice_loss(inputs, targets, num_masks):
 
 def sigmoid_ce_loss(inputs, targets, num_masks):
     """per matched mask: class-balanced BCE (pos_weight = #neg / #pos clamped to 30) averaged over its voxels; mean over masks"""
-    per_mask = []
-    for b in range(targets.shape[0]):
-        w = torch.clamp(compute_pos_weight(targets[b]), max=MAX_MASK_POS_WEIGHT)
-        per_mask.append(F.binary_cross_entropy_with_logits(inputs[b], targets[b], pos_weight=w))
-    return sum(per_mask) / len(per_mask)
+    # (one pass over the [T, N] block with a per-row weight instead of a Python loop of T reductions: the same means)
+    flat_t = targets.flatten(1)
+    n_pos = flat_t.sum(1)
+    w = torch.clamp((flat_t.shape[1] - n_pos).float() / n_pos, max=MAX_MASK_POS_WEIGHT)
+    per_mask = F.binary_cross_entropy_with_logits(inputs.flatten(1), flat_t, pos_weight=w[:, None], reduction="none").mean(1)
+    return per_mask.sum() / per_mask.shape[0]
 
 
 class HungarianMatcher(nn.Module):
@@ -80,6 +81,33 @@ class HungarianMatcher(nn.Module):
         super().__init__()
         assert cost_class != 0 or cost_mask != 0 or cost_dice != 0
         self.cost_class, self.cost_mask, self.cost_dice = cost_class, cost_mask, cost_dice
+
+    @torch.no_grad()
+    def forward_many(self, heads, targets):
+        """forward() for several prediction heads over the SAME targets (the decoder's final output and its auxiliary
+        layers, models/criterion.py:269-283): the cost matrices of all heads from batched products and ONE device -> host
+        transfer instead of one per head; the assignments themselves stay scipy's, one per head -> [forward(h, targets) ...]"""
+        n_heads = len(heads)
+        costs = []
+        for b in range(heads[0]["pred_logits"].shape[0]):
+            prob = torch.stack([h["pred_logits"][b] for h in heads]).softmax(-1)            # [H, Q, K + 1]
+            c_class = -prob[:, :, targets[b]["labels"]]
+            logits = torch.stack([h["pred_masks"][b] for h in heads]).float()               # [H, Q, N]
+            gt = targets[b]["masks"].to(logits)
+            n_vox = logits.shape[2]
+            pos = F.binary_cross_entropy_with_logits(logits, torch.ones_like(logits), reduction="none")
+            neg = F.binary_cross_entropy_with_logits(logits, torch.zeros_like(logits), reduction="none")
+            c_mask = (pos @ gt.t() + neg @ (1 - gt).t()) / n_vox
+            p = logits.sigmoid()
+            c_dice = 1 - (2 * p @ gt.t() + 1) / (p.sum(-1)[..., None] + gt.sum(-1)[None, None, :] + 1)
+            costs.append(self.cost_mask * c_mask + self.cost_class * c_class + self.cost_dice * c_dice)
+        host = [c.cpu() for c in costs] if len(costs) > 1 else [costs[0].cpu()]
+        out = [[] for _ in range(n_heads)]
+        for cost in host:
+            for h in range(n_heads):
+                i, j = linear_sum_assignment(cost[h].reshape(cost.shape[1], -1))
+                out[h].append((torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)))
+        return out
 
     @torch.no_grad()
     def forward(self, outputs, targets):
@@ -160,14 +188,19 @@ class SetCriterion(nn.Module):
         if not self._filter_targets(outputs, targets):
             return {"loss_dice": outputs["pred_logits"].sum() * 0.0}
         main = {k: v for k, v in outputs.items() if k != "aux_outputs"}
-        indices = self.matcher(main, targets)
+        aux_list = list(outputs.get("aux_outputs", []))
+        if hasattr(self.matcher, "forward_many"):     # all heads matched behind one device -> host transfer
+            matched = self.matcher.forward_many([main] + aux_list, targets)
+        else:
+            matched = [self.matcher(h, targets) for h in [main] + aux_list]
+        indices = matched[0]
         num_masks = float(max(sum(len(t["labels"]) for t in targets), 1))
         fns = {"labels": self.loss_labels, "masks": self.loss_masks}
         losses = {}
         for name in self.losses:
             losses.update(fns[name](outputs, targets, indices, num_masks))
-        for i, aux in enumerate(outputs.get("aux_outputs", [])):
-            idx = self.matcher(aux, targets)
+        for i, aux in enumerate(aux_list):
+            idx = matched[1 + i]
             for name in self.losses:
                 losses.update({f"{k}_{i}": v for k, v in fns[name](aux, targets, idx, num_masks).items()})
         return losses
