@@ -130,6 +130,8 @@ SIGNATURES = {
     "eprecon_profile_conv_ms": (_f, [_c.POINTER(_i64), _c.POINTER(_c.c_char_p)]),
     "eprecon_profile_conv_pairs": (_i64, []),
     "eprecon_mlp4x_supported": (_i, [_i, _i]),
+    "eprecon_spvcnn_forward_workspace_bytes": (_sz, [_vp]),
+    "eprecon_spvcnn_forward_async": (_i, [_vp, _vp]),
     "eprecon_spvcnn_geometry_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "eprecon_spvcnn_geometry_async": (_i, [_vp, _vp]),
     "eprecon_gru_stage_finish_workspace_bytes": (_sz, [_i64, _i64, _i64]),
@@ -290,6 +292,29 @@ class SpvcnnGeometryDesc(ctypes.Structure):
                 + [("workspace_bytes", ctypes.c_size_t)])
 
 
+SPVCNN_CONVS = 27
+
+
+class SpvcnnConv(ctypes.Structure):
+    """include/eprecon_hip.h: eprecon_spvcnn_conv"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("weight", "packed_weight", "packed_weight16")] + [(n, ctypes.c_int) for n in ("kvol", "cin", "cout")]
+
+
+class SpvcnnBn(ctypes.Structure):
+    """include/eprecon_hip.h: eprecon_spvcnn_bn"""
+    _fields_ = [("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("eps", ctypes.c_float)]
+
+
+class SpvcnnForwardDesc(ctypes.Structure):
+    """include/eprecon_hip.h: eprecon_spvcnn_forward_desc"""
+    _fields_ = ([(n, ctypes.c_int64) for n in ("n", "n1", "n2", "n4")] + [("cin", ctypes.c_int), ("cs", ctypes.c_int * 5)]
+                + [("feat", ctypes.c_void_p), ("ld_feat", ctypes.c_int)]
+                + [(n, ctypes.c_void_p) for n in ("offsets1", "order1", "offsets4", "order4", "k1", "k2", "k4", "down12", "up21", "down24",
+                                                  "up42", "idx8_1", "weight8_1", "idx8_4", "weight8_4")]
+                + [("conv", SpvcnnConv * SPVCNN_CONVS), ("bn", SpvcnnBn * SPVCNN_CONVS)]
+                + [("out", ctypes.c_void_p), ("ld_out", ctypes.c_int), ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t)])
+
+
 class Mlp4xHead(ctypes.Structure):
     """include/eprecon_hip.h: eprecon_mlp4x_head"""
     _fields_ = ([(n, ctypes.c_void_p) for n in ("w1", "b1", "g1", "be1", "w2", "b2", "g2", "be2", "w3", "b3", "y")]
@@ -369,6 +394,28 @@ def verify_deferred(items, host_values):
             raise EpreconError(f"{what}: expected {expected}, the device reports {int(got)} (EPRECON_ERR_ARG)")
 
 
+# EPRECON_PINNED_READS=0: the blocking reads go through Tensor.tolist() (a synchronous hipMemcpy into pageable memory: staging
+# copy + stream synchronisation inside the runtime).  Default: an asynchronous copy into a pinned buffer of the calling thread
+# and a busy-wait on the event behind it — the host resumes a few microseconds after the copy lands, and the GPU gets the
+# launches that depend on the counts that much earlier (10 reads per fragment).
+_PINNED_READS = os.environ.get("EPRECON_PINNED_READS", "1") == "1"
+_PINNED = __import__("threading").local()
+
+
+def _to_host(flat):
+    if not (_PINNED_READS and flat.is_cuda and flat.dtype == torch.int32 and flat.numel() <= 256):
+        return flat.tolist()
+    buf = getattr(_PINNED, "buf", None)
+    if buf is None:
+        buf = _PINNED.buf = torch.empty(256, dtype=torch.int32, pin_memory=True)
+        _PINNED.event = torch.cuda.Event()          # (default flags: synchronize() spins instead of sleeping)
+    n = flat.numel()
+    buf[:n].copy_(flat, non_blocking=True)
+    _PINNED.event.record()
+    _PINNED.event.synchronize()
+    return buf[:n].tolist()
+
+
 def read_counts(counts):
     """THE blocking device -> host read of the package: `counts` (an int32 device tensor) as a flat Python list.  The pending
     deferred checks of the current stream ride along in the same transfer and are verified before the counts are returned."""
@@ -376,10 +423,10 @@ def read_counts(counts):
     pending = take_deferred()
     flat = counts.reshape(-1)
     if pending:
-        host = torch.cat([flat] + [t.reshape(1).to(flat.dtype) for t, *_ in pending]).tolist()
+        host = _to_host(torch.cat([flat] + [t.reshape(1).to(flat.dtype) for t, *_ in pending]))
         verify_deferred(pending, host[flat.numel():])
         return host[:flat.numel()]
-    return flat.tolist()
+    return _to_host(flat)
 
 
 class PinnedRead:

@@ -848,6 +848,44 @@ size_t eprecon_gru_stage_finish_workspace_bytes(int64_t n, int64_t m1, int64_t m
 int eprecon_gru_stage_finish_async(const eprecon_gru_finish_desc *desc, void *stream);
 
 /*
+ * The BODY of one SPVCNN pass as ONE stream-ordered call (models/modules.py:148-175: stem, two k2s2 stages with residual
+ * blocks :46-72, two transposed stages with skip concatenation, three scatter-means and three trilinear devoxelisations
+ * ops/torchsparse_utils.py:40-105, two point MLPs models/modules.py:125-136; every BatchNorm in train mode, main.py:357).
+ * Replaces ~115 calls issued one by one from the host: 27 x eprecon_conv_desc_async, eprecon_batchnorm_finalize_affine_async,
+ * eprecon_batchnorm_apply_partials[_res]_async, eprecon_segment_mean_async, eprecon_devoxelize_async — the same entry points,
+ * descriptors and order, issued from inside the library (bit-identical results).  The geometry comes from
+ * eprecon_spvcnn_geometry_async.  conv[] / bn[] slots, in launch order:
+ *    0 stem | 1 stage1 down, 2-4 res (conv, conv, 1x1 skip), 5-6 res | 7 stage2 down, 8-10 res, 11-12 res | 13 point MLP 0 |
+ *   14 up1 transposed, 15-17 res, 18-19 res | 20 up2 transposed, 21-23 res, 24-25 res | 26 point MLP 1
+ * weight f32[kvol][cin][cout] (kvol 27: x-fastest offsets, 8: z-fastest, 1: a [cin][cout] matrix); packed_weight (kvol 27) and
+ * packed_weight16 (kvol 27 or 1, cout <= 64) are the operand-order copies of eprecon_conv_pack_weight[16]_async.
+ * cs[5]: the channel plan (32, 64, 128, 96, 96) x cr.  feat f32[n, cin] point features, out f32[n, cs[4]].
+ * workspace: eprecon_spvcnn_forward_workspace_bytes(desc) bytes, 256-byte aligned (every intermediate of the pass).
+ */
+#define EPRECON_SPVCNN_CONVS 27
+typedef struct eprecon_spvcnn_conv {
+    const float *weight; const float *packed_weight; const float *packed_weight16;
+    int kvol; int cin; int cout;
+} eprecon_spvcnn_conv;
+typedef struct eprecon_spvcnn_bn {
+    const float *gamma; const float *beta; float eps;
+} eprecon_spvcnn_bn;
+typedef struct eprecon_spvcnn_forward_desc {
+    int64_t n, n1, n2, n4;
+    int cin; int cs[5];
+    const float *feat; int ld_feat;
+    const int32_t *offsets1, *order1, *offsets4, *order4;
+    const int32_t *k1, *k2, *k4, *down12, *up21, *down24, *up42;
+    const int32_t *idx8_1; const float *weight8_1; const int32_t *idx8_4; const float *weight8_4;
+    eprecon_spvcnn_conv conv[EPRECON_SPVCNN_CONVS];
+    eprecon_spvcnn_bn bn[EPRECON_SPVCNN_CONVS];
+    float *out; int ld_out;
+    void *workspace; size_t workspace_bytes;
+} eprecon_spvcnn_forward_desc;
+size_t eprecon_spvcnn_forward_workspace_bytes(const eprecon_spvcnn_forward_desc *desc);
+int eprecon_spvcnn_forward_async(const eprecon_spvcnn_forward_desc *desc, void *stream);
+
+/*
  * The geometry of one SPVCNN pass after its host read (the sizes n1, n2, n4 of the voxel sets at tensor strides 1, 2, 4, numbered
  * by three queued eprecon_unique_coords(_dn)_async calls), in one call (csrc/spvcnn_geometry.hip): CSR point lists of strides 1
  * and 4 (offsets int32[m+1], order int32[n]; idx4 int32[n] = the stride-4 voxel of every point), the k2s2 maps down12 int32[8][n2],

@@ -91,7 +91,9 @@ def test_operators_refuse_cpu_tensors():
 @pytest.mark.parametrize("c_name,py_name", [("eprecon_conv_desc", "ConvDesc"), ("eprecon_gru_stage_desc", "GruStageDesc"),
                                             ("eprecon_decoder_layer_desc", "DecoderLayerDesc"),
                                             ("eprecon_mlp4x_head", "Mlp4xHead"), ("eprecon_mlp4x_desc", "Mlp4xDesc"),
-                                            ("eprecon_gru_finish_desc", "GruFinishDesc"), ("eprecon_spvcnn_geometry_desc", "SpvcnnGeometryDesc")])
+                                            ("eprecon_gru_finish_desc", "GruFinishDesc"), ("eprecon_spvcnn_geometry_desc", "SpvcnnGeometryDesc"),
+                                            ("eprecon_spvcnn_conv", "SpvcnnConv"), ("eprecon_spvcnn_bn", "SpvcnnBn"),
+                                            ("eprecon_spvcnn_forward_desc", "SpvcnnForwardDesc")])
 def test_struct_layouts_match_header(tmp_path, c_name, py_name):
     """the ctypes mirrors of the descriptor structs have the size and field offsets the C compiler gives the header's
     structs (a drift here would silently corrupt every launch that goes through them)"""

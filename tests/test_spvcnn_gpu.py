@@ -91,6 +91,15 @@ def test_spvcnn_matches_oracle(stage, cin, n):
             if p.dim() == 1:
                 p.add_(torch.randn_like(p) * 0.1)
         out = net(PointTensor(dev(feat), dev(pts))).cpu().numpy()
+        # the pass issued by ONE library call (default) and launch by launch from Python: the same launches, bit for bit
+        import eprecon_amd.modules as M
+        assert M._NATIVE_SPVCNN and net._native[1] is not None
+        M._NATIVE_SPVCNN = False
+        try:
+            py = net(PointTensor(dev(feat), dev(pts))).cpu().numpy()
+        finally:
+            M._NATIVE_SPVCNN = True
+        assert np.array_equal(out, py)
     ref = ON.spvcnn_forward(_sd(net), feat, pts, 1, vres)
     assert out.shape == ref.shape == (len(pts), int(96 * cr))
     err = np.abs(out - ref).max()

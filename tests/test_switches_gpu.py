@@ -109,6 +109,14 @@ def test_prefetch_off(scene, default_run, monkeypatch):
     assert 3 * n <= (r2 - r1) - (r1 - r0) <= 4 * n, ((r1 - r0) / n, (r2 - r1) / n)
 
 
+def test_spvcnn_issued_from_python(scene, default_run, monkeypatch):
+    """EPRECON_SPVCNN_NATIVE=0: the body of every SPVCNN pass issued launch by launch from Python instead of by one library call
+    (eprecon_spvcnn_forward_async): the same entry points with the same descriptors in the same order — bit-identical"""
+    import eprecon_amd.modules as M
+    monkeypatch.setattr(M, "_NATIVE_SPVCNN", False)
+    assert_same_scene(default_run, run_scene(scene), exact=True)
+
+
 def test_gru_one_stream(scene, default_run, monkeypatch):
     """EPRECON_GRU_STREAMS=0: the two ConvGRUs of a level on one stream"""
     monkeypatch.setattr(scene.net.gru_fusion, "two_streams", False)
