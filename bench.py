@@ -37,7 +37,27 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured streaming ceiling)
 F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, f32 in / f32 accumulate
 DOMINANT_KERNEL = "bp_gather_mlp_kernel<256,MEAN,6,1>"
-L1_PEAK_LINES = 256 * 2.4e9  # vector-L1 line accesses per second: 256 CUs x 1 line per clock x 2.4 GHz
+L1_PEAK_LINES = 256 * 2.4e9  # nominal: 256 CUs x one 64-byte segment per clock x 2.4 GHz (used only when no probe file is committed)
+
+
+def l1_peak_from_probe():
+    """The vector-L1 segment rate the roofline's `l1` record is measured against: CALIBRATED by tools/probes/l1_line_rate.hip on
+    the gather's own access shape (16-byte loads, six lanes per 96-byte texel, L1-resident table), read from the newest committed
+    profiles/rNN/l1_line_rate.txt -> (segments per second, source)."""
+    import re
+    path = newest_profile("l1_line_rate.txt")
+    if path:
+        text = open(path).read()
+        m = re.search(r"# PMC-calibrated peak \(mode 0, L1-resident\): ([0-9.]+) G accesses/s = ([0-9.]+) per clock per CU", text)
+        if m:   # the probe's rate counted by the same counter as the gather's accesses (TCP_TOTAL_CACHE_ACCESSES)
+            return float(m.group(1)) * 1e9, (f"{os.path.relpath(path, ROOT)}: probe mode 0 (96-byte texels, 6 lanes each, L1-resident), "
+                                             f"TCP_TOTAL_CACHE_ACCESSES per second = {m.group(1)} G/s = {m.group(2)} per clock per CU")
+        block = text.split("## L1-resident")[1].split("##")[0] if "## L1-resident" in text else ""
+        m = re.search(r"mode 0:.*?([0-9.]+) G segments/s = ([0-9.]+) per clk per CU", block)
+        if m:
+            return float(m.group(1)) * 1e9, (f"{os.path.relpath(path, ROOT)}: mode 0 (96-byte texels, 6 lanes each, L1-resident) "
+                                             f"{m.group(1)} G segments/s = {m.group(2)} per clock per CU")
+    return L1_PEAK_LINES, "nominal 256 CUs x 1 segment / clk x 2.4 GHz (no committed probe output found)"
 
 
 # The cfg4 workloads time the drop-in contract: every fragment complete when forward() returns.  The pipelined serving mode
@@ -542,8 +562,9 @@ def main():
                     # what actually limits this gather: vector-L1 line accesses per launch (PMC,
                     # TCP_TOTAL_CACHE_ACCESSES) against 256 CUs x 1 line / clk x 2.4 GHz
                     rate = rec["l1_accesses"] / (gm * 1e-3)
+                    peak, peak_src = l1_peak_from_probe()
                     l1 = {"line_accesses": rec["l1_accesses"], "achieved_glines_per_s": rate / 1e9,
-                          "peak_glines_per_s": L1_PEAK_LINES / 1e9, "frac": rate / L1_PEAK_LINES}
+                          "peak_glines_per_s": peak / 1e9, "frac": rate / peak, "peak_source": peak_src}
             else:
                 traffic_src = f"{os.path.relpath(pmc, ROOT)} measured {rec.get('kernel')!r}, not this kernel: traffic withheld"
         roof = {"bound": "hbm", "kernel": DOMINANT_KERNEL + " (dense 96^3, C=24, 120x160)",

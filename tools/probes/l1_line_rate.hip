@@ -70,8 +70,49 @@ static void run(const char *name, const char *table, size_t footprint, int segs_
            instr * useful_bytes_per_instr / s / 1e12);
 }
 
-int main()
+// ---- FETCH_SIZE calibration (`l1_line_rate calib` under rocprofv3 --pmc FETCH_SIZE): two launches whose HBM-side fetch is known ----
+// stream: every wave instruction reads its own contiguous 1 KB exactly once (1 GiB in total): fetch = 1 GiB;
+// gather: the gather's access shape — six lanes x 16 bytes per 96-byte texel — over a 1.5 GiB table, every texel visited exactly
+// once in a scrambled order (an odd multiplier is a bijection on 2^24 indices): no reuse inside an L1 or an XCD's 4 MB L2, so
+// every 128-byte line a texel touches is fetched: texels at byte offsets 0, 96, 64, 32 (mod 128) span 1, 2, 2, 1 lines ->
+// 1.5 lines = 192 bytes fetched per 96-byte texel when nothing is retained, 128 when a line's second toucher still finds it.
+__global__ __launch_bounds__(256) void calib_stream_kernel(const char *table, float *sink)
 {
+    const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(table + wave * 1024 + (threadIdx.x & 63) * 16);
+    if (v.x == 123.456f) sink[0] = v.y;
+}
+__global__ __launch_bounds__(240) void calib_gather_kernel(const char *table, unsigned log2_texels, float *sink)
+{
+    const unsigned g = blockIdx.x * 40u + threadIdx.x / 6u;             // one texel per 6-lane group, 40 groups per workgroup
+    const unsigned texel = (g * 2654435761u) & ((1u << log2_texels) - 1u);
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(table + (size_t)texel * 96 + (threadIdx.x % 6u) * 16);
+    if (v.x == 123.456f) sink[0] = v.y;
+}
+
+static int calibrate()
+{
+    const unsigned log2_texels = 24;
+    const size_t gather_bytes = ((size_t)1 << log2_texels) * 96, stream_bytes = (size_t)1 << 30;
+    char *table;
+    float *sink;
+    hipMalloc(&table, gather_bytes);
+    hipMalloc(&sink, 64);
+    hipMemset(table, 0, gather_bytes);
+    hipDeviceSynchronize();
+    hipLaunchKernelGGL(calib_stream_kernel, dim3((unsigned)(stream_bytes / 1024 / 4)), dim3(256), 0, 0, table, sink);
+    hipLaunchKernelGGL(calib_gather_kernel, dim3((1u << log2_texels) / 40u), dim3(240), 0, 0, table, log2_texels, sink);
+    hipDeviceSynchronize();
+    printf("# calibration launches: calib_stream_kernel reads %zu bytes once; calib_gather_kernel reads %u texels of 96 bytes once "
+           "(%zu bytes useful, %zu bytes of distinct 128-byte lines, %zu if every texel re-fetches the lines it spans)\n",
+           stream_bytes, ((1u << log2_texels) / 40u) * 40u, (size_t)((1u << log2_texels) / 40u) * 40u * 96, gather_bytes,
+           (size_t)((1u << log2_texels) / 40u) * 40u * 192);
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1 && argv[1][0] == 'c') return calibrate();
     const size_t big = 9ull * 120 * 160 * 24 * 4 + 4096;      // 16.6 MB: the maps of the timed level
     char *table;
     float *sink;
