@@ -65,6 +65,7 @@ struct BpParams {
     uint8_t *out_mask;
     int32_t *n_valid_dev;  // [1 + B]
     int32_t *block_offsets;
+    int xcd_slabs;  // 1 (default): every XCD walks one contiguous range of tiles (ep::xcd_remap); 0: tile = hardware block id
 };
 
 struct Proj {
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256) void bp_gather_kernel(BpParams p)
     int *sWave = sOut + VOX;                                             // [BLOCK/64]
 
     const int tid = threadIdx.x;
-    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int lb = p.xcd_slabs ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     stage_matrices(sP, p.krcam, p.V * p.batch, tid, BLOCK);
     __syncthreads();
 
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(256) void bp_gather_mlp_kernel(BpParams p)
     int *sWave = sOut + VOX;                                              // [BLOCK/64]
 
     const int tid = threadIdx.x;
-    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int lb = p.xcd_slabs ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     stage_matrices(sP, p.krcam, p.V * p.batch, tid, BLOCK);
     if (VPT > 1 && tid < VOX) sVis[tid] = 0;
     __syncthreads();
@@ -1014,6 +1015,11 @@ int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *or
     p.min_view = min_view; p.out_feats = out_feats; p.out_mean = out_mean; p.out_coords = out_coords;
     p.count = count; p.out_grid = out_grid; p.out_mask = out_mask; p.n_valid_dev = n_valid_dev;
     p.block_offsets = block_sums;
+    {   // EPRECON_BP_XCD_SLABS=0 (read per call): the gather's tiles in hardware block order — round-robin over the eight XCDs, so
+        // every XCD's L2 sees tiles from the whole volume — instead of one contiguous slab of the raster per XCD.  Same results.
+        const char *e = getenv("EPRECON_BP_XCD_SLABS");
+        p.xcd_slabs = (e && e[0] == '0') ? 0 : 1;
+    }
 
     // Tile = voxels handed to one 256-thread workgroup of the gather kernel.  Short lists get
     // small tiles so that the launch still covers the 256 CUs with several waves each

@@ -66,6 +66,18 @@ def test_channels_last_input_gives_identical_result(gold):
     assert torch.equal(f_cl.contiguous(), _dev(feats))
 
 
+@pytest.mark.parametrize("name", ["cfg1_l0", "cfg2_l1"])
+def test_tile_order_switch_gives_identical_result(gold, name, monkeypatch):
+    """EPRECON_BP_XCD_SLABS=0 (tiles in hardware block order instead of one contiguous slab of the raster per XCD: the A/B of
+    DESIGN.md 3a's fetch amplification) changes where a tile runs, not what it computes"""
+    window, coords, origin, feats, kr = bp_inputs(gold[name + "_meta"])
+    a = hip_run(coords, origin, window["voxel_size"], feats, kr, 2, 0)
+    monkeypatch.setenv("EPRECON_BP_XCD_SLABS", "0")
+    b = hip_run(coords, origin, window["voxel_size"], feats, kr, 2, 0)
+    assert a["n_valid"] == b["n_valid"] and torch.equal(a["coords"], b["coords"]) and torch.equal(a["feats"], b["feats"])
+    assert torch.equal(a["count"], b["count"])
+
+
 @pytest.mark.parametrize("name", ["cfg1_l0", "cfg1b2_l1"])
 def test_depth_channel(gold, name):
     from eprecon_amd.back_project import back_project

@@ -18,6 +18,23 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_RE
 done
 cd $R
 python tools/summarize_profiles.py $O $P r05_final 35 | head -16
+# 1b. the gather's tile order: one contiguous slab of the raster per XCD (default) against tiles in hardware
+#     block order — launch time by HIP events and HBM-side fetch (raw FETCH_SIZE, KiB) of the dense 96^3 launch
+{
+  echo "# bp_gather_mlp_kernel<256,MEAN,6,1> on the dense 96^3 level: EPRECON_BP_XCD_SLABS=1 (default: XCD k walks tiles [k n/8, (k+1) n/8), i.e. an x-slab of the raster) vs 0 (tile = hardware block id)"
+  for v in 1 0; do
+    EPRECON_BP_XCD_SLABS=$v python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra 2>/dev/null | python -c "
+import json,sys; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('slabs=$v  gather', round(d['roofline']['avg_launch_ms']*1e3,1), 'us  step', round(d['ms_per_step'],3), 'ms')"
+    ( cd /tmp; EPRECON_BP_XCD_SLABS=$v rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_order$v -o r -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $O/pmc_order$v.log 2>&1 )
+    python - <<PY
+import csv, glob
+v = [float(r["Counter_Value"]) for r in csv.DictReader(open(glob.glob("$O/pmc_order$v/**/*counter_collection.csv", recursive=True)[0]))
+     if "bp_gather_mlp_kernel<256" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
+print(f"slabs=$v  FETCH_SIZE raw {sum(v) / len(v):.0f} KiB per launch (n={len(v)}) -> x2 gfx950 correction {2 * sum(v) / len(v) * 1024 / 1e6:.1f} MB")
+PY
+    rm -f $O/pmc_order$v/r_kernel_trace.csv $O/pmc_order$v/*/r_kernel_trace.csv
+  done
+} > $P/bp_tile_order_ab.txt 2>&1
 # 2. cfg4 (whole NeuConNet.forward, unpipelined = the drop-in contract): bench line, kernel statistics, launches / fragment
 cd /tmp
 EPRECON_CFG4_PIPELINE=0 python $R/bench.py --workload cfg4 --steps 32 --warmup 8 > $O/bench_cfg4.json 2> $O/bench_cfg4.err
