@@ -48,7 +48,8 @@ for v in "default A=1" "python_spvcnn EPRECON_SPVCNN_NATIVE=0" "no_prefetch EPRE
   set -- $v; name=$1; shift
   env "$@" EPRECON_CFG4_PIPELINE=0 python bench.py --workload cfg4 --steps 32 --warmup 8 2>/dev/null | python -c "
 import json,sys; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$name', '$*', round(d['ms_per_step'],3), 'ms/fragment', d['blocking_reads_per_fragment'], 'blocking reads')"
-done > $P/cfg4_switches_ab.txt 2>&1
+done > $P/cfg4_switches_separate_runs.txt 2>&1
+python tools/ab_cfg4.py 12 > $P/cfg4_switches_ab.txt 2>/dev/null
 # 3. stage times (sync around every stage)
 python tools/profile_cfg4_stages.py 3 > $P/cfg4_stage_times.txt 2>&1
 python tools/profile_cfg2_stages.py > $P/cfg2_stage_times.txt 2>&1
