@@ -42,9 +42,8 @@ EPRECON_CFG4_PIPELINE=0 rocprofv3 --kernel-trace --stats --output-format csv -d 
 cd $R
 python tools/summarize_cfg4.py $O/stats_cfg4 $P $O/bench_cfg4.json > /dev/null
 rm -f $O/stats_cfg4/r_kernel_trace.csv
-# the switches of this round one by one (same box, same process layout): what each bought
-for v in "default A=1" "python_spvcnn EPRECON_SPVCNN_NATIVE=0" "no_prefetch EPRECON_PREFETCH=0" \
-         "round4_like EPRECON_SPVCNN_NATIVE=0 EPRECON_PREFETCH=0" "default_again A=1"; do
+# the switches of this round: separate runs (drift between runs of ONE build is visible here), then interleaved in one process
+for v in "default A=1" "round4_like EPRECON_SPVCNN_NATIVE=0 EPRECON_PREFETCH=0" "default_again A=1"; do
   set -- $v; name=$1; shift
   env "$@" EPRECON_CFG4_PIPELINE=0 python bench.py --workload cfg4 --steps 32 --warmup 8 2>/dev/null | python -c "
 import json,sys; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$name', '$*', round(d['ms_per_step'],3), 'ms/fragment', d['blocking_reads_per_fragment'], 'blocking reads')"
