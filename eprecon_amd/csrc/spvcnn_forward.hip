@@ -7,6 +7,8 @@
 // calls the same entry points in the same order, so the results are bit-identical to the Python-issued pass
 // (tests/test_spvcnn_gpu.py, tests/test_switches_gpu.py).  Intermediates live in a caller-provided arena whose size
 // eprecon_spvcnn_forward_workspace_bytes computes by walking the same sequence without launching.
+#include <vector>
+
 #include "common.hpp"
 
 namespace {
@@ -42,17 +44,68 @@ struct Pass {
     size_t used, cap;
     int rc;
 
+    // First-fit allocator over the arena with explicit release: a buffer is handed back as soon as its last consumer is queued
+    // (every launch of the pass goes to ONE stream, so a later launch that re-uses the bytes is ordered behind it).  Without the
+    // re-use every intermediate of the pass had its own cold address range — ~4x the footprint of the Python-issued pass, whose
+    // tensors the caching allocator recycles — and the call measured 0.1 ms per fragment SLOWER than the launches it replaces
+    // (profiles/r05/cfg4_switches_ab.txt, first collection).  The dry run replays the same sequence: `peak` is the arena size.
+    struct Block { size_t off, bytes; };
+    std::vector<Block> free_list, live;
+    size_t peak = 0;
+    static constexpr uintptr_t kFakeBase = 0x100000;
+
     void *alloc(size_t bytes)
     {
-        const size_t off = align_up(used, 256);
-        used = off + bytes;
-        if (dry) return reinterpret_cast<void *>(0x1000 + off);     // (never dereferenced)
-        if (used > cap) {
+        bytes = align_up(bytes > 0 ? bytes : 1, 256);
+        size_t off = (size_t)-1;
+        for (size_t i = 0; i < free_list.size(); ++i)
+            if (free_list[i].bytes >= bytes) {
+                off = free_list[i].off;
+                if (free_list[i].bytes == bytes) free_list.erase(free_list.begin() + i);
+                else { free_list[i].off += bytes; free_list[i].bytes -= bytes; }
+                break;
+            }
+        if (off == (size_t)-1) {
+            off = used;
+            used += bytes;
+            if (used > peak) peak = used;
+        }
+        live.push_back(Block{off, bytes});
+        if (dry) return reinterpret_cast<void *>(kFakeBase + off);     // (never dereferenced)
+        if (off + bytes > cap) {
             if (rc == EPRECON_OK) rc = EPRECON_ERR_WORKSPACE;
             return nullptr;
         }
         return base + off;
     }
+    void release(const void *p)
+    {
+        if (!p) return;
+        const size_t off = dry ? (size_t)(reinterpret_cast<uintptr_t>(p) - kFakeBase) : (size_t)(static_cast<const char *>(p) - base);
+        for (size_t i = 0; i < live.size(); ++i)
+            if (live[i].off == off) {
+                Block b = live[i];
+                live.erase(live.begin() + i);
+                // insert sorted by offset and merge with the neighbours
+                size_t k = 0;
+                while (k < free_list.size() && free_list[k].off < b.off) ++k;
+                free_list.insert(free_list.begin() + k, b);
+                if (k + 1 < free_list.size() && free_list[k].off + free_list[k].bytes == free_list[k + 1].off) {
+                    free_list[k].bytes += free_list[k + 1].bytes;
+                    free_list.erase(free_list.begin() + k + 1);
+                }
+                if (k > 0 && free_list[k - 1].off + free_list[k - 1].bytes == free_list[k].off) {
+                    free_list[k - 1].bytes += free_list[k].bytes;
+                    free_list.erase(free_list.begin() + k);
+                }
+                if (!free_list.empty() && free_list.back().off + free_list.back().bytes == used) {   // the top of the arena: give it back
+                    used = free_list.back().off;
+                    free_list.pop_back();
+                }
+                return;
+            }
+    }
+    void release(const Rows &r) { release(r.p); }
     Rows rows(int64_t n, int c, int ld = 0)
     {
         if (ld == 0) ld = (c + 3) & ~3;      // row pitch rounded up to 4 floats (16-byte gathers), as _segment_mean does
@@ -95,6 +148,7 @@ struct Pass {
         c.bn_partial = partial;
         *n_partial = rows_p;
         if (!dry && ok() && n_out > 0) step(eprecon_conv_desc_async(&c, stream));
+        if (need) release(c.workspace);
         return partial;
     }
     // sparse.bn_affine: summaries -> (scale, shift)
@@ -113,6 +167,7 @@ struct Pass {
         const int c = d->conv[s].cout;
         const size_t wsb = eprecon_batchnorm_apply_workspace_bytes(c);
         void *ws = alloc(wsb);
+        struct Done { Pass *p; void *ws; ~Done() { p->release(ws); } } done{this, ws};
         if (dry || !ok()) return;
         if (res_aff)
             step(eprecon_batchnorm_apply_partials_res_async(x.p, x.n, c, x.ld, partial, rows_p, d->bn[s].gamma, d->bn[s].beta,
@@ -126,10 +181,11 @@ struct Pass {
     // BasicConvolutionBlock / BasicDeconvolutionBlock / the stem / a point MLP: conv -> BatchNorm -> ReLU (in place)
     Rows basic(int s, const Rows &x, const int32_t *nbr, int64_t n_out, const Rows *out_slot)
     {
-        const Rows y = out_slot ? *out_slot : rows(n_out, d->conv[s].cout);
+        const Rows y = out_slot ? *out_slot : rows(n_out, d->conv[s].cout, d->conv[s].cout);
         int64_t rp = 0;
         const float *p = conv(s, x, nbr, n_out, y, nullptr, nullptr, &rp);
         apply(s, y, p, rp, nullptr, nullptr, y);
+        release(p);
         return y;
     }
     // ResidualBlock: ReLU( [conv-BN-ReLU-conv-BN](x) + [x | conv1x1-BN](x) ); a = first conv, a + 1 = second, a + 2 = the 1x1 skip
@@ -137,20 +193,29 @@ struct Pass {
     {
         const int64_t n = x.n;
         int64_t rp1 = 0, rp2 = 0, rps = 0;
-        const Rows y = rows(n, d->conv[a].cout);
+        // (the block's output first: what is allocated behind it are temporaries, handed back as the block goes)
+        const Rows y2 = rows(n, d->conv[a + 1].cout, d->conv[a + 1].cout);
+        const Rows out = out_slot ? *out_slot : y2;
+        const Rows y = rows(n, d->conv[a].cout, d->conv[a].cout);
         const float *p1 = conv(a, x, nbr, n, y, nullptr, nullptr, &rp1);
         const float *aff = affine(a, p1, rp1);
-        const Rows y2 = rows(n, d->conv[a + 1].cout);
+        release(p1);
         const float *p2 = conv(a + 1, y, nbr, n, y2, aff, aff + d->conv[a].cout, &rp2);
-        const Rows out = out_slot ? *out_slot : y2;
+        release(y);
+        release(aff);
         if (!has_skip) {
             apply(a + 1, y2, p2, rp2, &x, nullptr, out);
-            return out;
+        } else {
+            const Rows skip = rows(n, d->conv[a + 2].cout, d->conv[a + 2].cout);
+            const float *ps = conv(a + 2, x, nullptr, n, skip, nullptr, nullptr, &rps);
+            const float *saff = affine(a + 2, ps, rps);
+            release(ps);
+            apply(a + 1, y2, p2, rp2, &skip, saff, out);
+            release(skip);
+            release(saff);
         }
-        const Rows skip = rows(n, d->conv[a + 2].cout);
-        const float *ps = conv(a + 2, x, nullptr, n, skip, nullptr, nullptr, &rps);
-        const float *saff = affine(a + 2, ps, rps);
-        apply(a + 1, y2, p2, rp2, &skip, saff, out);
+        release(p2);
+        if (out_slot) release(y2);
         return out;
     }
     void seg_mean(const Rows &feat, const int32_t *offsets, const int32_t *order, const Rows &out)
@@ -170,42 +235,58 @@ struct Pass {
         const int *cs = D.cs;
         const int64_t n = D.n, n1 = D.n1, n2 = D.n2, n4 = D.n4;
         const Rows zf{const_cast<float *>(D.feat), n, D.cin, D.ld_feat};
+        // concat buffers: the skip branches are written in place (torchsparse.cat for free)
+        const Rows cat0 = rows(n1, cs[4] + cs[0], cs[4] + cs[0]), cat1 = rows(n2, cs[3] + cs[1], cs[3] + cs[1]);
         // x0 = initial_voxelize(z): scatter-mean of the point features into the stride-1 voxels
         const Rows x0 = rows(n1, D.cin);
         seg_mean(zf, D.offsets1, D.order1, x0);
-        // concat buffers: the skip branches are written in place (torchsparse.cat for free)
-        const Rows cat0 = rows(n1, cs[4] + cs[0], cs[4] + cs[0]), cat1 = rows(n2, cs[3] + cs[1], cs[3] + cs[1]);
         const Rows f0_slot = slice(cat0, cs[4], cs[0]);
         const Rows f0 = basic(kStem, x0, D.k1, n1, &f0_slot);
+        release(x0);
         const Rows z0 = rows(n, cs[0], cs[0]);
         devox(f0, D.idx8_1, D.weight8_1, z0, 0);
         const Rows x1 = rows(n1, cs[0]);
         seg_mean(z0, D.offsets1, D.order1, x1);
         Rows f = basic(kS1Down, x1, D.down12, n2, nullptr);
-        f = residual(kS1R1a, true, f, D.k2, nullptr);
+        release(x1);
+        Rows g = residual(kS1R1a, true, f, D.k2, nullptr);
+        release(f);
         const Rows f1_slot = slice(cat1, cs[3], cs[1]);
-        const Rows f1 = residual(kS1R2a, false, f, D.k2, &f1_slot);
+        const Rows f1 = residual(kS1R2a, false, g, D.k2, &f1_slot);
+        release(g);
         f = basic(kS2Down, f1, D.down24, n4, nullptr);
-        f = residual(kS2R1a, true, f, D.k4, nullptr);
-        const Rows f2 = residual(kS2R2a, false, f, D.k4, nullptr);
+        g = residual(kS2R1a, true, f, D.k4, nullptr);
+        release(f);
+        const Rows f2 = residual(kS2R2a, false, g, D.k4, nullptr);
+        release(g);
         // z1 = voxel_to_point(x2, z0) + MLP0(z0.F)
         const Rows z1 = rows(n, cs[2], cs[2]);
         basic(kMlp0, z0, nullptr, n, &z1);
+        release(z0);
         devox(f2, D.idx8_4, D.weight8_4, z1, 1);
+        release(f2);
         const Rows y3 = rows(n4, cs[2]);
         seg_mean(z1, D.offsets4, D.order4, y3);
         const Rows u1_slot = slice(cat1, 0, cs[3]);
         basic(kU1Up, y3, D.up42, n2, &u1_slot);
+        release(y3);
         f = residual(kU1R1a, true, cat1, D.k2, nullptr);
-        f = residual(kU1R2a, false, f, D.k2, nullptr);
+        release(cat1);
+        g = residual(kU1R2a, false, f, D.k2, nullptr);
+        release(f);
         const Rows u2_slot = slice(cat0, 0, cs[4]);
-        basic(kU2Up, f, D.up21, n1, &u2_slot);
+        basic(kU2Up, g, D.up21, n1, &u2_slot);
+        release(g);
         f = residual(kU2R1a, true, cat0, D.k1, nullptr);
-        f = residual(kU2R2a, false, f, D.k1, nullptr);
+        release(cat0);
+        g = residual(kU2R2a, false, f, D.k1, nullptr);
+        release(f);
         // z3 = voxel_to_point(y4, z1) + MLP1(z1.F) -> the caller's output rows
         const Rows out{D.out, n, cs[4], D.ld_out};
         basic(kMlp1, z1, nullptr, n, &out);
-        devox(f, D.idx8_1, D.weight8_1, out, 1);
+        release(z1);
+        devox(g, D.idx8_1, D.weight8_1, out, 1);
+        release(g);
         return rc;
     }
 };
@@ -237,9 +318,10 @@ extern "C" {
 size_t eprecon_spvcnn_forward_workspace_bytes(const eprecon_spvcnn_forward_desc *d)
 {
     if (check_desc(d) != EPRECON_OK) return 0;
-    Pass p{d, nullptr, true, nullptr, 0, 0, EPRECON_OK};
+    Pass p{};
+    p.d = d; p.dry = true; p.rc = EPRECON_OK;
     p.run();
-    return align_up(p.used, 256) + 256;
+    return align_up(p.peak, 256) + 256;
 }
 
 int eprecon_spvcnn_forward_async(const eprecon_spvcnn_forward_desc *d, void *stream)
@@ -250,7 +332,8 @@ int eprecon_spvcnn_forward_async(const eprecon_spvcnn_forward_desc *d, void *str
         !d->k1 || !d->k2 || !d->k4 || !d->down12 || !d->up21 || !d->down24 || !d->up42 || !d->idx8_1 || !d->weight8_1 || !d->idx8_4 ||
         !d->weight8_4 || (reinterpret_cast<uintptr_t>(d->workspace) & 255))
         return EPRECON_ERR_ARG;
-    Pass p{d, stream, false, static_cast<char *>(d->workspace), 0, d->workspace_bytes, EPRECON_OK};
+    Pass p{};
+    p.d = d; p.stream = stream; p.base = static_cast<char *>(d->workspace); p.cap = d->workspace_bytes; p.rc = EPRECON_OK;
     return p.run();
 }
 

@@ -685,6 +685,10 @@ class SPVCNN(nn.Module):
         z3 = voxel_to_point(SparseTensor(f, s1), z1, out=self.point_transforms[1].run(z1.F), accumulate=True)
         return z3.F
 
+    def _apply(self, fn, *args, **kwargs):
+        self._native_params = self._native = None      # .to() / .cuda() may replace the parameter objects
+        return super()._apply(fn, *args, **kwargs)
+
     def _native_slots(self):
         """(conv modules, BatchNorm modules) in the slot order of eprecon_spvcnn_forward_desc"""
         convs, bns = [], []
@@ -711,7 +715,9 @@ class SPVCNN(nn.Module):
         """the static part of eprecon_spvcnn_forward_desc (weights, their operand-order packings, BatchNorm parameters), built
         once per parameter version"""
         from . import _lib
-        params = list(self.parameters())
+        params = getattr(self, "_native_params", None)
+        if params is None:      # (walking the module tree costs ~0.25 ms per call: once)
+            params = self._native_params = list(self.parameters())
         key = (device, tuple((p_._version, p_.data_ptr()) for p_ in params))
         hit = getattr(self, "_native", None)
         if hit is not None and hit[0] == key:
