@@ -58,8 +58,13 @@ def test_driver_defaults(monkeypatch):
 def test_headline_roofline_recomputes_from_the_committed_profiles():
     """the bench line's `roofline` against profiles/rNN: algorithmic bytes / the rocprofv3 average of the same kernel, and the
     PMC traffic from the raw counters with the guide's gfx950 correction (FETCH_SIZE x2, KiB)"""
+    import glob
     import json
-    line = json.load(open(bench.newest_profile("bench_cfg2_r04_final.json")))
+    # the newest round that committed the driver's line, its rocprofv3 summary and its PMC record together
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "bench_cfg2_r*_final.json")))
+    assert lines and int(re.search(r"profiles/r(\d+)/", lines[-1]).group(1)) >= 4
+    rdir, tag = os.path.dirname(lines[-1]), re.search(r"bench_cfg2_(r\d+_final)\.json", lines[-1]).group(1)
+    line = json.load(open(lines[-1]))
     roof = line["roofline"]
     assert line["metric"] and line["n_gpus"] == 1 and line["dtype"] == "f32" and line["vs_baseline"] is None
     assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"]) and roof["peak"] == bench.HBM_PEAK_GBS
@@ -67,14 +72,16 @@ def test_headline_roofline_recomputes_from_the_committed_profiles():
     # 16 N + 4 V C H W + n_valid (4 C + 16) at N = 96^3, V = 9, C = 24, 120 x 160, every voxel valid
     n = 96 ** 3
     assert roof["algorithmic_bytes"] == 16 * n + 4 * 9 * 24 * 120 * 160 + n * (4 * 24 + 16)
-    summary = open(bench.newest_profile("bench_cfg2_r04_final_rocprof_summary.txt")).read()
+    summary = open(os.path.join(rdir, f"bench_cfg2_{tag}_rocprof_summary.txt")).read()
     avg_us = float(re.search(r"bp_gather_mlp_kernel<256, 0, 6, 1>.*?\| \d+ \| [0-9.]+ \| [0-9.]+ \| ([0-9.]+) \|", summary).group(1))
     assert abs(avg_us - roof["avg_launch_ms"] * 1e3) / avg_us < 0.05     # HIP events in bench.py vs rocprofv3's average
-    pmc = json.load(open(bench.newest_profile("pmc_traffic_bp_gather.json")))
+    pmc = json.load(open(os.path.join(rdir, "pmc_traffic_bp_gather.json")))
     fetch = float(re.search(r"bp_gather_mlp_kernel<256, 0, 6, 1> \| grid \d+ \| FETCH_SIZE \| ([0-9.]+)", summary).group(1))
     assert pmc["fetch_size_kib_raw"] == pytest.approx(fetch, rel=1e-4)
     assert pmc["traffic_bytes"] == pytest.approx(2 * pmc["fetch_size_kib_raw"] * 1024 + pmc["write_size_kib"] * 1024)
     assert os.path.exists(os.path.join(ROOT, pmc["source"]))
+    # (the line quotes the newest PMC record committed BEFORE it ran: the previous round's when the round's own passes are collected
+    # by the same script behind it — the two collections agree)
     assert roof["traffic"] == pytest.approx(pmc["traffic_bytes"], rel=0.02)
     cpu = line["cpu_baseline"]
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
