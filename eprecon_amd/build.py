@@ -12,8 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libeprecon_hip.so")
-# --offload-compress: the gfx950 code objects are stored zstd-compressed in the fat binary (7.6 -> 2.x MB; rocPRIM's radix sort
-# alone is 2.3 MB uncompressed) and unpacked by the HIP runtime at load
+# --offload-compress: the gfx950 code objects are stored zstd-compressed in the fat binary (5.3 -> 1.4 MB since round 5, when the
+# last library kernel — rocPRIM's radix sort, 2.3 MB uncompressed — left csrc/hash_order.hip) and unpacked by the HIP runtime at load
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "--offload-compress"]
 

@@ -119,7 +119,7 @@ def test_sphash_order_matches_oracle():
     _lib.check(lib.eprecon_sphash_async(_lib.ptr(ct), len(c), _lib.ptr(h), _lib.current_stream()), "sphash")
     ref = PV.sphash(c)
     assert np.array_equal(h.cpu().numpy(), ref) and (ref >= 0).all() and len(np.unique(ref)) == len(ref)
-    # the whole order in one call (hash + rocPRIM radix sort + inverse permutation) == argsort of the oracle's hashes
+    # the whole order in one call (hash + bucket sort + inverse permutation, csrc/hash_order.hip) == argsort of the oracle's hashes
     perm = torch.empty(len(c), dtype=torch.int32, device="cuda")
     rank = torch.empty(len(c), dtype=torch.int32, device="cuda")
     ws = torch.empty(lib.eprecon_sphash_order_workspace_bytes(len(c)), dtype=torch.uint8, device="cuda")
@@ -128,6 +128,28 @@ def test_sphash_order_matches_oracle():
     order = np.argsort(ref, kind="stable")
     assert np.array_equal(perm.cpu().numpy(), order)
     assert np.array_equal(rank.cpu().numpy()[order], np.arange(len(c)))
+
+
+@pytest.mark.parametrize("n", [1, 7, 130, 4097, 70000, 400000])
+def test_sphash_order_at_every_bucket_count(n):
+    """the bucket sort of csrc/hash_order.hip from one voxel to more voxels than its 32768 buckets x 8; rows repeated on purpose
+    (equal hashes: the order between them is the row order, as a stable sort gives)"""
+    from eprecon_amd import _lib
+    rng = np.random.default_rng(n)
+    c = np.concatenate([np.zeros((n, 1), np.int64), rng.integers(-3000, 3000, (n, 3))], 1).astype(np.int32)
+    if n > 100:
+        c[n // 2:n // 2 + 50] = c[:50]          # duplicates -> ties
+    lib = _lib.load()
+    ct = dev(c)
+    perm = torch.empty(n, dtype=torch.int32, device="cuda")
+    rank = torch.empty(n, dtype=torch.int32, device="cuda")
+    ws = torch.empty(lib.eprecon_sphash_order_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    for _ in range(2):      # (twice through the same workspace: the call clears what it counts in)
+        _lib.check(lib.eprecon_sphash_order_async(_lib.ptr(ct), n, _lib.ptr(perm), _lib.ptr(rank), _lib.ptr(ws), ws.numel(),
+                                                  _lib.current_stream()), "sphash_order")
+    order = np.argsort(PV.sphash(c), kind="stable")
+    assert np.array_equal(perm.cpu().numpy(), order)
+    assert np.array_equal(rank.cpu().numpy()[order], np.arange(n))
 
 
 @pytest.mark.parametrize("literal", [True, False])
