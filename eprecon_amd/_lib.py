@@ -36,7 +36,7 @@ SIGNATURES = {
     "eprecon_unique_workspace_bytes": (_sz, [_i64]),
     "eprecon_unique_coords_async": (_i, [_vp, _i64, _i, _vp, _c.c_uint32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "eprecon_unique_coords_dn_async": (_i, [_vp, _i64, _vp, _i, _vp, _c.c_uint32, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "eprecon_unique_hierarchy_dn_async": (_i, [_vp, _i64, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "eprecon_unique_hierarchy_dn_async": (_i, [_vp, _i64, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "eprecon_point_quantize_dn_async": (_i, [_vp, _i64, _vp, _f, _vp, _vp, _vp]),
     "eprecon_spvcnn_points_dn_async": (_i, [_vp, _i64, _vp, _i, _i, _vp, _i, _f, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eprecon_gru_stage_capacity": (_i64, [_vp, _i64, _i]),

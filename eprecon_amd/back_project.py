@@ -67,11 +67,12 @@ class PendingBackProject:
 
 
 def run_async(coords, origin, voxel_size, feats, krcam, min_view, mode=MODE_MEAN, min_valid_per_batch=1,
-              want_grid=False, want_mean=False, hold_read=False):
+              want_grid=False, want_mean=False, hold_read=False, extra_words=0):
     """Queue the back-projection on the current stream and return a PendingBackProject.
     hold_read: no host copy of the counts is queued — the caller reads `.n_valid_dev` itself, together with whatever else it
     queued on the device count `.n_valid_dev[0:1]` of the compacted rows `.coords_all` (torchsparse_utils.SpvcnnPrefetch), and
-    hands the values to result_from()."""
+    hands the values to result_from().  extra_words: `.n_valid_dev` gets that many more int32 behind the 1 + B counts (the caller's
+    own counts, so that one tensor is read)."""
     lib = _lib.load()
     dev = feats.device
     if dev.type != "cuda":
@@ -92,7 +93,7 @@ def run_async(coords, origin, voxel_size, feats, krcam, min_view, mode=MODE_MEAN
          "mean": torch.empty((n, c), dtype=torch.float32, device=dev) if want_mean else None,
          "grid": torch.empty((v * n * 2,), dtype=torch.float32, device=dev) if want_grid else None,
          "mask": torch.empty((v * n,), dtype=torch.uint8, device=dev) if want_grid else None}
-    n_valid_dev = torch.empty((1 + b,), dtype=torch.int32, device=dev)
+    n_valid_dev = torch.empty((1 + b + int(extra_words),), dtype=torch.int32, device=dev)
     ws_bytes = lib.eprecon_back_project_workspace_bytes(n, b, v, c, h, w, layout)
     ws = _lib.workspace(ws_bytes, dev)
     rc = lib.eprecon_back_project_async(
@@ -101,7 +102,7 @@ def run_async(coords, origin, voxel_size, feats, krcam, min_view, mode=MODE_MEAN
         _lib.ptr(t["coords"]), _lib.ptr(t["count"]), _lib.ptr(t["grid"]), _lib.ptr(t["mask"]),
         _lib.ptr(n_valid_dev), _lib.ptr(ws), ws.numel(), _lib.current_stream())
     _lib.check(rc, "eprecon_back_project_async")
-    read = None if hold_read else _lib.PinnedRead(n_valid_dev)
+    read = None if hold_read else _lib.PinnedRead(n_valid_dev[:1 + b])
     # inputs stay referenced until result(): the kernels may still be reading them
     t["_keep"] = (coords_i, origin_f, krcam_f, feats_c, n_valid_dev)
     pend = PendingBackProject(t, n, v, c, b, int(min_valid_per_batch), read, want_grid, want_mean)
@@ -213,13 +214,13 @@ class Back_Project(nn.Module):
 
 def forward_behind(module, coords, origin, voxel_size, feats, KRcam, min_view_number, behind):
     """Back_Project.forward with more work queued on the DEVICE count of its valid rows in front of the one host read:
-    behind(valid_coords int32[N,4] (first n_valid rows live), n_valid_dev int32[1]) -> (extra int32 device tensor,
-    finish(n_valid, host_extra)).  -> (what forward returns, finish(...)'s result | None).  Inference only."""
+    behind(valid_coords int32[N,4] (first n_valid rows live), n_valid_dev int32[1], extra_out int32[behind.n_extra]) ->
+    finish(n_valid, host_extra).  -> (what forward returns, finish(...)'s result | None).  Inference only."""
     pend = run_async(coords, origin, voxel_size, feats, KRcam, min_view_number, MODE_MEAN, want_grid=module.return_projection,
-                     hold_read=True)
-    extra, finish = behind(pend.coords_all, pend.n_valid_dev[0:1])
-    nb = pend.n_valid_dev.numel()
-    host = _lib.read_counts(torch.cat([pend.n_valid_dev, extra.reshape(-1)]))
+                     hold_read=True, extra_words=behind.n_extra)
+    nb = pend.n_valid_dev.numel() - behind.n_extra
+    finish = behind(pend.coords_all, pend.n_valid_dev[0:1], pend.n_valid_dev[nb:])
+    host = _lib.read_counts(pend.n_valid_dev)
     res = pend.result_from(host[:nb])
     if res is None:
         return None, None

@@ -589,9 +589,15 @@ int eprecon_unique_coords_dn_async(const int32_t *coords, int64_t n_cap, const i
                               workspace_bytes, stream);
 }
 
+__global__ void gather_headers_kernel(const int32_t *t0, const int32_t *t1, const int32_t *t2, int levels, int32_t *out)
+{
+    const int i = threadIdx.x;      // (status, count) of every level's table, side by side: ONE device -> host read later
+    if (i < 2 * levels) out[i] = (i < 2 ? t0 : i < 4 ? t1 : t2)[i & 1];
+}
+
 int eprecon_unique_hierarchy_dn_async(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, int levels, void *const *tables,
                                       const uint32_t *capacities, int32_t *const *inverse, int32_t *const *unique_coords,
-                                      void *workspace, size_t workspace_bytes, void *stream)
+                                      int32_t *summary, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (levels < 1 || levels > 3 || !tables || !capacities || !inverse || !unique_coords || n_cap < 0) return EPRECON_ERR_ARG;
     ep::FillRegion reg[9];
@@ -609,6 +615,11 @@ int eprecon_unique_hierarchy_dn_async(const int32_t *coords, int64_t n_cap, cons
         if (rc != EPRECON_OK) return rc;
         src = unique_coords[l];
         live = count;
+    }
+    if (summary) {
+        hipLaunchKernelGGL(gather_headers_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const int32_t *)tables[0],
+                           (const int32_t *)tables[levels > 1 ? 1 : 0], (const int32_t *)tables[levels > 2 ? 2 : 0], levels, summary);
+        EP_LAUNCH_CHECK();
     }
     return EPRECON_OK;
 }

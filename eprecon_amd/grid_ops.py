@@ -96,10 +96,10 @@ def sparsify(occ, threshold, target, coords, tsdf, feat_all, c_feat, batch_size,
     occ f32[N,1], target bool[N] | None, coords int32[N,4], tsdf f32[N,1], feat_all f32[N,C] ->
     (counts [kept, occupied per batch..., occupied & target per batch...], pre_coords, pre_tsdf [M,1], pre_occ [M,1],
     kept_all [M,C], pre_feat [M, c_feat + 2])
-    behind (optional): callable(kept_coords int32[N,4] (first M rows live), n_kept_dev int32[1]) -> (extra int32 device tensor,
-    finish(m, host_extra)): work queued on the DEVICE count of kept rows in front of the read (the next level's coordinate
-    side, torchsparse_utils.SpvcnnPrefetch; the panoptic pruning), whose own counts ride on this read; the call then
-    returns a 7-tuple whose last element is finish(...)'s result"""
+    behind (optional): callable(kept_coords int32[N,4] (first M rows live), n_kept_dev int32[1], extra_out int32[behind.n_extra])
+    -> finish(m, host_extra): work queued on the DEVICE count of kept rows in front of the read (the next level's coordinate
+    side, torchsparse_utils.SpvcnnPrefetch; the panoptic pruning), whose own counts — written into `extra_out`, the tail of this
+    call's counts buffer — ride on this read; the call then returns a 7-tuple whose last element is finish(...)'s result"""
     lib = _lib.load()
     n, c_all = feat_all.shape
     dev = feat_all.device
@@ -113,7 +113,8 @@ def sparsify(occ, threshold, target, coords, tsdf, feat_all, c_feat, batch_size,
     out_occ = torch.empty((n, 1), dtype=torch.float32, device=dev)
     out_all = torch.empty((n, c_all), dtype=torch.float32, device=dev)
     out_feat = torch.empty((n, c_feat + 2), dtype=torch.float32, device=dev)
-    counts = torch.empty(1 + 2 * batch_size, dtype=torch.int32, device=dev)
+    n_counts = 1 + 2 * batch_size
+    counts = torch.empty(n_counts + (behind.n_extra if behind is not None else 0), dtype=torch.int32, device=dev)
     ws = _lib.workspace(lib.eprecon_sparsify_workspace_bytes(n), dev)
     _lib.check(lib.eprecon_sparsify_async(
         _lib.ptr(occ), occ.stride(0), float(threshold), _lib.ptr(tgt), _lib.ptr(coords), _lib.ptr(tsdf), tsdf.stride(0),
@@ -121,11 +122,11 @@ def sparsify(occ, threshold, target, coords, tsdf, feat_all, c_feat, batch_size,
         _lib.ptr(out_occ), _lib.ptr(out_all), _lib.ptr(out_feat), _lib.ptr(counts), _lib.ptr(ws), ws.numel(),
         _lib.current_stream()), "eprecon_sparsify_async")
     if behind is not None:
-        extra, finish = behind(out_coords, counts[0:1])
-        host = _lib.read_counts(torch.cat([counts, extra.reshape(-1)]))
+        finish = behind(out_coords, counts[0:1], counts[n_counts:])
+        host = _lib.read_counts(counts)
         m = host[0]
-        return (host[:counts.numel()], out_coords[:m], out_tsdf[:m], out_occ[:m], out_all[:m], out_feat[:m],
-                finish(m, host[counts.numel():]))
+        return (host[:n_counts], out_coords[:m], out_tsdf[:m], out_occ[:m], out_all[:m], out_feat[:m],
+                finish(m, host[n_counts:]))
     host = _lib.read_counts(counts)     # (deferred checks ride on this read: back-projection without a read of its own)
     m = host[0]
     return host, out_coords[:m], out_tsdf[:m], out_occ[:m], out_all[:m], out_feat[:m]

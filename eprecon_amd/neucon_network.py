@@ -166,22 +166,24 @@ class NeuConNet(nn.Module):
         interval = 2 ** (self.n_scales - level)
         res = float(net.vres) / float(net.pres) if net.pres != 1 else float(net.vres)     # initial_voxelize's resolution
 
-        def behind(coords, n_dev):
+        def behind(coords, n_dev, extra_out):
             pf = SpvcnnPrefetch(coords, n_dev, children, interval, inputs["vol_origin_partial"], cfg.VOXEL_SIZE,
-                                inputs["world_to_aligned_camera"], res)
-            return pf.headers(), (lambda m, host: pf.finish(8 * m if children else m, host))
+                                inputs["world_to_aligned_camera"], res, summary=extra_out)
+            return lambda m, host: pf.finish(8 * m if children else m, host)
+        behind.n_extra = 6       # (status, unique count) of the three strided voxel sets
         return behind
 
     @staticmethod
     def _prune_behind(coords1, coords0):
         """the ancestor pruning of levels 1 and 0 (prune_to_ancestors) queued on the device count of the finest level's kept
         rows; finish -> (keep1, keep0, n1, n0)"""
-        def behind(fine, n_dev):
+        def behind(fine, n_dev, extra_out):
             dev = fine.device
             keep1 = SP.HashGrid(fine.shape[0], dev).build(fine, quantum=2, n_dev=n_dev).query(coords1.contiguous()) >= 0
             keep0 = SP.HashGrid(fine.shape[0], dev).build(fine, quantum=4, n_dev=n_dev).query(coords0.contiguous()) >= 0
-            sums = torch.stack([keep1.sum(), keep0.sum()]).to(torch.int32)
-            return sums, (lambda m, host: (keep1, keep0, int(host[0]), int(host[1])))
+            extra_out.copy_(torch.stack([keep1.sum(), keep0.sum()]))
+            return lambda m, host: (keep1, keep0, int(host[0]), int(host[1]))
+        behind.n_extra = 2       # the two kept-row counts
         return behind
 
     def forward(self, features, features_backbone2d_occ_pano, inputs, outputs, only_train_init=False,

@@ -99,10 +99,11 @@ def unique_coords_queued(coords, quantum=1, n_dev=None):
     return uniq, inverse, grid
 
 
-def unique_hierarchy_queued(coords, levels=3, n_dev=None):
+def unique_hierarchy_queued(coords, levels=3, n_dev=None, summary=None):
     """unique_coords_queued for the strides 1, 2, 4, ... of one point cloud in ONE library call (the tables of all strides are
     reset by one launch; level l numbers the unique rows of level l - 1 at quantum 2^l, its count taken from the device):
-    -> (uniqs, inverses, grids), each a list over the levels; the counts / status words sit in grids[l].header"""
+    -> (uniqs, inverses, grids), each a list over the levels; the counts / status words sit in grids[l].header and, side by
+    side, in `summary` (an int32[2 levels] device tensor of the caller's: what it reads back, no torch.cat of the headers)"""
     lib = _lib.load()
     coords = coords.contiguous()
     n, dev = coords.shape[0], coords.device
@@ -115,7 +116,7 @@ def unique_hierarchy_queued(coords, levels=3, n_dev=None):
     caps = (ctypes.c_uint32 * levels)(*[g.capacity for g in grids])
     inv_p, uniq_p = vp(*[t.data_ptr() for t in invs]), vp(*[t.data_ptr() for t in uniqs])
     _lib.check(lib.eprecon_unique_hierarchy_dn_async(_lib.ptr(coords), n, _lib.ptr(n_dev), levels, tables, caps, inv_p, uniq_p,
-                                                     _lib.ptr(ws), ws.numel(), _lib.current_stream()),
+                                                     _lib.ptr(summary), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
                "eprecon_unique_hierarchy_dn_async")
     return uniqs, invs, grids
 
@@ -221,8 +222,9 @@ def voxel_hierarchy(vox, levels=3, points=None):
     trilinear corner tables of strides 1 and 4, the strided maps, the three kernel maps — is queued by ONE library call
     behind the read (eprecon_spvcnn_geometry_async) -> (VoxelSet, inverse, tables)."""
     n = vox.shape[0]
-    uniqs, invs, grids = unique_hierarchy_queued(vox, levels)
-    host = _lib.read_counts(torch.cat([g.header for g in grids]))
+    summary = torch.empty(2 * levels, dtype=torch.int32, device=vox.device)
+    uniqs, invs, grids = unique_hierarchy_queued(vox, levels, summary=summary)
+    host = _lib.read_counts(summary)
     sizes = []
     for lvl in range(levels):
         check_hash_status(host[2 * lvl])

@@ -184,7 +184,9 @@ class SpvcnnPrefetch:
     voxelisation under the points tensor it returns, where SPVCNN.forward's initial_voxelize finds it: one blocking read per
     level less, bit-identical results (the same kernels' arithmetic on the same rows)."""
 
-    def __init__(self, src_coords, n_src_dev, children, interval, origin, voxel_size, world_to_aligned_camera, res):
+    def __init__(self, src_coords, n_src_dev, children, interval, origin, voxel_size, world_to_aligned_camera, res, summary=None):
+        """summary (optional): int32[6] device slice the six header words are written to (the tail of the compaction's own
+        counts buffer: one tensor to read, no torch.cat)"""
         lib = _lib.load()
         dev = src_coords.device
         assert src_coords.dtype == torch.int32 and src_coords.is_contiguous()
@@ -202,12 +204,13 @@ class SpvcnnPrefetch:
             _lib.ptr(src_coords), cap_src, _lib.ptr(n_src_dev), int(bool(children)), int(interval), _lib.ptr(origin), origin.shape[0],
             float(voxel_size), _lib.ptr(w2ac), self.res, _lib.ptr(self.up), _lib.ptr(self.r), _lib.ptr(self.scaled),
             _lib.ptr(self.vox), _lib.ptr(self.n_pts), _lib.current_stream()), "eprecon_spvcnn_points_dn_async")
-        self.uniqs, self.invs, self.grids = SP.unique_hierarchy_queued(self.vox, 3, n_dev=self.n_pts)
+        self.summary = summary if summary is not None else torch.empty(6, dtype=torch.int32, device=dev)
+        self.uniqs, self.invs, self.grids = SP.unique_hierarchy_queued(self.vox, 3, n_dev=self.n_pts, summary=self.summary)
         self._keep = (src_coords, n_src_dev, origin, w2ac)
 
     def headers(self):
         """int32[6]: (status word, unique count) of the three tables, to be read with the compaction's own counts"""
-        return torch.cat([g.header for g in self.grids])
+        return self.summary
 
     def finish(self, n_pts, host):
         """n_pts: live points (8 x kept rows, or the valid rows), host: the six header values -> (up_coords | None, r_coords):

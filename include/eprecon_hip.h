@@ -187,10 +187,11 @@ int eprecon_unique_coords_dn_async(const int32_t *coords, int64_t n_cap, const i
  * unique rows of level l - 1 (level 0: the first min(n_cap, *n_dev) rows of `coords`; n_dev NULL: all n_cap) at quantum 2^l into
  * tables[l] (capacities[l] slots, eprecon_hash_capacity(n_cap)), inverse[l] int32[n_cap], unique_coords[l] int32[n_cap,4]; the
  * count of level l is written next to its table's status word (int32 tables[l][1]).  The tables are reset by ONE launch.
+ * summary (optional, device int32[2 levels]): receives (status, count) of every level side by side — what the host reads.
  */
 int eprecon_unique_hierarchy_dn_async(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, int levels, void *const *tables,
                                       const uint32_t *capacities, int32_t *const *inverse, int32_t *const *unique_coords,
-                                      void *workspace, size_t workspace_bytes, void *stream);
+                                      int32_t *summary, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Kernel maps and sparse convolution  (K5, K10, K11, K13)
