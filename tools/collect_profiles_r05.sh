@@ -105,6 +105,9 @@ rocprofv3 --kernel-trace --output-format csv -d $O/busy -o r -- python $R/tools/
 cd $R
 python tools/gpu_busy_cfg4.py --summarize $(find $O/busy -name "*kernel_trace.csv" | head -1) > $P/cfg4_gpu_busy.txt
 rm -f $(find $O/busy -name "*kernel_trace.csv")
+# 7. per-stage / per-layer kernel accounting (stage markers + convolution log joined with the kernel trace; graphs off)
+bash tools/r04_layers.sh r05_layers > /dev/null 2>&1
+cp $R/gpurun_out/r05_layers/cfg4_layers.txt $P/cfg4_layers.txt
 # static: registers / LDS / scratch / waves per SIMD of every kernel, from the code objects' metadata (no GPU)
 python tools/kernel_resources.py > $P/kernel_resources.txt
 ls -la $P
