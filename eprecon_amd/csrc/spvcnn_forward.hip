@@ -1,12 +1,14 @@
 // The body of one SPVCNN pass (models/modules.py:148-175 with the blocks of :15-72 and the point <-> voxel transfers of
 // ops/torchsparse_utils.py:40-105) issued from ONE library call: 27 convolutions, their train-mode BatchNorms, 3 scatter-means
-// and 3 trilinear devoxelisations — ~115 launches that eprecon_amd/modules.py used to issue one by one from Python at ~15 us of
-// host time each.  On the two coarser levels of a fragment (1.3-1.4 ms of kernels against ~1.8 ms of Python) that stretch was
-// bound by the host's launch rate; from here a launch costs the host ~3 us.  Nothing new is computed: the call fills the same
-// descriptors with the same rules (eprecon_amd/sparse.py: conv_stats / _resolve_map, batchnorm_apply_partials, bn_affine) and
-// calls the same entry points in the same order, so the results are bit-identical to the Python-issued pass
-// (tests/test_spvcnn_gpu.py, tests/test_switches_gpu.py).  Intermediates live in a caller-provided arena whose size
-// eprecon_spvcnn_forward_workspace_bytes computes by walking the same sequence without launching.
+// and 3 trilinear devoxelisations — ~115 launches that eprecon_amd/modules.py otherwise issues one by one from Python at ~15 us
+// of host time each (here ~3 us).  Nothing new is computed: the call fills the same descriptors with the same rules
+// (eprecon_amd/sparse.py: conv_stats / _resolve_map, batchnorm_apply_partials, bn_affine) and calls the same entry points in the
+// same order, so the results are bit-identical to the Python-issued pass (tests/test_spvcnn_gpu.py, tests/test_switches_gpu.py).
+// What it buys (profiles/r05/cfg4_switches_ab_all.txt): the host runs ~1 ms per pass further ahead of the GPU; a
+// fragment that is bound by its kernels (12.8 of ~13.4 ms busy) does not get shorter by it — interleaved A/Bs put the call between
+// -0.01 and +0.10 ms per fragment against the Python-issued pass.
+// Intermediates live in a caller-provided arena whose size eprecon_spvcnn_forward_workspace_bytes computes by walking the same
+// sequence without launching; the arena is managed first-fit with explicit release (see Pass::alloc).
 #include <vector>
 
 #include "common.hpp"

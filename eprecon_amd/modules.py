@@ -632,7 +632,8 @@ class _PointMLP(nn.Sequential):
 
 # EPRECON_SPVCNN_NATIVE=0: the body of an SPVCNN pass issued launch by launch from Python (the round-4 path) instead of by ONE
 # library call (eprecon_spvcnn_forward_async, csrc/spvcnn_forward.hip): the same entry points, descriptors and order —
-# bit-identical results; ~115 launches whose host cost drops from ~15 us to ~3 us each
+# bit-identical results; ~115 launches whose host cost drops from ~15 us to ~3 us each (the host runs further ahead; the
+# GPU-bound fragment itself is not measurably shorter: DESIGN.md 7g)
 _NATIVE_SPVCNN = __import__("os").environ.get("EPRECON_SPVCNN_NATIVE", "1") == "1"
 
 
