@@ -44,6 +44,7 @@ SIGNATURES = {
     "eprecon_gru_stage_begin_async": (_i, [_vp, _vp]),
     "eprecon_gru_stage_commit_async": (_i, [_vp, _vp, _vp, _vp]),
     "eprecon_kernel_map_async": (_i, [_vp, _c.c_uint32, _vp, _i64, _i, _i, _vp, _vp]),
+    "eprecon_kernel_map_self_async": (_i, [_vp, _c.c_uint32, _vp, _i64, _i, _vp, _vp]),
     "eprecon_transpose_map_async": (_i, [_vp, _i64, _vp, _i, _vp, _vp]),
     "eprecon_sparse_conv_async": (_i, [_vp, _i64, _i, _vp, _i, _i64, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "eprecon_conv_bn_partial_bytes": (_sz, [_i64, _i]),

@@ -68,7 +68,7 @@ int exclusive_scan_i32_dn(const int32_t *in, int n, const int32_t *n_dev, int32_
 
 // Several device regions filled with a 32-bit pattern each in ONE launch (instead of a hipMemsetAsync / clear kernel per
 // region): the prologues of the stage calls clear a handful of index volumes, counters and hash tables of a few MB each, and
-// every launch they do not need is ~5 us of a fragment's chain.  Regions: 16-byte aligned, sizes multiples of 16 bytes.
+// every launch they do not need is ~5 us of a fragment's chain.  Regions: 4-byte aligned, sizes multiples of 4 bytes.
 struct FillRegion {
     void *p;
     size_t bytes;
@@ -78,6 +78,12 @@ constexpr int kMaxFillRegions = 12;
 int multi_fill(const FillRegion *regions, int count, hipStream_t st);
 // the three regions that reset an open-addressing table (header, keys = empty, values = int max): kernel_map.hip
 int table_clear_regions(void *table, uint32_t capacity, FillRegion *out3);
+
+// eprecon_kernel_map_self_async whose caller filled the map's upper half (offsets 14 .. 26) with -1 itself — the region
+// kernel_map_self_fill_region names, typically inside a multi_fill that resets other things too
+FillRegion kernel_map_self_fill_region(int32_t *nbr, int64_t n);
+int kernel_map_self_prefilled(const void *table, uint32_t capacity, const int32_t *coords, int64_t n, int stride, int32_t *nbr,
+                              void *stream);
 
 // eprecon_unique_coords_dn_async for callers inside the library: table_cleared = the caller reset the table itself (multi_fill);
 // status_copy (optional device int32): receives the table's status word from the call's last launch

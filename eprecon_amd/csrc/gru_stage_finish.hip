@@ -72,7 +72,7 @@ int eprecon_gru_stage_finish_async(const eprecon_gru_finish_desc *d, void *strea
     // ordered before the caller's later work either way, and the first error is what the call returns.
     auto second = [&]() -> int {  // ---- second voxelisation: side stream ----
         EP_STEP(eprecon_segment_lists_async(d->inverse2, d->n, d->m2, d->offsets2, d->order2, ws_b, half, side));
-        if (d->m2 > 0) EP_STEP(eprecon_kernel_map_async(d->table2, d->table_capacity, d->uniq2, d->m2, 3, 1, d->nbr2, side));
+        if (d->m2 > 0) EP_STEP(ep::kernel_map_self_prefilled(d->table2, d->table_capacity, d->uniq2, d->m2, 1, d->nbr2, side));
         if (d->literal)
             EP_STEP(eprecon_sphash_order_async(d->uniq2, d->m2, d->perm2, d->rank2, ws_b, half, side));
         else
@@ -81,11 +81,16 @@ int eprecon_gru_stage_finish_async(const eprecon_gru_finish_desc *d, void *strea
     };
     auto first = [&]() -> int {  // ---- first voxelisation: the caller's stream ----
         EP_STEP(eprecon_segment_lists_async(d->inverse1, d->n, d->m1, d->offsets1, d->order1, ws_a, half, stream));
-        if (d->m1 > 0) EP_STEP(eprecon_kernel_map_async(d->table1, d->table_capacity, d->uniq1, d->m1, 3, 1, d->nbr1, stream));
+        if (d->m1 > 0) EP_STEP(ep::kernel_map_self_prefilled(d->table1, d->table_capacity, d->uniq1, d->m1, 1, d->nbr1, stream));
         EP_STEP(eprecon_trilinear_map_async(d->table1, d->table_capacity, d->scaled1, d->n, 1, d->idx8_1, d->weight8_1, stream));
         if (d->literal) EP_STEP(eprecon_sphash_order_async(d->uniq1, d->m1, d->perm1, d->rank1, ws_a, half, stream));
         return EPRECON_OK;
     };
+    {   // the upper halves of the two self maps hold -1 before the mirrored entries are scattered into them: ONE launch, before the fork
+        ep::FillRegion reg[2] = {ep::kernel_map_self_fill_region(d->nbr1, d->m1), ep::kernel_map_self_fill_region(d->nbr2, d->m2)};
+        rc = ep::multi_fill(reg, 2, main);
+        if (rc != EPRECON_OK) return rc;
+    }
     EP_HIP_CHECK(hipEventRecord(f.ev_fork, main));
     EP_HIP_CHECK(hipStreamWaitEvent(f.side, f.ev_fork, 0));
     const int rc_second = second();

@@ -336,6 +336,25 @@ __global__ void kernel_map_kernel(HashTable t, const int4 *coords, int n, int ks
     nbr[(size_t)k * n + i] = key_in_range(c.x, x, y, z) ? hash_lookup(t, pack_key(c.x, x, y, z)) : -1;
 }
 
+// The same 3x3x3 map for a voxel set queried against ITS OWN table (row i of `coords` is the table's value for its key: the sets
+// the unique numbering produces): offset -o from voxel j leads to voxel i exactly when offset +o from i leads to j, so only the 13
+// offsets below the centre (and the centre) are looked up and every hit also fills the mirrored entry nbr[26 - k][j] = i.  The
+// upper half is pre-filled with -1 by the caller (hipMemsetAsync); a kernel map is injective per offset, so no two threads write
+// the same mirrored entry.  Half the hash probes of kernel_map_kernel (the probes, random reads of a table of tens of MB, are
+// what that kernel costs: 0.6 ms per cfg4 fragment), the same table bit for bit.
+__global__ void kernel_map_self_kernel(HashTable t, const int4 *coords, int n, int stride, int32_t *nbr)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;      // 0 .. 13
+    if (i >= n) return;
+    const int4 c = coords[i];
+    const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
+    const int x = c.y + dx * stride, y = c.z + dy * stride, z = c.w + dz * stride;
+    const int j = key_in_range(c.x, x, y, z) ? hash_lookup(t, pack_key(c.x, x, y, z)) : -1;
+    nbr[(size_t)k * n + i] = j;
+    if (k < 13 && j >= 0) nbr[(size_t)(26 - k) * n + j] = i;
+}
+
 // transposed k2s2 map: up[k][i] = parent row of fine voxel i when i is child k of its parent, else -1
 __global__ void transpose_map_kernel(const int4 *fine, int n, const int32_t *parent, int fine_stride,
                                      int32_t *up)
@@ -399,11 +418,14 @@ __global__ __launch_bounds__(256) void pixel_map_kernel(int maps, int h, int w, 
 namespace ep {
 namespace {
 struct FillParams {
-    uint4 *p[kMaxFillRegions];
-    unsigned long long end[kMaxFillRegions];   // exclusive prefix end, in 16-byte words
+    uint32_t *base[kMaxFillRegions];            // the region's start rounded DOWN to 16 bytes
+    unsigned long long end[kMaxFillRegions];    // exclusive prefix end, in 16-byte chunks
+    unsigned lead[kMaxFillRegions];             // 32-bit words of the first chunk in front of the region
+    unsigned long long words[kMaxFillRegions];  // the region's length in 32-bit words
     uint32_t value[kMaxFillRegions];
     int count;
 };
+// one thread per 16-byte chunk; chunks that straddle a region's first / last word write word by word
 __global__ __launch_bounds__(256) void multi_fill_kernel(FillParams f)
 {
     const unsigned long long e = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
@@ -412,7 +434,16 @@ __global__ __launch_bounds__(256) void multi_fill_kernel(FillParams f)
     for (int r = 0; r < f.count; ++r) {
         if (e < f.end[r]) {
             const uint32_t v = f.value[r];
-            f.p[r][e - begin] = make_uint4(v, v, v, v);
+            const unsigned long long w0 = (e - begin) * 4;                    // first word of the chunk, from the rounded-down base
+            const unsigned long long lo = f.lead[r], hi = f.lead[r] + f.words[r];
+            uint32_t *p = f.base[r] + w0;
+            if (w0 >= lo && w0 + 4 <= hi) {
+                *reinterpret_cast<uint4 *>(p) = make_uint4(v, v, v, v);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (w0 + k >= lo && w0 + k < hi) p[k] = v;
+            }
             return;
         }
         begin = f.end[r];
@@ -428,9 +459,14 @@ int multi_fill(const FillRegion *regions, int count, hipStream_t st)
     unsigned long long total = 0;
     for (int r = 0; r < count; ++r) {
         if (regions[r].bytes == 0) continue;
-        if (!regions[r].p || (reinterpret_cast<uintptr_t>(regions[r].p) & 15) || (regions[r].bytes & 15)) return EPRECON_ERR_ARG;
-        total += regions[r].bytes / 16;
-        f.p[f.count] = reinterpret_cast<uint4 *>(regions[r].p);
+        const uintptr_t a = reinterpret_cast<uintptr_t>(regions[r].p);
+        if (!regions[r].p || (a & 3) || (regions[r].bytes & 3)) return EPRECON_ERR_ARG;
+        const unsigned lead = (unsigned)((a & 15) / 4);
+        const unsigned long long words = regions[r].bytes / 4;
+        total += (lead + words + 3) / 4;
+        f.base[f.count] = reinterpret_cast<uint32_t *>(a & ~(uintptr_t)15);
+        f.lead[f.count] = lead;
+        f.words[f.count] = words;
         f.end[f.count] = total;
         f.value[f.count] = regions[r].value;
         ++f.count;
@@ -639,6 +675,49 @@ int eprecon_kernel_map_async(const void *table, uint32_t capacity, const int32_t
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }
+
+}  // extern "C"
+
+namespace ep {
+// the region of a self map that must hold -1 before kernel_map_self runs: offsets 14 .. 26
+FillRegion kernel_map_self_fill_region(int32_t *nbr, int64_t n)
+{
+    return FillRegion{nbr + (size_t)14 * n, (size_t)13 * n * sizeof(int32_t), 0xFFFFFFFFu};
+}
+}  // namespace ep
+
+namespace {
+int kernel_map_self_impl(const void *table, uint32_t capacity, const int32_t *coords, int64_t n, int stride, int32_t *nbr,
+                         bool prefilled, void *stream)
+{
+    if (!table || !is_pow2(capacity) || n < 0 || stride < 1 || (n > 0 && (!coords || !nbr))) return EPRECON_ERR_ARG;
+    if (n == 0) return EPRECON_OK;
+    HashTable t = make_table(const_cast<void *>(table), capacity);
+    if (!prefilled)
+        EP_HIP_CHECK(hipMemsetAsync(nbr + (size_t)14 * n, 0xFF, (size_t)13 * n * sizeof(int32_t), (hipStream_t)stream));
+    hipLaunchKernelGGL(kernel_map_self_kernel, dim3((unsigned)ceil_div(n, 256), 14), dim3(256), 0, (hipStream_t)stream, t,
+                       reinterpret_cast<const int4 *>(coords), (int)n, stride, nbr);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+}  // namespace
+
+namespace ep {
+int kernel_map_self_prefilled(const void *table, uint32_t capacity, const int32_t *coords, int64_t n, int stride, int32_t *nbr,
+                              void *stream)
+{
+    return kernel_map_self_impl(table, capacity, coords, n, stride, nbr, true, stream);
+}
+}  // namespace ep
+
+extern "C" {
+
+int eprecon_kernel_map_self_async(const void *table, uint32_t capacity, const int32_t *coords, int64_t n, int stride, int32_t *nbr,
+                                  void *stream)
+{
+    return kernel_map_self_impl(table, capacity, coords, n, stride, nbr, false, stream);
+}
+
 
 int eprecon_transpose_map_async(const int32_t *fine_coords, int64_t n, const int32_t *parent,
                                 int fine_stride, int32_t *up_map, void *stream)

@@ -37,12 +37,12 @@ int eprecon_spvcnn_geometry_async(const eprecon_spvcnn_geometry_desc *d, void *s
         if (d->n2 > 0) {
             EP_STEP(eprecon_kernel_map_async(d->table1, d->capacity1, d->coords2, d->n2, 2, 1, d->down12, side));
             EP_STEP(eprecon_transpose_map_async(d->coords1, d->n1, d->parent2, 1, d->up21, side));
-            EP_STEP(eprecon_kernel_map_async(d->table2, d->capacity2, d->coords2, d->n2, 3, 2, d->k2, side));
+            EP_STEP(ep::kernel_map_self_prefilled(d->table2, d->capacity2, d->coords2, d->n2, 2, d->k2, side));
         }
         if (d->n4 > 0) {
             EP_STEP(eprecon_kernel_map_async(d->table2, d->capacity2, d->coords4, d->n4, 2, 2, d->down24, side));
             EP_STEP(eprecon_transpose_map_async(d->coords2, d->n2, d->parent4, 2, d->up42, side));
-            EP_STEP(eprecon_kernel_map_async(d->table4, d->capacity4, d->coords4, d->n4, 3, 4, d->k4, side));
+            EP_STEP(ep::kernel_map_self_prefilled(d->table4, d->capacity4, d->coords4, d->n4, 4, d->k4, side));
             EP_STEP(eprecon_hash_query_async(d->table4, d->capacity4, d->vox, d->n, 4, d->idx4, side));
             EP_STEP(eprecon_segment_lists_async(d->idx4, d->n, d->n4, d->offsets4, d->order4, ws_b, half, side));
             EP_STEP(eprecon_trilinear_map_async(d->table4, d->capacity4, d->scaled, d->n, 4, d->idx8_4, d->weight8_4, side));
@@ -51,10 +51,16 @@ int eprecon_spvcnn_geometry_async(const eprecon_spvcnn_geometry_desc *d, void *s
     };
     auto unit = [&]() -> int {  // the stride-1 set: the caller's stream
         EP_STEP(eprecon_segment_lists_async(d->inverse1, d->n, d->n1, d->offsets1, d->order1, ws_a, half, stream));
-        EP_STEP(eprecon_kernel_map_async(d->table1, d->capacity1, d->coords1, d->n1, 3, 1, d->k1, stream));
+        EP_STEP(ep::kernel_map_self_prefilled(d->table1, d->capacity1, d->coords1, d->n1, 1, d->k1, stream));
         EP_STEP(eprecon_trilinear_map_async(d->table1, d->capacity1, d->scaled, d->n, 1, d->idx8_1, d->weight8_1, stream));
         return EPRECON_OK;
     };
+    {   // the upper halves of the three self maps (mirrored entries are scattered into them: -1 first), ONE launch, before the fork
+        ep::FillRegion reg[3] = {ep::kernel_map_self_fill_region(d->k1, d->n1), ep::kernel_map_self_fill_region(d->k2, d->n2),
+                                 ep::kernel_map_self_fill_region(d->k4, d->n4)};
+        rc = ep::multi_fill(reg, 3, main);
+        if (rc != EPRECON_OK) return rc;
+    }
     EP_HIP_CHECK(hipEventRecord(f.ev_fork, main));
     EP_HIP_CHECK(hipStreamWaitEvent(f.side, f.ev_fork, 0));
     const int rc_strided = strided();

@@ -193,6 +193,14 @@ int eprecon_unique_hierarchy_dn_async(const int32_t *coords, int64_t n_cap, cons
                                       const uint32_t *capacities, int32_t *const *inverse, int32_t *const *unique_coords,
                                       int32_t *summary, void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * eprecon_kernel_map_async(ksize 3) for a voxel set queried against ITS OWN table — coords int32[n,4] are pairwise distinct and
+ * row i is the table's value for its key (what eprecon_unique_coords*_async / eprecon_unique_hierarchy_dn_async leave behind) —
+ * with half the hash probes: the map of a submanifold 3x3x3 convolution (models/modules.py:19-23,181, spnn.Conv3d stride 1) is
+ * symmetric (offset -o from j reaches i exactly when +o from i reaches j).  Same int32[27][n] table, bit for bit.
+ */
+int eprecon_kernel_map_self_async(const void *table, uint32_t capacity, const int32_t *coords, int64_t n, int stride, int32_t *nbr,
+                                  void *stream);
 /* ------------------------------------------------------------------------------------------
  * Kernel maps and sparse convolution  (K5, K10, K11, K13)
  *

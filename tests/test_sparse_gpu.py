@@ -79,6 +79,25 @@ def test_kernel_maps():
     assert np.array_equal(d2.cpu().numpy(), OS.kernel_map(rc, rc2, 2, 4))
 
 
+@pytest.mark.parametrize("n,extent,stride", [(1, 4, 1), (300, 6, 1), (40000, 22, 2), (150000, 60, 1)])
+def test_self_kernel_map_with_half_the_probes_is_the_same_table(n, extent, stride):
+    """eprecon_kernel_map_self_async (the 13 offsets below the centre looked up, their mirror images filled in: the geometry calls
+    of an SPVCNN pass / a GRU level use it on the sets the unique numbering produced) == eprecon_kernel_map_async == the oracle"""
+    from eprecon_amd import _lib
+    from eprecon_amd.sparse import VoxelSet
+    rng = np.random.default_rng(n)
+    c = random_coords(rng, n, extent=extent, batch=2, stride=stride)
+    vs = VoxelSet(dev(c), stride=stride)
+    full = vs.kernel_map(3)
+    half = torch.full_like(full, 12345)
+    grid = vs.grid
+    _lib.check(_lib.load().eprecon_kernel_map_self_async(_lib.ptr(grid.mem), grid.capacity, _lib.ptr(vs.coords), vs.n, stride,
+                                                         _lib.ptr(half), _lib.current_stream()), "eprecon_kernel_map_self_async")
+    assert torch.equal(full, half)
+    if n <= 40000:
+        assert np.array_equal(half.cpu().numpy(), OS.kernel_map(c, c, 3, stride))
+
+
 @pytest.mark.parametrize("cin,cout", [(32, 32), (74, 8), (138, 16), (80, 32), (128, 128), (192, 96),
                                       (16, 1), (12, 24), (64, 96)])
 def test_sparse_conv_k3(cin, cout):
