@@ -85,6 +85,11 @@ FillRegion kernel_map_self_fill_region(int32_t *nbr, int64_t n);
 int kernel_map_self_prefilled(const void *table, uint32_t capacity, const int32_t *coords, int64_t n, int stride, int32_t *nbr,
                               void *stream);
 
+// eprecon_trilinear_map_async without hash probes (csrc/voxelize.hip): base_row[i] = row of point i's base voxel in the set whose
+// 3x3x3 kernel map nbr27 int32[27][m] is given; the corners are that voxel's neighbours at the offsets {0, +1}^3
+int trilinear_from_map(const float *points_xyzb, int64_t n, const int32_t *base_row, const int32_t *nbr27, int64_t m, int stride,
+                       int32_t *idx8, float *weight8, void *stream);
+
 // eprecon_unique_coords_dn_async for callers inside the library: table_cleared = the caller reset the table itself (multi_fill);
 // status_copy (optional device int32): receives the table's status word from the call's last launch
 int unique_coords_dn(const int32_t *coords, int64_t n_cap, const int32_t *n_dev, int quantum, void *table, uint32_t capacity,

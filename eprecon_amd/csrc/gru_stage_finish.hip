@@ -76,13 +76,16 @@ int eprecon_gru_stage_finish_async(const eprecon_gru_finish_desc *d, void *strea
         if (d->literal)
             EP_STEP(eprecon_sphash_order_async(d->uniq2, d->m2, d->perm2, d->rank2, ws_b, half, side));
         else
-            EP_STEP(eprecon_trilinear_map_async(d->table2, d->table_capacity, d->scaled2, d->n, 1, d->idx8_2, d->weight8_2, side));
+            EP_STEP(d->m2 > 0 ? ep::trilinear_from_map(d->scaled2, d->n, d->inverse2, d->nbr2, d->m2, 1, d->idx8_2, d->weight8_2, side)
+                              : eprecon_trilinear_map_async(d->table2, d->table_capacity, d->scaled2, d->n, 1, d->idx8_2, d->weight8_2, side));
         return EPRECON_OK;
     };
     auto first = [&]() -> int {  // ---- first voxelisation: the caller's stream ----
         EP_STEP(eprecon_segment_lists_async(d->inverse1, d->n, d->m1, d->offsets1, d->order1, ws_a, half, stream));
         if (d->m1 > 0) EP_STEP(ep::kernel_map_self_prefilled(d->table1, d->table_capacity, d->uniq1, d->m1, 1, d->nbr1, stream));
-        EP_STEP(eprecon_trilinear_map_async(d->table1, d->table_capacity, d->scaled1, d->n, 1, d->idx8_1, d->weight8_1, stream));
+        // (corners from the set's kernel map and the numbering's inverse: no hash probes, ep::trilinear_from_map)
+        EP_STEP(d->m1 > 0 ? ep::trilinear_from_map(d->scaled1, d->n, d->inverse1, d->nbr1, d->m1, 1, d->idx8_1, d->weight8_1, stream)
+                          : eprecon_trilinear_map_async(d->table1, d->table_capacity, d->scaled1, d->n, 1, d->idx8_1, d->weight8_1, stream));
         if (d->literal) EP_STEP(eprecon_sphash_order_async(d->uniq1, d->m1, d->perm1, d->rank1, ws_a, half, stream));
         return EPRECON_OK;
     };

@@ -45,14 +45,15 @@ int eprecon_spvcnn_geometry_async(const eprecon_spvcnn_geometry_desc *d, void *s
             EP_STEP(ep::kernel_map_self_prefilled(d->table4, d->capacity4, d->coords4, d->n4, 4, d->k4, side));
             EP_STEP(eprecon_hash_query_async(d->table4, d->capacity4, d->vox, d->n, 4, d->idx4, side));
             EP_STEP(eprecon_segment_lists_async(d->idx4, d->n, d->n4, d->offsets4, d->order4, ws_b, half, side));
-            EP_STEP(eprecon_trilinear_map_async(d->table4, d->capacity4, d->scaled, d->n, 4, d->idx8_4, d->weight8_4, side));
+            // (corners from the set's kernel map and the points' stride-4 rows: no hash probes, ep::trilinear_from_map)
+            EP_STEP(ep::trilinear_from_map(d->scaled, d->n, d->idx4, d->k4, d->n4, 4, d->idx8_4, d->weight8_4, side));
         }
         return EPRECON_OK;
     };
     auto unit = [&]() -> int {  // the stride-1 set: the caller's stream
         EP_STEP(eprecon_segment_lists_async(d->inverse1, d->n, d->n1, d->offsets1, d->order1, ws_a, half, stream));
         EP_STEP(ep::kernel_map_self_prefilled(d->table1, d->capacity1, d->coords1, d->n1, 1, d->k1, stream));
-        EP_STEP(eprecon_trilinear_map_async(d->table1, d->capacity1, d->scaled, d->n, 1, d->idx8_1, d->weight8_1, stream));
+        EP_STEP(ep::trilinear_from_map(d->scaled, d->n, d->inverse1, d->k1, d->n1, 1, d->idx8_1, d->weight8_1, stream));
         return EPRECON_OK;
     };
     {   // the upper halves of the three self maps (mirrored entries are scattered into them: -1 first), ONE launch, before the fork

@@ -193,6 +193,44 @@ __global__ void trilinear_map_kernel(HashTable t, const float4 *pts, int n, int 
     }
 }
 
+// The same table WITHOUT hash probes, for points whose base voxel row is already known and whose voxel set has its 3x3x3 kernel
+// map built: corner (ox, oy, oz) of the base voxel is the map's neighbour at offset (+ox, +oy, +oz) — nbr[((oz + 1) 3 + (oy + 1)) 3
+// + ox + 1][base] — eight reads of a table that is about to be read by every convolution on the set anyway, instead of eight
+// probes of the hash grid.  base: the point's own voxel at stride 1 (the unique numbering's inverse), the result of the stride-s
+// hash query of its voxel otherwise.  Same indices, same weights, bit for bit (trilinear_map_kernel's arithmetic).
+__global__ void trilinear_from_map_kernel(const float4 *pts, int n, const int32_t *base, const int32_t *nbr, int m, int stride,
+                                          int32_t *idx, float *wts)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    const float s = (float)stride;
+    const float xf = floorf(__fdiv_rn(p.x, s)) * s, yf = floorf(__fdiv_rn(p.y, s)) * s,
+                zf = floorf(__fdiv_rn(p.z, s)) * s;
+    const float xc = xf + s, yc = yf + s, zc = zf + s;
+    const int bi = base[i];
+    float w[8];
+    int id[8];
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int ox = (k >> 2) & 1, oy = (k >> 1) & 1, oz = k & 1;
+        const int kk = ((oz + 1) * 3 + (oy + 1)) * 3 + (ox + 1);
+        id[k] = (bi >= 0 && bi < m) ? nbr[(size_t)kk * m + bi] : -1;
+        float wk = (ox ? (p.x - xf) : (xc - p.x)) * (oy ? (p.y - yf) : (yc - p.y)) * (oz ? (p.z - zf) : (zc - p.z));
+        if (stride != 1) wk = __fdiv_rn(wk, s * s * s);
+        if (id[k] < 0) wk = 0.0f;
+        w[k] = wk;
+        sum += wk;
+    }
+    const float den = sum + 1e-8f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        idx[(size_t)i * 8 + k] = id[k];
+        wts[(size_t)i * 8 + k] = __fdiv_rn(w[k], den);
+    }
+}
+
 // out[i, c] (+)= sum_k w[i,k] * feat[idx[i,k], c]
 __global__ __launch_bounds__(256) void devoxelize_kernel(const float *feat, int ld_f, const int32_t *idx,
                                                          const float *wts, int n, int C, float *out,
@@ -494,6 +532,24 @@ int eprecon_trilinear_map_async(const void *table, uint32_t capacity, const floa
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }
+
+}  // extern "C"
+
+namespace ep {
+int trilinear_from_map(const float *points_xyzb, int64_t n, const int32_t *base_row, const int32_t *nbr27, int64_t m, int stride,
+                       int32_t *idx8, float *weight8, void *stream)
+{
+    if (n < 0 || m < 0 || m > 0x7fffffff || stride < 1 || (n > 0 && (!points_xyzb || !base_row || !nbr27 || !idx8 || !weight8)))
+        return EPRECON_ERR_ARG;
+    if (n == 0) return EPRECON_OK;
+    hipLaunchKernelGGL(trilinear_from_map_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(points_xyzb), (int)n, base_row, nbr27, (int)m, stride, idx8, weight8);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+}  // namespace ep
+
+extern "C" {
 
 int eprecon_devoxelize_async(const float *voxel_feat, int ld_feat, const int32_t *idx8, const float *weight8,
                              int64_t n, int channels, float *out, int ld_out, int accumulate, void *stream)
