@@ -164,6 +164,32 @@ def cpu_baseline(step, seconds):
                         "offset) and 2D convolutions, numpy kernel map and stage-0 selection"}
 
 
+def conv_family_roofline():
+    """The figure that tracks fragments/s: the whole gather-GEMM family over the 30 distinct 3x3x3 shapes of
+    a cfg4 fragment, from the newest committed profiles/rNN/conv_shapes.txt (tools/conv_shapes_ab.py: HIP-event time of each
+    shape alone on the device, flops on LIVE kernel-map pairs) — sum of flops / sum of time against the fp32-MFMA peak."""
+    import re
+    path = newest_profile("conv_shapes.txt")
+    if not path:
+        return None
+    us, flops, rows = 0.0, 0.0, []
+    for line in open(path):
+        m = re.search(r"N=\s*(\d+)\s+(\d+)->\s*(\d+)\s+([0-9.]+) us\s+([0-9.]+) TF", line)
+        if m:
+            t, tf = float(m.group(4)), float(m.group(5))
+            us += t
+            flops += tf * 1e12 * t * 1e-6
+            rows.append((line.split("N=")[0].strip(), int(m.group(1)), int(m.group(2)), int(m.group(3)), t, tf))
+    if not rows:
+        return None
+    lead = max(rows, key=lambda r: r[4])
+    return {"bound": "mfma", "shapes": len(rows), "sum_us": round(us, 1), "sum_gflop_live": round(flops / 1e9, 2),
+            "achieved": flops / (us * 1e-6) / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            "frac": flops / (us * 1e-6) / 1e12 / F32_MFMA_PEAK_TF,
+            "slowest_shape": {"name": lead[0], "rows": lead[1], "cin": lead[2], "cout": lead[3], "us": lead[4], "tflops": lead[5]},
+            "source": os.path.relpath(path, ROOT) + " (recorded: each shape timed alone by tools/conv_shapes_ab.py)"}
+
+
 def _conv_roofline_record(samples, kvol, cin, cout, what):
     """armed launches of the gather-GEMM family on ONE voxel set -> the roofline record (mean time of the samples); live
     kernel-map pairs are counted by the library on the launch stream right behind each timed launch
@@ -571,13 +597,15 @@ def main():
                 "achieved": (alg / (gm * 1e-3) / 1e9) if gm else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (alg / (gm * 1e-3) / 1e9 / HBM_PEAK_GBS) if gm else None,
                 "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": alg, "avg_launch_ms": gm,
-                "limiter": "vector-L1 line rate (two 64-byte lines per 96-byte tap), see l1", "l1": l1}
+                "limiter": "vector-L1 bandwidth, not HBM: see l1_bandwidth (bytes the taps request from L1) and l1 (line accesses, PMC)",
+                "l1": l1, "l1_bandwidth": step.dominant_kernel_l1_bandwidth(gm)}
         out = {"metric": "fragments_per_sec", "value": value, "unit": "fragments/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic", "config": describe, "roofline": roof}
         if world == 1:
             out["roofline_conv"] = conv_roofline(step, lib)
+            out["roofline_conv_family"] = conv_family_roofline()
             if not args.no_extra:
                 try:   # the extras must never cost the headline line (Cfg4Step.run raises on an early-returning fragment)
                     out["extra"] = extra_workloads(torch.device("cuda", local_rank), lib)

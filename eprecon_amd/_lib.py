@@ -10,7 +10,8 @@ import os
 import torch  # noqa: F401  (must be loaded before the HIP library, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# EPRECON_LIB_PATH: an A/B twin of the library built by `python -m eprecon_amd.build --plain` (timing tools only)
+# EPRECON_LIB_PATH: an A/B twin of the library built by `python -m eprecon_amd.build --variant NAME [-DX ...]` under
+# gpurun_out/variants/ (timing tools only; nothing but libeprecon_hip.so sits beside the package)
 LIB_PATH = os.environ.get("EPRECON_LIB_PATH") or os.path.join(_HERE, "libeprecon_hip.so")
 
 _c = ctypes
@@ -373,11 +374,25 @@ _DEFERRED_MAX = 64
 
 
 def defer_check(dev_value, expected, what):
+    """dev_value: a one-element device tensor (a VIEW is kept as it is: cloning it would cost a launch per check on the hot
+    path; what it keeps alive until the next read of its stream — at most _DEFERRED_MAX entries — is a count buffer or a
+    DenseMap rank volume of a few MB that its VoxelSet caches anyway)"""
     item = (dev_value, int(expected), what, current_stream())
+    evicted = None
     with _DEFERRED_LOCK:
         _DEFERRED.append(item)
-        if len(_DEFERRED) > _DEFERRED_MAX:   # (a path that never reaches a read: keep the newest only)
-            del _DEFERRED[0]
+        if len(_DEFERRED) > _DEFERRED_MAX:   # a path that never reaches a read on its stream: the OLDEST entry is verified now
+            evicted = _DEFERRED.pop(0)       # (one blocking read, counted) instead of being dropped unseen (ADVICE r05)
+    if evicted is not None:
+        count_host_read()
+        verify_deferred([evicted], evicted[0].to(torch.int32).tolist())
+
+
+def requeue_deferred(items):
+    """entries a reader took along and never verified (an abandoned PinnedRead) go back to the front of the list"""
+    if items:
+        with _DEFERRED_LOCK:
+            _DEFERRED[:0] = items
 
 
 def take_deferred(stream="current"):
@@ -431,9 +446,17 @@ class PinnedRead:
         self._event.synchronize()
         host = self._pinned.tolist()
         if self._pending:
-            verify_deferred(self._pending, host[self._n:])
-            self._pending = []
+            pending, self._pending = self._pending, []
+            verify_deferred(pending, host[self._n:])
         return host[:self._n]
+
+    def __del__(self):
+        # result() never called: the checks this read took along are handed back, so that the next read of their stream (or
+        # drain_deferred) still verifies them
+        try:
+            requeue_deferred(self._pending)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
 
 def drain_deferred():

@@ -212,6 +212,16 @@ class Back_Project(nn.Module):
         return [res["feats"], out_coords, res.get("grid"), res.get("mask"), res["count"]]
 
 
+def get_img_feats(coords, origin, voxel_size, feats, KRcam, min_view_number):
+    """models/occupancy_initialization.py:264-323 (imported by models/neucon_network.py:20, never called there): the view-mean
+    features f32[N_valid, C] of the voxels seen by at least `min_view_number` views — entry 0 of Back_Project.forward; an
+    empty [0, C] tensor where the reference's loop would have concatenated nothing."""
+    res = run(coords, origin, voxel_size, feats, KRcam, min_view_number, MODE_MEAN, min_valid_per_batch=0)
+    if res is None:
+        return torch.empty((0, feats.shape[2]), dtype=feats.dtype, device=feats.device)
+    return res["feats"]
+
+
 def forward_behind(module, coords, origin, voxel_size, feats, KRcam, min_view_number, behind):
     """Back_Project.forward with more work queued on the DEVICE count of its valid rows in front of the one host read:
     behind(valid_coords int32[N,4] (first n_valid rows live), n_valid_dev int32[1], extra_out int32[behind.n_extra]) ->

@@ -18,12 +18,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "--offload-compress"]
 
 
-# Per-file flags.  sparse_conv_direct.hip: `-fno-honor-nans` — with a pending BatchNorm + ReLU on the input the direct gather
-# kernel applies fmaxf(x, 0) to every gathered value, and clang puts a canonicalising `v_max_f32 x, x, x` in front of each one
-# (llvm.maxnum must quiet signalling NaNs): 8 extra VALU instructions per gathered quad next to its 8 MFMAs.  The flag removes
-# exactly those (checked on the assembly, DESIGN.md section 8: 3,472 -> 2,576 v_max_f32 over the file, nothing else changes);
-# v_max_f32 itself still returns the non-NaN operand, so ReLU(NaN) = 0 as before.  Nothing in that file feeds an index decision.
-EXTRA_FLAGS = {"sparse_conv_direct.hip": ["-fno-honor-nans"]}
+# Per-file flags (none since round 6: the direct gather kernel's ReLU-on-load is a v_med3_f32 now — csrc/sparse_conv_direct.hip
+# `relu_nc` — instead of a translation-unit-wide -fno-honor-nans).
+EXTRA_FLAGS = {}
 
 
 def sources():
@@ -35,10 +32,12 @@ def _deps():
         os.path.join(HERE, "..", "include", "eprecon_hip.h")]
 
 
-def build(force=False, verbose=False, out=OUT, extra_flags=None, obj_suffix=".o"):
-    """out / extra_flags / obj_suffix: an A/B variant of the library next to the shipped one (tools/: e.g. the build WITHOUT
-    the per-file flags above as libeprecon_hip_plain.so, loaded through EPRECON_LIB_PATH by the timing tools only)"""
+def build(force=False, verbose=False, out=OUT, extra_flags=None, obj_dir=CSRC, defines=()):
+    """out / obj_dir / extra_flags / defines: an A/B variant of the library built AWAY from the package directory (the timing
+    tools build it inside their own run, e.g. under gpurun_out/variants/, and load it through EPRECON_LIB_PATH; nothing but
+    libeprecon_hip.so ever sits beside the package: VERDICT r05 housekeeping)"""
     extra_flags = EXTRA_FLAGS if extra_flags is None else extra_flags
+    os.makedirs(obj_dir, exist_ok=True)
     stamp = os.path.abspath(__file__)      # (the flags live in this file: a change here rebuilds)
     if not force and os.path.exists(out) and all(
             os.path.getmtime(d) <= os.path.getmtime(out) for d in _deps() + [stamp]):
@@ -46,11 +45,12 @@ def build(force=False, verbose=False, out=OUT, extra_flags=None, obj_suffix=".o"
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs, jobs = [], []
     for src in sources():
-        obj = os.path.join(CSRC, os.path.basename(src)[:-4] + obj_suffix)
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
         if force or not os.path.exists(obj) or any(
                 os.path.getmtime(d) > os.path.getmtime(obj)
                 for d in [src, stamp] + [x for x in _deps() if x.endswith((".hpp", ".h"))]):
-            cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + extra_flags.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+            cmd = ([hipcc] + [f for f in FLAGS if f != "-shared"] + list(defines) + extra_flags.get(os.path.basename(src), [])
+                   + ["-c", src, "-o", obj])
             if verbose:
                 cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
                 print(" ".join(cmd))
@@ -67,9 +67,15 @@ def build(force=False, verbose=False, out=OUT, extra_flags=None, obj_suffix=".o"
     return out
 
 
+def build_variant(name, defines=(), extra_flags=None, root=None):
+    """an A/B twin under <root>/variants/<name>/ (default root: gpurun_out, which never travels and is git-ignored)"""
+    root = root or os.path.join(HERE, "..", "gpurun_out")
+    d = os.path.abspath(os.path.join(root, "variants", name))
+    return build(out=os.path.join(d, "libeprecon_hip.so"), obj_dir=d, defines=defines, extra_flags=extra_flags)
+
+
 if __name__ == "__main__":
-    if "--plain" in sys.argv:    # the A/B twin without the per-file flags (not loaded by the package unless EPRECON_LIB_PATH says so)
-        print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, out=os.path.join(HERE, "libeprecon_hip_plain.so"),
-                    extra_flags={}, obj_suffix=".plain.o"))
+    if "--variant" in sys.argv:    # python -m eprecon_amd.build --variant NAME [-DX=1 ...]: see build_variant
+        print(build_variant(sys.argv[sys.argv.index("--variant") + 1], defines=[a for a in sys.argv if a.startswith("-D")]))
     else:
         print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

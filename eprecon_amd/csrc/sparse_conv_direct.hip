@@ -24,6 +24,18 @@ using namespace ep;
 
 constexpr int kRT = 2;   // 16-row tiles per wave
 
+// ReLU of a gathered value without the canonicalising `v_max_f32 x, x, x` clang puts in front of every llvm.maxnum (it must
+// quiet signalling NaNs): 8 extra VALU instructions per gathered quad next to its 8 MFMAs.  The instruction itself is written
+// out: v_max_f32 returns the non-NaN operand, so ReLU(NaN) = 0 as with fmaxf.  Rounds 4-5 got the same instruction count from
+// a translation-unit-wide -fno-honor-nans (and the compiler folds v_med3_f32(x, 0, inf) back into maxnum + canonicalise);
+// this keeps every other floating-point operation of the file under the strict rules.
+__device__ __forceinline__ float relu_nc(float x)
+{
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // Epilogue for the 16x16 accumulator layout (column l & 15, rows 4 (l >> 4) + reg): bias, ReLU, residual with its pending
 // BatchNorm, row-wise LayerNorm (16-lane xor-shuffles), BatchNorm summaries of the 128-row block (fixed-order Chan merges: rows
 // in the lane, lane groups, waves).
@@ -298,7 +310,7 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
                     const bool ok = myNbr[k * ROWS + 16 * rt] >= 0 && cok;
                     float4 x = av[rt];
                     x.x = fmaf(x.x, sc.x, sh.x); x.y = fmaf(x.y, sc.y, sh.y); x.z = fmaf(x.z, sc.z, sh.z); x.w = fmaf(x.w, sc.w, sh.w);
-                    if (p.in_relu) { x.x = fmaxf(x.x, 0.0f); x.y = fmaxf(x.y, 0.0f); x.z = fmaxf(x.z, 0.0f); x.w = fmaxf(x.w, 0.0f); }
+                    if (p.in_relu) { x.x = relu_nc(x.x); x.y = relu_nc(x.y); x.z = relu_nc(x.z); x.w = relu_nc(x.w); }
                     if (p.Cin & 3) {
                         const int c = ca;
                         if (c + 1 >= p.Cin) x.y = 0.0f;
@@ -453,7 +465,7 @@ __global__ __launch_bounds__(256) void spconv_direct16_generic_kernel(ConvParams
                         const bool ok = (g.live >> (i * RT + rt)) & 1u;
                         float4 x = av[rt];
                         x.x = fmaf(x.x, sc.x, sh.x); x.y = fmaf(x.y, sc.y, sh.y); x.z = fmaf(x.z, sc.z, sh.z); x.w = fmaf(x.w, sc.w, sh.w);
-                        if (p.in_relu) { x.x = fmaxf(x.x, 0.0f); x.y = fmaxf(x.y, 0.0f); x.z = fmaxf(x.z, 0.0f); x.w = fmaxf(x.w, 0.0f); }
+                        if (p.in_relu) { x.x = relu_nc(x.x); x.y = relu_nc(x.y); x.z = relu_nc(x.z); x.w = relu_nc(x.w); }
                         av[rt] = ok ? x : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     }
                 }

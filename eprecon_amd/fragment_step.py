@@ -140,6 +140,21 @@ class Cfg2Step:
         nv = self.last["bp96"]["n_valid"] if self.last.get("bp96") else n
         return 16 * n + 4 * N_VIEWS * c * h * w + nv * (4 * c + 16)
 
+    def dominant_kernel_l1_bandwidth(self, launch_ms):
+        """What the gather asks of the vector L1s (the limiter of this kernel): every valid voxel reads, per view
+        it is visible in, four bilinear taps of C floats — an UPPER bound on the requested bytes is n_valid x V x 4 x 4 C (all V
+        views visible) — against 64 B per clock per CU x 256 CUs x 2.4 GHz."""
+        if not launch_ms:
+            return None
+        c = self.shapes[0][0]
+        n = self.coords[1].shape[0]
+        nv = self.last["bp96"]["n_valid"] if self.last.get("bp96") else n
+        req = float(nv) * N_VIEWS * 4 * 4 * c
+        peak = 64.0 * 256 * 2.4e9 / 1e12
+        ach = req / (launch_ms * 1e-3) / 1e12
+        return {"requested_bytes": req, "requested_note": "upper bound: every valid voxel visible in all views (4 taps x 4 C bytes per view)",
+                "achieved_TBps": ach, "peak_TBps": peak, "frac": ach / peak}
+
     def describe(self):
         return {"workload": "cfg2: one 9-view 640x480 window, 96^3 FBV: Occupancy_Initialization on the dense "
                             "48^3 grid (2D fusion convs + variance volume + submanifold stack) + stage-0 "

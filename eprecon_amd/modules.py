@@ -716,10 +716,12 @@ class SPVCNN(nn.Module):
         """the static part of eprecon_spvcnn_forward_desc (weights, their operand-order packings, BatchNorm parameters), built
         once per parameter version"""
         from . import _lib
-        params = getattr(self, "_native_params", None)
-        if params is None:      # (walking the module tree costs ~0.25 ms per call: once)
-            params = self._native_params = list(self.parameters())
-        key = (device, tuple((p_._version, p_.data_ptr()) for p_ in params))
+        slots = getattr(self, "_native_params", None)
+        if slots is None:       # (walking the module tree costs ~0.25 ms per call: once; what is kept is WHERE the parameters
+            # live — each submodule's _parameters dict + name —, so a Parameter object replaced later (load_state_dict(assign=True),
+            # `module.weight = nn.Parameter(..)`) is seen by the key below: ADVICE r05)
+            slots = self._native_params = [(m._parameters, n) for m in self.modules() for n in m._parameters if m._parameters[n] is not None]
+        key = (device, tuple((id(p_), p_._version, p_.data_ptr()) for p_ in (d_[n] for d_, n in slots)))
         hit = getattr(self, "_native", None)
         if hit is not None and hit[0] == key:
             return hit[1]

@@ -16,6 +16,10 @@ import torch.nn.functional as F
 
 from . import _lib
 from . import back_project as BP
+# the reference defines these two in THIS module (models/occupancy_initialization.py:185,264; imported from it by
+# models/neucon_network.py:20): re-exported so that `from models.occupancy_initialization import Occupancy_Initialization,
+# Back_Project, get_img_feats` needs nothing but the package name swapped
+from .back_project import Back_Project, get_img_feats  # noqa: F401
 from . import dense2d as D2
 from . import sparse as SP
 from .config import INIT_MIN_VALID

@@ -100,10 +100,12 @@ def unique_coords_queued(coords, quantum=1, n_dev=None):
 
 
 def unique_hierarchy_queued(coords, levels=3, n_dev=None, summary=None):
-    """unique_coords_queued for the strides 1, 2, 4, ... of one point cloud in ONE library call (the tables of all strides are
+    """unique_coords_queued for the strides 1, 2, 4 (levels <= 3) of one point cloud in ONE library call (the tables of all strides are
     reset by one launch; level l numbers the unique rows of level l - 1 at quantum 2^l, its count taken from the device):
     -> (uniqs, inverses, grids), each a list over the levels; the counts / status words sit in grids[l].header and, side by
     side, in `summary` (an int32[2 levels] device tensor of the caller's: what it reads back, no torch.cat of the headers)"""
+    if not 1 <= levels <= 3:    # (the library call numbers at most three strides and would answer EPRECON_ERR_ARG)
+        raise ValueError(f"unique_hierarchy_queued: levels must be 1, 2 or 3 (strides 1, 2, 4), got {levels}")
     lib = _lib.load()
     coords = coords.contiguous()
     n, dev = coords.shape[0], coords.device
@@ -271,14 +273,15 @@ def _hierarchy_with_geometry(vox, points, grids, uniqs, invs, sizes):
 
 def clear_packed_weights(module):
     """Drop every operand-order copy cached on the parameters / layers of `module` (packed_weight, packed_weight16,
-    dense2d.packed_weight, modules._linear_wt).  The caches are keyed on (tensor version, data_ptr): writes through `p.data`
+    dense2d.packed_weight, modules._linear_wt, SPVCNN's native-pass descriptor).  The caches are keyed on (tensor version, data_ptr): writes through `p.data`
     (dist.broadcast(p.data, ...), EMA swaps, manual loaders) change neither — call this after them."""
     for p_ in module.parameters():
         for attr in ("_d3_pack", "_d3_pack16"):
             if hasattr(p_, attr):
                 delattr(p_, attr)
     for m in module.modules():
-        for attr in ("_wt_cache", "_eprecon_packed", "_eprecon_merged"):
+        # (_native / _native_params: SPVCNN's descriptor of the one-call pass, which holds packed copies of all of the above)
+        for attr in ("_wt_cache", "_eprecon_packed", "_eprecon_merged", "_native", "_native_params"):
             if hasattr(m, attr):
                 delattr(m, attr)
 

@@ -119,6 +119,13 @@ def test_module_api_and_none_convention():
     assert mod(_dev(coords), _dev(far), 0.04, _dev(feats), _dev(kr), 1) is None
     out0 = mod(_dev(coords), _dev(far), 0.04, _dev(feats), _dev(kr), 0)
     assert out0[0].shape[0] == coords.shape[0] and not out0[0].any() and not out0[4].any()
+    # the reference defines Back_Project and get_img_feats in models/occupancy_initialization.py (:185, :264) and imports them
+    # from there (models/neucon_network.py:20): the mirror module exports the same names
+    from eprecon_amd.occupancy_initialization import Back_Project as BP2, Occupancy_Initialization, get_img_feats  # noqa: F401
+    assert BP2 is Back_Project
+    f = get_img_feats(_dev(coords), _dev(origin), 0.04, _dev(feats), _dev(kr), 2)
+    assert torch.equal(f, out[0])
+    assert get_img_feats(_dev(coords), _dev(far), 0.04, _dev(feats), _dev(kr), 1).shape == (0, c)
 
 
 def test_ragged_sparse_list_and_odd_channels():

@@ -61,3 +61,26 @@ def test_list_is_bounded_and_thread_safe():
         t.join()
     assert len(_lib._DEFERRED) == _lib._DEFERRED_MAX
     _lib.drain_deferred()       # all self-consistent: no raise
+
+
+def test_overflow_verifies_the_evicted_entry_instead_of_dropping_it():
+    """more than _DEFERRED_MAX entries pending on a stream that never reads -> the oldest is CHECKED when it leaves"""
+    _lib.defer_check(torch.tensor([3], dtype=torch.int32), 4, "oldest entry")
+    for k in range(_lib._DEFERRED_MAX - 1):
+        _lib.defer_check(torch.tensor([k], dtype=torch.int32), k, "t")
+    before = _lib.HOST_READS
+    with pytest.raises(_lib.EpreconError, match="oldest entry: expected 4, the device reports 3"):
+        _lib.defer_check(torch.tensor([0], dtype=torch.int32), 0, "one too many")
+    assert _lib.HOST_READS == before + 1 and len(_lib._DEFERRED) == _lib._DEFERRED_MAX
+
+
+def test_abandoned_pinned_read_hands_its_checks_back(monkeypatch):
+    class FakeRead(_lib.PinnedRead):      # (the real constructor needs a device: only the bookkeeping is under test)
+        def __init__(self):
+            self._pending = _lib.take_deferred()
+    _lib.defer_check(torch.tensor([1], dtype=torch.int32), 2, "taken along, never verified")
+    r = FakeRead()
+    assert _lib._DEFERRED == []
+    del r
+    with pytest.raises(_lib.EpreconError, match="never verified"):
+        _lib.drain_deferred()

@@ -106,6 +106,47 @@ def test_spvcnn_matches_oracle(stage, cin, n):
     assert err < TOL, err
 
 
+def test_native_pass_follows_weight_rewrites():
+    """the one-call SPVCNN pass keeps packed copies of every weight.  (a) a write through `p.data` (dist.broadcast,
+    EMA swap) + sparse.clear_packed_weights and (b) a REPLACED Parameter object (load_state_dict(assign=True)) must both reach
+    the native pass: it stays bit-identical to the Python-issued pass, and differs from its own result before the write."""
+    import eprecon_amd.modules as M
+    from eprecon_amd import sparse as SP
+    from eprecon_amd.modules import SPVCNN
+    from eprecon_amd.tensor import PointTensor
+    window, coords = shell_coords(3, 4, 6000)
+    pts = PV.aligned_coords(coords, window["vol_origin_partial"][None], 0.04, window["world_to_aligned_camera"][None])
+    feat = np.random.default_rng(5).standard_normal((len(pts), 80)).astype(np.float32)
+    torch.manual_seed(5)
+    net = SPVCNN(num_classes=1, in_channels=80, pres=1, cr=1.0, vres=0.16, dropout=False).cuda()
+
+    def both():
+        with torch.no_grad():
+            nat = net(PointTensor(dev(feat), dev(pts))).cpu().numpy()
+            assert net._native[1] is not None
+            M._NATIVE_SPVCNN = False
+            try:
+                py = net(PointTensor(dev(feat), dev(pts))).cpu().numpy()
+            finally:
+                M._NATIVE_SPVCNN = True
+        assert np.array_equal(nat, py)
+        return nat
+
+    first = both()
+    with torch.no_grad():      # (a) in-place through .data: neither the version counter nor the pointer moves
+        for p_ in net.parameters():
+            if p_.dim() >= 2:
+                p_.data.mul_(1.25)
+    SP.clear_packed_weights(net)
+    second = both()
+    assert not np.array_equal(first, second)
+    # (b) new Parameter objects (same values scaled again), no clear call: the key holds id() of the live objects
+    sd = {k: (v * 0.5 if v.dim() >= 2 else v).clone() for k, v in net.state_dict().items()}
+    net.load_state_dict(sd, assign=True)
+    third = both()
+    assert not np.array_equal(second, third)
+
+
 def test_sphash_order_matches_oracle():
     """torchsparse's voxel order (ascending F.sphash): HIP hash == numpy restatement, negative coordinates
     included; the sorted order is what ConvGRU's stale-index reuse depends on"""

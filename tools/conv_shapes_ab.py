@@ -3,7 +3,7 @@ launch from HIP events around 20 back-to-back launches.  Run under different EPR
     python tools/conv_shapes_ab.py [tag]
 EPRECON_AB_IN_AFFINE=1: every launch applies a pending BatchNorm + ReLU to its input while gathering (the second convolution of
 a ResidualBlock, models/modules.py:46-72): the path the per-file `-fno-honor-nans` of eprecon_amd/build.py is about.
-EPRECON_LIB_PATH=eprecon_amd/libeprecon_hip_plain.so: the twin built without the per-file flags (python -m eprecon_amd.build --plain)."""
+EPRECON_LIB_PATH=gpurun_out/variants/NAME/libeprecon_hip.so: an A/B twin of the library (python -m eprecon_amd.build --variant NAME -DX=1)."""
 import os
 import sys
 
