@@ -32,7 +32,7 @@ def _deps():
         os.path.join(HERE, "..", "include", "eprecon_hip.h")]
 
 
-def build(force=False, verbose=False, out=OUT, extra_flags=None, obj_dir=CSRC, defines=()):
+def build(force=False, verbose=False, out=OUT, extra_flags=None, obj_dir=CSRC, defines=(), only=None):
     """out / obj_dir / extra_flags / defines: an A/B variant of the library built AWAY from the package directory (the timing
     tools build it inside their own run, e.g. under gpurun_out/variants/, and load it through EPRECON_LIB_PATH; nothing but
     libeprecon_hip.so ever sits beside the package: VERDICT r05 housekeeping)"""
@@ -45,6 +45,9 @@ def build(force=False, verbose=False, out=OUT, extra_flags=None, obj_dir=CSRC, d
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs, jobs = [], []
     for src in sources():
+        if only is not None and os.path.basename(src) not in only:    # a variant of a few translation units: the rest are the
+            objs.append(os.path.join(CSRC, os.path.basename(src)[:-4] + ".o"))    # main build's objects (built first)
+            continue
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
         if force or not os.path.exists(obj) or any(
                 os.path.getmtime(d) > os.path.getmtime(obj)
@@ -67,15 +70,19 @@ def build(force=False, verbose=False, out=OUT, extra_flags=None, obj_dir=CSRC, d
     return out
 
 
-def build_variant(name, defines=(), extra_flags=None, root=None):
-    """an A/B twin under <root>/variants/<name>/ (default root: gpurun_out, which never travels and is git-ignored)"""
-    root = root or os.path.join(HERE, "..", "gpurun_out")
+def build_variant(name, defines=(), extra_flags=None, root=None, only=None):
+    """an A/B twin under <root>/variants/<name>/ (default root: gpurun_out, which never travels and is git-ignored); only = the
+    translation units the defines concern (the others are linked from the main build)"""
+    root = root or os.environ.get("EPRECON_VARIANT_ROOT") or os.path.join(HERE, "..", "gpurun_out")
     d = os.path.abspath(os.path.join(root, "variants", name))
-    return build(out=os.path.join(d, "libeprecon_hip.so"), obj_dir=d, defines=defines, extra_flags=extra_flags)
+    if only is not None:
+        build()
+    return build(out=os.path.join(d, "libeprecon_hip.so"), obj_dir=d, defines=defines, extra_flags=extra_flags, only=only)
 
 
 if __name__ == "__main__":
     if "--variant" in sys.argv:    # python -m eprecon_amd.build --variant NAME [-DX=1 ...]: see build_variant
-        print(build_variant(sys.argv[sys.argv.index("--variant") + 1], defines=[a for a in sys.argv if a.startswith("-D")]))
+        only = [a for a in sys.argv if a.endswith(".hip")] or None     # e.g. sparse_conv_direct.hip
+        print(build_variant(sys.argv[sys.argv.index("--variant") + 1], defines=[a for a in sys.argv if a.startswith("-D")], only=only))
     else:
         print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

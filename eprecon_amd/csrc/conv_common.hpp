@@ -71,5 +71,6 @@ __device__ __forceinline__ void chan_merge(float &n_a, float &mean_a, float &m2_
 bool direct16_ok(const ConvParams &p);
 constexpr int kDirectRows = 128;          // output rows (and rows of a BatchNorm summary block) per workgroup
 int launch_direct16(const ConvParams &p, hipStream_t st);
+int direct16_partial_block_rows(const ConvParams &p);   // 128, or 32 when the persistent form takes the launch
 
 }  // namespace epconv

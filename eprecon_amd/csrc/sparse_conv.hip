@@ -1089,9 +1089,23 @@ constexpr int kD16X = 2;                                     // tile x extent; y
 constexpr int kD16Halo = (kD16X + 2) * kD3HY * kD3HZ;        // 240
 
 // wq16[((((k * KCH + kc) * CT + t) * 4 + q) * 16 + col) * 4 + s] = W[k][16 kc + 4 q + s][16 t + col]
+// Tail section (C_out = 16 (ct - 1) + 1 .. 8 only), behind the tiles: the last <= 8 columns once more in the operand order of
+// v_mfma_f32_4x4x1_16B_f32 as the direct gather kernel feeds it (csrc/sparse_conv_direct.hip: tail_to_tile) —
+//   tail[((((k * KCH + kc) * 2 + cg) * 4 + q) * 4 + n) * 4 + s] = W[k][16 kc + 4 q + s][16 (ct - 1) + 4 cg + n]
 __global__ void pack_weights16_kernel(const float *w, int K, int Cin, int Cout, int kch, int ct, float *wq)
 {
     const int total = K * kch * ct * 256;
+    const int rem = Cout - 16 * (ct - 1);
+    const int total_tail = (rem >= 1 && rem <= 8) ? K * kch * 128 : 0;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total_tail; e += gridDim.x * blockDim.x) {
+        const int sidx = e & 3, n = (e >> 2) & 3, q = (e >> 4) & 3, cg = (e >> 6) & 1;
+        const int r = e >> 7;
+        const int kc = r % kch, k = r / kch;
+        const bool tail8 = kc == kch - 1 && Cin - 16 * kc <= 8;
+        const int c = tail8 ? (sidx < 2 ? 16 * kc + 2 * q + sidx : Cin) : 16 * kc + 4 * q + sidx;
+        const int co = 16 * (ct - 1) + 4 * cg + n;
+        wq[(size_t)total + e] = (c < Cin && co < Cout) ? w[((size_t)k * Cin + c) * Cout + co] : 0.0f;
+    }
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const int sidx = e & 3, col = (e >> 2) & 15, q = (e >> 6) & 3;
         int r = e >> 8;
@@ -2253,7 +2267,8 @@ extern "C" int eprecon_conv_pack_weight_async(const float *weight, int kvol, int
 extern "C" size_t eprecon_conv_pack_weight16_floats(int kvol, int cin, int cout)
 {
     if (kvol <= 0 || cin <= 0 || cout <= 0 || cout > 64) return 0;
-    return (size_t)kvol * ((cin + 15) / 16) * ((cout + 15) / 16) * 256;
+    const int rem = cout - 16 * ((cout + 15) / 16 - 1);      // columns of the last tile: <= 8 -> the tail section follows the tiles
+    return (size_t)kvol * ((cin + 15) / 16) * ((cout + 15) / 16) * 256 + (rem <= 8 ? (size_t)kvol * ((cin + 15) / 16) * 128 : 0);
 }
 
 extern "C" int eprecon_conv_pack_weight16_async(const float *weight, int kvol, int cin, int cout, float *packed, void *stream)
@@ -2336,11 +2351,11 @@ extern "C" int64_t eprecon_conv_desc_partial_rows(const eprecon_conv_desc *d)
     int64_t blocks;
     if (const int kind = conv3d_kind(p)) return d3_tiles_kind(p, kind);
     p.x_bytes = d->n_in > 0 ? ((d->n_in - 1) * (int64_t)p.ld_x + ((p.Cin + 3) & ~3)) * 4 : 0;
-    if (p.K == 9 && direct16_ok(p)) return ep::ceil_div(d->n_out, (int64_t)kDirectRows);
+    if (p.K == 9 && direct16_ok(p)) return ep::ceil_div(d->n_out, (int64_t)direct16_partial_block_rows(p));
     if (conv2d_tile_ok(p, &nt, &nch, &blocks)) return blocks;
     if (wide_ok(p)) return ep::ceil_div(d->n_out, (int64_t)kWideRows);
     if (splitk_ok(p)) return ep::ceil_div(d->n_out, (int64_t)32);
-    if (direct16_ok(p)) return ep::ceil_div(d->n_out, (int64_t)kDirectRows);
+    if (direct16_ok(p)) return ep::ceil_div(d->n_out, (int64_t)direct16_partial_block_rows(p));
     return ep::ceil_div(d->n_out, (int64_t)kRowsPerBlock);
 }
 

@@ -15,6 +15,8 @@
 // Summation order differs from the 32x32x2 kernels: equal within fp32 round-off, not bit for bit.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "common.hpp"
 #include "conv_common.hpp"
 
@@ -23,6 +25,14 @@ namespace {
 using namespace ep;
 
 constexpr int kRT = 2;   // 16-row tiles per wave
+
+// Timing ablations of the probe builds only (python -m eprecon_amd.build --variant X -DEP_DIRECT_ABL=N sparse_conv_direct.hip;
+// 0 in the library): 2 every gather reads one of 16 L1-resident rows, 4 no gathers, 8 every weight load reads the first
+// (offset, chunk) block, 16 no MFMAs (the operands are summed on the VALU instead, so the loads stay), 32 no weight loads.
+// Wrong results by design.
+#ifndef EP_DIRECT_ABL
+#define EP_DIRECT_ABL 0
+#endif
 
 // ReLU of a gathered value without the canonicalising `v_max_f32 x, x, x` clang puts in front of every llvm.maxnum (it must
 // quiet signalling NaNs): 8 extra VALU instructions per gathered quad next to its 8 MFMAs.  The instruction itself is written
@@ -39,12 +49,14 @@ __device__ __forceinline__ float relu_nc(float x)
 // Epilogue for the 16x16 accumulator layout (column l & 15, rows 4 (l >> 4) + reg): bias, ReLU, residual with its pending
 // BatchNorm, row-wise LayerNorm (16-lane xor-shuffles), BatchNorm summaries of the 128-row block (fixed-order Chan merges: rows
 // in the lane, lane groups, waves).
-template <int CT>
-__device__ __forceinline__ void direct_epilogue(const ConvParams &p, f32x4 (&acc)[kRT][CT], int row0, float *sStat)
+// PERWAVE (the persistent kernel below): row0 is the first of the WAVE's 32 rows and `block` its job index; the wave's own
+// summary (count, mean, M2 of 32 rows) is the partial row — no workgroup merge, no barrier.
+template <int CT, bool PERWAVE = false>
+__device__ __forceinline__ void direct_epilogue(const ConvParams &p, f32x4 (&acc)[kRT][CT], int row0, float *sStat, int block = 0)
 {
     constexpr int RT = kRT, NR = 4 * kRT;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = PERWAVE ? 0 : tid >> 6;
     const int l16 = lane & 15, q = lane >> 4;
     int orow[NR];
 #pragma unroll
@@ -134,11 +146,19 @@ __device__ __forceinline__ void direct_epilogue(const ConvParams &p, f32x4 (&acc
                 chan_merge(a_n, a_mean, a_m2, lower ? on : n, lower ? om : mean, lower ? oq : m2);
                 n = a_n; mean = a_mean; m2 = a_m2;
             }
+            if constexpr (PERWAVE) {
+                if (q == 0 && colok[t]) {
+                    float *dst = p.bn_partial + (size_t)block * 3 * p.Cout + 16 * t + l16;
+                    dst[0] = n; dst[p.Cout] = mean; dst[2 * p.Cout] = m2;
+                }
+                continue;
+            }
             if (q == 0) {
                 float *d = sStat + (wave * 3) * 16 * CT + 16 * t + l16;
                 d[0] = n; d[16 * CT] = mean; d[2 * 16 * CT] = m2;
             }
         }
+        if constexpr (PERWAVE) return;
         __syncthreads();
         if (tid < 16 * CT && tid < p.Cout) {
             float a_n = 0.0f, a_mean = 0.0f, a_m2 = 0.0f;
@@ -149,6 +169,31 @@ __device__ __forceinline__ void direct_epilogue(const ConvParams &p, f32x4 (&acc
             dst[0] = a_n; dst[p.Cout] = a_mean; dst[2 * p.Cout] = a_m2;
         }
     }
+}
+
+// C_out = 16 m + 8 (8, 24, 40, 56: the ConvGRU / SPVCNN channel plans at the finest level): the last 8 columns run on
+// v_mfma_f32_4x4x1_16B_f32 instead of a half-empty 16-column tile.  That instruction multiplies 16 independent 4x1 by 1x4
+// blocks (lane 4 b + i holds A_b[i] / B_b[i], register r of lane 4 b + j holds D_b[r][j]); fed with the SAME A register as the
+// 16x16x4 MFMA (lane = row l & 15, k slot g = l >> 4), block b = 4 g + (row >> 2) is rows 4 (row >> 2) .. + 3 at the ONE input
+// channel of k slot g, so with B_b[j] = W[channel of slot g][column 16 m + 4 cg + j] one instruction adds a k slot's product
+// into a per-slot partial of 16 rows x 4 columns: 512 flops in 8 cycles, the fp32 rate of every MFMA shape.  Two of them (cg =
+// 0, 1: 16 cycles) replace one 16x16x4 (32 cycles) per gathered register; the four k-slot partials are summed once, here, in
+// fixed order, and handed to the shared epilogue in the 16x16 accumulator layout (column l & 15, rows 4 (l >> 4) + reg;
+// columns 8 .. 15 zero: the epilogue masks them by C_out anyway).
+__device__ __forceinline__ void tail_to_tile(const f32x4 (&acct)[kRT][2], f32x4 (&dst)[kRT], int lane)
+{
+    const int l16 = lane & 15, q = lane >> 4;
+    const int src = 4 * q + (l16 & 3);      // k slot 0's lane of (rows 4 q .. 4 q + 3, column l16 & 3): after the sums every slot holds the total
+#pragma unroll
+    for (int rt = 0; rt < kRT; ++rt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v0 = acct[rt][0][j], v1 = acct[rt][1][j];
+            v0 += __shfl_xor(v0, 16); v1 += __shfl_xor(v1, 16);
+            v0 += __shfl_xor(v0, 32); v1 += __shfl_xor(v1, 32);
+            const float t0 = __shfl(v0, src), t1 = __shfl(v1, src);
+            dst[rt][j] = l16 < 4 ? t0 : (l16 < 8 ? t1 : 0.0f);
+        }
 }
 
 // The workgroup's slice of the kernel map -> LDS ([K][128 rows]), and for every wave the offsets at which at least one of its
@@ -200,12 +245,21 @@ struct LiveCursor {
 
 // chunks per stage for a layer of KCH chunks: the stages of an offset are KCH / G
 constexpr int stage_chunks(int kch) { return kch % 3 == 0 ? 3 : (kch % 2 == 0 ? 2 : 1); }
+// ... of the TAIL form: its stage carries 8 more B registers per chunk (A/B-ed by the build: -DEP_TAIL_STAGE=1 one chunk per stage)
+#ifndef EP_TAIL_STAGE
+#define EP_TAIL_STAGE 0
+#endif
+#define EP_TAIL_G(kch) (EP_TAIL_STAGE == 1 ? 1 : (EP_TAIL_STAGE == 2 ? ((kch) % 2 == 0 ? 2 : 1) : stage_chunks(kch)))
 
-template <int CT, int KCH, int G = stage_chunks(KCH)>
+// TAIL: the last column tile holds <= 8 columns and runs on the 4x4x1 MFMAs (tail_to_tile above); its B operands are the tail
+// section of the packing (pack_weights16_kernel: behind the CT tiles, 512 B per (offset, chunk)).
+template <int CT, int KCH, bool TAIL = false, int G = stage_chunks(KCH)>
 __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RT = kRT, ROWS = kDirectRows;
+    constexpr int CTM = TAIL ? CT - 1 : CT;          // full 16-column tiles on the 16x16x4 MFMA
+    constexpr int CTA = CTM > 0 ? CTM : 1;           // (array extent: no zero-length arrays)
     constexpr int PARTS = KCH / G;
     constexpr int cpad = 16 * KCH;
     int *sNbr = reinterpret_cast<int *>(smem);                        // [K][ROWS]
@@ -229,11 +283,21 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
     // 27 offsets are (profiles/r04/conv_tile_liveness.txt).
     const unsigned live = stage_map(p, row0, sNbr, sFlag, tid);
 
-    f32x4 acc[RT][CT];
+    // One full tile per row tile (C_out = 16, 24) leaves TWO independent 16x16x4 accumulators: consecutive MFMAs on one
+    // accumulator issue 32 cycles apart but the result returns after 40 — a quarter of the matrix pipe's time in bubbles
+    // (the compiler groups the 16x16x4s whatever order the source puts them in: ISA of round 6).  The channels of such a layer
+    // are split over NS = 2 accumulator sets (components x, z / y, w of every gathered quad), summed once before the epilogue.
+    constexpr int NS = CTM == 1 ? 2 : 1;
+    f32x4 acc[NS][RT][CTA];
+    f32x4 acct[RT][2];      // TAIL: per-k-slot partials of the last 8 columns (two groups of 4)
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-        for (int t = 0; t < CT; ++t) acc[rt][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+            for (int t = 0; t < CTA; ++t) acc[ns][rt][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        acct[rt][0] = acct[rt][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
     const unsigned row_bytes = (unsigned)p.ld_x * 4u, oob = (unsigned)p.x_bytes;
@@ -242,6 +306,10 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wq16), 0, (int)((unsigned)p.K * KCH * kChunkBytes), 0x00020000);
     const unsigned wlane = (unsigned)lane * 16u;
+    // tail section: [K][KCH][2 column groups][4 k slots][4 columns] float4 = 512 B per (offset, chunk)
+    const __amdgpu_buffer_rsrc_t wtrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.wq16) + (size_t)p.K * KCH * CT * 256, 0, (int)((unsigned)p.K * KCH * 512u), 0x00020000);
+    const unsigned tlane = (unsigned)(4 * q + (lane & 3)) * 16u;
     const int *myNbr = sNbr + wave * 16 * RT + l16;
     // a last chunk of <= 8 channels (C_in = 8, 24, 40): lane group q takes channels 2 q, 2 q + 1 and the chunk is two MFMAs
     const int last_c = p.Cin - 16 * (KCH - 1);      // channels of the last chunk
@@ -252,34 +320,55 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
 
     struct Stage {
         float4 a[G][RT];
-        float4 b[G][CT];
+        float4 b[G][CTA];
+        float4 bt[G][TAIL ? 2 : 1];
     };
     // stage u = (offset k = u / PARTS, chunks kc0 .. kc0 + G - 1 with kc0 = (u % PARTS) * G)
     auto fetch = [&](const LiveCursor &c, Stage &g) {
         const int k = c.k, part = c.part;                                // (wave-uniform: the weight offset below is a scalar)
         const unsigned xs = 64u * (unsigned)(part * G);                 // (scalar) byte offset of the stage's first chunk
-        const unsigned ws = (unsigned)(k * KCH + part * G) * kChunkBytes;
+        const unsigned ws = (EP_DIRECT_ABL & 8) ? 0u : (unsigned)(k * KCH + part * G) * kChunkBytes;
         const bool has_last = part == PARTS - 1;                         // (uniform) the stage holds the layer's last chunk
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            const int j = myNbr[k * ROWS + 16 * rt];
+            int j = myNbr[k * ROWS + 16 * rt];
+            if (EP_DIRECT_ABL & 2) j = j >= 0 ? l16 : j;
             const unsigned rowsel = j >= 0 ? __umul24((unsigned)j, row_bytes) : oob;
             const unsigned v0 = rowsel + cq;
 #pragma unroll
             for (int i = 0; i < G; ++i) {
                 unsigned off = v0 + 64u * i;
                 if (i == G - 1 && has_last) off = last_ok ? rowsel + cq_last + 64u * i : oob;
+                if (EP_DIRECT_ABL & 4) {
+                    g.a[i][rt] = make_float4(__uint_as_float(off), 1.0f, 2.0f, 3.0f);
+                    continue;
+                }
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, xs, 0);
                 g.a[i][rt] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
             }
         }
 #pragma unroll
-        for (int i = 0; i < G; ++i)
+        for (int i = 0; i < G; ++i) {
 #pragma unroll
-            for (int t = 0; t < CT; ++t) {
+            for (int t = 0; t < CTM; ++t) {
+                if (EP_DIRECT_ABL & 32) {
+                    g.b[i][t] = make_float4(__uint_as_float(ws), 1.0f, 2.0f, 3.0f);
+                    continue;
+                }
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + (unsigned)t * 1024u, ws + (unsigned)i * kChunkBytes, 0);
                 g.b[i][t] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
             }
+            if constexpr (TAIL && (EP_DIRECT_ABL & 32)) {
+                g.bt[i][0] = g.bt[i][1] = make_float4(__uint_as_float(ws), 1.0f, 2.0f, 3.0f);
+            } else if constexpr (TAIL) {
+                const unsigned wts = (EP_DIRECT_ABL & 8) ? 0u : (unsigned)(k * KCH + part * G + i) * 512u;
+#pragma unroll
+                for (int cg = 0; cg < 2; ++cg) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wtrsrc, tlane + (unsigned)cg * 256u, wts, 0);
+                    g.bt[i][cg] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                }
+            }
+        }
     };
     auto consume = [&](const LiveCursor &c, const Stage &g) {
         const int k = c.k, part = c.part;
@@ -321,24 +410,31 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
                 }
             }
             // independent accumulators alternate: a 16x16x4 MFMA issues every 32 cycles and returns after 40
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int t = 0; t < CT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].x, g.b[i][t].x, acc[rt][t], 0, 0, 0);
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int t = 0; t < CT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].y, g.b[i][t].y, acc[rt][t], 0, 0, 0);
+#define EP_DIRECT_STEP(comp, set)                                                                                                    \
+    do {                                                                                                                             \
+        if (EP_DIRECT_ABL & 16) {                                                                                                    \
+            _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                                                      \
+                _Pragma("unroll") for (int t = 0; t < CTM; ++t) acc[0][rt][t][0] += av[rt].comp + g.b[i][t].comp;                    \
+                if constexpr (TAIL) acct[rt][0][0] += av[rt].comp + g.bt[i][0].comp + g.bt[i][1].comp;                               \
+            }                                                                                                                        \
+            break;                                                                                                                   \
+        }                                                                                                                            \
+        _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                                            \
+            _Pragma("unroll") for (int t = 0; t < CTM; ++t)                                                                          \
+                acc[(set) % NS][rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].comp, g.b[i][t].comp, acc[(set) % NS][rt][t], 0, 0, 0); \
+        if constexpr (TAIL) {                                                                                                        \
+            _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                                        \
+                _Pragma("unroll") for (int cg = 0; cg < 2; ++cg)                                                                     \
+                    acct[rt][cg] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[rt].comp, g.bt[i][cg].comp, acct[rt][cg], 0, 0, 0);         \
+        }                                                                                                                            \
+    } while (0)
+            EP_DIRECT_STEP(x, 0);
+            EP_DIRECT_STEP(y, 1);
             if (!t8) {
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                    for (int t = 0; t < CT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].z, g.b[i][t].z, acc[rt][t], 0, 0, 0);
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                    for (int t = 0; t < CT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].w, g.b[i][t].w, acc[rt][t], 0, 0, 0);
+                EP_DIRECT_STEP(z, 0);
+                EP_DIRECT_STEP(w, 1);
             }
+#undef EP_DIRECT_STEP
         }
     };
     if (!(p.debug & 1) && U > 0) {
@@ -360,7 +456,288 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    direct_epilogue<CT>(p, acc, row0, sStat);
+    if constexpr (NS == 2) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < CTM; ++t) acc[0][rt][t] += acc[1][rt][t];
+    }
+    if constexpr (TAIL) {
+        f32x4 full[RT][CT];
+        f32x4 last[RT];
+        tail_to_tile(acct, last, lane);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+            for (int t = 0; t < CTM; ++t) full[rt][t] = acc[0][rt][t];
+            full[rt][CT - 1] = last[rt];
+        }
+        direct_epilogue<CT>(p, full, row0, sStat);
+    } else {
+        direct_epilogue<CT>(p, acc[0], row0, sStat);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent form for long lists whose packed weights fit the LDS (round 6).  What the ablations of the kernel above say about
+// the cfg4-leading layer (48 -> 24 on 320,868 rows, profiles/r06/conv_direct_ablate.txt): without its MFMAs the launch still
+// takes 72 % of its time, without its weight loads 13 % less, without its gathers 13 % less — every wave re-reads the SAME
+// operand-order weights through the vector L1 (9 of its 15 16-byte loads per offset; 64 B/clk/CU), and a wave stuck issuing
+// loads cannot issue MFMAs.  Here ONE workgroup of 8 waves per CU copies the whole packing into LDS once (124 KB for 48 -> 24;
+// ds_read_b128 delivers 256 B/clk/CU, no L1 traffic), and its waves then pull 32-row jobs from a device counter until the list
+// is exhausted: no barrier after the prologue, no per-workgroup launch / staging cost, the dispatch balanced at the granularity
+// of a wave's job whatever else runs on the chip.  The map slice of a job is staged by the wave itself in its own LDS window
+// (the ballots of the staging passes are its live-offset mask); gathers, MFMA loop and epilogue are the direct kernel's; the
+// BatchNorm summaries are per job (32 rows; the caller sizes them through eprecon_conv_desc_partial_rows).
+// Job counters: same-address device atomics retire one per ~21 ns on this part (tools/probes/atomic_probe.hip), so ONE counter
+// for the launch's ~12k pulls would cost more than the convolution (measured: 278 us).  The jobs are split into 8 contiguous
+// shares — workgroup b pulls from share b % 8, the XCD the dispatcher puts it on when the chip is free; nothing depends on that —
+// each with its own pair (next job, waves done) 64 bytes apart, out of a zero-initialised device array, one set per launch in
+// rotation.  Every wave's LAST pull fails by construction and the last wave of a share to leave puts its pair back to zero, so a
+// set can be reused (HIP graph replays reuse theirs).
+// ---------------------------------------------------------------------------------------------
+constexpr int kPersistWaves = 8;
+constexpr int kJobRows = 16 * kRT;
+constexpr int kPersistSlots = 512, kShares = 8, kCtrStride = 16;     // (16 uints = 64 B between the pairs of a set)
+__device__ unsigned int g_persist_ctr[kPersistSlots * kShares * kCtrStride];
+
+template <int CT, int KCH, bool TAIL, int G = stage_chunks(KCH)>
+__global__ __launch_bounds__(64 * kPersistWaves) void spconv_persist16_kernel(ConvParams p, int njobs, unsigned int *ctr)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RT = kRT, ROWS = kJobRows;
+    constexpr int CTM = TAIL ? CT - 1 : CT;
+    constexpr int CTA = CTM > 0 ? CTM : 1;
+    constexpr int PARTS = KCH / G;
+    constexpr int cpad = 16 * KCH;
+    constexpr int kQuads = CTM * 64 + (TAIL ? 32 : 0);      // float4s of one (offset, chunk) block in LDS
+    float4 *sW = reinterpret_cast<float4 *>(smem);                                  // [K][KCH][kQuads]
+    int *sNbr = reinterpret_cast<int *>(sW + (size_t)p.K * KCH * kQuads);           // [waves][K][32]
+    float *sAff = reinterpret_cast<float *>(sNbr + kPersistWaves * p.K * ROWS);     // [2][cpad]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, q = lane >> 4;
+
+    {   // the packing -> LDS, once per CU
+        const float4 *wm = reinterpret_cast<const float4 *>(p.wq16);
+        const float4 *wt = wm + (size_t)p.K * KCH * CT * 64;
+        const int blocks = p.K * KCH;
+        for (int e = tid; e < blocks * kQuads; e += 64 * kPersistWaves) {
+            const int blk = e / kQuads, r = e - blk * kQuads;
+            sW[e] = r < CTM * 64 ? wm[(size_t)blk * CT * 64 + r] : wt[(size_t)blk * 32 + (r - CTM * 64)];
+        }
+    }
+    if (p.in_scale)
+        for (int c = tid; c < cpad; c += 64 * kPersistWaves) {
+            sAff[c] = c < p.Cin ? p.in_scale[c] : 0.0f;
+            sAff[cpad + c] = c < p.Cin ? p.in_shift[c] : 0.0f;
+        }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const unsigned row_bytes = (unsigned)p.ld_x * 4u, oob = (unsigned)p.x_bytes;
+    int *wNbr = sNbr + wave * p.K * ROWS;
+    const int *myNbr = wNbr + l16;
+    const int last_c = p.Cin - 16 * (KCH - 1);
+    const bool tail8 = last_c <= 8;
+    const unsigned cq = 16u * (unsigned)q;
+    const unsigned cq_last = tail8 ? 8u * (unsigned)q : cq;
+    const bool last_ok = (tail8 ? 2 : 4) * q < last_c;
+    const int tq = CTM * 64 + 4 * q + (lane & 3);       // this lane's float4 of a block's tail section (+ 16 cg)
+    const int total = p.K * ROWS;
+
+    struct Stage {
+        float4 a[G][RT];
+        float4 b[G][CTA];
+        float4 bt[G][TAIL ? 2 : 1];
+    };
+
+    // this workgroup's share of the jobs: [job_lo, job_hi)
+    const unsigned share = blockIdx.x % (unsigned)kShares;
+    ctr += share * kCtrStride;
+    const unsigned per = ((unsigned)njobs + kShares - 1) / kShares;
+    const unsigned job_lo = share * per, job_hi = min(job_lo + per, (unsigned)njobs);
+    unsigned job = 0;
+    if (lane == 0) job = atomicAdd(&ctr[0], 1u);
+    job = (unsigned)__builtin_amdgcn_readfirstlane((int)job) + job_lo;
+    while (job < job_hi) {
+        const int row0 = (int)job * ROWS;
+        // the job's slice of the kernel map -> the wave's LDS window [K][32]; pass `it` covers offsets 2 it (lanes 0 .. 31) and
+        // 2 it + 1: the halves of its ballot are those offsets' liveness
+        unsigned live = 0u;
+        {
+            int jv[kMapLoads];
+#pragma unroll
+            for (int it = 0; it < kMapLoads; ++it) {
+                const int e = lane + 64 * it;
+                const int k = e >> 5, row = row0 + (e & 31);
+                int j = -1;
+                if (e < total && row < p.n_out) j = p.nbr ? p.nbr[(size_t)k * p.n_out + row] : row;
+                jv[it] = j;
+            }
+#pragma unroll
+            for (int it = 0; it < kMapLoads; ++it) {
+                const int e = lane + 64 * it;
+                if (e < total) wNbr[e] = jv[it];
+                const unsigned long long b = __ballot(jv[it] >= 0);
+                live |= ((unsigned)b != 0u ? 1u : 0u) << (2 * it);
+                live |= ((unsigned)(b >> 32) != 0u ? 1u : 0u) << (2 * it + 1);
+            }
+        }
+        live = (unsigned)__builtin_amdgcn_readfirstlane((int)live);
+        unsigned next = 0;
+        if (lane == 0) next = atomicAdd(&ctr[0], 1u);        // the next job's index travels while this one runs
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the window is written before any lane reads another lane's entry
+
+        constexpr int NS = CTM == 1 ? 2 : 1;       // (two accumulator sets when a row tile has one full column tile: see above)
+        f32x4 acc[NS][RT][CTA];
+        f32x4 acct[RT][2];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+                for (int t = 0; t < CTA; ++t) acc[ns][rt][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            acct[rt][0] = acct[rt][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        const int U = __builtin_popcount(live) * PARTS;
+
+        auto fetch = [&](const LiveCursor &c, Stage &g) {
+            const int k = c.k, part = c.part;
+            const unsigned xs = 64u * (unsigned)(part * G);
+            const bool has_last = part == PARTS - 1;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int j = myNbr[k * ROWS + 16 * rt];
+                const unsigned rowsel = j >= 0 ? __umul24((unsigned)j, row_bytes) : oob;
+                const unsigned v0 = rowsel + cq;
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    unsigned off = v0 + 64u * i;
+                    if (i == G - 1 && has_last) off = last_ok ? rowsel + cq_last + 64u * i : oob;
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, xs, 0);
+                    g.a[i][rt] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                }
+            }
+            const float4 *wb = sW + (size_t)(k * KCH + part * G) * kQuads;
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+#pragma unroll
+                for (int t = 0; t < CTM; ++t) g.b[i][t] = wb[i * kQuads + t * 64 + lane];
+                if constexpr (TAIL) {
+                    g.bt[i][0] = wb[i * kQuads + tq];
+                    g.bt[i][1] = wb[i * kQuads + tq + 16];
+                }
+            }
+        };
+        auto consume = [&](const LiveCursor &c, const Stage &g) {
+            const int k = c.k, part = c.part;
+            const bool has_last = part == PARTS - 1;
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const bool t8 = tail8 && i == G - 1 && has_last;
+                float4 av[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) av[rt] = g.a[i][rt];
+                if ((p.Cin & 3) && i == G - 1 && has_last) {
+                    const int c = 16 * (KCH - 1) + (t8 ? 2 : 4) * q;
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        if (c + 1 >= p.Cin) av[rt].y = 0.0f;
+                        if (c + 2 >= p.Cin) av[rt].z = 0.0f;
+                        if (c + 3 >= p.Cin) av[rt].w = 0.0f;
+                    }
+                }
+                if (p.in_scale) {
+                    const int kc = part * G + i;
+                    const int ca = 16 * kc + (t8 ? 2 : 4) * q;
+                    const float4 sc = make_float4(sAff[ca], sAff[ca + 1], sAff[ca + 2], sAff[ca + 3]);
+                    const float4 sh = make_float4(sAff[cpad + ca], sAff[cpad + ca + 1], sAff[cpad + ca + 2], sAff[cpad + ca + 3]);
+                    const bool cok = (i == G - 1 && has_last) ? last_ok : true;
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const bool ok = myNbr[k * ROWS + 16 * rt] >= 0 && cok;
+                        float4 x = av[rt];
+                        x.x = fmaf(x.x, sc.x, sh.x); x.y = fmaf(x.y, sc.y, sh.y); x.z = fmaf(x.z, sc.z, sh.z); x.w = fmaf(x.w, sc.w, sh.w);
+                        if (p.in_relu) { x.x = relu_nc(x.x); x.y = relu_nc(x.y); x.z = relu_nc(x.z); x.w = relu_nc(x.w); }
+                        if (p.Cin & 3) {
+                            if (ca + 1 >= p.Cin) x.y = 0.0f;
+                            if (ca + 2 >= p.Cin) x.z = 0.0f;
+                            if (ca + 3 >= p.Cin) x.w = 0.0f;
+                        }
+                        av[rt] = ok ? x : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    }
+                }
+#define EP_PERSIST_STEP(comp, set)                                                                                                   \
+    do {                                                                                                                             \
+        _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                                            \
+            _Pragma("unroll") for (int t = 0; t < CTM; ++t)                                                                          \
+                acc[(set) % NS][rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].comp, g.b[i][t].comp, acc[(set) % NS][rt][t], 0, 0, 0); \
+        if constexpr (TAIL) {                                                                                                        \
+            _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                                        \
+                _Pragma("unroll") for (int cg = 0; cg < 2; ++cg)                                                                     \
+                    acct[rt][cg] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[rt].comp, g.bt[i][cg].comp, acct[rt][cg], 0, 0, 0);         \
+        }                                                                                                                            \
+    } while (0)
+                EP_PERSIST_STEP(x, 0);
+                EP_PERSIST_STEP(y, 1);
+                if (!t8) {
+                    EP_PERSIST_STEP(z, 0);
+                    EP_PERSIST_STEP(w, 1);
+                }
+#undef EP_PERSIST_STEP
+            }
+        };
+        if (U > 0) {
+            Stage s_a, s_b;
+            LiveCursor cf(live), cc(live);
+            fetch(cf, s_a);
+            for (int u = 0; u < U; u += 2) {
+                cf.next(PARTS);
+                fetch(cf, s_b);
+                __builtin_amdgcn_sched_barrier(0);
+                consume(cc, s_a);
+                cc.next(PARTS);
+                __builtin_amdgcn_sched_barrier(0);
+                cf.next(PARTS);
+                fetch(cf, s_a);
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + 1 < U) consume(cc, s_b);
+                cc.next(PARTS);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (NS == 2) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < CTM; ++t) acc[0][rt][t] += acc[1][rt][t];
+        }
+        if constexpr (TAIL) {
+            f32x4 full[RT][CT];
+            f32x4 last[RT];
+            tail_to_tile(acct, last, lane);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                for (int t = 0; t < CTM; ++t) full[rt][t] = acc[0][rt][t];
+                full[rt][CT - 1] = last[rt];
+            }
+            direct_epilogue<CT, true>(p, full, row0, nullptr, (int)job);
+        } else {
+            direct_epilogue<CT, true>(p, acc[0], row0, nullptr, (int)job);
+        }
+        job = (unsigned)__builtin_amdgcn_readfirstlane((int)next) + job_lo;
+    }
+    if (lane == 0) {
+        // workgroups of this share: b = share, share + 8, ... < gridDim.x
+        const unsigned mates = (gridDim.x - share + kShares - 1) / kShares;
+        const unsigned done = atomicAdd(&ctr[1], 1u);
+        if (done == mates * (unsigned)kPersistWaves - 1u) {      // every wave of the share has made its last (failing) pull
+            __hip_atomic_store(&ctr[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctr[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // Any chunk count (C_in > 96): the (offset, chunk) sequence is walked with run-time indices, two chunks per stage.
@@ -389,11 +766,14 @@ __global__ __launch_bounds__(256) void spconv_direct16_generic_kernel(ConvParams
     // (live offsets of the wave's 32 rows: see the template kernel)
     const unsigned live = stage_map(p, row0, sNbr, sFlag, tid);
 
-    f32x4 acc[RT][CT];
+    constexpr int NS = CT == 1 ? 2 : 1;       // (two accumulator sets for a single column tile: see the template kernel)
+    f32x4 acc[NS][RT][CT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
-        for (int t = 0; t < CT; ++t) acc[rt][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < CT; ++t) acc[ns][rt][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
     const unsigned row_bytes = (unsigned)p.ld_x * 4u, oob = (unsigned)p.x_bytes;
@@ -473,20 +853,20 @@ __global__ __launch_bounds__(256) void spconv_direct16_generic_kernel(ConvParams
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                    for (int t = 0; t < CT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].x, g.b[i][t].x, acc[rt][t], 0, 0, 0);
+                    for (int t = 0; t < CT; ++t) acc[0 % NS][rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].x, g.b[i][t].x, acc[0 % NS][rt][t], 0, 0, 0);
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                    for (int t = 0; t < CT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].y, g.b[i][t].y, acc[rt][t], 0, 0, 0);
+                    for (int t = 0; t < CT; ++t) acc[1 % NS][rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].y, g.b[i][t].y, acc[1 % NS][rt][t], 0, 0, 0);
                 if (!t8) {
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                        for (int t = 0; t < CT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].z, g.b[i][t].z, acc[rt][t], 0, 0, 0);
+                        for (int t = 0; t < CT; ++t) acc[0 % NS][rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].z, g.b[i][t].z, acc[0 % NS][rt][t], 0, 0, 0);
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                        for (int t = 0; t < CT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].w, g.b[i][t].w, acc[rt][t], 0, 0, 0);
+                        for (int t = 0; t < CT; ++t) acc[1 % NS][rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].w, g.b[i][t].w, acc[1 % NS][rt][t], 0, 0, 0);
                 }
             }
         }
@@ -506,7 +886,88 @@ __global__ __launch_bounds__(256) void spconv_direct16_generic_kernel(ConvParams
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    direct_epilogue<CT>(p, acc, row0, sStat);
+    if constexpr (NS == 2) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[0][rt][0] += acc[1][rt][0];
+    }
+    direct_epilogue<CT>(p, acc[0], row0, sStat);
+}
+
+
+// EPRECON_CONV_TAIL8=0: C_out = 16 m + 8 on padded 16-column tiles (the round-5 form; read per launch: tests flip it)
+static bool tail8_enabled()
+{
+    const char *e = getenv("EPRECON_CONV_TAIL8");
+    return !(e && e[0] == '0');
+}
+
+constexpr size_t kLdsBytes = 160 * 1024;
+
+static size_t persist_lds_bytes(const ConvParams &p)
+{
+    const int kch = (p.Cin + 15) / 16, ct = (p.Cout + 15) / 16;
+    const bool tail = p.Cout - 16 * (ct - 1) <= 8;
+    const size_t quads = (size_t)(tail ? ct - 1 : ct) * 64 + (tail ? 32 : 0);
+    return (size_t)p.K * kch * quads * 16 + (size_t)kPersistWaves * p.K * kJobRows * sizeof(int) + (size_t)2 * 16 * kch * sizeof(float);
+}
+
+static int device_cus()
+{
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// EPRECON_CONV_PERSIST=1: long lists with LDS-sized weights on the persistent kernel (read per launch).  OFF by default: measured
+// equal to the per-tile kernel on the cfg4-leading layer (48 -> 24 on 320,868 rows: 203.6 against 203.3 us) and 10-19 % slower
+// on the 198k-row layers, whose 24.2 jobs per CU are 2.02 per wave of three resident ones — a third round for 1 % of the jobs
+// (profiles/r06/conv_forms_ab.txt).
+static bool persist_enabled()
+{
+    const char *e = getenv("EPRECON_CONV_PERSIST");
+    return e && e[0] == '1';
+}
+
+// (opt-in: any list with a job per wave of a few workgroups may take it)
+constexpr int kPersistMinRows = 8192;
+
+static bool persist_ok(const ConvParams &p)
+{
+    if (!persist_enabled() || (p.Cin + 15) / 16 > 6) return false;
+    if (p.Cout - 16 * ((p.Cout + 15) / 16 - 1) <= 8 && !tail8_enabled()) return false;    // (its 8-column tail is the 4x4x1 form)
+    if (p.bn_partial && !p.flex_partial) return false;          // its summaries are per 32-row job
+    if (persist_lds_bytes(p) > kLdsBytes) return false;
+    {   // (the instantiated forms: launch_k's rule)
+        const int kch = (p.Cin + 15) / 16, ct = (p.Cout + 15) / 16;
+        const bool tail = p.Cout - 16 * (ct - 1) <= 8;
+        if (kch * ((tail ? ct - 1 : ct) * 1024 + (tail ? 512 : 0)) > 4864) return false;
+    }
+    return p.n_out >= kPersistMinRows;
+}
+
+template <int CT, int KCH, bool TAIL>
+int launch_persist(const ConvParams &p, hipStream_t st)
+{
+    static bool attr_set = false;
+    auto kern = spconv_persist16_kernel<CT, KCH, TAIL>;
+    if (!attr_set) {
+        EP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+        attr_set = true;
+    }
+    static unsigned int *ctr_base = nullptr;
+    if (!ctr_base) EP_HIP_CHECK(hipGetSymbolAddress(reinterpret_cast<void **>(&ctr_base), HIP_SYMBOL(g_persist_ctr)));
+    static std::atomic<unsigned> slot{0};
+    unsigned int *ctr = ctr_base + (size_t)kShares * kCtrStride * (slot.fetch_add(1u) % (unsigned)kPersistSlots);
+    const int njobs = ceil_div(p.n_out, kJobRows);
+    const int grid = max(kShares, min(device_cus(), ceil_div(njobs, kPersistWaves)));    // (every share has a workgroup)
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * kPersistWaves), persist_lds_bytes(p), st, p, njobs, ctr);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
 }
 
 template <int CT, int KCH>
@@ -514,7 +975,20 @@ int launch_k(const ConvParams &p, hipStream_t st)
 {
     const size_t lds = (size_t)p.K * kDirectRows * sizeof(int) + (size_t)kWaves * 3 * 16 * CT * sizeof(float) + (size_t)2 * 16 * KCH * sizeof(float) + (size_t)p.K * kWaves * sizeof(int);
     // (one chunk per stage — 80 registers, six waves per SIMD instead of three — measured no faster: 266 vs 250 us on 48 -> 24)
-    hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH>), dim3((unsigned)ceil_div(p.n_out, kDirectRows)), dim3(256), lds, st, p);
+    const int rem = p.Cout - 16 * (CT - 1);       // columns of the last tile
+    // (instantiated only where a 27-offset packing can fit the LDS beside the eight job windows: <= 4.9 KB per offset)
+    if constexpr (KCH * (CT * 1024 - 512) <= 4864) {
+        if (persist_ok(p)) {
+            if (rem <= 8) return launch_persist<CT, KCH, true>(p, st);
+            if constexpr (KCH * CT * 1024 <= 4864) return launch_persist<CT, KCH, false>(p, st);
+        }
+    }
+    const dim3 grid((unsigned)ceil_div(p.n_out, kDirectRows));
+    if (rem <= 8 && tail8_enabled()) {
+        hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH, true, EP_TAIL_G(KCH)>), grid, dim3(256), lds, st, p);
+    } else {
+        hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH, false>), grid, dim3(256), lds, st, p);
+    }
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }
@@ -556,6 +1030,9 @@ bool direct16_ok(const ConvParams &p)
         return false;
     return true;
 }
+
+// rows of one BatchNorm summary block of the launch launch_direct16 would make (eprecon_conv_desc_partial_rows)
+int direct16_partial_block_rows(const ConvParams &p) { return persist_ok(p) ? kJobRows : kDirectRows; }
 
 int launch_direct16(const ConvParams &p, hipStream_t st)
 {

@@ -277,6 +277,58 @@ def test_direct_gather_kernel_on_a_long_list(cin, cout):
     assert not wide[:, :4].any() and not wide[:, 4 + cout:].any()
 
 
+@pytest.mark.parametrize("form", ["padded", "persist"])
+@pytest.mark.parametrize("cin,cout", [(48, 24), (74, 8), (32, 24), (24, 24), (80, 40), (16, 16), (32, 32)])
+def test_direct_kernel_forms_agree(monkeypatch, form, cin, cout):
+    """Round 6: the last 8 columns of C_out = 16 m + 8 on v_mfma_f32_4x4x1_16B_f32 (default; the (48, 24) / (74, 8) / (24, 24)
+    cases of the test above run it) against the padded 16-column tile (EPRECON_CONV_TAIL8=0), and the persistent form with the
+    packing resident in LDS and 32-row jobs pulled from device counters (EPRECON_CONV_PERSIST=1: per-job BatchNorm summaries).
+    Every form against the oracle; the summaries of every form must describe the same output."""
+    from eprecon_amd import sparse as SP
+    rng = np.random.default_rng(cin * 17 + cout)
+    c = random_coords(rng, 41003, extent=34, batch=1)
+    n = len(c)
+    x = rng.standard_normal((n, cin)).astype(np.float32)
+    w = (rng.standard_normal((27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    vs = SP.VoxelSet(dev(c))
+    nbr_d = vs.kernel_map(3)
+    nbr = OS.kernel_map(c, c, 3, 1)
+    cp = (cin + 3) & ~3
+    buf = torch.full((n, cp), float("nan"), device="cuda")
+    buf[:, :cin] = dev(x)
+    dx, dw, db = buf[:, :cin], dev(w), dev(b)
+    sc = rng.uniform(0.5, 1.5, cin).astype(np.float32)
+    sh = rng.standard_normal(cin).astype(np.float32)
+    want = OS.sparse_conv(np.maximum(x * sc + sh, 0), nbr, w, b)
+
+    def run():
+        (y, part), name = _last_conv_kernel((27, cin, cout, 1000), lambda: SP.conv_stats(dx, dw, nbr_d, in_affine=(dev(sc), dev(sh), True), bias=db))
+        assert name == "spconv_direct16_kernel"
+        return y.cpu().numpy(), part.cpu().numpy().astype(np.float64)
+
+    y0, p0 = run()
+    monkeypatch.setenv("EPRECON_CONV_TAIL8" if form == "padded" else "EPRECON_CONV_PERSIST", "0" if form == "padded" else "1")
+    y1, p1 = run()
+    persist_takes_it = form == "persist" and ((cin + 15) // 16) * (1024 * (cout // 16) + 512 * (cout % 16 == 8)) <= 4864
+    assert p1.shape[0] == ((n + 31) // 32 if persist_takes_it else (n + 127) // 128)
+    for y, part in ((y0, p0), (y1, p1)):
+        assert np.abs(y - want).max() < TOL
+        cnt, mean, m2 = part[:, 0], part[:, 1], part[:, 2]
+        assert cnt[:, 0].sum() == n
+        tot_mean = (cnt * mean).sum(0) / n
+        tot_m2 = (m2 + cnt * (mean - tot_mean) ** 2).sum(0)
+        assert np.abs(tot_mean - want.mean(0)).max() < 1e-4 and np.abs(tot_m2 / n - want.var(0)).max() < 1e-3
+    assert np.abs(y0 - y1).max() < 1e-4
+    # the persistent form's counters come back to zero: a second launch on the same set (512 launches later) would hang or
+    # skip rows otherwise — run it enough times to wrap the rotation once
+    if persist_takes_it:
+        for _ in range(520):
+            SP.conv_stats(dx, dw, nbr_d, in_affine=(dev(sc), dev(sh), True), bias=db)
+        y2, _ = run()
+        assert np.array_equal(y1, y2)
+
+
 @pytest.mark.parametrize("n,cin,cout", [(204, 64, 128), (204, 128, 128), (1532, 160, 96), (1532, 64, 64), (1532, 32, 64),
                                         (7561, 32, 32), (9415, 192, 96)])
 def test_short_list_kernel(monkeypatch, n, cin, cout):
