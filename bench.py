@@ -87,6 +87,12 @@ def parse():
                     help="approximate CPU time to spend on the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the cfg3 / cfg4 timings reported under `extra`")
+    ap.add_argument("--scenes-per-gpu", type=int, default=0,
+                    help="with --workload cfg4: K independent scenes on ONE GPU at the same time, each in its own process with "
+                         "its own NeuConNet, map handles and streams (SURVEY.md 8e: fragments of different scenes are pure "
+                         "replicas); value = fragments/s over all K scenes")
+    ap.add_argument("--scene-seed-base", type=int, default=0, help="scene k of --scenes-per-gpu runs Cfg4Step(seed = base + k)")
+    ap.add_argument("--scene-child", type=int, default=-1, help=argparse.SUPPRESS)   # (internal: one scene of --scenes-per-gpu)
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "train"],
                     help="cfg2 (default) = BASELINE.json configs[1], the headline metric; cfg4 = the full "
                          "coarse-to-fine forward over 4 sequential fragments (extra measurement, no roofline)")
@@ -367,9 +373,23 @@ def extra_workloads(device, lib, steps3=12, steps4=16, warm4=4):
         out["train_finest_voxels_min_max"] = [min(step.voxels), max(step.voxels)] if step.voxels else None
         out["train_workload"] = step.describe()["workload"] + " (lr 1e-6, see bench.py)"
 
+    def scenes():
+        # a cfg4 fragment keeps the GPU "busy" with ~600 launches that occupy a fraction of its 256 CUs;
+        # K independent scenes side by side (one process each: K Python threads would share one interpreter lock) fill it.
+        # This process keeps its context but queues nothing while the children run.
+        sync()
+        for k in (1, 2, 4):
+            rec = scenes_per_gpu(k, 16, 8)
+            out[f"cfg4_fragments_per_sec_k{k}"] = rec["fragments_per_sec"]
+            out[f"cfg4_ms_per_fragment_by_scene_k{k}"] = rec["ms_per_fragment_by_scene"]
+        out["cfg4_scenes_per_gpu_note"] = ("K independent scenes on ONE GPU, one process each, started together: aggregate "
+                                            "fragments/s = K x 16 / (last finish - first start); per-scene outputs are "
+                                            "bit-identical to the solo run (tests/test_bench_records.py)")
+
     leg("cfg34", cfg34)
     leg("e2e", e2e)
     leg("train", train)
+    leg("scenes", scenes)
     prof = newest_profile("cfg4_kernel_stats.json")
     if prof:
         rec = json.load(open(prof))
@@ -390,6 +410,7 @@ def fragment_summary(extra):
             "cfg4_fragments_per_sec": extra.get("cfg4_fragments_per_sec"),
             "cfg4_launches_per_fragment": extra.get("launches_per_fragment"),
             "cfg4_blocking_reads_per_fragment": extra.get("blocking_reads_per_fragment"),
+            "cfg4_fragments_per_sec_per_gpu_by_scenes": {str(k): extra.get(f"cfg4_fragments_per_sec_k{k}") for k in (1, 2, 4)},
             "cfg4_roofline_conv_alone_frac": (conv.get("alone") or {}).get("frac"),
             "cfg4_roofline_conv_in_situ_frac": conv.get("frac"),
             "e2e_ms_per_fragment": extra.get("e2e_ms_per_fragment")}
@@ -472,6 +493,85 @@ def bench_cfg4(args, step, world, rank, dist, use_dist=False):
         dist.destroy_process_group()
 
 
+def _fragment_digest(out):
+    """sha1 over the outputs of one fragment (voxel list, TSDF, panoptic labels + segments): what 'bit-identical' compares"""
+    import hashlib
+    h = hashlib.sha1()
+    h.update(out["coords"].cpu().numpy().tobytes())
+    h.update(out["tsdf"].cpu().numpy().tobytes())
+    for info in out.get("panoptic_info", []):
+        seg, segments = info["panoptic_seg"]
+        h.update(seg.cpu().numpy().tobytes())
+        h.update(repr([(d.get("id"), d.get("isthing"), d.get("category_id")) for d in segments]).encode())
+    return h.hexdigest()
+
+
+def scene_child(args):
+    """one scene of `--scenes-per-gpu K`: build, warm up, hash one pass over the scene's fragments, report READY, wait for GO on
+    stdin, time `--steps` fragments, report DONE with wall-clock start / end (one host: the parent compares the clocks)"""
+    import torch
+    from eprecon_amd import _lib as L
+    from eprecon_amd.fragment_step import Cfg4Step
+    torch.cuda.set_device(0)
+    step = Cfg4Step(seed=args.scene_seed_base + args.scene_child, device=torch.device("cuda", 0), pipeline=PIPELINE)
+    for _ in range(max(args.warmup, step.n_fragments)):
+        step.run()
+    while step.k != 0:          # align on the first fragment of the scene
+        step.run()
+    digests = [_fragment_digest(step.run()) for _ in range(step.n_fragments)]
+    step.voxels.clear()
+    torch.cuda.synchronize()
+    print("READY " + json.dumps({"scene": args.scene_child, "seed": step.seed, "digests": digests}), flush=True)
+    if sys.stdin.readline().strip() != "GO":
+        raise SystemExit("scene child: no GO")
+    reads0 = L.HOST_READS
+    t_wall0, t0 = time.time(), time.perf_counter()
+    for _ in range(args.steps):
+        step.run()
+    step.flush()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    print("DONE " + json.dumps({"scene": args.scene_child, "t_start": t_wall0, "t_end": t_wall0 + elapsed, "elapsed": elapsed,
+                                "ms_per_fragment": elapsed / args.steps * 1e3,
+                                "blocking_reads_per_fragment": (L.HOST_READS - reads0) / args.steps,
+                                "finest_voxels_min_max": [min(step.voxels), max(step.voxels)], "workload": step.describe()}), flush=True)
+
+
+def scenes_per_gpu(k, steps, warmup, seed_base=0, timeout=900):
+    """K scene processes on device 0, started together -> the record of `bench.py --workload cfg4 --scenes-per-gpu K`"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "cfg4", "--steps", str(steps), "--warmup", str(warmup),
+           "--scene-seed-base", str(seed_base)]
+    kids = [subprocess.Popen(cmd + ["--scene-child", str(i)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for i in range(k)]
+
+    def wait_for(proc, tag):
+        while True:
+            line = proc.stdout.readline()
+            if not line:
+                raise RuntimeError(f"scene process exited before {tag} (code {proc.poll()})")
+            if line.startswith(tag + " "):
+                return json.loads(line[len(tag) + 1:])
+    try:
+        ready = [wait_for(p_, "READY") for p_ in kids]
+        for p_ in kids:
+            p_.stdin.write("GO\n")
+            p_.stdin.flush()
+        done = [wait_for(p_, "DONE") for p_ in kids]
+        for p_ in kids:
+            p_.wait(timeout=timeout)
+    finally:
+        for p_ in kids:
+            if p_.poll() is None:
+                p_.kill()
+    span = max(d["t_end"] for d in done) - min(d["t_start"] for d in done)
+    return {"scenes_per_gpu": k, "fragments_per_sec": k * steps / span, "span_s": span, "steps_per_scene": steps,
+            "ms_per_fragment_by_scene": [round(d["ms_per_fragment"], 3) for d in done],
+            "start_skew_ms": round((max(d["t_start"] for d in done) - min(d["t_start"] for d in done)) * 1e3, 3),
+            "finest_voxels_min_max_by_scene": [d["finest_voxels_min_max"] for d in done],
+            "blocking_reads_per_fragment": done[0]["blocking_reads_per_fragment"],
+            "digests_by_scene": {str(r["seed"]): r["digests"] for r in ready}, "workload": done[0]["workload"]}
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as child processes of this one (same command line,
     the rendezvous variables torch.distributed.run would set) and wait for them.  Rank 0's JSON line goes to this process's
@@ -492,6 +592,20 @@ def spawn_ranks(n):
 
 def main():
     args = parse()
+    if args.scene_child >= 0:
+        return scene_child(args)
+    if args.scenes_per_gpu > 0:
+        if args.workload != "cfg4" or args.gpus != 1:
+            raise SystemExit("--scenes-per-gpu K goes with --workload cfg4 --gpus 1")
+        rec = scenes_per_gpu(args.scenes_per_gpu, args.steps, args.warmup, args.scene_seed_base)
+        cfg = dict(rec.pop("workload"), scenes_per_gpu=args.scenes_per_gpu,
+                   scenes="K independent scenes (seeds base .. base + K - 1), one process each on device 0, started together; "
+                          "value = K x steps / (last finish - first start)")
+        print(json.dumps({"metric": "fragments_per_sec", "value": rec["fragments_per_sec"], "unit": "fragments/s", "n_gpus": 1,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["span_s"] / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": cfg, **rec}), flush=True)
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(spawn_ranks(args.gpus))
     import torch

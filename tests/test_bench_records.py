@@ -106,9 +106,24 @@ def test_whole_fragment_figures_are_first_class():
     """the cfg4 figures (ms per fragment, launches, blocking reads, the leading convolution alone) sit at the top level of the line"""
     extra = {"cfg4_ms_per_fragment": 12.5, "cfg4_fragments_per_sec": 80.0, "launches_per_fragment": 800.0,
              "blocking_reads_per_fragment": 8.0, "e2e_ms_per_fragment": 18.0,
-             "roofline_conv_cfg4": {"frac": 0.2, "alone": {"frac": 0.33}}}
+             "roofline_conv_cfg4": {"frac": 0.2, "alone": {"frac": 0.33}}, "cfg4_fragments_per_sec_k2": 150.0}
     s = bench.fragment_summary(extra)
     assert s == {"cfg4_ms_per_fragment": 12.5, "cfg4_fragments_per_sec": 80.0, "cfg4_launches_per_fragment": 800.0,
                  "cfg4_blocking_reads_per_fragment": 8.0, "cfg4_roofline_conv_alone_frac": 0.33,
+                 "cfg4_fragments_per_sec_per_gpu_by_scenes": {"1": None, "2": 150.0, "4": None},
                  "cfg4_roofline_conv_in_situ_frac": 0.2, "e2e_ms_per_fragment": 18.0}
     assert bench.fragment_summary({"cfg34_error": "x"})["cfg4_ms_per_fragment"] is None
+
+
+def test_conv_family_record_recomputes_from_the_committed_shape_list():
+    """`roofline_conv_family`: sum of live flops / sum of time over the newest profiles/rNN/conv_shapes.txt"""
+    r = bench.conv_family_roofline()
+    assert r and r["shapes"] == 30 and r["bound"] == "mfma"
+    assert r["frac"] == pytest.approx(r["sum_gflop_live"] * 1e9 / (r["sum_us"] * 1e-6) / 1e12 / bench.F32_MFMA_PEAK_TF, rel=1e-3)
+    assert 0.05 < r["frac"] < 1.0 and r["slowest_shape"]["us"] <= r["sum_us"]
+
+
+def test_scenes_per_gpu_is_a_cfg4_single_gpu_mode(monkeypatch, capsys):
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--scenes-per-gpu", "2"])
+    with pytest.raises(SystemExit, match="--scenes-per-gpu K goes with --workload cfg4"):
+        bench.main()

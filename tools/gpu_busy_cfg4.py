@@ -32,6 +32,18 @@ def summarize(path):
     print(f"# cfg4 unpipelined under rocprofv3 --kernel-trace, {N} steady-state fragments between two markers")
     print(f"wall {(t1 - t0) / N / 1e6:.2f} ms/fragment   GPU busy (union over streams) {busy / N / 1e6:.2f} ms   "
           f"sum of kernel durations {total / N / 1e6:.2f} ms   launches {len(seg) / N:.0f}   idle {(t1 - t0 - busy) / N / 1e6:.2f} ms/fragment")
+    # CU-level occupancy: a launch of W workgroups covers at most min(W, 256) of the 256 CUs while it runs;
+    # sum over launches of that share x duration, against 256 CUs x wall — what "busy" leaves out: ~600 of a fragment's launches
+    # are 3-30 us kernels on <= 10k rows that occupy a fraction of the chip
+    def wgs(r):
+        g = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
+        w = int(r["Workgroup_Size_X"]) * int(r.get("Workgroup_Size_Y", 1) or 1) * int(r.get("Workgroup_Size_Z", 1) or 1)
+        return max(1, g // max(w, 1))
+    cu_time = sum(min(wgs(r), 256) / 256.0 * (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in seg)
+    small = [r for r in seg if wgs(r) < 256]
+    print(f"CU-level occupancy: sum over launches of min(workgroups, 256) / 256 x duration = {cu_time / N / 1e6:.2f} ms per fragment = "
+          f"{cu_time / (t1 - t0):.2f} of 256 CUs x wall ({cu_time / max(busy, 1):.2f} of the busy time); launches with fewer than 256 "
+          f"workgroups: {len(small) / N:.0f} per fragment, {sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in small) / N / 1e6:.2f} ms")
     big = [g for g in gaps if g > 20000]
     print(f"idle gaps longer than 20 us: {len(big) / N:.1f} per fragment, {sum(big) / N / 1e6:.2f} ms; longer than 5 us: "
           f"{sum(1 for g in gaps if g > 5000) / N:.0f} per fragment, {sum(g for g in gaps if g > 5000) / N / 1e6:.2f} ms")
