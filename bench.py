@@ -372,6 +372,23 @@ def extra_workloads(device, lib, steps3=12, steps4=16, warm4=4):
         out["train_early_returns"] = n_early
         out["train_finest_voxels_min_max"] = [min(step.voxels), max(step.voxels)] if step.voxels else None
         out["train_workload"] = step.describe()["workload"] + " (lr 1e-6, see bench.py)"
+        # the reference trains at BATCH_SIZE 4 (config/train.yaml:2): the same step on a batch of TWO consecutive windows
+        del step
+        import gc
+        gc.collect()
+        step = TrainStep(seed=0, device=device, lr=1e-6, batch=2)
+        step.raise_on_early_return = False
+        for _ in range(2):
+            step.run()
+        full_ms = []
+        for _ in range(4):
+            before = step.early_returns
+            ms = _timed(step.run, 1, sync)
+            if step.early_returns == before:
+                full_ms.append(ms)
+        out["train_b2_ms_per_step"] = float(np.mean(full_ms)) if full_ms else None
+        out["train_b2_full_steps"] = len(full_ms)
+        out["train_b2_finest_voxels_min_max"] = [min(step.voxels), max(step.voxels)] if step.voxels else None
 
     def scenes():
         # a cfg4 fragment keeps the GPU "busy" with ~600 launches that occupy a fraction of its 256 CUs;

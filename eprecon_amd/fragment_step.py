@@ -417,15 +417,19 @@ class TrainStep:
 
     LW = (1.0, 0.8, 0.64, 1.2)       # config/train.yaml:44
 
-    def __init__(self, seed=0, device=None, height=480, width=640, lr=1e-4, rank=0, world=1):
+    def __init__(self, seed=0, device=None, height=480, width=640, lr=1e-4, rank=0, world=1, batch=1):
+        """batch: fragment windows per step and rank (consecutive windows of the scene; the reference trains at BATCH_SIZE 4,
+        config/train.yaml:2 — every stage of the forward loops over the batch elements, the BatchNorms see them all)"""
         from .config import ModelCfg
         from .neucon_network import NeuConNet
         self.device = device or torch.device("cuda")
+        self.batch = batch
         torch.manual_seed(4321)
         self.net = NeuConNet(ModelCfg()).to(self.device)
         self.net.train()
-        w = S.make_window(seed=seed * 100 + rank, width=width, height=height, advance=0.32 * rank)
-        f1, f2, inp = S.make_model_inputs([w], feat_seed=seed * 100 + rank, scene=f"scene{seed:04d}", panoptic=True)
+        ws = [S.make_window(seed=seed * 100 + rank * batch + b, width=width, height=height, advance=0.32 * (rank * batch + b))
+              for b in range(batch)]
+        f1, f2, inp = S.make_model_inputs(ws, feat_seed=seed * 100 + rank, scene=f"scene{seed:04d}", panoptic=True)
         self.f1, self.f2, self.inputs = (S.to_device(x, self.device) for x in (f1, f2, inp))
         calibrate_occupancy_heads(self.net, self.f1, self.f2, self.inputs)
         for views in (self.f1, self.f2):
@@ -452,7 +456,8 @@ class TrainStep:
         self.raise_on_early_return = world == 1
 
     def describe(self):
-        return {"workload": "one optimisation step on one 9-view 640x480 fragment (empty scene map): NeuConNet.forward under "
+        return {"workload": f"one optimisation step on {'a batch of ' + str(self.batch) + ' consecutive' if self.batch > 1 else 'one'} 9-view "
+                            f"640x480 fragment{'s' if self.batch > 1 else ''} (empty scene map): NeuConNet.forward under "
                             "autograd, TSDF / occupancy losses of the three levels + panoptic set criterion, backward through "
                             "the HIP operators, clip_grad_norm_(1.0), Adam; image pyramids are leaf tensors",
                 "parallelism": "DistributedDataParallel over RCCL, one fragment per rank" if self.model is not self.net else "single"}

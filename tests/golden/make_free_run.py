@@ -27,8 +27,11 @@ from eprecon_amd.config import ModelCfg  # noqa: E402
 from oracle import free_run as FR  # noqa: E402
 
 SEED, WINDOW, FEAT_SEED = 7, dict(seed=0, width=320, height=240), 3
-WINDOWS = {320: WINDOW, 640: dict(seed=0, width=640, height=480)}
-FILES = {320: "free_run.npz", 640: "free_run_640.npz"}
+# (size key -> the windows of the batch; "320b2": TWO consecutive windows of one scene in one forward, round 6 — the reference
+# trains at BATCH_SIZE 4, config/train.yaml:2, and loops `for b in range(bs)` in every stage)
+WINDOWS = {320: [WINDOW], 640: [dict(seed=0, width=640, height=480)],
+           "320b2": [dict(seed=0, width=320, height=240), dict(seed=1, width=320, height=240, advance=0.32)]}
+FILES = {320: "free_run.npz", 640: "free_run_640.npz", "320b2": "free_run_b2.npz"}
 KEEP = (0.45, 0.35, 0.25)
 
 
@@ -38,8 +41,8 @@ def build(size=320):
     torch.manual_seed(SEED)
     net = NeuConNet(ModelCfg())
     net.train()
-    window = S.make_window(**WINDOWS[size])
-    feats, feats2, inputs = S.make_model_inputs([window], feat_seed=FEAT_SEED)
+    windows = [S.make_window(**w) for w in WINDOWS[size]]
+    feats, feats2, inputs = S.make_model_inputs(windows, feat_seed=FEAT_SEED)
     return net, feats, feats2, inputs
 
 
@@ -48,9 +51,10 @@ def main(size=320):
     sd = {k: v.detach().numpy().copy() for k, v in net.state_dict().items()}
     init = net.initialization
     with torch.no_grad():   # the dense 2D fusion stack: the same PyTorch modules on the CPU (pinned to the reference's, dense_blocks.npz)
-        fused = init.feat_fusion_pre(torch.stack([torch.from_numpy(v[2][0]) for v in feats]),
-                                     torch.stack([torch.from_numpy(v[1][0]) for v in feats]),
-                                     torch.stack([torch.from_numpy(v[0][0]) for v in feats])).unsqueeze(1).numpy()
+        bs = feats[0][0].shape[0]
+        fused = torch.stack([init.feat_fusion_pre(torch.stack([torch.from_numpy(v[2][b]) for v in feats]),
+                                                  torch.stack([torch.from_numpy(v[1][b]) for v in feats]),
+                                                  torch.stack([torch.from_numpy(v[0][b]) for v in feats])) for b in range(bs)], 1).numpy()
     rec = FR.forward(sd, fused, feats2, inputs, keep_fraction=KEEP)
     assert "early" not in rec, rec.get("early")
     out = {"seed": np.array(SEED), "feat_seed": np.array(FEAT_SEED), "keep_fraction": np.array(KEEP),
@@ -66,7 +70,8 @@ def main(size=320):
         out[f"s{i}_counts"] = np.array([st["n_in"], st["n_fused"], st["n_occ"]])
         print(f"stage {i}: in {st['n_in']} fused {st['n_fused']} occupied {st['n_occ']}  "
               f"|logit| < 1e-3: {(np.abs(st['occ']) < 1e-3).sum()}  min |logit| {np.abs(st['occ']).min():.2e}")
-    out["size"] = np.array(size)
+    out["size"] = np.array(WINDOWS[size][0]["width"])
+    out["batch"] = np.array(len(WINDOWS[size]))
     path = os.path.join(HERE, FILES[size])
     np.savez_compressed(path, **out)
     print(f"free_run: {os.path.getsize(path) / 1024:.0f} KiB, finest voxels {len(rec['coords'])}")
@@ -75,5 +80,6 @@ def main(size=320):
 if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument("--size", type=int, default=320, choices=sorted(WINDOWS))
-    main(ap.parse_args().size)
+    ap.add_argument("--size", default="320", choices=[str(k) for k in WINDOWS])
+    a = ap.parse_args().size
+    main(int(a) if a.isdigit() else a)

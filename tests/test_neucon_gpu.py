@@ -20,16 +20,21 @@ def npy(t):
     return t.detach().cpu().numpy()
 
 
-@pytest.fixture(scope="module")
-def run():
+@pytest.fixture(scope="module", params=[1, 2], ids=["B1", "B2"])
+def run(request):
+    """B2 (round 6): a TWO-window batch — consecutive fragments of one scene, the reference's `for b in range(bs)` loops
+    (models/neucon_network.py:248-601, models/gru_fusion.py:275) with BatchNorm statistics over the voxels of both windows;
+    the reference trains at BATCH_SIZE 4 (config/train.yaml:2).  Every stage-wise check below runs at both sizes."""
     from eprecon_amd.neucon_network import NeuConNet
     cfg = ModelCfg()
     torch.manual_seed(7)
     np.random.seed(7)
     net = NeuConNet(cfg).cuda()
     net.train()
-    window = S.make_window(seed=0, width=320, height=240)
-    feats, feats2, inputs = S.make_model_inputs([window], feat_seed=3)
+    bs = request.param
+    windows = [S.make_window(seed=k, width=320, height=240, advance=0.32 * k) for k in range(bs)]
+    window = windows[0]
+    feats, feats2, inputs = S.make_model_inputs(windows, feat_seed=3)
     dev = torch.device("cuda")
     from eprecon_amd.fragment_step import calibrate_occupancy_heads
     d_feats, d_feats2, d_inputs = S.to_device(feats, dev), S.to_device(feats2, dev), S.to_device(inputs, dev)
@@ -39,7 +44,7 @@ def run():
         outputs, loss = net(d_feats, d_feats2, d_inputs, {})
     sd = {k: npy(v) for k, v in net.state_dict().items()}
     return {"net": net, "outputs": outputs, "trace": {t["stage"]: t for t in net.trace}, "sd": sd,
-            "window": window, "feats2": feats2, "inputs": inputs}
+            "window": window, "feats2": feats2, "inputs": inputs, "bs": bs}
 
 
 def test_reaches_the_finest_level(run):
@@ -47,11 +52,16 @@ def test_reaches_the_finest_level(run):
     assert "coords" in out and "tsdf" in out, "early return: " + str(list(run["trace"]))
     assert out["coords"].shape[0] > 500 and out["coords"].shape[1] == 4
     assert out["tsdf"].shape == (out["coords"].shape[0], 1)
-    assert len(out["panoptic_levels"]) == 1
-    assert out["panoptic_levels"][0]["mask_features"].shape == (out["coords"].shape[0], 48)
-    seg, info = out["panoptic_info"][0]["panoptic_seg"]
-    assert seg.shape[0] == out["coords"].shape[0] and seg.dtype == torch.int32
-    assert out["panoptic_out"][0]["pred_masks"].shape == (1, 80, out["coords"].shape[0])
+    bs = run["bs"]
+    assert len(out["panoptic_levels"]) == bs and len(out["panoptic_info"]) == bs
+    per_batch = [int((out["coords"][:, 0] == b).sum()) for b in range(bs)]
+    assert sum(per_batch) == out["coords"].shape[0] and min(per_batch) > 200
+    assert bool((out["coords"][1:, 0] >= out["coords"][:-1, 0]).all())          # grouped by ascending batch index
+    for b in range(bs):
+        assert out["panoptic_levels"][b]["mask_features"].shape == (per_batch[b], 48)
+        seg, info = out["panoptic_info"][b]["panoptic_seg"]
+        assert seg.shape[0] == per_batch[b] and seg.dtype == torch.int32
+        assert out["panoptic_out"][b]["pred_masks"].shape == (1, 80, per_batch[b])
 
 
 def test_neuralrecon_boundary_runs_end_to_end():
@@ -83,7 +93,7 @@ def test_neuralrecon_boundary_runs_end_to_end():
 def test_stage0_selection_and_backprojection(run):
     tr, inputs = run["trace"], run["inputs"]
     sel = npy(tr["init"]["selected"])
-    assert np.array_equal(sel, OG.init_select(npy(tr["init"]["occ_init"]), npy(tr["init"]["coord_init"]), 1))
+    assert np.array_equal(sel, OG.init_select(npy(tr["init"]["occ_init"]), npy(tr["init"]["coord_init"]), run["bs"]))
     # stage-0 Back_Project on those voxels
     f = np.stack([v[2] for v in run["feats2"]])
     kr = np.ascontiguousarray(inputs["proj_matrices"][:, :, 2].transpose(1, 0, 2, 3))
@@ -139,13 +149,13 @@ def test_mask_features_match_oracle(run):
     from oracle import sparse as OSP
     tr, sd = run["trace"], run["sd"]
     coords, x = npy(tr["panoptic"]["coords"][2]), npy(tr["panoptic"]["feats"][2])
-    assert x.shape[1] == 48 and len(np.unique(coords[:, 0])) == 1
+    assert x.shape[1] == 48 and len(np.unique(coords[:, 0])) == run["bs"]
     nbr = OSP.kernel_map(coords, coords, 3, 1)
     for i in range(3):
         pre = f"panoptic_feat_fusion.mask_feat_extraction_{i}."
         y = OSP.sparse_conv(x, nbr, sd[pre + "SConv3d.weight"], sd[pre + "SConv3d.bias"])
         x = OSP.layernorm_rows(y, sd[pre + "norm.weight"], sd[pre + "norm.bias"], residual=x, pre_relu=True)
-    got = npy(run["outputs"]["panoptic_levels"][0]["mask_features"])
+    got = np.concatenate([npy(lv["mask_features"]) for lv in run["outputs"]["panoptic_levels"]])
     assert got.shape == x.shape and np.abs(got - x).max() < 1e-3
 
 
