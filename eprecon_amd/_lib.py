@@ -53,6 +53,10 @@ SIGNATURES = {
                                              _vp, _vp]),
     "eprecon_conv_desc_async": (_i, [_vp, _vp]),
     "eprecon_conv_desc_partial_rows": (_i64, [_vp]),
+    "eprecon_bn_acc_words": (_sz, [_i]),
+    "eprecon_conv_desc_takes_bn_acc": (_i, [_vp]),
+    "eprecon_batchnorm_acc_affine_async": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "eprecon_affine_rows_acc_async": (_i, [_vp, _i64, _i, _i, _vp, _i, _i, _f, _i, _vp, _i, _vp]),
     "eprecon_affine_rows_res_async": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "eprecon_batchnorm_finalize_affine_async": (_i, [_vp, _i64, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "eprecon_affine_rows_async": (_i, [_vp, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
@@ -237,7 +241,11 @@ class ConvDesc(ctypes.Structure):
                 ("img_h", ctypes.c_int), ("img_w", ctypes.c_int), ("img_maps", ctypes.c_int),
                 ("vox_rank", ctypes.c_void_p), ("grid_x", ctypes.c_int), ("grid_y", ctypes.c_int), ("grid_z", ctypes.c_int),
                 ("packed_weight", ctypes.c_void_p), ("packed_weight16", ctypes.c_void_p),
-                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t)]
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+                ("bn_acc", ctypes.c_void_p), ("bn_acc_ld", ctypes.c_int), ("bn_acc_c0", ctypes.c_int),
+                ("bn_gamma", ctypes.c_void_p), ("bn_beta", ctypes.c_void_p),
+                ("in_acc", ctypes.c_void_p), ("in_acc_ld", ctypes.c_int), ("in_acc_c0", ctypes.c_int),
+                ("in_eps", ctypes.c_float), ("in_affine_scratch", ctypes.c_void_p)]
 
 
 class GruStageDesc(ctypes.Structure):

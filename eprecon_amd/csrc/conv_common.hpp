@@ -46,7 +46,107 @@ struct ConvParams {
     int splitk_pipe;  // split-K kernel: 1 software-pipelined stages, 2 also B operands straight from the packed weights (wq)
     void *ws;         // caller's scratch (eprecon_conv_desc.workspace): partial sums of the cross-workgroup split-K kernel
     size_t ws_bytes;
+    // BatchNorm form (c) (round 6): the producer adds its workgroups' per-channel sums to ORDER-INDEPENDENT
+    // integer accumulators instead of (or beside) the per-workgroup summaries, and the consumer turns them into (scale, shift)
+    // in its prologue — no finalize launch between two convolutions.  A block: int64[kBnCopies][ld][kBnWords] sums followed by
+    // float[2][ld] (gamma, beta: written by the producer's first workgroup); *_c0 = first channel of this layer in the block.
+    long long *bn_acc;
+    int bn_acc_ld, bn_acc_c0;
+    const float *bn_gamma, *bn_beta;      // the producer's BatchNorm parameters (copied into the block) or nullptr (1, 0)
+    const long long *in_acc;              // consumer: the block its input's pending BatchNorm lives in
+    int in_acc_ld, in_acc_c0;
+    float in_eps;
 };
+
+// ---- BatchNorm form (c): exact, order-independent sums ------------------------------------------------------------------
+// Per (copy, channel) seven int64 words: S1 = sum n_w mean_w and S2 = sum (M2_w + n_w mean_w^2) over the producer's workgroups
+// w, each as THREE limbs of a 2^-40 fixed-point value (fraction, integer bits 0..39, integer bits 40.. signed), and the
+// count.  Every add is a fire-and-forget 64-bit integer atomic (integer addition commutes: the result does not depend on the
+// order the workgroups finish in, so inference stays run-to-run bit-identical); a limb sum cannot overflow (2^40 x 2^23 adds).
+// The limbs are exact images of the doubles they come from, so sum n mean^2 - (sum n mean)^2 / N cancels exactly as the
+// between-workgroup term of a Chan merge does.  kBnCopies copies spread the same-address atomics (21 ns each on this part).
+constexpr int kBnCopies = 8, kBnWords = 7;
+#ifndef EP_BN_ABL       // timing ablations of probe builds only: 1 no atomics, 2 no finish in the consumers (wrong results)
+#define EP_BN_ABL 0
+#endif
+
+__device__ __forceinline__ void bn_limbs(double x, long long &l0, long long &l1, long long &l2)
+{
+    const double v = x * 1099511627776.0;                    // 2^40 (exact scaling)
+    const double hi = floor(v * (1.0 / 1099511627776.0));    // floor(x)
+    l0 = (long long)(v - hi * 1099511627776.0);              // fraction bits, in [0, 2^40) (below 2^-40: truncated)
+    const long long h = (long long)hi;
+    l1 = h & ((1ll << 40) - 1);
+    l2 = h >> 40;
+}
+
+__device__ __forceinline__ void bn_acc_add(long long *acc, int ld, int c, int copy, float n, float mean, float m2)
+{
+    if (n <= 0.0f || (EP_BN_ABL & 1)) return;
+    unsigned long long *a = reinterpret_cast<unsigned long long *>(acc) + ((size_t)copy * ld + c) * kBnWords;
+    const double dn = (double)n, dm = (double)mean;
+    long long l0, l1, l2;
+    bn_limbs(dn * dm, l0, l1, l2);
+    atomicAdd(a + 0, (unsigned long long)l0);
+    if (EP_BN_ABL & 4) return;      // (one atomic per channel instead of seven)
+    atomicAdd(a + 1, (unsigned long long)l1); atomicAdd(a + 2, (unsigned long long)l2);
+    bn_limbs((double)m2 + dn * dm * dm, l0, l1, l2);
+    atomicAdd(a + 3, (unsigned long long)l0); atomicAdd(a + 4, (unsigned long long)l1); atomicAdd(a + 5, (unsigned long long)l2);
+    atomicAdd(a + 6, (unsigned long long)(long long)n);
+}
+
+// the BatchNorm of channel c of the block in affine form: y = x * scale + shift
+__device__ __forceinline__ void bn_acc_affine(const long long *acc, int ld, int c, float eps, float &scale, float &shift)
+{
+    if (EP_BN_ABL & 2) { scale = 1.0f; shift = 0.0f; return; }
+    long long w[kBnWords] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < kBnCopies; ++k) {
+        const long long *a = acc + ((size_t)k * ld + c) * kBnWords;
+#pragma unroll
+        for (int j = 0; j < kBnWords; ++j) w[j] += a[j];
+    }
+    const double two40 = 1099511627776.0;
+    const double s1 = ((double)w[2] * two40 + (double)w[1]) + (double)w[0] * (1.0 / two40);
+    const double s2 = ((double)w[5] * two40 + (double)w[4]) + (double)w[3] * (1.0 / two40);
+    const double n = (double)w[6];
+    const float *gb = reinterpret_cast<const float *>(acc + (size_t)kBnCopies * ld * kBnWords);
+    const double mean = n > 0.0 ? s1 / n : 0.0;
+    double var = n > 0.0 ? s2 / n - mean * mean : 0.0;     // biased variance
+    if (var < 0.0) var = 0.0;
+    const float sc = gb[c] / sqrtf((float)var + eps);
+    scale = sc;
+    shift = gb[ld + c] - (float)mean * sc;
+}
+
+// prologue of the gather kernels: (scale, shift) of the input channels -> sAff[0 .. cpad) / sAff[cpad .. 2 cpad), from the
+// producer-finished vectors or from the accumulator block (zero beyond Cin)
+template <int THREADS>
+__device__ __forceinline__ void stage_in_affine(const ConvParams &p, float *sAff, int cpad, int tid)
+{
+    if (!p.in_scale) return;
+    for (int c = tid; c < cpad; c += THREADS) {
+        float sc = 0.0f, sh = 0.0f;
+        if (c < p.Cin) {
+            if (p.in_acc) bn_acc_affine(p.in_acc, p.in_acc_ld, p.in_acc_c0 + c, p.in_eps, sc, sh);
+            else { sc = p.in_scale[c]; sh = p.in_shift[c]; }
+        }
+        sAff[c] = sc;
+        sAff[cpad + c] = sh;
+    }
+}
+
+// producer side: one thread per channel hands over its workgroup's summary; `first` (the launch's first workgroup) also leaves
+// the BatchNorm parameters in the block
+__device__ __forceinline__ void bn_acc_publish(const ConvParams &p, int col, int copy, bool first, float n, float mean, float m2)
+{
+    bn_acc_add(p.bn_acc, p.bn_acc_ld, p.bn_acc_c0 + col, copy & (kBnCopies - 1), n, mean, m2);
+    if (first) {
+        float *gb = reinterpret_cast<float *>(p.bn_acc + (size_t)kBnCopies * p.bn_acc_ld * kBnWords);
+        gb[p.bn_acc_c0 + col] = p.bn_gamma ? p.bn_gamma[col] : 1.0f;
+        gb[p.bn_acc_ld + p.bn_acc_c0 + col] = p.bn_beta ? p.bn_beta[col] : 0.0f;
+    }
+}
 
 constexpr int kWaves = 4;
 typedef float f32x4 __attribute__((ext_vector_type(4)));

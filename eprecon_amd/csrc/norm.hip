@@ -11,6 +11,7 @@
 #include <stdlib.h>
 
 #include "common.hpp"
+#include "conv_common.hpp"
 
 namespace {
 using namespace ep;
@@ -245,6 +246,38 @@ __global__ __launch_bounds__(256) void affine_rows_kernel(const float *x, int n,
     out[(size_t)r * ld_out + c] = v;
 }
 
+// BatchNorm form (c) (csrc/conv_common.hpp): the accumulator block of a producer -> (scale, shift) vectors — the stand-alone
+// finish for consumers that do not do it in their prologue (dense-grid tile kernels, residual operands)
+__global__ __launch_bounds__(256) void bn_acc_affine_kernel(const long long *acc, int ld, int c0, int C, float eps, float *scale,
+                                                            float *shift)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float sc, sh;
+    epconv::bn_acc_affine(acc, ld, c0 + c, eps, sc, sh);
+    scale[c] = sc;
+    shift[c] = sh;
+}
+
+// ... and the materialising consumer: out = [relu](x * scale + shift), every workgroup finishing the block itself (C <= 512)
+constexpr int kAccRowsMaxC = 512;
+__global__ __launch_bounds__(256) void affine_rows_acc_kernel(const float *x, int n, int C, int ld_x, const long long *acc, int ld,
+                                                              int c0, float eps, int relu, float *out, int ld_out)
+{
+    __shared__ float sAff[2 * kAccRowsMaxC];
+    for (int c = threadIdx.x; c < C; c += 256) epconv::bn_acc_affine(acc, ld, c0 + c, eps, sAff[c], sAff[kAccRowsMaxC + c]);
+    __syncthreads();
+    // a workgroup applies them to 16 x 256 elements
+    for (int k = 0; k < 16; ++k) {
+        const size_t e = ((size_t)blockIdx.x * 16 + k) * 256 + threadIdx.x;
+        if (e >= (size_t)n * C) return;
+        const int r = (int)(e / C), c = (int)(e - (size_t)r * C);
+        float v = fmaf(x[(size_t)r * ld_x + c], sAff[c], sAff[kAccRowsMaxC + c]);
+        if (relu) v = fmaxf(v, 0.0f);
+        out[(size_t)r * ld_out + c] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void affine_rows_res_kernel(const float *x, int n, int C, int ld_x, const float *scale,
                                                               const float *shift, const float *res, int ld_res, int relu,
                                                               float *out, int ld_out)
@@ -386,6 +419,29 @@ int eprecon_affine_rows_async(const float *x, int64_t n, int channels, int ld_x,
     if (n == 0) return EPRECON_OK;
     hipLaunchKernelGGL(affine_rows_kernel, dim3((unsigned)ceil_div(n * channels, (int64_t)256)), dim3(256), 0,
                        (hipStream_t)stream, x, (int)n, channels, ld_x, scale, shift, relu, out, ld_out);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_batchnorm_acc_affine_async(const long long *acc, int acc_ld, int acc_c0, int channels, float eps, float *scale_out,
+                                       float *shift_out, void *stream)
+{
+    if (!acc || !scale_out || !shift_out || channels <= 0 || acc_c0 < 0 || acc_c0 + channels > acc_ld) return EPRECON_ERR_ARG;
+    hipLaunchKernelGGL(bn_acc_affine_kernel, dim3((unsigned)ceil_div(channels, 256)), dim3(256), 0, (hipStream_t)stream, acc, acc_ld,
+                       acc_c0, channels, eps, scale_out, shift_out);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_affine_rows_acc_async(const float *x, int64_t n, int channels, int ld_x, const long long *acc, int acc_ld, int acc_c0,
+                                  float eps, int relu, float *out, int ld_out, void *stream)
+{
+    if (!x || !out || !acc || n < 0 || channels <= 0 || channels > kAccRowsMaxC || ld_x < channels || ld_out < channels ||
+        acc_c0 < 0 || acc_c0 + channels > acc_ld || n * channels > 0x7fffffffll * 256)
+        return EPRECON_ERR_ARG;
+    if (n == 0) return EPRECON_OK;
+    hipLaunchKernelGGL(affine_rows_acc_kernel, dim3((unsigned)ceil_div(n * channels, (int64_t)4096)), dim3(256), 0,
+                       (hipStream_t)stream, x, (int)n, channels, ld_x, acc, acc_ld, acc_c0, eps, relu, out, ld_out);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }

@@ -190,7 +190,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
         conv_epilogue_ln<NT>(p, acc, rm, r32, half);
         return;
     }
-    const bool stats = p.bn_partial != nullptr;
+    const bool stats = p.bn_partial != nullptr || p.bn_acc != nullptr;
     if (stats) __syncthreads();  // every wave is done reading the weights that sStat overlays
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -254,8 +254,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
             for (int w = 0; w < kWaves; ++w)
                 chan_merge(a_n, a_mean, a_m2, sStat[(w * 3) * TN + tid], sStat[(w * 3 + 1) * TN + tid],
                            sStat[(w * 3 + 2) * TN + tid]);
-            float *dst = p.bn_partial + (size_t)partial_row * 3 * p.Cout + col0 + tid;
-            dst[0] = a_n; dst[p.Cout] = a_mean; dst[2 * p.Cout] = a_m2;
+            if (p.bn_partial) {
+                float *dst = p.bn_partial + (size_t)partial_row * 3 * p.Cout + col0 + tid;
+                dst[0] = a_n; dst[p.Cout] = a_mean; dst[2 * p.Cout] = a_m2;
+            }
+            if (p.bn_acc) bn_acc_publish(p, col0 + tid, partial_row, partial_row == 0, a_n, a_mean, a_m2);
         }
     }
 }
@@ -279,11 +282,7 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvParams p)
 
     // neighbour tile + live-offset flags
     for (int k = tid; k < p.K; k += 256) sActive[k] = 0;
-    if (p.in_scale)
-        for (int c = tid; c < cinA; c += 256) {
-            sAff[c] = c < p.Cin ? p.in_scale[c] : 0.0f;
-            sAff[cinA + c] = c < p.Cin ? p.in_shift[c] : 0.0f;
-        }
+    stage_in_affine<256>(p, sAff, cinA, tid);
     __syncthreads();
     for (int e = tid; e < p.K * kRowsPerBlock; e += 256) {
         const int k = e / kRowsPerBlock, r = e - k * kRowsPerBlock;
@@ -509,11 +508,7 @@ __global__ __launch_bounds__(256) void spconv_resident_kernel(ConvParams p, int 
     const int wrow0 = blockIdx.x * kRowsPerBlock + wave * kRowsPerWave;
     const int col0 = blockIdx.y * TN;
     const float *wbase = p.w + col0;
-    if (p.in_scale)
-        for (int c = tid; c < cin_all; c += 256) {
-            sAff[c] = c < p.Cin ? p.in_scale[c] : 0.0f;
-            sAff[cin_all + c] = c < p.Cin ? p.in_shift[c] : 0.0f;
-        }
+    stage_in_affine<256>(p, sAff, cin_all, tid);
     // the neighbour indices of the whole tile go to LDS up front: a gather then depends on ONE
     // memory latency (the rows), not two (index, then rows)
     for (int e = tid; e < p.K * kRowsPerBlock; e += 256) {
@@ -729,6 +724,12 @@ __global__ __launch_bounds__(256) void conv2d_tile_kernel(ConvParams p, int tile
     const int x0 = tx * kTileW, y0 = ty * kTileH;
     const size_t map_row0 = (size_t)map * p.img_h * p.img_w;
 
+    // (BatchNorm form (c): the input's pending BatchNorm comes as an accumulator block -> its affine form in LDS first)
+    __shared__ __attribute__((aligned(16))) float sInAff[2 * cin_pad];
+    if (p.in_acc) {
+        stage_in_affine<256>(p, sInAff, cin_pad, tid);
+        __syncthreads();
+    }
     // ---- stage the weights of all nine offsets and the halo tile; one barrier ----
     if (cin_pad == p.Cin) {
         stage_weights<TN>(sW, p.w + col0, 0, 9 * p.Cin, p.Cout, p.Cout - col0, 9 * cin_pad, tid);
@@ -758,8 +759,14 @@ __global__ __launch_bounds__(256) void conv2d_tile_kernel(ConvParams p, int tile
         const int c = c4 * 4;
         float4 v = hv[it];
         if (p.in_scale) {
-            const float4 sc = *reinterpret_cast<const float4 *>(p.in_scale + min(c, p.Cin - 4));
-            const float4 sh = *reinterpret_cast<const float4 *>(p.in_shift + min(c, p.Cin - 4));
+            float4 sc, sh;
+            if (p.in_acc) {
+                sc = *reinterpret_cast<const float4 *>(sInAff + min(c, cin_pad - 4));
+                sh = *reinterpret_cast<const float4 *>(sInAff + cin_pad + min(c, cin_pad - 4));
+            } else {
+                sc = *reinterpret_cast<const float4 *>(p.in_scale + min(c, p.Cin - 4));
+                sh = *reinterpret_cast<const float4 *>(p.in_shift + min(c, p.Cin - 4));
+            }
             v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
             v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
             if (p.in_relu) {
@@ -1467,11 +1474,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_splitk_kernel(ConvParams p)
     const int col0 = blockIdx.y * TN;
 
     for (int k = tid; k < p.K; k += THREADS) sActive[k] = 0;
-    if (p.in_scale)
-        for (int c = tid; c < cinA; c += THREADS) {
-            sAff[c] = c < p.Cin ? p.in_scale[c] : 0.0f;
-            sAff[cinA + c] = c < p.Cin ? p.in_shift[c] : 0.0f;
-        }
+    stage_in_affine<THREADS>(p, sAff, cinA, tid);
     __syncthreads();
     for (int e = tid; e < p.K * ROWS; e += THREADS) {
         const int k = e / ROWS, r = e - k * ROWS;
@@ -1827,11 +1830,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         const int row = row0 + r;
         sNbr[e] = row < p.n_out ? p.nbr[(size_t)(k0 + kk) * p.n_out + row] : -1;
     }
-    if (p.in_scale)
-        for (int c = tid; c < cinA; c += 256) {
-            sAff[c] = c < p.Cin ? p.in_scale[c] : 0.0f;
-            sAff[cinA + c] = c < p.Cin ? p.in_shift[c] : 0.0f;
-        }
+    stage_in_affine<256>(p, sAff, cinA, tid);
 
     f32x16 acc[NTT];
 #pragma unroll
@@ -2319,6 +2318,31 @@ static void params_from_desc(ConvParams &p, const eprecon_conv_desc *d)
     p.wq16 = d->packed_weight16;
     p.ws = d->workspace; p.ws_bytes = d->workspace_bytes;
     p.flex_partial = 1;
+    p.bn_acc = d->bn_acc; p.bn_acc_ld = d->bn_acc_ld; p.bn_acc_c0 = d->bn_acc_c0; p.bn_gamma = d->bn_gamma; p.bn_beta = d->bn_beta;
+    p.in_acc = d->in_acc; p.in_acc_ld = d->in_acc_ld; p.in_acc_c0 = d->in_acc_c0; p.in_eps = d->in_eps;
+}
+
+extern "C" int eprecon_batchnorm_acc_affine_async(const long long *acc, int acc_ld, int acc_c0, int channels, float eps,
+                                                  float *scale_out, float *shift_out, void *stream);
+
+// BatchNorm form (c) — which launches take part.  PRODUCER: every kernel whose summaries go through conv_epilogue or
+// direct_epilogue (all gather forms and the 2D image-tile kernel); the dense-grid 3D tile kernels keep their own epilogues.
+// CONSUMER: the same families finish the accumulators in their prologue; for the others the library queues the stand-alone
+// finish (one launch, like the finalize it replaces) into the caller's in_affine_scratch.
+static bool bn_acc_family(const ConvParams &p) { return conv3d_kind(p) == 0; }
+
+extern "C" size_t eprecon_bn_acc_words(int ld)
+{
+    return ld > 0 ? (size_t)epconv::kBnCopies * ld * epconv::kBnWords + (size_t)(2 * ld + 1) / 2 : 0;
+}
+
+extern "C" int eprecon_conv_desc_takes_bn_acc(const eprecon_conv_desc *d)
+{
+    if (!d || d->n_out <= 0) return 0;
+    ConvParams p = {};
+    params_from_desc(p, d);
+    p.n_out = (int)d->n_out;
+    return !p.ln && !p.accumulate && bn_acc_family(p) ? 1 : 0;
 }
 
 extern "C" int eprecon_conv_desc_async(const eprecon_conv_desc *d, void *stream)
@@ -2326,6 +2350,24 @@ extern "C" int eprecon_conv_desc_async(const eprecon_conv_desc *d, void *stream)
     if (!d) return EPRECON_ERR_ARG;
     ConvParams p = {};
     params_from_desc(p, d);
+    p.n_out = (int)(d->n_out > 0 && d->n_out <= 0x7fffffff ? d->n_out : 0);
+    if (p.bn_acc && (p.bn_acc_ld <= 0 || p.bn_acc_c0 < 0 || p.bn_acc_c0 + p.Cout > p.bn_acc_ld || p.ln || p.accumulate || !bn_acc_family(p)))
+        return EPRECON_ERR_ARG;        // (ask eprecon_conv_desc_takes_bn_acc first)
+    if (p.in_acc) {
+        if (p.in_scale || p.in_shift || p.in_acc_ld <= 0 || p.in_acc_c0 < 0 || p.in_acc_c0 + p.Cin > p.in_acc_ld) return EPRECON_ERR_ARG;
+        if (bn_acc_family(p)) {
+            // (the kernels test in_scale for "there is a pending BatchNorm": any non-null value; stage_in_affine reads in_acc)
+            p.in_scale = p.in_shift = reinterpret_cast<const float *>(p.in_acc);
+        } else {
+            if (!d->in_affine_scratch) return EPRECON_ERR_ARG;
+            const int rc = eprecon_batchnorm_acc_affine_async(p.in_acc, p.in_acc_ld, p.in_acc_c0, p.Cin, p.in_eps, d->in_affine_scratch,
+                                                              d->in_affine_scratch + p.Cin, stream);
+            if (rc != EPRECON_OK) return rc;
+            p.in_scale = d->in_affine_scratch;
+            p.in_shift = d->in_affine_scratch + p.Cin;
+            p.in_acc = nullptr;
+        }
+    }
     return conv_check_and_run(p, d->n_in, d->n_out, stream);
 }
 

@@ -127,7 +127,7 @@ __device__ __forceinline__ void direct_epilogue(const ConvParams &p, f32x4 (&acc
 #pragma unroll
         for (int r = 0; r < NR; ++r)
             if (colok[t] && orow[r] >= 0) p.out[(size_t)orow[r] * p.ld_out + 16 * t + l16] = v[t][r];
-    if (p.bn_partial) {  // (uniform) (count, mean, M2) of the stored values per column: rows in the lane, lane groups, waves
+    if (p.bn_partial || p.bn_acc) {  // (uniform) (count, mean, M2) of the stored values per column: rows in the lane, lane groups, waves
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
             float n = 0.0f, sum = 0.0f;
@@ -148,8 +148,11 @@ __device__ __forceinline__ void direct_epilogue(const ConvParams &p, f32x4 (&acc
             }
             if constexpr (PERWAVE) {
                 if (q == 0 && colok[t]) {
-                    float *dst = p.bn_partial + (size_t)block * 3 * p.Cout + 16 * t + l16;
-                    dst[0] = n; dst[p.Cout] = mean; dst[2 * p.Cout] = m2;
+                    if (p.bn_partial) {
+                        float *dst = p.bn_partial + (size_t)block * 3 * p.Cout + 16 * t + l16;
+                        dst[0] = n; dst[p.Cout] = mean; dst[2 * p.Cout] = m2;
+                    }
+                    if (p.bn_acc) bn_acc_publish(p, 16 * t + l16, block, block == 0, n, mean, m2);
                 }
                 continue;
             }
@@ -165,8 +168,11 @@ __device__ __forceinline__ void direct_epilogue(const ConvParams &p, f32x4 (&acc
 #pragma unroll
             for (int w = 0; w < kWaves; ++w)
                 chan_merge(a_n, a_mean, a_m2, sStat[(w * 3) * 16 * CT + tid], sStat[(w * 3 + 1) * 16 * CT + tid], sStat[(w * 3 + 2) * 16 * CT + tid]);
-            float *dst = p.bn_partial + (size_t)blockIdx.x * 3 * p.Cout + tid;
-            dst[0] = a_n; dst[p.Cout] = a_mean; dst[2 * p.Cout] = a_m2;
+            if (p.bn_partial) {
+                float *dst = p.bn_partial + (size_t)blockIdx.x * 3 * p.Cout + tid;
+                dst[0] = a_n; dst[p.Cout] = a_mean; dst[2 * p.Cout] = a_m2;
+            }
+            if (p.bn_acc) bn_acc_publish(p, tid, (int)blockIdx.x, blockIdx.x == 0, a_n, a_mean, a_m2);
         }
     }
 }
@@ -271,11 +277,7 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
     const int l16 = lane & 15, q = lane >> 4;
     const int row0 = (int)blockIdx.x * ROWS;
 
-    if (p.in_scale)
-        for (int c = tid; c < cpad; c += 256) {
-            sAff[c] = c < p.Cin ? p.in_scale[c] : 0.0f;
-            sAff[cpad + c] = c < p.Cin ? p.in_shift[c] : 0.0f;
-        }
+    stage_in_affine<256>(p, sAff, cpad, tid);
     // Offsets none of the wave's 32 rows has a neighbour at are skipped altogether (no gathers, no weight loads, no MFMAs):
     // an output-stationary kernel otherwise multiplies zeros for every missing neighbour.  On the surface-shaped sets of a
     // fragment 12-25 % of the (32-row, offset) groups are dead; on the second voxelisation of ConvGRU's convr — already
@@ -527,11 +529,7 @@ __global__ __launch_bounds__(64 * kPersistWaves) void spconv_persist16_kernel(Co
             sW[e] = r < CTM * 64 ? wm[(size_t)blk * CT * 64 + r] : wt[(size_t)blk * 32 + (r - CTM * 64)];
         }
     }
-    if (p.in_scale)
-        for (int c = tid; c < cpad; c += 64 * kPersistWaves) {
-            sAff[c] = c < p.Cin ? p.in_scale[c] : 0.0f;
-            sAff[cpad + c] = c < p.Cin ? p.in_shift[c] : 0.0f;
-        }
+    stage_in_affine<64 * kPersistWaves>(p, sAff, cpad, tid);
     __syncthreads();
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
@@ -758,11 +756,7 @@ __global__ __launch_bounds__(256) void spconv_direct16_generic_kernel(ConvParams
     const int l16 = lane & 15, q = lane >> 4;
     const int row0 = (int)blockIdx.x * ROWS;
 
-    if (p.in_scale)
-        for (int c = tid; c < cpad; c += 256) {
-            sAff[c] = c < p.Cin ? p.in_scale[c] : 0.0f;
-            sAff[cpad + c] = c < p.Cin ? p.in_shift[c] : 0.0f;
-        }
+    stage_in_affine<256>(p, sAff, cpad, tid);
     // (live offsets of the wave's 32 rows: see the template kernel)
     const unsigned live = stage_map(p, row0, sNbr, sFlag, tid);
 

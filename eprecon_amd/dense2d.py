@@ -81,15 +81,100 @@ def packed_weight(conv):
 DIRECT_2D_MIN_ROWS = 100000
 
 
+# EPRECON_BN_ACC=1: the BatchNorms of the 2D fusion stack finished by their CONSUMERS from order-independent integer accumulators
+# (round 6, csrc/conv_common.hpp "BatchNorm form (c)") instead of by a finalize launch behind every layer.  Built, parity-green,
+# deterministic — and SLOWER on this part, hence opt-in: cfg2 1.823 ms against 1.600 (profiles/r06/bn_acc_ab.txt).  Device-scope
+# atomics cost 37 us per step for every int64 word a workgroup adds per channel (seven words here: +0.26 ms), and even with
+# the atomics compiled out (wrong results, timing only) the step takes 1.56 ms: the 37 finalize launches it removes were worth
+# 0.04 ms, not the 0.2 ms their summed durations suggest (three branches of the stack run side by side).
+BN_ACC = os.environ.get("EPRECON_BN_ACC", "0") == "1"
+
+
+class BnArena:
+    """The accumulator blocks of ONE pass over a stack of layers: carved out of one int64 buffer that a single fill zeroes
+    at the start of the pass (`begin`).  A block must be zero before its producer runs and is read by every consumer of the
+    layer, so blocks are never reused inside a pass; the next pass reuses the same addresses (HIP-graph replays included:
+    the fill is part of the captured pass)."""
+
+    def __init__(self, device, words=1 << 19):
+        self.buf = torch.zeros(words, dtype=torch.int64, device=device)
+        self.offset = 0
+        self.high = words          # extent to clear at the next begin(): everything the first time
+
+    def begin(self):
+        if self.high:
+            self.buf[:self.high].zero_()
+        self.offset = 0
+        self.high = 0
+
+    def take(self, words):
+        words = (words + 1) & ~1          # 16-byte aligned blocks
+        if self.offset + words > self.buf.numel():
+            raise _lib.EpreconError("BatchNorm accumulator arena exhausted (eprecon_amd.dense2d.BnArena)")
+        t = self.buf[self.offset:self.offset + words]
+        self.offset += words
+        self.high = max(self.high, self.offset)
+        return t
+
+
+_ARENA = None     # the arena of the pass being issued (set by `bn_pass`); None: BatchNorms are finished by finalize launches
+
+
+class bn_pass:
+    """with bn_pass(arena): the layers issued inside leave their BatchNorms in accumulator blocks of `arena` (zeroed here)"""
+
+    def __init__(self, arena):
+        self.arena = arena
+
+    def __enter__(self):
+        global _ARENA
+        self.prev, _ARENA = _ARENA, self.arena
+        if self.arena is not None:
+            self.arena.begin()
+        return self.arena
+
+    def __exit__(self, *exc):
+        global _ARENA
+        _ARENA = self.prev
+        return False
+
+
+class AccSlice:
+    """channels [c0, c0 + c) of an accumulator block of `ld` channels (`block`: the int64 tensor)"""
+    __slots__ = ("block", "ld", "c0", "c")
+
+    def __init__(self, block, ld, c0, c):
+        self.block, self.ld, self.c0, self.c = block, ld, c0, c
+
+    @classmethod
+    def new(cls, channels):
+        words = int(_lib.load().eprecon_bn_acc_words(channels))
+        return cls(_ARENA.take(words), channels, 0, channels)
+
+    def part(self, a, b):
+        return AccSlice(self.block, self.ld, self.c0 + a, b - a)
+
+
 class Act:
     """An activation of the 2D stack: rows f32[N, C] (possibly a channel slice of a concat buffer) plus
-    the BatchNorm of its producer still pending in affine form (scale, shift f32[C], ReLU flag).  The
-    stored rows are the un-normalised convolution output; consumers apply the affine while gathering.
-    scale is None for a materialised tensor."""
-    __slots__ = ("rows", "scale", "shift", "relu")
+    the BatchNorm of its producer still pending — in affine form (scale, shift f32[C], ReLU flag) or, round 6, as the
+    accumulator block its producer summed into (acc: AccSlice, eps).  The stored rows are the un-normalised convolution
+    output; consumers apply the BatchNorm while gathering.  scale and acc are None for a materialised tensor."""
+    __slots__ = ("rows", "scale", "shift", "relu", "acc", "eps")
 
-    def __init__(self, rows, scale=None, shift=None, relu=False):
-        self.rows, self.scale, self.shift, self.relu = rows, scale, shift, relu
+    def __init__(self, rows, scale=None, shift=None, relu=False, acc=None, eps=1e-5):
+        self.rows, self.scale, self.shift, self.relu, self.acc, self.eps = rows, scale, shift, relu, acc, eps
+
+    def affine(self):
+        """(scale, shift) vectors of a pending BatchNorm held as accumulators: one launch (consumers that cannot finish the
+        block themselves: residual operands)"""
+        if self.acc is not None and self.scale is None:
+            a = torch.empty((2, self.acc.c), dtype=torch.float32, device=self.rows.device)
+            _lib.check(_lib.load().eprecon_batchnorm_acc_affine_async(
+                self.acc.block.data_ptr(), self.acc.ld, self.acc.c0, self.acc.c, float(self.eps), a[0].data_ptr(), a[1].data_ptr(),
+                _lib.current_stream()), "eprecon_batchnorm_acc_affine_async")
+            self.scale, self.shift = a[0], a[1]
+        return self.scale, self.shift
 
 
 def _dptr(t):
@@ -116,9 +201,6 @@ def conv_bn_launch(w, bias, gamma, beta, eps, k, x, grid, out=None, aff=None, re
     nbr = grid.kernel_map(k)
     if out is None:
         out = torch.empty((n, cout), dtype=torch.float32, device=dev)
-    if aff is None:
-        a = torch.empty((2, cout), dtype=torch.float32, device=dev)
-        aff = (a[0], a[1])
     d = _lib.ConvDesc()
     d.x, d.n_in, d.ld_x = rows.data_ptr(), n, rows.stride(0)
     d.nbr, d.kvol, d.n_out = _dptr(nbr), kvol, n
@@ -127,10 +209,16 @@ def conv_bn_launch(w, bias, gamma, beta, eps, k, x, grid, out=None, aff=None, re
     if residual is not None:
         assert residual.rows.shape == (n, cout)
         d.residual, d.ld_res = residual.rows.data_ptr(), residual.rows.stride(0)
-        d.res_scale, d.res_shift, d.res_relu = _dptr(residual.scale), _dptr(residual.shift), int(residual.relu)
+        r_scale, r_shift = residual.affine()
+        d.res_scale, d.res_shift, d.res_relu = _dptr(r_scale), _dptr(r_shift), int(residual.relu)
     d.out, d.ld_out = out.data_ptr(), out.stride(0)
     d.relu, d.accumulate = int(pre_relu), 0
-    d.in_scale, d.in_shift, d.in_relu = _dptr(x.scale), _dptr(x.shift), int(x.relu)
+    if x.acc is not None and x.scale is None:     # the input's BatchNorm is finished by this launch's prologue
+        assert x.acc.c == cin
+        d.in_acc, d.in_acc_ld, d.in_acc_c0, d.in_eps = x.acc.block.data_ptr(), x.acc.ld, x.acc.c0, float(x.eps)
+    else:
+        d.in_scale, d.in_shift = _dptr(x.scale), _dptr(x.shift)
+    d.in_relu = int(x.relu)
     if k == 3:
         d.img_h, d.img_w, d.img_maps = grid.height, grid.width, grid.maps  # narrow layers: image-tile kernel
         if n < DIRECT_2D_MIN_ROWS:
@@ -139,6 +227,18 @@ def conv_bn_launch(w, bias, gamma, beta, eps, k, x, grid, out=None, aff=None, re
         if cout <= SP.DIRECT_MAX_COUT and n >= DIRECT_2D_MIN_ROWS:
             pw = SP.packed_weight16(w)               # long pixel lists: the direct gather kernel on the pixel map
             d.packed_weight16 = pw.data_ptr()
+    if _ARENA is not None and (aff is None or isinstance(aff, AccSlice)) and lib.eprecon_conv_desc_takes_bn_acc(ctypes.byref(d)):
+        # the launch sums into an accumulator block; whoever consumes the result finishes the BatchNorm: no finalize launch
+        acc = aff if aff is not None else AccSlice.new(cout)
+        assert acc.c == cout
+        d.bn_acc, d.bn_acc_ld, d.bn_acc_c0 = acc.block.data_ptr(), acc.ld, acc.c0
+        d.bn_gamma, d.bn_beta = _dptr(gamma), _dptr(beta)
+        _lib.check(lib.eprecon_conv_desc_async(ctypes.byref(d), _lib.current_stream()), "eprecon_conv_desc_async")
+        return Act(out, relu=relu, acc=acc, eps=eps)
+    if aff is None:
+        a = torch.empty((2, cout), dtype=torch.float32, device=dev)
+        aff = (a[0], a[1])
+    assert not isinstance(aff, AccSlice), "an accumulator slice was handed to a launch that cannot produce into it"
     # the summaries are per workgroup: 128-row blocks (gather forms) or image tiles (tile kernel)
     partial = torch.empty((lib.eprecon_conv_desc_partial_rows(ctypes.byref(d)), 3, cout), dtype=torch.float32, device=dev)
     d.bn_partial = partial.data_ptr()
@@ -151,7 +251,7 @@ def conv_bn_launch(w, bias, gamma, beta, eps, k, x, grid, out=None, aff=None, re
 
 def materialize(act, out=None):
     """apply the pending BatchNorm (+ReLU): returns plain rows"""
-    if act.scale is None:
+    if act.scale is None and act.acc is None:
         if out is not None and out.data_ptr() != act.rows.data_ptr():
             out.copy_(act.rows)
             return out
@@ -160,6 +260,12 @@ def materialize(act, out=None):
     n, c = rows.shape
     if out is None:
         out = torch.empty((n, c), dtype=torch.float32, device=rows.device)
+    if act.scale is None and c <= 512:      # every workgroup finishes the accumulator block itself: one launch
+        _lib.check(_lib.load().eprecon_affine_rows_acc_async(
+            rows.data_ptr(), n, c, rows.stride(0), act.acc.block.data_ptr(), act.acc.ld, act.acc.c0, float(act.eps), int(act.relu),
+            out.data_ptr(), out.stride(0), _lib.current_stream()), "eprecon_affine_rows_acc_async")
+        return out
+    act.affine()
     _lib.check(_lib.load().eprecon_affine_rows_async(
         rows.data_ptr(), n, c, rows.stride(0), act.scale.data_ptr(), act.shift.data_ptr(), int(act.relu),
         out.data_ptr(), out.stride(0), _lib.current_stream()), "eprecon_affine_rows_async")

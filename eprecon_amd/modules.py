@@ -362,9 +362,15 @@ class ELAN(nn.Module):
         h = d // 2
         dev = x.rows.device
         cat = torch.empty((x.rows.shape[0], 4 * d), dtype=torch.float32, device=dev)
-        aff = torch.empty((2, 4 * d), dtype=torch.float32, device=dev)
-        part = lambda a, b: D2.Act(cat[:, a:b], aff[0, a:b], aff[1, a:b], True)
-        sl = lambda a, b: dict(out=cat[:, a:b], aff=(aff[0, a:b], aff[1, a:b]))
+        if D2._ARENA is not None:      # BatchNorm form (c): one accumulator block for the concat buffer, a slice per branch
+            acc = D2.AccSlice.new(4 * d)
+            eps = self.conv1.bn.eps
+            part = lambda a, b: D2.Act(cat[:, a:b], relu=True, acc=acc.part(a, b), eps=eps)
+            sl = lambda a, b: dict(out=cat[:, a:b], aff=acc.part(a, b))
+        else:
+            aff = torch.empty((2, 4 * d), dtype=torch.float32, device=dev)
+            part = lambda a, b: D2.Act(cat[:, a:b], aff[0, a:b], aff[1, a:b], True)
+            sl = lambda a, b: dict(out=cat[:, a:b], aff=(aff[0, a:b], aff[1, a:b]))
         self.conv1.run_act(x, grid, **sl(0, d))
         self.conv2.run_act(x, grid, **sl(d, 2 * d))
         self.conv3.run_act(part(d, 2 * d), grid, **sl(2 * d, 2 * d + h))

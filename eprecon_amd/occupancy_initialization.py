@@ -60,6 +60,7 @@ class Occupancy_Initialization(nn.Module):
         self.use_hip_conv = os.environ.get("EPRECON_MIOPEN_CONV2D", "0") != "1"
         self._channels_last = False
         self._side_streams = None
+        self._bn_arena = None       # accumulator blocks of the 2D stack's BatchNorms (dense2d.BnArena), one per module
 
     def feat_fusion_pre(self, feats_1x, feats_2x, feats_4x):
         """[V,80,H/16,W/16], [V,40,H/8,W/8], [V,24,H/4,W/4] -> [V,32,H/8,W/8]  (:41-58)"""
@@ -102,22 +103,27 @@ class Occupancy_Initialization(nn.Module):
         if self._side_streams is None:
             self._side_streams = (_lib.side_stream(dev, _lib.SIDE_BRANCH_A), _lib.side_stream(dev, _lib.SIDE_BRANCH_B))
         s1, s4 = self._side_streams
-        s1.wait_stream(main)
-        s4.wait_stream(main)
-        with torch.cuda.stream(s4):
-            f4 = self.self_fusion_4x.run_rows(rows[2], g4)
-            cat[:, c1 + c2:] = D2.rows_of(self.pool4x(D2.maps_of(f4, g4.maps, g4.height, g4.width)))
-        with torch.cuda.stream(s1):
-            f1 = self.self_fusion_1x.run_rows(rows[0], g1)
-            up = upsample2x_bilinear(D2.maps_of(f1, g1.maps, g1.height, g1.width))
-            cat[:, 0:c1] = D2.rows_of(up)
-        self.self_fusion_2x.run_rows(rows[1], g2, out=cat[:, c1:c1 + c2])
-        main.wait_stream(s1)
-        main.wait_stream(s4)
-        a = self.fusion_down.run_act(D2.Act(cat), g2)
-        for blk in (self.post_fusion_1, self.post_fusion_2, self.post_fusion_3, self.post_fusion_4):
-            a = blk.run_act(a, g2)
-        return D2.maps_of(D2.materialize(a), g2.maps, g2.height, g2.width)
+        # BatchNorm form (c) (round 6): the 36 layers of the pass leave their BatchNorm sums in accumulator blocks of ONE arena,
+        # zeroed here by one fill in front of the fork; no finalize launch between two layers (EPRECON_BN_ACC=0: as before)
+        if D2.BN_ACC and self._bn_arena is None:
+            self._bn_arena = D2.BnArena(dev)
+        with D2.bn_pass(self._bn_arena if D2.BN_ACC else None):
+            s1.wait_stream(main)
+            s4.wait_stream(main)
+            with torch.cuda.stream(s4):
+                f4 = self.self_fusion_4x.run_rows(rows[2], g4)
+                cat[:, c1 + c2:] = D2.rows_of(self.pool4x(D2.maps_of(f4, g4.maps, g4.height, g4.width)))
+            with torch.cuda.stream(s1):
+                f1 = self.self_fusion_1x.run_rows(rows[0], g1)
+                up = upsample2x_bilinear(D2.maps_of(f1, g1.maps, g1.height, g1.width))
+                cat[:, 0:c1] = D2.rows_of(up)
+            self.self_fusion_2x.run_rows(rows[1], g2, out=cat[:, c1:c1 + c2])
+            main.wait_stream(s1)
+            main.wait_stream(s4)
+            a = self.fusion_down.run_act(D2.Act(cat), g2)
+            for blk in (self.post_fusion_1, self.post_fusion_2, self.post_fusion_3, self.post_fusion_4):
+                a = blk.run_act(a, g2)
+            return D2.maps_of(D2.materialize(a), g2.maps, g2.height, g2.width)
 
     def _fusion_graphed(self, views):
         """feat_fusion_pre through a captured HIP graph (inference only; the result buffer is reused

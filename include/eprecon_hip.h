@@ -296,7 +296,30 @@ typedef struct eprecon_conv_desc {
      * packed_weight): eprecon_conv_desc_workspace_bytes(desc) bytes (0: none needed); without it those shapes stay on the
      * short-list kernel */
     void *workspace; size_t workspace_bytes;
+    /* BatchNorm of the OUTPUT without a finalize launch (round 6; replaces bn_partial + eprecon_batchnorm_finalize_affine_async
+     * between two layers, models/modules.py:15-29,313-399): the launch adds per-channel sums of the stored values to an
+     * accumulator block with order-independent 64-bit integer atomics (exact fixed-point limbs: deterministic), and the
+     * consumer of this layer's output names the block as in_acc and finishes it in its prologue.  A block of `ld` channels is
+     * int64[eprecon_bn_acc_words(ld)]: int64[8][ld][7] sums, ZEROED by the caller before the producer runs, followed by
+     * float[2][ld] (gamma, beta: the producer copies bn_gamma / bn_beta there; NULL = 1 / 0); bn_acc_c0 = first channel of
+     * this layer inside the block (layers writing channel slices of one concatenated activation share a block).  Only for
+     * launches eprecon_conv_desc_takes_bn_acc() accepts (no ln / accumulate, not the dense-grid 3D tile kernels). */
+    long long *bn_acc; int bn_acc_ld; int bn_acc_c0; const float *bn_gamma; const float *bn_beta;
+    /* ... and of the INPUT: the block the producer(s) of x filled, instead of in_scale / in_shift (in_relu still applies);
+     * in_affine_scratch float[2 * cin]: where the library finishes the block with a launch of its own for the kernels that do
+     * not do it in their prologue */
+    const long long *in_acc; int in_acc_ld; int in_acc_c0; float in_eps; float *in_affine_scratch;
 } eprecon_conv_desc;
+/* int64 words of an accumulator block of `ld` channels (sums + the two parameter vectors) */
+size_t eprecon_bn_acc_words(int ld);
+/* 1 when the launch described by desc can produce into bn_acc (ask before setting it) */
+int eprecon_conv_desc_takes_bn_acc(const eprecon_conv_desc *desc);
+/* a block -> (scale, shift) vectors of `channels` channels from acc_c0 on: the stand-alone finish */
+int eprecon_batchnorm_acc_affine_async(const long long *acc, int acc_ld, int acc_c0, int channels, float eps, float *scale_out,
+                                       float *shift_out, void *stream);
+/* out[i, c] = [relu]( x[i, c] * scale[c] + shift[c] ) with (scale, shift) finished from a block by every workgroup (channels <= 512) */
+int eprecon_affine_rows_acc_async(const float *x, int64_t n, int channels, int ld_x, const long long *acc, int acc_ld, int acc_c0,
+                                  float eps, int relu, float *out, int ld_out, void *stream);
 int eprecon_conv_desc_async(const eprecon_conv_desc *desc, void *stream);
 size_t eprecon_conv_desc_workspace_bytes(const eprecon_conv_desc *desc);
 /* number of bn_partial rows the launch described by desc writes (nblk of the finalize call) */

@@ -59,6 +59,60 @@ def test_fused_conv_epilogues(v, h, w, ci, co, k):
     assert torch.equal(out, out2) and torch.equal(partial, partial2)
 
 
+@pytest.fixture(autouse=True, params=["finalize", "acc"])
+def bn_mode(request):
+    """every test of the rows path runs twice: with a finalize launch behind every layer (rounds 1-5) and with the layers'
+    BatchNorms left in order-independent accumulator blocks that their consumers finish (round 6: BatchNorm form (c))"""
+    from eprecon_amd import dense2d as D2
+    if request.param == "finalize":
+        old, D2.BN_ACC = D2.BN_ACC, False
+        try:
+            yield request.param
+        finally:
+            D2.BN_ACC = old
+    else:
+        with D2.bn_pass(D2.BnArena(_dev())):
+            yield request.param
+
+
+def test_accumulator_blocks_give_the_finalize_launch_result_and_the_same_bits_every_run():
+    """form (c) against the Chan-merged summaries of the same launch: (scale, shift) of one 3x3 layer on 43,200 pixel rows
+    agree to fp32 round-off; two runs of the whole accumulating 2D stack are bit-identical (integer atomics commute)"""
+    import ctypes
+    from eprecon_amd import _lib, dense2d as D2, sparse as SP
+    from eprecon_amd.modules import Conv2d_Block
+    from eprecon_amd.occupancy_initialization import Occupancy_Initialization
+    dev = _dev()
+    torch.manual_seed(5)
+    blk = Conv2d_Block(32, 32, 3).to(dev).train()
+    blk.bn.weight.data.uniform_(0.5, 1.5)
+    blk.bn.bias.data.uniform_(-1, 1)
+    x = torch.randn(9, 32, 60, 80, device=dev) * 3 + 7        # a mean well away from zero
+    g = D2.PixelGrid.get(9, 60, 80, dev)
+    with torch.no_grad():
+        with D2.bn_pass(D2.BnArena(dev)):
+            a = blk.run_act(D2.Act(D2.rows_of(_cl(x))), g)
+            assert a.acc is not None and a.scale is None
+            sc, sh = a.affine()
+        with D2.bn_pass(None):
+            b = blk.run_act(D2.Act(D2.rows_of(_cl(x))), g)
+        assert torch.equal(a.rows, b.rows)
+        assert (sc - b.scale).abs().max().item() < 1e-5 * b.scale.abs().max().item() + 1e-7
+        assert (sh - b.shift).abs().max().item() < 1e-5 * b.shift.abs().max().item() + 1e-6
+        ref = blk(x)
+        assert (D2.maps_of(D2.materialize(a), 9, 60, 80) - ref).abs().max().item() < TOL
+        net = Occupancy_Initialization([80, 40, 24], 32, 9).to(dev).train()
+        net.use_hip_graph = False
+        f = [torch.randn(9, 80, 15, 20, device=dev), torch.randn(9, 40, 30, 40, device=dev), torch.randn(9, 24, 60, 80, device=dev)]
+        old, D2.BN_ACC = D2.BN_ACC, True
+        try:
+            r1 = net.feat_fusion_pre(*f).clone()
+            r2 = net.feat_fusion_pre(*f).clone()
+        finally:
+            D2.BN_ACC = old
+        assert torch.equal(r1, r2)
+
+
 @pytest.mark.parametrize("c,h,w", [(24, 30, 40), (40, 15, 20), (80, 8, 10)])
 def test_fusion_block_rows(c, h, w):
     from eprecon_amd import dense2d as D2
