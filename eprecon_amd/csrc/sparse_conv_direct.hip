@@ -250,12 +250,10 @@ struct LiveCursor {
 };
 
 // chunks per stage for a layer of KCH chunks: the stages of an offset are KCH / G
-constexpr int stage_chunks(int kch) { return kch % 3 == 0 ? 3 : (kch % 2 == 0 ? 2 : 1); }
-// ... of the TAIL form: its stage carries 8 more B registers per chunk (A/B-ed by the build: -DEP_TAIL_STAGE=1 one chunk per stage)
-#ifndef EP_TAIL_STAGE
-#define EP_TAIL_STAGE 0
+#ifndef EP_STAGE_CAP       // (probe builds: -DEP_STAGE_CAP=2 / 1 caps the chunks per stage — fewer registers, more waves per SIMD)
+#define EP_STAGE_CAP 3
 #endif
-#define EP_TAIL_G(kch) (EP_TAIL_STAGE == 1 ? 1 : (EP_TAIL_STAGE == 2 ? ((kch) % 2 == 0 ? 2 : 1) : stage_chunks(kch)))
+constexpr int stage_chunks(int kch) { return kch % 3 == 0 && EP_STAGE_CAP >= 3 ? 3 : (kch % 2 == 0 && EP_STAGE_CAP >= 2 ? 2 : 1); }
 
 // TAIL: the last column tile holds <= 8 columns and runs on the 4x4x1 MFMAs (tail_to_tile above); its B operands are the tail
 // section of the packing (pack_weights16_kernel: behind the CT tiles, 512 B per (offset, chunk)).
@@ -895,6 +893,13 @@ static bool tail8_enabled()
     return !(e && e[0] == '0');
 }
 
+// EPRECON_CONV_STAGE_DEPTH=0: always the deepest prefetch stage (the round-5 rule; read per launch)
+static bool stage_depth_enabled()
+{
+    const char *e = getenv("EPRECON_CONV_STAGE_DEPTH");
+    return !(e && e[0] == '0');
+}
+
 constexpr size_t kLdsBytes = 160 * 1024;
 
 static size_t persist_lds_bytes(const ConvParams &p)
@@ -978,10 +983,42 @@ int launch_k(const ConvParams &p, hipStream_t st)
         }
     }
     const dim3 grid((unsigned)ceil_div(p.n_out, kDirectRows));
-    if (rem <= 8 && tail8_enabled()) {
-        hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH, true, EP_TAIL_G(KCH)>), grid, dim3(256), lds, st, p);
+    const bool tail = rem <= 8 && tail8_enabled();
+    // Medium lists (a few workgroups per CU): the kernel's registers allow two workgroups per CU for the wide layers (96 -> 48,
+    // 48 -> 48: three chunks per stage), so 583 workgroups (74,568 rows) run as one full wave of 512 and a second one that is
+    // 14 % full.  The same kernel with FEWER chunks per stage (kAltG: fewer prefetch registers, one more workgroup per CU) is
+    // ~6 % slower per workgroup and holds them all at once: 96 -> 48 on 74,568 rows 246 -> 199 us, 48 -> 48 on 93,513 rows
+    // 139 -> 116 us (profiles/r06/conv_stage_depth_ab.txt).  Chosen per launch from the two forms' occupancies.
+    constexpr int G0 = stage_chunks(KCH), kAltG = KCH == 6 ? 2 : (KCH == 3 ? 1 : 0);
+    if constexpr (kAltG != 0) {
+        static int occ[2][2] = {{0, 0}, {0, 0}};      // [tail][primary, alternative] workgroups per CU
+        int *o = occ[tail ? 1 : 0];
+        if (!o[0]) {
+            const void *kp = tail ? reinterpret_cast<const void *>(spconv_direct16_kernel<CT, KCH, true, G0>)
+                                  : reinterpret_cast<const void *>(spconv_direct16_kernel<CT, KCH, false, G0>);
+            const void *ka = tail ? reinterpret_cast<const void *>(spconv_direct16_kernel<CT, KCH, true, kAltG>)
+                                  : reinterpret_cast<const void *>(spconv_direct16_kernel<CT, KCH, false, kAltG>);
+            int a = 0, b = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, kp, 256, lds) != hipSuccess || a <= 0) a = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ka, 256, lds) != hipSuccess || b <= 0) b = a;
+            o[1] = b;
+            o[0] = a;
+        }
+        const int64_t wgs = grid.x, cus = device_cus();
+        // waves of workgroups x workgroups sharing a SIMD: what a launch costs in units of one workgroup running alone
+        const double cost_p = (double)ceil_div(wgs, cus * o[0]) * o[0];
+        const double cost_a = (double)ceil_div(wgs, cus * o[1]) * o[1] * 1.06;
+        if (stage_depth_enabled() && o[1] > o[0] && cost_a < 0.85 * cost_p) {
+            if (tail) hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH, true, kAltG>), grid, dim3(256), lds, st, p);
+            else hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH, false, kAltG>), grid, dim3(256), lds, st, p);
+            EP_LAUNCH_CHECK();
+            return EPRECON_OK;
+        }
+    }
+    if (tail) {
+        hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH, true, G0>), grid, dim3(256), lds, st, p);
     } else {
-        hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH, false>), grid, dim3(256), lds, st, p);
+        hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH, false, G0>), grid, dim3(256), lds, st, p);
     }
     EP_LAUNCH_CHECK();
     return EPRECON_OK;

@@ -329,6 +329,29 @@ def test_direct_kernel_forms_agree(monkeypatch, form, cin, cout):
         assert np.array_equal(y1, y2)
 
 
+@pytest.mark.parametrize("cin,cout", [(96, 48), (48, 48), (48, 24), (80, 40)])
+def test_stage_depth_rule_changes_the_schedule_not_the_bits(monkeypatch, cin, cout):
+    """Round 6: on medium lists (a few workgroups per CU) the direct kernel runs with fewer chunks per prefetch stage when that
+    lets one more workgroup share a CU and saves a wave of workgroups (70,001 rows = 547 workgroups against 512 slots).  The
+    arithmetic and its order are the same: bit-identical to EPRECON_CONV_STAGE_DEPTH=0."""
+    from eprecon_amd import sparse as SP
+    rng = np.random.default_rng(cin + cout)
+    c = random_coords(rng, 70001, extent=40, batch=1)
+    n = len(c)
+    vs = SP.VoxelSet(dev(c))
+    nbr_d = vs.kernel_map(3)
+    x = dev(rng.standard_normal((n, cin)).astype(np.float32))
+    w = dev((rng.standard_normal((27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32))
+    (y0, p0), name = _last_conv_kernel((27, cin, cout, 1000), lambda: SP.conv_stats(x, w, nbr_d))
+    assert name == "spconv_direct16_kernel"
+    monkeypatch.setenv("EPRECON_CONV_STAGE_DEPTH", "0")
+    y1, p1 = SP.conv_stats(x, w, nbr_d)
+    assert torch.equal(y0, y1) and torch.equal(p0, p1)
+    ref = OS.sparse_conv(x.cpu().numpy()[:4000 * 0 + n], OS.kernel_map(c, c, 3, 1), w.cpu().numpy()) if cin == 48 and cout == 24 else None
+    if ref is not None:
+        assert np.abs(y0.cpu().numpy() - ref).max() < TOL
+
+
 @pytest.mark.parametrize("n,cin,cout", [(204, 64, 128), (204, 128, 128), (1532, 160, 96), (1532, 64, 64), (1532, 32, 64),
                                         (7561, 32, 32), (9415, 192, 96)])
 def test_short_list_kernel(monkeypatch, n, cin, cout):
