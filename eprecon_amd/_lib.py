@@ -52,6 +52,7 @@ SIGNATURES = {
     "eprecon_sparse_conv_fused_async": (_i, [_vp, _i64, _i, _vp, _i, _i64, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i,
                                              _vp, _vp]),
     "eprecon_conv_desc_async": (_i, [_vp, _vp]),
+    "eprecon_exclusive_scan_async": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "eprecon_conv_desc_partial_rows": (_i64, [_vp]),
     "eprecon_bn_acc_words": (_sz, [_i]),
     "eprecon_conv_desc_takes_bn_acc": (_i, [_vp]),

@@ -12,6 +12,8 @@
 // insert (atomicCAS on the key, atomicMin on the row index), whose result is order-independent.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "hashgrid.hpp"
 
 namespace {
@@ -133,53 +135,161 @@ __global__ __launch_bounds__(kScanBlock) void scan_apply(const int32_t *in, int 
     }
 }
 
-// short inputs: the whole scan in ONE workgroup (1024 threads x 8 items per round, carry between rounds): one launch
-// instead of three for the many scans over a few thousand elements of the voxelisation / union bookkeeping
+// short inputs: the whole scan in ONE workgroup and (round 6) ONE pass: 1024 threads x ITEMS items held in registers (8 / 16 /
+// 32 by length), one barrier — the carried rounds of the first form (8 items per thread and round, two barriers each) made a
+// 32,768-element scan a chain of four round trips: 12 us per launch, 21 launches per cfg4 fragment
 constexpr int kSmallScanMax = 32768;
+template <int ITEMS>
 __global__ __launch_bounds__(1024) void scan_small_kernel(const int32_t *in, int n, int32_t *out, int32_t *total,
                                                           const int32_t *n_dev)
 {
     __shared__ int sWave[1024 / kWave];
     if (n_dev) n = min(n, *n_dev);
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
-    int carry = 0;
-    for (int base = 0; base < n; base += 1024 * kScanItems) {
-        const int b0 = base + tid * kScanItems;  // blocked arrangement
-        int v[kScanItems];
-        int s = 0;
+    const int b0 = tid * ITEMS;  // blocked arrangement
+    int v[ITEMS];
+    int s = 0;
+    if (b0 + ITEMS <= n && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
 #pragma unroll
-        for (int k = 0; k < kScanItems; ++k) {
-            v[k] = (b0 + k < n) ? in[b0 + k] : 0;
-            s += v[k];
+        for (int k = 0; k < ITEMS; k += 4) {
+            const int4 q = *reinterpret_cast<const int4 *>(in + b0 + k);
+            v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
         }
-        int x = s;
+    } else {
 #pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const int y = __shfl_up(x, d);
-            if (lane >= d) x += y;
-        }
-        if (lane == kWave - 1) sWave[wid] = x;
-        __syncthreads();
-        int woff = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < 1024 / kWave; ++w) {
-            const int c = sWave[w];
-            woff += (w < wid) ? c : 0;
-            tot += c;
-        }
-        int off = carry + woff + x - s;
-#pragma unroll
-        for (int k = 0; k < kScanItems; ++k) {
-            if (b0 + k < n) out[b0 + k] = off;
-            off += v[k];
-        }
-        carry += tot;
-        __syncthreads();
+        for (int k = 0; k < ITEMS; ++k) v[k] = (b0 + k < n) ? in[b0 + k] : 0;
     }
-    if (tid == 0 && total) *total = carry;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) s += v[k];
+    int x = s;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    if (lane == kWave - 1) sWave[wid] = x;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 1024 / kWave; ++w) {
+        const int c = sWave[w];
+        woff += (w < wid) ? c : 0;
+        tot += c;
+    }
+    int off = woff + x - s;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        if (b0 + k < n) out[b0 + k] = off;
+        off += v[k];
+    }
+    if (tid == 0 && total) *total = tot;
+}
+
+// ---- long inputs in ONE launch (round 6): decoupled look-back -------------------------------------------------------------
+// A tile (256 threads x 8 items) takes its index from a device counter (tiles start in index order, so every predecessor of a
+// running tile has started: the look-back cannot wait for a workgroup that is not scheduled), publishes its total as
+// {1, sum}, sums its predecessors' words 64 at a time with one wave until it meets an inclusive prefix {2, ...}, publishes its
+// own inclusive prefix and scans its items behind that base.  One 64-bit word per tile carries flag and value together (no
+// fence: a single agent-scope atomic store / load).  The words and the two counters live in a zero-initialised device array, one
+// set per launch in rotation; the last tile to finish clears its set (graph replays reuse theirs).  Replaces tile-sums + apply
+// (two launches) for up to kLbMaxTiles tiles; bit-identical results (integer sums).
+constexpr int kLbSlots = 64, kLbMaxTiles = 4096;
+__device__ unsigned long long g_lb_state[kLbSlots * kLbMaxTiles];
+__device__ unsigned int g_lb_ctr[kLbSlots * 2];
+
+__global__ __launch_bounds__(kScanBlock) void scan_lookback_kernel(const int32_t *in, int n, int32_t *out, int32_t *total,
+                                                                   const int32_t *n_dev, unsigned long long *state, unsigned int *ctr)
+{
+    __shared__ int sWave[kScanBlock / kWave];
+    __shared__ int sTile, sBase;
+    if (n_dev) n = min(n, *n_dev);
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+    const int ntiles = (int)gridDim.x;
+    if (tid == 0) sTile = (int)atomicAdd(&ctr[0], 1u);
+    __syncthreads();
+    const int tile = sTile;
+    const int base = tile * kScanTile + tid * kScanItems;  // blocked arrangement
+    int v[kScanItems];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        s += v[k];
+    }
+    int x = s;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    if (lane == kWave - 1) sWave[wid] = x;
+    __syncthreads();
+    int woff = 0, agg = 0;
+#pragma unroll
+    for (int w = 0; w < kScanBlock / kWave; ++w) {
+        const int c = sWave[w];
+        woff += (w < wid) ? c : 0;
+        agg += c;
+    }
+    if (wid == 0) {      // one wave publishes and looks back
+        int prefix = 0;
+        if (tile > 0) {
+            if (lane == 0)
+                __hip_atomic_store(&state[tile], (1ull << 62) | (unsigned int)agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int win = tile - 1;           // (wave-uniform) nearest predecessor of the current window of 64
+            while (true) {
+                const int j = win - lane;
+                unsigned long long w = 0ull;
+                if (j >= 0) {
+                    do {
+                        w = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } while ((w >> 62) == 0ull);
+                }
+                // lanes are ordered nearest predecessor first: everything up to (and including) the first inclusive prefix counts
+                const unsigned long long incl = __ballot(j >= 0 && (w >> 62) == 2ull);
+                const int first = incl ? __builtin_ctzll(incl) : kWave;
+                int part = (j >= 0 && lane <= first) ? (int)(unsigned int)w : 0;
+#pragma unroll
+                for (int d = kWave / 2; d > 0; d >>= 1) part += __shfl_xor(part, d);
+                prefix += part;
+                if (incl || win < kWave) break;      // an inclusive prefix closes the sum; so does reaching tile 0
+                win -= kWave;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&state[tile], (2ull << 62) | (unsigned int)(prefix + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sBase = prefix;
+            if (total && tile == ntiles - 1) *total = prefix + agg;
+        }
+    }
+    __syncthreads();
+    int off = sBase + woff + x - s;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        if (base + k < n) out[base + k] = off;
+        off += v[k];
+    }
+    // the last tile to get here puts the set back to zero (every tile has read what it needed: it is past its look-back)
+    __syncthreads();
+    if (tid == 0) sTile = (int)atomicAdd(&ctr[1], 1u);
+    __syncthreads();
+    if (sTile == ntiles - 1) {
+        for (int t = tid; t < ntiles; t += kScanBlock) __hip_atomic_store(&state[t], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_store(&ctr[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctr[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 }  // namespace
+
+// EPRECON_SCAN_LOOKBACK=0: long scans as tile sums + apply (two launches, rounds 1-5; read per call)
+static bool lookback_enabled()
+{
+    const char *e = getenv("EPRECON_SCAN_LOOKBACK");
+    return !(e && e[0] == '0');
+}
 
 namespace ep {
 // scratch: ceil(n / 2048) int32.  `total_dev` (optional) receives the grand total.  n_dev (optional, device): the live
@@ -192,11 +302,27 @@ int exclusive_scan_i32_dn(const int32_t *in, int n, const int32_t *n_dev, int32_
         return EPRECON_OK;
     }
     if (n <= kSmallScanMax) {
-        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in, n, out, total_dev, n_dev);
+        if (n <= 8192) hipLaunchKernelGGL(scan_small_kernel<8>, dim3(1), dim3(1024), 0, st, in, n, out, total_dev, n_dev);
+        else if (n <= 16384) hipLaunchKernelGGL(scan_small_kernel<16>, dim3(1), dim3(1024), 0, st, in, n, out, total_dev, n_dev);
+        else hipLaunchKernelGGL(scan_small_kernel<32>, dim3(1), dim3(1024), 0, st, in, n, out, total_dev, n_dev);
         EP_LAUNCH_CHECK();
         return EPRECON_OK;
     }
     const int nblk = (int)ceil_div(n, kScanTile);
+    if (nblk <= kLbMaxTiles && lookback_enabled()) {
+        static unsigned long long *state_base = nullptr;
+        static unsigned int *ctr_base = nullptr;
+        if (!state_base) {
+            EP_HIP_CHECK(hipGetSymbolAddress(reinterpret_cast<void **>(&state_base), HIP_SYMBOL(g_lb_state)));
+            EP_HIP_CHECK(hipGetSymbolAddress(reinterpret_cast<void **>(&ctr_base), HIP_SYMBOL(g_lb_ctr)));
+        }
+        static std::atomic<unsigned> slot{0};
+        const unsigned sidx = slot.fetch_add(1u) % (unsigned)kLbSlots;
+        hipLaunchKernelGGL(scan_lookback_kernel, dim3(nblk), dim3(kScanBlock), 0, st, in, n, out, total_dev, n_dev,
+                           state_base + (size_t)sidx * kLbMaxTiles, ctr_base + 2 * sidx);
+        EP_LAUNCH_CHECK();
+        return EPRECON_OK;
+    }
     hipLaunchKernelGGL(scan_tile_sums, dim3(nblk), dim3(kScanBlock), 0, st, in, n, scratch, n_dev);
     EP_LAUNCH_CHECK();
     if (nblk <= 4096) {       // (8.4 M elements: two launches; the tile totals are summed by the consumers)
@@ -548,6 +674,15 @@ int eprecon_hash_status(const void *table, void *stream)
     EP_HIP_CHECK(hipMemcpyAsync(&s, table, sizeof(s), hipMemcpyDeviceToHost, (hipStream_t)stream));
     EP_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     return s == 0 ? EPRECON_OK : (s & 1 ? EPRECON_ERR_UNSUPPORTED : EPRECON_ERR_WORKSPACE);
+}
+
+/* out[i] = sum of in[0 .. i) (int32, n < 2^31); *total (optional) = the grand total; scratch: ceil(n / 2048) int32 (used by the
+ * two-launch form only).  The device-wide scan every compaction / numbering of the path runs on: one workgroup up to 32,768
+ * elements, one decoupled look-back launch up to 8.4 M. */
+int eprecon_exclusive_scan_async(const int32_t *in, int64_t n, int32_t *out, int32_t *total, int32_t *scratch, void *stream)
+{
+    if (n < 0 || n > 0x7fffffff || (n > 0 && (!in || !out || !scratch))) return EPRECON_ERR_ARG;
+    return ep::exclusive_scan_i32(in, (int)n, out, scratch, total, (hipStream_t)stream);
 }
 
 size_t eprecon_unique_workspace_bytes(int64_t n)

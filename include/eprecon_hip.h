@@ -168,6 +168,10 @@ int eprecon_hash_status(const void *table, void *stream);
  *   n_unique_dev         int32[1]
  * afterwards the table maps key -> voxel id (so eprecon_hash_query_async returns ids). */
 size_t eprecon_unique_workspace_bytes(int64_t n);
+/* exclusive prefix sum of int32 (the device scan behind every compaction / unique numbering of the path: torch.nonzero,
+ * boolean-mask indexing and torch.unique at models/neucon_network.py:298-318,454-507, ops/torchsparse_utils.py:20-22):
+ * out[i] = in[0] + ... + in[i - 1]; *total (optional, device) = the sum of all n; scratch int32[ceil(n / 2048)] */
+int eprecon_exclusive_scan_async(const int32_t *in, int64_t n, int32_t *out, int32_t *total, int32_t *scratch, void *stream);
 int eprecon_unique_coords_async(const int32_t *coords, int64_t n, int quantum, void *table,
                                 uint32_t capacity, int32_t *inverse, int32_t *unique_coords,
                                 int32_t *n_unique_dev, void *workspace, size_t workspace_bytes,

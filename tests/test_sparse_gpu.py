@@ -29,6 +29,37 @@ def test_hash_build_query(n, stride):
     assert np.array_equal(g.query(dev(q)).cpu().numpy(), OS.Index(c).lookup(q))
 
 
+@pytest.mark.parametrize("n", [1, 63, 2049, 8192, 8193, 16385, 32768, 32769, 100003, 320868, 2500001])
+def test_device_scan_all_forms(monkeypatch, n):
+    """the exclusive scan behind every compaction: one workgroup / one pass up to 32,768 elements, one decoupled look-back launch
+    beyond (round 6; EPRECON_SCAN_LOOKBACK=0: tile sums + apply) — against numpy, the grand total included, twice (the
+    look-back's state words clean themselves), and 70 launches in a row (more than the 64 state sets in rotation)"""
+    from eprecon_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(n)
+    x = rng.integers(0, 9, n).astype(np.int32)
+    want = np.concatenate([[0], np.cumsum(x[:-1], dtype=np.int64)]).astype(np.int32)
+    dx = dev(x)
+    scratch = torch.empty((n + 2047) // 2048 + 1, dtype=torch.int32, device="cuda")
+
+    def run():
+        out = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+        tot = torch.full((1,), -7, dtype=torch.int32, device="cuda")
+        _lib.check(lib.eprecon_exclusive_scan_async(_lib.ptr(dx), n, _lib.ptr(out), _lib.ptr(tot), _lib.ptr(scratch),
+                                                    _lib.current_stream()), "eprecon_exclusive_scan_async")
+        return out.cpu().numpy(), int(tot.item())
+    for _ in range(2):
+        got, tot = run()
+        assert np.array_equal(got, want) and tot == int(x.sum())
+    if n in (100003, 320868):
+        for _ in range(70):
+            got, tot = run()
+        assert np.array_equal(got, want) and tot == int(x.sum())
+        monkeypatch.setenv("EPRECON_SCAN_LOOKBACK", "0")
+        got, tot = run()
+        assert np.array_equal(got, want) and tot == int(x.sum())
+
+
 def test_hash_rejects_out_of_range_keys():
     from eprecon_amd import _lib
     from eprecon_amd.sparse import HashGrid

@@ -97,35 +97,14 @@ def test_only_train_init_loss(step):
     assert any(p.grad is not None and float(p.grad.abs().sum()) > 0 for p in step.net.initialization.parameters())
 
 
-def test_ddp_wraps_the_training_step_single_rank():
-    """DistributedDataParallel over RCCL with one rank: the reference's wrapper (main.py:155-162) around the recording
-    path; the all-reduce hooks fire on the HIP Functions' gradients"""
-    import torch.distributed as dist
-    from eprecon_amd.fragment_step import TrainStep
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29517")
-    created = not dist.is_initialized()
-    if created:
-        dist.init_process_group("nccl", rank=0, world_size=1)
-    try:
-        from torch.nn.parallel import DistributedDataParallel
-        s = TrainStep(seed=1, lr=2e-6)   # (lr: see the `step` fixture)
-        s.model = DistributedDataParallel(s.net, device_ids=[0], output_device=0, broadcast_buffers=False,
-                                          find_unused_parameters=True)
-        s.optimizer = torch.optim.Adam(s.model.parameters(), lr=2e-6)
-        a = s.run()
-        b = s.run()
-        assert np.isfinite(a["total_loss"]) and np.isfinite(b["total_loss"])
-    finally:
-        if created:
-            dist.destroy_process_group()
-
-
 def test_training_step_on_a_batch_of_two_windows():
     """Round 6 (VERDICT r05 missing 3): the reference trains at BATCH_SIZE 4 (config/train.yaml:2) and every stage of its
     forward loops over the batch elements.  One step on TWO consecutive windows of a scene: the recording forward gives the
     inference forward's voxel lists, the level losses are the criterion's arithmetic on the traced per-voxel predictions and
-    targets of BOTH windows (restated in float64), every window's image pyramid receives a gradient, Adam steps run."""
+    targets of BOTH windows (restated in float64), every window's image pyramid receives a gradient, Adam steps run.
+    (Defined in front of the DistributedDataParallel test on purpose: a NEW HIP-graph capture + replay in a process that has
+    been through RCCL process-group set-up and tear-down twice segfaults inside the runtime's graph launch about one run in
+    two on this stack — seen only in the whole-suite order; every network of this suite captures its graphs before that.)"""
     from eprecon_amd.fragment_step import TrainStep, seed_subsampling
     s = TrainStep(seed=0, lr=2e-6, batch=2)
     net = s.net
@@ -171,3 +150,27 @@ def test_training_step_on_a_batch_of_two_windows():
     a = s.run()
     b = s.run()
     assert s.early_returns == 0 and np.isfinite(a["total_loss"]) and np.isfinite(b["total_loss"])
+
+
+def test_ddp_wraps_the_training_step_single_rank():
+    """DistributedDataParallel over RCCL with one rank: the reference's wrapper (main.py:155-162) around the recording
+    path; the all-reduce hooks fire on the HIP Functions' gradients"""
+    import torch.distributed as dist
+    from eprecon_amd.fragment_step import TrainStep
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        from torch.nn.parallel import DistributedDataParallel
+        s = TrainStep(seed=1, lr=2e-6)   # (lr: see the `step` fixture)
+        s.model = DistributedDataParallel(s.net, device_ids=[0], output_device=0, broadcast_buffers=False,
+                                          find_unused_parameters=True)
+        s.optimizer = torch.optim.Adam(s.model.parameters(), lr=2e-6)
+        a = s.run()
+        b = s.run()
+        assert np.isfinite(a["total_loss"]) and np.isfinite(b["total_loss"])
+    finally:
+        if created:
+            dist.destroy_process_group()
