@@ -399,6 +399,11 @@ def extra_workloads(device, lib, steps3=12, steps4=16, warm4=4):
             rec = scenes_per_gpu(k, 16, 8)
             out[f"cfg4_fragments_per_sec_k{k}"] = rec["fragments_per_sec"]
             out[f"cfg4_ms_per_fragment_by_scene_k{k}"] = rec["ms_per_fragment_by_scene"]
+        # the same for the configuration the headline is quoted on: K streams of the cfg2 step on the one GPU
+        for k in (2, 4):
+            rec = scenes_per_gpu(k, 100, 10, workload="cfg2")
+            out[f"cfg2_fragments_per_sec_k{k}"] = rec["fragments_per_sec"]
+            out[f"cfg2_ms_per_step_by_stream_k{k}"] = rec["ms_per_fragment_by_scene"]
         out["cfg4_scenes_per_gpu_note"] = ("K independent scenes on ONE GPU, one process each, started together: aggregate "
                                             "fragments/s = K x 16 / (last finish - first start); per-scene outputs are "
                                             "bit-identical to the solo run (tests/test_bench_records.py)")
@@ -528,8 +533,10 @@ def scene_child(args):
     stdin, time `--steps` fragments, report DONE with wall-clock start / end (one host: the parent compares the clocks)"""
     import torch
     from eprecon_amd import _lib as L
-    from eprecon_amd.fragment_step import Cfg4Step
+    from eprecon_amd.fragment_step import Cfg2Step, Cfg4Step
     torch.cuda.set_device(0)
+    if args.workload == "cfg2":
+        return window_child(args, Cfg2Step(seed=args.scene_seed_base + args.scene_child, device=torch.device("cuda", 0)))
     step = Cfg4Step(seed=args.scene_seed_base + args.scene_child, device=torch.device("cuda", 0), pipeline=PIPELINE)
     for _ in range(max(args.warmup, step.n_fragments)):
         step.run()
@@ -554,10 +561,36 @@ def scene_child(args):
                                 "finest_voxels_min_max": [min(step.voxels), max(step.voxels)], "workload": step.describe()}), flush=True)
 
 
-def scenes_per_gpu(k, steps, warmup, seed_base=0, timeout=900):
-    """K scene processes on device 0, started together -> the record of `bench.py --workload cfg4 --scenes-per-gpu K`"""
+def window_child(args, step):
+    """one window stream of `--workload cfg2 --scenes-per-gpu K`: the headline step (its own window, seed = base + index) in a
+    process of its own, deferred reads as in the headline loop"""
+    import torch
+    defer = os.environ.get("EPRECON_CFG2_DEFER", "1") == "1"
+    for _ in range(args.warmup):
+        step.run()
+    out = step.run()
+    digest = [str(int(out["init"][0].shape[0])) if out.get("init") else "none"] + [str(int(out[k]["n_valid"])) for k in ("bp24", "bp48", "bp96") if out.get(k)]
+    torch.cuda.synchronize()
+    print("READY " + json.dumps({"scene": args.scene_child, "seed": step.seed, "digests": digest}), flush=True)
+    if sys.stdin.readline().strip() != "GO":
+        raise SystemExit("window child: no GO")
+    step.defer_reads = defer
+    t_wall0, t0 = time.time(), time.perf_counter()
+    for _ in range(args.steps):
+        step.run()
+    step.flush()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    print("DONE " + json.dumps({"scene": args.scene_child, "t_start": t_wall0, "t_end": t_wall0 + elapsed, "elapsed": elapsed,
+                                "ms_per_fragment": elapsed / args.steps * 1e3, "blocking_reads_per_fragment": None,
+                                "finest_voxels_min_max": None, "workload": step.describe()}), flush=True)
+
+
+def scenes_per_gpu(k, steps, warmup, seed_base=0, timeout=900, workload="cfg4"):
+    """K scene processes on device 0, started together -> the record of `bench.py --workload cfg4 --scenes-per-gpu K`
+    (workload="cfg2": K streams of the headline step, one window each)"""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "cfg4", "--steps", str(steps), "--warmup", str(warmup),
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", str(steps), "--warmup", str(warmup),
            "--scene-seed-base", str(seed_base)]
     kids = [subprocess.Popen(cmd + ["--scene-child", str(i)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for i in range(k)]
 
@@ -611,10 +644,10 @@ def main():
     args = parse()
     if args.scene_child >= 0:
         return scene_child(args)
-    if args.scenes_per_gpu > 0:
-        if args.workload != "cfg4" or args.gpus != 1:
-            raise SystemExit("--scenes-per-gpu K goes with --workload cfg4 --gpus 1")
-        rec = scenes_per_gpu(args.scenes_per_gpu, args.steps, args.warmup, args.scene_seed_base)
+    if args.scenes_per_gpu > 0:      # (--workload cfg2 by default: state it)
+        if args.workload not in ("cfg4", "cfg2") or args.gpus != 1:
+            raise SystemExit("--scenes-per-gpu K goes with --workload cfg4 (or cfg2) --gpus 1")
+        rec = scenes_per_gpu(args.scenes_per_gpu, args.steps, args.warmup, args.scene_seed_base, workload=args.workload)
         cfg = dict(rec.pop("workload"), scenes_per_gpu=args.scenes_per_gpu,
                    scenes="K independent scenes (seeds base .. base + K - 1), one process each on device 0, started together; "
                           "value = K x steps / (last finish - first start)")

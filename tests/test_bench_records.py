@@ -124,6 +124,6 @@ def test_conv_family_record_recomputes_from_the_committed_shape_list():
 
 
 def test_scenes_per_gpu_is_a_cfg4_single_gpu_mode(monkeypatch, capsys):
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--scenes-per-gpu", "2"])
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--scenes-per-gpu", "2", "--workload", "train"])
     with pytest.raises(SystemExit, match="--scenes-per-gpu K goes with --workload cfg4"):
         bench.main()
