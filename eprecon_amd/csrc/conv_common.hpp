@@ -95,12 +95,13 @@ __device__ __forceinline__ void bn_acc_add(long long *acc, int ld, int c, int co
     atomicAdd(a + 6, (unsigned long long)(long long)n);
 }
 
-// the BatchNorm of channel c of the block in affine form: y = x * scale + shift
+// the BatchNorm of channel c of the block in affine form: y = x * scale + shift.  (The copies are walked ONE at a time: with the
+// loop unrolled, 56 int64 loads in flight pushed the 1,024-thread split-K kernel, whose prologue inlines this, into scratch.)
 __device__ __forceinline__ void bn_acc_affine(const long long *acc, int ld, int c, float eps, float &scale, float &shift)
 {
     if (EP_BN_ABL & 2) { scale = 1.0f; shift = 0.0f; return; }
     long long w[kBnWords] = {0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < kBnCopies; ++k) {
         const long long *a = acc + ((size_t)k * ld + c) * kBnWords;
 #pragma unroll
@@ -121,14 +122,14 @@ __device__ __forceinline__ void bn_acc_affine(const long long *acc, int ld, int 
 
 // prologue of the gather kernels: (scale, shift) of the input channels -> sAff[0 .. cpad) / sAff[cpad .. 2 cpad), from the
 // producer-finished vectors or from the accumulator block (zero beyond Cin)
-template <int THREADS>
+template <int THREADS, bool ACC = true>
 __device__ __forceinline__ void stage_in_affine(const ConvParams &p, float *sAff, int cpad, int tid)
 {
     if (!p.in_scale) return;
     for (int c = tid; c < cpad; c += THREADS) {
         float sc = 0.0f, sh = 0.0f;
         if (c < p.Cin) {
-            if (p.in_acc) bn_acc_affine(p.in_acc, p.in_acc_ld, p.in_acc_c0 + c, p.in_eps, sc, sh);
+            if (ACC && p.in_acc) bn_acc_affine(p.in_acc, p.in_acc_ld, p.in_acc_c0 + c, p.in_eps, sc, sh);
             else { sc = p.in_scale[c]; sh = p.in_shift[c]; }
         }
         sAff[c] = sc;

@@ -181,7 +181,9 @@ __device__ __forceinline__ void conv_epilogue_ln(const ConvParams &p, f32x16 (&a
     }
 }
 
-template <int NT, class RowMap>
+// ACC = false compiles the accumulator-block form of the summaries out (the 1,024-thread split-K instantiation sits at its
+// register cap: the extra kernel arguments alone pushed it into scratch; its launcher steps down to eight waves instead)
+template <int NT, bool ACC = true, class RowMap>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)[NT], RowMap rm, int col0, int r32,
                                               int half, int wave, float *sStat, int partial_row, int ncb)
 {
@@ -190,7 +192,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
         conv_epilogue_ln<NT>(p, acc, rm, r32, half);
         return;
     }
-    const bool stats = p.bn_partial != nullptr || p.bn_acc != nullptr;
+    const bool stats = p.bn_partial != nullptr || (ACC && p.bn_acc != nullptr);
     if (stats) __syncthreads();  // every wave is done reading the weights that sStat overlays
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -254,11 +256,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
             for (int w = 0; w < kWaves; ++w)
                 chan_merge(a_n, a_mean, a_m2, sStat[(w * 3) * TN + tid], sStat[(w * 3 + 1) * TN + tid],
                            sStat[(w * 3 + 2) * TN + tid]);
-            if (p.bn_partial) {
+            if (!ACC || p.bn_partial) {
                 float *dst = p.bn_partial + (size_t)partial_row * 3 * p.Cout + col0 + tid;
                 dst[0] = a_n; dst[p.Cout] = a_mean; dst[2 * p.Cout] = a_m2;
             }
-            if (p.bn_acc) bn_acc_publish(p, col0 + tid, partial_row, partial_row == 0, a_n, a_mean, a_m2);
+            if (ACC && p.bn_acc) bn_acc_publish(p, col0 + tid, partial_row, partial_row == 0, a_n, a_mean, a_m2);
         }
     }
 }
@@ -1451,7 +1453,9 @@ constexpr int splitk_w_floats(int rt, int nw)
 }
 
 // NW: waves per workgroup (4, or 8 / 16 when the 32-row x 32-column workgroups alone leave most SIMDs idle)
-template <bool VEC4, int RT, int NW>
+// ACC: the BatchNorm accumulator-block forms of prologue and epilogue (EPRECON_BN_ACC=1) are their own instantiations — compiled
+// into the default ones they cost split-K<true, 1, 8> twelve registers and a wave per SIMD (43 -> 53 us on 7,561 rows 80 -> 48)
+template <bool VEC4, int RT, int NW, bool ACC = false>
 __global__ __launch_bounds__(64 * NW) void spconv_splitk_kernel(ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1474,7 +1478,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_splitk_kernel(ConvParams p)
     const int col0 = blockIdx.y * TN;
 
     for (int k = tid; k < p.K; k += THREADS) sActive[k] = 0;
-    stage_in_affine<THREADS>(p, sAff, cinA, tid);
+    stage_in_affine<THREADS, ACC>(p, sAff, cinA, tid);
     __syncthreads();
     for (int e = tid; e < p.K * ROWS; e += THREADS) {
         const int k = e / ROWS, r = e - k * ROWS;
@@ -1500,8 +1504,11 @@ __global__ __launch_bounds__(64 * NW) void spconv_splitk_kernel(ConvParams p)
     const bool w_v4 = (p.Cout & 3) == 0 && ((p.Cout - col0) & 3) == 0 && (reinterpret_cast<uintptr_t>(p.w) & 15) == 0;
     // bdirect: the caller packed the weights in MFMA operand order (pack_weights_kernel, p.wq): the B operands of a stage are
     // four 16-byte loads straight into registers — no slab in LDS, no ds_read per MFMA pair, no wave barrier
-    const bool bdirect = p.wq != nullptr && p.splitk_pipe == 2;
-    if (VEC4 && (w_v4 || bdirect) && p.splitk_pipe) {
+    // (the 1,024-thread form sits at its 128-register cap: its 16-byte instantiation is launched with packed weights only and
+    // compiles the LDS-slab stages and the unpipelined loop out — with them it spilled eight registers to scratch)
+    constexpr bool BD_ONLY = VEC4 && NW == 16;
+    const bool bdirect = BD_ONLY || (p.wq != nullptr && p.splitk_pipe == 2);
+    if (BD_ONLY || (VEC4 && (w_v4 || bdirect) && p.splitk_pipe)) {
         if (tid == 0) {
             int n = 0;
             for (int k = 0; k < p.K; ++k)
@@ -1744,7 +1751,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_splitk_kernel(ConvParams p)
         if (t > 0 && row0 + 32 * t >= p.n_out) break;  // (block-uniform) no second tile in the last workgroup
         f32x16 one[1] = {acc[t]};
         const LinearRows rm{row0 + 32 * t, wave == 0 ? p.n_out : 0};
-        conv_epilogue<1>(p, one, rm, col0, r32, half, min(wave, kWaves - 1), sW, (int)blockIdx.x * RT + t, (int)gridDim.y);
+        conv_epilogue<1, ACC>(p, one, rm, col0, r32, half, min(wave, kWaves - 1), sW, (int)blockIdx.x * RT + t, (int)gridDim.y);
         if (t + 1 < RT) __syncthreads();  // the next tile's summaries reuse the scratch
     }
 }
@@ -1763,13 +1770,23 @@ int launch_splitk_v(ConvParams &p, hipStream_t st)
     const int64_t wgs = (int64_t)grid.x * grid.y;
     const int stages = p.K * ((p.Cin + 31) / 32);
     int nw = 4;
-    if (!rt2 && wgs * 16 <= 4096 && stages >= 32) nw = 16;
+    // (a pending BatchNorm held as an accumulator block, EPRECON_BN_ACC=1, is finished in the prologue: the 1,024-thread form
+    // has no registers to spare for that — its instantiation compiles the block path out — and takes eight waves then)
+    if (!rt2 && wgs * 16 <= 4096 && stages >= 32 && !p.in_acc && !p.bn_acc && (!VEC4 || p.splitk_pipe == 2)) nw = 16;
     else if (wgs * 8 <= 4096 && stages >= 16) nw = 8;
     const size_t w_floats = (size_t)splitk_w_floats(rt2 ? 2 : 1, nw);
     const size_t lds = w_floats * sizeof(float) + (size_t)p.K * rows * sizeof(int) +
                        (size_t)(((p.K + 3) & ~3) + ((p.K + 4) & ~3)) * sizeof(int) + (size_t)2 * ((p.Cin + 3) & ~3) * sizeof(float) + 16;
     // (128-row workgroups — every staged slab feeding four row tiles, half the weight traffic again — measured 157 vs 169 us on
     // 9,415 rows 192 -> 96 with 576 bytes of spills per lane: the weight traffic is not what limits these launches; not kept)
+    if (p.in_acc || p.bn_acc) {      // (opt-in form: its own instantiations, at most eight waves)
+        if (rt2 && nw == 8) hipLaunchKernelGGL((spconv_splitk_kernel<VEC4, 2, 8, true>), grid, dim3(512), lds, st, p);
+        else if (rt2) hipLaunchKernelGGL((spconv_splitk_kernel<VEC4, 2, 4, true>), grid, dim3(256), lds, st, p);
+        else if (nw == 8) hipLaunchKernelGGL((spconv_splitk_kernel<VEC4, 1, 8, true>), grid, dim3(512), lds, st, p);
+        else hipLaunchKernelGGL((spconv_splitk_kernel<VEC4, 1, 4, true>), grid, dim3(256), lds, st, p);
+        EP_LAUNCH_CHECK();
+        return EPRECON_OK;
+    }
     if (rt2 && nw == 8)
         hipLaunchKernelGGL((spconv_splitk_kernel<VEC4, 2, 8>), grid, dim3(512), lds, st, p);
     else if (rt2)
