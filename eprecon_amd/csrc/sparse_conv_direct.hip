@@ -46,6 +46,47 @@ __device__ __forceinline__ float relu_nc(float x)
     return r;
 }
 
+// ---- opt-in bf16x3 operands (EPRECON_CONV_BF16X3=1; DESIGN.md 3b, SURVEY.md section 7 "with an error budget") ---------------
+// x = hi + lo + e with hi = the top 16 bits of x (a bf16 by truncation), lo = bf16(x - hi) (round to nearest even; x - hi is exact)
+// and |e| <= 2^-17 |x|.  A product a * w is taken as a_hi w_hi + a_hi w_lo + a_lo w_hi on the bf16 matrix pipe (fp32 accumulate):
+// what is dropped is a_lo w_lo and the two e terms, <= ~2^-15 |a w| in all against fp32's 2^-24.  Both operands are split in
+// registers from the SAME fp32 gathers and the same operand-order packing (wq16) the fp32 path loads: no second weight format.
+// The 16-byte quad of a lane (four consecutive input channels, the k slot of v_mfma_f32_16x16x4_f32) is also the lane's four k
+// values of v_mfma_f32_16x16x16_bf16, and two quads side by side are its eight of v_mfma_f32_16x16x32_bf16 — A and B agree on
+// which channel sits in which k position, which is all a dot product over k needs.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct BfQuad { unsigned hi[2], lo[2]; };       // four values as two packed bf16 pairs each
+__device__ __forceinline__ BfQuad bf_split(const float4 &v)
+{
+    const unsigned b0 = __float_as_uint(v.x), b1 = __float_as_uint(v.y), b2 = __float_as_uint(v.z), b3 = __float_as_uint(v.w);
+    BfQuad r;
+    r.hi[0] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);       // (upper halves of two registers side by side)
+    r.hi[1] = __builtin_amdgcn_perm(b3, b2, 0x07060302u);
+    const f32x2 r01 = {v.x - __uint_as_float(b0 & 0xffff0000u), v.y - __uint_as_float(b1 & 0xffff0000u)};
+    const f32x2 r23 = {v.z - __uint_as_float(b2 & 0xffff0000u), v.w - __uint_as_float(b3 & 0xffff0000u)};
+    r.lo[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, bf16x2));      // v_cvt_pk_bf16_f32
+    r.lo[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf16x2));
+    return r;
+}
+__device__ __forceinline__ f32x4 bf_mfma32(const unsigned (&a0)[2], const unsigned (&a1)[2], const unsigned (&b0)[2],
+                                           const unsigned (&b1)[2], f32x4 acc)
+{
+    union { bf16x8 v; unsigned u[4]; } a, b;
+    a.u[0] = a0[0]; a.u[1] = a0[1]; a.u[2] = a1[0]; a.u[3] = a1[1];
+    b.u[0] = b0[0]; b.u[1] = b0[1]; b.u[2] = b1[0]; b.u[3] = b1[1];
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 bf_mfma16(const unsigned (&a0)[2], const unsigned (&b0)[2], f32x4 acc)
+{
+    union { s16x4 v; unsigned u[2]; } a, b;
+    a.u[0] = a0[0]; a.u[1] = a0[1];
+    b.u[0] = b0[0]; b.u[1] = b0[1];
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.v, b.v, acc, 0, 0, 0);
+}
+
 // Epilogue for the 16x16 accumulator layout (column l & 15, rows 4 (l >> 4) + reg): bias, ReLU, residual with its pending
 // BatchNorm, row-wise LayerNorm (16-lane xor-shuffles), BatchNorm summaries of the 128-row block (fixed-order Chan merges: rows
 // in the lane, lane groups, waves).
@@ -257,7 +298,8 @@ constexpr int stage_chunks(int kch) { return kch % 3 == 0 && EP_STAGE_CAP >= 3 ?
 
 // TAIL: the last column tile holds <= 8 columns and runs on the 4x4x1 MFMAs (tail_to_tile above); its B operands are the tail
 // section of the packing (pack_weights16_kernel: behind the CT tiles, 512 B per (offset, chunk)).
-template <int CT, int KCH, bool TAIL = false, int G = stage_chunks(KCH)>
+// BF: the bf16x3 operand form above (opt-in; padded 16-column tiles only: a half-empty tile costs 17 cycles there).
+template <int CT, int KCH, bool TAIL = false, int G = stage_chunks(KCH), bool BF = false>
 __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -287,7 +329,8 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
     // accumulator issue 32 cycles apart but the result returns after 40 — a quarter of the matrix pipe's time in bubbles
     // (the compiler groups the 16x16x4s whatever order the source puts them in: ISA of round 6).  The channels of such a layer
     // are split over NS = 2 accumulator sets (components x, z / y, w of every gathered quad), summed once before the epilogue.
-    constexpr int NS = CTM == 1 ? 2 : 1;
+    static_assert(!(BF && TAIL), "the bf16x3 form runs on padded column tiles");
+    constexpr int NS = (CTM == 1 && !BF) ? 2 : 1;
     f32x4 acc[NS][RT][CTA];
     f32x4 acct[RT][2];      // TAIL: per-k-slot partials of the last 8 columns (two groups of 4)
 #pragma unroll
@@ -373,6 +416,7 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
     auto consume = [&](const LiveCursor &c, const Stage &g) {
         const int k = c.k, part = c.part;
         const bool has_last = part == PARTS - 1;
+        BfQuad qa[BF ? G : 1][RT], qb[BF ? G : 1][CTA];                // BF: the stage's operands as bf16 (hi, lo) pairs
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const bool t8 = tail8 && i == G - 1 && has_last;          // (uniform) .z / .w of the gathered values are not used
@@ -409,6 +453,16 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
                     av[rt] = ok ? x : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 }
             }
+            if constexpr (BF) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    if (t8) av[rt].z = av[rt].w = 0.0f;     // (the fp32 form skips these two k slots; their weights are zeros)
+                    qa[i][rt] = bf_split(av[rt]);
+                }
+#pragma unroll
+                for (int t = 0; t < CTM; ++t) qb[i][t] = bf_split(g.b[i][t]);
+                continue;
+            }
             // independent accumulators alternate: a 16x16x4 MFMA issues every 32 cycles and returns after 40
 #define EP_DIRECT_STEP(comp, set)                                                                                                    \
     do {                                                                                                                             \
@@ -435,6 +489,32 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
                 EP_DIRECT_STEP(w, 1);
             }
 #undef EP_DIRECT_STEP
+        }
+        if constexpr (BF) {     // chunks in pairs on the K = 32 instruction, an odd last one on K = 16; three products each
+#pragma unroll
+            for (int i = 0; i + 1 < G; i += 2)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < CTM; ++t) {
+                        f32x4 c = acc[0][rt][t];
+                        c = bf_mfma32(qa[i][rt].lo, qa[i + 1][rt].lo, qb[i][t].hi, qb[i + 1][t].hi, c);    // (small terms first)
+                        c = bf_mfma32(qa[i][rt].hi, qa[i + 1][rt].hi, qb[i][t].lo, qb[i + 1][t].lo, c);
+                        c = bf_mfma32(qa[i][rt].hi, qa[i + 1][rt].hi, qb[i][t].hi, qb[i + 1][t].hi, c);
+                        acc[0][rt][t] = c;
+                    }
+            if constexpr (G & 1) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < CTM; ++t) {
+                        f32x4 c = acc[0][rt][t];
+                        c = bf_mfma16(qa[G - 1][rt].lo, qb[G - 1][t].hi, c);
+                        c = bf_mfma16(qa[G - 1][rt].hi, qb[G - 1][t].lo, c);
+                        c = bf_mfma16(qa[G - 1][rt].hi, qb[G - 1][t].hi, c);
+                        acc[0][rt][t] = c;
+                    }
+            }
         }
     };
     if (!(p.debug & 1) && U > 0) {
@@ -893,6 +973,14 @@ static bool tail8_enabled()
     return !(e && e[0] == '0');
 }
 
+// EPRECON_CONV_BF16X3=1: the template kernel's bf16x3 operand form (C_in <= 96, C_out <= 64; read per launch).  OFF by default:
+// the library's results are exact-fp32 products; this is the opt-in with a stated error budget.
+static bool bf16x3_enabled()
+{
+    const char *e = getenv("EPRECON_CONV_BF16X3");
+    return e && e[0] == '1';
+}
+
 // EPRECON_CONV_STAGE_DEPTH=0: always the deepest prefetch stage (the round-5 rule; read per launch)
 static bool stage_depth_enabled()
 {
@@ -983,6 +1071,11 @@ int launch_k(const ConvParams &p, hipStream_t st)
         }
     }
     const dim3 grid((unsigned)ceil_div(p.n_out, kDirectRows));
+    if (bf16x3_enabled()) {
+        hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH, false, stage_chunks(KCH), true>), grid, dim3(256), lds, st, p);
+        EP_LAUNCH_CHECK();
+        return EPRECON_OK;
+    }
     const bool tail = rem <= 8 && tail8_enabled();
     // Medium lists (a few workgroups per CU): the kernel's registers allow two workgroups per CU for the wide layers (96 -> 48,
     // 48 -> 48: three chunks per stage), so 583 workgroups (74,568 rows) run as one full wave of 512 and a second one that is

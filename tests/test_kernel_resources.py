@@ -37,8 +37,8 @@ def test_no_kernel_of_this_repository_uses_scratch(kernels):
 
 
 @pytest.mark.parametrize("needle,min_waves", [
-    ("spconv_direct16_kernel<2, 3, false, 3>", 3),     # the round-5 cfg4 leader: 144 unified VGPRs
-    ("spconv_direct16_kernel<2, 3, true, 3>", 2),      # ... and its 16 + 8 form (round 6: eight more B registers per chunk)
+    ("spconv_direct16_kernel<2, 3, false, 3, false>", 3),     # the round-5 cfg4 leader: 144 unified VGPRs
+    ("spconv_direct16_kernel<2, 3, true, 3, false>", 2),     # ... and its 16 + 8 form (round 6: eight more B registers per chunk)
     ("conv3d_tile16_kernel<2, 2>", 7),          # the cfg2 sparse stack on dense grids
     ("bp_gather_mlp_kernel<64, 2, 8, 1>", 8),   # the kernel the bench line names
 ])
