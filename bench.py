@@ -170,12 +170,12 @@ def cpu_baseline(step, seconds):
                         "offset) and 2D convolutions, numpy kernel map and stage-0 selection"}
 
 
-def conv_family_roofline():
+def conv_family_roofline(name="conv_shapes.txt"):
     """The figure that tracks fragments/s: the whole gather-GEMM family over the 30 distinct 3x3x3 shapes of
     a cfg4 fragment, from the newest committed profiles/rNN/conv_shapes.txt (tools/conv_shapes_ab.py: HIP-event time of each
     shape alone on the device, flops on LIVE kernel-map pairs) — sum of flops / sum of time against the fp32-MFMA peak."""
     import re
-    path = newest_profile("conv_shapes.txt")
+    path = newest_profile(name)
     if not path:
         return None
     us, flops, rows = 0.0, 0.0, []
@@ -327,6 +327,15 @@ def extra_workloads(device, lib, steps3=12, steps4=16, warm4=4):
         out["cfg4_early_returns"] = step.early_returns
         out["cfg4_workload"] = step.describe()["workload"]
         out["roofline_conv_cfg4"] = conv_roofline_cfg4(step, lib)
+        # beside, never instead of, the exact-fp32 figure: the direct gather kernel's opt-in bf16x3 operand form (read per
+        # launch; error budget in tests/test_sparse_gpu.py::test_bf16x3_opt_in_is_within_its_error_budget)
+        os.environ["EPRECON_CONV_BF16X3"] = "1"
+        try:
+            for _ in range(2):
+                step.run()
+            out["cfg4_bf16x3_opt_in_ms_per_fragment"] = _timed(step.run, max(4, steps4 // 2), sync)
+        finally:
+            del os.environ["EPRECON_CONV_BF16X3"]
         if PIPELINE_FIGURE:
             # throughput mode (opt-in for NeuConNet, other outputs contract): the panoptic branch of fragment k issued by a
             # worker thread on its own stream while the main thread runs fragment k + 1; the last fragment's branch
@@ -770,6 +779,10 @@ def main():
         if world == 1:
             out["roofline_conv"] = conv_roofline(step, lib)
             out["roofline_conv_family"] = conv_family_roofline()
+            bfx = conv_family_roofline("conv_shapes_bf16x3.txt")      # the opt-in: beside the exact-fp32 record, priced the same way
+            if bfx:
+                bfx["opt_in"] = "EPRECON_CONV_BF16X3=1 (bf16 matrix pipe, three products, fp32 accumulate; priced against the fp32-MFMA peak like the exact path)"
+                out["roofline_conv_family_bf16x3_opt_in"] = bfx
             if not args.no_extra:
                 try:   # the extras must never cost the headline line (Cfg4Step.run raises on an early-returning fragment)
                     out["extra"] = extra_workloads(torch.device("cuda", local_rank), lib)

@@ -118,7 +118,8 @@ def test_spvcnn_and_heads(run4, k, i):
     r, feat = ONC.spvcnn_stage(sd, i, t["coords"], t["feat_in"], inp["vol_origin_partial"],
                                inp["world_to_aligned_camera"])
     assert np.array_equal(t["r_coords"], r)
-    assert np.abs(t["feat_out"] - feat).max() < TOL
+    err = np.abs(t["feat_out"] - feat).max()
+    assert err < TOL, (err, np.abs(feat).max())
     h = tr[f"heads{i}"]
     tsdf, occ, occupancy = ONC.heads_stage(sd, i, h["feat"])
     assert np.abs(h["tsdf"] - tsdf).max() < TOL and np.abs(h["occ"] - occ).max() < TOL
