@@ -16,6 +16,40 @@ MIN_MASK_VOXELS = 100          # masks with <= 100 voxels are dropped as noise (
 MAX_MASK_POS_WEIGHT = 30.0
 
 
+class _Take(torch.autograd.Function):
+    """x.index_select(dim, idx) for a list of DISTINCT indices (the rows a mask keeps: idx = mask.nonzero()).  What boolean-mask
+    indexing computes — but the list is found once and shared by every tensor the mask is applied to (x[mask] runs nonzero,
+    a blocking device -> host read of the row count, per tensor), and the backward writes the gradient rows into zeros with
+    index_copy_ (IndexBackward0 re-runs nonzero on the mask: a second blocking read per tensor).  Same values, bit for bit:
+    every destination row receives exactly one source row.  One optimisation step had 172 blocking reads, 38 of them inside
+    the backward (tools/profile_train_syncs.py)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, dim):
+        ctx.save_for_backward(idx)
+        ctx.shape, ctx.dim = x.shape, dim
+        return x.index_select(dim, idx)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (idx,) = ctx.saved_tensors
+        out = grad.new_zeros(ctx.shape)
+        out.index_copy_(ctx.dim, idx, grad.contiguous())
+        return out, None, None
+
+
+def take(x, idx, dim=0):
+    """rows / columns `idx` (distinct, int64, on x's device) of x along dim"""
+    if dim < 0:
+        dim += x.dim()
+    return _Take.apply(x, idx, dim) if x.requires_grad else x.index_select(dim, idx)
+
+
+def mask_rows(mask):
+    """the row list of a boolean mask: ONE blocking read (its length)"""
+    return torch.nonzero(mask.reshape(-1)).squeeze(1)
+
+
 def apply_log_transform(tsdf):
     """sign(t) * log(|t| + 1)  (utils.py apply_log_transform)"""
     return torch.sign(tsdf) * torch.log(torch.abs(tsdf) + 1)
@@ -33,14 +67,15 @@ def compute_loss(tsdf, occ, tsdf_target, occ_target, loss_weight=(1, 1), mask=No
     (#neg / #pos * pos_weight) + L1 of the log-transformed TSDF on the occupied targets"""
     tsdf, occ, tsdf_target, occ_target = tsdf.reshape(-1), occ.reshape(-1), tsdf_target.reshape(-1), occ_target.reshape(-1)
     if mask is not None:
-        m = mask.reshape(-1)
-        tsdf, occ, tsdf_target, occ_target = tsdf[m], occ[m], tsdf_target[m], occ_target[m]
-    n_pos = occ_target.sum()
-    if n_pos == 0:
+        rows = mask_rows(mask)
+        tsdf, occ, tsdf_target, occ_target = take(tsdf, rows), take(occ, rows), tsdf_target[rows], occ_target[rows]
+    pos = mask_rows(occ_target)      # (its length is n_pos: the guard below costs no second read)
+    if pos.numel() == 0:
         return tsdf.sum() * 0.0
+    n_pos = occ_target.sum()
     w = (occ_target.shape[0] - n_pos).float() / n_pos * pos_weight
     occ_loss = F.binary_cross_entropy_with_logits(occ, occ_target.float(), pos_weight=w)
-    tsdf_loss = (apply_log_transform(tsdf[occ_target]) - apply_log_transform(tsdf_target[occ_target])).abs().mean()
+    tsdf_loss = (apply_log_transform(take(tsdf, pos)) - apply_log_transform(tsdf_target[pos])).abs().mean()
     return loss_weight[0] * occ_loss + loss_weight[1] * tsdf_loss
 
 
@@ -48,8 +83,8 @@ def compute_loss_init(occ_init, tsdf_init_target, occ_init_target):
     """NeuConNet.compute_loss_init (models/neucon_network.py:627-664): BCE of the initial occupancy logits against
     (tsdf_target > 0) on the voxels whose target is observed"""
     occ_init, t, o = occ_init.reshape(-1), tsdf_init_target.reshape(-1), occ_init_target.reshape(-1)
-    valid = (t == 0) | (o == 1)
-    occ_init, t = occ_init[valid], t[valid]
+    rows = mask_rows((t == 0) | (o == 1))
+    occ_init, t = take(occ_init, rows), t[rows]
     if t.sum() == 0:
         return occ_init.sum() * 0.0
     target = (t > 0).float()
@@ -102,11 +137,20 @@ class HungarianMatcher(nn.Module):
             c_dice = 1 - (2 * p @ gt.t() + 1) / (p.sum(-1)[..., None] + gt.sum(-1)[None, None, :] + 1)
             costs.append(self.cost_mask * c_mask + self.cost_class * c_class + self.cost_dice * c_dice)
         host = [c.cpu() for c in costs] if len(costs) > 1 else [costs[0].cpu()]
-        out = [[] for _ in range(n_heads)]
+        pairs = []
         for cost in host:
             for h in range(n_heads):
-                i, j = linear_sum_assignment(cost[h].reshape(cost.shape[1], -1))
-                out[h].append((torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)))
+                pairs.append(linear_sum_assignment(cost[h].reshape(cost.shape[1], -1)))
+        # the assignments go back to the device in ONE transfer (the losses index device tensors with them: as host tensors
+        # every such indexing — three per head and loss — was a blocking copy of its own)
+        import numpy as np
+        flat = torch.as_tensor(np.concatenate([np.asarray(a, dtype=np.int64) for ij in pairs for a in ij]) if pairs else
+                               np.zeros(0, np.int64)).to(costs[0].device)
+        out = [[] for _ in range(n_heads)]
+        at = 0
+        for n, (i, j) in enumerate(pairs):
+            out[n % n_heads].append((flat[at:at + len(i)], flat[at + len(i):at + len(i) + len(j)]))
+            at += len(i) + len(j)
         return out
 
     @torch.no_grad()
@@ -172,16 +216,20 @@ class SetCriterion(nn.Module):
                 keep = torch.isin(t["labels"], self.valid_classes.to(t["labels"].device))
             else:
                 keep = t["masks"].sum(1) > min_voxels
-            vox = t["masks"][keep].any(0) if keep.any() else torch.zeros_like(t["masks"][0], dtype=torch.bool)
-            labels = t["labels"][keep]
+            # (the kept masks and the voxels they cover as index lists, found once each: boolean indexing finds them again —
+            # a blocking read — for every tensor it is applied to, and once more per tensor in the backward)
+            kept = mask_rows(keep)
+            masks = t["masks"][kept]
+            cols = mask_rows(masks.any(0)) if kept.numel() else kept
+            labels = t["labels"][kept]
             if min_voxels is None:   # ScanNet id -> 1 + position in the list of evaluated classes
                 labels = torch.searchsorted(self.valid_classes.to(labels.device), labels) + 1
-            t["labels"], t["masks"] = labels, t["masks"][keep][:, vox]
-            if t["masks"].sum() == 0:
+            t["labels"], t["masks"] = labels, masks[:, cols]
+            if cols.numel() == 0:    # (no kept mask covers a voxel: the selected block sums to zero)
                 return False
-            outputs["pred_masks"] = outputs["pred_masks"][..., vox]
+            outputs["pred_masks"] = take(outputs["pred_masks"], cols, -1)
             for aux in outputs.get("aux_outputs", []):
-                aux["pred_masks"] = aux["pred_masks"][..., vox]
+                aux["pred_masks"] = take(aux["pred_masks"], cols, -1)
         return True
 
     def forward(self, outputs, targets):

@@ -487,14 +487,17 @@ class NeuConNet(nn.Module):
     def _panoptic_loss(self, panoptic_outs, coords_fine, occ_target, occupancy, inputs, bs):
         """models/neucon_network.py:589-622: the set criterion on the voxels whose ground truth is observed; the
         weighted terms are summed and divided by 3, then averaged over the batch"""
-        supervised = occ_target[occupancy].view(-1)
+        # (the supervised voxels as index lists found once: boolean-mask indexing finds them again — a blocking read — for each
+        # of the seven prediction heads, and once more per head in the backward; criterion.take)
+        from .criterion import mask_rows, take
+        supervised = take(occ_target.view(-1), mask_rows(occupancy)).view(-1)
+        sup_rows = mask_rows(supervised)
         for b in range(bs):
-            rows = coords_fine[:, 0] == b
-            keep = supervised[rows]
-            panoptic_outs[b]["pred_masks"] = panoptic_outs[b]["pred_masks"][..., keep]
+            keep = sup_rows if bs == 1 else mask_rows(supervised[coords_fine[:, 0] == b])
+            panoptic_outs[b]["pred_masks"] = take(panoptic_outs[b]["pred_masks"], keep, -1)
             for aux in panoptic_outs[b]["aux_outputs"]:
-                aux["pred_masks"] = aux["pred_masks"][..., keep]
-        targets = self.get_panoptic_targets(coords_fine[supervised], inputs, 0, bs)
+                aux["pred_masks"] = take(aux["pred_masks"], keep, -1)
+        targets = self.get_panoptic_targets(coords_fine[sup_rows], inputs, 0, bs)
         total = []
         for b in range(bs):
             losses = self.criterion(panoptic_outs[b], [targets[b]])
