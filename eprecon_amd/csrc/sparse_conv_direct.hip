@@ -290,6 +290,21 @@ struct LiveCursor {
     }
 };
 
+// Probe builds only (-DEP_DIRECT_PRIO=1 / 2): wave priority raised over the MFMA phase (1) or over the load-issuing phase (2)
+#ifndef EP_DIRECT_PRIO
+#define EP_DIRECT_PRIO 0
+#endif
+#if EP_DIRECT_PRIO == 1
+#define EP_PRIO_MFMA() __builtin_amdgcn_s_setprio(2)
+#define EP_PRIO_FETCH() __builtin_amdgcn_s_setprio(0)
+#elif EP_DIRECT_PRIO == 2
+#define EP_PRIO_MFMA() __builtin_amdgcn_s_setprio(0)
+#define EP_PRIO_FETCH() __builtin_amdgcn_s_setprio(2)
+#else
+#define EP_PRIO_MFMA() ((void)0)
+#define EP_PRIO_FETCH() ((void)0)
+#endif
+
 // chunks per stage for a layer of KCH chunks: the stages of an offset are KCH / G
 #ifndef EP_STAGE_CAP       // (probe builds: -DEP_STAGE_CAP=2 / 1 caps the chunks per stage — fewer registers, more waves per SIMD)
 #define EP_STAGE_CAP 3
@@ -523,18 +538,23 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
         fetch(cf, s_a);
         for (int u = 0; u < U; u += 2) {
             cf.next(PARTS);
+            EP_PRIO_FETCH();
             fetch(cf, s_b);
             __builtin_amdgcn_sched_barrier(0);
+            EP_PRIO_MFMA();
             consume(cc, s_a);
             cc.next(PARTS);
             __builtin_amdgcn_sched_barrier(0);
             cf.next(PARTS);
+            EP_PRIO_FETCH();
             fetch(cf, s_a);
             __builtin_amdgcn_sched_barrier(0);
+            EP_PRIO_MFMA();
             if (u + 1 < U) consume(cc, s_b);
             cc.next(PARTS);
             __builtin_amdgcn_sched_barrier(0);
         }
+        EP_PRIO_FETCH();
     }
     if constexpr (NS == 2) {
 #pragma unroll
