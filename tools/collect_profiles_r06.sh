@@ -70,6 +70,9 @@ rm -f $(find $O/busy -name "*kernel_trace.csv")
 # 6. per-stage / per-layer kernel accounting (stage markers + convolution log joined with the kernel trace; graphs off)
 bash tools/r04_layers.sh r06_layers > /dev/null 2>&1
 cp $R/gpurun_out/r06_layers/cfg4_layers.txt $P/cfg4_layers.txt
+# 7. the optimisation step: blocking reads by call site, host profile
+python tools/profile_train_syncs.py 2>&1 | grep -v -e amdgpu.ids -e "prototype feature" -e _cuda_set_sync_debug_mode > $P/train_syncs.txt
+python tools/profile_train_host.py 5 2>&1 | grep -v amdgpu.ids | head -45 > $P/train_host_profile.txt
 # static: registers / LDS / scratch / waves per SIMD of every kernel, from the code objects' metadata (no GPU)
 python tools/kernel_resources.py > $P/kernel_resources.txt
 ls -la $P
