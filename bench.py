@@ -298,6 +298,10 @@ def extra_workloads(device, lib, steps3=12, steps4=16, warm4=4):
             import gc
             sync()
             gc.collect()
+            # (what survives is long-lived: out of the collector's way — a full collection over the heap the earlier legs left
+            # behind, triggered from inside the ~7,000-launch optimisation step, cost that leg 8 ms per step)
+            if os.environ.get("EPRECON_BENCH_GC_FREEZE", "1") == "1":
+                gc.freeze()
             torch.cuda.empty_cache()
             fn()
         except Exception as exc:  # noqa: BLE001

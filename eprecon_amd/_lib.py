@@ -161,6 +161,7 @@ SIGNATURES = {
     "eprecon_conv_pack_weight_async": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "eprecon_conv_pack_weight16_floats": (_sz, [_i, _i, _i]),
     "eprecon_conv_pack_weight16_async": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "eprecon_conv_pack_many_async": (_i, [_vp, _i, _vp]),
     "eprecon_nchw_to_nhwc_async": (_i, [_vp, _vp, _i, _i, _i, _vp]),
 }
 

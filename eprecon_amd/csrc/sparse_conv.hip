@@ -888,10 +888,11 @@ constexpr int kD3WvNarrow = 4;
 // Weights [K][Cin][Cout] -> MFMA operand order, zero padded, one slab per block of 32 * nt output columns:
 //   wq[(((((cb * K + k) * NCH + ch) * 2 + half) * NT + t) * 32 + col) * 4 + s] = W[k][ch*8 + 4*half + s][cb*32*NT + 32 t + col]
 // (the float4 a lane (half, col) multiplies with its four consecutive input channels of chunk ch)
-__global__ void pack_weights_kernel(const float *w, int K, int Cin, int Cout, int nch, int nt, int ncb, float *wq)
+__device__ __forceinline__ void pack_weights_body(const float *w, int K, int Cin, int Cout, int nch, int nt, int ncb, float *wq,
+                                                  int first, int step)
 {
     const int total = ncb * K * nch * 2 * nt * 32 * 4;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    for (int e = first; e < total; e += step) {
         const int sidx = e & 3, col = (e >> 2) & 31;
         int r = e >> 7;
         const int t = r % nt; r /= nt;
@@ -902,8 +903,12 @@ __global__ void pack_weights_kernel(const float *w, int K, int Cin, int Cout, in
         wq[e] = (c < Cin && co < Cout) ? w[((size_t)k * Cin + c) * Cout + co] : 0.0f;
     }
 }
+__global__ void pack_weights_kernel(const float *w, int K, int Cin, int Cout, int nch, int nt, int ncb, float *wq)
+{
+    pack_weights_body(w, K, Cin, Cout, nch, nt, ncb, wq, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
 // the (NT, column blocks) the dense-grid kernel uses for C_out output channels; the packing follows it
-inline void d3_columns(int cout, int *nt, int *ncb) { *nt = cout <= 32 ? 1 : 2; *ncb = (cout + 32 * *nt - 1) / (32 * *nt); }
+__host__ __device__ inline void d3_columns(int cout, int *nt, int *ncb) { *nt = cout <= 32 ? 1 : 2; *ncb = (cout + 32 * *nt - 1) / (32 * *nt); }
 
 template <int WV>
 __device__ __forceinline__ void d3_tile_origin(int tile, int tiles_y, int tiles_z, int &x0, int &y0, int &z0)
@@ -1101,12 +1106,13 @@ constexpr int kD16Halo = (kD16X + 2) * kD3HY * kD3HZ;        // 240
 // Tail section (C_out = 16 (ct - 1) + 1 .. 8 only), behind the tiles: the last <= 8 columns once more in the operand order of
 // v_mfma_f32_4x4x1_16B_f32 as the direct gather kernel feeds it (csrc/sparse_conv_direct.hip: tail_to_tile) —
 //   tail[((((k * KCH + kc) * 2 + cg) * 4 + q) * 4 + n) * 4 + s] = W[k][16 kc + 4 q + s][16 (ct - 1) + 4 cg + n]
-__global__ void pack_weights16_kernel(const float *w, int K, int Cin, int Cout, int kch, int ct, float *wq)
+__device__ __forceinline__ void pack_weights16_body(const float *w, int K, int Cin, int Cout, int kch, int ct, float *wq, int first,
+                                                    int step)
 {
     const int total = K * kch * ct * 256;
     const int rem = Cout - 16 * (ct - 1);
     const int total_tail = (rem >= 1 && rem <= 8) ? K * kch * 128 : 0;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total_tail; e += gridDim.x * blockDim.x) {
+    for (int e = first; e < total_tail; e += step) {
         const int sidx = e & 3, n = (e >> 2) & 3, q = (e >> 4) & 3, cg = (e >> 6) & 1;
         const int r = e >> 7;
         const int kc = r % kch, k = r / kch;
@@ -1115,7 +1121,7 @@ __global__ void pack_weights16_kernel(const float *w, int K, int Cin, int Cout, 
         const int co = 16 * (ct - 1) + 4 * cg + n;
         wq[(size_t)total + e] = (c < Cin && co < Cout) ? w[((size_t)k * Cin + c) * Cout + co] : 0.0f;
     }
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    for (int e = first; e < total; e += step) {
         const int sidx = e & 3, col = (e >> 2) & 15, q = (e >> 6) & 3;
         int r = e >> 8;
         const int t = r % ct; r /= ct;
@@ -1125,6 +1131,25 @@ __global__ void pack_weights16_kernel(const float *w, int K, int Cin, int Cout, 
         const int c = tail8 ? (sidx < 2 ? 16 * kc + 2 * q + sidx : Cin) : 16 * kc + 4 * q + sidx;
         const int co = 16 * t + col;
         wq[e] = (c < Cin && co < Cout) ? w[((size_t)k * Cin + c) * Cout + co] : 0.0f;
+    }
+}
+__global__ void pack_weights16_kernel(const float *w, int K, int Cin, int Cout, int kch, int ct, float *wq)
+{
+    pack_weights16_body(w, K, Cin, Cout, kch, ct, wq, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// Many packings in ONE launch (eprecon_conv_pack_many_async): block (x, y) works on job y.  An optimisation step changes every
+// weight, so every layer's operand-order copies are rebuilt once per step: ~190 launches of 4 us as separate calls.
+__global__ void pack_many_kernel(const eprecon_pack_job *jobs)
+{
+    const eprecon_pack_job j = jobs[blockIdx.y];
+    const int first = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
+    if (j.kind == 0) {
+        int nt, ncb;
+        d3_columns(j.cout, &nt, &ncb);
+        pack_weights_body(j.weight, j.kvol, j.cin, j.cout, (j.cin + 7) / 8, nt, ncb, j.packed, first, step);
+    } else {
+        pack_weights16_body(j.weight, j.kvol, j.cin, j.cout, (j.cin + 15) / 16, (j.cout + 15) / 16, j.packed, first, step);
     }
 }
 
@@ -2293,6 +2318,15 @@ extern "C" int eprecon_conv_pack_weight16_async(const float *weight, int kvol, i
     const size_t total = eprecon_conv_pack_weight16_floats(kvol, cin, cout);
     hipLaunchKernelGGL(pack_weights16_kernel, dim3((unsigned)min((size_t)1024, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        weight, kvol, cin, cout, (cin + 15) / 16, (cout + 15) / 16, packed);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+extern "C" int eprecon_conv_pack_many_async(const eprecon_pack_job *jobs_dev, int njobs, void *stream)
+{
+    if (njobs < 0 || (njobs > 0 && !jobs_dev) || njobs > 65535) return EPRECON_ERR_ARG;
+    if (njobs == 0) return EPRECON_OK;
+    hipLaunchKernelGGL(pack_many_kernel, dim3(32, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }

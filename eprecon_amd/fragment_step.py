@@ -487,5 +487,9 @@ class TrainStep:
         loss_dict["total_loss"].backward()
         torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1.0)
         self.optimizer.step()
+        # every weight has changed: all operand-order copies rebuilt by ONE launch here instead of one per layer at its next use
+        if os.environ.get("EPRECON_TRAIN_REPACK", "1") == "1":
+            from .sparse import repack_registered
+            repack_registered()
         self.last = {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in loss_dict.items()}
         return self.last

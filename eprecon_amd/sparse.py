@@ -180,6 +180,64 @@ class DenseMap:
         return self.kind(x, cin, cout, accumulate, ln, stats) != 0
 
 
+# Every packing made from a weight tensor's own storage is remembered here (weak reference to the tensor object the cache lives
+# on): repack_registered() rebuilds them all in ONE launch after an optimizer step (TrainStep.run) instead of one launch per
+# layer at its next use — ~190 launches per step.  id(owner) -> {kind: (weakref, shape)}
+_PACK_REGISTRY = {}
+_PACK_TABLE = {"key": None, "jobs": None, "entries": None}
+
+
+def _register_pack(owner, kind, shape, source_ptr):
+    import weakref
+    if source_ptr != owner.data_ptr():      # packed from a temporary contiguous copy: nothing a later launch could re-read
+        return
+    slot = _PACK_REGISTRY.setdefault(id(owner), {})
+    if kind not in slot or slot[kind][0]() is not owner or slot[kind][1] != tuple(shape):
+        slot[kind] = (weakref.ref(owner), tuple(shape))
+        _PACK_TABLE["key"] = None
+
+
+def repack_registered():
+    """Rebuild every registered operand-order copy whose weight has changed since it was packed (an optimizer step changes
+    them all), in one launch on the current stream; the caches' tags follow, so the layers' next packed_weight /
+    packed_weight16 calls are hits.  Tensors that were freed, moved or re-shaped drop out of the registry.  -> jobs launched"""
+    import numpy as np
+    entries = []
+    for oid in list(_PACK_REGISTRY):
+        slot = _PACK_REGISTRY[oid]
+        for kind in list(slot):
+            ref, shape = slot[kind]
+            owner = ref()
+            hit = getattr(owner, "_d3_pack" if kind == 0 else "_d3_pack16", None) if owner is not None else None
+            if owner is None or hit is None or not owner.is_cuda or (kind == 1 and hit[0][2] != shape):
+                del slot[kind]
+                _PACK_TABLE["key"] = None
+                continue
+            entries.append((owner, kind, shape, hit[1]))
+        if not slot:
+            del _PACK_REGISTRY[oid]
+    stale = [e for e in entries if (e[0]._version, e[0].data_ptr()) != getattr(e[0], "_d3_pack" if e[1] == 0 else "_d3_pack16")[0][:2]]
+    if not stale:
+        return 0
+    key = tuple((o.data_ptr(), k, s, p.data_ptr()) for o, k, s, p in stale)
+    if _PACK_TABLE["key"] != key:     # (the table is uploaded once: pointers and shapes do not change from step to step)
+        job = np.zeros(len(stale), dtype=np.dtype([("weight", "<u8"), ("packed", "<u8"), ("kvol", "<i4"), ("cin", "<i4"),
+                                                   ("cout", "<i4"), ("kind", "<i4")]))
+        for i, (o, k, s, p) in enumerate(stale):
+            job[i] = (o.data_ptr(), p.data_ptr(), s[0], s[1], s[2], k)
+        _PACK_TABLE["jobs"] = torch.from_numpy(job.view(np.uint8).copy()).to(stale[0][0].device)
+        _PACK_TABLE["key"] = key
+    lib = _lib.load()
+    _lib.check(lib.eprecon_conv_pack_many_async(_lib.ptr(_PACK_TABLE["jobs"]), len(stale), _lib.current_stream()),
+               "eprecon_conv_pack_many_async")
+    for o, k, s, p in stale:
+        if k == 0:
+            o._d3_pack = ((o._version, o.data_ptr()), p)
+        else:
+            o._d3_pack16 = ((o._version, o.data_ptr(), s), p)
+    return len(stale)
+
+
 def packed_weight(weight):
     """`weight` f32[27, Cin, Cout] in the operand order of the dense-grid kernel, packed once per weight version"""
     hit = getattr(weight, "_d3_pack", None)
@@ -193,6 +251,7 @@ def packed_weight(weight):
                    "eprecon_conv_pack_weight_async")
         hit = (tag, packed)
         weight._d3_pack = hit
+        _register_pack(weight, 0, (kvol, cin, cout), w.data_ptr())
     return hit[1]
 
 
@@ -212,6 +271,7 @@ def packed_weight16(weight, owner=None):
                    "eprecon_conv_pack_weight16_async")
         hit = (tag, packed)
         owner._d3_pack16 = hit
+        _register_pack(owner, 1, (kvol, cin, cout), w.data_ptr())
     return hit[1]
 
 

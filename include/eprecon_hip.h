@@ -363,6 +363,15 @@ int eprecon_conv_pack_weight_async(const float *weight, int kvol, int cin, int c
 /* ... -> the operand order of the 16x16x4 MFMA kernels, cout <= 64 (0 floats / EPRECON_ERR_ARG beyond) */
 size_t eprecon_conv_pack_weight16_floats(int kvol, int cin, int cout);
 int eprecon_conv_pack_weight16_async(const float *weight, int kvol, int cin, int cout, float *packed, void *stream);
+/* Many packings in one launch: `jobs` is an array of njobs (<= 65,535) descriptors in DEVICE memory; kind 0 = the order of
+ * eprecon_conv_pack_weight_async, 1 = of eprecon_conv_pack_weight16_async (cout <= 64); `packed` sized by the matching
+ * *_floats call.  An optimisation step (main.py:297-313: optimizer.step()) changes every weight, so the operand-order copies
+ * of every spnn.Conv3d (models/modules.py:15-72, 178-222) are rebuilt once per step: one launch instead of one per layer. */
+typedef struct eprecon_pack_job {
+    const float *weight; float *packed;
+    int32_t kvol; int32_t cin; int32_t cout; int32_t kind;
+} eprecon_pack_job;
+int eprecon_conv_pack_many_async(const eprecon_pack_job *jobs, int njobs, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Normalisation epilogues  (K12)

@@ -579,3 +579,30 @@ def test_pointwise_layers_on_long_lists_take_the_direct_kernel(monkeypatch, cin,
     y_old, name_old = _last_conv_kernel((1, cin, cout, 1), lambda: SP.sparse_conv(dx, dw, None, db))
     assert name_old != "spconv_direct16_kernel"
     assert np.abs(y_old.cpu().numpy() - ref).max() < TOL
+
+
+def test_repack_registered_rebuilds_every_packing_in_one_launch():
+    """after an in-place update of the weights (an optimizer step), sparse.repack_registered() rebuilds the operand-order copies
+    of all of them with one eprecon_conv_pack_many_async launch: the same bits as a fresh per-layer packing, into the same
+    buffers, and the caches' tags follow (the layers' next packed_weight / packed_weight16 calls are hits)"""
+    from eprecon_amd import sparse as SP
+    rng = np.random.default_rng(3)
+    shapes = [(27, 48, 24), (27, 96, 48), (27, 32, 32), (1, 24, 24), (27, 76, 8), (27, 160, 96), (9, 40, 64)]
+    ws = [torch.nn.Parameter(dev(rng.standard_normal(s).astype(np.float32))) for s in shapes]
+    first = []
+    for w in ws:
+        first.append((SP.packed_weight(w), SP.packed_weight16(w) if w.shape[2] <= 64 else None))
+    assert SP.repack_registered() == 0                                  # nothing has changed
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(1.5).add_(0.25)
+    n16 = sum(1 for w in ws if w.shape[2] <= 64)
+    assert SP.repack_registered() == len(ws) + n16
+    for w, (p0, p16) in zip(ws, first):
+        assert SP.packed_weight(w) is p0 and (p16 is None or SP.packed_weight16(w) is p16)      # hits, same buffers
+        fresh = torch.nn.Parameter(w.detach().clone())
+        assert torch.equal(SP.packed_weight(fresh), p0)
+        if p16 is not None:
+            assert torch.equal(SP.packed_weight16(fresh), p16)
+    assert SP.repack_registered() == 0
+    del ws, first
