@@ -305,6 +305,29 @@ struct LiveCursor {
 #define EP_PRIO_FETCH() ((void)0)
 #endif
 
+// Probe builds only (-DEP_DIRECT_FLAT=1 / 2; wrong results for layers with a pending BatchNorm, ragged or 8-channel last chunks and
+// odd stage counts): 1 the consume step as ONE basic block (no uniform branches), 2 also no fence between a stage's loads and the
+// previous stage's MFMAs, the loads spread among the MFMAs with sched_group_barrier (one VMEM read, then EP_FLAT_MFMAS matrix ops)
+#ifndef EP_DIRECT_FLAT
+#define EP_DIRECT_FLAT 0
+#endif
+#ifndef EP_FLAT_MFMAS
+#define EP_FLAT_MFMAS 4
+#endif
+#if EP_DIRECT_FLAT >= 2
+#define EP_FLAT_FENCE() ((void)0)
+#define EP_FLAT_MIX()                                                                  \
+    do {                                                                               \
+        _Pragma("unroll") for (int sg = 0; sg < 24; ++sg) {                            \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                         \
+            __builtin_amdgcn_sched_group_barrier(0x008, EP_FLAT_MFMAS, 0);             \
+        }                                                                              \
+    } while (0)
+#else
+#define EP_FLAT_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define EP_FLAT_MIX() ((void)0)
+#endif
+
 // chunks per stage for a layer of KCH chunks: the stages of an offset are KCH / G
 #ifndef EP_STAGE_CAP       // (probe builds: -DEP_STAGE_CAP=2 / 1 caps the chunks per stage — fewer registers, more waves per SIMD)
 #define EP_STAGE_CAP 3
@@ -434,11 +457,11 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
         BfQuad qa[BF ? G : 1][RT], qb[BF ? G : 1][CTA];                // BF: the stage's operands as bf16 (hi, lo) pairs
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            const bool t8 = tail8 && i == G - 1 && has_last;          // (uniform) .z / .w of the gathered values are not used
+            const bool t8 = !EP_DIRECT_FLAT && tail8 && i == G - 1 && has_last;          // (uniform) .z / .w of the gathered values are not used
             float4 av[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) av[rt] = g.a[i][rt];
-            if ((p.Cin & 3) && i == G - 1 && has_last) {   // (uniform) ragged channel count on a padded pitch: the pad lanes stay out
+            if (!EP_DIRECT_FLAT && (p.Cin & 3) && i == G - 1 && has_last) {   // (uniform) ragged channel count on a padded pitch: the pad lanes stay out
                 const int c = 16 * (KCH - 1) + (t8 ? 2 : 4) * q;
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
@@ -447,7 +470,7 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
                     if (c + 3 >= p.Cin) av[rt].w = 0.0f;
                 }
             }
-            if (p.in_scale) {  // (uniform) the producer's pending BatchNorm (+ ReLU) on the gathered values
+            if (!EP_DIRECT_FLAT && p.in_scale) {  // (uniform) the producer's pending BatchNorm (+ ReLU) on the gathered values
                 const int kc = part * G + i;
                 const int ca = 16 * kc + (t8 ? 2 : 4) * q;
                 const float4 sc = make_float4(sAff[ca], sAff[ca + 1], sAff[ca + 2], sAff[ca + 3]);
@@ -540,17 +563,19 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
             cf.next(PARTS);
             EP_PRIO_FETCH();
             fetch(cf, s_b);
-            __builtin_amdgcn_sched_barrier(0);
+            EP_FLAT_FENCE();
             EP_PRIO_MFMA();
             consume(cc, s_a);
+            EP_FLAT_MIX();
             cc.next(PARTS);
             __builtin_amdgcn_sched_barrier(0);
             cf.next(PARTS);
             EP_PRIO_FETCH();
             fetch(cf, s_a);
-            __builtin_amdgcn_sched_barrier(0);
+            EP_FLAT_FENCE();
             EP_PRIO_MFMA();
-            if (u + 1 < U) consume(cc, s_b);
+            if (EP_DIRECT_FLAT >= 2 || u + 1 < U) consume(cc, s_b);
+            EP_FLAT_MIX();
             cc.next(PARTS);
             __builtin_amdgcn_sched_barrier(0);
         }
