@@ -18,7 +18,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "--offload-compress"]
 
 
-# Per-file flags (none since round 6: the direct gather kernel's ReLU-on-load is a v_med3_f32 now — csrc/sparse_conv_direct.hip
+# Per-file flags (none since round 6: the direct gather kernel's ReLU-on-load is a v_med3_f32 now — csrc/sparse_conv_direct_impl.hpp
 # `relu_nc` — instead of a translation-unit-wide -fno-honor-nans).
 EXTRA_FLAGS = {}
 
@@ -45,7 +45,9 @@ def build(force=False, verbose=False, out=OUT, extra_flags=None, obj_dir=CSRC, d
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs, jobs = [], []
     for src in sources():
-        if only is not None and os.path.basename(src) not in only:    # a variant of a few translation units: the rest are the
+        # (a name selects its family: sparse_conv_direct.hip also means sparse_conv_direct_ct1.hip ... — the kernels of
+        # csrc/sparse_conv_direct_impl.hpp are instantiated by those)
+        if only is not None and not any(os.path.basename(src)[:-4].startswith(o[:-4]) for o in only):    # a variant of a few translation units: the rest are the
             objs.append(os.path.join(CSRC, os.path.basename(src)[:-4] + ".o"))    # main build's objects (built first)
             continue
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")

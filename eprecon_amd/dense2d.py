@@ -75,7 +75,7 @@ def packed_weight(conv):
     return cached[1]
 
 
-# 3x3 layers on long pixel lists through the direct gather kernel (csrc/sparse_conv_direct.hip) on the pixel map instead of the
+# 3x3 layers on long pixel lists through the direct gather kernel (csrc/sparse_conv_direct_impl.hpp) on the pixel map instead of the
 # image-tile kernel: rocprofv3 durations on the 9 x 120 x 160 level 24->12 36.6 -> 23.4 us, 12->12 28.6 -> 17.6, 24->24 38.2 ->
 # 36.8; on 9 x 60 x 80 it is a wash (40->40 33.7 -> 28.7, 32->32 17.5 -> 18.4), hence the row threshold.
 DIRECT_2D_MIN_ROWS = 100000

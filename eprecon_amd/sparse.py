@@ -347,7 +347,7 @@ def clear_packed_weights(module):
 
 
 # point-wise layers (K = 1) on lists at least this long take the direct kernel too (a streaming [N, C_in] x [C_in, C_out <= 64]
-# product: csrc/sparse_conv_direct.hip); shorter lists are launch-bound on any kernel
+# product: csrc/sparse_conv_direct_impl.hpp); shorter lists are launch-bound on any kernel
 K1_DIRECT_MIN_ROWS = 20000
 
 

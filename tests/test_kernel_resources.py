@@ -37,8 +37,10 @@ def test_no_kernel_of_this_repository_uses_scratch(kernels):
 
 
 @pytest.mark.parametrize("needle,min_waves", [
-    ("spconv_direct16_kernel<2, 3, false, 3, false>", 3),     # the round-5 cfg4 leader: 144 unified VGPRs
-    ("spconv_direct16_kernel<2, 3, true, 3, false>", 2),     # ... and its 16 + 8 form (round 6: eight more B registers per chunk)
+    ("spconv_direct16_kernel<2, 3, false, 3, false, 0>", 3),     # the round-5 cfg4 leader: 144 unified VGPRs
+    ("spconv_direct16_kernel<2, 3, true, 3, false, 0>", 2),      # ... and its 16 + 8 form (round 6: eight more B registers per chunk)
+    ("spconv_direct16_kernel<2, 3, true, 3, false, 1>", 3),      # ... with the loads spread among the MFMAs (the cfg4 leader now): 102 + 40
+    ("spconv_direct16_kernel<3, 6, false, 3, false, 1>", 3),     # 96 -> 48 likewise
     ("conv3d_tile16_kernel<2, 2>", 7),          # the cfg2 sparse stack on dense grids
     ("bp_gather_mlp_kernel<64, 2, 8, 1>", 8),   # the kernel the bench line names
 ])

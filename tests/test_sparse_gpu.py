@@ -443,6 +443,41 @@ def test_stage_depth_rule_changes_the_schedule_not_the_bits(monkeypatch, cin, co
         assert np.abs(y0.cpu().numpy() - ref).max() < TOL
 
 
+@pytest.mark.parametrize("affine", [False, True])
+@pytest.mark.parametrize("cin,cout", [(48, 24), (96, 48), (80, 40), (32, 24), (48, 48), (16, 16), (64, 8), (76, 8), (24, 24)])
+def test_interleaved_schedule_changes_the_schedule_not_the_bits(monkeypatch, cin, cout, affine):
+    """Round 6: layers whose consume step holds no launch-uniform branch (no 8-channel or ragged last chunk; with or without a
+    pending BatchNorm + ReLU of the input) run on instantiations of the direct kernel that spread the next stage's loads among
+    this stage's MFMAs instead of issuing them in a burst behind a scheduling fence.  The products enter every accumulator in the
+    same order: bit-identical to EPRECON_CONV_INTERLEAVE=0, summaries included; (76, 8) and (24, 24) are not eligible (8-channel
+    last chunk) and must not change either.  Odd and even stage counts both occur (the live-offset count of a wave varies)."""
+    from eprecon_amd import sparse as SP
+    rng = np.random.default_rng(cin * 7 + cout)
+    c = random_coords(rng, 41003, extent=34, batch=1)
+    n = len(c)
+    vs = SP.VoxelSet(dev(c))
+    nbr_d = vs.kernel_map(3)
+    x = dev(rng.standard_normal((n, cin)).astype(np.float32))
+    w = dev((rng.standard_normal((27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32))
+    aff = (dev(rng.uniform(0.5, 1.5, cin).astype(np.float32)), dev(rng.standard_normal(cin).astype(np.float32)), True) if affine else None
+    (y0, p0), name = _last_conv_kernel((27, cin, cout, 1000), lambda: SP.conv_stats(x, w, nbr_d, in_affine=aff))
+    assert name == "spconv_direct16_kernel"
+    monkeypatch.setenv("EPRECON_CONV_INTERLEAVE", "0")
+    y1, p1 = SP.conv_stats(x, w, nbr_d, in_affine=aff)
+    assert torch.equal(y0, y1) and torch.equal(p0, p1)
+    if affine:      # ... and without the ReLU (the branch-free form selects it with a bit mask)
+        monkeypatch.delenv("EPRECON_CONV_INTERLEAVE")
+        aff2 = (aff[0], aff[1], False)
+        y2, _ = SP.conv_stats(x, w, nbr_d, in_affine=aff2)
+        monkeypatch.setenv("EPRECON_CONV_INTERLEAVE", "0")
+        y3, _ = SP.conv_stats(x, w, nbr_d, in_affine=aff2)
+        assert torch.equal(y2, y3) and not torch.equal(y2, y0)
+    xa = x.cpu().numpy()
+    if affine:
+        xa = np.maximum(xa * aff[0].cpu().numpy() + aff[1].cpu().numpy(), 0)
+    assert np.abs(y0.cpu().numpy() - OS.sparse_conv(xa, OS.kernel_map(c, c, 3, 1), w.cpu().numpy())).max() < TOL
+
+
 @pytest.mark.parametrize("n,cin,cout", [(204, 64, 128), (204, 128, 128), (1532, 160, 96), (1532, 64, 64), (1532, 32, 64),
                                         (7561, 32, 32), (9415, 192, 96)])
 def test_short_list_kernel(monkeypatch, n, cin, cout):

@@ -1,6 +1,6 @@
 """Where the time of the cfg4-leading convolution goes (3x3x3 48 -> 24 on the real kernel map of the scene's last fragment,
 spconv_direct16_kernel): time against the number of rows (the first n rows of the map: startup, slope, tail) — and, run under the
-ablation builds of csrc/sparse_conv_direct.hip (EP_DIRECT_ABL, EPRECON_LIB_PATH), the same launch without its gathers / weight
+ablation builds of csrc/sparse_conv_direct_impl.hpp (EP_DIRECT_ABL, EPRECON_LIB_PATH), the same launch without its gathers / weight
 traffic / MFMAs.
     python tools/conv_direct_probe.py [--sweep]"""
 import os

@@ -1,4 +1,4 @@
-"""A/B of the 16 + 8 column split of the direct gather kernel (csrc/sparse_conv_direct.hip, TAIL form: the last 8 columns of
+"""A/B of the 16 + 8 column split of the direct gather kernel (csrc/sparse_conv_direct_impl.hpp, TAIL form: the last 8 columns of
 C_out = 16 m + 8 on v_mfma_f32_4x4x1_16B_f32) against the padded 16-column tile (EPRECON_CONV_TAIL8=0), in ONE process: the
 shapes of tools/conv_shapes_ab.py with C_out = 8 / 24 / 40 on random 35 %-filled sets, and the cfg4-leading instance (48 -> 24 on
 the real kernel map of the scene's last fragment).  Prints max |difference| of the two outputs (summation order differs) and
