@@ -1153,6 +1153,14 @@ __global__ void pack_many_kernel(const eprecon_pack_job *jobs)
     }
 }
 
+// EP_TILE16_MIX (compile time): 1 (default) the loads an offset issues — CT weight quads two offsets ahead, the next offset's A
+// quad from LDS — are spread among its 4 CT MFMAs (sched_group_barrier: one VMEM read per four MFMAs, then the LDS read) instead
+// of issued in front of them behind a scheduling fence (0: the round-3..5 schedule; 2: no fence at all, the compiler's choice —
+// measured equal to 0).  32 -> 32 + LayerNorm on the 94k-voxel set: 71.3 -> 64.5 us, 0.44 -> 0.49 of the fp32-MFMA peak; the cfg2
+// step 1.595 -> 1.574 ms (tools/probes/t16_ab.sh, two interleaved rounds).  The same products in the same order: bit-identical.
+#ifndef EP_TILE16_MIX
+#define EP_TILE16_MIX 1
+#endif
 template <int CT, int KCH>
 __global__ __launch_bounds__(256, 7) void conv3d_tile16_kernel(ConvParams p, int tiles_y, int tiles_z, int ntiles)
 {
@@ -1226,7 +1234,9 @@ __global__ __launch_bounds__(256, 7) void conv3d_tile16_kernel(ConvParams p, int
         for (int k = 0; k < 27; ++k) {
             if (k + kAheadB < 27) load_b(k + kAheadB, bq[(k + kAheadB) % (kAheadB + 1)]);
             if (k + 1 < 27) aq[(k + 1) & 1] = load_a(k + 1);
+#if EP_TILE16_MIX == 0
             __builtin_amdgcn_sched_barrier(0);
+#endif
             const float4 av = aq[k & 1];
             const float4(&bk)[CT] = bq[k % (kAheadB + 1)];
             // the CT accumulators alternate: a 16x16x4 MFMA issues every 32 cycles but returns after 40
@@ -1238,6 +1248,14 @@ __global__ __launch_bounds__(256, 7) void conv3d_tile16_kernel(ConvParams p, int
             for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bk[t].z, acc[t], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bk[t].w, acc[t], 0, 0, 0);
+#if EP_TILE16_MIX == 1      // (probe builds: this offset's loads spread among its MFMAs instead of in front of them)
+#pragma unroll
+            for (int sg = 0; sg < CT; ++sg) {
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     }
