@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
     // (the compiler groups the 16x16x4s whatever order the source puts them in: ISA of round 6).  The channels of such a layer
     // are split over NS = 2 accumulator sets (components x, z / y, w of every gathered quad), summed once before the epilogue.
     static_assert(!(BF && TAIL), "the bf16x3 form runs on padded column tiles");
-    static_assert(!(BF && MODE != 0), "the bf16x3 form keeps the fenced schedule (its stage is VALU work, not MFMAs)");
+
     constexpr int NS = (CTM == 1 && !BF) ? 2 : 1;
     f32x4 acc[NS][RT][CTA];
     f32x4 acct[RT][2];      // TAIL: per-k-slot partials of the last 8 columns (two groups of 4)
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
         }
     } else if (U > 0) {
         constexpr int kStageLoads = RT * G + G * CTM + (TAIL ? 2 * G : 0);
-        constexpr int kStageMfma = G * 4 * (RT * CTM + (TAIL ? 2 * RT : 0));
+        constexpr int kStageMfma = BF ? 3 * RT * CTM * ((G + 1) / 2) : G * 4 * (RT * CTM + (TAIL ? 2 * RT : 0));
         constexpr int kMixMfma = (kStageMfma + kStageLoads - 1) / kStageLoads + EP_MIX_EXTRA;
         Stage s_a, s_b;
         LiveCursor cf(live), cc(live);
@@ -1148,7 +1148,10 @@ int launch_k(const ConvParams &p_in, hipStream_t st)
     }
     const dim3 grid((unsigned)ceil_div(p.n_out, kDirectRows));
     if (bf16x3_enabled()) {
-        hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH, false, stage_chunks(KCH), true>), grid, dim3(256), lds, st, p);
+        const int bmode = (interleave_enabled() && p.Cin - 16 * (KCH - 1) > 8 && (p.Cin & 3) == 0) ? (p.in_scale ? 2 : 1) : 0;
+        if (bmode == 2) hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH, false, stage_chunks(KCH), true, 2>), grid, dim3(256), lds, st, p);
+        else if (bmode == 1) hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH, false, stage_chunks(KCH), true, 1>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH, false, stage_chunks(KCH), true>), grid, dim3(256), lds, st, p);
         EP_LAUNCH_CHECK();
         return EPRECON_OK;
     }
