@@ -1498,7 +1498,13 @@ constexpr int splitk_w_floats(int rt, int nw)
 // NW: waves per workgroup (4, or 8 / 16 when the 32-row x 32-column workgroups alone leave most SIMDs idle)
 // ACC: the BatchNorm accumulator-block forms of prologue and epilogue (EPRECON_BN_ACC=1) are their own instantiations — compiled
 // into the default ones they cost split-K<true, 1, 8> twelve registers and a wave per SIMD (43 -> 53 us on 7,561 rows 80 -> 48)
-template <bool VEC4, int RT, int NW, bool ACC = false>
+// FAST (16-byte gathers + packed weights, the launcher's choice): the stage loop holds NO launch-uniform branch — packed weights
+// are a compile-time fact, every slab runs its four 8-channel chunks (a chunk past C_in multiplies zeros: the gathered values are
+// masked, the weight loads clamped), the pending BatchNorm of the input is the AFF instantiation — so a stage's loads and its
+// 16 RT MFMAs are ONE basic block the compiler schedules together (round 6: 128 -> 96 on 9,324 rows 115.6 -> 91.5 us, 48 -> 48 on
+// 7,561 rows 41.9 -> 31.7, 32 -> 32 on 10,121 rows 29.7 -> 20.9; profiles/r06/conv_splitk_flat_ab.txt).  The same products in
+// the same order as the general form: bit-identical.
+template <bool VEC4, int RT, int NW, bool ACC = false, bool FAST = false, bool AFF = false>
 __global__ __launch_bounds__(64 * NW) void spconv_splitk_kernel(ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1549,7 +1555,8 @@ __global__ __launch_bounds__(64 * NW) void spconv_splitk_kernel(ConvParams p)
     // four 16-byte loads straight into registers — no slab in LDS, no ds_read per MFMA pair, no wave barrier
     // (the 1,024-thread form sits at its 128-register cap: its 16-byte instantiation is launched with packed weights only and
     // compiles the LDS-slab stages and the unpipelined loop out — with them it spilled eight registers to scratch)
-    constexpr bool BD_ONLY = VEC4 && NW == 16;
+    static_assert(!FAST || (VEC4 && !ACC), "the branch-free form: 16-byte gathers, packed weights, per-workgroup summaries");
+    constexpr bool BD_ONLY = VEC4 && (NW == 16 || FAST);
     const bool bdirect = BD_ONLY || (p.wq != nullptr && p.splitk_pipe == 2);
     if (BD_ONLY || (VEC4 && (w_v4 || bdirect) && p.splitk_pipe)) {
         if (tid == 0) {
@@ -1601,6 +1608,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_splitk_kernel(ConvParams p)
         };
         // (two stages ahead — 247 registers at RT = 2 — measured no faster: 165 vs 161 us on 9,415 rows 192 -> 96; the 64-row
         // workgroups of that launch run in two rounds of ~80 us on one workgroup per CU, which is what sets its time)
+        const unsigned relu_mask = p.in_relu ? 0xffffffffu : 0u;
         Stage cur, nxt;
         if (wave < nst) fetch(wave, cur);
         for (int st = wave; st < nst; st += NW) {
@@ -1621,7 +1629,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_splitk_kernel(ConvParams p)
                     a[t][ch][0] = cur.a[t][ch].x; a[t][ch][1] = cur.a[t][ch].y;
                     a[t][ch][2] = cur.a[t][ch].z; a[t][ch][3] = cur.a[t][ch].w;
                 }
-            if (p.in_scale) {   // the producer's pending BatchNorm (+ ReLU): this lane's 16 channels of the slab
+            if (FAST ? AFF : p.in_scale != nullptr) {   // the producer's pending BatchNorm (+ ReLU): this lane's 16 channels of the slab
 #pragma unroll
                 for (int ch = 0; ch < 4; ++ch) {
                     const int cc = min(c0 + ch * 8 + 4 * half, cinA - 4);
@@ -1633,7 +1641,12 @@ __global__ __launch_bounds__(64 * NW) void spconv_splitk_kernel(ConvParams p)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const float x = fmaf(a[t][ch][q], sc[q], sh[q]);
-                            a[t][ch][q] = p.in_relu ? fmaxf(x, 0.0f) : x;
+                            if constexpr (FAST) {   // (no branch: the ReLU's result chosen by a launch-uniform bit mask — same bits)
+                                const unsigned r = __float_as_uint(fmaxf(x, 0.0f)), b = __float_as_uint(x);
+                                a[t][ch][q] = __uint_as_float((r & relu_mask) | (b & ~relu_mask));
+                            } else {
+                                a[t][ch][q] = p.in_relu ? fmaxf(x, 0.0f) : x;
+                            }
                         }
                 }
             }
@@ -1645,11 +1658,11 @@ __global__ __launch_bounds__(64 * NW) void spconv_splitk_kernel(ConvParams p)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) a[t][ch][q] = (cur.j[t] >= 0 && c + q < p.Cin) ? a[t][ch][q] : 0.0f;
                 }
-            const int nch = min(4, (p.Cin - c0 + 7) / 8);
+            const int nch = FAST ? 4 : min(4, (p.Cin - c0 + 7) / 8);
             if (bdirect) {
 #pragma unroll
                 for (int ch = 0; ch < 4; ++ch) {
-                    if (ch < nch) {
+                    if (FAST || ch < nch) {
                         const float bw[4] = {cur.w4[ch].x, cur.w4[ch].y, cur.w4[ch].z, cur.w4[ch].w};
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
@@ -1829,6 +1842,33 @@ int launch_splitk_v(ConvParams &p, hipStream_t st)
         else hipLaunchKernelGGL((spconv_splitk_kernel<VEC4, 1, 4, true>), grid, dim3(256), lds, st, p);
         EP_LAUNCH_CHECK();
         return EPRECON_OK;
+    }
+    // 16-byte gathers on packed weights: the branch-free instantiations (EPRECON_CONV_SPLITK_FAST=0: the general form)
+    if constexpr (VEC4) {
+        const char *e = getenv("EPRECON_CONV_SPLITK_FAST");      // (read per launch: tests flip it)
+        if (p.splitk_pipe == 2 && !(e && e[0] == '0')) {
+            const bool aff = p.in_scale != nullptr;
+#define EP_SPLITK_FAST_LAUNCH(RTv, NWv)                                                                                              \
+    do {                                                                                                                             \
+        if (aff) hipLaunchKernelGGL((spconv_splitk_kernel<true, RTv, NWv, false, true, true>), grid, dim3(64 * NWv), lds, st, p);    \
+        else hipLaunchKernelGGL((spconv_splitk_kernel<true, RTv, NWv, false, true, false>), grid, dim3(64 * NWv), lds, st, p);       \
+    } while (0)
+            if (rt2 && nw == 8) EP_SPLITK_FAST_LAUNCH(2, 8);
+            else if (rt2) EP_SPLITK_FAST_LAUNCH(2, 4);
+            else if (nw == 16) {
+                static const hipError_t attr_a = hipFuncSetAttribute(reinterpret_cast<const void *>(&spconv_splitk_kernel<true, 1, 16, false, true, true>),
+                                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                static const hipError_t attr_b = hipFuncSetAttribute(reinterpret_cast<const void *>(&spconv_splitk_kernel<true, 1, 16, false, true, false>),
+                                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                EP_HIP_CHECK(attr_a);
+                EP_HIP_CHECK(attr_b);
+                EP_SPLITK_FAST_LAUNCH(1, 16);
+            } else if (nw == 8) EP_SPLITK_FAST_LAUNCH(1, 8);
+            else EP_SPLITK_FAST_LAUNCH(1, 4);
+#undef EP_SPLITK_FAST_LAUNCH
+            EP_LAUNCH_CHECK();
+            return EPRECON_OK;
+        }
     }
     if (rt2 && nw == 8)
         hipLaunchKernelGGL((spconv_splitk_kernel<VEC4, 2, 8>), grid, dim3(512), lds, st, p);

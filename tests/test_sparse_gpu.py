@@ -507,6 +507,17 @@ def test_short_list_kernel(monkeypatch, n, cin, cout):
     tot_mean = (cnt * mean).sum(0) / n
     tot_m2 = (m2 + cnt * (mean - tot_mean) ** 2).sum(0)
     assert np.abs(tot_mean - ref.mean(0)).max() < 1e-4 and np.abs(tot_m2 / n - ref.var(0)).max() < 1e-3
+    # Round 6: with 16-byte gathers on packed weights the launch takes the branch-free instantiation (packed weights a compile-time
+    # fact, every slab its four chunks, the pending BatchNorm its own instantiation: a stage's loads and MFMAs are one basic block).
+    # The same products in the same order: bit-identical to the general form (EPRECON_CONV_SPLITK_FAST=0), with and without
+    # the pending BatchNorm, with and without its ReLU.
+    for aff in ((dev(sc), dev(sh), True), (dev(sc), dev(sh), False), None):
+        monkeypatch.delenv("EPRECON_CONV_SPLITK_FAST", raising=False)
+        y0, p0 = SP.conv_stats(dev(x), dev(w), nbr_d, in_affine=aff)
+        monkeypatch.setenv("EPRECON_CONV_SPLITK_FAST", "0")
+        y1, p1 = SP.conv_stats(dev(x), dev(w), nbr_d, in_affine=aff)
+        assert torch.equal(y0, y1) and torch.equal(p0, p1)
+    assert torch.equal(y0.cpu(), torch.from_numpy(OS.sparse_conv(x, nbr, w))) or np.abs(y0.cpu().numpy() - OS.sparse_conv(x, nbr, w)).max() < TOL
 
 
 @pytest.mark.parametrize("n,cin,cout", [(9415, 192, 96), (11880, 160, 80), (6000, 128, 128), (4200, 100, 72), (30011, 96, 96)])

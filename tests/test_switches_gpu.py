@@ -53,7 +53,7 @@ def test_default_is_deterministic(scene, default_run):
 
 @pytest.mark.parametrize("env", [{"EPRECON_CONV_DIRECT": "0"}, {"EPRECON_CONV_WIDEK": "0"}, {"EPRECON_CONV_SPLITK": "0"},
                                  {"EPRECON_CONV_DENSE3D": "0"}, {"EPRECON_CONV_DENSE3D": "1"},
-                                 {"EPRECON_CONV_TAIL8": "0"}, {"EPRECON_CONV_PERSIST": "1"}, {"EPRECON_CONV_BF16X3": "1"}, {"EPRECON_CONV_INTERLEAVE": "0"},
+                                 {"EPRECON_CONV_TAIL8": "0"}, {"EPRECON_CONV_PERSIST": "1"}, {"EPRECON_CONV_BF16X3": "1"}, {"EPRECON_CONV_INTERLEAVE": "0"}, {"EPRECON_CONV_SPLITK_FAST": "0"},
                                  {"EPRECON_CONV_DIRECT": "0", "EPRECON_CONV_WIDEK": "0", "EPRECON_CONV_SPLITK": "0",
                                   "EPRECON_CONV_DENSE3D": "0"}])
 def test_convolution_selection_switches(scene, default_run, env, monkeypatch):

@@ -60,6 +60,7 @@ python tools/conv_shapes_ab.py round6 2>/dev/null > $P/conv_shapes.txt
 EPRECON_CONV_TAIL8=0 EPRECON_CONV_STAGE_DEPTH=0 python tools/conv_shapes_ab.py "round6 build with the round-5 rules (padded tail, deepest stage)" 2>/dev/null > $P/conv_shapes_r05_rules.txt
 EPRECON_CONV_BF16X3=1 python tools/conv_shapes_ab.py "round6, opt-in bf16x3 operand form of the direct gather kernel" 2>/dev/null > $P/conv_shapes_bf16x3.txt
 bash tools/probes/interleave_ab.sh > $P/conv_interleave_ab.txt 2>/dev/null
+bash tools/probes/splitk_fast_ab.sh > $P/conv_splitk_flat_ab.txt 2>/dev/null
 python tools/conv_tail_ab.py --instance 2>/dev/null | grep -v calibration > $P/conv_forms_ab_final.txt
 # 5. where the HOST time of a cfg4 fragment goes; how much of a fragment's wall time the GPU is busy (+ CU-level occupancy)
 python tools/profile_cfg4_host.py 8 2>/dev/null > $P/cfg4_host_profile.txt
