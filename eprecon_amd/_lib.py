@@ -163,6 +163,7 @@ SIGNATURES = {
     "eprecon_conv_pack_weight16_async": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "eprecon_conv_pack_many_async": (_i, [_vp, _i, _vp]),
     "eprecon_nchw_to_nhwc_async": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "eprecon_views_to_rows_async": (_i, [_vp, _vp]),
 }
 
 EPRECON_OK, EPRECON_EMPTY = 0, 1
@@ -224,6 +225,12 @@ def current_stream():
     if _raw_stream is not None and _raw_device is not None:
         return _raw_stream(_raw_device()) or None
     return torch.cuda.current_stream().cuda_stream or None
+
+
+class ViewsDesc(ctypes.Structure):
+    """include/eprecon_hip.h: eprecon_views_desc"""
+    _fields_ = [("src", (ctypes.c_void_p * 16) * 3), ("dst", ctypes.c_void_p * 3), ("channels", ctypes.c_int32 * 3),
+                ("hw", ctypes.c_int32 * 3), ("levels", ctypes.c_int32), ("n_views", ctypes.c_int32)]
 
 
 class ConvDesc(ctypes.Structure):

@@ -719,6 +719,36 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restri
 }
 
 
+// the per-view maps of up to three levels in one launch (eprecon_views_to_rows_async): block -> (level, view, 64-pixel tile)
+struct ViewsParams {
+    eprecon_views_desc d;
+    int tile0[4];        // first block of level l; tile0[levels] = grid size
+    int tiles[3];        // 64-pixel tiles per map of level l
+};
+__global__ __launch_bounds__(256) void views_to_rows_kernel(ViewsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *tile = reinterpret_cast<float *>(smem);  // [C][kTrPix + 1]
+    const int b = blockIdx.x;
+    const int l = b >= p.tile0[2] ? 2 : (b >= p.tile0[1] ? 1 : 0);
+    const int r = b - p.tile0[l];
+    const int v = r / p.tiles[l], t = r - v * p.tiles[l];
+    const int C = p.d.channels[l], hw = p.d.hw[l];
+    const int p0 = t * kTrPix;
+    const int npix = min(kTrPix, hw - p0);
+    const float *src = p.d.src[l][v];
+    float *dst = p.d.dst[l] + ((size_t)v * hw + p0) * C;
+    for (int e = threadIdx.x; e < C * kTrPix; e += 256) {
+        const int c = e / kTrPix, px = e - c * kTrPix;
+        if (px < npix) tile[c * (kTrPix + 1) + px] = src[(size_t)c * hw + p0 + px];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < npix * C; e += 256) {
+        const int px = e / C, c = e - px * C;
+        dst[e] = tile[c * (kTrPix + 1) + px];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Backward of the back-projection with respect to the image features (training): the
 // transpose of the bilinear gather is a scatter of four weighted taps per (voxel, visible view, channel).
@@ -962,6 +992,31 @@ int eprecon_nchw_to_nhwc_async(const float *in, float *out, int maps, int channe
     const dim3 grid((unsigned)ep::ceil_div(hw, kTrPix), (unsigned)maps);
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), lds, (hipStream_t)stream, in, out,
                        channels, hw, channels);
+    EP_LAUNCH_CHECK();
+    return EPRECON_OK;
+}
+
+int eprecon_views_to_rows_async(const eprecon_views_desc *desc, void *stream)
+{
+    if (!desc || desc->levels < 1 || desc->levels > 3 || desc->n_views < 1 || desc->n_views > 16) return EPRECON_ERR_ARG;
+    ViewsParams p = {};
+    p.d = *desc;
+    int cmax = 0, at = 0;
+    for (int l = 0; l < 3; ++l) {
+        p.tile0[l] = at;
+        if (l >= desc->levels) { p.tiles[l] = 1; continue; }
+        if (desc->channels[l] <= 0 || desc->hw[l] <= 0 || !desc->dst[l]) return EPRECON_ERR_ARG;
+        for (int v = 0; v < desc->n_views; ++v)
+            if (!desc->src[l][v]) return EPRECON_ERR_ARG;
+        p.tiles[l] = ep::ceil_div(desc->hw[l], kTrPix);
+        at += p.tiles[l] * desc->n_views;
+        cmax = desc->channels[l] > cmax ? desc->channels[l] : cmax;
+    }
+    p.tile0[3] = at;
+    for (int l = desc->levels; l < 3; ++l) p.tile0[l] = at;      // (no block maps to an absent level)
+    const size_t lds = (size_t)cmax * (kTrPix + 1) * sizeof(float);
+    if (lds > 64 * 1024) return EPRECON_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(views_to_rows_kernel, dim3((unsigned)at), dim3(256), lds, (hipStream_t)stream, p);
     EP_LAUNCH_CHECK();
     return EPRECON_OK;
 }

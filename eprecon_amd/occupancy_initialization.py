@@ -87,12 +87,13 @@ class Occupancy_Initialization(nn.Module):
         """Inference on the GPU: the whole 2D stack on pixel-row matrices (channels-last), every
         convolution + BatchNorm on the HIP gather-GEMM path (dense2d.py); the 32-channel result is
         returned as a channels-last [V,32,H/8,W/8] view and feeds the back-projection in place."""
-        dev = feats_1x.device
-        rows, grids = [], []
-        for t in (feats_1x, feats_2x, feats_4x):
-            v, c, h, w = t.shape
-            rows.append(D2.rows_of(t.float().contiguous(memory_format=torch.channels_last)))
-            grids.append(D2.PixelGrid.get(v, h, w, dev))
+        return self._fusion_on_rows([D2.rows_of(t.float().contiguous(memory_format=torch.channels_last))
+                                     for t in (feats_1x, feats_2x, feats_4x)], [tuple(t.shape) for t in (feats_1x, feats_2x, feats_4x)])
+
+    def _fusion_on_rows(self, rows, shapes):
+        """the stack on the pixel rows [V*h*w, C] of the three levels (shapes: their [V,C,h,w])"""
+        dev = rows[0].device
+        grids = [D2.PixelGrid.get(v, h, w, dev) for v, c, h, w in shapes]
         g1, g2, g4 = grids
         c1, c2, c4 = (r.shape[1] for r in rows)
         cat = torch.empty((g2.n, c1 + c2 + c4), dtype=torch.float32, device=dev)
@@ -130,26 +131,55 @@ class Occupancy_Initialization(nn.Module):
         by the next call, the caller consumes it immediately).  `views`: three lists (1/16, 1/8, 1/4 level)
         of the per-view [C,h,w] maps; they are stacked straight into the graph's input buffers."""
         key = tuple(tuple(v[0].shape) + (len(v),) for v in views) + (views[0][0].device,)
+        # The graph's inputs are the pixel ROWS of the three levels: one launch writes them from the 27 per-view maps
+        # (eprecon_views_to_rows_async) where three torch.stack launches in front of the replay and three channels-last copies
+        # inside it used to (HIP convolution path, float32 contiguous maps, <= 16 views; otherwise stacked NCHW inputs as before).
+        direct = self.use_hip_conv and len(views[0]) <= 16 and all(
+            m.dtype == torch.float32 and m.is_contiguous() for v in views for m in v)
+        key = key + (direct,)
         entry = self._graphs.get(key)
         if entry is None:
-            static_in = [torch.stack(v) for v in views]
+            shapes = [(len(v),) + tuple(v[0].shape) for v in views]
+            if direct:
+                static_in = [torch.empty((n * h * w, c), dtype=torch.float32, device=views[0][0].device) for n, c, h, w in shapes]
+                self._views_to_rows(views, static_in)
+                run = lambda: self._fusion_on_rows(static_in, shapes)
+            else:
+                static_in = [torch.stack(v) for v in views]
+                run = lambda: self.feat_fusion_pre(*static_in)
             side = _lib.side_stream(static_in[0].device, _lib.SIDE_SETUP)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(3):  # first-use work (kernel maps, packed weights) happens outside the capture
-                    self.feat_fusion_pre(*static_in)
+                    run()
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             # thread_local: the RCCL watchdog thread of a multi-GPU run may touch the runtime during the capture
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                static_out = self.feat_fusion_pre(*static_in)
+                static_out = run()
             entry = (graph, static_in, static_out)
             self._graphs[key] = entry
         graph, static_in, static_out = entry
-        for s_, v in zip(static_in, views):
-            torch.stack(v, out=s_)
+        if direct:
+            self._views_to_rows(views, static_in)
+        else:
+            for s_, v in zip(static_in, views):
+                torch.stack(v, out=s_)
         graph.replay()
         return static_out
+
+    @staticmethod
+    def _views_to_rows(views, rows):
+        """the per-view [C,h,w] maps of the three levels -> their pixel-row buffers, one launch"""
+        import ctypes
+        d = _lib.ViewsDesc()
+        d.levels, d.n_views = len(views), len(views[0])
+        for l, (v, r) in enumerate(zip(views, rows)):
+            c, h, w = v[0].shape
+            d.channels[l], d.hw[l], d.dst[l] = c, h * w, r.data_ptr()
+            for i, m in enumerate(v):
+                d.src[l][i] = m.data_ptr()
+        _lib.check(_lib.load().eprecon_views_to_rows_async(ctypes.byref(d), _lib.current_stream()), "eprecon_views_to_rows_async")
 
     def sparse_stack(self, var, vset):
         """variance volume f32[N,32] on the voxel set -> occupancy logit f32[N,1]  (:131-174)"""

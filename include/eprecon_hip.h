@@ -134,6 +134,16 @@ int eprecon_profile_mark_async(int id, void *stream);
 /* NCHW -> NHWC re-layout of a stack of feature maps: in f32[maps, C, H*W] -> out f32[maps, H*W, C] */
 int eprecon_nchw_to_nhwc_async(const float *in, float *out, int maps, int channels, int hw,
                                void *stream);
+/* The same for the per-view maps of up to three pyramid levels in ONE launch: src[l][v] f32[C_l, hw_l] (one contiguous map per
+ * view, as models/occupancy_initialization.py:79-90 receives them: features_all[view][level][batch]) -> dst[l] f32[n_views * hw_l,
+ * C_l] (pixel rows, views stacked).  Replaces torch.stack per level + the channels-last copy in front of the 2D fusion stack. */
+typedef struct eprecon_views_desc {
+    const float *src[3][16];
+    float *dst[3];
+    int32_t channels[3]; int32_t hw[3];
+    int32_t levels; int32_t n_views;
+} eprecon_views_desc;
+int eprecon_views_to_rows_async(const eprecon_views_desc *desc, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Hash grid over voxel coordinates  (K6 / K7)

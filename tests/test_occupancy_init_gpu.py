@@ -105,3 +105,10 @@ def test_hip_dense_path_matches_pytorch_path():
         graphed2 = net._fusion_graphed(views)
     assert (got - ref).abs().max().item() < 2e-4
     assert (graphed - ref).abs().max().item() < 2e-4 and torch.equal(graphed, graphed2)
+    # round 6: the graph's inputs are the pixel rows, written from the 27 per-view maps by ONE launch (eprecon_views_to_rows_async)
+    # instead of three torch.stack launches + three channels-last copies: the same rows, the same stack -> the same bits
+    assert torch.equal(graphed, got)
+    with torch.no_grad():   # maps that are not contiguous float32 take the stacked-NCHW inputs as before
+        odd = [[m.transpose(1, 2).contiguous().transpose(1, 2) for m in v] for v in views]
+        assert not odd[0][0].is_contiguous()
+        assert torch.equal(net._fusion_graphed(odd), got)
