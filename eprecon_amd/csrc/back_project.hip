@@ -697,11 +697,15 @@ __global__ __launch_bounds__(1024) void bp_depth_norm_kernel(float *out_feats, i
 // NCHW -> NHWC through an LDS tile: reads coalesced along H*W, writes coalesced along (pixel, C)
 // ---------------------------------------------------------------------------------------------
 constexpr int kTrPix = 64;
+// zero / zero_n (optional): int32 words the first block clears on its way — the valid-voxel counters of the back-projection
+// this re-layout is the first launch of (one launch less than a memset in front of it)
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restrict__ in,
-                                                           float *__restrict__ out, int C, int hw, int Cs)
+                                                           float *__restrict__ out, int C, int hw, int Cs,
+                                                           int32_t *zero = nullptr, int zero_n = 0)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *tile = reinterpret_cast<float *>(smem);  // [C][kTrPix + 1]
+    if (blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < zero_n) zero[threadIdx.x] = 0;
     const int map = blockIdx.y;
     const int p0 = blockIdx.x * kTrPix;
     const int npix = min(kTrPix, hw - p0);
@@ -1041,7 +1045,9 @@ int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *or
         return EPRECON_ERR_WORKSPACE;
     if ((size_t)n_views * batch * channels * height * width > 0x7fffffffull) return EPRECON_ERR_UNSUPPORTED;
 
-    EP_HIP_CHECK(hipMemsetAsync(n_valid_dev, 0, sizeof(int32_t) * (size_t)(1 + batch), st));
+    // (the counters are cleared by the re-layout launch below when there is one: NCHW features, <= 255 batch elements)
+    const bool clear_in_relayout = n > 0 && feats_layout == EPRECON_LAYOUT_NCHW && batch < 256;
+    if (!clear_in_relayout) EP_HIP_CHECK(hipMemsetAsync(n_valid_dev, 0, sizeof(int32_t) * (size_t)(1 + batch), st));
     if (n == 0) return EPRECON_OK;
 
     char *ws = reinterpret_cast<char *>(workspace);
@@ -1056,7 +1062,7 @@ int eprecon_back_project_async(const int32_t *coords, int64_t n, const float *or
         const size_t lds_t = (size_t)channels * (kTrPix + 1) * sizeof(float);
         if (lds_t > 64 * 1024) return EPRECON_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)ep::ceil_div(height * width, kTrPix), (unsigned)(n_views * batch)),
-                           dim3(256), lds_t, st, feats, tmp, channels, height * width, pix_stride);
+                           dim3(256), lds_t, st, feats, tmp, channels, height * width, pix_stride, n_valid_dev, 1 + batch);
         EP_LAUNCH_CHECK();
         nhwc = tmp;
         ws += ep::align_up((size_t)n_views * batch * pix_stride * height * width * sizeof(float), 256);
