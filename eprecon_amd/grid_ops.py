@@ -16,7 +16,7 @@ def init_select(logit, coords, batch_size, dim=24, cell=4, threshold=0.3, must_b
     assert coords.dtype == torch.int32 and logit.dtype == torch.float32
     dev = coords.device
     out = torch.empty((batch_size * dim ** 3, 4), dtype=torch.int32, device=dev)
-    counts = torch.zeros(1 + batch_size, dtype=torch.int32, device=dev)
+    counts = torch.empty(1 + batch_size, dtype=torch.int32, device=dev)      # (init_select_kernel writes every word)
     ws = _lib.workspace(lib.eprecon_init_select_workspace_bytes(batch_size, dim), dev)
     _lib.check(lib.eprecon_init_select_async(_lib.ptr(logit), _lib.ptr(coords), coords.shape[0],
                                              float(threshold), batch_size, dim, cell, _lib.ptr(out),
@@ -53,7 +53,7 @@ def init_select_async(logit, coords, batch_size, dim=24, cell=4, threshold=0.3):
     assert coords.dtype == torch.int32 and logit.dtype == torch.float32
     dev = coords.device
     out = torch.empty((batch_size * dim ** 3, 4), dtype=torch.int32, device=dev)
-    counts = torch.zeros(1 + batch_size, dtype=torch.int32, device=dev)
+    counts = torch.empty(1 + batch_size, dtype=torch.int32, device=dev)      # (init_select_kernel writes every word)
     ws = _lib.workspace(lib.eprecon_init_select_workspace_bytes(batch_size, dim), dev)
     _lib.check(lib.eprecon_init_select_async(_lib.ptr(logit), _lib.ptr(coords), coords.shape[0],
                                              float(threshold), batch_size, dim, cell, _lib.ptr(out),

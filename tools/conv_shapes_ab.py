@@ -44,6 +44,15 @@ def main():
     total = 0.0
     with torch.no_grad():
         for n, ci, co, what in SHAPES:
+            # Every shape on freshly mapped device memory (EPRECON_AB_EMPTY_CACHE=0: on whatever blocks the caching allocator
+            # hands back).  On some boxes of the pool one shape — 76 -> 8 on 198,184 rows, the 24th of the list — took 1.7-2.7 ms
+            # instead of 0.16 in 8 of 12 processes when its buffers were carved out of blocks cached from earlier shapes, under
+            # every kernel selection, and in 0 of 12 with this line (profiles/r06/conv_shapes_placement.txt); other boxes never
+            # showed it.  A property of where the buffers sit, not of the launch: the list is about the launches.
+            if os.environ.get("EPRECON_AB_EMPTY_CACHE", "1") == "1":
+                x = w = out = vs = nbr = None
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
             vs = SP.VoxelSet(torch.from_numpy(coords_for(n, rng)).to(dev), 1)
             nbr = vs.kernel_map(3)
             pairs = int((nbr >= 0).sum())
