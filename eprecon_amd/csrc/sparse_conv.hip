@@ -1611,6 +1611,66 @@ __global__ __launch_bounds__(64 * NW) void spconv_splitk_kernel(ConvParams p)
         const unsigned relu_mask = p.in_relu ? 0xffffffffu : 0u;
         Stage cur, nxt;
         if (wave < nst) fetch(wave, cur);
+        if constexpr (FAST) {
+            // Branch-free form: the pending BatchNorm (AFF) and the masks are applied to a stage's gathered values ONE STAGE AHEAD —
+            // to `nxt`, behind the MFMAs of `cur` in program order, so that the vector ALU works in the shadow of the matrix pipe
+            // instead of between a stage's loads and its first MFMA.  Same values, same products, same order.
+            auto prep = [&](Stage &g) {
+                const int c0 = g.c0;
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    const int c = c0 + ch * 8 + 4 * half;
+                    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (AFF) {
+                        const int cc = min(c, cinA - 4);
+                        const float4 sc4 = *reinterpret_cast<const float4 *>(sAff + cc);
+                        const float4 sh4 = *reinterpret_cast<const float4 *>(sAff + cinA + cc);
+                        sc[0] = sc4.x; sc[1] = sc4.y; sc[2] = sc4.z; sc[3] = sc4.w;
+                        sh[0] = sh4.x; sh[1] = sh4.y; sh[2] = sh4.z; sh[3] = sh4.w;
+                    }
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) {
+                        float v[4] = {g.a[t][ch].x, g.a[t][ch].y, g.a[t][ch].z, g.a[t][ch].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if constexpr (AFF) {
+                                const float x = fmaf(v[q], sc[q], sh[q]);
+                                const unsigned r = __float_as_uint(fmaxf(x, 0.0f)), b = __float_as_uint(x);
+                                v[q] = __uint_as_float((r & relu_mask) | (b & ~relu_mask));
+                            }
+                            v[q] = (g.j[t] >= 0 && c + q < p.Cin) ? v[q] : 0.0f;
+                        }
+                        g.a[t][ch] = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+            };
+            if (wave < nst) prep(cur);
+            for (int st = wave; st < nst; st += NW) {
+                fetch(min(st + NW, nst - 1), nxt);
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    const float bw[4] = {cur.w4[ch].x, cur.w4[ch].y, cur.w4[ch].z, cur.w4[ch].w};
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) {
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[t][ch].x, bw[0], acc[t], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[t][ch].y, bw[1], acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[t][ch].z, bw[2], acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[t][ch].w, bw[3], acc[t], 0, 0, 0);
+                }
+                // (the stage fetched past the end is not consumed: with sixteen waves — a few stages each — and a BatchNorm to apply,
+                // skipping its preparation is worth the branch; everywhere else the branch costs more than the work it saves)
+                if constexpr (AFF && NW == 16) {
+                    if (st + NW < nst) prep(nxt);
+                } else {
+                    prep(nxt);
+                }
+                cur = nxt;
+            }
+        } else
         for (int st = wave; st < nst; st += NW) {
             fetch(min(st + NW, nst - 1), nxt);
             const int c0 = cur.c0;
