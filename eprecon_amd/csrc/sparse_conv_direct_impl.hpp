@@ -314,7 +314,8 @@ constexpr int stage_chunks(int kch) { return kch % 3 == 0 && EP_STAGE_CAP >= 3 ?
 // TAIL: the last column tile holds <= 8 columns and runs on the 4x4x1 MFMAs (tail_to_tile above); its B operands are the tail
 // section of the packing (pack_weights16_kernel: behind the CT tiles, 512 B per (offset, chunk)).
 // BF: the bf16x3 operand form above (opt-in; padded 16-column tiles only: a half-empty tile costs 17 cycles there).
-// MODE (the launcher's choice, launch_k): 0 any layer; 1 / 2 branch-free layers without / with a pending BatchNorm of the input
+// MODE (the launcher's choice, launch_k): 0 any layer; 1 / 2 branch-free layers without / with a pending BatchNorm of the input;
+// 3 / 4 the same for layers whose last chunk holds <= 8 channels (C_in = 8, 24, 40) when an offset is one stage
 // (see `consume` and the main loop)
 template <int CT, int KCH, bool TAIL = false, int G = stage_chunks(KCH), bool BF = false, int MODE = 0>
 __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
@@ -347,6 +348,7 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
     // (the compiler groups the 16x16x4s whatever order the source puts them in: ISA of round 6).  The channels of such a layer
     // are split over NS = 2 accumulator sets (components x, z / y, w of every gathered quad), summed once before the epilogue.
     static_assert(!(BF && TAIL), "the bf16x3 form runs on padded column tiles");
+    static_assert(MODE < 3 || (G == KCH && !BF), "modes 3 / 4: one stage per offset, exact-fp32 form");
 
     constexpr int NS = (CTM == 1 && !BF) ? 2 : 1;
     f32x4 acc[NS][RT][CTA];
@@ -442,7 +444,9 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
         BfQuad qa[BF ? G : 1][RT], qb[BF ? G : 1][CTA];                // BF: the stage's operands as bf16 (hi, lo) pairs
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            const bool t8 = MODE == 0 && tail8 && i == G - 1 && has_last;          // (uniform) .z / .w of the gathered values are not used
+            // (MODE 3 / 4: an 8-channel last chunk as a compile-time fact — the launcher takes them only when an offset is ONE stage,
+            // PARTS == 1, so that the last chunk of every stage is the layer's last)
+            const bool t8 = MODE >= 3 ? i == G - 1 : (MODE == 0 && tail8 && i == G - 1 && has_last);   // .z / .w of the gathered values are not used
             float4 av[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) av[rt] = g.a[i][rt];
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
                     if (c + 3 >= p.Cin) av[rt].w = 0.0f;
                 }
             }
-            if (MODE == 2 || (MODE == 0 && p.in_scale)) {  // (uniform) the producer's pending BatchNorm (+ ReLU) on the gathered values
+            if (MODE == 2 || MODE == 4 || (MODE == 0 && p.in_scale)) {  // (uniform) the producer's pending BatchNorm (+ ReLU) on the gathered values
                 const int kc = part * G + i;
                 const int ca = 16 * kc + (t8 ? 2 : 4) * q;
                 const float4 sc = make_float4(sAff[ca], sAff[ca + 1], sAff[ca + 2], sAff[ca + 3]);
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
                     const bool ok = myNbr[k * ROWS + 16 * rt] >= 0 && cok;
                     float4 x = av[rt];
                     x.x = fmaf(x.x, sc.x, sh.x); x.y = fmaf(x.y, sc.y, sh.y); x.z = fmaf(x.z, sc.z, sh.z); x.w = fmaf(x.w, sc.w, sh.w);
-                    if constexpr (MODE == 2) {      // (no branch: v_max + v_bfi per value; a NaN stays a NaN without the ReLU)
+                    if constexpr (MODE == 2 || MODE == 4) {      // (no branch: v_max + v_bfi per value; a NaN stays a NaN without the ReLU)
                         x.x = relu_sel(x.x, relu_mask); x.y = relu_sel(x.y, relu_mask);
                         x.z = relu_sel(x.z, relu_mask); x.w = relu_sel(x.w, relu_mask);
                     } else {
@@ -574,7 +578,7 @@ __global__ __launch_bounds__(256) void spconv_direct16_kernel(ConvParams p)
         }
     } else if (U > 0) {
         constexpr int kStageLoads = RT * G + G * CTM + (TAIL ? 2 * G : 0);
-        constexpr int kStageMfma = BF ? 3 * RT * CTM * ((G + 1) / 2) : G * 4 * (RT * CTM + (TAIL ? 2 * RT : 0));
+        constexpr int kStageMfma = BF ? 3 * RT * CTM * ((G + 1) / 2) : (G * 4 - (MODE >= 3 ? 2 : 0)) * (RT * CTM + (TAIL ? 2 * RT : 0));
         constexpr int kMixMfma = (kStageMfma + kStageLoads - 1) / kStageLoads + EP_MIX_EXTRA;
         Stage s_a, s_b;
         LiveCursor cf(live), cc(live);
@@ -1161,7 +1165,10 @@ int launch_k(const ConvParams &p_in, hipStream_t st)
     // BatchNorm of the input (profiles/r06/conv_interleave_ab.txt: -10 ... -12 % on 48 -> 24 / 80 -> 40 / 32 -> 24 / 48 -> 48 without,
     // -5 ... -18 % with; where the stage-depth rule below finds room for one more workgroup per CU, the layers WITH a pending
     // BatchNorm stay on its shallow fenced form: 48 -> 48 on 93,513 rows 132.7 against 140.0 us)
-    const int mode = (interleave_enabled() && p.Cin - 16 * (KCH - 1) > 8 && (p.Cin & 3) == 0) ? (p.in_scale ? 2 : 1) : 0;
+    int mode = (interleave_enabled() && p.Cin - 16 * (KCH - 1) > 8 && (p.Cin & 3) == 0) ? (p.in_scale ? 2 : 1) : 0;
+    if constexpr (G0 == KCH) {      // (C_in = 8, 24, 40: the 8-channel last chunk is part of every stage)
+        if (interleave_enabled() && p.Cin - 16 * (KCH - 1) <= 8 && (p.Cin & 3) == 0) mode = p.in_scale ? 4 : 3;
+    }
     // Medium lists (a few workgroups per CU): the kernel's registers allow two workgroups per CU for the wide layers (96 -> 48,
     // 48 -> 48: three chunks per stage), so 583 workgroups (74,568 rows) run as one full wave of 512 and a second one that is
     // 14 % full.  The same kernel with FEWER chunks per stage (kAltG: fewer prefetch registers, one more workgroup per CU) is
@@ -1186,9 +1193,23 @@ int launch_k(const ConvParams &p_in, hipStream_t st)
         // waves of workgroups x workgroups sharing a SIMD: what a launch costs in units of one workgroup running alone
         const double cost_p = (double)ceil_div(wgs, cus * o[0]) * o[0];
         const double cost_a = (double)ceil_div(wgs, cus * o[1]) * o[1] * 1.06;
-        if (stage_depth_enabled() && o[1] > o[0] && cost_a < 0.85 * cost_p && mode != 1) {
+        if (stage_depth_enabled() && o[1] > o[0] && cost_a < 0.85 * cost_p && mode != 1 && mode != 3) {
             if (tail) hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH, true, kAltG>), grid, dim3(256), lds, st, p);
             else hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH, false, kAltG>), grid, dim3(256), lds, st, p);
+            EP_LAUNCH_CHECK();
+            return EPRECON_OK;
+        }
+    }
+    if constexpr (G0 == KCH) {
+        if (mode == 4) {
+            if (tail) hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH, true, G0, false, 4>), grid, dim3(256), lds, st, p);
+            else hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH, false, G0, false, 4>), grid, dim3(256), lds, st, p);
+            EP_LAUNCH_CHECK();
+            return EPRECON_OK;
+        }
+        if (mode == 3) {
+            if (tail) hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH, true, G0, false, 3>), grid, dim3(256), lds, st, p);
+            else hipLaunchKernelGGL((spconv_direct16_kernel<CT, KCH, false, G0, false, 3>), grid, dim3(256), lds, st, p);
             EP_LAUNCH_CHECK();
             return EPRECON_OK;
         }

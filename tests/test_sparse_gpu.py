@@ -444,13 +444,15 @@ def test_stage_depth_rule_changes_the_schedule_not_the_bits(monkeypatch, cin, co
 
 
 @pytest.mark.parametrize("affine", [False, True])
-@pytest.mark.parametrize("cin,cout", [(48, 24), (96, 48), (80, 40), (32, 24), (48, 48), (16, 16), (64, 8), (76, 8), (24, 24)])
+@pytest.mark.parametrize("cin,cout", [(48, 24), (96, 48), (80, 40), (32, 24), (48, 48), (16, 16), (64, 8), (76, 8), (24, 24),
+                                      (40, 24), (8, 16), (56, 32)])
 def test_interleaved_schedule_changes_the_schedule_not_the_bits(monkeypatch, cin, cout, affine):
     """Round 6: layers whose consume step holds no launch-uniform branch (no 8-channel or ragged last chunk; with or without a
     pending BatchNorm + ReLU of the input) run on instantiations of the direct kernel that spread the next stage's loads among
     this stage's MFMAs instead of issuing them in a burst behind a scheduling fence.  The products enter every accumulator in the
-    same order: bit-identical to EPRECON_CONV_INTERLEAVE=0, summaries included; (76, 8) and (24, 24) are not eligible (8-channel
-    last chunk) and must not change either.  Odd and even stage counts both occur (the live-offset count of a wave varies)."""
+    same order: bit-identical to EPRECON_CONV_INTERLEAVE=0, summaries included.  (24, 24), (40, 24), (8, 16) have an 8-channel
+    last chunk and one stage per offset: their own instantiations (modes 3 / 4); (56, 32) — two stages per offset — stays on the
+    general form and must not change either.  Odd and even stage counts both occur (the live-offset count of a wave varies)."""
     from eprecon_amd import sparse as SP
     rng = np.random.default_rng(cin * 7 + cout)
     c = random_coords(rng, 41003, extent=34, batch=1)
