@@ -77,8 +77,10 @@ def packed_weight(conv):
 
 # 3x3 layers on long pixel lists through the direct gather kernel (csrc/sparse_conv_direct_impl.hpp) on the pixel map instead of the
 # image-tile kernel: rocprofv3 durations on the 9 x 120 x 160 level 24->12 36.6 -> 23.4 us, 12->12 28.6 -> 17.6, 24->24 38.2 ->
-# 36.8; on 9 x 60 x 80 it is a wash (40->40 33.7 -> 28.7, 32->32 17.5 -> 18.4), hence the row threshold.
-DIRECT_2D_MIN_ROWS = 100000
+# 36.8; on 9 x 60 x 80 it was a wash in round 4 (40->40 33.7 -> 28.7, 32->32 17.5 -> 18.4).  Round 6, with the direct kernel's loads
+# spread among its MFMAs: the 43,200-pixel level on it too takes the cfg2 step from 1.491 to 1.457 ms (tools/probes/cfg2_direct2d.py,
+# three interleaved pairs); the 10,800-pixel level stays on the split-K kernel (1.459 / 1.494 against 1.448 / 1.467: inside the noise).
+DIRECT_2D_MIN_ROWS = 40000
 
 
 # EPRECON_BN_ACC=1: the BatchNorms of the 2D fusion stack finished by their CONSUMERS from order-independent integer accumulators
