@@ -81,6 +81,7 @@ def packed_weight(conv):
 # spread among its MFMAs: the 43,200-pixel level on it too takes the cfg2 step from 1.491 to 1.457 ms (tools/probes/cfg2_direct2d.py,
 # three interleaved pairs); the 10,800-pixel level stays on the split-K kernel (1.459 / 1.494 against 1.448 / 1.467: inside the noise).
 DIRECT_2D_MIN_ROWS = 40000
+K1_DIRECT_2D_MIN_ROWS = 20000     # point-wise layers of the stack (1 x 1 convolutions): see conv_bn_launch
 
 
 # EPRECON_BN_ACC=1: the BatchNorms of the 2D fusion stack finished by their CONSUMERS from order-independent integer accumulators
@@ -229,6 +230,11 @@ def conv_bn_launch(w, bias, gamma, beta, eps, k, x, grid, out=None, aff=None, re
         if cout <= SP.DIRECT_MAX_COUT and n >= DIRECT_2D_MIN_ROWS:
             pw = SP.packed_weight16(w)               # long pixel lists: the direct gather kernel on the pixel map
             d.packed_weight16 = pw.data_ptr()
+    elif k == 1 and cout <= SP.DIRECT_MAX_COUT and n >= K1_DIRECT_2D_MIN_ROWS:
+        # point-wise layers on long pixel lists: the direct kernel as a streaming product (sparse.K1_DIRECT_MIN_ROWS' rule; the
+        # slab kernel took 144 -> 32 on 43,200 pixels in 23 us, 160 -> 40 in 34, 96 -> 24 on 172,800 in 37: 14 / 19 / 30 on this one)
+        pw = SP.packed_weight16(w)
+        d.packed_weight16 = pw.data_ptr()
     if _ARENA is not None and (aff is None or isinstance(aff, AccSlice)) and lib.eprecon_conv_desc_takes_bn_acc(ctypes.byref(d)):
         # the launch sums into an accumulator block; whoever consumes the result finishes the BatchNorm: no finalize launch
         acc = aff if aff is not None else AccSlice.new(cout)

@@ -12,6 +12,8 @@ from eprecon_amd.fragment_step import Cfg2Step  # noqa: E402
 
 if len(sys.argv) > 1:
     D2.DIRECT_2D_MIN_ROWS = int(sys.argv[1])
+if len(sys.argv) > 2:
+    D2.K1_DIRECT_2D_MIN_ROWS = int(sys.argv[2])
 step = Cfg2Step(seed=0, device=torch.device("cuda"))
 step.defer_reads = True
 for _ in range(30):
@@ -23,4 +25,4 @@ for _ in range(300):
     step.run()
 step.flush()
 torch.cuda.synchronize()
-print(f"DIRECT_2D_MIN_ROWS={D2.DIRECT_2D_MIN_ROWS}: {(time.perf_counter() - t0) / 300 * 1e3:.4f} ms per step")
+print(f"DIRECT_2D_MIN_ROWS={D2.DIRECT_2D_MIN_ROWS} K1={D2.K1_DIRECT_2D_MIN_ROWS}: {(time.perf_counter() - t0) / 300 * 1e3:.4f} ms per step")
