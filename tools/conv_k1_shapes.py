@@ -11,8 +11,10 @@ from eprecon_amd import sparse as SP  # noqa: E402
 
 SHAPES = [(74568, 96, 96), (74568, 80, 80), (93512, 48, 96), (11880, 192, 192), (11880, 192, 96), (11880, 160, 160), (11880, 160, 80),
           (172800, 96, 24), (43200, 160, 40), (43200, 144, 32), (10800, 80, 80), (11744, 128, 96), (9324, 128, 96), (7561, 80, 48),
-          (1532, 160, 96), (320868, 24, 24), (198184, 32, 24), (57444, 96, 48)]
+          (1532, 160, 96), (11880, 96, 48), (9324, 64, 32), (7561, 48, 48), (4000, 64, 64), (320868, 24, 24), (198184, 32, 24), (57444, 96, 48)]
 tag = sys.argv[1] if len(sys.argv) > 1 else "default"
+if len(sys.argv) > 2:      # rows from which point-wise layers with C_out <= 64 take the direct kernel (sparse.K1_DIRECT_MIN_ROWS)
+    SP.K1_DIRECT_MIN_ROWS = int(sys.argv[2])
 print(f"# {tag}: rows C_in -> C_out | us per launch | kernel | GB/s of (rows x (C_in + C_out) x 4 B) | TF")
 tot = 0.0
 with torch.no_grad():
